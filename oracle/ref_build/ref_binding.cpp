@@ -1,0 +1,59 @@
+// TEST INFRASTRUCTURE ONLY -- never linked into the product library.
+//
+// Registration shim for the *unmodified* reference CPU attention kernels.  The two
+// functions declared below are defined in the reference tree
+// (/root/reference/sgl-kernel/csrc/cpu/decode.cpp:1375 and extend.cpp:579); the
+// Makefile next to this file compiles those two translation units where they lie and
+// links them with this shim into oracle/_ref/libsgl_ref_cpu.so.  Nothing from the
+// reference is copied into this repository.
+//
+// The reference registers its ops through torch_extension_cpu.cpp, which drags in all
+// nineteen translation units (MoE, shm, numa ...).  We only need the attention path, so
+// we register just these two under our own namespace `sgl_ref`.
+#include <ATen/ATen.h>
+#include <torch/library.h>
+
+void decode_attention_cpu(
+    at::Tensor& query,
+    at::Tensor& k_cache,
+    at::Tensor& v_cache,
+    at::Tensor& output,
+    at::Tensor& key,
+    at::Tensor& value,
+    at::Tensor& loc,
+    at::Tensor& attn_logits,
+    at::Tensor& req_to_token,
+    at::Tensor& req_pool_indices,
+    at::Tensor& seq_lens,
+    double sm_scale,
+    double logit_cap);
+
+void extend_attention_cpu(
+    at::Tensor& q_extend,
+    at::Tensor& k_extend,
+    at::Tensor& v_extend,
+    at::Tensor& o_extend,
+    at::Tensor& k_buffer,
+    at::Tensor& v_buffer,
+    at::Tensor& req_to_token,
+    at::Tensor& req_pool_indices,
+    at::Tensor& seq_lens,
+    at::Tensor& extend_seq_lens,
+    at::Tensor& extend_start_loc,
+    int64_t max_len_extend,
+    double sm_scale,
+    double logit_cap);
+
+TORCH_LIBRARY(sgl_ref, m) {
+  m.def(
+      "decode_attention_cpu(Tensor query, Tensor k_cache, Tensor v_cache, Tensor(a!) output, Tensor key, "
+      "Tensor value, Tensor loc, Tensor(b!) attn_logits, Tensor req_to_token, Tensor req_pool_indices, "
+      "Tensor seq_lens, float sm_scale, float logit_cap) -> ()");
+  m.impl("decode_attention_cpu", c10::DispatchKey::CPU, &decode_attention_cpu);
+  m.def(
+      "extend_attention_cpu(Tensor q_extend, Tensor k_extend, Tensor v_extend, Tensor(a!) o_extend, "
+      "Tensor k_buffer, Tensor v_buffer, Tensor req_to_token, Tensor req_pool_indices, Tensor seq_lens, "
+      "Tensor extend_seq_lens, Tensor extend_start_loc, int max_len_extend, float sm_scale, "
+      "float logit_cap) -> ()");
+  m.impl("extend_attention_cpu", c10::DispatchKey::CPU, &extend_attention_cpu);
+}

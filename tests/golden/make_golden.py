@@ -1,0 +1,439 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz -- run ONLY in the build container (needs /root/reference).
+
+What it does
+------------
+* loads ``oracle/_ref/libsgl_ref_cpu.so`` (the reference's own decode.cpp/extend.cpp,
+  compiled from /root/reference by ``oracle/ref_build/Makefile``) and runs
+  ``decode_attention_cpu`` / ``extend_attention_cpu`` on seeded inputs;
+* imports the pure-torch reference helpers that live inside the reference's own tests
+  (``awq_dequantize_torch``, ``torch_scaled_mm``, ``torch_per_token_quant_fp8``) by file
+  path, with a placeholder for the un-installed ``sgl_kernel``/``sglang`` imports those
+  test files make at module import (the helpers themselves are plain torch);
+* also computes an fp32 SDPA-style ground truth with plain torch;
+* asserts that ``oracle/`` (our C restatement) agrees with all of the above, then writes
+  inputs + expected outputs as small .npz fixtures.
+
+The fixtures are data (inputs and expected outputs); no reference source text is stored.
+The GPU box never runs this script and never sees /root/reference.
+"""
+from __future__ import annotations
+
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+import oracle  # noqa: E402
+
+
+# ----------------------------------------------------------------------------- reference loaders
+def _load_ref_lib():
+    so = os.path.join(ROOT, "oracle", "_ref", "libsgl_ref_cpu.so")
+    if not os.path.exists(so):
+        raise SystemExit("build oracle/_ref first: make -C oracle/ref_build")
+    torch.ops.load_library(so)
+    return torch.ops.sgl_ref
+
+
+def _load_by_path(name, path, placeholders):
+    saved = {}
+    for modname, attrs in placeholders.items():
+        saved[modname] = sys.modules.get(modname)
+        m = types.ModuleType(modname)
+        for a in attrs:
+            setattr(m, a, lambda *args, **kw: False)
+        sys.modules[modname] = m
+    try:
+        spec = importlib.util.spec_from_file_location(name, path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        for modname, old in saved.items():
+            if old is None:
+                sys.modules.pop(modname, None)
+            else:
+                sys.modules[modname] = old
+    return mod
+
+
+def _ref_helpers():
+    t_awq = _load_by_path("ref_test_awq", f"{REF}/sgl-kernel/tests/test_awq_dequant.py",
+                          {"sgl_kernel": ["awq_dequantize"]})
+    t_mm = _load_by_path("ref_test_fp8_gemm", f"{REF}/sgl-kernel/tests/test_fp8_gemm.py",
+                         {"sgl_kernel": ["fp8_scaled_mm"]})
+    t_q = _load_by_path("ref_test_ptq", f"{REF}/sgl-kernel/tests/test_per_token_quant_fp8.py",
+                        {"sgl_kernel": ["sgl_per_token_quant_fp8"], "sglang": [], "sglang.srt": [],
+                         "sglang.srt.utils": ["is_hip"]})
+    return t_awq.awq_dequantize_torch, t_mm.torch_scaled_mm, t_q.torch_per_token_quant_fp8
+
+
+# ----------------------------------------------------------------------------- utilities
+def u16(t):
+    return t.contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+def u8(t):
+    return t.contiguous().view(torch.uint8).numpy()
+
+
+def sdpa_f32(q, k_all, v_all, scale, logit_cap=0.0, causal_offset=None):
+    """q [Lq,Hq,D], k_all [Lk,Hkv,D], v_all [Lk,Hkv,Dv] -> [Lq,Hq,Dv] fp32.
+    causal_offset: query row r may see keys [0, causal_offset + r]."""
+    Hq, Hkv = q.size(1), k_all.size(1)
+    g = Hq // Hkv
+    qf, kf, vf = q.float(), k_all.float().repeat_interleave(g, 1), v_all.float().repeat_interleave(g, 1)
+    s = torch.einsum("qhd,khd->hqk", qf, kf) * scale
+    if logit_cap > 0:
+        s = logit_cap * torch.tanh(s / logit_cap)
+    if causal_offset is not None:
+        Lq, Lk = q.size(0), k_all.size(0)
+        mask = torch.arange(Lk)[None, :] > (causal_offset + torch.arange(Lq))[:, None]
+        s = s.masked_fill(mask[None], float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    return torch.einsum("hqk,khd->qhd", p, vf)
+
+
+# ----------------------------------------------------------------------------- decode
+DECODE_CASES = [
+    # name, B, Hq, Hkv, D, Dv, S, ragged, dtype, idx, logit_cap, splits
+    # the 11 configs of test/srt/cpu/test_decode.py:146-158 at reduced S
+    ("ref00", 2, 16, 16, 64, 64, 64, False, "bf16", "i32", 0.0, 8),
+    ("ref01", 2, 16, 1, 16, 16, 64, False, "bf16", "i32", 0.0, 8),
+    ("ref02", 2, 32, 8, 33, 55, 64, False, "bf16", "i32", 0.0, 8),
+    ("ref03", 2, 16, 1, 64, 64, 64, False, "bf16", "i32", 0.0, 8),
+    ("ref04", 2, 64, 1, 13, 13, 64, False, "bf16", "i32", 0.0, 8),
+    ("ref05", 2, 128, 1, 80, 80, 64, False, "bf16", "i32", 0.0, 8),
+    ("ref06", 2, 128, 2, 512, 512, 40, False, "bf16", "i32", 0.0, 8),
+    ("ref07", 1, 16, 1, 576, 512, 64, False, "bf16", "i32", 0.0, 8),  # MLA-shaped: k/v share storage in the ref
+    ("ref08", 1, 16, 16, 576, 512, 40, False, "bf16", "i32", 0.0, 8),
+    ("ref09", 1, 22, 1, 576, 512, 64, False, "bf16", "i32", 0.0, 8),
+    ("ref10", 1, 40, 8, 128, 128, 129, False, "bf16", "i32", 0.0, 8),
+    # model geometries, ragged lengths, shuffled page table
+    ("llama8b", 2, 32, 8, 128, 128, 257, True, "bf16", "i32", 0.0, 8),
+    ("llama8b_f16", 2, 32, 8, 128, 128, 150, True, "fp16", "i64", 0.0, 4),
+    ("llama70b_tp8", 3, 8, 1, 128, 128, 257, True, "bf16", "i32", 0.0, 8),
+    ("llama2_7b", 2, 32, 32, 128, 128, 66, True, "bf16", "i32", 0.0, 2),
+    ("qwen2_05b", 3, 14, 2, 64, 64, 257, True, "bf16", "i32", 0.0, 8),
+    ("cap30", 2, 32, 8, 128, 128, 100, True, "bf16", "i32", 30.0, 3),
+    ("short", 4, 32, 8, 128, 128, 5, True, "bf16", "i32", 0.0, 8),  # seq_len < num_kv_splits
+]
+
+
+def gen_decode_inputs(B, Hq, Hkv, D, Dv, S, ragged, dtype, idx, seed):
+    g = torch.Generator().manual_seed(seed)
+    dt = torch.bfloat16 if dtype == "bf16" else torch.float16
+    n_tok = B * S + 16
+    q = torch.randn(B, Hq, D, generator=g).to(dt)
+    k_buffer = torch.randn(n_tok, Hkv, D, generator=g).to(dt)
+    v_buffer = torch.randn(n_tok, Hkv, Dv, generator=g).to(dt)
+    key = torch.randn(B, Hkv, D, generator=g).to(dt)
+    value = torch.randn(B, Hkv, Dv, generator=g).to(dt)
+    if ragged:
+        seq_lens = torch.randint(max(1, S // 2), S + 1, (B,), generator=g)
+        seq_lens[0] = S
+    else:
+        seq_lens = torch.full((B,), S)
+    perm = torch.randperm(n_tok - 1, generator=g) + 1  # slot 0 is the padding slot (memory_pool.py:223)
+    max_ctx = S + 3
+    req_to_token = torch.zeros(B + 2, max_ctx, dtype=torch.int64)
+    req_pool_indices = torch.randperm(B + 2, generator=g)[:B]
+    off = 0
+    for b in range(B):
+        L = int(seq_lens[b])
+        req_to_token[req_pool_indices[b], :L] = perm[off:off + L]
+        off += L
+    # the new token of request b lives in the last position of its sequence
+    loc = torch.stack([req_to_token[req_pool_indices[b], int(seq_lens[b]) - 1] for b in range(B)])
+    req_to_token = req_to_token.to(torch.int32 if idx == "i32" else torch.int64)
+    return dict(q=q, k_buffer=k_buffer, v_buffer=v_buffer, key=key, value=value, loc=loc,
+                req_to_token=req_to_token, req_pool_indices=req_pool_indices, seq_lens=seq_lens)
+
+
+def run_decode_case(ref, case, seed):
+    name, B, Hq, Hkv, D, Dv, S, ragged, dtype, idx, cap, splits = case
+    inp = gen_decode_inputs(B, Hq, Hkv, D, Dv, S, ragged, dtype, idx, seed)
+    sm_scale = 1.0 / D**0.5
+    dt = inp["q"].dtype
+
+    def fresh():
+        return inp["k_buffer"].clone(), inp["v_buffer"].clone()
+
+    # reference compiled kernel
+    kb, vb = fresh()
+    o_ref = torch.zeros(B, Hq, Dv, dtype=dt)
+    logits = torch.zeros(B, Hq, splits, Dv + 1)
+    ref.decode_attention_cpu(inp["q"], kb, vb, o_ref, inp["key"], inp["value"], inp["loc"], logits,
+                             inp["req_to_token"], inp["req_pool_indices"], inp["seq_lens"], sm_scale, cap)
+    # oracle
+    kb2, vb2 = fresh()
+    o_orc = torch.zeros(B, Hq, Dv, dtype=dt)
+    logits2 = torch.zeros(B, Hq, splits, Dv + 1)
+    oracle.decode_attention(inp["q"], kb2, vb2, o_orc, inp["key"], inp["value"], inp["loc"], logits2,
+                            inp["req_to_token"], inp["req_pool_indices"], inp["seq_lens"], sm_scale, cap)
+    assert torch.equal(kb.view(torch.int16), kb2.view(torch.int16)), name + ": KV write differs"
+    assert torch.equal(vb.view(torch.int16), vb2.view(torch.int16)), name + ": KV write differs"
+    # fp32 ground truth
+    o_f32 = torch.zeros(B, Hq, Dv)
+    for b in range(B):
+        L = int(inp["seq_lens"][b])
+        toks = inp["req_to_token"][inp["req_pool_indices"][b], :L].long()
+        o_f32[b] = sdpa_f32(inp["q"][b:b + 1], kb[toks], vb[toks], sm_scale, cap)[0]
+    d_ref = (o_ref.float() - o_f32).abs().max().item()
+    d_orc = (o_orc.float() - o_f32).abs().max().item()
+    d_ro = (o_ref.float() - o_orc.float()).abs().max().item()
+    ulp = 2.0 ** -8 if dtype == "bf16" else 2.0 ** -11
+    bound = 1e-3 + ulp * o_f32.abs().max().item()
+    print(f"decode {name:14s} |ref-f32|={d_ref:.2e} |orc-f32|={d_orc:.2e} |ref-orc|={d_ro:.2e} bound={bound:.2e}")
+    # The reference kernel leaves the LSE slot of EMPTY splits unwritten and then reads it in
+    # the merge (decode.cpp:832, :987-994): with seq_len < num_kv_splits its output depends on
+    # whatever attn_logits held.  Such cases are pinned by the fp32 ground truth only.
+    ref_valid = bool((inp["seq_lens"] >= splits).all())
+    assert d_orc <= bound, name
+    assert (not ref_valid) or d_ro <= 2 * bound, name
+    out = {k: (u16(v) if v.dtype in (torch.bfloat16, torch.float16) else v.numpy()) for k, v in inp.items()}
+    out.update(o_ref=u16(o_ref), o_f32=o_f32.numpy(), ref_valid=np.bool_(ref_valid),
+               meta=np.array([B, Hq, Hkv, D, Dv, S, splits], dtype=np.int64),
+               logit_cap=np.float32(cap), sm_scale=np.float32(sm_scale), dtype=np.bytes_(dtype))
+    return name, out
+
+
+# ----------------------------------------------------------------------------- extend
+EXTEND_CASES = [
+    # name, B, N_CTX, Hq, Hkv, D, Dv, dtype, zero_prefix
+    ("ref0", 1, 123, 1, 1, 128, 96, "bf16", False),   # test/srt/cpu/test_extend.py:184-186
+    ("ref1", 1, 123, 16, 1, 128, 96, "bf16", False),
+    ("ref2", 4, 160, 16, 4, 128, 96, "bf16", False),  # (4,1230,...) at reduced N_CTX
+    ("ref2_noprefix", 4, 120, 16, 4, 128, 96, "bf16", True),
+    ("llama8b", 2, 150, 32, 8, 128, 128, "bf16", False),
+    ("llama8b_f16", 2, 100, 32, 8, 128, 128, "fp16", False),
+    ("qwen2_05b", 3, 200, 14, 2, 64, 64, "bf16", False),
+    ("llama2_7b", 2, 70, 32, 32, 128, 128, "bf16", False),
+]
+
+
+def gen_extend_inputs(B, N_CTX, Hq, Hkv, D, Dv, dtype, zero_prefix, seed):
+    g = torch.Generator().manual_seed(seed)
+    dt = torch.bfloat16 if dtype == "bf16" else torch.float16
+    prefix = torch.randint(1, N_CTX // 2, (B,), generator=g)
+    if zero_prefix:
+        prefix.zero_()
+    elif B > 1:
+        prefix[B - 1] = 0  # mix: one request without cached prefix
+    ext = torch.randint(1, N_CTX // 2, (B,), generator=g)
+    seq = prefix + ext
+    total = int(seq.sum())
+    n_tok = total + 8
+    perm = torch.randperm(n_tok - 1, generator=g) + 1
+    max_ctx = int(seq.max()) + 2
+    req_pool_indices = torch.randperm(B + 1, generator=g)[:B]
+    req_to_token = torch.zeros(B + 1, max_ctx, dtype=torch.int32)
+    k_buffer = torch.randn(n_tok, Hkv, D, generator=g).to(dt)
+    v_buffer = torch.randn(n_tok, Hkv, Dv, generator=g).to(dt)
+    ext_total = int(ext.sum())
+    q_extend = torch.randn(ext_total, Hq, D, generator=g).to(dt)
+    k_extend = torch.empty(ext_total, Hkv, D, dtype=dt)
+    v_extend = torch.empty(ext_total, Hkv, Dv, dtype=dt)
+    start_loc = torch.zeros(B, dtype=torch.int64)
+    start_loc[1:] = torch.cumsum(ext[:-1], 0)
+    off = 0
+    for b in range(B):
+        L = int(seq[b])
+        toks = perm[off:off + L]
+        off += L
+        req_to_token[req_pool_indices[b], :L] = toks.to(torch.int32)
+        p, e, s0 = int(prefix[b]), int(ext[b]), int(start_loc[b])
+        k_extend[s0:s0 + e] = k_buffer[toks[p:]]
+        v_extend[s0:s0 + e] = v_buffer[toks[p:]]
+    return dict(q_extend=q_extend, k_extend=k_extend, v_extend=v_extend, k_buffer=k_buffer, v_buffer=v_buffer,
+                req_to_token=req_to_token, req_pool_indices=req_pool_indices, seq_lens=seq,
+                extend_seq_lens=ext, extend_start_loc=start_loc)
+
+
+def run_extend_case(ref, case, seed):
+    name, B, N_CTX, Hq, Hkv, D, Dv, dtype, zero_prefix = case
+    inp = gen_extend_inputs(B, N_CTX, Hq, Hkv, D, Dv, dtype, zero_prefix, seed)
+    dt = inp["q_extend"].dtype
+    sm_scale = 1.0 / D**0.5
+    max_len_extend = int(inp["extend_seq_lens"].max())
+    ext_total = inp["q_extend"].size(0)
+    o_ref = torch.zeros(ext_total, Hq, Dv, dtype=dt)
+    # the reference takes extend_seq_lens / extend_start_loc in req_to_token's index dtype
+    ref.extend_attention_cpu(inp["q_extend"], inp["k_extend"], inp["v_extend"], o_ref, inp["k_buffer"],
+                             inp["v_buffer"], inp["req_to_token"], inp["req_pool_indices"], inp["seq_lens"],
+                             inp["extend_seq_lens"].to(torch.int32), inp["extend_start_loc"].to(torch.int32),
+                             max_len_extend, sm_scale, 0.0)
+    o_orc = torch.zeros(ext_total, Hq, Dv, dtype=dt)
+    oracle.extend_attention(inp["q_extend"], inp["k_extend"], inp["v_extend"], o_orc, inp["k_buffer"],
+                            inp["v_buffer"], inp["req_to_token"], inp["req_pool_indices"], inp["seq_lens"],
+                            inp["extend_seq_lens"], inp["extend_start_loc"], max_len_extend, sm_scale, 0.0)
+    o_f32 = torch.zeros(ext_total, Hq, Dv)
+    for b in range(B):
+        L, e, s0 = int(inp["seq_lens"][b]), int(inp["extend_seq_lens"][b]), int(inp["extend_start_loc"][b])
+        toks = inp["req_to_token"][inp["req_pool_indices"][b], :L].long()
+        o_f32[s0:s0 + e] = sdpa_f32(inp["q_extend"][s0:s0 + e], inp["k_buffer"][toks], inp["v_buffer"][toks],
+                                    sm_scale, 0.0, causal_offset=L - e)
+    d_ref = (o_ref.float() - o_f32).abs().max().item()
+    d_orc = (o_orc.float() - o_f32).abs().max().item()
+    d_ro = (o_ref.float() - o_orc.float()).abs().max().item()
+    ulp = 2.0 ** -8 if dtype == "bf16" else 2.0 ** -11
+    bound = 1e-3 + ulp * o_f32.abs().max().item()
+    print(f"extend {name:14s} |ref-f32|={d_ref:.2e} |orc-f32|={d_orc:.2e} |ref-orc|={d_ro:.2e} bound={bound:.2e}")
+    # The reference's own test covers bf16 only (test/srt/cpu/test_extend.py:79).  Its fp16
+    # path goes through an fp16 brgemm (gemm.h:27-29) that returns garbage on this CPU
+    # (no AMX-FP16), so fp16 cases are pinned by the fp32 ground truth alone.
+    ref_valid = d_ref <= 4 * bound
+    assert dtype != "bf16" or ref_valid, name
+    assert d_orc <= 2 * bound, name
+    assert (not ref_valid) or d_ro <= 2 * bound, name
+    out = {k: (u16(v) if v.dtype in (torch.bfloat16, torch.float16) else v.numpy()) for k, v in inp.items()}
+    out.update(o_ref=u16(o_ref), o_f32=o_f32.numpy(), ref_valid=np.bool_(ref_valid),
+               meta=np.array([B, Hq, Hkv, D, Dv, max_len_extend], dtype=np.int64),
+               sm_scale=np.float32(sm_scale), dtype=np.bytes_(dtype))
+    return name, out
+
+
+# ----------------------------------------------------------------------------- quant / gemm / awq / kv-indices
+def run_quant_cases(torch_per_token_quant_fp8):
+    out = {}
+    for i, (T, K, dtype) in enumerate([(1, 896, "bf16"), (64, 4096, "bf16"), (128, 1368, "fp16"),
+                                       (7, 14336, "bf16"), (5, 512, "fp16")]):
+        g = torch.Generator().manual_seed(100 + i)
+        dt = torch.bfloat16 if dtype == "bf16" else torch.float16
+        x = (torch.randn(T, K, generator=g) * (0.02 if i % 2 else 3.0)).to(dt)
+        if T > 4:
+            x[3].zero_()  # an all-zero row: scale 0 -> scale_inv 0 -> q 0 (per_token_quant_fp8.cu:52-57)
+        q = torch.empty(T, K, dtype=torch.float8_e4m3fn)
+        s = torch.empty(T, dtype=torch.float32)
+        oracle.per_token_quant_fp8(x, q, s)
+        # reference formula for the scale (per_token_quant_fp8.cu:47-50) in torch
+        s_ref = x.float().abs().amax(dim=1) / 448.0
+        assert torch.equal(s, s_ref), "scale"
+        # the reference test's torch oracle (tests/test_per_token_quant_fp8.py:14-22), fed the scale
+        nz = s > 0
+        q_ref = torch_per_token_quant_fp8(x[nz], s[nz])
+        mism = (q[nz].view(torch.uint8) != q_ref.view(torch.uint8)).float().mean().item()
+        print(f"quant T={T} K={K} {dtype}: bit mismatch vs reference torch oracle = {mism:.2e}")
+        # identical formula (multiply by reciprocal, clamp, RNE cast) -> must be bit-exact
+        assert mism == 0.0
+        assert (q[~nz].view(torch.uint8) == 0).all()
+        out[f"x{i}"] = u16(x)
+        out[f"q{i}"] = u8(q)
+        out[f"s{i}"] = s.numpy()
+        out[f"dtype{i}"] = np.bytes_(dtype)
+    out["n"] = np.int64(5)
+    return out
+
+
+def run_gemm_cases(torch_scaled_mm):
+    out = {}
+    cases = [(1, 128, 512, True, "bf16"), (64, 256, 1024, False, "bf16"), (128, 16, 2048, True, "fp16"),
+             (33, 144, 512, False, "fp16"), (64, 512, 4096, True, "bf16")]
+    for i, (M, N, K, with_bias, dtype) in enumerate(cases):
+        g = torch.Generator().manual_seed(200 + i)
+        dt = torch.bfloat16 if dtype == "bf16" else torch.float16
+        # same construction as tests/test_fp8_gemm.py:17-31
+        a = ((torch.rand(M, K, generator=g) - 0.5) * 2 * 448).clamp(-448, 448).to(torch.float8_e4m3fn)
+        b = ((torch.rand(N, K, generator=g) - 0.5) * 2 * 448).clamp(-448, 448).to(torch.float8_e4m3fn)
+        sa = torch.randn(M, generator=g) * 0.001
+        sb = torch.randn(N, generator=g) * 0.001
+        bias = torch.randn(N, generator=g).to(dt) if with_bias else None
+        o_ref = torch_scaled_mm(a, b.t(), sa, sb, dt, bias)
+        o_orc = oracle.fp8_scaled_mm(a, b.t(), sa, sb, dt, bias, bias_after_round=True)
+        o_orc2 = oracle.fp8_scaled_mm(a, b.t(), sa, sb, dt, bias, bias_after_round=False)
+        d = (o_ref.float() - o_orc.float()).abs()
+        rel = (d / o_ref.float().abs().clamp_min(1e-6)).max().item()
+        print(f"fp8mm M={M} N={N} K={K} bias={with_bias} {dtype}: max|ref-orc|={d.max().item():.3e} maxrel={rel:.2e}"
+              f" epilogue-variant diff={(o_orc.float() - o_orc2.float()).abs().max().item():.3e}")
+        # reference tolerance is rtol 0.02 / atol 1 (tests/test_fp8_gemm.py:33-35); we ask for 1 ulp
+        torch.testing.assert_close(o_ref.float(), o_orc.float(), rtol=2.0 ** -7, atol=2e-2)
+        out[f"a{i}"], out[f"b{i}"] = u8(a), u8(b)
+        out[f"sa{i}"], out[f"sb{i}"] = sa.numpy(), sb.numpy()
+        if with_bias:
+            out[f"bias{i}"] = u16(bias)
+        out[f"o{i}"] = u16(o_ref)
+        out[f"dtype{i}"] = np.bytes_(dtype)
+    out["n"] = np.int64(len(cases))
+    return out
+
+
+def run_awq_cases(awq_dequantize_torch):
+    out = {}
+    cases = [(128, 16, 128, "fp16"), (256, 32, 128, "bf16"), (512, 72, 128, "fp16"), (384, 64, 384, "fp16"),
+             (1024, 48, 128, "bf16")]
+    for i, (K, Nc, G, dtype) in enumerate(cases):
+        g = torch.Generator().manual_seed(300 + i)
+        dt = torch.bfloat16 if dtype == "bf16" else torch.float16
+        # same construction as tests/test_awq_dequant.py:80-102
+        qweight = torch.randint(0, torch.iinfo(torch.int32).max, (K, Nc), dtype=torch.int32, generator=g)
+        qzeros = torch.randint(0, torch.iinfo(torch.int32).max, (K // G, Nc), dtype=torch.int32, generator=g)
+        scales = torch.rand(K // G, Nc * 8, generator=g).to(dt)
+        w_ref = awq_dequantize_torch(qweight, scales, qzeros, G)
+        w_orc = oracle.awq_dequantize(qweight, scales, qzeros)
+        assert w_ref.dtype == dt
+        assert torch.equal(w_ref.view(torch.int16), w_orc.view(torch.int16)), "awq dequant must be exact"
+        M = 8
+        x = (torch.randn(M, K, generator=g) * 0.5).to(dt)
+        y_ref = (x.float() @ w_ref.float())
+        y_orc = oracle.awq_gemm(x, qweight, scales, qzeros)
+        torch.testing.assert_close(y_ref, y_orc.float(), rtol=2.0 ** (-7 if dtype == "bf16" else -10), atol=1e-2)
+        print(f"awq K={K} N={Nc * 8} G={G} {dtype}: dequant exact; gemm max|d|="
+              f"{(y_ref - y_orc.float()).abs().max().item():.3e}")
+        out[f"qweight{i}"], out[f"qzeros{i}"] = qweight.numpy(), qzeros.numpy()
+        out[f"scales{i}"], out[f"w{i}"] = u16(scales), u16(w_ref)
+        out[f"x{i}"], out[f"y_f32_{i}"] = u16(x), y_ref.numpy()
+        out[f"dtype{i}"] = np.bytes_(dtype)
+    out["n"] = np.int64(len(cases))
+    return out
+
+
+def run_kvindices_cases():
+    out = {}
+    rng = np.random.default_rng(7)
+    cases = [(1, 64, 128), (37, 256, 300), (300, 512, 257)]
+    for i, (batch, max_batch, max_ctx) in enumerate(cases):
+        # same construction as test/srt/test_create_kvindices.py:18-49 (smaller pools)
+        req_to_token = torch.arange(max_batch * max_ctx, dtype=torch.int32).reshape(max_batch, max_ctx)
+        rpi = torch.from_numpy(rng.choice(max_batch, size=batch, replace=False)).to(torch.int32)
+        lens = torch.from_numpy(rng.choice(max_ctx, size=batch, replace=batch > max_ctx)).to(torch.int32)
+        indptr = torch.zeros(batch + 1, dtype=torch.int32)
+        indptr[1:] = torch.cumsum(lens, 0)
+        ref_out = torch.cat([req_to_token[int(rpi[j]), :int(lens[j])] for j in range(batch)]).contiguous()
+        got = torch.empty(int(indptr[-1]), dtype=torch.int32)
+        oracle.create_kv_indices(req_to_token, rpi, lens, indptr, None, got)
+        assert torch.equal(ref_out, got)
+        out[f"rpi{i}"], out[f"lens{i}"], out[f"indptr{i}"] = rpi.numpy(), lens.numpy(), indptr.numpy()
+        out[f"shape{i}"] = np.array([max_batch, max_ctx], dtype=np.int64)
+        out[f"kv_indices{i}"] = ref_out.numpy()
+    out["n"] = np.int64(len(cases))
+    print("kv_indices: exact")
+    return out
+
+
+def main():
+    torch.set_num_threads(8)
+    ref = _load_ref_lib()
+    awq_dequantize_torch, torch_scaled_mm, torch_per_token_quant_fp8 = _ref_helpers()
+    for i, case in enumerate(DECODE_CASES):
+        name, data = run_decode_case(ref, case, seed=1000 + i)
+        np.savez_compressed(os.path.join(HERE, f"decode_{name}.npz"), **data)
+    for i, case in enumerate(EXTEND_CASES):
+        name, data = run_extend_case(ref, case, seed=2000 + i)
+        np.savez_compressed(os.path.join(HERE, f"extend_{name}.npz"), **data)
+    np.savez_compressed(os.path.join(HERE, "per_token_quant_fp8.npz"), **run_quant_cases(torch_per_token_quant_fp8))
+    np.savez_compressed(os.path.join(HERE, "fp8_scaled_mm.npz"), **run_gemm_cases(torch_scaled_mm))
+    np.savez_compressed(os.path.join(HERE, "awq.npz"), **run_awq_cases(awq_dequantize_torch))
+    np.savez_compressed(os.path.join(HERE, "kv_indices.npz"), **run_kvindices_cases())
+    print("golden vectors written to", HERE)
+
+
+if __name__ == "__main__":
+    main()
