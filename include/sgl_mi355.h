@@ -1,0 +1,128 @@
+/*
+ * sgl_mi355.h -- C ABI of the MI355X (gfx950 / CDNA4) sgl-kernel backend.
+ *
+ * Every entry point replaces one operator of the reference (SGLang 0.4.10.post2 fork,
+ * paths relative to /root/reference); the reference interface it stands in for is cited
+ * next to it.  The ABI is plain C: raw DEVICE pointers, sizes and strides in ELEMENTS,
+ * a `void* stream` (hipStream_t; NULL = the null stream) and an `int` status.  No torch
+ * types.  All functions are asynchronous on `stream`, allocate nothing, never
+ * synchronise, and are safe to capture into a hipGraph.
+ *
+ * Status: 0 = ok; otherwise one of SGL_MI355_ERR_*; sgl_mi355_last_error() returns the
+ * thread-local message (the torch/ctypes shim turns it into RuntimeError/ValueError the
+ * way TORCH_CHECK does in the reference).
+ *
+ * 16-bit float tensors are passed as `const void*` with a dtype code.
+ */
+#ifndef SGL_MI355_H
+#define SGL_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGL_MI355_BF16 0
+#define SGL_MI355_FP16 1
+
+#define SGL_MI355_OK 0
+#define SGL_MI355_ERR_INVALID_ARGUMENT 1 /* TORCH_CHECK-class precondition failure   */
+#define SGL_MI355_ERR_UNSUPPORTED 2      /* TORCH_CHECK_NOT_IMPLEMENTED-class        */
+#define SGL_MI355_ERR_RUNTIME 3          /* a HIP runtime call failed                */
+
+/* ABI version of this header; bumped on any signature change. */
+#define SGL_MI355_ABI_VERSION 1
+int sgl_mi355_abi_version(void);
+
+/* Copies the calling thread's last error message (NUL-terminated) into buf. Returns its length. */
+size_t sgl_mi355_last_error(char* buf, size_t buf_size);
+
+/* Number of bytes of attention scratch this library wants for a decode call of the given
+ * shape when the caller lets it choose the split count (see sgl_mi355_decode_attention). */
+
+/* ------------------------------------------------------------------------------------------
+ * Page-table flatten.
+ * Replaces: create_flashinfer_kv_indices_triton
+ *           python/sglang/srt/layers/attention/utils.py:10-46
+ *   kv_indices[kv_indptr[r] + j] = req_to_token[req_pool_indices[r]][kv_start_idx[r] + j],
+ *   j in [0, page_kernel_lens[r]).   Integer copy: bit-exact.
+ * req_pool_indices / page_kernel_lens / kv_start_idx may be int32 or int64 (`*_is64`);
+ * kv_start_idx may be NULL. */
+int sgl_mi355_create_kv_indices(
+    const int32_t* req_to_token, int64_t req_to_token_stride,
+    const void* req_pool_indices, int req_pool_indices_is64,
+    const void* page_kernel_lens, int page_kernel_lens_is64,
+    const int32_t* kv_indptr,
+    const void* kv_start_idx, int kv_start_idx_is64,
+    int32_t* kv_indices, int64_t batch_size, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * KV pool write.
+ * Replaces: MHATokenToKVPool.set_kv_buffer, python/sglang/srt/mem_cache/memory_pool.py:369-407
+ *           (and decode_set_kv_buffer, sgl-kernel/csrc/cpu/decode.cpp:771-810)
+ *   k_buffer[loc[t]][h][:] = key[t][h][:]; v_buffer likewise.  loc is int64 [num_tokens]
+ *   (ForwardBatch.out_cache_loc) or int32.  Head rows must be 4-byte multiples. */
+int sgl_mi355_set_kv_buffer(
+    void* k_buffer, void* v_buffer, const void* key, const void* value,
+    const void* loc, int loc_is64, int64_t num_tokens, int64_t num_kv_heads,
+    int64_t head_size, int64_t head_size_v,
+    int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h,
+    int64_t key_stride_n, int64_t key_stride_h, int64_t value_stride_n, int64_t value_stride_h,
+    int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Paged decode attention, op-level form.
+ * Replaces: decode_attention_cpu(query, k_cache, v_cache, output, key, value, loc, attn_logits,
+ *             req_to_token, req_pool_indices, seq_lens, sm_scale, logit_cap)
+ *           schema sgl-kernel/csrc/cpu/torch_extension_cpu.cpp:263-267,
+ *           impl   sgl-kernel/csrc/cpu/decode.cpp:1375-1575
+ *   query [B,Hq,D]; k_cache [N,Hkv,D]; v_cache [N,Hkv,Dv]; output [B,Hq,Dv];
+ *   key [B,Hkv,D] / value [B,Hkv,Dv] = this step's K/V, written to the pool at loc[b]
+ *   BEFORE attention (decode.cpp:1468-1486; pass loc = NULL to skip);
+ *   attn_logits: fp32 scratch [B,Hq,num_kv_splits,Dv+1] owned by the caller, column Dv holds
+ *   the split's log-sum-exp (decode.cpp:989-994); req_to_token [R,max_context_len] int32 or
+ *   int64; req_pool_indices, seq_lens int64 [B].
+ *   All last dims contiguous; strides in elements. */
+int sgl_mi355_decode_attention(
+    const void* query, void* k_cache, void* v_cache, void* output,
+    const void* key, const void* value, const int64_t* loc,
+    float* attn_logits, const void* req_to_token, int req_to_token_is64,
+    const int64_t* req_pool_indices, const int64_t* seq_lens,
+    int64_t num_seqs, int64_t max_context_len, int64_t num_heads, int64_t num_kv_heads,
+    int64_t head_size, int64_t head_size_v, int64_t num_kv_splits,
+    int64_t q_stride_b, int64_t q_stride_h,
+    int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h,
+    int64_t key_stride_n, int64_t key_stride_h, int64_t value_stride_n, int64_t value_stride_h,
+    int64_t o_stride_b, int64_t o_stride_h,
+    float sm_scale, float logit_cap, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Paged decode attention, backend form (flattened page table).
+ * Replaces: decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_logits,
+ *             attn_lse, num_kv_splits, max_kv_splits, sm_scale, logit_cap)
+ *           python/sglang/srt/layers/attention/triton_ops/decode_attention.py:677-728
+ *           (kernels :240-401 stage 1, :491-548 stage 2), called from
+ *           TritonAttnBackend.forward_decode, triton_backend.py:687-732.
+ *   kv_indptr int32 [B+1]; kv_indices int32 [sum len]; attn_logits fp32
+ *   [B,Hq,max_kv_splits,Dv]; attn_lse fp32 [B,Hq,max_kv_splits]; num_kv_splits int32 [B]
+ *   (per-request split count, 1..max_kv_splits) or NULL (= every request uses
+ *   max_kv_splits).  Split length follows the reference:
+ *   ceil(ceil(len/splits)/32)*32 (decode_attention.py:303-307).
+ *   When max_kv_splits == 1 and num_kv_splits == NULL the merge pass is skipped and
+ *   attn_logits/attn_lse may be NULL. */
+int sgl_mi355_decode_attention_fwd(
+    const void* q, const void* k_buffer, const void* v_buffer, void* o,
+    const int32_t* kv_indptr, const int32_t* kv_indices,
+    float* attn_logits, float* attn_lse, const int32_t* num_kv_splits, int64_t max_kv_splits,
+    int64_t batch, int64_t num_heads, int64_t num_kv_heads, int64_t head_size, int64_t head_size_v,
+    int64_t q_stride_b, int64_t q_stride_h,
+    int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h,
+    int64_t o_stride_b, int64_t o_stride_h,
+    float sm_scale, float logit_cap, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGL_MI355_H */

@@ -1,0 +1,83 @@
+"""Build the MI355X kernel library (hipcc, gfx950 only) in-tree.
+
+    python -m sglang_npu_amd.build_ext [--force] [--jobs N]
+
+Every ``csrc/*.hip`` is compiled to an object with ``hipcc --offload-arch=gfx950`` and the
+objects are linked into ``sglang_npu_amd/lib/libsgl_mi355.so`` -- the C-ABI shared library
+declared in ``include/sgl_mi355.h``.  No GPU is needed to build (hipcc cross-compiles).
+"""
+from __future__ import annotations
+
+import argparse
+import concurrent.futures as cf
+import glob
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIB_DIR = os.path.join(PKG, "lib")
+LIB = os.path.join(LIB_DIR, "libsgl_mi355.so")
+OBJ_DIR = os.path.join(PKG, "build")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+
+CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+            "-ffp-contract=fast", "-I", os.path.join(ROOT, "include")]
+
+
+def _deps():
+    return glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
+
+
+def _stale(out, srcs):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(s) > t for s in srcs)
+
+
+def _compile(src, obj, extra):
+    cmd = [HIPCC] + CXXFLAGS + extra + ["-c", src, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    return src, r.returncode, r.stdout + r.stderr
+
+
+def build(force: bool = False, jobs: int = 4, verbose: bool = True, extra=None) -> str:
+    os.makedirs(LIB_DIR, exist_ok=True)
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    deps = _deps()
+    todo, objs = [], []
+    for s in srcs:
+        o = os.path.join(OBJ_DIR, os.path.basename(s)[:-4] + ".o")
+        objs.append(o)
+        if force or _stale(o, [s] + deps):
+            todo.append((s, o))
+    if todo:
+        with cf.ThreadPoolExecutor(max_workers=max(1, jobs)) as ex:
+            for src, rc, out in ex.map(lambda so: _compile(so[0], so[1], extra or []), todo):
+                if verbose and out.strip():
+                    print(out, file=sys.stderr)
+                if rc != 0:
+                    raise RuntimeError(f"hipcc failed on {src}:\n{out}")
+                if verbose:
+                    print(f"[build_ext] compiled {os.path.basename(src)}")
+    if force or todo or _stale(LIB, objs):
+        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
+        if verbose:
+            print(f"[build_ext] linked {LIB}")
+    return LIB
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--jobs", type=int, default=4)
+    a = ap.parse_args()
+    print(build(force=a.force, jobs=a.jobs))

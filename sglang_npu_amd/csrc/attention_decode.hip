@@ -1,0 +1,631 @@
+// Paged (token-level) decode attention for MI355X / gfx950.
+//
+// Replaces (see include/sgl_mi355.h for the full citations):
+//   * decode_attention_cpu            sgl-kernel/csrc/cpu/decode.cpp:1375-1575
+//   * decode_attention_fwd (Triton)   python/sglang/srt/layers/attention/triton_ops/decode_attention.py:677-728
+//
+// Design (MI355X-first, not a translation of either reference):
+//   * One workgroup = 4 waves per (request, kv-head [, head-block], kv-split).  The GQA group
+//     (<= 16 q heads) is the N dim of v_mfma_f32_16x16x32, so K/V are read once per group.
+//   * Every wave is an independent pipeline: it owns a private LDS ring (2 stages x
+//     {K tile, V tile} of 32 tokens) filled by LDS-DMA (global_load_lds_dwordx4, one
+//     256-B K/V row = 16 lanes x 16 B, so each wave instruction moves four whole rows
+//     of the token-level page table -- fully coalesced), waits with counted s_waitcnt
+//     vmcnt(N) and never meets a workgroup barrier inside the loop.  ~24 KB per wave /
+//     96 KB per CU stay in flight, which is what hides HBM latency.
+//   * The page-table slice of the split is staged once into LDS (int32), so the loop
+//     has no ordinary global loads (hipcc would drain the DMA queue with vmcnt(0) at
+//     each of them).
+//   * QK^T: A = K rows (tokens) read by ds_read_b128 from an XOR-swizzled image
+//     (conflict-free), B = Q^T kept in registers.  S^T lands with the head on the lane
+//     (col = lane&15), so the softmax max needs two wave shuffles and everything else
+//     is lane-local.
+//   * PV: O^T = V^T P^T.  V^T fragments come from ds_read_b64_tr_b16 (hardware
+//     transpose) on the same swizzled image; P^T is the S^T accumulator packed to
+//     16-bit (k-slot order permuted identically on both operands).  The head is again
+//     on the lane, so the online-softmax rescale is lane-local.
+//   * fp32 accumulate; p rounded to the KV dtype before PV (as decode_attention.py:373).
+//   * 4 waves are merged through LDS; with one split the result is written directly,
+//     otherwise fp32 partials + LSE go to the caller's scratch and a small merge
+//     kernel finishes (same math as _fwd_kernel_stage2 / decode_accumulate_kv_splits).
+//   * Head sizes other than 64/128 (or Dv != D) take a generic wave-per-head kernel.
+#include <math.h>
+
+#include "common.h"
+
+namespace sglm {
+namespace {
+
+constexpr int kWaves = 4;
+constexpr int kTile = 32;        // tokens per pipeline stage
+constexpr int kStages = 2;
+constexpr int kMaxIdx = 4096;    // page-table entries staged in LDS per pass
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+struct DecodeArgs {
+  const void* q;
+  int64_t q_sb, q_sh;
+  const void* k;
+  int64_t k_sn, k_sh;
+  const void* v;
+  int64_t v_sn, v_sh;
+  void* out;
+  int64_t o_sb, o_sh;
+  float* mid_o;  // fp32 partials [b][h][split][dv]
+  int64_t mo_sb, mo_sh, mo_ss;
+  float* mid_lse;  // natural-log LSE per (b,h,split)
+  int64_t ml_sb, ml_sh, ml_ss;
+  const void* indices;            // page table (int32 or int64)
+  const int32_t* kv_indptr;       // mode 0: slice = indices[kv_indptr[b] : kv_indptr[b+1]]
+  const int64_t* req_pool_indices;  // mode 1: slice = indices[req_pool_indices[b]*r2t_stride : +seq_lens[b]]
+  const int64_t* seq_lens;
+  int64_t r2t_stride;
+  const int32_t* num_kv_splits;  // optional per-request split count
+  int num_splits;                // grid extent along splits
+  int split_align;               // split length is rounded up to this many tokens
+  int num_heads, num_kv_heads, group;
+  float sm_scale, logit_cap;
+  int mode;
+};
+
+__device__ __forceinline__ void split_range(const DecodeArgs& a, int b, int split, int64_t& base, int& s0, int& s1) {
+  int len;
+  if (a.mode == 0) {
+    base = a.kv_indptr[b];
+    len = a.kv_indptr[b + 1] - (int)base;
+  } else {
+    base = a.req_pool_indices[b] * a.r2t_stride;
+    len = (int)a.seq_lens[b];
+  }
+  int splits = a.num_kv_splits ? a.num_kv_splits[b] : a.num_splits;
+  splits = splits < 1 ? 1 : splits;
+  int per = ceil_div(ceil_div(len, splits), a.split_align) * a.split_align;
+  s0 = per * split;
+  s1 = s0 + per < len ? s0 + per : len;
+  if (split >= splits) s1 = s0;  // no work
+}
+
+// 16-B chunk swizzle of a [token][D] 16-bit tile (see DESIGN.md "LDS image"):
+// XOR the 32-B unit index with a per-row value so that both the ds_read_b128 row reads of the
+// QK^T operand and the ds_read_b64_tr_b16 transposed reads of the PV operand are conflict-free.
+template <int D>
+__device__ __forceinline__ int swz_chunk(int c, int row) {
+  const int f = (D == 128) ? (row & 7) : ((row >> 1) & 3);
+  return (((c >> 1) ^ f) << 1) | (c & 1);
+}
+
+template <int DTYPE, int D, typename IdxT, bool DIRECT_OUT>
+__global__ __launch_bounds__(kWaves * 64) void decode_mfma_kernel(DecodeArgs a) {
+  using H = Half16<DTYPE>;
+  using T = typename H::T;
+  using x8 = typename H::x8;
+  using x4 = typename H::x4;
+  constexpr int ROWB = D * 2;               // bytes per K/V row
+  constexpr int CH = ROWB / 16;             // 16-B chunks per row
+  constexpr int ROWS_PER_DMA = 1024 / ROWB; // rows moved by one wave-instruction
+  constexpr int NI = kTile / ROWS_PER_DMA;  // DMA instructions per K (or V) tile
+  constexpr int TILE_BYTES = kTile * ROWB;
+  constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+  constexpr int WAVE_BYTES = kStages * STAGE_BYTES;
+  constexpr int KS = D / 32;                // MFMA k-steps for QK^T
+  constexpr int NDV = D / 16;               // 16-wide output column blocks
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int32_t* idx_lds = reinterpret_cast<int32_t*>(smem + kWaves * WAVE_BYTES);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hl = lane & 15;  // head within block (S^T / O^T column)
+  const int g = lane >> 4;   // lane group
+
+  // blockIdx.x = ((b * (Hkv*nhb) + hblk) * num_splits + split)
+  const int nhb = (a.group + 15) >> 4;
+  int bid = blockIdx.x;
+  const int split = bid % a.num_splits;
+  bid /= a.num_splits;
+  const int hblk = bid % (a.num_kv_heads * nhb);
+  const int b = bid / (a.num_kv_heads * nhb);
+  const int kvh = hblk / nhb;
+  const int hb = hblk - kvh * nhb;
+  const int h0 = kvh * a.group + hb * 16;
+  const int nh = (a.group - hb * 16) < 16 ? (a.group - hb * 16) : 16;
+
+  int64_t base;
+  int s0, s1;
+  split_range(a, b, split, base, s0, s1);
+
+  if (s0 >= s1) {
+    // Empty split: tell the merge pass to ignore it.  (With DIRECT_OUT an empty range
+    // means an empty sequence: the output row is zero.)
+    if (tid < nh) {
+      if (DIRECT_OUT) {
+        T* o = reinterpret_cast<T*>(a.out) + (int64_t)b * a.o_sb + (int64_t)(h0 + tid) * a.o_sh;
+        for (int d = 0; d < D; ++d) o[d] = H::from_f32(0.f);
+      } else {
+        a.mid_lse[(int64_t)b * a.ml_sb + (int64_t)(h0 + tid) * a.ml_sh + (int64_t)split * a.ml_ss] = -INFINITY;
+      }
+    }
+    return;
+  }
+
+  // ---- Q^T fragments (B operand): lane (hl, g) holds Q[h0+hl][32*ks + 8*g .. +8]
+  x8 qf[KS];
+  {
+    const T* qp = reinterpret_cast<const T*>(a.q) + (int64_t)b * a.q_sb + (int64_t)(h0 + hl) * a.q_sh;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (hl < nh) {
+        qf[ks] = *reinterpret_cast<const x8*>(qp + 32 * ks + 8 * g);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[ks][j] = (T)0.f;
+      }
+    }
+    // Consume the fragments here so that hipcc's wait for these (ordinary) loads lands before
+    // the loop; left to itself it puts `s_waitcnt vmcnt(0)` at their first use INSIDE the
+    // loop, which would drain the DMA queue every iteration.
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
+  }
+
+  const char* kbase = reinterpret_cast<const char*>(a.k) + (int64_t)kvh * a.k_sh * 2;
+  const char* vbase = reinterpret_cast<const char*>(a.v) + (int64_t)kvh * a.v_sh * 2;
+  const int64_t k_row_bytes = a.k_sn * 2;
+  const int64_t v_row_bytes = a.v_sn * 2;
+  char* wave_lds = smem + wave * WAVE_BYTES;
+
+  // DMA source mapping of this lane: row within a piece and the (unswizzled) chunk it fetches
+  const int dma_row = lane / CH;
+  const int dma_pos = lane % CH;
+
+  // online-softmax state (log2 domain), one head per lane column
+  float m_run = -INFINITY;
+  float l_run = 0.f;  // partial over this lane's token slots
+  f32x4 o_acc[NDV];
+#pragma unroll
+  for (int i = 0; i < NDV; ++i) o_acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const float scale_log2 = a.sm_scale * kLog2e;
+  const bool has_cap = a.logit_cap > 0.f;
+
+  for (int p0 = s0; p0 < s1; p0 += kMaxIdx) {
+    const int n_pass = (s1 - p0) < kMaxIdx ? (s1 - p0) : kMaxIdx;
+    __syncthreads();  // previous pass finished with idx_lds
+    {
+      const IdxT* src = reinterpret_cast<const IdxT*>(a.indices) + base + p0;
+      for (int i = tid; i < n_pass; i += kWaves * 64) idx_lds[i] = (int32_t)src[i];
+    }
+    __syncthreads();
+
+    const int ntiles = ceil_div(n_pass, kTile);
+    const int nt = (ntiles - wave + kWaves - 1) / kWaves;  // tiles wave, wave+4, ... of this pass
+
+    auto issue = [&](int jt, int stage, bool is_v) {
+      const int tok0 = (wave + kWaves * jt) * kTile;
+      const uint32_t dst = __builtin_amdgcn_readfirstlane(
+          lds_addr_of(wave_lds + stage * STAGE_BYTES + (is_v ? TILE_BYTES : 0)));
+      const char* gb = is_v ? vbase : kbase;
+      const int64_t rb = is_v ? v_row_bytes : k_row_bytes;
+      int32_t tok[NI];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        int tp = tok0 + i * ROWS_PER_DMA + dma_row;
+        tp = tp < n_pass ? tp : n_pass - 1;  // tail rows re-read a valid token; masked below
+        tok[i] = idx_lds[tp];
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int c = swz_chunk<D>(dma_pos, i * ROWS_PER_DMA + dma_row);
+        lds_dma16(gb + (int64_t)tok[i] * rb + c * 16, dst + i * 1024);
+      }
+    };
+
+    if (nt > 0) {
+      issue(0, 0, false);
+      issue(0, 0, true);
+    }
+    if (nt > 1) {
+      issue(1, 1, false);
+      issue(1, 1, true);
+    }
+
+    for (int jt = 0; jt < nt; ++jt) {
+      const int st = jt & 1;
+      const char* kst = wave_lds + st * STAGE_BYTES;
+      const char* vst = kst + TILE_BYTES;
+      const int tok0 = (wave + kWaves * jt) * kTile;
+      const bool more1 = jt + 1 < nt;
+      const bool more2 = jt + 2 < nt;
+
+      // ---- wait for K(jt): younger ops allowed in flight = V(jt) [+ K,V(jt+1)]
+      if (more1) wait_vmcnt<3 * NI>(); else wait_vmcnt<NI>();
+
+      // ---- S^T = K Q^T  (rows = tokens, cols = heads)
+      f32x4 s_acc[2];
+#pragma unroll
+      for (int th = 0; th < 2; ++th) {
+        s_acc[th] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int row = 16 * th + hl;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const int c = swz_chunk<D>(4 * ks + g, row);
+          const x8 kf = *reinterpret_cast<const x8*>(kst + row * ROWB + c * 16);
+          s_acc[th] = H::mfma16(kf, qf[ks], s_acc[th]);
+        }
+      }
+      wait_lgkmcnt0();  // K fragments are in registers: the K buffer may be refilled
+      if (more2) issue(jt + 2, st, false);
+
+      // ---- online softmax (log2 domain); token of (th, r) = tok0 + 16*th + 4*g + r
+      float sv[8];
+      float m_tile = -INFINITY;
+#pragma unroll
+      for (int th = 0; th < 2; ++th) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float s = s_acc[th][r];
+          if (has_cap) {
+            s = s * a.sm_scale;
+            s = a.logit_cap * tanhf(s / a.logit_cap) * kLog2e;
+          } else {
+            s = s * scale_log2;
+          }
+          const bool valid = (tok0 + 16 * th + 4 * g + r) < n_pass;
+          s = valid ? s : -INFINITY;
+          sv[th * 4 + r] = s;
+          m_tile = fmaxf(m_tile, s);
+        }
+      }
+      m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 16));
+      m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32));
+      const float m_new = fmaxf(m_run, m_tile);  // finite: every tile holds >= 1 valid token
+      const float alpha = exp2f(m_run - m_new);
+      float psum = 0.f;
+      x8 pf;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float p = exp2f(sv[i] - m_new);
+        psum += p;
+        pf[i] = H::from_f32(p);
+      }
+      l_run = l_run * alpha + psum;
+      m_run = m_new;
+#pragma unroll
+      for (int i = 0; i < NDV; ++i) o_acc[i] *= alpha;
+
+      // ---- wait for V(jt): younger ops allowed = [K,V(jt+1)] [+ K(jt+2)]
+      if (more2) wait_vmcnt<3 * NI>(); else if (more1) wait_vmcnt<2 * NI>(); else wait_vmcnt<0>();
+
+      // ---- O^T += V^T P^T ; k-slot (g, j): j<4 -> token 4g+j, j>=4 -> token 16+4g+(j-4)
+      {
+        const int q4 = (lane >> 2) & 3;  // row within the 4-row transposed block
+        const int p4 = lane & 3;         // 8-B piece within the 32-B column block
+        const int row_lo = 4 * g + q4;
+#pragma unroll
+        for (int dvb = 0; dvb < NDV; ++dvb) {
+          const int c = 2 * dvb + (p4 >> 1);
+          const int off = swz_chunk<D>(c, row_lo) * 16 + 8 * (p4 & 1);  // same for row_lo + 16
+          const x4 v_lo = H::ds_read_tr(vst + row_lo * ROWB + off);
+          const x4 v_hi = H::ds_read_tr(vst + (row_lo + 16) * ROWB + off);
+          x8 vf;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            vf[j] = v_lo[j];
+            vf[4 + j] = v_hi[j];
+          }
+          o_acc[dvb] = H::mfma16(vf, pf, o_acc[dvb]);
+        }
+      }
+      wait_lgkmcnt0();  // V fragments are in registers: the V buffer may be refilled
+      if (more2) issue(jt + 2, st, true);
+    }
+  }
+
+  // ---- reduce l over the 4 lane groups, then merge the 4 waves through LDS
+  l_run += __shfl_xor(l_run, 16);
+  l_run += __shfl_xor(l_run, 32);
+
+  __syncthreads();  // every wave is done with its ring (all DMA waited, all reads retired)
+  float* mrg_o = reinterpret_cast<float*>(smem);               // [wave][16][D]
+  float* mrg_m = mrg_o + kWaves * 16 * D;                      // [wave][16]
+  float* mrg_l = mrg_m + kWaves * 16;                          // [wave][16]
+  if (hl < nh) {
+    float* dst = mrg_o + (wave * 16 + hl) * D;
+#pragma unroll
+    for (int dvb = 0; dvb < NDV; ++dvb) *reinterpret_cast<f32x4*>(dst + dvb * 16 + 4 * g) = o_acc[dvb];
+    if (g == 0) {
+      mrg_m[wave * 16 + hl] = m_run;
+      mrg_l[wave * 16 + hl] = l_run;
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < nh * D; e += kWaves * 64) {
+    const int h = e / D;
+    const int dv = e - h * D;
+    float M = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) M = fmaxf(M, mrg_m[w * 16 + h]);
+    float L = 0.f, val = 0.f;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) {
+      const float f = exp2f(mrg_m[w * 16 + h] - M);  // a wave without tiles has m = -inf -> 0
+      L += mrg_l[w * 16 + h] * f;
+      val += mrg_o[(w * 16 + h) * D + dv] * f;
+    }
+    const float r = val / L;
+    if (DIRECT_OUT) {
+      reinterpret_cast<T*>(a.out)[(int64_t)b * a.o_sb + (int64_t)(h0 + h) * a.o_sh + dv] = H::from_f32(r);
+    } else {
+      a.mid_o[(int64_t)b * a.mo_sb + (int64_t)(h0 + h) * a.mo_sh + (int64_t)split * a.mo_ss + dv] = r;
+      if (dv == 0)
+        a.mid_lse[(int64_t)b * a.ml_sb + (int64_t)(h0 + h) * a.ml_sh + (int64_t)split * a.ml_ss] =
+            (M + log2f(L)) * kLn2;
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------
+// Generic fallback: one wave per (request, head, split); any head sizes up to 1024.
+// Lane l owns elements l, l+64, ...  Correctness path for the odd shapes the reference
+// tests (D = 13, 33/55, 80, 512, 576/512 ...), not a performance path.
+template <int DTYPE, typename IdxT, bool DIRECT_OUT>
+__global__ __launch_bounds__(64) void decode_generic_kernel(DecodeArgs a, int D, int Dv) {
+  using H = Half16<DTYPE>;
+  using T = typename H::T;
+  constexpr int MAXE = 16;
+  const int lane = threadIdx.x;
+  int bid = blockIdx.x;
+  const int split = bid % a.num_splits;
+  bid /= a.num_splits;
+  const int h = bid % a.num_heads;
+  const int b = bid / a.num_heads;
+  const int kvh = h / a.group;
+
+  int64_t base;
+  int s0, s1;
+  split_range(a, b, split, base, s0, s1);
+  if (s0 >= s1) {
+    if (DIRECT_OUT) {
+      T* o = reinterpret_cast<T*>(a.out) + (int64_t)b * a.o_sb + (int64_t)h * a.o_sh;
+      for (int d = lane; d < Dv; d += 64) o[d] = H::from_f32(0.f);
+    } else if (lane == 0) {
+      a.mid_lse[(int64_t)b * a.ml_sb + (int64_t)h * a.ml_sh + (int64_t)split * a.ml_ss] = -INFINITY;
+    }
+    return;
+  }
+  float qv[MAXE], acc[MAXE];
+  const T* qp = reinterpret_cast<const T*>(a.q) + (int64_t)b * a.q_sb + (int64_t)h * a.q_sh;
+#pragma unroll
+  for (int i = 0; i < MAXE; ++i) {
+    const int d = lane + 64 * i;
+    qv[i] = d < D ? H::to_f32(qp[d]) : 0.f;
+    acc[i] = 0.f;
+  }
+  float m_run = -INFINITY, l_run = 0.f;
+  const IdxT* idx = reinterpret_cast<const IdxT*>(a.indices) + base;
+  const T* kb = reinterpret_cast<const T*>(a.k) + (int64_t)kvh * a.k_sh;
+  const T* vb = reinterpret_cast<const T*>(a.v) + (int64_t)kvh * a.v_sh;
+  for (int n = s0; n < s1; ++n) {
+    const int64_t tok = (int64_t)idx[n];
+    const T* kp = kb + tok * a.k_sn;
+    const T* vp = vb + tok * a.v_sn;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXE; ++i) {
+      const int d = lane + 64 * i;
+      if (d < D) s += qv[i] * H::to_f32(kp[d]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    s *= a.sm_scale;
+    if (a.logit_cap > 0.f) s = a.logit_cap * tanhf(s / a.logit_cap);
+    const float m_new = fmaxf(m_run, s);
+    const float alpha = expf(m_run - m_new);
+    const float p = expf(s - m_new);
+    const float pr = H::to_f32(H::from_f32(p));
+    l_run = l_run * alpha + p;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < MAXE; ++i) {
+      const int d = lane + 64 * i;
+      if (d < Dv) acc[i] = acc[i] * alpha + pr * H::to_f32(vp[d]);
+    }
+  }
+  const float inv = 1.f / l_run;
+#pragma unroll
+  for (int i = 0; i < MAXE; ++i) {
+    const int d = lane + 64 * i;
+    if (d < Dv) {
+      if (DIRECT_OUT)
+        reinterpret_cast<T*>(a.out)[(int64_t)b * a.o_sb + (int64_t)h * a.o_sh + d] = H::from_f32(acc[i] * inv);
+      else
+        a.mid_o[(int64_t)b * a.mo_sb + (int64_t)h * a.mo_sh + (int64_t)split * a.mo_ss + d] = acc[i] * inv;
+    }
+  }
+  if (!DIRECT_OUT && lane == 0)
+    a.mid_lse[(int64_t)b * a.ml_sb + (int64_t)h * a.ml_sh + (int64_t)split * a.ml_ss] = m_run + logf(l_run);
+}
+
+// --------------------------------------------------------------------------------------
+// Merge of the kv-splits: out = sum_s exp(lse_s - M) o_s / sum_s exp(lse_s - M)
+// (decode_accumulate_kv_splits, decode.cpp:812-860; _fwd_kernel_stage2, decode_attention.py:491-548)
+template <int DTYPE>
+__global__ __launch_bounds__(64) void decode_merge_kernel(DecodeArgs a, int Dv) {
+  using H = Half16<DTYPE>;
+  using T = typename H::T;
+  const int lane = threadIdx.x;
+  const int h = blockIdx.x % a.num_heads;
+  const int b = blockIdx.x / a.num_heads;
+  const float* lse = a.mid_lse + (int64_t)b * a.ml_sb + (int64_t)h * a.ml_sh;
+  const float* mo = a.mid_o + (int64_t)b * a.mo_sb + (int64_t)h * a.mo_sh;
+  float M = -INFINITY;
+  for (int s = 0; s < a.num_splits; ++s) M = fmaxf(M, lse[(int64_t)s * a.ml_ss]);
+  T* o = reinterpret_cast<T*>(a.out) + (int64_t)b * a.o_sb + (int64_t)h * a.o_sh;
+  if (M == -INFINITY) {  // empty sequence
+    for (int d = lane; d < Dv; d += 64) o[d] = H::from_f32(0.f);
+    return;
+  }
+  float L = 0.f;
+  for (int s = 0; s < a.num_splits; ++s) L += expf(lse[(int64_t)s * a.ml_ss] - M);
+  const float inv = 1.f / L;
+  for (int d = lane; d < Dv; d += 64) {
+    float acc = 0.f;
+    for (int s = 0; s < a.num_splits; ++s) {
+      const float l = lse[(int64_t)s * a.ml_ss];
+      if (l != -INFINITY) acc += expf(l - M) * mo[(int64_t)s * a.mo_ss + d];
+    }
+    o[d] = H::from_f32(acc * inv);
+  }
+}
+
+template <int D>
+constexpr int mfma_lds_bytes() {
+  return kWaves * kStages * 2 * kTile * D * 2 + kMaxIdx * 4;
+}
+
+template <typename K>
+int set_max_lds(K kernel, int bytes) {
+  return check_hip(
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes),
+      "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+}
+
+template <int DTYPE, int D, typename IdxT, bool DIRECT>
+int launch_mfma(const DecodeArgs& a, int64_t batch, hipStream_t stream) {
+  auto kern = decode_mfma_kernel<DTYPE, D, IdxT, DIRECT>;
+  constexpr int lds = mfma_lds_bytes<D>();
+  static int attr_rc = set_max_lds(kern, lds);
+  if (attr_rc != 0) return attr_rc;
+  const int nhb = (a.group + 15) / 16;
+  const int64_t grid = batch * a.num_kv_heads * nhb * a.num_splits;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kWaves * 64), lds, stream, a);
+  return check_hip(hipGetLastError(), "decode_mfma_kernel launch");
+}
+
+template <int DTYPE, typename IdxT, bool DIRECT>
+int launch_generic(const DecodeArgs& a, int64_t batch, int D, int Dv, hipStream_t stream) {
+  const int64_t grid = batch * a.num_heads * a.num_splits;
+  hipLaunchKernelGGL((decode_generic_kernel<DTYPE, IdxT, DIRECT>), dim3((unsigned)grid), dim3(64), 0, stream, a, D, Dv);
+  return check_hip(hipGetLastError(), "decode_generic_kernel launch");
+}
+
+template <int DTYPE, typename IdxT>
+int dispatch_stage1(const DecodeArgs& a, int64_t batch, int D, int Dv, bool direct, hipStream_t stream) {
+  const bool aligned = (a.q_sb % 8 == 0) && (a.q_sh % 8 == 0) && (a.k_sn % 8 == 0) && (a.k_sh % 8 == 0) &&
+                       (a.v_sn % 8 == 0) && (a.v_sh % 8 == 0) &&
+                       (reinterpret_cast<uintptr_t>(a.q) % 16 == 0) && (reinterpret_cast<uintptr_t>(a.k) % 16 == 0) &&
+                       (reinterpret_cast<uintptr_t>(a.v) % 16 == 0);
+  if (D == Dv && aligned && (D == 128 || D == 64)) {
+    if (D == 128)
+      return direct ? launch_mfma<DTYPE, 128, IdxT, true>(a, batch, stream)
+                    : launch_mfma<DTYPE, 128, IdxT, false>(a, batch, stream);
+    return direct ? launch_mfma<DTYPE, 64, IdxT, true>(a, batch, stream)
+                  : launch_mfma<DTYPE, 64, IdxT, false>(a, batch, stream);
+  }
+  return direct ? launch_generic<DTYPE, IdxT, true>(a, batch, D, Dv, stream)
+                : launch_generic<DTYPE, IdxT, false>(a, batch, D, Dv, stream);
+}
+
+template <int DTYPE>
+int run_decode(DecodeArgs a, int64_t batch, int D, int Dv, bool idx64, hipStream_t stream) {
+  const bool direct = (a.num_splits == 1 && a.num_kv_splits == nullptr);
+  int rc = idx64 ? dispatch_stage1<DTYPE, int64_t>(a, batch, D, Dv, direct, stream)
+                 : dispatch_stage1<DTYPE, int32_t>(a, batch, D, Dv, direct, stream);
+  if (rc != 0 || direct) return rc;
+  hipLaunchKernelGGL((decode_merge_kernel<DTYPE>), dim3((unsigned)(batch * a.num_heads)), dim3(64), 0, stream, a, Dv);
+  return check_hip(hipGetLastError(), "decode_merge_kernel launch");
+}
+
+int check_common(
+    int64_t batch, int64_t num_heads, int64_t num_kv_heads, int64_t D, int64_t Dv, int64_t splits, int dtype) {
+  SGLM_CHECK_ARG(dtype == SGL_MI355_BF16 || dtype == SGL_MI355_FP16, "decode: dtype must be bf16 (0) or fp16 (1), got %d", dtype);
+  SGLM_CHECK_ARG(batch >= 0 && num_heads > 0 && num_kv_heads > 0, "decode: bad sizes batch=%ld heads=%ld kv_heads=%ld",
+                 (long)batch, (long)num_heads, (long)num_kv_heads);
+  SGLM_CHECK_ARG(num_heads % num_kv_heads == 0, "decode: num_heads (%ld) must be a multiple of num_kv_heads (%ld)",
+                 (long)num_heads, (long)num_kv_heads);
+  SGLM_CHECK_ARG(D > 0 && Dv > 0 && D <= 1024 && Dv <= 1024, "decode: head sizes must be in [1,1024], got %ld/%ld",
+                 (long)D, (long)Dv);
+  SGLM_CHECK_ARG(splits >= 1 && splits <= 65535, "decode: num_kv_splits must be in [1,65535], got %ld", (long)splits);
+  SGLM_CHECK_ARG(batch * num_heads * splits < (1ll << 31), "decode: grid too large");
+  return 0;
+}
+
+}  // namespace
+}  // namespace sglm
+
+using namespace sglm;
+
+extern "C" int sgl_mi355_decode_attention(
+    const void* query, void* k_cache, void* v_cache, void* output, const void* key, const void* value,
+    const int64_t* loc, float* attn_logits, const void* req_to_token, int req_to_token_is64,
+    const int64_t* req_pool_indices, const int64_t* seq_lens, int64_t num_seqs, int64_t max_context_len,
+    int64_t num_heads, int64_t num_kv_heads, int64_t head_size, int64_t head_size_v, int64_t num_kv_splits,
+    int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n,
+    int64_t v_stride_h, int64_t key_stride_n, int64_t key_stride_h, int64_t value_stride_n, int64_t value_stride_h,
+    int64_t o_stride_b, int64_t o_stride_h, float sm_scale, float logit_cap, int dtype, void* stream) {
+  int rc = check_common(num_seqs, num_heads, num_kv_heads, head_size, head_size_v, num_kv_splits, dtype);
+  if (rc) return rc;
+  SGLM_CHECK_ARG(query && k_cache && v_cache && output && req_to_token && req_pool_indices && seq_lens,
+                 "decode_attention: null tensor pointer");
+  SGLM_CHECK_ARG(attn_logits != nullptr || num_kv_splits == 1, "decode_attention: attn_logits is required when num_kv_splits > 1");
+  if (num_seqs == 0) return 0;
+  if (loc != nullptr) {
+    SGLM_CHECK_ARG(key && value, "decode_attention: key/value are required when loc is given");
+    rc = sgl_mi355_set_kv_buffer(k_cache, v_cache, key, value, loc, 1, num_seqs, num_kv_heads, head_size, head_size_v,
+                                 k_stride_n, k_stride_h, v_stride_n, v_stride_h, key_stride_n, key_stride_h,
+                                 value_stride_n, value_stride_h, dtype, stream);
+    if (rc) return rc;
+  }
+  DecodeArgs a{};
+  a.q = query; a.q_sb = q_stride_b; a.q_sh = q_stride_h;
+  a.k = k_cache; a.k_sn = k_stride_n; a.k_sh = k_stride_h;
+  a.v = v_cache; a.v_sn = v_stride_n; a.v_sh = v_stride_h;
+  a.out = output; a.o_sb = o_stride_b; a.o_sh = o_stride_h;
+  // attn_logits [B][Hq][splits][Dv+1], LSE in column Dv (decode.cpp:989-994)
+  const int64_t l2 = head_size_v + 1, l1 = num_kv_splits * l2, l0 = num_heads * l1;
+  a.mid_o = attn_logits; a.mo_sb = l0; a.mo_sh = l1; a.mo_ss = l2;
+  a.mid_lse = attn_logits ? attn_logits + head_size_v : nullptr; a.ml_sb = l0; a.ml_sh = l1; a.ml_ss = l2;
+  a.indices = req_to_token; a.mode = 1;
+  a.req_pool_indices = req_pool_indices; a.seq_lens = seq_lens; a.r2t_stride = max_context_len;
+  a.num_kv_splits = nullptr; a.num_splits = (int)num_kv_splits;
+  a.split_align = 1;  // SPLIT_SIZE = div_up(seq_len, num_kv_splits) (decode.cpp:916)
+  a.num_heads = (int)num_heads; a.num_kv_heads = (int)num_kv_heads; a.group = (int)(num_heads / num_kv_heads);
+  a.sm_scale = sm_scale; a.logit_cap = logit_cap;
+  hipStream_t s = as_stream(stream);
+  return dtype == SGL_MI355_BF16
+             ? run_decode<SGL_MI355_BF16>(a, num_seqs, (int)head_size, (int)head_size_v, req_to_token_is64 != 0, s)
+             : run_decode<SGL_MI355_FP16>(a, num_seqs, (int)head_size, (int)head_size_v, req_to_token_is64 != 0, s);
+}
+
+extern "C" int sgl_mi355_decode_attention_fwd(
+    const void* q, const void* k_buffer, const void* v_buffer, void* o, const int32_t* kv_indptr,
+    const int32_t* kv_indices, float* attn_logits, float* attn_lse, const int32_t* num_kv_splits,
+    int64_t max_kv_splits, int64_t batch, int64_t num_heads, int64_t num_kv_heads, int64_t head_size,
+    int64_t head_size_v, int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h,
+    int64_t v_stride_n, int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h, float sm_scale, float logit_cap,
+    int dtype, void* stream) {
+  int rc = check_common(batch, num_heads, num_kv_heads, head_size, head_size_v, max_kv_splits, dtype);
+  if (rc) return rc;
+  SGLM_CHECK_ARG(q && k_buffer && v_buffer && o && kv_indptr, "decode_attention_fwd: null tensor pointer");
+  const bool direct = (max_kv_splits == 1 && num_kv_splits == nullptr);
+  SGLM_CHECK_ARG(direct || (attn_logits && attn_lse), "decode_attention_fwd: attn_logits/attn_lse are required when splitting");
+  if (batch == 0) return 0;
+  DecodeArgs a{};
+  a.q = q; a.q_sb = q_stride_b; a.q_sh = q_stride_h;
+  a.k = k_buffer; a.k_sn = k_stride_n; a.k_sh = k_stride_h;
+  a.v = v_buffer; a.v_sn = v_stride_n; a.v_sh = v_stride_h;
+  a.out = o; a.o_sb = o_stride_b; a.o_sh = o_stride_h;
+  // attn_logits [B][Hq][max_kv_splits][Dv], attn_lse [B][Hq][max_kv_splits] (triton_backend.py:207-216)
+  a.mid_o = attn_logits; a.mo_ss = head_size_v; a.mo_sh = max_kv_splits * head_size_v; a.mo_sb = num_heads * a.mo_sh;
+  a.mid_lse = attn_lse; a.ml_ss = 1; a.ml_sh = max_kv_splits; a.ml_sb = num_heads * max_kv_splits;
+  a.indices = kv_indices; a.mode = 0; a.kv_indptr = kv_indptr;
+  a.num_kv_splits = num_kv_splits; a.num_splits = (int)max_kv_splits;
+  a.split_align = 32;  // _MIN_BLOCK_KV (decode_attention.py:303-307)
+  a.num_heads = (int)num_heads; a.num_kv_heads = (int)num_kv_heads; a.group = (int)(num_heads / num_kv_heads);
+  a.sm_scale = sm_scale; a.logit_cap = logit_cap;
+  hipStream_t s = as_stream(stream);
+  return dtype == SGL_MI355_BF16 ? run_decode<SGL_MI355_BF16>(a, batch, (int)head_size, (int)head_size_v, false, s)
+                                 : run_decode<SGL_MI355_FP16>(a, batch, (int)head_size, (int)head_size_v, false, s);
+}

@@ -1,0 +1,120 @@
+// Shared helpers for the MI355X (gfx950) kernel library.  Internal header: the public
+// C ABI lives in include/sgl_mi355.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sgl_mi355.h"
+
+namespace sglm {
+
+// Thread-local error message, returned through sgl_mi355_last_error().
+void set_error(const char* fmt, ...);
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+int check_hip(hipError_t e, const char* what);
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(2))) int i32x2;
+
+// Per-dtype traits: the 16-bit storage type, its MFMA fragment types and intrinsics.
+template <int DTYPE>
+struct Half16;
+
+template <>
+struct Half16<SGL_MI355_BF16> {
+  using T = __bf16;
+  using x8 = bf16x8;
+  using x4 = bf16x4;
+  static __device__ __forceinline__ f32x4 mfma16(x8 a, x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x16 mfma32(x8 a, x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ x4 ds_read_tr(const void* lds_ptr) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) x4*)(lds_ptr));
+  }
+  static __device__ __forceinline__ float to_f32(T v) { return (float)v; }
+  static __device__ __forceinline__ T from_f32(float v) { return (T)v; }
+};
+
+template <>
+struct Half16<SGL_MI355_FP16> {
+  using T = _Float16;
+  using x8 = f16x8;
+  using x4 = f16x4;
+  static __device__ __forceinline__ f32x4 mfma16(x8 a, x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x16 mfma32(x8 a, x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ x4 ds_read_tr(const void* lds_ptr) {
+    typedef __attribute__((__vector_size__(4 * sizeof(__fp16)))) __fp16 raw4;
+    raw4 r = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) raw4*)(lds_ptr));
+    return __builtin_bit_cast(x4, r);
+  }
+  static __device__ __forceinline__ float to_f32(T v) { return (float)v; }
+  static __device__ __forceinline__ T from_f32(float v) { return (T)v; }
+};
+
+// s_waitcnt vmcnt(N) with a compile-time N (the immediate must be a literal).
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void wait_lgkmcnt0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// One LDS-DMA piece: 64 lanes x 16 B, per-lane global source, LDS destination
+// lds_addr + lane*16 (lds_addr = wave-uniform LDS byte address).
+//
+// Issued through inline asm on purpose: hipcc's waitcnt pass, when it can see an LDS-DMA in
+// flight, puts `s_waitcnt vmcnt(0)` in front of every later LDS read it cannot prove
+// disjoint (all of ours), which would drain the whole prefetch queue once per tile.  Hidden
+// in asm the DMA is invisible to that pass; completion is tracked by hand with counted
+// wait_vmcnt<N>() (vmcnt retires in issue order), and every LDS read of DMA-written bytes
+// sits behind such a wait.  M0 (the DMA's LDS base) is written and restored inside the
+// statement because the compiler owns it.
+__device__ __forceinline__ void lds_dma16(const void* gsrc, uint32_t lds_addr) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_addr)
+      : "memory");
+}
+
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+
+__device__ __forceinline__ int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace sglm
+
+#define SGLM_CHECK_ARG(cond, ...)            \
+  do {                                       \
+    if (!(cond)) {                           \
+      ::sglm::set_error(__VA_ARGS__);        \
+      return SGL_MI355_ERR_INVALID_ARGUMENT; \
+    }                                        \
+  } while (0)
+
+#define SGLM_CHECK_HIP(expr)                           \
+  do {                                                 \
+    int _rc = ::sglm::check_hip((expr), #expr);        \
+    if (_rc != 0) return _rc;                          \
+  } while (0)

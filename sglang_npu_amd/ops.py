@@ -1,0 +1,159 @@
+"""Operator-level API of the MI355X backend.
+
+Same names, argument order and error behaviour as the reference operators they replace
+(``torch.ops.sgl_kernel.*`` / ``sgl_kernel`` Python wrappers / the Triton entry points),
+implemented by calling the C ABI in ``include/sgl_mi355.h`` with raw device pointers and the
+caller's current HIP stream.  Tensors must live on a ROCm device; nothing here computes on
+the host and nothing falls back to PyTorch.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+_P = ctypes.c_void_p
+_I64 = ctypes.c_int64
+_I = ctypes.c_int
+_F = ctypes.c_float
+
+
+def _dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return 0
+    if t.dtype == torch.float16:
+        return 1
+    raise RuntimeError(f"expected a bfloat16 or float16 tensor, got {t.dtype}")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else _P(t.data_ptr())
+
+
+def _stream(t: torch.Tensor):
+    return _P(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("sglang_npu_amd ops take ROCm device tensors; got a CPU tensor (there is no CPU path)")
+
+
+def _is64(t: torch.Tensor, what: str) -> int:
+    if t.dtype == torch.int64:
+        return 1
+    if t.dtype == torch.int32:
+        return 0
+    raise RuntimeError(f"{what} must be int32 or int64, got {t.dtype}")
+
+
+# --------------------------------------------------------------------------- page table / KV pool
+def create_kv_indices(req_to_token, req_pool_indices, page_kernel_lens, kv_indptr, kv_start_idx, kv_indices):
+    """create_flashinfer_kv_indices_triton[(bs,)](req_to_token, req_pool_indices, page_kernel_lens,
+    kv_indptr, kv_start_idx, kv_indices, req_to_token.stride(0))
+    -- python/sglang/srt/layers/attention/utils.py:10-46."""
+    _need_gpu(req_to_token, req_pool_indices, page_kernel_lens, kv_indptr, kv_indices)
+    if req_to_token.dtype != torch.int32 or kv_indptr.dtype != torch.int32 or kv_indices.dtype != torch.int32:
+        raise RuntimeError("create_kv_indices: req_to_token, kv_indptr and kv_indices must be int32")
+    if req_to_token.stride(1) != 1 or not kv_indices.is_contiguous():
+        raise RuntimeError("create_kv_indices: req_to_token rows and kv_indices must be contiguous")
+    bs = req_pool_indices.numel()
+    _lib.check(_lib.lib().sgl_mi355_create_kv_indices(
+        _ptr(req_to_token), _I64(req_to_token.stride(0)),
+        _ptr(req_pool_indices), _I(_is64(req_pool_indices, "req_pool_indices")),
+        _ptr(page_kernel_lens), _I(_is64(page_kernel_lens, "page_kernel_lens")),
+        _ptr(kv_indptr),
+        _ptr(kv_start_idx), _I(_is64(kv_start_idx, "kv_start_idx") if kv_start_idx is not None else 0),
+        _ptr(kv_indices), _I64(bs), _stream(req_to_token)))
+    return kv_indices
+
+
+def set_kv_buffer(k_buffer, v_buffer, loc, cache_k, cache_v):
+    """MHATokenToKVPool.set_kv_buffer: k_buffer[loc] = cache_k; v_buffer[loc] = cache_v
+    -- python/sglang/srt/mem_cache/memory_pool.py:369-407."""
+    _need_gpu(k_buffer, v_buffer, loc, cache_k, cache_v)
+    if k_buffer.dim() != 3 or cache_k.dim() != 3:
+        raise RuntimeError("set_kv_buffer: expected [N,H,D] pool and [T,H,D] new entries")
+    for t in (k_buffer, v_buffer, cache_k, cache_v):
+        if t.stride(-1) != 1:
+            raise RuntimeError("set_kv_buffer: last dim must be contiguous")
+    if cache_k.dtype != k_buffer.dtype or cache_v.dtype != v_buffer.dtype:
+        raise RuntimeError("set_kv_buffer: dtype of new entries must match the pool")
+    _lib.check(_lib.lib().sgl_mi355_set_kv_buffer(
+        _ptr(k_buffer), _ptr(v_buffer), _ptr(cache_k), _ptr(cache_v), _ptr(loc), _I(_is64(loc, "loc")),
+        _I64(loc.numel()), _I64(k_buffer.size(1)), _I64(k_buffer.size(2)), _I64(v_buffer.size(2)),
+        _I64(k_buffer.stride(0)), _I64(k_buffer.stride(1)), _I64(v_buffer.stride(0)), _I64(v_buffer.stride(1)),
+        _I64(cache_k.stride(0)), _I64(cache_k.stride(1)), _I64(cache_v.stride(0)), _I64(cache_v.stride(1)),
+        _I(_dtype_code(k_buffer)), _stream(k_buffer)))
+
+
+# --------------------------------------------------------------------------- decode attention
+def decode_attention(query, k_cache, v_cache, output, key, value, loc, attn_logits, req_to_token,
+                     req_pool_indices, seq_lens, sm_scale, logit_cap):
+    """torch.ops.sgl_kernel.decode_attention_cpu(...) argument for argument
+    -- sgl-kernel/csrc/cpu/torch_extension_cpu.cpp:263-267, decode.cpp:1375-1575.
+    Checks mirror decode.cpp:1391-1451."""
+    _need_gpu(query, k_cache, v_cache, output, attn_logits, req_to_token, req_pool_indices, seq_lens)
+    for name, t in (("query", query), ("k_cache", k_cache), ("v_cache", v_cache), ("output", output)):
+        if t.dim() != 3:
+            raise RuntimeError(f"decode_attention: {name} must be 3-D")
+        if t.stride(-1) != 1:
+            raise RuntimeError(f"decode_attention: {name} must be contiguous at the last dimension")
+    B = seq_lens.size(0)
+    Hq, D = query.size(1), query.size(2)
+    Hkv, Dv = k_cache.size(1), v_cache.size(2)
+    if seq_lens.dtype != torch.int64 or req_pool_indices.dtype != torch.int64:
+        raise RuntimeError("decode_attention: seq_lens and req_pool_indices must be int64")
+    if attn_logits.dtype != torch.float32 or tuple(attn_logits.shape[:2]) != (B, Hq) or attn_logits.size(3) != Dv + 1 \
+            or not attn_logits.is_contiguous():
+        raise RuntimeError("decode_attention: attn_logits must be contiguous float32 [B, Hq, splits, Dv+1]")
+    if loc is not None:
+        if loc.dim() != 1 or loc.numel() != B or loc.dtype != torch.int64:
+            raise RuntimeError("decode_attention: loc must be int64 [num_seqs]")
+        for name, t in (("key", key), ("value", value)):
+            if t.dim() != 3 or t.stride(-1) != 1:
+                raise RuntimeError(f"decode_attention: {name} must be 3-D, contiguous at the last dimension")
+        nk = (key.stride(0), key.stride(1), value.stride(0), value.stride(1))
+    else:
+        nk = (0, 0, 0, 0)
+    if req_to_token.dim() != 2 or req_to_token.stride(1) != 1 or req_to_token.stride(0) != req_to_token.size(1):
+        raise RuntimeError("decode_attention: req_to_token must be a contiguous 2-D tensor")
+    _lib.check(_lib.lib().sgl_mi355_decode_attention(
+        _ptr(query), _ptr(k_cache), _ptr(v_cache), _ptr(output), _ptr(key), _ptr(value), _ptr(loc),
+        _ptr(attn_logits), _ptr(req_to_token), _I(_is64(req_to_token, "req_to_token")),
+        _ptr(req_pool_indices), _ptr(seq_lens),
+        _I64(B), _I64(req_to_token.size(1)), _I64(Hq), _I64(Hkv), _I64(D), _I64(Dv), _I64(attn_logits.size(2)),
+        _I64(query.stride(0)), _I64(query.stride(1)), _I64(k_cache.stride(0)), _I64(k_cache.stride(1)),
+        _I64(v_cache.stride(0)), _I64(v_cache.stride(1)), _I64(nk[0]), _I64(nk[1]), _I64(nk[2]), _I64(nk[3]),
+        _I64(output.stride(0)), _I64(output.stride(1)),
+        _F(sm_scale), _F(logit_cap), _I(_dtype_code(query)), _stream(query)))
+
+
+def decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_logits, attn_lse, num_kv_splits,
+                         max_kv_splits, sm_scale, logit_cap=0.0):
+    """decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_logits, attn_lse,
+    num_kv_splits, max_kv_splits, sm_scale, logit_cap)
+    -- python/sglang/srt/layers/attention/triton_ops/decode_attention.py:677-728."""
+    _need_gpu(q, k_buffer, v_buffer, o, kv_indptr, kv_indices)
+    if attn_logits is not None:
+        assert max_kv_splits == attn_logits.shape[2]  # decode_attention.py:692
+        if attn_logits.dtype != torch.float32 or not attn_logits.is_contiguous() or not attn_lse.is_contiguous():
+            raise RuntimeError("decode_attention_fwd: attn_logits/attn_lse must be contiguous float32")
+    if kv_indptr.dtype != torch.int32 or kv_indices.dtype != torch.int32:
+        raise RuntimeError("decode_attention_fwd: kv_indptr and kv_indices must be int32")
+    if num_kv_splits is not None and num_kv_splits.dtype != torch.int32:
+        raise RuntimeError("decode_attention_fwd: num_kv_splits must be int32")
+    for name, t in (("q", q), ("k_buffer", k_buffer), ("v_buffer", v_buffer), ("o", o)):
+        if t.dim() != 3 or t.stride(-1) != 1:
+            raise RuntimeError(f"decode_attention_fwd: {name} must be 3-D, contiguous at the last dimension")
+    _lib.check(_lib.lib().sgl_mi355_decode_attention_fwd(
+        _ptr(q), _ptr(k_buffer), _ptr(v_buffer), _ptr(o), _ptr(kv_indptr), _ptr(kv_indices),
+        _ptr(attn_logits), _ptr(attn_lse), _ptr(num_kv_splits), _I64(max_kv_splits),
+        _I64(q.size(0)), _I64(q.size(1)), _I64(k_buffer.size(1)), _I64(q.size(2)), _I64(v_buffer.size(2)),
+        _I64(q.stride(0)), _I64(q.stride(1)), _I64(k_buffer.stride(0)), _I64(k_buffer.stride(1)),
+        _I64(v_buffer.stride(0)), _I64(v_buffer.stride(1)), _I64(o.stride(0)), _I64(o.stride(1)),
+        _F(sm_scale), _F(logit_cap), _I(_dtype_code(q)), _stream(q)))

@@ -1,0 +1,188 @@
+"""GPU: paged decode attention (HIP, through the C ABI) against the golden vectors, the oracle
+and size-independent properties at BASELINE.json's full size."""
+import pytest
+import torch
+
+import oracle
+from conftest import golden_names, load_golden, tol_for
+from sglang_npu_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _to(d, keys):
+    return {k: d[k].to(DEV) for k in keys}
+
+
+@pytest.mark.parametrize("name", golden_names("decode_"))
+def test_decode_op_form_vs_golden(name):
+    g = load_golden(name)
+    B, Hq, Hkv, D, Dv, S, splits = [int(x) for x in g["meta"]]
+    t = _to(g, ["q", "k_buffer", "v_buffer", "key", "value", "loc", "req_to_token", "req_pool_indices", "seq_lens"])
+    o = torch.zeros(B, Hq, Dv, dtype=t["q"].dtype, device=DEV)
+    logits = torch.zeros(B, Hq, splits, Dv + 1, device=DEV)
+    ops.decode_attention(t["q"], t["k_buffer"], t["v_buffer"], o, t["key"], t["value"], t["loc"], logits,
+                         t["req_to_token"], t["req_pool_indices"], t["seq_lens"], g["sm_scale"], g["logit_cap"])
+    torch.cuda.synchronize()
+    exp_k, exp_v = g["k_buffer"].clone(), g["v_buffer"].clone()
+    exp_k[g["loc"]] = g["key"]
+    exp_v[g["loc"]] = g["value"]
+    assert torch.equal(t["k_buffer"].cpu().view(torch.int16), exp_k.view(torch.int16)), "KV write must be bit-exact"
+    assert torch.equal(t["v_buffer"].cpu().view(torch.int16), exp_v.view(torch.int16)), "KV write must be bit-exact"
+    bound = tol_for(g["dtype"], g["o_f32"])  # 1e-3 + 1 ulp of the 16-bit output
+    err = (o.float().cpu() - g["o_f32"]).abs().max().item()
+    assert err <= bound, f"{name}: |hip - f32 truth| = {err:.3e} > {bound:.3e}"
+    if g["ref_valid"]:
+        err_ref = (o.float().cpu() - g["o_ref"].float()).abs().max().item()
+        assert err_ref <= 2 * bound, f"{name}: |hip - reference kernel| = {err_ref:.3e}"
+
+
+def _random_case(B, Hq, Hkv, D, S, dtype, seed, ragged=True, idx_dtype=torch.int32):
+    g = torch.Generator().manual_seed(seed)
+    n_tok = B * S + 8
+    q = torch.randn(B, Hq, D, generator=g).to(dtype)
+    kb = torch.randn(n_tok, Hkv, D, generator=g).to(dtype)
+    vb = torch.randn(n_tok, Hkv, D, generator=g).to(dtype)
+    seq = torch.randint(max(1, S // 2), S + 1, (B,), generator=g) if ragged else torch.full((B,), S)
+    perm = torch.randperm(n_tok - 1, generator=g) + 1
+    r2t = torch.zeros(B, S, dtype=idx_dtype)
+    off = 0
+    for b in range(B):
+        L = int(seq[b])
+        r2t[b, :L] = perm[off:off + L].to(idx_dtype)
+        off += L
+    return q, kb, vb, r2t, torch.arange(B), seq
+
+
+@pytest.mark.parametrize("Hq,Hkv,D", [(32, 8, 128), (8, 1, 128), (32, 32, 128), (14, 2, 64), (64, 2, 128)])
+@pytest.mark.parametrize("splits", [1, 3, 8])
+def test_decode_backend_form_vs_oracle(Hq, Hkv, D, splits):
+    B, S = 5, 700
+    dtype = torch.bfloat16
+    q, kb, vb, r2t, rpi, seq = _random_case(B, Hq, Hkv, D, S, dtype, seed=Hq * 131 + splits)
+    # oracle (CPU restatement of decode.cpp / decode_attention.py), p rounded like the Triton kernel
+    o_ref = torch.zeros(B, Hq, D, dtype=dtype)
+    oracle.decode_attention(q, kb.clone(), vb.clone(), o_ref, None, None, None, torch.zeros(B, Hq, 8, D + 1), r2t, rpi,
+                            seq, 1.0 / D ** 0.5, 0.0, p_round=True)
+    # HIP: flatten the page table, then the backend form with per-request split counts
+    d = dict(q=q.to(DEV), kb=kb.to(DEV), vb=vb.to(DEV), r2t=r2t.to(DEV), rpi=rpi.to(DEV), seq=seq.to(DEV))
+    kv_indptr = torch.zeros(B + 1, dtype=torch.int32, device=DEV)
+    kv_indptr[1:] = torch.cumsum(d["seq"], 0)
+    kv_indices = torch.empty(int(seq.sum()), dtype=torch.int32, device=DEV)
+    ops.create_kv_indices(d["r2t"], d["rpi"], d["seq"], kv_indptr, None, kv_indices)
+    exp_idx = torch.cat([r2t[b, :int(seq[b])] for b in range(B)])
+    assert torch.equal(kv_indices.cpu(), exp_idx), "kv_indices must be bit-exact"
+    o = torch.zeros(B, Hq, D, dtype=dtype, device=DEV)
+    if splits == 1:
+        ops.decode_attention_fwd(d["q"], d["kb"], d["vb"], o, kv_indptr, kv_indices, None, None, None, 1,
+                                 1.0 / D ** 0.5)
+    else:
+        logits = torch.full((B, Hq, splits, D), float("nan"), device=DEV)
+        lse = torch.full((B, Hq, splits), float("nan"), device=DEV)
+        nks = torch.tensor([1 + (b % splits) for b in range(B)], dtype=torch.int32, device=DEV)
+        ops.decode_attention_fwd(d["q"], d["kb"], d["vb"], o, kv_indptr, kv_indices, logits, lse, nks, splits,
+                                 1.0 / D ** 0.5)
+    torch.cuda.synchronize()
+    bound = tol_for(dtype, o_ref.float())
+    err = (o.float().cpu() - o_ref.float()).abs().max().item()
+    assert err <= bound, f"|hip - oracle| = {err:.3e} > {bound:.3e}"
+
+
+def test_decode_fp16_int64_table_and_logit_cap():
+    B, Hq, Hkv, D, S = 3, 32, 8, 128, 300
+    q, kb, vb, r2t, rpi, seq = _random_case(B, Hq, Hkv, D, S, torch.float16, seed=5, idx_dtype=torch.int64)
+    o_ref = torch.zeros(B, Hq, D, dtype=torch.float16)
+    logits = torch.zeros(B, Hq, 4, D + 1)
+    oracle.decode_attention(q, kb.clone(), vb.clone(), o_ref, None, None, None, logits, r2t, rpi, seq, 0.2, 20.0,
+                            p_round=True)
+    o = torch.zeros(B, Hq, D, dtype=torch.float16, device=DEV)
+    ops.decode_attention(q.to(DEV), kb.to(DEV), vb.to(DEV), o, None, None, None, logits.to(DEV), r2t.to(DEV),
+                         rpi.to(DEV), seq.to(DEV), 0.2, 20.0)
+    bound = tol_for(torch.float16, o_ref.float())
+    assert (o.float().cpu() - o_ref.float()).abs().max().item() <= bound
+
+
+def test_decode_online_softmax_rescale_is_exercised():
+    """Force the running max to jump late (a spiked key near the end of the sequence and another
+    in the middle), so every rescale branch of the online softmax is taken with a large factor."""
+    B, Hq, Hkv, D, S = 2, 32, 8, 128, 1500
+    dtype = torch.bfloat16
+    q, kb, vb, r2t, rpi, seq = _random_case(B, Hq, Hkv, D, S, dtype, seed=77, ragged=False)
+    for b in range(B):
+        for pos, gain in ((S // 2 + 3, 3.0), (S - 37, 6.0)):
+            tok = int(r2t[b, pos])
+            kb[tok] = (q[b].view(Hkv, Hq // Hkv, D)[:, 0] * gain).to(dtype)  # aligned with head 0 of each group
+    o_ref = torch.zeros(B, Hq, D, dtype=dtype)
+    oracle.decode_attention(q, kb.clone(), vb.clone(), o_ref, None, None, None, torch.zeros(B, Hq, 1, D + 1), r2t, rpi,
+                            seq, 1.0 / D ** 0.5, 0.0, p_round=True)
+    for splits in (1, 4):
+        o = torch.zeros(B, Hq, D, dtype=dtype, device=DEV)
+        ops.decode_attention(q.to(DEV), kb.to(DEV), vb.to(DEV), o, None, None, None,
+                             torch.zeros(B, Hq, splits, D + 1, device=DEV), r2t.to(DEV), rpi.to(DEV), seq.to(DEV),
+                             1.0 / D ** 0.5, 0.0)
+        bound = tol_for(dtype, o_ref.float())
+        assert (o.float().cpu() - o_ref.float()).abs().max().item() <= bound
+
+
+def test_decode_full_size_properties():
+    """BASELINE config 2 (Llama-3-8B, bs=64, S=2048) on the GPU only -- too big for the oracle in
+    seconds, so check size-independent properties:
+      (1) split count does not change the result (1 vs 8 splits);
+      (2) relabelling pool slots (permuting the pool + page table together) does not change it;
+      (3) constant V rows come back unchanged (softmax weights sum to one);
+      (4) a bounded sample of rows agrees with the oracle."""
+    B, Hq, Hkv, D, S = 64, 32, 8, 128, 2048
+    dtype = torch.bfloat16
+    g = torch.Generator(device=DEV).manual_seed(1)
+    n_tok = B * S + 1
+    q = torch.randn(B, Hq, D, device=DEV, generator=g).to(dtype)
+    kb = torch.randn(n_tok, Hkv, D, device=DEV, generator=g).to(dtype)
+    vb = torch.randn(n_tok, Hkv, D, device=DEV, generator=g).to(dtype)
+    perm = torch.randperm(n_tok - 1, device=DEV, generator=g) + 1
+    r2t = perm.view(B, S).to(torch.int32)
+    rpi = torch.arange(B, device=DEV)
+    seq = torch.randint(S // 2, S + 1, (B,), device=DEV, generator=g)
+    seq[0] = S
+    scale = 1.0 / D ** 0.5
+
+    def run(kb_, vb_, r2t_, splits):
+        o = torch.zeros(B, Hq, D, dtype=dtype, device=DEV)
+        ops.decode_attention(q, kb_, vb_, o, None, None, None, torch.zeros(B, Hq, splits, D + 1, device=DEV), r2t_,
+                             rpi, seq, scale, 0.0)
+        return o
+
+    o1 = run(kb, vb, r2t, 1)
+    o8 = run(kb, vb, r2t, 8)
+    bound = tol_for(dtype, o1.float())
+    assert (o1.float() - o8.float()).abs().max().item() <= bound  # (1)
+    relabel = torch.randperm(n_tok, device=DEV, generator=g)
+    inv = torch.empty_like(relabel)
+    inv[relabel] = torch.arange(n_tok, device=DEV)
+    o_p = run(kb[relabel], vb[relabel], inv[r2t.long()].to(torch.int32), 1)  # slot s moved to inv[s]
+    assert torch.equal(o_p.view(torch.int16), o1.view(torch.int16))  # (2) same arithmetic, same order: bit-exact
+    c = torch.randn(1, Hkv, D, device=DEV, generator=g).to(dtype)
+    o_c = run(kb, c.expand(n_tok, Hkv, D).contiguous(), r2t, 2)
+    exp = c[0].repeat_interleave(Hq // Hkv, 0).float()
+    assert (o_c.float() - exp[None]).abs().max().item() <= tol_for(dtype, exp) + 2.0 ** -8 * 4  # (3)
+    # (4) oracle on 2 requests
+    sel = [0, 37]
+    o_ref = torch.zeros(len(sel), Hq, D, dtype=dtype)
+    oracle.decode_attention(q[sel].cpu(), kb.cpu(), vb.cpu(), o_ref, None, None, None,
+                            torch.zeros(len(sel), Hq, 1, D + 1), r2t.cpu(), torch.tensor(sel), seq[sel].cpu(), scale,
+                            0.0, p_round=True)
+    assert (o1[sel].float().cpu() - o_ref.float()).abs().max().item() <= tol_for(dtype, o_ref.float())
+
+
+def test_decode_empty_batch_and_zero_length():
+    dtype = torch.bfloat16
+    q = torch.randn(2, 32, 128, device=DEV).to(dtype)
+    kb = torch.randn(64, 8, 128, device=DEV).to(dtype)
+    o = torch.full((2, 32, 128), 7.0, dtype=dtype, device=DEV)
+    r2t = torch.arange(64, dtype=torch.int32, device=DEV).view(2, 32)
+    seq = torch.tensor([0, 5], device=DEV)
+    ops.decode_attention(q, kb, kb, o, None, None, None, torch.zeros(2, 32, 2, 129, device=DEV), r2t,
+                         torch.arange(2, device=DEV), seq, 0.1, 0.0)
+    assert (o[0] == 0).all()  # empty sequence -> zero row
+    ops.decode_attention(q[:0], kb, kb, o[:0], None, None, None, torch.zeros(0, 32, 2, 129, device=DEV), r2t,
+                         torch.arange(0, device=DEV), seq[:0], 0.1, 0.0)  # empty batch: no-op

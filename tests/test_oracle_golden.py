@@ -1,0 +1,125 @@
+"""CPU: the oracle (oracle/sgl_oracle.c) against every committed golden vector.
+
+The fixtures were produced in the build container by tests/golden/make_golden.py from the
+reference's own compiled CPU kernels and the torch references inside the reference's tests.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import golden_names, load_golden, tol_for
+
+
+@pytest.mark.parametrize("name", golden_names("decode_"))
+def test_decode_oracle_vs_reference(name):
+    g = load_golden(name)
+    B, Hq, Hkv, D, Dv, S, splits = [int(x) for x in g["meta"]]
+    kb, vb = g["k_buffer"].clone(), g["v_buffer"].clone()
+    o = torch.zeros(B, Hq, Dv, dtype=g["q"].dtype)
+    logits = torch.zeros(B, Hq, splits, Dv + 1)
+    oracle.decode_attention(g["q"], kb, vb, o, g["key"], g["value"], g["loc"], logits, g["req_to_token"],
+                            g["req_pool_indices"], g["seq_lens"], g["sm_scale"], g["logit_cap"])
+    # KV write is a byte copy: exact
+    exp_k, exp_v = g["k_buffer"].clone(), g["v_buffer"].clone()
+    exp_k[g["loc"]] = g["key"]
+    exp_v[g["loc"]] = g["value"]
+    assert torch.equal(kb.view(torch.int16), exp_k.view(torch.int16))
+    assert torch.equal(vb.view(torch.int16), exp_v.view(torch.int16))
+    bound = tol_for(g["dtype"], g["o_f32"])
+    assert (o.float() - g["o_f32"]).abs().max().item() <= bound
+    if g["ref_valid"]:
+        assert (o.float() - g["o_ref"].float()).abs().max().item() <= 2 * bound
+
+
+@pytest.mark.parametrize("name", golden_names("extend_"))
+def test_extend_oracle_vs_reference(name):
+    g = load_golden(name)
+    B, Hq, Hkv, D, Dv, max_len_extend = [int(x) for x in g["meta"]]
+    o = torch.zeros(g["q_extend"].size(0), Hq, Dv, dtype=g["q_extend"].dtype)
+    oracle.extend_attention(g["q_extend"], g["k_extend"], g["v_extend"], o, g["k_buffer"], g["v_buffer"],
+                            g["req_to_token"], g["req_pool_indices"], g["seq_lens"], g["extend_seq_lens"],
+                            g["extend_start_loc"], max_len_extend, g["sm_scale"], 0.0)
+    bound = tol_for(g["dtype"], g["o_f32"])
+    assert (o.float() - g["o_f32"]).abs().max().item() <= 2 * bound
+    if g["ref_valid"]:
+        assert (o.float() - g["o_ref"].float()).abs().max().item() <= 2 * bound
+
+
+def test_kv_indices_exact():
+    z = np.load("tests/golden/kv_indices.npz") if False else None
+    g = load_golden("kv_indices")
+    for i in range(int(g["n"])):
+        max_batch, max_ctx = [int(x) for x in g[f"shape{i}"]]
+        r2t = torch.arange(max_batch * max_ctx, dtype=torch.int32).reshape(max_batch, max_ctx)
+        out = torch.empty(int(g[f"indptr{i}"][-1]), dtype=torch.int32)
+        oracle.create_kv_indices(r2t, g[f"rpi{i}"], g[f"lens{i}"], g[f"indptr{i}"], None, out)
+        assert torch.equal(out, g[f"kv_indices{i}"])
+
+
+def _h(arr, dtype):
+    return arr.view(torch.int16).view(torch.bfloat16 if dtype == "bf16" else torch.float16)
+
+
+def test_per_token_quant_fp8_bit_exact():
+    z = np.load("tests/golden/per_token_quant_fp8.npz")
+    for i in range(int(z["n"])):
+        dtype = z[f"dtype{i}"].item().decode()
+        x = _h(torch.from_numpy(z[f"x{i}"].view(np.int16).copy()), dtype)
+        q = torch.empty(x.shape, dtype=torch.uint8)
+        s = torch.empty(x.size(0), dtype=torch.float32)
+        oracle.per_token_quant_fp8(x, q, s)
+        assert torch.equal(s, torch.from_numpy(z[f"s{i}"]))
+        assert torch.equal(q, torch.from_numpy(z[f"q{i}"]))
+
+
+def test_fp8_scaled_mm_vs_reference_torch():
+    z = np.load("tests/golden/fp8_scaled_mm.npz")
+    for i in range(int(z["n"])):
+        dtype = z[f"dtype{i}"].item().decode()
+        dt = torch.bfloat16 if dtype == "bf16" else torch.float16
+        a = torch.from_numpy(z[f"a{i}"]).view(torch.float8_e4m3fn)
+        b = torch.from_numpy(z[f"b{i}"]).view(torch.float8_e4m3fn)
+        bias = _h(torch.from_numpy(z[f"bias{i}"].view(np.int16).copy()), dtype) if f"bias{i}" in z.files else None
+        o = oracle.fp8_scaled_mm(a, b.t(), torch.from_numpy(z[f"sa{i}"]), torch.from_numpy(z[f"sb{i}"]), dt, bias,
+                                 bias_after_round=True)
+        ref = _h(torch.from_numpy(z[f"o{i}"].view(np.int16).copy()), dtype)
+        # reference tolerance: rtol 0.02 / atol 1 (sgl-kernel/tests/test_fp8_gemm.py:33-35); ours: 1 ulp
+        torch.testing.assert_close(o.float(), ref.float(), rtol=2.0 ** -7, atol=2e-2)
+
+
+def test_awq_dequant_exact_and_gemm():
+    z = np.load("tests/golden/awq.npz")
+    for i in range(int(z["n"])):
+        dtype = z[f"dtype{i}"].item().decode()
+        qw, qz = torch.from_numpy(z[f"qweight{i}"]), torch.from_numpy(z[f"qzeros{i}"])
+        sc = _h(torch.from_numpy(z[f"scales{i}"].view(np.int16).copy()), dtype)
+        w = oracle.awq_dequantize(qw, sc, qz)
+        assert torch.equal(w.view(torch.int16), torch.from_numpy(z[f"w{i}"].view(np.int16).copy()))
+        x = _h(torch.from_numpy(z[f"x{i}"].view(np.int16).copy()), dtype)
+        y = oracle.awq_gemm(x, qw, sc, qz)
+        torch.testing.assert_close(y.float(), torch.from_numpy(z[f"y_f32_{i}"]),
+                                   rtol=2.0 ** (-7 if dtype == "bf16" else -10), atol=1e-2)
+
+
+def test_scalar_converters_match_torch():
+    g = torch.Generator().manual_seed(0)
+    x = torch.cat([torch.randn(4096, generator=g) * 100, torch.randn(4096, generator=g) * 1e-2,
+                   torch.tensor([0.0, -0.0, 448.0, -448.0, 2.0 ** -9, 2.0 ** -10, 1.5 * 2.0 ** -9, 240.0, 464.0])])
+    xc = x.clamp(-448, 448)
+    lib = oracle.load()
+    import ctypes
+    y = torch.empty(x.numel(), dtype=torch.uint8)
+    lib.orc_cvt_f32_to_e4m3(ctypes.c_void_p(xc.data_ptr()), ctypes.c_void_p(y.data_ptr()), ctypes.c_int64(x.numel()))
+    assert torch.equal(y, xc.to(torch.float8_e4m3fn).view(torch.uint8))
+    back = torch.empty(256, dtype=torch.float32)
+    allb = torch.arange(256, dtype=torch.uint8)
+    lib.orc_cvt_e4m3_to_f32(ctypes.c_void_p(allb.data_ptr()), ctypes.c_void_p(back.data_ptr()), ctypes.c_int64(256))
+    ref = allb.view(torch.float8_e4m3fn).float()
+    assert torch.equal(torch.nan_to_num(back, nan=-1.0), torch.nan_to_num(ref, nan=-1.0))
+    for code, dt in ((0, torch.bfloat16), (1, torch.float16)):
+        h = torch.empty(x.numel(), dtype=torch.int16)
+        xs = x * (1e-3 if code else 1.0)
+        lib.orc_cvt_f32_to_h(ctypes.c_void_p(xs.data_ptr()), ctypes.c_void_p(h.data_ptr()), ctypes.c_int64(x.numel()),
+                             ctypes.c_int(code))
+        assert torch.equal(h, xs.to(dt).view(torch.int16))
