@@ -30,16 +30,16 @@
 //     kernel finishes (same math as _fwd_kernel_stage2 / decode_accumulate_kv_splits).
 //   * Head sizes other than 64/128 (or Dv != D) take a generic wave-per-head kernel.
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 
 namespace sglm {
 namespace {
 
-constexpr int kWaves = 4;
 constexpr int kTile = 32;        // tokens per pipeline stage
 constexpr int kStages = 2;
-constexpr int kMaxIdx = 4096;    // page-table entries staged in LDS per pass
+constexpr int kMaxIdx = 2048;    // page-table entries staged in LDS per pass (x kWaves/2)
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 
@@ -95,7 +95,7 @@ __device__ __forceinline__ int swz_chunk(int c, int row) {
   return (((c >> 1) ^ f) << 1) | (c & 1);
 }
 
-template <int DTYPE, int D, typename IdxT, bool DIRECT_OUT>
+template <int DTYPE, int D, typename IdxT, bool DIRECT_OUT, int kWaves>
 __global__ __launch_bounds__(kWaves * 64) void decode_mfma_kernel(DecodeArgs a) {
   using H = Half16<DTYPE>;
   using T = typename H::T;
@@ -112,6 +112,7 @@ __global__ __launch_bounds__(kWaves * 64) void decode_mfma_kernel(DecodeArgs a) 
   constexpr int NDV = D / 16;               // 16-wide output column blocks
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int kIdxCap = (kWaves == 4) ? 4 * kMaxIdx : kMaxIdx;
   int32_t* idx_lds = reinterpret_cast<int32_t*>(smem + kWaves * WAVE_BYTES);
 
   const int tid = threadIdx.x;
@@ -190,8 +191,8 @@ __global__ __launch_bounds__(kWaves * 64) void decode_mfma_kernel(DecodeArgs a) 
   const float scale_log2 = a.sm_scale * kLog2e;
   const bool has_cap = a.logit_cap > 0.f;
 
-  for (int p0 = s0; p0 < s1; p0 += kMaxIdx) {
-    const int n_pass = (s1 - p0) < kMaxIdx ? (s1 - p0) : kMaxIdx;
+  for (int p0 = s0; p0 < s1; p0 += kIdxCap) {
+    const int n_pass = (s1 - p0) < kIdxCap ? (s1 - p0) : kIdxCap;
     __syncthreads();  // previous pass finished with idx_lds
     {
       const IdxT* src = reinterpret_cast<const IdxT*>(a.indices) + base + p0;
@@ -480,9 +481,21 @@ __global__ __launch_bounds__(64) void decode_merge_kernel(DecodeArgs a, int Dv) 
   }
 }
 
-template <int D>
+template <int D, int kWaves>
 constexpr int mfma_lds_bytes() {
-  return kWaves * kStages * 2 * kTile * D * 2 + kMaxIdx * 4;
+  return kWaves * kStages * 2 * kTile * D * 2 + ((kWaves == 4) ? 4 * kMaxIdx : kMaxIdx) * 4;
+}
+
+// Waves per workgroup.  2-wave workgroups need <= 72 KB of LDS, so two of them share a CU and
+// one's prologue/merge overlaps the other's streaming; 4-wave workgroups (one per CU) finish a
+// single long sequence sooner.  SGL_MI355_DECODE_WAVES=2|4 overrides (tuning aid).
+inline int pick_waves(int64_t workgroups) {
+  static const int forced = [] {
+    const char* e = getenv("SGL_MI355_DECODE_WAVES");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced == 2 || forced == 4) return forced;
+  return workgroups > 1024 ? 2 : 4;
 }
 
 template <typename K>
@@ -492,16 +505,22 @@ int set_max_lds(K kernel, int bytes) {
       "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
 }
 
-template <int DTYPE, int D, typename IdxT, bool DIRECT>
-int launch_mfma(const DecodeArgs& a, int64_t batch, hipStream_t stream) {
-  auto kern = decode_mfma_kernel<DTYPE, D, IdxT, DIRECT>;
-  constexpr int lds = mfma_lds_bytes<D>();
+template <int DTYPE, int D, typename IdxT, bool DIRECT, int kWaves>
+int launch_mfma_w(const DecodeArgs& a, int64_t grid, hipStream_t stream) {
+  auto kern = decode_mfma_kernel<DTYPE, D, IdxT, DIRECT, kWaves>;
+  constexpr int lds = mfma_lds_bytes<D, kWaves>();
   static int attr_rc = set_max_lds(kern, lds);
   if (attr_rc != 0) return attr_rc;
-  const int nhb = (a.group + 15) / 16;
-  const int64_t grid = batch * a.num_kv_heads * nhb * a.num_splits;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kWaves * 64), lds, stream, a);
   return check_hip(hipGetLastError(), "decode_mfma_kernel launch");
+}
+
+template <int DTYPE, int D, typename IdxT, bool DIRECT>
+int launch_mfma(const DecodeArgs& a, int64_t batch, hipStream_t stream) {
+  const int nhb = (a.group + 15) / 16;
+  const int64_t grid = batch * a.num_kv_heads * nhb * a.num_splits;
+  return pick_waves(grid) == 2 ? launch_mfma_w<DTYPE, D, IdxT, DIRECT, 2>(a, grid, stream)
+                               : launch_mfma_w<DTYPE, D, IdxT, DIRECT, 4>(a, grid, stream);
 }
 
 template <int DTYPE, typename IdxT, bool DIRECT>
@@ -567,10 +586,10 @@ extern "C" int sgl_mi355_decode_attention(
     int64_t o_stride_b, int64_t o_stride_h, float sm_scale, float logit_cap, int dtype, void* stream) {
   int rc = check_common(num_seqs, num_heads, num_kv_heads, head_size, head_size_v, num_kv_splits, dtype);
   if (rc) return rc;
+  if (num_seqs == 0) return 0;
   SGLM_CHECK_ARG(query && k_cache && v_cache && output && req_to_token && req_pool_indices && seq_lens,
                  "decode_attention: null tensor pointer");
   SGLM_CHECK_ARG(attn_logits != nullptr || num_kv_splits == 1, "decode_attention: attn_logits is required when num_kv_splits > 1");
-  if (num_seqs == 0) return 0;
   if (loc != nullptr) {
     SGLM_CHECK_ARG(key && value, "decode_attention: key/value are required when loc is given");
     rc = sgl_mi355_set_kv_buffer(k_cache, v_cache, key, value, loc, 1, num_seqs, num_kv_heads, head_size, head_size_v,
@@ -608,10 +627,10 @@ extern "C" int sgl_mi355_decode_attention_fwd(
     int dtype, void* stream) {
   int rc = check_common(batch, num_heads, num_kv_heads, head_size, head_size_v, max_kv_splits, dtype);
   if (rc) return rc;
+  if (batch == 0) return 0;
   SGLM_CHECK_ARG(q && k_buffer && v_buffer && o && kv_indptr, "decode_attention_fwd: null tensor pointer");
   const bool direct = (max_kv_splits == 1 && num_kv_splits == nullptr);
   SGLM_CHECK_ARG(direct || (attn_logits && attn_lse), "decode_attention_fwd: attn_logits/attn_lse are required when splitting");
-  if (batch == 0) return 0;
   DecodeArgs a{};
   a.q = q; a.q_sb = q_stride_b; a.q_sh = q_stride_h;
   a.k = k_buffer; a.k_sn = k_stride_n; a.k_sh = k_stride_h;
