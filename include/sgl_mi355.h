@@ -39,9 +39,6 @@ int sgl_mi355_abi_version(void);
 /* Copies the calling thread's last error message (NUL-terminated) into buf. Returns its length. */
 size_t sgl_mi355_last_error(char* buf, size_t buf_size);
 
-/* Number of bytes of attention scratch this library wants for a decode call of the given
- * shape when the caller lets it choose the split count (see sgl_mi355_decode_attention). */
-
 /* ------------------------------------------------------------------------------------------
  * Page-table flatten.
  * Replaces: create_flashinfer_kv_indices_triton
@@ -121,6 +118,35 @@ int sgl_mi355_decode_attention_fwd(
     int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h,
     int64_t o_stride_b, int64_t o_stride_h,
     float sm_scale, float logit_cap, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-token dynamic FP8 (OCP e4m3fn) activation quantisation.
+ * Replaces: sgl_per_token_quant_fp8(Tensor input, Tensor output_q, Tensor output_s) -> ()
+ *           schema sgl-kernel/csrc/common_extension.cc:98-130, impl
+ *           sgl-kernel/csrc/gemm/per_token_quant_fp8.cu:15-87,166-227
+ *   scale[t] = absmax(input[t,:]) / 448;  inv = scale == 0 ? 0 : 1/scale;
+ *   output_q[t,k] = e4m3fn(clamp(float(input[t,k]) * inv, -448, 448))   (multiply by the reciprocal)
+ *   input [T,K] bf16/fp16 contiguous, K % 8 == 0 (per_token_quant_fp8.cu:173); output_q [T,K] bytes;
+ *   output_s [T] (or [T,1]) fp32.  Bit-exact with the reference formula. */
+int sgl_mi355_per_token_quant_fp8(
+    const void* input, void* output_q, float* output_s, int64_t num_tokens, int64_t hidden_dim, int dtype,
+    void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * FP8 x FP8 GEMM with per-row (token) and per-column (channel) scales.
+ * Replaces: fp8_scaled_mm(Tensor mat_a, Tensor mat_b, Tensor scales_a, Tensor scales_b,
+ *                         ScalarType out_dtype, Tensor? bias) -> Tensor
+ *           schema sgl-kernel/csrc/common_extension.cc:106-109, impl
+ *           sgl-kernel/csrc/gemm/fp8_gemm_kernel.cu:1071-1146 (epilogue :498-546)
+ *   out[m,n] = cast(((sum_k a[m,k] b[k,n])_f32 * scales_b[n]) * scales_a[m] (+ bias[n]))
+ *   mat_a [M,K] e4m3fn row-major (a_stride_m bytes between rows); mat_b [K,N] e4m3fn with
+ *   stride(0) == 1, i.e. passed as its K-major storage W[N][K] (b_stride_n bytes between
+ *   columns); scales fp32 contiguous [M] / [N]; bias [N] in out dtype or NULL; out [M,N]
+ *   contiguous bf16/fp16.  K % 16 == 0 and (N*2) % 16 == 0 as in the reference
+ *   (fp8_gemm_kernel.cu:1086-1089,1108). */
+int sgl_mi355_fp8_scaled_mm(
+    const void* mat_a, const void* mat_b, const float* scales_a, const float* scales_b, const void* bias, void* out,
+    int64_t M, int64_t N, int64_t K, int64_t a_stride_m, int64_t b_stride_n, int out_dtype, void* stream);
 
 #ifdef __cplusplus
 }

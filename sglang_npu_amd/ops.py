@@ -157,3 +157,55 @@ def decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_l
         _I64(q.stride(0)), _I64(q.stride(1)), _I64(k_buffer.stride(0)), _I64(k_buffer.stride(1)),
         _I64(v_buffer.stride(0)), _I64(v_buffer.stride(1)), _I64(o.stride(0)), _I64(o.stride(1)),
         _F(sm_scale), _F(logit_cap), _I(_dtype_code(q)), _stream(q)))
+
+
+# --------------------------------------------------------------------------- FP8 w8a8
+def sgl_per_token_quant_fp8(input: torch.Tensor, output_q: torch.Tensor, output_s: torch.Tensor) -> None:
+    """sgl_kernel.sgl_per_token_quant_fp8(input, output_q, output_s)
+    -- sgl-kernel/python/sgl_kernel/gemm.py:140-145, per_token_quant_fp8.cu:166-227."""
+    _need_gpu(input, output_q, output_s)
+    if input.dim() != 2 or not input.is_contiguous() or not output_q.is_contiguous() or not output_s.is_contiguous():
+        raise RuntimeError("sgl_per_token_quant_fp8: input [T,K], output_q and output_s must be contiguous")
+    if output_q.dtype not in (torch.float8_e4m3fn, torch.uint8) or output_q.shape != input.shape:
+        raise RuntimeError("sgl_per_token_quant_fp8: output_q must be float8_e4m3fn with input's shape")
+    if output_s.dtype != torch.float32 or output_s.numel() != input.size(0):
+        raise RuntimeError("sgl_per_token_quant_fp8: output_s must be float32 with one entry per token")
+    _lib.check(_lib.lib().sgl_mi355_per_token_quant_fp8(
+        _ptr(input), _ptr(output_q), _ptr(output_s), _I64(input.size(0)), _I64(input.size(1)),
+        _I(_dtype_code(input)), _stream(input)))
+
+
+def fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None) -> torch.Tensor:
+    """sgl_kernel.fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None)
+    -- sgl-kernel/python/sgl_kernel/gemm.py:34-42, fp8_gemm_kernel.cu:1071-1146 (same checks)."""
+    _need_gpu(mat_a, mat_b, scales_a, scales_b, bias)
+    if mat_a.dim() != 2 or mat_b.dim() != 2:
+        raise RuntimeError("mat_a and mat_b must be 2D tensors")
+    if mat_a.stride(1) != 1:
+        raise RuntimeError("mat_a must be a row major tensor")
+    if mat_b.stride(0) != 1:
+        raise RuntimeError("mat_b must be a column major tensor")
+    if mat_a.size(1) != mat_b.size(0):
+        raise RuntimeError("mat_a and mat_b shapes cannot be multiplied")
+    if mat_a.dtype != torch.float8_e4m3fn or mat_b.dtype != torch.float8_e4m3fn:
+        raise RuntimeError("mat_a and mat_b must be Float8_e4m3fn")
+    if out_dtype not in (torch.float16, torch.bfloat16):
+        raise RuntimeError("out_dtype must be Half or BFloat16")
+    M, K = mat_a.shape
+    N = mat_b.size(1)
+    if scales_a.numel() != M or scales_b.numel() != N:
+        raise RuntimeError("size of scales is not matched")
+    if not scales_a.is_contiguous() or not scales_b.is_contiguous():
+        raise RuntimeError("scales must be contiguous")
+    if scales_a.dtype != torch.float32 or scales_b.dtype != torch.float32:
+        raise RuntimeError("scales must be Float32")
+    if bias is not None:
+        if bias.numel() != N or not bias.is_contiguous() or bias.dtype != out_dtype:
+            raise RuntimeError("bias must be contiguous [N] in the output dtype")
+    out = torch.empty((M, N), dtype=out_dtype, device=mat_a.device)
+    b_stride_n = mat_b.stride(1) if N > 1 else K
+    _lib.check(_lib.lib().sgl_mi355_fp8_scaled_mm(
+        _ptr(mat_a), _ptr(mat_b), _ptr(scales_a), _ptr(scales_b), _ptr(bias), _ptr(out),
+        _I64(M), _I64(N), _I64(K), _I64(mat_a.stride(0) if M > 1 else K), _I64(b_stride_n),
+        _I(0 if out_dtype == torch.bfloat16 else 1), _stream(mat_a)))
+    return out

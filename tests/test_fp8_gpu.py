@@ -1,0 +1,122 @@
+"""GPU: per-token FP8 quant (bit-exact) and fp8_scaled_mm against the golden vectors
+(reference torch oracles) and the C oracle."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from sglang_npu_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _h(arr, dtype):
+    t = torch.from_numpy(arr.view(np.int16).copy())
+    return t.view(torch.bfloat16 if dtype == "bf16" else torch.float16)
+
+
+def test_per_token_quant_golden_bit_exact():
+    z = np.load("tests/golden/per_token_quant_fp8.npz")
+    for i in range(int(z["n"])):
+        dtype = z[f"dtype{i}"].item().decode()
+        x = _h(z[f"x{i}"], dtype).to(DEV)
+        q = torch.empty(x.shape, dtype=torch.float8_e4m3fn, device=DEV)
+        s = torch.empty(x.size(0), 1, dtype=torch.float32, device=DEV)
+        ops.sgl_per_token_quant_fp8(x, q, s)
+        assert torch.equal(s.cpu().view(-1), torch.from_numpy(z[f"s{i}"])), "scale must be exact"
+        assert torch.equal(q.cpu().view(torch.uint8), torch.from_numpy(z[f"q{i}"])), "q must be bit-exact"
+
+
+@pytest.mark.parametrize("T,K", [(1, 4096), (64, 4096), (64, 14336), (128, 1368), (512, 896), (3, 8)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_per_token_quant_vs_oracle_bit_exact(T, K, dtype):
+    g = torch.Generator().manual_seed(T * 7 + K)
+    x = (torch.randn(T, K, generator=g) * 2.5).to(dtype)
+    x[0, :3] = torch.tensor([0.0, -0.0, 1e-30]).to(dtype)
+    if T > 2:
+        x[2].zero_()
+    q_ref = torch.empty(T, K, dtype=torch.uint8)
+    s_ref = torch.empty(T)
+    oracle.per_token_quant_fp8(x, q_ref, s_ref)
+    q = torch.empty(T, K, dtype=torch.float8_e4m3fn, device=DEV)
+    s = torch.empty(T, dtype=torch.float32, device=DEV)
+    ops.sgl_per_token_quant_fp8(x.to(DEV), q, s)
+    assert torch.equal(s.cpu(), s_ref)
+    assert torch.equal(q.cpu().view(torch.uint8), q_ref)
+
+
+def test_quant_rejects_bad_hidden_dim():
+    x = torch.zeros(2, 12, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(RuntimeError, match="divisible by 8"):
+        ops.sgl_per_token_quant_fp8(x, torch.empty(2, 12, dtype=torch.float8_e4m3fn, device=DEV),
+                                    torch.empty(2, device=DEV))
+
+
+def test_fp8_scaled_mm_golden():
+    z = np.load("tests/golden/fp8_scaled_mm.npz")
+    for i in range(int(z["n"])):
+        dtype = z[f"dtype{i}"].item().decode()
+        dt = torch.bfloat16 if dtype == "bf16" else torch.float16
+        a = torch.from_numpy(z[f"a{i}"]).view(torch.float8_e4m3fn).to(DEV)
+        b = torch.from_numpy(z[f"b{i}"]).view(torch.float8_e4m3fn).to(DEV)
+        bias = _h(z[f"bias{i}"], dtype).to(DEV) if f"bias{i}" in z.files else None
+        o = ops.fp8_scaled_mm(a, b.t(), torch.from_numpy(z[f"sa{i}"]).to(DEV), torch.from_numpy(z[f"sb{i}"]).to(DEV),
+                              dt, bias)
+        ref = _h(z[f"o{i}"], dtype)
+        # the reference's own bound is rtol 0.02 / atol 1 (sgl-kernel/tests/test_fp8_gemm.py:33-35);
+        # ours: one output ulp (+ the bias rounding the reference oracle adds)
+        torch.testing.assert_close(o.float().cpu(), ref.float(), rtol=2.0 ** -7, atol=2e-2)
+
+
+def _rand_fp8(shape, g):
+    return ((torch.rand(shape, generator=g) - 0.5) * 2 * 448).clamp(-448, 448).to(torch.float8_e4m3fn)
+
+
+@pytest.mark.parametrize("M", [1, 7, 16, 33, 64, 65, 128, 200, 512])
+@pytest.mark.parametrize("N,K", [(128, 512), (6144, 4096), (4096, 1024), (1280, 8192), (72, 144), (4096, 14336)])
+def test_fp8_scaled_mm_vs_oracle(M, N, K):
+    if M > 128 and N * K > 8e6:
+        pytest.skip("oracle too slow; covered by the linearity test")
+    g = torch.Generator().manual_seed(M * 1000 + N + K)
+    dt = torch.bfloat16 if (M + N) % 2 == 0 else torch.float16
+    a, w = _rand_fp8((M, K), g), _rand_fp8((N, K), g)
+    sa = torch.rand(M, generator=g) * 1e-3 + 1e-4
+    sb = torch.rand(N, generator=g) * 1e-3 + 1e-4
+    bias = torch.randn(N, generator=g).to(dt) if M % 2 else None
+    ref = oracle.fp8_scaled_mm(a, w.t(), sa, sb, dt, bias)
+    out = ops.fp8_scaled_mm(a.to(DEV), w.to(DEV).t(), sa.to(DEV), sb.to(DEV), dt, bias.to(DEV) if bias is not None else None)
+    # fp32 accumulation of exact products: only the summation order differs -> <= 1 output ulp
+    ulp = 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10
+    torch.testing.assert_close(out.float().cpu(), ref.float(), rtol=ulp, atol=1e-3 * float(ref.float().abs().max()))
+
+
+def test_fp8_scaled_mm_full_size_properties():
+    """BASELINE config 3 shapes at full size: (a) rows are independent -- the M=64 (skinny kernel)
+    result equals the matching rows of an M=256 (tiled kernel) call to within one ulp; (b) scaling
+    scales_a by 2 doubles the output exactly (power-of-two)."""
+    g = torch.Generator(device=DEV).manual_seed(3)
+    for (K, N) in [(4096, 6144), (4096, 28672), (14336, 4096)]:
+        a = ((torch.rand(256, K, device=DEV, generator=g) - 0.5) * 16).to(torch.float8_e4m3fn)
+        w = ((torch.rand(N, K, device=DEV, generator=g) - 0.5) * 16).to(torch.float8_e4m3fn)
+        sa = torch.rand(256, device=DEV, generator=g) * 1e-2 + 1e-3
+        sb = torch.rand(N, device=DEV, generator=g) * 1e-2 + 1e-3
+        big = ops.fp8_scaled_mm(a, w.t(), sa, sb, torch.bfloat16)
+        small = ops.fp8_scaled_mm(a[:64], w.t(), sa[:64], sb, torch.bfloat16)
+        torch.testing.assert_close(small.float(), big[:64].float(), rtol=2.0 ** -7, atol=1e-6)
+        dbl = ops.fp8_scaled_mm(a[:64], w.t(), sa[:64] * 2, sb, torch.bfloat16)
+        assert torch.equal(dbl, small * 2)
+        # spot-check 4 rows x 64 columns against fp64 on the host
+        rows, cols = [0, 17, 40, 63], slice(1000, 1064)
+        ref = (a[rows].float().double() @ w[cols].float().double().t()) * sb[cols].double() * sa[rows].double()[:, None]
+        torch.testing.assert_close(small[rows][:, cols].double(), ref, rtol=2.0 ** -7, atol=1e-6)
+
+
+def test_fp8_scaled_mm_checks():
+    a = torch.zeros(4, 24, dtype=torch.float8_e4m3fn, device=DEV)
+    w = torch.zeros(16, 24, dtype=torch.float8_e4m3fn, device=DEV)
+    s = torch.ones(16, device=DEV)
+    with pytest.raises(RuntimeError, match="16 bytes"):
+        ops.fp8_scaled_mm(a, w.t(), s[:4], s, torch.bfloat16)
+    with pytest.raises(RuntimeError, match="column major"):
+        ops.fp8_scaled_mm(a, torch.zeros(24, 16, dtype=torch.float8_e4m3fn, device=DEV), s[:4], s, torch.bfloat16)
