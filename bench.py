@@ -1,0 +1,292 @@
+#!/usr/bin/env python3
+"""Headline benchmark: output tokens/s of a Llama-3-8B-shaped FP8 (w8a8) model decoding bs=64 requests
+with RadixAttention-style token-level paged KV (BASELINE.json configs[1]/[2]) on N MI355X GPUs.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU, TP = N over RCCL/xGMI)
+
+One "step" = one decode step of the whole batch: for each of the 32 layers
+  fused-add RMSNorm -> per-token FP8 quant -> qkv GEMM (fp8_scaled_mm) -> RoPE -> KV-pool write ->
+  paged decode attention -> o_proj GEMM (+ all-reduce) -> RMSNorm -> quant -> gate_up GEMM -> SiLU*mul ->
+  quant -> down GEMM (+ all-reduce), then final norm, LM head, greedy argmax.
+Every op of the hot path is this repo's HIP library (sglang_npu_amd/lib/libsgl_mi355.so); the step is
+captured once into a HIP graph and replayed, like the reference's decode path
+(model_runner.py:1663-1669).  Inputs (weights, KV pool, page table) are resident in HBM before the
+timed region.  Data is synthetic: random-init weights with the reference's dummy-loader recipe, a
+random-permutation page table (worst case for HBM), context length CTX per request.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (paged decode attention):
+achieved = algorithmic bytes per launch / its average launch duration, measured with HIP events
+around every launch of it in an instrumented (eager) pass over the same K steps.
+`cpu_baseline` = the CPU oracle (a port of the reference's CPU algorithm, oracle/) timed on the
+host cores on a bounded sample (1 of the 32 layers' hot path), scaled to the full step.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--ctx", type=int, default=2048)
+    ap.add_argument("--model", default="llama3-8b", choices=["llama3-8b", "llama3-70b", "llama2-7b", "qwen2-0.5b"])
+    ap.add_argument("--quant", default="w8a8_fp8", choices=["w8a8_fp8", "awq", "none"])
+    ap.add_argument("--layers", type=int, default=None, help="override the layer count (debug only; invalidates the number)")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def build(args, device, tp):
+    from sglang_npu_amd import model as M
+    from sglang_npu_amd.harness import (MHATokenToKVPool, ModelRunnerLike, ReqToTokenPool, ServerArgs,
+                                        install_attention_backend)
+    cfg = {"llama3-8b": M.LLAMA3_8B, "llama3-70b": M.LLAMA3_70B, "llama2-7b": M.LLAMA2_7B,
+           "qwen2-0.5b": M.QWEN2_05B}[args.model]
+    dtype = torch.float16 if args.quant == "awq" else torch.bfloat16
+    quant = None if args.quant == "none" else args.quant
+    net = M.LlamaForCausalLM(cfg, quant, dtype, str(device), num_layers=args.layers).load_dummy_weights()
+    n_layers = len(net.layers)
+    B, ctx = args.batch, args.ctx
+    max_len = ctx + args.steps + args.warmup + 8
+    n_tok = B * max_len + 1
+    hkv = cfg.get_num_kv_heads(tp)
+    r2t_pool = ReqToTokenPool(B, max_len, str(device))
+    kv_pool = MHATokenToKVPool(n_tok, 1, dtype, hkv, cfg.head_dim, n_layers, str(device))
+    g = torch.Generator(device=device).manual_seed(1234)
+    for l in range(n_layers):  # KV of the already-decoded context: N(0,1) like the reference's kernel tests
+        kv_pool.k_buffer[l].normal_(generator=g)
+        kv_pool.v_buffer[l].normal_(generator=g)
+    # token-level page table = one random permutation of the pool (slot 0 stays the padding slot)
+    perm = (torch.randperm(n_tok - 1, device=device, generator=g) + 1).to(torch.int32)
+    r2t_pool.req_to_token.copy_(perm[: B * max_len].view(B, max_len))
+    runner = ModelRunnerLike(cfg, r2t_pool, kv_pool, str(device), device.index or 0, tp, ServerArgs())
+    backend = install_attention_backend(runner)
+    return net, cfg, runner, backend, max_len
+
+
+class DecodeLoop:
+    """Static-buffer decode loop (the shape of cuda_graph_runner.py: static inputs, metadata refreshed
+    before every replay)."""
+
+    def __init__(self, net, runner, backend, B, ctx, device, use_graph=True):
+        from sglang_npu_amd.harness import ForwardBatch, ForwardMode
+        self.net, self.runner, self.backend, self.B, self.device = net, runner, backend, B, device
+        self.input_ids = torch.randint(0, 10000, (B,), device=device)
+        self.seq_lens = torch.full((B,), ctx, dtype=torch.int64, device=device)  # includes the token being decoded
+        self.positions = self.seq_lens - 1
+        self.req_pool_indices = torch.arange(B, dtype=torch.int64, device=device)
+        self.out_cache_loc = torch.zeros(B, dtype=torch.int64, device=device)
+        self.r2t = runner.req_to_token_pool.req_to_token
+        self.rows = torch.arange(B, device=device)
+        self.fb = ForwardBatch(ForwardMode.DECODE, B, self.input_ids, self.req_pool_indices, self.seq_lens,
+                               self.out_cache_loc, B * ctx, None, self.positions,
+                               req_to_token_pool=runner.req_to_token_pool, token_to_kv_pool=runner.token_to_kv_pool,
+                               attn_backend=backend)
+        self.next_ids = torch.zeros(B, dtype=torch.int64, device=device)
+        self.graph = None
+        self.use_graph = use_graph
+        self._refresh()
+
+    def _refresh(self):
+        # what the scheduler does between steps: the new token's slot is the page-table entry at seq_len-1
+        self.positions.copy_(self.seq_lens - 1)
+        self.out_cache_loc.copy_(self.r2t[self.rows, self.positions].to(torch.int64))
+
+    def _forward(self):
+        logits = self.net(self.input_ids, self.positions, self.fb)
+        self.next_ids.copy_(torch.argmax(logits, dim=-1))
+
+    def capture(self):
+        self.backend.init_cuda_graph_state(self.B, self.B)
+        self.backend.init_forward_metadata_capture_cuda_graph(self.B, self.B, self.req_pool_indices, self.seq_lens,
+                                                              None, self.fb.forward_mode, None)
+        s = torch.cuda.Stream(device=self.device)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                self._forward()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._forward()
+
+    def step(self):
+        if self.graph is not None:
+            self.backend.init_forward_metadata_replay_cuda_graph(self.B, self.req_pool_indices, self.seq_lens,
+                                                                 0, None, self.fb.forward_mode, None, None)
+            self.graph.replay()
+        else:
+            self.backend.init_forward_metadata(self.fb)
+            self._forward()
+        # feed the sampled token back and advance every request by one position
+        self.input_ids.copy_(self.next_ids % 10000)
+        self.seq_lens += 1
+        self._refresh()
+
+
+def time_attention_kernel(loop, steps):
+    """Average duration of the dominant kernel (paged decode attention), HIP events around each launch
+    of it on the launching stream, over `steps` eager steps of the same loop."""
+    from sglang_npu_amd import ops
+    durations = []
+    real = ops.decode_attention_paged
+    pairs = []
+
+    def timed(*a, **kw):
+        st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        st.record()
+        real(*a, **kw)
+        en.record()
+        pairs.append((st, en))
+
+    ops.decode_attention_paged = timed
+    g = loop.graph
+    loop.graph = None
+    try:
+        for _ in range(steps):
+            loop.step()
+        torch.cuda.synchronize()
+    finally:
+        ops.decode_attention_paged = real
+        loop.graph = g
+    durations = [s.elapsed_time(e) for s, e in pairs]
+    durations.sort()
+    # drop the slowest 5 % (first-touch / clock ramp) but keep the mean honest otherwise
+    keep = durations[: max(1, int(len(durations) * 0.95))]
+    return sum(keep) / len(keep), len(durations)
+
+
+def cpu_baseline(cfg, B, ctx, n_layers_full):
+    """Time the CPU oracle on ONE layer's hot path (attention over ctx tokens + 4 quant-GEMMs), all host
+    cores, and scale to the full step.  Bounded to tens of seconds."""
+    import oracle
+    lib_path = oracle.build(native=True, out=os.path.join("/tmp", f"libsgl_oracle_native_{os.getpid()}.so"), force=True)
+    lib = oracle.load(lib_path)
+    cores = int(lib.orc_num_threads())
+    g = torch.Generator().manual_seed(0)
+    Hq, Hkv, D, H, I = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cfg.hidden_size, cfg.intermediate_size
+    n_tok = B * ctx + 1
+    q = torch.randn(B, Hq, D, generator=g).bfloat16()
+    kb = torch.randn(n_tok, Hkv, D, generator=g).bfloat16()
+    vb = torch.randn(n_tok, Hkv, D, generator=g).bfloat16()
+    r2t = (torch.randperm(n_tok - 1, generator=g) + 1).to(torch.int32).view(B, ctx)
+    o = torch.zeros(B, Hq, D, dtype=torch.bfloat16)
+    logits = torch.zeros(B, Hq, 8, D + 1)
+    rpi, seq = torch.arange(B), torch.full((B,), ctx)
+    t0 = time.perf_counter()
+    oracle.decode_attention(q, kb, vb, o, None, None, None, logits, r2t, rpi, seq, D ** -0.5, 0.0, lib=lib)
+    t_attn = time.perf_counter() - t0
+    t_lin = 0.0
+    for (K, N) in [(H, (Hq + 2 * Hkv) * D), (Hq * D, H), (H, 2 * I), (I, H)]:
+        x = torch.randn(B, K, generator=g).bfloat16()
+        w = ((torch.rand(N, K, generator=g) - 0.5) * 8).to(torch.float8_e4m3fn)
+        sb = torch.rand(N, generator=g) * 1e-2
+        t0 = time.perf_counter()
+        xq = torch.empty(B, K, dtype=torch.uint8)
+        xs = torch.empty(B)
+        oracle.per_token_quant_fp8(x, xq, xs, lib=lib)
+        oracle.fp8_scaled_mm(xq.view(torch.float8_e4m3fn), w.t(), xs, sb, torch.bfloat16, lib=lib)
+        t_lin += time.perf_counter() - t0
+    t_layer = t_attn + t_lin
+    return {"value": round(B / (t_layer * n_layers_full), 3), "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"1 of {n_layers_full} layers (decode attention {t_attn * 1e3:.0f} ms + 4 quant-GEMMs "
+                      f"{t_lin * 1e3:.0f} ms at bs={B}, ctx={ctx}), scaled x{n_layers_full}; norms/LM head not counted"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if args.gpus > 1 and world == 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    from sglang_npu_amd import _lib
+    from sglang_npu_amd.distributed import init_distributed_environment
+    _lib.lib()  # fail loudly if the HIP library is missing
+    tp_group = init_distributed_environment(device=device)
+    tp = tp_group.world_size
+
+    net, cfg, runner, backend, max_len = build(args, device, tp)
+    loop = DecodeLoop(net, runner, backend, args.batch, args.ctx, device)
+    if not args.no_graph:
+        loop.capture()
+
+    def barrier():
+        if tp > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loop.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loop.step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if tp > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = args.batch * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel: paged decode attention (HBM-bound)
+    ctx_mid = args.ctx + args.warmup + args.steps + args.steps // 2  # mean sequence length of the instrumented pass
+    hq, hkv, d = cfg.num_attention_heads // tp, cfg.get_num_kv_heads(tp), cfg.head_dim
+    attn_ms, n_launch = time_attention_kernel(loop, min(args.steps, 8))
+    ctx_mid = args.ctx + args.warmup + args.steps + min(args.steps, 8) / 2
+    alg_bytes = args.batch * ctx_mid * hkv * 2 * d * 2 + 4 * args.batch * ctx_mid + 2 * args.batch * hq * 2 * d
+    achieved = alg_bytes / (attn_ms * 1e-3) / 1e9
+    out = {
+        "metric": "output tokens/s (decode, whole model step)", "value": round(value, 1), "unit": "tokens/s",
+        "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "fp8_e4m3 (GEMM) / bf16 (attention, KV)" if args.quant == "w8a8_fp8" else args.quant,
+        "data": "synthetic (dummy-loader random weights, N(0,1) KV, random-permutation page table)",
+        "config": {"workload": f"{args.model} {args.quant} decode bs={args.batch} ctx={args.ctx} TP={tp} "
+                               f"(token-level paged KV, HIP graph replay)",
+                   "global_batch": args.batch, "seq_len": args.ctx, "layers": len(net.layers),
+                   "parallelism": f"tp{tp}"},
+        "roofline": {"bound": "hbm", "kernel": "decode_mfma_kernel (paged decode attention)",
+                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "avg_launch_us": round(attn_ms * 1e3, 2), "launches_timed": n_launch,
+                     "algorithmic_bytes_per_launch": int(alg_bytes)},
+    }
+    if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(cfg, args.batch, args.ctx, cfg.num_hidden_layers)
+        except Exception as e:  # the baseline must never take the GPU number down with it
+            out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if tp > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -148,6 +148,34 @@ int sgl_mi355_fp8_scaled_mm(
     const void* mat_a, const void* mat_b, const float* scales_a, const float* scales_b, const void* bias, void* out,
     int64_t M, int64_t N, int64_t K, int64_t a_stride_m, int64_t b_stride_n, int out_dtype, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Elementwise ops around the hot path.
+ * Replace: sgl_kernel.rmsnorm / fused_add_rmsnorm / silu_and_mul /
+ *          apply_rope_with_cos_sin_cache_inplace as called from
+ *          python/sglang/srt/layers/layernorm.py:59-133, activation.py:59-83,
+ *          rotary_embedding.py:79-260 (CUDA sources sgl-kernel/csrc/elementwise/*.cu).
+ *   rmsnorm:            out = x * rsqrt(mean(x^2) + eps) * weight           (fp32 math, one rounding)
+ *   fused_add_rmsnorm:  residual = x + residual (rounded to dtype); x = norm(fp32 sum) * weight; in place
+ *   silu_and_mul:       out[t,:d] = silu(x[t,:d]) * x[t,d:2d]
+ *   rotary_embedding:   in place on query [T,Hq*D] / key [T,Hk*D]; cos_sin_cache fp32 [max_pos, rot_dim] =
+ *                       [cos | sin]; positions int64 [T]; is_neox selects half-split vs interleaved pairs.
+ *   *_quant_fp8:        the same op fused with sgl_per_token_quant_fp8 of its 16-bit result
+ *                       (out_q [T,H] e4m3fn, out_s [T] fp32); `out` / `residual` may be NULL. */
+int sgl_mi355_rmsnorm(void* out, const void* x, const void* weight, int64_t num_tokens, int64_t hidden, float eps,
+                      int dtype, void* stream);
+int sgl_mi355_fused_add_rmsnorm(void* x, void* residual, const void* weight, int64_t num_tokens, int64_t hidden,
+                                float eps, int dtype, void* stream);
+int sgl_mi355_rmsnorm_quant_fp8(void* out_q, float* out_s, void* out, const void* x, void* residual,
+                                const void* weight, int64_t num_tokens, int64_t hidden, float eps, int dtype,
+                                void* stream);
+int sgl_mi355_silu_and_mul(void* out, const void* x, int64_t num_tokens, int64_t d, int dtype, void* stream);
+int sgl_mi355_silu_and_mul_quant_fp8(void* out_q, float* out_s, const void* x, int64_t num_tokens, int64_t d,
+                                     int dtype, void* stream);
+int sgl_mi355_rotary_embedding(const int64_t* positions, void* query, void* key, const float* cos_sin_cache,
+                               int64_t num_tokens, int64_t num_q_heads, int64_t num_k_heads, int64_t head_size,
+                               int64_t rot_dim, int64_t q_stride_t, int64_t k_stride_t, int is_neox, int dtype,
+                               void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,257 @@
+"""MI355X attention backend -- the drop-in behind SGLang's ``AttentionBackend`` interface.
+
+Interface mirrored: python/sglang/srt/layers/attention/base_attn_backend.py:14-117 (same method
+names, arguments and return conventions).  Behaviour mirrored: TritonAttnBackend,
+python/sglang/srt/layers/attention/triton_backend.py:40-732 (metadata, KV write before the
+kernel, output allocation), with the HIP kernels of this package underneath:
+
+  forward_decode  -> ops.set_kv_buffer + ops.decode_attention / decode_attention_fwd
+  forward_extend  -> ops.set_kv_buffer + ops.extend_attention_fwd
+
+Differences that are deliberate (MI355X-first):
+  * decode reads ``req_to_token`` directly (the kernel gathers page-table rows itself), so the
+    per-step ``kv_indices`` flatten pass of triton_backend.py:172-188 is skipped unless
+    ``flat_kv_indices=True`` (kept for speculative-decoding style callers that hand in indices);
+  * the split count is chosen on the host from the batch geometry only (no device round trip,
+    graph-replay safe): one split as soon as every CU has a workgroup, otherwise enough splits
+    to fill the 256 CUs, never more than ``--triton-attention-num-kv-splits``.
+
+Registration: SGLang has no backend registry (server_args.py:1264-1280 closed ``choices``,
+model_runner.py:1384-1471 if/elif); see ``harness.install_attention_backend`` and INTEGRATION.md.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import ops
+from .harness import AttentionType, ForwardBatch, ForwardMode
+
+NUM_CUS = 256
+
+
+@dataclass
+class ForwardMetadata:
+    attn_logits: Optional[torch.Tensor]
+    attn_lse: Optional[torch.Tensor]
+    max_extend_len: Optional[int]
+    num_kv_splits: int
+    kv_indptr: Optional[torch.Tensor]
+    kv_indices: Optional[torch.Tensor]
+    qo_indptr: Optional[torch.Tensor]
+    custom_mask: Optional[torch.Tensor] = None
+    mask_indptr: Optional[torch.Tensor] = None
+
+
+class AttentionBackend:
+    """Same surface as base_attn_backend.py:14-117."""
+
+    def init_forward_metadata(self, forward_batch: ForwardBatch):
+        raise NotImplementedError()
+
+    def init_cuda_graph_state(self, max_bs: int, max_num_tokens: int):
+        raise NotImplementedError()
+
+    def init_forward_metadata_capture_cuda_graph(self, bs, num_tokens, req_pool_indices, seq_lens, encoder_lens,
+                                                 forward_mode, spec_info):
+        raise NotImplementedError()
+
+    def init_forward_metadata_replay_cuda_graph(self, bs, req_pool_indices, seq_lens, seq_lens_sum, encoder_lens,
+                                                forward_mode, spec_info, seq_lens_cpu):
+        raise NotImplementedError()
+
+    def get_cuda_graph_seq_len_fill_value(self):
+        raise NotImplementedError()
+
+    def forward(self, q, k, v, layer, forward_batch: ForwardBatch, save_kv_cache: bool = True, **kwargs):
+        """Dispatch exactly as base_attn_backend.py:57-89."""
+        if forward_batch.forward_mode.is_idle():
+            return q.new_empty(q.shape[0], layer.tp_q_head_num * layer.v_head_dim)
+        elif forward_batch.forward_mode.is_decode():
+            return self.forward_decode(q, k, v, layer, forward_batch, save_kv_cache=save_kv_cache, **kwargs)
+        else:
+            return self.forward_extend(q, k, v, layer, forward_batch, save_kv_cache=save_kv_cache, **kwargs)
+
+    def forward_decode(self, q, k, v, layer, forward_batch, save_kv_cache=True):
+        raise NotImplementedError()
+
+    def forward_extend(self, q, k, v, layer, forward_batch, save_kv_cache=True):
+        raise NotImplementedError()
+
+    def support_triton(self):
+        return True
+
+
+class MI355AttnBackend(AttentionBackend):
+    def __init__(self, model_runner, skip_prefill: bool = False, flat_kv_indices: bool = False):
+        super().__init__()
+        self.skip_prefill = skip_prefill
+        self.flat_kv_indices = flat_kv_indices
+        max_bs = model_runner.req_to_token_pool.size
+        self.device = model_runner.device
+        self.req_to_token = model_runner.req_to_token_pool.req_to_token
+        tp = getattr(model_runner, "tp_size", 1)
+        self.num_head = model_runner.model_config.num_attention_heads // tp
+        self.num_kv_head = model_runner.model_config.get_num_kv_heads(tp)
+        self.max_kv_splits = model_runner.server_args.triton_attention_num_kv_splits
+        self.v_head_dim = model_runner.token_to_kv_pool.get_value_buffer(0).shape[-1]
+        self.max_context_len = model_runner.model_config.context_len
+        if getattr(model_runner, "sliding_window_size", None):
+            raise NotImplementedError("MI355AttnBackend: sliding-window attention is not implemented yet")
+        self.kv_indptr = torch.zeros((max_bs + 1,), dtype=torch.int32, device=self.device)
+        if not skip_prefill:
+            self.qo_indptr = torch.zeros((max_bs + 1,), dtype=torch.int32, device=self.device)
+        self.forward_metadata: Optional[ForwardMetadata] = None
+        self._graph = None  # static buffers once init_cuda_graph_state has run
+
+    # ---------------------------------------------------------------- split policy (host only)
+    def choose_num_kv_splits(self, bs: int, max_seq_len: Optional[int] = None) -> int:
+        group = max(1, self.num_head // self.num_kv_head)
+        wgs = bs * self.num_kv_head * ((group + 15) // 16)
+        if wgs >= NUM_CUS:
+            return 1
+        splits = min(self.max_kv_splits, -(-2 * NUM_CUS // wgs))
+        if max_seq_len is not None:
+            splits = min(splits, max(1, max_seq_len // 256))  # keep >= 256 tokens per split
+        return max(1, splits)
+
+    def _scratch(self, bs: int, splits: int):
+        """fp32 partials of the kv-splits.  Direct form: one tensor [bs, H, splits, Dv+1] with the LSE in
+        the last column (the layout of decode_attention_cpu); flat form: Triton's logits + lse pair."""
+        if splits == 1:
+            return None, None
+        if not self.flat_kv_indices:
+            return torch.empty((bs, self.num_head, splits, self.v_head_dim + 1), dtype=torch.float32,
+                               device=self.device), None
+        logits = torch.empty((bs, self.num_head, splits, self.v_head_dim), dtype=torch.float32, device=self.device)
+        lse = torch.empty((bs, self.num_head, splits), dtype=torch.float32, device=self.device)
+        return logits, lse
+
+    # ---------------------------------------------------------------- metadata
+    def init_forward_metadata(self, forward_batch: ForwardBatch):
+        """Once per step (model_runner.py:1553-1554 / :1572-1573), as triton_backend.py:160-336."""
+        bs = forward_batch.batch_size
+        if forward_batch.spec_info is not None:
+            raise NotImplementedError("MI355AttnBackend: speculative decoding metadata is not implemented")
+        if forward_batch.forward_mode.is_decode_or_idle():
+            max_len = int(forward_batch.seq_lens_cpu.max()) if forward_batch.seq_lens_cpu is not None else None
+            splits = self.choose_num_kv_splits(bs, max_len)
+            kv_indptr = kv_indices = None
+            if self.flat_kv_indices:
+                kv_indptr = self.kv_indptr
+                kv_indptr[1:bs + 1] = torch.cumsum(forward_batch.seq_lens, dim=0)
+                kv_indptr = kv_indptr[:bs + 1]
+                kv_indices = torch.empty(forward_batch.seq_lens_sum, dtype=torch.int32, device=self.device)
+                ops.create_kv_indices(self.req_to_token, forward_batch.req_pool_indices, forward_batch.seq_lens,
+                                      kv_indptr, None, kv_indices)
+            logits, lse = self._scratch(bs, splits)
+            self.forward_metadata = ForwardMetadata(logits, lse, None, splits, kv_indptr, kv_indices, None)
+        else:
+            kv_indptr = self.kv_indptr
+            kv_indptr[1:bs + 1] = torch.cumsum(forward_batch.extend_prefix_lens, dim=0)
+            kv_indptr = kv_indptr[:bs + 1]
+            n_prefix = (sum(forward_batch.extend_prefix_lens_cpu) if forward_batch.extend_prefix_lens_cpu is not None
+                        else int(forward_batch.extend_prefix_lens.sum().item()))
+            kv_indices = torch.empty(max(n_prefix, 1), dtype=torch.int32, device=self.device)
+            ops.create_kv_indices(self.req_to_token, forward_batch.req_pool_indices, forward_batch.extend_prefix_lens,
+                                  kv_indptr, None, kv_indices)
+            qo_indptr = self.qo_indptr
+            qo_indptr[1:bs + 1] = torch.cumsum(forward_batch.extend_seq_lens, dim=0)
+            qo_indptr = qo_indptr[:bs + 1]
+            max_extend_len = (max(forward_batch.extend_seq_lens_cpu) if forward_batch.extend_seq_lens_cpu is not None
+                              else int(torch.max(forward_batch.extend_seq_lens).item()))
+            self.forward_metadata = ForwardMetadata(None, None, max_extend_len, 1, kv_indptr, kv_indices, qo_indptr)
+
+    # ---------------------------------------------------------------- graph capture / replay
+    def init_cuda_graph_state(self, max_bs: int, max_num_tokens: int, kv_indices_buf: Optional[torch.Tensor] = None):
+        """triton_backend.py:338-388: allocate every buffer a captured decode step touches."""
+        splits = self.max_kv_splits
+        g = {
+            "attn_logits": torch.zeros((max_num_tokens, self.num_head, splits, self.v_head_dim + 1),
+                                       dtype=torch.float32, device=self.device),
+            "attn_lse": torch.zeros((max_num_tokens, self.num_head, splits), dtype=torch.float32, device=self.device),
+        }
+        if self.flat_kv_indices:
+            g["kv_indices"] = kv_indices_buf if kv_indices_buf is not None else torch.zeros(
+                (max_num_tokens * self.max_context_len,), dtype=torch.int32, device=self.device)
+        self._graph = g
+
+    def init_forward_metadata_capture_cuda_graph(self, bs, num_tokens, req_pool_indices, seq_lens, encoder_lens,
+                                                 forward_mode, spec_info):
+        assert encoder_lens is None, "Not supported"
+        if not forward_mode.is_decode_or_idle() or spec_info is not None:
+            raise ValueError(f"Invalid forward mode: {forward_mode=} for CUDA Graph capture.")
+        splits = self.choose_num_kv_splits(bs)  # depends on bs only: identical at capture and replay
+        g = self._graph
+        logits = lse = None
+        if splits > 1:
+            dv = self.v_head_dim if self.flat_kv_indices else self.v_head_dim + 1
+            logits = g["attn_logits"].view(-1)[: bs * self.num_head * splits * dv].view(bs, self.num_head, splits, dv)
+            if self.flat_kv_indices:
+                lse = g["attn_lse"].view(-1)[: bs * self.num_head * splits].view(bs, self.num_head, splits)
+        kv_indptr = kv_indices = None
+        if self.flat_kv_indices:
+            kv_indptr = self.kv_indptr
+            kv_indptr[1:bs + 1] = torch.cumsum(seq_lens, dim=0)
+            kv_indptr = kv_indptr[:bs + 1]
+            kv_indices = g["kv_indices"]
+            ops.create_kv_indices(self.req_to_token, req_pool_indices, seq_lens, kv_indptr, None, kv_indices)
+        self.forward_metadata = ForwardMetadata(logits, lse, None, splits, kv_indptr, kv_indices, None)
+
+    def init_forward_metadata_replay_cuda_graph(self, bs, req_pool_indices, seq_lens, seq_lens_sum, encoder_lens,
+                                                forward_mode, spec_info, seq_lens_cpu):
+        if not forward_mode.is_decode_or_idle() or spec_info is not None:
+            raise ValueError(f"Invalid forward mode: {forward_mode=} for CUDA Graph replay.")
+        if self.flat_kv_indices:  # refresh the flattened table in place (triton_backend.py:539-552)
+            kv_indptr = self.kv_indptr
+            kv_indptr[1:bs + 1] = torch.cumsum(seq_lens[:bs], dim=0)
+            ops.create_kv_indices(self.req_to_token, req_pool_indices[:bs], seq_lens[:bs], kv_indptr[:bs + 1], None,
+                                  self._graph["kv_indices"])
+        # the direct form reads req_to_token / req_pool_indices / seq_lens, all graph inputs updated by the
+        # graph runner itself: nothing to do here.
+
+    def get_cuda_graph_seq_len_fill_value(self):
+        return 1
+
+    # ---------------------------------------------------------------- forward
+    def forward_decode(self, q, k, v, layer, forward_batch: ForwardBatch, save_kv_cache=True):
+        q = q.reshape(-1, layer.tp_q_head_num * layer.qk_head_dim)
+        if layer.qk_head_dim != layer.v_head_dim:
+            o = q.new_empty((q.shape[0], layer.tp_q_head_num * layer.v_head_dim))
+        else:
+            o = torch.empty_like(q)
+        if save_kv_cache:
+            forward_batch.token_to_kv_pool.set_kv_buffer(layer, forward_batch.out_cache_loc, k, v)
+        md = self.forward_metadata
+        kb = forward_batch.token_to_kv_pool.get_key_buffer(layer.layer_id)
+        vb = forward_batch.token_to_kv_pool.get_value_buffer(layer.layer_id)
+        q3 = q.view(-1, layer.tp_q_head_num, layer.qk_head_dim)
+        o3 = o.view(-1, layer.tp_q_head_num, layer.v_head_dim)
+        if md.kv_indices is not None:
+            ops.decode_attention_fwd(q3, kb, vb, o3, md.kv_indptr, md.kv_indices, md.attn_logits, md.attn_lse, None,
+                                     md.num_kv_splits, layer.scaling, layer.logit_cap)
+        else:
+            ops.decode_attention_paged(q3, kb, vb, o3, self.req_to_token, forward_batch.req_pool_indices,
+                                       forward_batch.seq_lens, md.attn_logits, md.num_kv_splits, layer.scaling,
+                                       layer.logit_cap)
+        return o
+
+    def forward_extend(self, q, k, v, layer, forward_batch: ForwardBatch, save_kv_cache=True):
+        if layer.qk_head_dim != layer.v_head_dim:
+            o = q.new_empty((q.shape[0], layer.tp_q_head_num * layer.v_head_dim))
+        else:
+            o = torch.empty_like(q)
+        if save_kv_cache:
+            forward_batch.token_to_kv_pool.set_kv_buffer(layer, forward_batch.out_cache_loc, k, v)
+        causal = layer.attn_type != AttentionType.ENCODER_ONLY
+        md = self.forward_metadata
+        ops.extend_attention_fwd(
+            q.view(-1, layer.tp_q_head_num, layer.qk_head_dim), k.contiguous(), v.contiguous(),
+            o.view(-1, layer.tp_q_head_num, layer.v_head_dim),
+            forward_batch.token_to_kv_pool.get_key_buffer(layer.layer_id),
+            forward_batch.token_to_kv_pool.get_value_buffer(layer.layer_id),
+            md.qo_indptr, md.kv_indptr, md.kv_indices, md.custom_mask, causal, md.mask_indptr, md.max_extend_len,
+            layer.scaling, layer.logit_cap)
+        return o

@@ -1,0 +1,329 @@
+// Per-layer elementwise ops around the hot path (SURVEY 8f "next" rows 1-2), MI355X / gfx950.
+// All are HBM/L2-bound byte movers: 16-B vector loads/stores, one workgroup per token row,
+// everything between the load and the store stays in registers (single pass over memory).
+//
+// Replaces:
+//   * rmsnorm / fused_add_rmsnorm      python/sglang/srt/layers/layernorm.py:59-172 (forward_cuda ->
+//                                      sgl_kernel.rmsnorm / fused_add_rmsnorm;
+//                                      sgl-kernel/csrc/elementwise/fused_add_rms_norm_kernel.cu)
+//   * silu_and_mul                     python/sglang/srt/layers/activation.py:59-83,
+//                                      sgl-kernel/csrc/elementwise/activation.cu
+//   * apply_rope_with_cos_sin_cache_inplace (neox / gpt-j)
+//                                      python/sglang/srt/layers/rotary_embedding.py:79-260,
+//                                      sgl-kernel/csrc/elementwise/rope.cu
+//   * fusion new in this backend: (add +) RMSNorm + per-token FP8 quant and SiLU*mul + per-token FP8
+//     quant in one pass -- removes the standalone quant kernel (per_token_quant_fp8.cu) and one
+//     activation round trip per GEMM input.  Same arithmetic as running the two reference ops
+//     back to back (the normalised / activated row is rounded to the 16-bit dtype first, then
+//     quantised with scale = absmax/448 and a reciprocal multiply).
+#include "common.h"
+
+namespace sglm {
+namespace {
+
+constexpr float kFp8Max = 448.0f;
+
+__device__ __forceinline__ float block_reduce_sum(float v, float* red) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  const int nw = blockDim.x >> 6;
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = 0.f;
+  for (int i = 0; i < nw; ++i) r += red[i];
+  __syncthreads();
+  return r;
+}
+
+__device__ __forceinline__ float block_reduce_max(float v, float* red) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+  const int nw = blockDim.x >> 6;
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = 0.f;
+  for (int i = 0; i < nw; ++i) r = fmaxf(r, red[i]);
+  __syncthreads();
+  return r;
+}
+
+__device__ __forceinline__ uint2 pack8_fp8(const float* f) {
+  int lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+  int hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+  return uint2{(unsigned)lo, (unsigned)hi};
+}
+
+// (residual-add +) RMSNorm (+ FP8 quant).  H % 8 == 0, H <= 256 * 8 * VPT.
+//   x: [T,H] input; residual: nullable, in/out (residual = x + residual, rounded to dtype);
+//   out: nullable 16-bit output; out_q/out_s: nullable FP8 output + per-row scale.
+template <int DTYPE, int VPT>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(
+    const typename Half16<DTYPE>::T* x /* may alias out */, typename Half16<DTYPE>::T* residual,
+    const typename Half16<DTYPE>::T* __restrict__ weight, typename Half16<DTYPE>::T* out,
+    uint8_t* __restrict__ out_q, float* __restrict__ out_s, int H, float eps) {
+  using Hh = Half16<DTYPE>;
+  using x8 = typename Hh::x8;
+  __shared__ float red[4];
+  const int64_t row = blockIdx.x;
+  const int nv = H >> 3;
+  float v[VPT][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int vi = threadIdx.x + 256 * i;
+    if (vi < nv) {
+      const x8 xv = reinterpret_cast<const x8*>(x + row * H)[vi];
+      if (residual) {
+        const x8 rv = reinterpret_cast<const x8*>(residual + row * H)[vi];
+        x8 nr;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          v[i][j] = Hh::to_f32(xv[j]) + Hh::to_f32(rv[j]);  // the norm continues on the unrounded fp32 sum
+          nr[j] = Hh::from_f32(v[i][j]);
+        }
+        reinterpret_cast<x8*>(residual + row * H)[vi] = nr;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[i][j] = Hh::to_f32(xv[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss += v[i][j] * v[i][j];
+    }
+  }
+  ss = block_reduce_sum(ss, red);
+  const float inv = 1.0f / sqrtf(ss / (float)H + eps);
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int vi = threadIdx.x + 256 * i;
+    if (vi < nv) {
+      const x8 wv = reinterpret_cast<const x8*>(weight)[vi];
+      x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        o[j] = Hh::from_f32(v[i][j] * inv * Hh::to_f32(wv[j]));
+        v[i][j] = Hh::to_f32(o[j]);  // the quantiser sees the 16-bit value, as the unfused pair does
+        amax = fmaxf(amax, fabsf(v[i][j]));
+      }
+      if (out) reinterpret_cast<x8*>(out + row * H)[vi] = o;
+    }
+  }
+  if (out_q) {
+    amax = block_reduce_max(amax, red);
+    const float scale = amax / kFp8Max;
+    if (threadIdx.x == 0) out_s[row] = scale;
+    const float sinv = scale == 0.f ? 0.f : 1.0f / scale;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      const int vi = threadIdx.x + 256 * i;
+      if (vi < nv) {
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = fminf(fmaxf(v[i][j] * sinv, -kFp8Max), kFp8Max);
+        reinterpret_cast<uint2*>(out_q + row * H)[vi] = pack8_fp8(f);
+      }
+    }
+  }
+}
+
+// out[t, :d] = silu(x[t, :d]) * x[t, d:2d]  (+ optional per-row FP8 quant of the result)
+template <int DTYPE, int VPT>
+__global__ __launch_bounds__(256) void silu_mul_kernel(
+    const typename Half16<DTYPE>::T* __restrict__ x, typename Half16<DTYPE>::T* __restrict__ out,
+    uint8_t* __restrict__ out_q, float* __restrict__ out_s, int d) {
+  using Hh = Half16<DTYPE>;
+  using x8 = typename Hh::x8;
+  __shared__ float red[4];
+  const int64_t row = blockIdx.x;
+  const int nv = d >> 3;
+  float v[VPT][8];
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int vi = threadIdx.x + 256 * i;
+    if (vi < nv) {
+      const x8 a = reinterpret_cast<const x8*>(x + row * 2 * d)[vi];
+      const x8 b = reinterpret_cast<const x8*>(x + row * 2 * d + d)[vi];
+      x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float af = Hh::to_f32(a[j]);
+        const float s = af / (1.0f + __expf(-af));
+        o[j] = Hh::from_f32(s * Hh::to_f32(b[j]));  // fp32 math, one rounding (activation.cu)
+        v[i][j] = Hh::to_f32(o[j]);
+        amax = fmaxf(amax, fabsf(v[i][j]));
+      }
+      if (out) reinterpret_cast<x8*>(out + row * d)[vi] = o;
+    }
+  }
+  if (out_q) {
+    amax = block_reduce_max(amax, red);
+    const float scale = amax / kFp8Max;
+    if (threadIdx.x == 0) out_s[row] = scale;
+    const float sinv = scale == 0.f ? 0.f : 1.0f / scale;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      const int vi = threadIdx.x + 256 * i;
+      if (vi < nv) {
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = fminf(fmaxf(v[i][j] * sinv, -kFp8Max), kFp8Max);
+        reinterpret_cast<uint2*>(out_q + row * d)[vi] = pack8_fp8(f);
+      }
+    }
+  }
+}
+
+// In-place rotary embedding on q [T,Hq,D] and k [T,Hk,D] (row strides given), fp32 cos/sin cache
+// [max_pos, rot_dim] = [cos | sin].  One thread per (token, head, pair).
+template <int DTYPE>
+__global__ __launch_bounds__(256) void rope_kernel(
+    typename Half16<DTYPE>::T* __restrict__ q, typename Half16<DTYPE>::T* __restrict__ k,
+    const int64_t* __restrict__ positions, const float* __restrict__ cache, int64_t T, int Hq, int Hk, int D,
+    int rot_dim, int64_t q_st, int64_t k_st, int neox) {
+  using Hh = Half16<DTYPE>;
+  const int half = rot_dim >> 1;
+  const int64_t total = T * (int64_t)(Hq + Hk) * half;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int p = (int)(i % half);
+    const int64_t th = i / half;
+    const int h = (int)(th % (Hq + Hk));
+    const int64_t t = th / (Hq + Hk);
+    typename Hh::T* base = h < Hq ? q + t * q_st + (int64_t)h * D : k + t * k_st + (int64_t)(h - Hq) * D;
+    const float* cs = cache + positions[t] * rot_dim;
+    const float c = cs[p], s = cs[half + p];
+    const int i1 = neox ? p : 2 * p;
+    const int i2 = neox ? p + half : 2 * p + 1;
+    const float x1 = Hh::to_f32(base[i1]), x2 = Hh::to_f32(base[i2]);
+    base[i1] = Hh::from_f32(x1 * c - x2 * s);
+    base[i2] = Hh::from_f32(x2 * c + x1 * s);
+  }
+}
+
+template <int DTYPE>
+int launch_rmsnorm(const void* x, void* residual, const void* weight, void* out, void* out_q, float* out_s, int64_t T,
+                   int64_t H, float eps, hipStream_t s) {
+  using T16 = typename Half16<DTYPE>::T;
+  const int nv = (int)(H >> 3);
+  const int vpt = (nv + 255) / 256;
+#define RMS_LAUNCH(V)                                                                                        \
+  hipLaunchKernelGGL((rmsnorm_kernel<DTYPE, V>), dim3((unsigned)T), dim3(256), 0, s, (const T16*)x, (T16*)residual, \
+                     (const T16*)weight, (T16*)out, (uint8_t*)out_q, out_s, (int)H, eps)
+  if (vpt <= 1) RMS_LAUNCH(1);
+  else if (vpt <= 2) RMS_LAUNCH(2);
+  else if (vpt <= 4) RMS_LAUNCH(4);
+  else RMS_LAUNCH(8);
+#undef RMS_LAUNCH
+  return check_hip(hipGetLastError(), "rmsnorm launch");
+}
+
+template <int DTYPE>
+int launch_silu(const void* x, void* out, void* out_q, float* out_s, int64_t T, int64_t d, hipStream_t s) {
+  using T16 = typename Half16<DTYPE>::T;
+  const int nv = (int)(d >> 3);
+  const int vpt = (nv + 255) / 256;
+#define SILU_LAUNCH(V)                                                                                     \
+  hipLaunchKernelGGL((silu_mul_kernel<DTYPE, V>), dim3((unsigned)T), dim3(256), 0, s, (const T16*)x, (T16*)out, \
+                     (uint8_t*)out_q, out_s, (int)d)
+  if (vpt <= 1) SILU_LAUNCH(1);
+  else if (vpt <= 2) SILU_LAUNCH(2);
+  else if (vpt <= 4) SILU_LAUNCH(4);
+  else if (vpt <= 8) SILU_LAUNCH(8);
+  else SILU_LAUNCH(16);
+#undef SILU_LAUNCH
+  return check_hip(hipGetLastError(), "silu_and_mul launch");
+}
+
+int check_rows(const char* op, int64_t T, int64_t H, int64_t max_h, int dtype) {
+  SGLM_CHECK_ARG(dtype == SGL_MI355_BF16 || dtype == SGL_MI355_FP16, "%s: bad dtype %d", op, dtype);
+  SGLM_CHECK_ARG(T >= 0 && T < (1ll << 31), "%s: bad number of rows %ld", op, (long)T);
+  SGLM_CHECK_ARG(H > 0 && H % 8 == 0 && H <= max_h, "%s: row length (%ld) must be a multiple of 8 and <= %ld", op,
+                 (long)H, (long)max_h);
+  return 0;
+}
+
+}  // namespace
+}  // namespace sglm
+
+using namespace sglm;
+
+extern "C" int sgl_mi355_rmsnorm(
+    void* out, const void* x, const void* weight, int64_t num_tokens, int64_t hidden, float eps, int dtype,
+    void* stream) {
+  int rc = check_rows("rmsnorm", num_tokens, hidden, 16384, dtype);
+  if (rc) return rc;
+  if (num_tokens == 0) return 0;
+  SGLM_CHECK_ARG(out && x && weight, "rmsnorm: null tensor pointer");
+  return dtype == SGL_MI355_BF16
+             ? launch_rmsnorm<SGL_MI355_BF16>(x, nullptr, weight, out, nullptr, nullptr, num_tokens, hidden, eps, as_stream(stream))
+             : launch_rmsnorm<SGL_MI355_FP16>(x, nullptr, weight, out, nullptr, nullptr, num_tokens, hidden, eps, as_stream(stream));
+}
+
+extern "C" int sgl_mi355_fused_add_rmsnorm(
+    void* x, void* residual, const void* weight, int64_t num_tokens, int64_t hidden, float eps, int dtype,
+    void* stream) {
+  int rc = check_rows("fused_add_rmsnorm", num_tokens, hidden, 16384, dtype);
+  if (rc) return rc;
+  if (num_tokens == 0) return 0;
+  SGLM_CHECK_ARG(x && residual && weight, "fused_add_rmsnorm: null tensor pointer");
+  return dtype == SGL_MI355_BF16
+             ? launch_rmsnorm<SGL_MI355_BF16>(x, residual, weight, x, nullptr, nullptr, num_tokens, hidden, eps, as_stream(stream))
+             : launch_rmsnorm<SGL_MI355_FP16>(x, residual, weight, x, nullptr, nullptr, num_tokens, hidden, eps, as_stream(stream));
+}
+
+extern "C" int sgl_mi355_rmsnorm_quant_fp8(
+    void* out_q, float* out_s, void* out /* nullable */, const void* x, void* residual /* nullable, in/out */,
+    const void* weight, int64_t num_tokens, int64_t hidden, float eps, int dtype, void* stream) {
+  int rc = check_rows("rmsnorm_quant_fp8", num_tokens, hidden, 16384, dtype);
+  if (rc) return rc;
+  if (num_tokens == 0) return 0;
+  SGLM_CHECK_ARG(out_q && out_s && x && weight, "rmsnorm_quant_fp8: null tensor pointer");
+  return dtype == SGL_MI355_BF16
+             ? launch_rmsnorm<SGL_MI355_BF16>(x, residual, weight, out, out_q, out_s, num_tokens, hidden, eps, as_stream(stream))
+             : launch_rmsnorm<SGL_MI355_FP16>(x, residual, weight, out, out_q, out_s, num_tokens, hidden, eps, as_stream(stream));
+}
+
+extern "C" int sgl_mi355_silu_and_mul(void* out, const void* x, int64_t num_tokens, int64_t d, int dtype, void* stream) {
+  int rc = check_rows("silu_and_mul", num_tokens, d, 32768, dtype);
+  if (rc) return rc;
+  if (num_tokens == 0) return 0;
+  SGLM_CHECK_ARG(out && x, "silu_and_mul: null tensor pointer");
+  return dtype == SGL_MI355_BF16 ? launch_silu<SGL_MI355_BF16>(x, out, nullptr, nullptr, num_tokens, d, as_stream(stream))
+                                 : launch_silu<SGL_MI355_FP16>(x, out, nullptr, nullptr, num_tokens, d, as_stream(stream));
+}
+
+extern "C" int sgl_mi355_silu_and_mul_quant_fp8(
+    void* out_q, float* out_s, const void* x, int64_t num_tokens, int64_t d, int dtype, void* stream) {
+  int rc = check_rows("silu_and_mul_quant_fp8", num_tokens, d, 32768, dtype);
+  if (rc) return rc;
+  if (num_tokens == 0) return 0;
+  SGLM_CHECK_ARG(out_q && out_s && x, "silu_and_mul_quant_fp8: null tensor pointer");
+  return dtype == SGL_MI355_BF16 ? launch_silu<SGL_MI355_BF16>(x, nullptr, out_q, out_s, num_tokens, d, as_stream(stream))
+                                 : launch_silu<SGL_MI355_FP16>(x, nullptr, out_q, out_s, num_tokens, d, as_stream(stream));
+}
+
+extern "C" int sgl_mi355_rotary_embedding(
+    const int64_t* positions, void* query, void* key, const float* cos_sin_cache, int64_t num_tokens,
+    int64_t num_q_heads, int64_t num_k_heads, int64_t head_size, int64_t rot_dim, int64_t q_stride_t,
+    int64_t k_stride_t, int is_neox, int dtype, void* stream) {
+  SGLM_CHECK_ARG(dtype == SGL_MI355_BF16 || dtype == SGL_MI355_FP16, "rotary_embedding: bad dtype %d", dtype);
+  SGLM_CHECK_ARG(rot_dim > 0 && rot_dim % 2 == 0 && rot_dim <= head_size, "rotary_embedding: bad rot_dim %ld", (long)rot_dim);
+  SGLM_CHECK_ARG(num_tokens >= 0 && num_q_heads >= 0 && num_k_heads >= 0, "rotary_embedding: bad sizes");
+  if (num_tokens == 0 || num_q_heads + num_k_heads == 0) return 0;
+  SGLM_CHECK_ARG(positions && cos_sin_cache && (query || num_q_heads == 0) && (key || num_k_heads == 0),
+                 "rotary_embedding: null tensor pointer");
+  const int64_t total = num_tokens * (num_q_heads + num_k_heads) * (rot_dim / 2);
+  const unsigned grid = (unsigned)((total + 255) / 256 < 65535 * 16 ? (total + 255) / 256 : 65535 * 16);
+  hipStream_t s = as_stream(stream);
+  if (dtype == SGL_MI355_BF16)
+    hipLaunchKernelGGL((rope_kernel<SGL_MI355_BF16>), dim3(grid), dim3(256), 0, s, (__bf16*)query, (__bf16*)key, positions,
+                       cos_sin_cache, num_tokens, (int)num_q_heads, (int)num_k_heads, (int)head_size, (int)rot_dim,
+                       q_stride_t, k_stride_t, is_neox);
+  else
+    hipLaunchKernelGGL((rope_kernel<SGL_MI355_FP16>), dim3(grid), dim3(256), 0, s, (_Float16*)query, (_Float16*)key,
+                       positions, cos_sin_cache, num_tokens, (int)num_q_heads, (int)num_k_heads, (int)head_size,
+                       (int)rot_dim, q_stride_t, k_stride_t, is_neox);
+  return check_hip(hipGetLastError(), "rotary_embedding launch");
+}

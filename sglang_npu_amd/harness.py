@@ -1,0 +1,208 @@
+"""Minimal host-side stand-ins for the SGLang objects the hot path talks to.
+
+The real server (scheduler, radix cache, model runner) stays SGLang's untouched Python and is
+out of scope.  To run the drop-in backend on the GPU box without any reference file
+we need objects with the same *fields* the backends read; these classes provide exactly those
+fields and nothing else.  Names and semantics follow the reference:
+
+  ForwardMode / ForwardBatch  python/sglang/srt/model_executor/forward_batch_info.py:68-300
+  ReqToTokenPool              python/sglang/srt/mem_cache/memory_pool.py:47-110
+  MHATokenToKVPool            python/sglang/srt/mem_cache/memory_pool.py:162-407
+  RadixAttention              python/sglang/srt/layers/radix_attention.py:44-110
+  ModelRunner fields          as read by triton_backend.py:62-122
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from enum import IntEnum, auto
+from typing import Any, List, Optional
+
+import torch
+
+from . import ops
+
+
+class ForwardMode(IntEnum):
+    EXTEND = auto()
+    DECODE = auto()
+    MIXED = auto()
+    IDLE = auto()
+    TARGET_VERIFY = auto()
+    DRAFT_EXTEND = auto()
+
+    def is_prefill(self):
+        return self.is_extend()
+
+    def is_extend(self):
+        return self in (ForwardMode.EXTEND, ForwardMode.MIXED, ForwardMode.DRAFT_EXTEND, ForwardMode.TARGET_VERIFY)
+
+    def is_decode(self):
+        return self == ForwardMode.DECODE
+
+    def is_mixed(self):
+        return self == ForwardMode.MIXED
+
+    def is_idle(self):
+        return self == ForwardMode.IDLE
+
+    def is_decode_or_idle(self):
+        return self in (ForwardMode.DECODE, ForwardMode.IDLE)
+
+    def is_target_verify(self):
+        return self == ForwardMode.TARGET_VERIFY
+
+    def is_draft_extend(self):
+        return self == ForwardMode.DRAFT_EXTEND
+
+
+class AttentionType:
+    DECODER = "decoder"
+    ENCODER_ONLY = "encoder_only"
+
+
+class ReqToTokenPool:
+    """req_to_token[int32 R x Lmax]: row r holds the KV-pool slot of every token of request r."""
+
+    def __init__(self, size: int, max_context_len: int, device: str):
+        self.size = size
+        self.max_context_len = max_context_len
+        self.device = device
+        self.req_to_token = torch.zeros((size, max_context_len), dtype=torch.int32, device=device)
+
+
+class MHATokenToKVPool:
+    """Per-layer K/V pools [size + page_size, Hkv, D]; slot 0 is the padding slot
+    (memory_pool.py:222-241)."""
+
+    def __init__(self, size: int, page_size: int, dtype: torch.dtype, head_num: int, head_dim: int, layer_num: int,
+                 device: str, v_head_dim: Optional[int] = None):
+        self.size, self.page_size, self.dtype = size, page_size, dtype
+        self.head_num, self.head_dim, self.layer_num, self.device = head_num, head_dim, layer_num, device
+        self.v_head_dim = v_head_dim or head_dim
+        self.k_buffer = [torch.zeros((size + page_size, head_num, head_dim), dtype=dtype, device=device)
+                         for _ in range(layer_num)]
+        self.v_buffer = [torch.zeros((size + page_size, head_num, self.v_head_dim), dtype=dtype, device=device)
+                         for _ in range(layer_num)]
+
+    def get_key_buffer(self, layer_id: int):
+        return self.k_buffer[layer_id]
+
+    def get_value_buffer(self, layer_id: int):
+        return self.v_buffer[layer_id]
+
+    def get_kv_buffer(self, layer_id: int):
+        return self.k_buffer[layer_id], self.v_buffer[layer_id]
+
+    def set_kv_buffer(self, layer, loc: torch.Tensor, cache_k: torch.Tensor, cache_v: torch.Tensor,
+                      k_scale=None, v_scale=None):
+        """k_buffer[layer][loc] = cache_k (memory_pool.py:369-407) -- done by the HIP copy kernel."""
+        lid = layer.layer_id
+        ops.set_kv_buffer(self.k_buffer[lid], self.v_buffer[lid], loc,
+                          cache_k.view(-1, self.head_num, self.head_dim),
+                          cache_v.view(-1, self.head_num, self.v_head_dim))
+
+
+@dataclass
+class ForwardBatch:
+    forward_mode: ForwardMode
+    batch_size: int
+    input_ids: torch.Tensor
+    req_pool_indices: torch.Tensor
+    seq_lens: torch.Tensor
+    out_cache_loc: torch.Tensor
+    seq_lens_sum: int
+    seq_lens_cpu: Optional[torch.Tensor] = None
+    positions: Optional[torch.Tensor] = None
+    extend_num_tokens: Optional[int] = None
+    extend_seq_lens: Optional[torch.Tensor] = None
+    extend_prefix_lens: Optional[torch.Tensor] = None
+    extend_start_loc: Optional[torch.Tensor] = None
+    extend_prefix_lens_cpu: Optional[List[int]] = None
+    extend_seq_lens_cpu: Optional[List[int]] = None
+    req_to_token_pool: Optional[ReqToTokenPool] = None
+    token_to_kv_pool: Optional[MHATokenToKVPool] = None
+    attn_backend: Any = None
+    spec_info: Any = None
+    encoder_lens: Optional[torch.Tensor] = None
+
+
+class RadixAttention(torch.nn.Module):
+    """The attention layer every model holds (radix_attention.py:44-110): views q/k/v and delegates
+    to forward_batch.attn_backend.forward."""
+
+    def __init__(self, num_heads: int, head_dim: int, scaling: float, num_kv_heads: int, layer_id: int,
+                 logit_cap: float = 0.0, v_head_dim: int = -1, sliding_window_size: int = -1,
+                 attn_type: str = AttentionType.DECODER):
+        super().__init__()
+        self.tp_q_head_num = num_heads
+        self.tp_k_head_num = num_kv_heads
+        self.tp_v_head_num = num_kv_heads
+        self.head_dim = head_dim
+        self.qk_head_dim = head_dim
+        self.v_head_dim = v_head_dim if v_head_dim != -1 else head_dim
+        self.scaling = scaling
+        self.layer_id = layer_id
+        self.logit_cap = logit_cap
+        self.sliding_window_size = sliding_window_size or -1
+        self.attn_type = attn_type
+        self.k_scale = None
+        self.v_scale = None
+
+    def forward(self, q, k, v, forward_batch: ForwardBatch, save_kv_cache: bool = True, **kwargs):
+        if k is not None:
+            assert v is not None
+            k = k.view(-1, self.tp_k_head_num, self.qk_head_dim)
+            v = v.view(-1, self.tp_v_head_num, self.v_head_dim)
+        return forward_batch.attn_backend.forward(q, k, v, self, forward_batch, save_kv_cache, **kwargs)
+
+
+@dataclass
+class ModelConfig:
+    num_attention_heads: int
+    num_key_value_heads: int
+    head_dim: int
+    hidden_size: int
+    intermediate_size: int
+    num_hidden_layers: int
+    vocab_size: int
+    context_len: int
+    rms_norm_eps: float = 1e-5
+    rope_theta: float = 500000.0
+    is_encoder_decoder: bool = False
+
+    def get_num_kv_heads(self, tp_size: int) -> int:
+        # replicated when there are fewer KV heads than ranks (model_config.py get_num_kv_heads)
+        return max(1, self.num_key_value_heads // tp_size)
+
+
+@dataclass
+class ServerArgs:
+    page_size: int = 1
+    triton_attention_num_kv_splits: int = 8
+    speculative_num_draft_tokens: int = 0
+    speculative_num_steps: int = 0
+    attention_backend: str = "mi355"
+
+
+@dataclass
+class ModelRunnerLike:
+    """The fields of ModelRunner an attention backend reads (triton_backend.py:62-122)."""
+    model_config: ModelConfig
+    req_to_token_pool: ReqToTokenPool
+    token_to_kv_pool: MHATokenToKVPool
+    device: str
+    gpu_id: int = 0
+    tp_size: int = 1
+    server_args: ServerArgs = field(default_factory=ServerArgs)
+    sliding_window_size: Optional[int] = None
+    attn_backend: Any = None
+
+
+def install_attention_backend(model_runner, backend_cls=None):
+    """The registration shim (the reference has no plugin registry; the only dynamic
+    hook is that `forward_batch.attn_backend` is whatever `model_runner.attn_backend` holds).
+    Works on a live SGLang ModelRunner as well as on ModelRunnerLike."""
+    if backend_cls is None:
+        from .attention_backend import MI355AttnBackend as backend_cls
+    model_runner.attn_backend = backend_cls(model_runner)
+    return model_runner.attn_backend

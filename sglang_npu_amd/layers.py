@@ -1,0 +1,60 @@
+"""Elementwise layers around the hot path, same class names / forward signatures as the reference.
+
+  RMSNorm          python/sglang/srt/layers/layernorm.py:59-172   (forward(x, residual=None))
+  SiluAndMul       python/sglang/srt/layers/activation.py:59-83
+  RotaryEmbedding  python/sglang/srt/layers/rotary_embedding.py:79-260 (fp32 cos/sin cache, neox)
+  Sampler (greedy) python/sglang/srt/layers/sampler.py:72-75       (torch.argmax -- plumbing)
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple, Union
+
+import torch
+
+from . import ops
+
+
+class RMSNorm(torch.nn.Module):
+    def __init__(self, hidden_size: int, eps: float = 1e-6, dtype=torch.bfloat16):
+        super().__init__()
+        self.weight = torch.nn.Parameter(torch.ones(hidden_size, dtype=dtype), requires_grad=False)
+        self.variance_epsilon = eps
+        self.hidden_size = hidden_size
+
+    def forward(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None
+                ) -> Union[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]]:
+        if residual is not None:
+            ops.fused_add_rmsnorm(x, residual, self.weight.data, self.variance_epsilon)
+            return x, residual
+        return ops.rmsnorm(x, self.weight.data, self.variance_epsilon)
+
+    def forward_quant_fp8(self, x, residual=None):
+        """Fused (add +) norm + per-token FP8 quant; returns ((q, scale), residual)."""
+        q, s, _ = ops.rmsnorm_quant_fp8(x, self.weight.data, self.variance_epsilon, residual=residual)
+        return (q, s), (residual if residual is not None else None)
+
+
+class SiluAndMul(torch.nn.Module):
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return ops.silu_and_mul(x)
+
+
+class RotaryEmbedding(torch.nn.Module):
+    def __init__(self, head_size: int, rotary_dim: int, max_position_embeddings: int, base: float,
+                 is_neox_style: bool = True, dtype=torch.bfloat16, device=None):
+        super().__init__()
+        self.head_size, self.rotary_dim, self.is_neox_style = head_size, rotary_dim, is_neox_style
+        inv_freq = 1.0 / (base ** (torch.arange(0, rotary_dim, 2, dtype=torch.float) / rotary_dim))
+        t = torch.arange(max_position_embeddings, dtype=torch.float)
+        freqs = torch.einsum("i,j -> ij", t, inv_freq)
+        cache = torch.cat((freqs.cos(), freqs.sin()), dim=-1)  # kept in fp32 (rotary_embedding.py:98-100)
+        self.register_buffer("cos_sin_cache", cache.to(device) if device is not None else cache, persistent=False)
+
+    def forward(self, positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor):
+        ops.apply_rope_with_cos_sin_cache_inplace(positions, query, key, self.head_size, self.cos_sin_cache,
+                                                  self.is_neox_style)
+        return query, key
+
+
+def greedy_sample(logits: torch.Tensor) -> torch.Tensor:
+    return torch.argmax(logits, dim=-1)

@@ -1,0 +1,217 @@
+"""Synthetic-weight Llama/Qwen2-shaped decoder stack wired to the MI355X backend.
+
+Only used by bench.py / tests / smoke: SGLang's own model files stay untouched.  The
+module tree and the per-layer call order follow the reference so the hot path is exercised exactly
+where it sits there:
+  LlamaMLP.forward             python/sglang/srt/models/llama.py:94-98
+  LlamaAttention.forward       python/sglang/srt/models/llama.py:186-191
+  LlamaDecoderLayer.forward    python/sglang/srt/models/llama.py:245-268
+  LlamaModel / ForCausalLM     python/sglang/srt/models/llama.py:330ff
+Weights: the dummy loader's recipe (model_loader/weight_utils.py:752-781): every float parameter
+~ U(-1e-3, 1e-3) from a generator seeded 1234 per parameter (drawn at FULL size, then TP-sliced, so
+shards are consistent across ranks); FP8 weights are then per-channel quantised like
+w8a8_fp8.py:119-125; AWQ tensors follow sgl-kernel/tests/test_awq_dequant.py:80-102.
+
+With ``fuse_quant=True`` (FP8 only) the layer uses the backend's fused norm+quant / silu+quant
+kernels so each GEMM input is produced directly in FP8 -- same arithmetic as the unfused sequence.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import ops
+from .distributed import get_tensor_model_parallel_rank, get_tensor_model_parallel_world_size, get_tp_group
+from .harness import ForwardBatch, ModelConfig, RadixAttention
+from .layers import RMSNorm, RotaryEmbedding, SiluAndMul
+from .linear import MergedColumnParallelLinear, QKVParallelLinear, RowParallelLinear
+from .quantization import AWQConfig, W8A8Fp8Config
+
+
+def _dummy(shape, dtype, device, low=-1e-3, high=1e-3, seed=1234):
+    """initialize_dummy_weights: values depend only on numel + dtype (weight_utils.py:752-781)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    t = torch.empty(shape, dtype=torch.float16 if dtype in (torch.bfloat16, torch.float16) else torch.float32,
+                    device=device)
+    t.uniform_(low, high, generator=g)
+    return t.to(dtype)
+
+
+class LlamaMLP(torch.nn.Module):
+    def __init__(self, hidden_size, intermediate_size, quant_config, dtype):
+        super().__init__()
+        self.gate_up_proj = MergedColumnParallelLinear(hidden_size, [intermediate_size] * 2, params_dtype=dtype,
+                                                       quant_config=quant_config)
+        self.down_proj = RowParallelLinear(intermediate_size, hidden_size, params_dtype=dtype, quant_config=quant_config)
+        self.act_fn = SiluAndMul()
+
+    def forward(self, x):
+        gate_up, _ = self.gate_up_proj(x)
+        x = self.act_fn(gate_up)
+        x, _ = self.down_proj(x)
+        return x
+
+
+class LlamaAttention(torch.nn.Module):
+    def __init__(self, cfg: ModelConfig, layer_id: int, quant_config, dtype, device):
+        super().__init__()
+        tp = get_tensor_model_parallel_world_size()
+        self.total_num_heads, self.total_num_kv_heads = cfg.num_attention_heads, cfg.num_key_value_heads
+        self.num_heads = self.total_num_heads // tp
+        self.num_kv_heads = max(1, self.total_num_kv_heads // tp)
+        self.head_dim = cfg.head_dim
+        self.q_size, self.kv_size = self.num_heads * self.head_dim, self.num_kv_heads * self.head_dim
+        self.scaling = self.head_dim ** -0.5
+        self.qkv_proj = QKVParallelLinear(cfg.hidden_size, self.head_dim, self.total_num_heads, self.total_num_kv_heads,
+                                          params_dtype=dtype, quant_config=quant_config)
+        self.o_proj = RowParallelLinear(self.total_num_heads * self.head_dim, cfg.hidden_size, params_dtype=dtype,
+                                        quant_config=quant_config)
+        self.rotary_emb = RotaryEmbedding(self.head_dim, self.head_dim, cfg.context_len, cfg.rope_theta, True, dtype,
+                                          device)
+        self.attn = RadixAttention(self.num_heads, self.head_dim, self.scaling, self.num_kv_heads, layer_id)
+
+    def forward(self, positions, hidden_states, forward_batch: ForwardBatch):
+        qkv, _ = self.qkv_proj(hidden_states)
+        q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
+        q, k = self.rotary_emb(positions, q, k)
+        attn_output = self.attn(q, k, v, forward_batch)
+        output, _ = self.o_proj(attn_output)
+        return output
+
+
+class LlamaDecoderLayer(torch.nn.Module):
+    def __init__(self, cfg: ModelConfig, layer_id: int, quant_config, dtype, device):
+        super().__init__()
+        self.self_attn = LlamaAttention(cfg, layer_id, quant_config, dtype, device)
+        self.mlp = LlamaMLP(cfg.hidden_size, cfg.intermediate_size, quant_config, dtype)
+        self.input_layernorm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps, dtype)
+        self.post_attention_layernorm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps, dtype)
+
+    def forward(self, positions, hidden_states, forward_batch, residual):
+        if residual is None:
+            residual = hidden_states
+            hidden_states = self.input_layernorm(hidden_states)
+        else:
+            hidden_states, residual = self.input_layernorm(hidden_states, residual)
+        hidden_states = self.self_attn(positions, hidden_states, forward_batch)
+        hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
+        hidden_states = self.mlp(hidden_states)
+        return hidden_states, residual
+
+
+class LlamaForCausalLM(torch.nn.Module):
+    def __init__(self, cfg: ModelConfig, quantization: Optional[str] = None, dtype=torch.bfloat16, device="cuda:0",
+                 num_layers: Optional[int] = None, with_lm_head: bool = True):
+        super().__init__()
+        self.cfg, self.dtype, self.device_str = cfg, dtype, device
+        self.quant_config = None
+        if quantization == "w8a8_fp8":
+            self.quant_config = W8A8Fp8Config(is_checkpoint_fp8_serialized=False)
+        elif quantization == "awq":
+            self.quant_config = AWQConfig(4, 128, True)
+        elif quantization is not None:
+            raise ValueError(f"unknown quantization {quantization}")
+        tp = get_tensor_model_parallel_world_size()
+        self.vocab_per_rank = cfg.vocab_size // tp
+        n_layers = num_layers if num_layers is not None else cfg.num_hidden_layers
+        with torch.device(device):
+            self.layers = torch.nn.ModuleList(
+                [LlamaDecoderLayer(cfg, i, self.quant_config, dtype, device) for i in range(n_layers)])
+            self.norm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps, dtype)
+        self.embed_tokens = None
+        self.lm_head = None
+        self.with_lm_head = with_lm_head
+
+    # ------------------------------------------------------------------ synthetic weights
+    @torch.no_grad()
+    def load_dummy_weights(self):
+        dev, dt, cfg = self.device_str, self.dtype, self.cfg
+        tp, rank = get_tensor_model_parallel_world_size(), get_tensor_model_parallel_rank()
+
+        def shard_rows(full, sizes_full):
+            # column-parallel: each logical sub-matrix is sliced by rows (output features)
+            outs, off = [], 0
+            for s in sizes_full:
+                per = s // tp
+                outs.append(full[off + rank * per: off + (rank + 1) * per])
+                off += s
+            return torch.cat(outs, 0)
+
+        for layer in self.layers:
+            at, mlp = layer.self_attn, layer.mlp
+            kv_rep = max(1, tp // cfg.num_key_value_heads)
+            qkv_sizes = [cfg.num_attention_heads * cfg.head_dim, cfg.num_key_value_heads * cfg.head_dim,
+                         cfg.num_key_value_heads * cfg.head_dim]
+            specs = [
+                (at.qkv_proj, sum(qkv_sizes), cfg.hidden_size, "col", qkv_sizes),
+                (at.o_proj, cfg.hidden_size, cfg.num_attention_heads * cfg.head_dim, "row", None),
+                (mlp.gate_up_proj, 2 * cfg.intermediate_size, cfg.hidden_size, "col", [cfg.intermediate_size] * 2),
+                (mlp.down_proj, cfg.hidden_size, cfg.intermediate_size, "row", None),
+            ]
+            for lin, n_full, k_full, kind, sizes in specs:
+                if isinstance(self.quant_config, AWQConfig):
+                    self._fill_awq(lin)
+                    continue
+                w = _dummy((n_full, k_full), dt, dev)
+                if kind == "col":
+                    if lin is at.qkv_proj and kv_rep > 1:
+                        # replicate KV heads when tp > num_kv_heads (linear.py QKVParallelLinear)
+                        q, k, v = w.split(sizes, 0)
+                        hd = cfg.head_dim
+                        q = q[rank * at.q_size:(rank + 1) * at.q_size]
+                        kvh = rank // kv_rep
+                        w = torch.cat([q, k[kvh * hd:(kvh + 1) * hd], v[kvh * hd:(kvh + 1) * hd]], 0)
+                    else:
+                        w = shard_rows(w, sizes)
+                else:
+                    per = k_full // tp
+                    w = w[:, rank * per:(rank + 1) * per]
+                lin.weight.data = w.contiguous().to(lin.weight.dtype)
+                lin.quant_method.process_weights_after_loading(lin)
+            layer.input_layernorm.weight.data = _dummy((cfg.hidden_size,), dt, dev, 0.5, 1.5)
+            layer.post_attention_layernorm.weight.data = _dummy((cfg.hidden_size,), dt, dev, 0.5, 1.5, seed=4321)
+        self.norm.weight.data = _dummy((cfg.hidden_size,), dt, dev, 0.5, 1.5)
+        self.embed_tokens = _dummy((cfg.vocab_size, cfg.hidden_size), dt, dev, -1.0, 1.0, seed=99)
+        if self.with_lm_head:
+            full = _dummy((cfg.vocab_size, cfg.hidden_size), dt, dev, -2e-2, 2e-2, seed=77)
+            self.lm_head = full[rank * self.vocab_per_rank:(rank + 1) * self.vocab_per_rank].contiguous()
+        return self
+
+    def _fill_awq(self, lin):
+        g = torch.Generator(device=self.device_str)
+        g.manual_seed(1234)
+        imax = torch.iinfo(torch.int32).max
+        lin.qweight.data = torch.randint(0, imax, lin.qweight.shape, dtype=torch.int32, device=self.device_str, generator=g)
+        lin.qzeros.data = torch.randint(0, imax, lin.qzeros.shape, dtype=torch.int32, device=self.device_str, generator=g)
+        lin.scales.data = (torch.rand(lin.scales.shape, device=self.device_str, generator=g) * 2e-3).to(lin.scales.dtype)
+        lin.quant_method.process_weights_after_loading(lin)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, input_ids, positions, forward_batch: ForwardBatch):
+        hidden_states = self.embed_tokens[input_ids]
+        residual = None
+        for layer in self.layers:
+            hidden_states, residual = layer(positions, hidden_states, forward_batch, residual)
+        hidden_states, _ = self.norm(hidden_states, residual)
+        if not self.with_lm_head:
+            return hidden_states
+        logits = torch.matmul(hidden_states, self.lm_head.t())  # plain library GEMM (LM head)
+        if get_tensor_model_parallel_world_size() > 1:
+            logits = get_tp_group().all_gather(logits, dim=-1)
+        return logits
+
+
+LLAMA3_8B = ModelConfig(num_attention_heads=32, num_key_value_heads=8, head_dim=128, hidden_size=4096,
+                        intermediate_size=14336, num_hidden_layers=32, vocab_size=128256, context_len=8192,
+                        rms_norm_eps=1e-5, rope_theta=500000.0)
+LLAMA3_70B = ModelConfig(num_attention_heads=64, num_key_value_heads=8, head_dim=128, hidden_size=8192,
+                         intermediate_size=28672, num_hidden_layers=80, vocab_size=128256, context_len=8192,
+                         rms_norm_eps=1e-5, rope_theta=500000.0)
+LLAMA2_7B = ModelConfig(num_attention_heads=32, num_key_value_heads=32, head_dim=128, hidden_size=4096,
+                        intermediate_size=11008, num_hidden_layers=32, vocab_size=32000, context_len=4096,
+                        rms_norm_eps=1e-5, rope_theta=10000.0)
+QWEN2_05B = ModelConfig(num_attention_heads=14, num_key_value_heads=2, head_dim=64, hidden_size=896,
+                        intermediate_size=4864, num_hidden_layers=24, vocab_size=151936, context_len=32768,
+                        rms_norm_eps=1e-6, rope_theta=1000000.0)

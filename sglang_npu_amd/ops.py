@@ -133,6 +133,38 @@ def decode_attention(query, k_cache, v_cache, output, key, value, loc, attn_logi
         _F(sm_scale), _F(logit_cap), _I(_dtype_code(query)), _stream(query)))
 
 
+def decode_attention_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens, attn_logits,
+                           num_kv_splits, sm_scale, logit_cap=0.0):
+    """Decode straight from the request page table (no flattened kv_indices, no KV write): the form
+    MI355AttnBackend.forward_decode uses.  Same C entry point as decode_attention
+    (sgl_mi355_decode_attention with loc = NULL).  attn_logits: fp32 [B, Hq, num_kv_splits, Dv+1]
+    scratch, or None when num_kv_splits == 1."""
+    _need_gpu(q, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens)
+    if req_pool_indices.dtype != torch.int64 or seq_lens.dtype != torch.int64:
+        raise RuntimeError("decode_attention_paged: req_pool_indices and seq_lens must be int64")
+    for name, t in (("q", q), ("k_buffer", k_buffer), ("v_buffer", v_buffer), ("o", o)):
+        if t.dim() != 3 or t.stride(-1) != 1:
+            raise RuntimeError(f"decode_attention_paged: {name} must be 3-D, contiguous at the last dimension")
+    B, Hq, D = q.shape
+    Dv = v_buffer.size(2)
+    if num_kv_splits > 1:
+        if attn_logits is None or attn_logits.dtype != torch.float32 or not attn_logits.is_contiguous() or \
+                attn_logits.numel() < B * Hq * num_kv_splits * (Dv + 1):
+            raise RuntimeError("decode_attention_paged: attn_logits must be contiguous float32 "
+                               "[B, Hq, num_kv_splits, Dv+1]")
+    if req_to_token.dim() != 2 or req_to_token.stride(1) != 1 or req_to_token.stride(0) != req_to_token.size(1):
+        raise RuntimeError("decode_attention_paged: req_to_token must be a contiguous 2-D tensor")
+    _lib.check(_lib.lib().sgl_mi355_decode_attention(
+        _ptr(q), _ptr(k_buffer), _ptr(v_buffer), _ptr(o), None, None, None,
+        _ptr(attn_logits), _ptr(req_to_token), _I(_is64(req_to_token, "req_to_token")),
+        _ptr(req_pool_indices), _ptr(seq_lens),
+        _I64(B), _I64(req_to_token.size(1)), _I64(Hq), _I64(k_buffer.size(1)), _I64(D), _I64(Dv), _I64(num_kv_splits),
+        _I64(q.stride(0)), _I64(q.stride(1)), _I64(k_buffer.stride(0)), _I64(k_buffer.stride(1)),
+        _I64(v_buffer.stride(0)), _I64(v_buffer.stride(1)), _I64(0), _I64(0), _I64(0), _I64(0),
+        _I64(o.stride(0)), _I64(o.stride(1)),
+        _F(sm_scale), _F(logit_cap), _I(_dtype_code(q)), _stream(q)))
+
+
 def decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_logits, attn_lse, num_kv_splits,
                          max_kv_splits, sm_scale, logit_cap=0.0):
     """decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_logits, attn_lse,
@@ -209,3 +241,84 @@ def fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None) -> tor
         _I64(M), _I64(N), _I64(K), _I64(mat_a.stride(0) if M > 1 else K), _I64(b_stride_n),
         _I(0 if out_dtype == torch.bfloat16 else 1), _stream(mat_a)))
     return out
+
+
+# --------------------------------------------------------------------------- elementwise ("next" rows)
+def _rows(x):
+    if x.dim() < 1 or not x.is_contiguous():
+        raise RuntimeError("expected a contiguous tensor")
+    return x.numel() // x.size(-1), x.size(-1)
+
+
+def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """sgl_kernel.rmsnorm(x, weight, eps) (layernorm.py:86-88)."""
+    _need_gpu(x, weight)
+    T, H = _rows(x)
+    out = torch.empty_like(x) if out is None else out
+    _lib.check(_lib.lib().sgl_mi355_rmsnorm(_ptr(out), _ptr(x), _ptr(weight), _I64(T), _I64(H), _F(eps),
+                                            _I(_dtype_code(x)), _stream(x)))
+    return out
+
+
+def fused_add_rmsnorm(x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float) -> None:
+    """sgl_kernel.fused_add_rmsnorm(x, residual, weight, eps): in place (layernorm.py:82-85)."""
+    _need_gpu(x, residual, weight)
+    T, H = _rows(x)
+    if residual.shape != x.shape or not residual.is_contiguous():
+        raise RuntimeError("fused_add_rmsnorm: residual must match x and be contiguous")
+    _lib.check(_lib.lib().sgl_mi355_fused_add_rmsnorm(_ptr(x), _ptr(residual), _ptr(weight), _I64(T), _I64(H),
+                                                      _F(eps), _I(_dtype_code(x)), _stream(x)))
+
+
+def rmsnorm_quant_fp8(x, weight, eps, residual=None, want_out: bool = False):
+    """(add +) RMSNorm + per-token FP8 quant in one pass.  Returns (q [T,H] e4m3fn, scale [T,1] f32, out|None)."""
+    _need_gpu(x, weight, residual)
+    T, H = _rows(x)
+    q = torch.empty(x.shape, dtype=torch.float8_e4m3fn, device=x.device)
+    s = torch.empty((T, 1), dtype=torch.float32, device=x.device)
+    out = torch.empty_like(x) if want_out else None
+    _lib.check(_lib.lib().sgl_mi355_rmsnorm_quant_fp8(_ptr(q), _ptr(s), _ptr(out), _ptr(x), _ptr(residual),
+                                                      _ptr(weight), _I64(T), _I64(H), _F(eps),
+                                                      _I(_dtype_code(x)), _stream(x)))
+    return q, s, out
+
+
+def silu_and_mul(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """sgl_kernel.silu_and_mul(x, out) (activation.py:64-69)."""
+    _need_gpu(x)
+    T, H2 = _rows(x)
+    d = H2 // 2
+    out = torch.empty(x.shape[:-1] + (d,), dtype=x.dtype, device=x.device) if out is None else out
+    _lib.check(_lib.lib().sgl_mi355_silu_and_mul(_ptr(out), _ptr(x), _I64(T), _I64(d), _I(_dtype_code(x)),
+                                                 _stream(x)))
+    return out
+
+
+def silu_and_mul_quant_fp8(x: torch.Tensor):
+    """SiLU*mul + per-token FP8 quant in one pass.  Returns (q [T,d] e4m3fn, scale [T,1] f32)."""
+    _need_gpu(x)
+    T, H2 = _rows(x)
+    d = H2 // 2
+    q = torch.empty(x.shape[:-1] + (d,), dtype=torch.float8_e4m3fn, device=x.device)
+    s = torch.empty((T, 1), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().sgl_mi355_silu_and_mul_quant_fp8(_ptr(q), _ptr(s), _ptr(x), _I64(T), _I64(d),
+                                                           _I(_dtype_code(x)), _stream(x)))
+    return q, s
+
+
+def apply_rope_with_cos_sin_cache_inplace(positions, query, key, head_size, cos_sin_cache, is_neox=True):
+    """sgl_kernel.apply_rope_with_cos_sin_cache_inplace(positions, query, key, head_size, cos_sin_cache, is_neox)
+    (rotary_embedding.py:236-247).  query [T, Hq*D], key [T, Hk*D], rows may be strided views."""
+    _need_gpu(positions, query, key, cos_sin_cache)
+    if cos_sin_cache.dtype != torch.float32 or not cos_sin_cache.is_contiguous():
+        raise RuntimeError("cos_sin_cache should be float32")  # same check as the reference wrapper
+    if positions.dtype != torch.int64:
+        positions = positions.to(torch.int64)
+    if query.stride(-1) != 1 or key.stride(-1) != 1:
+        raise RuntimeError("query/key must be contiguous at the last dimension")
+    T = positions.numel()
+    _lib.check(_lib.lib().sgl_mi355_rotary_embedding(
+        _ptr(positions), _ptr(query), _ptr(key), _ptr(cos_sin_cache), _I64(T),
+        _I64(query.size(-1) // head_size), _I64(key.size(-1) // head_size), _I64(head_size),
+        _I64(cos_sin_cache.size(1)), _I64(query.stride(0)), _I64(key.stride(0)), _I(1 if is_neox else 0),
+        _I(_dtype_code(query)), _stream(query)))

@@ -1,0 +1,267 @@
+"""Quant-linear methods of the MI355X backend -- the drop-in behind SGLang's quant-linear operator API.
+
+Interface mirrored (same method names / argument meaning):
+  QuantizationConfig / LinearMethodBase   python/sglang/srt/layers/quantization/base_config.py:15-80,113-203
+  W8A8Fp8Config / W8A8Fp8LinearMethod      python/sglang/srt/layers/quantization/w8a8_fp8.py:34-189
+  apply_fp8_linear                          python/sglang/srt/layers/quantization/fp8_utils.py:510-533,653-704
+  AWQConfig / AWQLinearMethod               python/sglang/srt/layers/quantization/awq.py:75-150,319-418
+  QUANTIZATION_METHODS registry             python/sglang/srt/layers/quantization/__init__.py:74-121
+
+``create_weights`` registers the same attributes on the layer (``weight``, ``weight_scale`` /
+``qweight``, ``qzeros``, ``scales``) with the same shapes and dtypes, so a checkpoint loader written
+for the reference fills them unchanged; ``process_weights_after_loading`` stores ``weight.t()``
+(K-major [K,N] view) exactly like w8a8_fp8.py:115,132; ``apply`` runs the HIP kernels.  gfx950 uses
+OCP e4m3fn (is_fp8_fnuz() is False there), so no fnuz normalisation step exists here.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional
+
+import torch
+
+from . import ops
+
+
+class QuantizeMethodBase:
+    def create_weights(self, layer: torch.nn.Module, *weight_args, **extra_weight_attrs):
+        raise NotImplementedError()
+
+    def apply(self, layer: torch.nn.Module, *args, **kwargs) -> torch.Tensor:
+        raise NotImplementedError()
+
+    def process_weights_after_loading(self, layer: torch.nn.Module) -> None:
+        return
+
+
+class LinearMethodBase(QuantizeMethodBase):
+    def create_weights(self, layer, input_size_per_partition: int, output_partition_sizes: List[int], input_size: int,
+                       output_size: int, params_dtype: torch.dtype, **extra_weight_attrs):
+        raise NotImplementedError()
+
+    def apply(self, layer, x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+        raise NotImplementedError()
+
+
+class QuantizationConfig:
+    def get_name(self) -> str:
+        raise NotImplementedError()
+
+    def get_supported_act_dtypes(self) -> List[torch.dtype]:
+        raise NotImplementedError()
+
+    @classmethod
+    def get_min_capability(cls) -> int:
+        raise NotImplementedError()
+
+    @staticmethod
+    def get_config_filenames() -> List[str]:
+        raise NotImplementedError()
+
+    @classmethod
+    def from_config(cls, config: Dict[str, Any]) -> "QuantizationConfig":
+        raise NotImplementedError()
+
+    def get_quant_method(self, layer: torch.nn.Module, prefix: str) -> Optional[QuantizeMethodBase]:
+        raise NotImplementedError()
+
+    def get_scaled_act_names(self) -> List[str]:
+        return []
+
+
+# ----------------------------------------------------------------------------- unquantised
+class UnquantizedLinearMethod(LinearMethodBase):
+    """layers/quantization/unquant.py: F.linear.  Plain library GEMM (hipBLASLt through torch) -- the
+    bf16 plumbing config only; not part of the hand-written hot path."""
+
+    def create_weights(self, layer, input_size_per_partition, output_partition_sizes, input_size, output_size,
+                       params_dtype, **extra_weight_attrs):
+        w = torch.nn.Parameter(torch.empty(sum(output_partition_sizes), input_size_per_partition, dtype=params_dtype),
+                               requires_grad=False)
+        layer.register_parameter("weight", w)
+
+    def apply(self, layer, x, bias=None):
+        return torch.nn.functional.linear(x, layer.weight, bias)
+
+
+# ----------------------------------------------------------------------------- FP8 w8a8
+def apply_fp8_linear(input: torch.Tensor, weight: torch.Tensor, weight_scale: torch.Tensor,
+                     input_scale: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp8_utils.py:653-704 (the cutlass branch): dynamic per-token activation quant, then
+    fp8_scaled_mm(qinput, weight, x_scale, weight_scale, out_dtype=input.dtype, bias)."""
+    if input_scale is not None:
+        raise NotImplementedError("static activation scales (per-tensor) are not part of this path")
+    input_2d = input.view(-1, input.shape[-1])
+    output_shape = [*input.shape[:-1], weight.shape[1]]
+    qinput = torch.empty_like(input_2d, dtype=torch.float8_e4m3fn)
+    x_scale = torch.empty((input_2d.shape[0], 1), dtype=torch.float32, device=input.device)
+    ops.sgl_per_token_quant_fp8(input_2d.contiguous(), qinput, x_scale)
+    output = ops.fp8_scaled_mm(qinput, weight, x_scale, weight_scale, out_dtype=input.dtype, bias=bias)
+    return output.view(*output_shape)
+
+
+def per_channel_quant_fp8_weight(weight: torch.Tensor):
+    """Weight-side quantisation of an unquantised checkpoint, w8a8_fp8.py:119-125:
+    per output channel, scale = rowmax/448, q = cast(w / scale).  Load-time, off the hot path."""
+    w = weight.float()
+    amax = w.abs().amax(dim=1, keepdim=True).clamp(min=1e-12)
+    scale = amax / 448.0
+    q = (w / scale).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    return q, scale
+
+
+class W8A8Fp8Config(QuantizationConfig):
+    def __init__(self, is_checkpoint_fp8_serialized: bool = False):
+        self.is_checkpoint_fp8_serialized = is_checkpoint_fp8_serialized
+
+    def get_name(self) -> str:
+        return "w8a8_fp8"
+
+    def get_supported_act_dtypes(self):
+        return [torch.float16, torch.bfloat16]
+
+    @classmethod
+    def get_min_capability(cls) -> int:
+        return 89
+
+    @staticmethod
+    def get_config_filenames():
+        return []
+
+    @classmethod
+    def from_config(cls, config):
+        quant_method = config.get("quant_method", "") if isinstance(config, dict) else ""
+        return cls(is_checkpoint_fp8_serialized="compressed-tensors" in quant_method or "w8a8_fp8" in quant_method)
+
+    def get_quant_method(self, layer, prefix: str):
+        from .linear import LinearBase
+        if isinstance(layer, LinearBase):
+            return W8A8Fp8LinearMethod(self)
+        return None
+
+
+class W8A8Fp8LinearMethod(LinearMethodBase):
+    def __init__(self, quantization_config: W8A8Fp8Config):
+        self.quantization_config = quantization_config
+
+    def create_weights(self, layer, input_size_per_partition, output_partition_sizes, input_size, output_size,
+                       params_dtype, **extra_weight_attrs):
+        # w8a8_fp8.py:136-173: weight [N_part, K] (fp8 if the checkpoint is serialised in fp8, else
+        # params_dtype and quantised after loading), weight_scale [N_part, 1] fp32
+        weight_dtype = torch.float8_e4m3fn if self.quantization_config.is_checkpoint_fp8_serialized else params_dtype
+        n = sum(output_partition_sizes)
+        layer.register_parameter("weight", torch.nn.Parameter(
+            torch.empty(n, input_size_per_partition, dtype=weight_dtype), requires_grad=False))
+        layer.register_parameter("weight_scale", torch.nn.Parameter(
+            torch.empty((n, 1), dtype=torch.float32), requires_grad=False))
+        layer.logical_widths = output_partition_sizes
+        layer.input_scale = None
+
+    def process_weights_after_loading(self, layer) -> None:
+        # w8a8_fp8.py:113-133
+        weight = layer.weight
+        if self.quantization_config.is_checkpoint_fp8_serialized:
+            weight_scale = layer.weight_scale.detach()
+        else:
+            weight, weight_scale = per_channel_quant_fp8_weight(layer.weight)
+        layer.weight = torch.nn.Parameter(weight.t(), requires_grad=False)  # K-major [K, N] view
+        layer.weight_scale = torch.nn.Parameter(weight_scale.contiguous(), requires_grad=False)
+        layer.input_scale = None
+
+    def apply(self, layer, x: torch.Tensor, bias: Optional[torch.Tensor] = None):
+        return apply_fp8_linear(x, layer.weight, layer.weight_scale, input_scale=layer.input_scale, bias=bias)
+
+
+# ----------------------------------------------------------------------------- AWQ INT4
+class AWQConfig(QuantizationConfig):
+    """awq.py:75-150."""
+
+    def __init__(self, weight_bits: int = 4, group_size: int = 128, zero_point: bool = True):
+        if weight_bits != 4:
+            raise ValueError(f"Currently, only 4-bit weight quantization is supported for AWQ, but got {weight_bits} bits.")
+        self.weight_bits, self.group_size, self.zero_point = weight_bits, group_size, zero_point
+        self.pack_factor = 32 // weight_bits
+
+    def get_name(self) -> str:
+        return "awq"
+
+    def get_supported_act_dtypes(self):
+        # the reference is fp16-only (awq.py:111-112); the kernels here also take bf16
+        return [torch.float16, torch.bfloat16]
+
+    @classmethod
+    def get_min_capability(cls) -> int:
+        return 75
+
+    @staticmethod
+    def get_config_filenames():
+        return ["quant_config.json", "quantize_config.json"]
+
+    @classmethod
+    def from_config(cls, config):
+        def get(keys, default=None):
+            for k in keys:
+                if k in config:
+                    return config[k]
+            if default is None:
+                raise ValueError(f"Cannot find any of {keys} in the model's quantization config.")
+            return default
+        return cls(get(["w_bit", "bits"]), get(["q_group_size", "group_size"]), get(["zero_point"], True))
+
+    def get_quant_method(self, layer, prefix: str):
+        from .linear import LinearBase
+        if isinstance(layer, LinearBase):
+            return AWQLinearMethod(self)
+        return None
+
+
+class AWQLinearMethod(LinearMethodBase):
+    """awq.py:319-418."""
+
+    def __init__(self, quant_config: AWQConfig):
+        self.quant_config = quant_config
+
+    def create_weights(self, layer, input_size_per_partition, output_partition_sizes, input_size, output_size,
+                       params_dtype, **extra_weight_attrs):
+        g = self.quant_config.group_size
+        if g == -1:
+            g = input_size_per_partition
+        if input_size_per_partition % g != 0:
+            raise ValueError("The input size is not aligned with the quantized weight shape. "
+                             "This can be caused by too large tensor parallel size.")
+        n = sum(output_partition_sizes)
+        if n % self.quant_config.pack_factor != 0:
+            raise ValueError("The output size is not aligned with the quantized weight shape. "
+                             "This can be caused by too large tensor parallel size.")
+        pf = self.quant_config.pack_factor
+        layer.register_parameter("qweight", torch.nn.Parameter(
+            torch.empty(input_size_per_partition, n // pf, dtype=torch.int32), requires_grad=False))
+        layer.register_parameter("qzeros", torch.nn.Parameter(
+            torch.empty(input_size_per_partition // g, n // pf, dtype=torch.int32), requires_grad=False))
+        layer.register_parameter("scales", torch.nn.Parameter(
+            torch.empty(input_size_per_partition // g, n, dtype=params_dtype), requires_grad=False))
+
+    def process_weights_after_loading(self, layer) -> None:
+        layer.qweight = torch.nn.Parameter(layer.qweight.data, requires_grad=False)
+        layer.qzeros = torch.nn.Parameter(layer.qzeros.data, requires_grad=False)
+        layer.scales = torch.nn.Parameter(layer.scales.data, requires_grad=False)
+
+    def apply(self, layer, x: torch.Tensor, bias: Optional[torch.Tensor] = None):
+        # awq.py:401-418 computes awq_dequantize(...) then x @ W; here the dequant is fused into the GEMM
+        qweight, scales, qzeros = layer.qweight, layer.scales, layer.qzeros
+        pack_factor = self.quant_config.pack_factor
+        out_shape = x.shape[:-1] + (qweight.shape[-1] * pack_factor,)
+        reshaped_x = x.reshape(-1, x.shape[-1])
+        out = ops.awq_gemm(reshaped_x, qweight, scales, qzeros, bias)
+        return out.reshape(out_shape)
+
+
+QUANTIZATION_METHODS = {
+    "w8a8_fp8": W8A8Fp8Config,
+    "awq": AWQConfig,
+}
+
+
+def get_quantization_config(quantization: str):
+    if quantization not in QUANTIZATION_METHODS:
+        raise ValueError(f"Invalid quantization method: {quantization}. Available methods: {list(QUANTIZATION_METHODS)}")
+    return QUANTIZATION_METHODS[quantization]

@@ -1,0 +1,83 @@
+"""GPU: RMSNorm / fused-add RMSNorm / SiLU*mul / RoPE and their FP8-fused forms vs the oracle."""
+import pytest
+import torch
+
+import oracle
+from sglang_npu_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _close(a, b, dtype, extra=0.0):
+    ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    torch.testing.assert_close(a.float().cpu(), b.float(), rtol=ulp, atol=1e-3 * float(b.float().abs().max()) + extra)
+
+
+@pytest.mark.parametrize("T,H", [(64, 4096), (1, 896), (7, 8192), (33, 1368), (3, 16384)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_rmsnorm_and_fused_add(T, H, dtype):
+    g = torch.Generator().manual_seed(T + H)
+    x = torch.randn(T, H, generator=g).to(dtype)
+    res = torch.randn(T, H, generator=g).to(dtype)
+    w = (torch.rand(H, generator=g) + 0.5).to(dtype)
+    ref = oracle.rmsnorm(x, w, 1e-5)
+    _close(ops.rmsnorm(x.to(DEV), w.to(DEV), 1e-5), ref, dtype)
+    res_ref = res.clone()
+    ref2 = oracle.rmsnorm(x, w, 1e-5, residual=res_ref)
+    xd, rd = x.to(DEV).clone(), res.to(DEV).clone()
+    ops.fused_add_rmsnorm(xd, rd, w.to(DEV), 1e-5)
+    assert torch.equal(rd.cpu().view(torch.int16), res_ref.view(torch.int16)), "residual = round(x + residual) exactly"
+    _close(xd, ref2, dtype)
+
+
+@pytest.mark.parametrize("T,d", [(64, 14336), (5, 4864), (1, 11008), (16, 3584)])
+def test_silu_and_mul(T, d):
+    g = torch.Generator().manual_seed(d)
+    x = (torch.randn(T, 2 * d, generator=g) * 2).bfloat16()
+    _close(ops.silu_and_mul(x.to(DEV)), oracle.silu_and_mul(x), torch.bfloat16)
+
+
+@pytest.mark.parametrize("Hq,Hk,D", [(32, 8, 128), (14, 2, 64), (8, 1, 128)])
+def test_rope_neox(Hq, Hk, D):
+    from sglang_npu_amd.layers import RotaryEmbedding
+    g = torch.Generator().manual_seed(D + Hq)
+    T = 37
+    rot = RotaryEmbedding(D, D, 4096, 500000.0, True)
+    qkv = torch.randn(T, (Hq + 2 * Hk) * D, generator=g).bfloat16()
+    pos = torch.randint(0, 4096, (T,), generator=g)
+    q_ref = qkv[:, :Hq * D].clone().view(T, Hq, D)
+    k_ref = qkv[:, Hq * D:(Hq + Hk) * D].clone().view(T, Hk, D)
+    oracle.rope_neox(q_ref, pos, rot.cos_sin_cache)
+    oracle.rope_neox(k_ref, pos, rot.cos_sin_cache)
+    d = qkv.to(DEV)
+    q, k, v = d.split([Hq * D, Hk * D, Hk * D], dim=-1)  # strided views, like llama.py:188
+    ops.apply_rope_with_cos_sin_cache_inplace(pos.to(DEV), q, k, D, rot.cos_sin_cache.to(DEV), True)
+    _close(q.reshape(T, Hq, D), q_ref, torch.bfloat16)
+    _close(k.reshape(T, Hk, D), k_ref, torch.bfloat16)
+    assert torch.equal(v.cpu(), qkv[:, (Hq + Hk) * D:]), "v must be untouched"
+
+
+def test_fused_norm_quant_equals_unfused_pair():
+    g = torch.Generator().manual_seed(11)
+    T, H = 64, 4096
+    x = torch.randn(T, H, generator=g).bfloat16().to(DEV)
+    res = torch.randn(T, H, generator=g).bfloat16().to(DEV)
+    w = (torch.rand(H, generator=g) + 0.5).bfloat16().to(DEV)
+    x2, r2 = x.clone(), res.clone()
+    ops.fused_add_rmsnorm(x2, r2, w, 1e-5)
+    q_ref = torch.empty(T, H, dtype=torch.float8_e4m3fn, device=DEV)
+    s_ref = torch.empty(T, 1, device=DEV)
+    ops.sgl_per_token_quant_fp8(x2, q_ref, s_ref)
+    r3 = res.clone()
+    q, s, out = ops.rmsnorm_quant_fp8(x, w, 1e-5, residual=r3, want_out=True)
+    assert torch.equal(r3, r2) and torch.equal(out, x2)
+    assert torch.equal(s, s_ref) and torch.equal(q.view(torch.uint8), q_ref.view(torch.uint8)), "fusion must be bit-exact"
+    # silu + quant
+    y = (torch.randn(T, 2 * 14336, generator=g) * 2).bfloat16().to(DEV)
+    a = ops.silu_and_mul(y)
+    qa_ref = torch.empty(a.shape, dtype=torch.float8_e4m3fn, device=DEV)
+    sa_ref = torch.empty(T, 1, device=DEV)
+    ops.sgl_per_token_quant_fp8(a, qa_ref, sa_ref)
+    qa, sa = ops.silu_and_mul_quant_fp8(y)
+    assert torch.equal(sa, sa_ref) and torch.equal(qa.view(torch.uint8), qa_ref.view(torch.uint8))
