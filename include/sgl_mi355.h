@@ -120,6 +120,49 @@ int sgl_mi355_decode_attention_fwd(
     float sm_scale, float logit_cap, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Ragged prefix + extend ("prefill") attention, backend form.
+ * Replaces: extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr,
+ *             kv_indptr, kv_indices, custom_mask, is_causal, mask_indptr, max_len_extend, sm_scale,
+ *             logit_cap, sliding_window_size)
+ *           python/sglang/srt/layers/attention/triton_ops/extend_attention.py:306-438 (kernel :41-303),
+ *           called from TritonAttnBackend.forward_extend, triton_backend.py:632-685.
+ *   q_extend [T,Hq,D], k_extend [T,Hkv,D], v_extend [T,Hkv,Dv], o_extend [T,Hq,Dv]: the new tokens of all
+ *   requests back to back; qo_indptr int32 [B+1] = cumulative extend lengths; kv_indptr int32 [B+1] =
+ *   cumulative PREFIX lengths; kv_indices int32 = pool slots of the prefix tokens; k_buffer/v_buffer the
+ *   KV pool.  custom_mask / sliding window are not supported (pass the plain causal case). */
+int sgl_mi355_extend_attention_fwd(
+    const void* q_extend, const void* k_extend, const void* v_extend, void* o_extend,
+    const void* k_buffer, const void* v_buffer,
+    const int32_t* qo_indptr, const int32_t* kv_indptr, const int32_t* kv_indices, int is_causal,
+    int64_t max_len_extend, int64_t batch, int64_t num_heads, int64_t num_kv_heads,
+    int64_t head_size, int64_t head_size_v,
+    int64_t q_stride_t, int64_t q_stride_h, int64_t ke_stride_t, int64_t ke_stride_h,
+    int64_t ve_stride_t, int64_t ve_stride_h, int64_t o_stride_t, int64_t o_stride_h,
+    int64_t kb_stride_n, int64_t kb_stride_h, int64_t vb_stride_n, int64_t vb_stride_h,
+    float sm_scale, float logit_cap, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Ragged prefix + extend attention, op-level form.
+ * Replaces: extend_attention_cpu(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, req_to_token,
+ *             req_pool_indices, seq_lens, extend_seq_lens, extend_start_loc, max_len_extend, sm_scale,
+ *             logit_cap)
+ *           schema sgl-kernel/csrc/cpu/torch_extension_cpu.cpp:269-275, impl
+ *           sgl-kernel/csrc/cpu/extend.cpp:579-723.
+ *   prefix_len = seq_lens[b] - extend_seq_lens[b] (extend.cpp:305-309); prefix tokens are
+ *   req_to_token[req_pool_indices[b]][0:prefix_len]; always causal.  The four per-request vectors are
+ *   int64 here (the Python shim widens int32 inputs). */
+int sgl_mi355_extend_attention(
+    const void* q_extend, const void* k_extend, const void* v_extend, void* o_extend,
+    const void* k_buffer, const void* v_buffer, const void* req_to_token, int req_to_token_is64,
+    const int64_t* req_pool_indices, const int64_t* seq_lens, const int64_t* extend_seq_lens,
+    const int64_t* extend_start_loc, int64_t max_len_extend, int64_t num_seqs, int64_t max_context_len,
+    int64_t num_heads, int64_t num_kv_heads, int64_t head_size, int64_t head_size_v,
+    int64_t q_stride_t, int64_t q_stride_h, int64_t ke_stride_t, int64_t ke_stride_h,
+    int64_t ve_stride_t, int64_t ve_stride_h, int64_t o_stride_t, int64_t o_stride_h,
+    int64_t kb_stride_n, int64_t kb_stride_h, int64_t vb_stride_n, int64_t vb_stride_h,
+    float sm_scale, float logit_cap, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Per-token dynamic FP8 (OCP e4m3fn) activation quantisation.
  * Replaces: sgl_per_token_quant_fp8(Tensor input, Tensor output_q, Tensor output_s) -> ()
  *           schema sgl-kernel/csrc/common_extension.cc:98-130, impl
@@ -153,7 +196,7 @@ int sgl_mi355_fp8_scaled_mm(
  * Replace: sgl_kernel.rmsnorm / fused_add_rmsnorm / silu_and_mul /
  *          apply_rope_with_cos_sin_cache_inplace as called from
  *          python/sglang/srt/layers/layernorm.py:59-133, activation.py:59-83,
- *          rotary_embedding.py:79-260 (CUDA sources sgl-kernel/csrc/elementwise/*.cu).
+ *          rotary_embedding.py:79-260 (CUDA sources under sgl-kernel/csrc/elementwise/).
  *   rmsnorm:            out = x * rsqrt(mean(x^2) + eps) * weight           (fp32 math, one rounding)
  *   fused_add_rmsnorm:  residual = x + residual (rounded to dtype); x = norm(fp32 sum) * weight; in place
  *   silu_and_mul:       out[t,:d] = silu(x[t,:d]) * x[t,d:2d]

@@ -1,0 +1,529 @@
+// Ragged prefix + extend ("prefill") attention for MI355X / gfx950.
+//
+// Replaces (see include/sgl_mi355.h):
+//   * extend_attention_fwd (Triton)  python/sglang/srt/layers/attention/triton_ops/extend_attention.py:306-438
+//                                    (kernel :41-303), called from triton_backend.py:632-685
+//   * extend_attention_cpu           sgl-kernel/csrc/cpu/extend.cpp:579-723 (impl :224-560)
+//
+// Math: for request b, query row r of its extend part (absolute position prefix_len + r), softmax over
+//   stage 1: every cached prefix token, gathered from the KV pool through the page table;
+//   stage 2: the new tokens k_extend/v_extend[start + j], j <= r (causal) -- contiguous memory;
+// fp32 accumulation, p rounded to the 16-bit dtype before p@V (extend.cpp:409-410,
+// extend_attention.py:196,276), out = acc / sum.
+//
+// Design (FlashAttention-2 shape, tiled for 64-wide waves and 32x32x16 MFMA):
+//   * Workgroup = 4 waves = up to 4 q-heads of one GQA group x 32 query positions (or fewer heads and
+//     more positions for small groups), so one K/V tile in LDS serves the whole group: K/V are read once
+//     per group, not once per head.
+//   * K/V tiles of 64 tokens arrive by LDS-DMA (per-lane source address: the same instruction gathers
+//     page-table rows in stage 1 and streams contiguous rows in stage 2), double-buffered; the prefix
+//     page-table slice is staged in LDS so the loop issues no ordinary global loads.
+//   * Per wave S^T = K Q^T with v_mfma_f32_32x32x16 (A = K rows via ds_read_b128 from a swizzled image,
+//     B = Q^T in registers).  The query row sits on the lane (col = lane&31), so the online softmax is
+//     lane-local plus one cross-half shuffle.  O^T += V^T P^T with V^T fragments from
+//     ds_read_b64_tr_b16 and P^T taken straight from the S^T accumulator registers (no LDS round trip).
+//   * Head sizes other than 64/128 (e.g. the reference test's D=128, Dv=96) use a generic kernel.
+#include <math.h>
+
+#include "common.h"
+
+namespace sglm {
+namespace {
+
+constexpr int kBN = 64;          // keys per tile
+constexpr int kIdxCap = 4096;    // prefix page-table entries staged in LDS per pass
+constexpr float kLog2e = 1.4426950408889634f;
+
+struct ExtendArgs {
+  const void* q;  int64_t q_st, q_sh;      // q_extend [T,Hq,D]
+  const void* ke; int64_t ke_st, ke_sh;    // k_extend [T,Hkv,D]
+  const void* ve; int64_t ve_st, ve_sh;
+  void* o;        int64_t o_st, o_sh;      // o_extend [T,Hq,Dv]
+  const void* kb; int64_t kb_sn, kb_sh;    // pool
+  const void* vb; int64_t vb_sn, vb_sh;
+  // mode 0 (Triton form): qo_indptr/kv_indptr int32 [B+1], kv_indices int32
+  const int32_t* qo_indptr;
+  const int32_t* kv_indptr;
+  // mode 1 (CPU-op form): req_to_token rows, int64 per-request vectors
+  const int64_t* req_pool_indices;
+  const int64_t* seq_lens;
+  const int64_t* extend_seq_lens;
+  const int64_t* extend_start_loc;
+  int64_t r2t_stride;
+  const void* indices;  // kv_indices (int32) or req_to_token (int32/int64)
+  int num_heads, num_kv_heads, group;
+  int num_mblocks;      // grid extent along query blocks
+  float sm_scale, logit_cap;
+  int causal, mode;
+};
+
+__device__ __forceinline__ void seq_info(const ExtendArgs& a, int b, int64_t& idx_base, int& prefix, int& ext,
+                                         int64_t& q_start) {
+  if (a.mode == 0) {
+    q_start = a.qo_indptr[b];
+    ext = a.qo_indptr[b + 1] - (int)q_start;
+    idx_base = a.kv_indptr[b];
+    prefix = a.kv_indptr[b + 1] - (int)idx_base;
+  } else {
+    q_start = a.extend_start_loc[b];
+    ext = (int)a.extend_seq_lens[b];
+    prefix = (int)a.seq_lens[b] - ext;
+    idx_base = a.req_pool_indices[b] * a.r2t_stride;
+  }
+}
+
+template <int D>
+__device__ __forceinline__ int swz_k(int c, int row) {  // ds_read_b128 row reads, 32 rows per operand
+  return (D == 128) ? (c ^ (row & 15)) : (c ^ ((row >> 1) & 7));
+}
+template <int D>
+__device__ __forceinline__ int swz_v(int c, int row) {  // ds_read_b64_tr_b16: keep 32-B units intact
+  const int f = (D == 128) ? ((row & 3) << 1) : (((row >> 1) & 1) << 1);
+  return (((c >> 1) ^ f) << 1) | (c & 1);
+}
+
+// GH = q heads per workgroup (1, 2 or 4); the other 4/GH waves take further 32-row position blocks.
+template <int DTYPE, int D, typename IdxT, int GH>
+__global__ __launch_bounds__(256) void extend_mfma_kernel(ExtendArgs a) {
+  using H = Half16<DTYPE>;
+  using T = typename H::T;
+  using x8 = typename H::x8;
+  using x4 = typename H::x4;
+  constexpr int ROWB = D * 2;
+  constexpr int CH = ROWB / 16;
+  constexpr int ROWS_PER_DMA = 1024 / ROWB;
+  constexpr int PIECES = kBN / ROWS_PER_DMA;    // DMA pieces per K (or V) tile
+  constexpr int PPW = PIECES / 4;               // pieces per wave
+  constexpr int TILE_BYTES = kBN * ROWB;
+  constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+  constexpr int KS = D / 16;                    // 32x32x16 k-steps over the head dim
+  constexpr int NDVB = D / 32;                  // 32-wide output blocks
+  constexpr int NPB = 4 / GH;                   // position blocks per workgroup
+  constexpr int BP = 32 * NPB;                  // query positions per workgroup
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int32_t* idx_lds = reinterpret_cast<int32_t*>(smem + 2 * STAGE_BYTES);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 31, hh = lane >> 5;
+
+  // blockIdx.x = ((b * (Hq/GH)) + hgrp) * num_mblocks + mblk ; heavy (late) query blocks first
+  int bid = blockIdx.x;
+  const int mblk = a.num_mblocks - 1 - (bid % a.num_mblocks);
+  bid /= a.num_mblocks;
+  const int hgroups = a.num_heads / GH;
+  const int hgrp = bid % hgroups;
+  const int b = bid / hgroups;
+  const int head0 = hgrp * GH;
+  const int kvh = head0 / a.group;
+
+  int64_t idx_base, q_start;
+  int prefix, ext;
+  seq_info(a, b, idx_base, prefix, ext, q_start);
+  const int p0 = mblk * BP;
+  if (p0 >= ext) return;
+
+  const int head = head0 + (wave % GH);
+  const int pw0 = p0 + 32 * (wave / GH);  // first query position of this wave
+  const int qpos = pw0 + col;             // this lane's query position within the extend part
+  const bool q_ok = qpos < ext;
+
+  // ---- Q^T fragments: lane (col, hh) holds Q[qpos][head][16s + 8hh .. +8]
+  x8 qf[KS];
+  {
+    const T* qp = reinterpret_cast<const T*>(a.q) + (q_start + (q_ok ? qpos : 0)) * a.q_st + (int64_t)head * a.q_sh;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      if (q_ok) {
+        qf[s] = *reinterpret_cast<const x8*>(qp + 16 * s + 8 * hh);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[s][j] = (T)0.f;
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(qf[s]));  // keep hipcc's wait for these loads out of the loop
+  }
+
+  const int n_ext_keys = a.causal ? ((p0 + BP) < ext ? (p0 + BP) : ext) : ext;
+  const int nt1 = (prefix + kBN - 1) / kBN;
+  const int nt2 = (n_ext_keys + kBN - 1) / kBN;
+
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x16 o_acc[NDVB];
+#pragma unroll
+  for (int i = 0; i < NDVB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o_acc[i][r] = 0.f;
+
+  const float scale_log2 = a.sm_scale * kLog2e;
+  const bool has_cap = a.logit_cap > 0.f;
+  const int dma_row = lane / CH, dma_pos = lane % CH;
+  const char* kpool = reinterpret_cast<const char*>(a.kb) + (int64_t)kvh * a.kb_sh * 2;
+  const char* vpool = reinterpret_cast<const char*>(a.vb) + (int64_t)kvh * a.vb_sh * 2;
+  const char* kext = reinterpret_cast<const char*>(a.ke) + (q_start * a.ke_st + (int64_t)kvh * a.ke_sh) * 2;
+  const char* vext = reinterpret_cast<const char*>(a.ve) + (q_start * a.ve_st + (int64_t)kvh * a.ve_sh) * 2;
+
+  // issue this wave's share (PPW K pieces + PPW V pieces) of tile `t` of the given phase into `stage`
+  auto issue = [&](int phase, int t, int stage, int idx_off, int n_keys) __attribute__((always_inline)) {
+    const uint32_t kdst = __builtin_amdgcn_readfirstlane(lds_addr_of(smem + stage * STAGE_BYTES));
+    const uint32_t vdst = kdst + TILE_BYTES;
+    int64_t koff[PPW], voff[PPW];
+    const char *kb_ = phase == 0 ? kpool : kext, *vb_ = phase == 0 ? vpool : vext;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int row = (wave * PPW + i) * ROWS_PER_DMA + dma_row;
+      int kidx = t * kBN + row;
+      kidx = kidx < n_keys ? kidx : n_keys - 1;  // tail rows re-read a valid key; masked in the softmax
+      if (phase == 0) {
+        const int64_t slot = idx_lds[kidx - idx_off];
+        koff[i] = slot * a.kb_sn * 2;
+        voff[i] = slot * a.vb_sn * 2;
+      } else {
+        koff[i] = (int64_t)kidx * a.ke_st * 2;
+        voff[i] = (int64_t)kidx * a.ve_st * 2;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int row = (wave * PPW + i) * ROWS_PER_DMA + dma_row;
+      lds_dma16(kb_ + koff[i] + swz_k<D>(dma_pos, row) * 16, kdst + (wave * PPW + i) * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int row = (wave * PPW + i) * ROWS_PER_DMA + dma_row;
+      lds_dma16(vb_ + voff[i] + swz_v<D>(dma_pos, row) * 16, vdst + (wave * PPW + i) * 1024);
+    }
+  };
+
+  auto compute = [&](int phase, int t, int stage, int n_keys) __attribute__((always_inline)) {
+    const char* kst = smem + stage * STAGE_BYTES;
+    const char* vst = kst + TILE_BYTES;
+    // ---- S^T = K Q^T for the two 32-key halves
+    f32x16 s_acc[2];
+#pragma unroll
+    for (int th = 0; th < 2; ++th) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s_acc[th][r] = 0.f;
+      const int row = 32 * th + col;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const x8 kf = *reinterpret_cast<const x8*>(kst + row * ROWB + swz_k<D>(2 * s + hh, row) * 16);
+        s_acc[th] = H::mfma32(kf, qf[s], s_acc[th]);
+      }
+    }
+    // ---- online softmax; key of (th, r) = t*64 + 32th + (r&3) + 8(r>>2) + 4hh
+    float m_tile = -INFINITY;
+#pragma unroll
+    for (int th = 0; th < 2; ++th)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float s = s_acc[th][r];
+        if (has_cap) {
+          s = s * a.sm_scale;
+          s = a.logit_cap * tanhf(s / a.logit_cap) * kLog2e;
+        } else {
+          s = s * scale_log2;
+        }
+        const int key = t * kBN + 32 * th + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        bool ok = key < n_keys;
+        if (phase == 1 && a.causal) ok = ok && (key <= qpos);
+        s = ok ? s : -INFINITY;
+        s_acc[th][r] = s;
+        m_tile = fmaxf(m_tile, s);
+      }
+    m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32));
+    const float m_new = fmaxf(m_run, m_tile);
+    // a row may have seen no visible key yet (its first tile fully masked): keep everything at zero
+    const float m_safe = m_new == -INFINITY ? 0.f : m_new;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);
+    float psum = 0.f;
+    x8 pf[2][2];
+#pragma unroll
+    for (int th = 0; th < 2; ++th)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(s_acc[th][r] - m_safe);
+        psum += p;
+        pf[th][r >> 3][r & 7] = H::from_f32(p);
+      }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < NDVB; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o_acc[i][r] *= alpha;
+    // ---- O^T += V^T P^T
+    const int grp = lane >> 4;       // 16-lane group: column half (grp&1), k half hh = grp>>1
+    const int q4 = (lane >> 2) & 3;  // row within a 4-row transposed block
+    const int p4 = lane & 3;         // 8-B piece of the 32-B column block
+#pragma unroll
+    for (int th = 0; th < 2; ++th)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int r_lo = 32 * th + 16 * s2 + 4 * hh + q4;
+        const int r_hi = r_lo + 8;
+#pragma unroll
+        for (int dvb = 0; dvb < NDVB; ++dvb) {
+          const int c = 4 * dvb + 2 * (grp & 1) + (p4 >> 1);
+          const x4 v_lo = H::ds_read_tr(vst + r_lo * ROWB + swz_v<D>(c, r_lo) * 16 + 8 * (p4 & 1));
+          const x4 v_hi = H::ds_read_tr(vst + r_hi * ROWB + swz_v<D>(c, r_hi) * 16 + 8 * (p4 & 1));
+          x8 vf;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            vf[j] = v_lo[j];
+            vf[4 + j] = v_hi[j];
+          }
+          o_acc[dvb] = H::mfma32(vf, pf[th][s2], o_acc[dvb]);
+        }
+      }
+  };
+
+  // tile sequence: stage 1 (prefix, in passes of kIdxCap page-table entries), then stage 2 (new tokens)
+  // Every pass runs the same double-buffered loop.
+  auto run_phase = [&](int phase, int t_begin, int t_end, int idx_off, int n_keys) __attribute__((always_inline)) {
+    if (t_begin >= t_end) return;
+    issue(phase, t_begin, 0, idx_off, n_keys);
+    for (int t = t_begin; t < t_end; ++t) {
+      const int st = (t - t_begin) & 1;
+      if (t + 1 < t_end) {
+        issue(phase, t + 1, st ^ 1, idx_off, n_keys);
+        wait_vmcnt<2 * PPW>();
+      } else {
+        wait_vmcnt<0>();
+      }
+      __builtin_amdgcn_s_barrier();  // every wave's share of tile t has landed
+      compute(phase, t, st, n_keys);
+      wait_lgkmcnt0();
+      __builtin_amdgcn_s_barrier();  // everyone is done reading stage st before it is refilled
+    }
+  };
+
+  for (int i0 = 0; i0 < prefix; i0 += kIdxCap) {
+    const int n = (prefix - i0) < kIdxCap ? (prefix - i0) : kIdxCap;
+    {
+      const IdxT* src = reinterpret_cast<const IdxT*>(a.indices) + idx_base + i0;
+      for (int i = tid; i < n; i += 256) idx_lds[i] = (int32_t)src[i];
+    }
+    __syncthreads();
+    run_phase(0, i0 / kBN, (i0 + n + kBN - 1) / kBN, i0, i0 + n);  // kIdxCap is a multiple of kBN
+    __syncthreads();
+  }
+  (void)nt1;
+  run_phase(1, 0, nt2, 0, n_ext_keys);
+
+  // ---- epilogue: out = acc / l ; lane (col = qrow, hh), reg r -> dv = 32*dvb + (r&3) + 8(r>>2) + 4hh
+  l_run += __shfl_xor(l_run, 32);
+  if (q_ok) {
+    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    T* op = reinterpret_cast<T*>(a.o) + (q_start + qpos) * a.o_st + (int64_t)head * a.o_sh;
+#pragma unroll
+    for (int dvb = 0; dvb < NDVB; ++dvb)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = H::from_f32(o_acc[dvb][4 * r4 + j] * inv);
+        *reinterpret_cast<x4*>(op + 32 * dvb + 8 * r4 + 4 * hh) = v;
+      }
+  }
+}
+
+// Generic fallback: one wave per (query row, head); any head sizes up to 1024.
+template <int DTYPE, typename IdxT>
+__global__ __launch_bounds__(64) void extend_generic_kernel(ExtendArgs a, int D, int Dv, int max_len_extend) {
+  using H = Half16<DTYPE>;
+  using T = typename H::T;
+  constexpr int MAXE = 16;
+  const int lane = threadIdx.x;
+  int bid = blockIdx.x;
+  const int r = bid % max_len_extend;
+  bid /= max_len_extend;
+  const int h = bid % a.num_heads;
+  const int b = bid / a.num_heads;
+  int64_t idx_base, q_start;
+  int prefix, ext;
+  seq_info(a, b, idx_base, prefix, ext, q_start);
+  if (r >= ext) return;
+  const int kvh = h / a.group;
+  float qv[MAXE], acc[MAXE];
+  const T* qp = reinterpret_cast<const T*>(a.q) + (q_start + r) * a.q_st + (int64_t)h * a.q_sh;
+#pragma unroll
+  for (int i = 0; i < MAXE; ++i) {
+    const int d = lane + 64 * i;
+    qv[i] = d < D ? H::to_f32(qp[d]) : 0.f;
+    acc[i] = 0.f;
+  }
+  float m_run = -INFINITY, l_run = 0.f;
+  const IdxT* idx = reinterpret_cast<const IdxT*>(a.indices) + idx_base;
+  const int n_new = a.causal ? r + 1 : ext;
+  for (int n = 0; n < prefix + n_new; ++n) {
+    const T *kp, *vp;
+    if (n < prefix) {
+      const int64_t tok = (int64_t)idx[n];
+      kp = reinterpret_cast<const T*>(a.kb) + tok * a.kb_sn + (int64_t)kvh * a.kb_sh;
+      vp = reinterpret_cast<const T*>(a.vb) + tok * a.vb_sn + (int64_t)kvh * a.vb_sh;
+    } else {
+      kp = reinterpret_cast<const T*>(a.ke) + (q_start + n - prefix) * a.ke_st + (int64_t)kvh * a.ke_sh;
+      vp = reinterpret_cast<const T*>(a.ve) + (q_start + n - prefix) * a.ve_st + (int64_t)kvh * a.ve_sh;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXE; ++i) {
+      const int d = lane + 64 * i;
+      if (d < D) s += qv[i] * H::to_f32(kp[d]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    s *= a.sm_scale;
+    if (a.logit_cap > 0.f) s = a.logit_cap * tanhf(s / a.logit_cap);
+    const float m_new = fmaxf(m_run, s);
+    const float alpha = expf(m_run - m_new);
+    const float p = expf(s - m_new);
+    const float pr = H::to_f32(H::from_f32(p));
+    l_run = l_run * alpha + p;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < MAXE; ++i) {
+      const int d = lane + 64 * i;
+      if (d < Dv) acc[i] = acc[i] * alpha + pr * H::to_f32(vp[d]);
+    }
+  }
+  const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+  T* op = reinterpret_cast<T*>(a.o) + (q_start + r) * a.o_st + (int64_t)h * a.o_sh;
+#pragma unroll
+  for (int i = 0; i < MAXE; ++i) {
+    const int d = lane + 64 * i;
+    if (d < Dv) op[d] = H::from_f32(acc[i] * inv);
+  }
+}
+
+template <int DTYPE, int D, typename IdxT, int GH>
+int launch_mfma(ExtendArgs a, int64_t batch, int max_len_extend, hipStream_t s) {
+  auto kern = extend_mfma_kernel<DTYPE, D, IdxT, GH>;
+  constexpr int lds = 2 * 2 * kBN * D * 2 + kIdxCap * 4;
+  static int attr_rc = check_hip(
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
+      "hipFuncSetAttribute");
+  if (attr_rc) return attr_rc;
+  constexpr int BP = 32 * (4 / GH);
+  a.num_mblocks = (max_len_extend + BP - 1) / BP;
+  const int64_t grid = batch * (a.num_heads / GH) * a.num_mblocks;
+  if (grid <= 0) return 0;
+  if (grid >= (1ll << 31)) {
+    set_error("extend_attention: grid too large");
+    return SGL_MI355_ERR_INVALID_ARGUMENT;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, a);
+  return check_hip(hipGetLastError(), "extend_mfma_kernel launch");
+}
+
+template <int DTYPE, typename IdxT>
+int dispatch(ExtendArgs a, int64_t batch, int D, int Dv, int max_len_extend, hipStream_t s) {
+  const bool aligned = (a.q_st % 8 == 0) && (a.q_sh % 8 == 0) && (a.ke_st % 8 == 0) && (a.ke_sh % 8 == 0) &&
+                       (a.ve_st % 8 == 0) && (a.ve_sh % 8 == 0) && (a.kb_sn % 8 == 0) && (a.kb_sh % 8 == 0) &&
+                       (a.vb_sn % 8 == 0) && (a.vb_sh % 8 == 0) && (a.o_st % 4 == 0) && (a.o_sh % 4 == 0) &&
+                       (reinterpret_cast<uintptr_t>(a.q) % 16 == 0) && (reinterpret_cast<uintptr_t>(a.ke) % 16 == 0) &&
+                       (reinterpret_cast<uintptr_t>(a.ve) % 16 == 0) && (reinterpret_cast<uintptr_t>(a.kb) % 16 == 0) &&
+                       (reinterpret_cast<uintptr_t>(a.vb) % 16 == 0) && (reinterpret_cast<uintptr_t>(a.o) % 8 == 0);
+  if (D == Dv && aligned && (D == 128 || D == 64)) {
+    const int gh = (a.group % 4 == 0) ? 4 : (a.group % 2 == 0 ? 2 : 1);
+#define EXT_LAUNCH(DD, GG) return launch_mfma<DTYPE, DD, IdxT, GG>(a, batch, max_len_extend, s)
+    if (D == 128) {
+      if (gh == 4) EXT_LAUNCH(128, 4);
+      if (gh == 2) EXT_LAUNCH(128, 2);
+      EXT_LAUNCH(128, 1);
+    } else {
+      if (gh == 4) EXT_LAUNCH(64, 4);
+      if (gh == 2) EXT_LAUNCH(64, 2);
+      EXT_LAUNCH(64, 1);
+    }
+#undef EXT_LAUNCH
+  }
+  const int64_t grid = batch * a.num_heads * (int64_t)max_len_extend;
+  if (grid <= 0) return 0;
+  if (grid >= (1ll << 31)) {
+    set_error("extend_attention: grid too large for the generic kernel");
+    return SGL_MI355_ERR_INVALID_ARGUMENT;
+  }
+  hipLaunchKernelGGL((extend_generic_kernel<DTYPE, IdxT>), dim3((unsigned)grid), dim3(64), 0, s, a, D, Dv, max_len_extend);
+  return check_hip(hipGetLastError(), "extend_generic_kernel launch");
+}
+
+int check_common(int64_t batch, int64_t Hq, int64_t Hkv, int64_t D, int64_t Dv, int64_t max_len_extend, int dtype) {
+  SGLM_CHECK_ARG(dtype == SGL_MI355_BF16 || dtype == SGL_MI355_FP16, "extend_attention: dtype must be bf16 (0) or fp16 (1)");
+  SGLM_CHECK_ARG(batch >= 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "extend_attention: bad head counts %ld/%ld", (long)Hq, (long)Hkv);
+  SGLM_CHECK_ARG(D > 0 && Dv > 0 && D <= 1024 && Dv <= 1024, "extend_attention: head sizes must be in [1,1024]");
+  SGLM_CHECK_ARG(max_len_extend >= 0 && max_len_extend < (1ll << 30), "extend_attention: bad max_len_extend");
+  return 0;
+}
+
+}  // namespace
+}  // namespace sglm
+
+using namespace sglm;
+
+extern "C" int sgl_mi355_extend_attention_fwd(
+    const void* q_extend, const void* k_extend, const void* v_extend, void* o_extend, const void* k_buffer,
+    const void* v_buffer, const int32_t* qo_indptr, const int32_t* kv_indptr, const int32_t* kv_indices, int is_causal,
+    int64_t max_len_extend, int64_t batch, int64_t num_heads, int64_t num_kv_heads, int64_t head_size,
+    int64_t head_size_v, int64_t q_stride_t, int64_t q_stride_h, int64_t ke_stride_t, int64_t ke_stride_h,
+    int64_t ve_stride_t, int64_t ve_stride_h, int64_t o_stride_t, int64_t o_stride_h, int64_t kb_stride_n,
+    int64_t kb_stride_h, int64_t vb_stride_n, int64_t vb_stride_h, float sm_scale, float logit_cap, int dtype,
+    void* stream) {
+  int rc = check_common(batch, num_heads, num_kv_heads, head_size, head_size_v, max_len_extend, dtype);
+  if (rc) return rc;
+  if (batch == 0 || max_len_extend == 0) return 0;
+  SGLM_CHECK_ARG(q_extend && k_extend && v_extend && o_extend && qo_indptr && kv_indptr,
+                 "extend_attention_fwd: null tensor pointer");
+  ExtendArgs a{};
+  a.q = q_extend; a.q_st = q_stride_t; a.q_sh = q_stride_h;
+  a.ke = k_extend; a.ke_st = ke_stride_t; a.ke_sh = ke_stride_h;
+  a.ve = v_extend; a.ve_st = ve_stride_t; a.ve_sh = ve_stride_h;
+  a.o = o_extend; a.o_st = o_stride_t; a.o_sh = o_stride_h;
+  a.kb = k_buffer; a.kb_sn = kb_stride_n; a.kb_sh = kb_stride_h;
+  a.vb = v_buffer; a.vb_sn = vb_stride_n; a.vb_sh = vb_stride_h;
+  a.qo_indptr = qo_indptr; a.kv_indptr = kv_indptr; a.indices = kv_indices; a.mode = 0;
+  a.num_heads = (int)num_heads; a.num_kv_heads = (int)num_kv_heads; a.group = (int)(num_heads / num_kv_heads);
+  a.sm_scale = sm_scale; a.logit_cap = logit_cap; a.causal = is_causal;
+  hipStream_t s = as_stream(stream);
+  return dtype == SGL_MI355_BF16
+             ? dispatch<SGL_MI355_BF16, int32_t>(a, batch, (int)head_size, (int)head_size_v, (int)max_len_extend, s)
+             : dispatch<SGL_MI355_FP16, int32_t>(a, batch, (int)head_size, (int)head_size_v, (int)max_len_extend, s);
+}
+
+extern "C" int sgl_mi355_extend_attention(
+    const void* q_extend, const void* k_extend, const void* v_extend, void* o_extend, const void* k_buffer,
+    const void* v_buffer, const void* req_to_token, int req_to_token_is64, const int64_t* req_pool_indices,
+    const int64_t* seq_lens, const int64_t* extend_seq_lens, const int64_t* extend_start_loc, int64_t max_len_extend,
+    int64_t num_seqs, int64_t max_context_len, int64_t num_heads, int64_t num_kv_heads, int64_t head_size,
+    int64_t head_size_v, int64_t q_stride_t, int64_t q_stride_h, int64_t ke_stride_t, int64_t ke_stride_h,
+    int64_t ve_stride_t, int64_t ve_stride_h, int64_t o_stride_t, int64_t o_stride_h, int64_t kb_stride_n,
+    int64_t kb_stride_h, int64_t vb_stride_n, int64_t vb_stride_h, float sm_scale, float logit_cap, int dtype,
+    void* stream) {
+  int rc = check_common(num_seqs, num_heads, num_kv_heads, head_size, head_size_v, max_len_extend, dtype);
+  if (rc) return rc;
+  if (num_seqs == 0 || max_len_extend == 0) return 0;
+  SGLM_CHECK_ARG(q_extend && k_extend && v_extend && o_extend && req_to_token && req_pool_indices && seq_lens &&
+                     extend_seq_lens && extend_start_loc,
+                 "extend_attention: null tensor pointer");
+  ExtendArgs a{};
+  a.q = q_extend; a.q_st = q_stride_t; a.q_sh = q_stride_h;
+  a.ke = k_extend; a.ke_st = ke_stride_t; a.ke_sh = ke_stride_h;
+  a.ve = v_extend; a.ve_st = ve_stride_t; a.ve_sh = ve_stride_h;
+  a.o = o_extend; a.o_st = o_stride_t; a.o_sh = o_stride_h;
+  a.kb = k_buffer; a.kb_sn = kb_stride_n; a.kb_sh = kb_stride_h;
+  a.vb = v_buffer; a.vb_sn = vb_stride_n; a.vb_sh = vb_stride_h;
+  a.req_pool_indices = req_pool_indices; a.seq_lens = seq_lens; a.extend_seq_lens = extend_seq_lens;
+  a.extend_start_loc = extend_start_loc; a.r2t_stride = max_context_len; a.indices = req_to_token; a.mode = 1;
+  a.num_heads = (int)num_heads; a.num_kv_heads = (int)num_kv_heads; a.group = (int)(num_heads / num_kv_heads);
+  a.sm_scale = sm_scale; a.logit_cap = logit_cap; a.causal = 1;  // extend.cpp is always causal
+  hipStream_t s = as_stream(stream);
+  const int D = (int)head_size, Dv = (int)head_size_v, ml = (int)max_len_extend;
+  if (dtype == SGL_MI355_BF16)
+    return req_to_token_is64 ? dispatch<SGL_MI355_BF16, int64_t>(a, num_seqs, D, Dv, ml, s)
+                             : dispatch<SGL_MI355_BF16, int32_t>(a, num_seqs, D, Dv, ml, s);
+  return req_to_token_is64 ? dispatch<SGL_MI355_FP16, int64_t>(a, num_seqs, D, Dv, ml, s)
+                           : dispatch<SGL_MI355_FP16, int32_t>(a, num_seqs, D, Dv, ml, s);
+}

@@ -85,6 +85,7 @@ __device__ __forceinline__ void wait_lgkmcnt0() { asm volatile("s_waitcnt lgkmcn
 // sits behind such a wait.  M0 (the DMA's LDS base) is written and restored inside the
 // statement because the compiler owns it.
 __device__ __forceinline__ void lds_dma16(const void* gsrc, uint32_t lds_addr) {
+  lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);  // make wave-uniformity provable ("s" operand)
   uint32_t keep;
   asm volatile(
       "s_mov_b32 %0, m0\n\t"

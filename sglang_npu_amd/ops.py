@@ -191,6 +191,64 @@ def decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_l
         _F(sm_scale), _F(logit_cap), _I(_dtype_code(q)), _stream(q)))
 
 
+# --------------------------------------------------------------------------- extend attention
+def _check3(name, t):
+    if t.dim() != 3 or t.stride(-1) != 1:
+        raise RuntimeError(f"{name} must be 3-D, contiguous at the last dimension")
+
+
+def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices,
+                         custom_mask, is_causal, mask_indptr, max_len_extend, sm_scale=None, logit_cap=0.0,
+                         sliding_window_size=-1):
+    """extend_attention_fwd(...) -- python/sglang/srt/layers/attention/triton_ops/extend_attention.py:306-438,
+    same positional arguments.  custom_mask / sliding window: not implemented (NotImplementedError)."""
+    if custom_mask is not None or mask_indptr is not None:
+        raise NotImplementedError("extend_attention_fwd: custom_mask is not implemented in the MI355X backend")
+    if sliding_window_size is not None and sliding_window_size > 0:
+        raise NotImplementedError("extend_attention_fwd: sliding window is not implemented in the MI355X backend")
+    _need_gpu(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr, kv_indptr)
+    for n, t in (("q_extend", q_extend), ("k_extend", k_extend), ("v_extend", v_extend), ("o_extend", o_extend),
+                 ("k_buffer", k_buffer), ("v_buffer", v_buffer)):
+        _check3(n, t)
+    if qo_indptr.dtype != torch.int32 or kv_indptr.dtype != torch.int32 or \
+            (kv_indices is not None and kv_indices.dtype != torch.int32):
+        raise RuntimeError("extend_attention_fwd: qo_indptr, kv_indptr and kv_indices must be int32")
+    D = q_extend.size(2)
+    sm_scale = sm_scale if sm_scale is not None else 1.0 / (D ** 0.5)
+    _lib.check(_lib.lib().sgl_mi355_extend_attention_fwd(
+        _ptr(q_extend), _ptr(k_extend), _ptr(v_extend), _ptr(o_extend), _ptr(k_buffer), _ptr(v_buffer),
+        _ptr(qo_indptr), _ptr(kv_indptr), _ptr(kv_indices), _I(1 if is_causal else 0), _I64(max_len_extend),
+        _I64(qo_indptr.numel() - 1), _I64(q_extend.size(1)), _I64(k_extend.size(1)), _I64(D), _I64(v_extend.size(2)),
+        _I64(q_extend.stride(0)), _I64(q_extend.stride(1)), _I64(k_extend.stride(0)), _I64(k_extend.stride(1)),
+        _I64(v_extend.stride(0)), _I64(v_extend.stride(1)), _I64(o_extend.stride(0)), _I64(o_extend.stride(1)),
+        _I64(k_buffer.stride(0)), _I64(k_buffer.stride(1)), _I64(v_buffer.stride(0)), _I64(v_buffer.stride(1)),
+        _F(sm_scale), _F(logit_cap), _I(_dtype_code(q_extend)), _stream(q_extend)))
+
+
+def extend_attention(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, req_to_token, req_pool_indices,
+                     seq_lens, extend_seq_lens, extend_start_loc, max_len_extend, sm_scale, logit_cap):
+    """torch.ops.sgl_kernel.extend_attention_cpu(...) argument for argument
+    -- sgl-kernel/csrc/cpu/torch_extension_cpu.cpp:269-275, extend.cpp:579-723."""
+    _need_gpu(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, req_to_token, req_pool_indices, seq_lens,
+              extend_seq_lens, extend_start_loc)
+    for n, t in (("q_extend", q_extend), ("k_extend", k_extend), ("v_extend", v_extend), ("o_extend", o_extend),
+                 ("k_buffer", k_buffer), ("v_buffer", v_buffer)):
+        _check3(n, t)
+    if req_to_token.dim() != 2 or req_to_token.stride(1) != 1 or req_to_token.stride(0) != req_to_token.size(1):
+        raise RuntimeError("extend_attention: req_to_token must be a contiguous 2-D tensor")
+    w = [t if t.dtype == torch.int64 else t.to(torch.int64)
+         for t in (req_pool_indices, seq_lens, extend_seq_lens, extend_start_loc)]
+    _lib.check(_lib.lib().sgl_mi355_extend_attention(
+        _ptr(q_extend), _ptr(k_extend), _ptr(v_extend), _ptr(o_extend), _ptr(k_buffer), _ptr(v_buffer),
+        _ptr(req_to_token), _I(_is64(req_to_token, "req_to_token")), _ptr(w[0]), _ptr(w[1]), _ptr(w[2]), _ptr(w[3]),
+        _I64(max_len_extend), _I64(w[1].numel()), _I64(req_to_token.size(1)), _I64(q_extend.size(1)),
+        _I64(k_extend.size(1)), _I64(q_extend.size(2)), _I64(v_extend.size(2)),
+        _I64(q_extend.stride(0)), _I64(q_extend.stride(1)), _I64(k_extend.stride(0)), _I64(k_extend.stride(1)),
+        _I64(v_extend.stride(0)), _I64(v_extend.stride(1)), _I64(o_extend.stride(0)), _I64(o_extend.stride(1)),
+        _I64(k_buffer.stride(0)), _I64(k_buffer.stride(1)), _I64(v_buffer.stride(0)), _I64(v_buffer.stride(1)),
+        _F(sm_scale), _F(logit_cap), _I(_dtype_code(q_extend)), _stream(q_extend)))
+
+
 # --------------------------------------------------------------------------- FP8 w8a8
 def sgl_per_token_quant_fp8(input: torch.Tensor, output_q: torch.Tensor, output_s: torch.Tensor) -> None:
     """sgl_kernel.sgl_per_token_quant_fp8(input, output_q, output_s)

@@ -62,3 +62,10 @@ def tol_for(dtype, ref_f32: torch.Tensor):
     atol = 1e-3 + ulp(dtype) * max|ref|."""
     ulp = 2.0 ** -8 if dtype in ("bf16", torch.bfloat16) else 2.0 ** -11
     return 1e-3 + ulp * float(ref_f32.abs().max())
+
+
+def tol_pair(dtype, ref: torch.Tensor):
+    """Bound for comparing TWO 16-bit results (HIP vs the oracle's 16-bit output): each carries half an
+    ulp of output rounding, so they may sit one full ulp apart: atol = 1e-3 + 2 * ulp/2 * max|ref|."""
+    ulp = 2.0 ** -7 if dtype in ("bf16", torch.bfloat16) else 2.0 ** -10
+    return 1e-3 + ulp * float(ref.float().abs().max())

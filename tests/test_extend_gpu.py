@@ -1,0 +1,155 @@
+"""GPU: ragged prefix + extend attention (HIP, through the C ABI) against the golden vectors, the
+oracle and size-independent properties."""
+import pytest
+import torch
+
+import oracle
+from conftest import golden_names, load_golden, tol_for, tol_pair
+from sglang_npu_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("name", golden_names("extend_"))
+def test_extend_op_form_vs_golden(name):
+    g = load_golden(name)
+    B, Hq, Hkv, D, Dv, max_len_extend = [int(x) for x in g["meta"]]
+    keys = ["q_extend", "k_extend", "v_extend", "k_buffer", "v_buffer", "req_to_token", "req_pool_indices", "seq_lens",
+            "extend_seq_lens", "extend_start_loc"]
+    t = {k: g[k].to(DEV) for k in keys}
+    o = torch.zeros(g["q_extend"].size(0), Hq, Dv, dtype=t["q_extend"].dtype, device=DEV)
+    ops.extend_attention(t["q_extend"], t["k_extend"], t["v_extend"], o, t["k_buffer"], t["v_buffer"],
+                         t["req_to_token"], t["req_pool_indices"], t["seq_lens"],
+                         t["extend_seq_lens"].to(torch.int32), t["extend_start_loc"].to(torch.int32), max_len_extend,
+                         g["sm_scale"], 0.0)
+    torch.cuda.synchronize()
+    bound = tol_for(g["dtype"], g["o_f32"])
+    err = (o.float().cpu() - g["o_f32"]).abs().max().item()
+    assert err <= 2 * bound, f"{name}: |hip - f32 truth| = {err:.3e} > {2 * bound:.3e}"
+    if g["ref_valid"]:
+        err_ref = (o.float().cpu() - g["o_ref"].float()).abs().max().item()
+        assert err_ref <= 2 * bound, f"{name}: |hip - reference kernel| = {err_ref:.3e}"
+
+
+def _case(B, Hq, Hkv, D, max_prefix, max_ext, dtype, seed, zero_prefix=False):
+    g = torch.Generator().manual_seed(seed)
+    prefix = torch.randint(0, max_prefix + 1, (B,), generator=g)
+    if zero_prefix:
+        prefix.zero_()
+    ext = torch.randint(1, max_ext + 1, (B,), generator=g)
+    ext[0] = max_ext
+    seq = prefix + ext
+    n_tok = int(seq.sum()) + 4
+    perm = torch.randperm(n_tok - 1, generator=g) + 1
+    r2t = torch.zeros(B, int(seq.max()), dtype=torch.int32)
+    kb = torch.randn(n_tok, Hkv, D, generator=g).to(dtype)
+    vb = torch.randn(n_tok, Hkv, D, generator=g).to(dtype)
+    T = int(ext.sum())
+    q = torch.randn(T, Hq, D, generator=g).to(dtype)
+    ke, ve = torch.empty(T, Hkv, D, dtype=dtype), torch.empty(T, Hkv, D, dtype=dtype)
+    start = torch.zeros(B, dtype=torch.int64)
+    start[1:] = torch.cumsum(ext[:-1], 0)
+    off = 0
+    for b in range(B):
+        L, p, e, s0 = int(seq[b]), int(prefix[b]), int(ext[b]), int(start[b])
+        toks = perm[off:off + L]
+        off += L
+        r2t[b, :L] = toks.to(torch.int32)
+        ke[s0:s0 + e], ve[s0:s0 + e] = kb[toks[p:]], vb[toks[p:]]
+    return dict(q=q, ke=ke, ve=ve, kb=kb, vb=vb, r2t=r2t, rpi=torch.arange(B), seq=seq, ext=ext, start=start, prefix=prefix)
+
+
+@pytest.mark.parametrize("Hq,Hkv,D", [(32, 8, 128), (8, 1, 128), (32, 32, 128), (14, 2, 64), (6, 2, 128), (3, 1, 64)])
+@pytest.mark.parametrize("zero_prefix", [False, True])
+def test_extend_backend_form_vs_oracle(Hq, Hkv, D, zero_prefix):
+    B = 4
+    dtype = torch.bfloat16
+    c = _case(B, Hq, Hkv, D, 300, 260, dtype, seed=Hq * 7 + D + int(zero_prefix), zero_prefix=zero_prefix)
+    T = c["q"].size(0)
+    o_ref = torch.zeros(T, Hq, D, dtype=dtype)
+    oracle.extend_attention(c["q"], c["ke"], c["ve"], o_ref, c["kb"], c["vb"], c["r2t"], c["rpi"], c["seq"], c["ext"],
+                            c["start"], int(c["ext"].max()), D ** -0.5, 0.0)
+    d = {k: v.to(DEV) for k, v in c.items()}
+    # Triton-form metadata exactly as triton_backend.py:284-312 builds it
+    kv_indptr = torch.zeros(B + 1, dtype=torch.int32, device=DEV)
+    kv_indptr[1:] = torch.cumsum(d["prefix"], 0)
+    kv_indices = torch.empty(max(int(c["prefix"].sum()), 1), dtype=torch.int32, device=DEV)
+    ops.create_kv_indices(d["r2t"], d["rpi"], d["prefix"], kv_indptr, None, kv_indices)
+    qo_indptr = torch.zeros(B + 1, dtype=torch.int32, device=DEV)
+    qo_indptr[1:] = torch.cumsum(d["ext"], 0)
+    o = torch.zeros(T, Hq, D, dtype=dtype, device=DEV)
+    ops.extend_attention_fwd(d["q"], d["ke"], d["ve"], o, d["kb"], d["vb"], qo_indptr, kv_indptr, kv_indices, None,
+                             True, None, int(c["ext"].max()), D ** -0.5, 0.0)
+    bound = tol_pair(dtype, o_ref)
+    err = (o.float().cpu() - o_ref.float()).abs().max().item()
+    assert err <= bound, f"|hip - oracle| = {err:.3e} > {bound:.3e}"
+
+
+def test_extend_long_prefix_multi_pass_and_fp16_cap():
+    # prefix > 4096 page-table entries exercises the multi-pass staging; fp16 + logit cap + int64 table
+    B, Hq, Hkv, D = 2, 8, 2, 128
+    dtype = torch.float16
+    c = _case(B, Hq, Hkv, D, 4500, 70, dtype, seed=3)
+    c["prefix"][0] = 4500
+    c = _case(B, Hq, Hkv, D, 4500, 70, dtype, seed=4)
+    T = c["q"].size(0)
+    o_ref = torch.zeros(T, Hq, D, dtype=dtype)
+    oracle.extend_attention(c["q"], c["ke"], c["ve"], o_ref, c["kb"], c["vb"], c["r2t"], c["rpi"], c["seq"], c["ext"],
+                            c["start"], int(c["ext"].max()), 0.2, 25.0)
+    d = {k: v.to(DEV) for k, v in c.items()}
+    o = torch.zeros(T, Hq, D, dtype=dtype, device=DEV)
+    ops.extend_attention(d["q"], d["ke"], d["ve"], o, d["kb"], d["vb"], d["r2t"].long(), d["rpi"], d["seq"], d["ext"],
+                         d["start"], int(c["ext"].max()), 0.2, 25.0)
+    assert (o.float().cpu() - o_ref.float()).abs().max().item() <= tol_pair(dtype, o_ref)
+
+
+def test_extend_full_size_properties():
+    """Prefill-sized case (Llama-3-8B geometry, 4 x 2048 new tokens + cached prefixes) on the GPU only:
+      (1) chunked prefill is consistent: extending [0:L) in one go equals extending the second half with the
+          first half as cached prefix (same keys, different kernel stage) to within one ulp;
+      (2) the last row of each request equals single-token decode over the same keys;
+      (3) a bounded sample of rows agrees with the oracle."""
+    B, Hq, Hkv, D, L = 4, 32, 8, 128, 2048
+    dtype = torch.bfloat16
+    g = torch.Generator(device=DEV).manual_seed(5)
+    n_tok = B * L + 1
+    kb = torch.randn(n_tok, Hkv, D, device=DEV, generator=g).to(dtype)
+    vb = torch.randn(n_tok, Hkv, D, device=DEV, generator=g).to(dtype)
+    r2t = (torch.randperm(n_tok - 1, device=DEV, generator=g) + 1).view(B, L).to(torch.int32)
+    q = torch.randn(B * L, Hq, D, device=DEV, generator=g).to(dtype)
+    ke = kb[r2t.long().view(-1)].contiguous()
+    ve = vb[r2t.long().view(-1)].contiguous()
+    rpi = torch.arange(B, device=DEV)
+    full = torch.full((B,), L, device=DEV)
+    start = torch.arange(B, device=DEV) * L
+    o_full = torch.zeros(B * L, Hq, D, dtype=dtype, device=DEV)
+    ops.extend_attention(q, ke, ve, o_full, kb, vb, r2t, rpi, full, full, start, L, D ** -0.5, 0.0)
+    # (1) second half with the first half cached
+    h = L // 2
+    sel = (torch.arange(B, device=DEV)[:, None] * L + h + torch.arange(h, device=DEV)[None]).view(-1)
+    o_half = torch.zeros(B * h, Hq, D, dtype=dtype, device=DEV)
+    ops.extend_attention(q[sel].contiguous(), ke[sel].contiguous(), ve[sel].contiguous(), o_half, kb, vb, r2t, rpi,
+                         full, torch.full((B,), h, device=DEV), torch.arange(B, device=DEV) * h, h, D ** -0.5, 0.0)
+    bound = tol_pair(dtype, o_full)
+    assert (o_half.float() - o_full[sel].float()).abs().max().item() <= bound
+    # (2) last row == decode
+    last = start + L - 1
+    o_dec = torch.zeros(B, Hq, D, dtype=dtype, device=DEV)
+    ops.decode_attention(q[last].contiguous(), kb, vb, o_dec, None, None, None, torch.zeros(B, Hq, 1, D + 1, device=DEV),
+                         r2t, rpi, full, D ** -0.5, 0.0)
+    assert (o_dec.float() - o_full[last].float()).abs().max().item() <= bound
+    # (3) oracle on one short slice: request 1, rows [0, 96)
+    rows = 96
+    o_ref = torch.zeros(rows, Hq, D, dtype=dtype)
+    oracle.extend_attention(q[L:L + rows].cpu(), ke[L:L + rows].cpu(), ve[L:L + rows].cpu(), o_ref, kb.cpu(), vb.cpu(),
+                            r2t.cpu(), torch.tensor([1]), torch.tensor([rows]), torch.tensor([rows]), torch.tensor([0]),
+                            rows, D ** -0.5, 0.0)
+    assert (o_full[L:L + rows].float().cpu() - o_ref.float()).abs().max().item() <= tol_pair(dtype, o_ref)
+
+
+def test_extend_rejects_custom_mask():
+    x = torch.zeros(1, 1, 64, dtype=torch.bfloat16, device=DEV)
+    i = torch.zeros(2, dtype=torch.int32, device=DEV)
+    with pytest.raises(NotImplementedError):
+        ops.extend_attention_fwd(x, x, x, x, x, x, i, i, i, torch.zeros(1, device=DEV), True, None, 1)
