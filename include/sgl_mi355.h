@@ -192,6 +192,23 @@ int sgl_mi355_fp8_scaled_mm(
     int64_t M, int64_t N, int64_t K, int64_t a_stride_m, int64_t b_stride_n, int out_dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * AWQ INT4 (group-wise zero-point) weight-only path.
+ * Replaces: awq_dequantize(Tensor qweight, Tensor scales, Tensor qzeros) -> Tensor
+ *           schema sgl-kernel/csrc/common_extension.cc:98-130, impl sgl-kernel/csrc/gemm/awq_kernel.cu:126-221
+ *           (HIP path today: awq_dequantize_triton, layers/quantization/awq_triton.py:13-107)
+ *   qweight int32 [K, N/8]; qzeros int32 [K/G, N/8]; scales fp16/bf16 [K/G, N]; out [K, N] in the scales dtype
+ *   out[k][8c+j] = (nib(qweight[k][c], ORDER[j]) - nib(qzeros[k/G][c], ORDER[j])) * scales[k/G][8c+j],
+ *   ORDER = [0,4,1,5,2,6,3,7].  Bit-exact.
+ * and:     AWQLinearMethod.apply, python/sglang/srt/layers/quantization/awq.py:401-418
+ *   out = x @ awq_dequantize(...) (+ bias), with the dequant fused into the GEMM main loop (M <= 64);
+ *   `workspace` (fp32, >= 16*M*N floats for full freedom, may be NULL) holds split-K partials. */
+int sgl_mi355_awq_dequantize(const int32_t* qweight, const void* scales, const int32_t* qzeros, void* out,
+                             int64_t K, int64_t N, int64_t group_size, int dtype, void* stream);
+int sgl_mi355_awq_gemm(const void* x, const int32_t* qweight, const void* scales, const int32_t* qzeros,
+                       const void* bias, void* out, float* workspace, int64_t workspace_floats,
+                       int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Elementwise ops around the hot path.
  * Replace: sgl_kernel.rmsnorm / fused_add_rmsnorm / silu_and_mul /
  *          apply_rope_with_cos_sin_cache_inplace as called from

@@ -77,9 +77,12 @@ class GroupCoordinator:
             return input_
         if dim < 0:
             dim += input_.dim()
-        out = torch.empty((self.world_size,) + tuple(input_.shape), dtype=input_.dtype, device=input_.device)
-        dist.all_gather_into_tensor(out, input_.contiguous(), group=self.device_group)
-        out = out.movedim(0, dim)
+        inp = input_.contiguous()
+        if inp.dim() == 0:
+            inp = inp.view(1)
+        flat = torch.empty((self.world_size * inp.shape[0],) + tuple(inp.shape[1:]), dtype=inp.dtype, device=inp.device)
+        dist.all_gather_into_tensor(flat, inp, group=self.device_group)
+        out = flat.view((self.world_size,) + tuple(input_.shape)).movedim(0, dim)
         shape = list(input_.shape)
         shape[dim] *= self.world_size
         return out.reshape(shape)

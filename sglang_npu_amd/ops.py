@@ -301,6 +301,56 @@ def fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None) -> tor
     return out
 
 
+# --------------------------------------------------------------------------- AWQ INT4
+def awq_dequantize(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tensor) -> torch.Tensor:
+    """sgl_kernel.awq_dequantize(qweight, scales, qzeros) -- sgl-kernel/python/sgl_kernel/gemm.py:7-12,
+    awq_kernel.cu:186-221.  group_size = K // scales.size(0) as in the reference."""
+    _need_gpu(qweight, scales, qzeros)
+    if qweight.dtype != torch.int32 or qzeros.dtype != torch.int32:
+        raise RuntimeError("awq_dequantize: qweight and qzeros must be int32")
+    if not (qweight.is_contiguous() and scales.is_contiguous() and qzeros.is_contiguous()):
+        raise RuntimeError("awq_dequantize: tensors must be contiguous")
+    K, Nc = qweight.shape
+    if scales.size(0) == 0 or K % scales.size(0) != 0 or scales.size(1) != Nc * 8 or qzeros.shape != (scales.size(0), Nc):
+        raise RuntimeError("awq_dequantize: inconsistent shapes")
+    out = torch.empty((K, Nc * 8), dtype=scales.dtype, device=scales.device)
+    _lib.check(_lib.lib().sgl_mi355_awq_dequantize(_ptr(qweight), _ptr(scales), _ptr(qzeros), _ptr(out), _I64(K),
+                                                   _I64(Nc * 8), _I64(K // scales.size(0)), _I(_dtype_code(scales)),
+                                                   _stream(scales)))
+    return out
+
+
+_awq_workspace = {}
+
+
+def awq_gemm(x: torch.Tensor, qweight, scales, qzeros, bias=None) -> torch.Tensor:
+    """AWQLinearMethod.apply body (awq.py:413-417): x [M,K] @ dequant(qweight) (+ bias).  M <= 64 runs the
+    fused dequant-GEMM kernel; larger M dequantises once and uses the plain library GEMM, as the reference does."""
+    _need_gpu(x, qweight, scales, qzeros, bias)
+    if x.dim() != 2 or not x.is_contiguous() or x.dtype != scales.dtype:
+        raise RuntimeError("awq_gemm: x must be a contiguous [M,K] tensor in the scales dtype")
+    M, K = x.shape
+    N = qweight.size(1) * 8
+    if qweight.size(0) != K:
+        raise RuntimeError("awq_gemm: x and qweight shapes cannot be multiplied")
+    G = K // scales.size(0)
+    if M > 64 or N % 32 or K % 32 or G % 32:
+        out = torch.matmul(x, awq_dequantize(qweight, scales, qzeros))
+        if bias is not None:
+            out.add_(bias)
+        return out
+    out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    need = 16 * M * N
+    ws = _awq_workspace.get(x.device)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 16 * 64 * 4096), dtype=torch.float32, device=x.device)
+        _awq_workspace[x.device] = ws
+    _lib.check(_lib.lib().sgl_mi355_awq_gemm(_ptr(x), _ptr(qweight), _ptr(scales), _ptr(qzeros), _ptr(bias), _ptr(out),
+                                             _ptr(ws), _I64(ws.numel()), _I64(M), _I64(N), _I64(K), _I64(G),
+                                             _I(_dtype_code(x)), _stream(x)))
+    return out
+
+
 # --------------------------------------------------------------------------- elementwise ("next" rows)
 def _rows(x):
     if x.dim() < 1 or not x.is_contiguous():

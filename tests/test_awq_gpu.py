@@ -1,0 +1,64 @@
+"""GPU: AWQ INT4 dequant (bit-exact) and the fused dequant-GEMM vs golden vectors and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from sglang_npu_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _h(arr, dtype):
+    t = torch.from_numpy(arr.view(np.int16).copy())
+    return t.view(torch.bfloat16 if dtype == "bf16" else torch.float16)
+
+
+def test_awq_golden_dequant_exact_and_gemm():
+    z = np.load("tests/golden/awq.npz")
+    for i in range(int(z["n"])):
+        dtype = z[f"dtype{i}"].item().decode()
+        qw, qz = torch.from_numpy(z[f"qweight{i}"]).to(DEV), torch.from_numpy(z[f"qzeros{i}"]).to(DEV)
+        sc = _h(z[f"scales{i}"], dtype).to(DEV)
+        w = ops.awq_dequantize(qw, sc, qz)
+        assert torch.equal(w.cpu().view(torch.int16), torch.from_numpy(z[f"w{i}"].view(np.int16).copy())), "dequant must be exact"
+        x = _h(z[f"x{i}"], dtype).to(DEV)
+        y = ops.awq_gemm(x, qw, sc, qz)
+        torch.testing.assert_close(y.float().cpu(), torch.from_numpy(z[f"y_f32_{i}"]),
+                                   rtol=2.0 ** (-7 if dtype == "bf16" else -10), atol=1e-2)
+
+
+# (K, N/8) from sgl-kernel/tests/test_awq_dequant.py:70-71 (subset) + Llama-2-7B layer shapes
+@pytest.mark.parametrize("K,Nc,G", [(128, 16, 128), (3584, 448, 3584), (1536, 72, 128), (4096, 512, 128), (11008, 512, 128),
+                                    (512, 4736, 512)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_awq_dequantize_vs_oracle_exact(K, Nc, G, dtype):
+    g = torch.Generator().manual_seed(K + Nc)
+    imax = torch.iinfo(torch.int32).max
+    qw = torch.randint(0, imax, (K, Nc), dtype=torch.int32, generator=g)
+    qz = torch.randint(0, imax, (K // G, Nc), dtype=torch.int32, generator=g)
+    sc = torch.rand(K // G, Nc * 8, generator=g).to(dtype)
+    ref = oracle.awq_dequantize(qw, sc, qz)
+    out = ops.awq_dequantize(qw.to(DEV), sc.to(DEV), qz.to(DEV))
+    assert torch.equal(out.cpu().view(torch.int16), ref.view(torch.int16))
+
+
+@pytest.mark.parametrize("M", [1, 5, 16, 33, 64, 100])
+@pytest.mark.parametrize("K,N", [(4096, 4096), (4096, 12288), (11008, 4096), (256, 128), (4096, 22016)])
+def test_awq_gemm_vs_oracle(M, K, N):
+    if M > 16 and K * N > 5e7:
+        pytest.skip("oracle too slow")
+    dtype = torch.float16
+    g = torch.Generator().manual_seed(M + K + N)
+    imax = torch.iinfo(torch.int32).max
+    G = 128
+    qw = torch.randint(0, imax, (K, N // 8), dtype=torch.int32, generator=g)
+    qz = torch.randint(0, imax, (K // G, N // 8), dtype=torch.int32, generator=g)
+    sc = (torch.rand(K // G, N, generator=g) * 2e-2).to(dtype)
+    x = torch.randn(M, K, generator=g).to(dtype)
+    bias = torch.randn(N, generator=g).to(dtype) if M % 2 else None
+    ref = oracle.awq_gemm(x, qw, sc, qz, bias)
+    out = ops.awq_gemm(x.to(DEV), qw.to(DEV), sc.to(DEV), qz.to(DEV), bias.to(DEV) if bias is not None else None)
+    # fp32 accumulation of identical fp16 operands: summation order only -> 1 output ulp (+ bias rounding)
+    torch.testing.assert_close(out.float().cpu(), ref.float(), rtol=2.0 ** -10, atol=2e-3 * float(ref.float().abs().max()))

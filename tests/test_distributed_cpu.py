@@ -1,0 +1,86 @@
+"""CPU: the N>1 path (TP group, all-reduce / all-gather, row/column-parallel linears) on world_size-2 gloo."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from sglang_npu_amd import distributed as D
+    from sglang_npu_amd.linear import MergedColumnParallelLinear, QKVParallelLinear, RowParallelLinear
+    try:
+        tp = D.init_distributed_environment(backend="gloo")
+        assert tp.world_size == world and D.get_tensor_model_parallel_rank() == rank
+        # integer-valued payloads: the sum is exact whatever the algorithm (test_custom_allreduce.py:118)
+        for n in (1, 128, 4097, 1 << 16):
+            for dt in (torch.float32, torch.bfloat16, torch.float16):
+                x = torch.randint(0, 4, (n,), generator=torch.Generator().manual_seed(rank)).to(dt)
+                ref = sum(torch.randint(0, 4, (n,), generator=torch.Generator().manual_seed(r)).to(dt) for r in range(world))
+                out = D.tensor_model_parallel_all_reduce(x.clone())
+                assert torch.equal(out, ref), (n, dt)
+                h = tp.all_reduce_async(x.clone())
+                assert torch.equal(h.wait(), ref)
+        g = D.tensor_model_parallel_all_gather(torch.full((3, 2), float(rank)), dim=-1)
+        assert g.shape == (3, 2 * world) and torch.equal(g[:, 2 * rank], torch.full((3,), float(rank)))
+        # row-parallel (K split + all-reduce) o column-parallel (N split) == the unsharded product
+        gen = torch.Generator().manual_seed(0)
+        K, N = 64, 48
+        w1, w2 = torch.randn(N, K, generator=gen), torch.randn(K, N, generator=gen)
+        x = torch.randn(5, K, generator=gen)
+        col = MergedColumnParallelLinear(K, [N // 2, N // 2], params_dtype=torch.float32)
+        half = N // 2 // world
+        col.weight.data = torch.cat([w1[rank * half:(rank + 1) * half], w1[N // 2 + rank * half: N // 2 + (rank + 1) * half]])
+        row = RowParallelLinear(N, K, params_dtype=torch.float32)
+        perm = torch.cat([torch.arange(r * half, (r + 1) * half) for r in range(world)] +
+                         [N // 2 + torch.arange(r * half, (r + 1) * half) for r in range(world)])
+        cols_mine = torch.cat([torch.arange(rank * half, (rank + 1) * half), N // 2 + torch.arange(rank * half, (rank + 1) * half)])
+        row.weight.data = w2[:, cols_mine].contiguous()
+        y, _ = col(x)
+        z, _ = row(y)
+        ref = (x @ w1.t()) @ w2.t()
+        torch.testing.assert_close(z, ref, rtol=1e-4, atol=1e-4)
+        qkv = QKVParallelLinear(64, 16, 8, 1, params_dtype=torch.float32)  # fewer KV heads than ranks -> replicated
+        assert qkv.num_heads == 8 // world and qkv.num_kv_heads == 1
+        assert qkv.output_partition_sizes == [8 * 16 // world, 16, 16]
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        if torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_tp2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=150) for _ in procs]
+    for p in procs:
+        p.join(30)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}: {msg}"
+
+
+def test_single_rank_all_reduce_is_identity():
+    from sglang_npu_amd import distributed as D
+    D.set_tp_group(D.GroupCoordinator(None, 0, 1, None))
+    x = torch.arange(8.0)
+    assert D.tensor_model_parallel_all_reduce(x) is x  # parallel_state.py:478-479
