@@ -33,7 +33,7 @@ extern "C" {
 #define SGL_MI355_ERR_RUNTIME 3          /* a HIP runtime call failed                */
 
 /* ABI version of this header; bumped on any signature change. */
-#define SGL_MI355_ABI_VERSION 1
+#define SGL_MI355_ABI_VERSION 2
 int sgl_mi355_abi_version(void);
 
 /* Copies the calling thread's last error message (NUL-terminated) into buf. Returns its length. */
@@ -186,9 +186,11 @@ int sgl_mi355_per_token_quant_fp8(
  *   stride(0) == 1, i.e. passed as its K-major storage W[N][K] (b_stride_n bytes between
  *   columns); scales fp32 contiguous [M] / [N]; bias [N] in out dtype or NULL; out [M,N]
  *   contiguous bf16/fp16.  K % 16 == 0 and (N*2) % 16 == 0 as in the reference
- *   (fp8_gemm_kernel.cu:1086-1089,1108). */
+ *   (fp8_gemm_kernel.cu:1086-1089,1108).  `workspace` (fp32, caller-owned, may be NULL) lets the
+ *   M <= 64 path keep split-K partials: ceil(K/2048) * M * N floats are enough. */
 int sgl_mi355_fp8_scaled_mm(
     const void* mat_a, const void* mat_b, const float* scales_a, const float* scales_b, const void* bias, void* out,
+    float* workspace, int64_t workspace_floats,
     int64_t M, int64_t N, int64_t K, int64_t a_stride_m, int64_t b_stride_n, int out_dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -25,6 +25,9 @@
 //     epilogue with 16-B stores.
 // The MFMA k index is contracted, so both kernels hand lane group g the contiguous 32 B
 // [32g, 32g+32) of each 128-wide k-step (four MFMAs' worth) -- the same permutation on A and B.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace sglm {
@@ -95,31 +98,37 @@ __device__ __forceinline__ void load32(Frag32& f, const uint8_t* p, int k, int k
   f.v[1] = (row_ok && k + 16 < kend) ? *reinterpret_cast<const uint4*>(p + k + 16) : uint4{0, 0, 0, 0};
 }
 
-// skinny: M <= 16*MB.  Workgroup = WN*WK waves: WN column blocks of 16, K split WK ways.
-template <int OUT_DTYPE, int MB, int WN, int WK>
-__global__ __launch_bounds__(64 * WN * WK) void fp8_gemm_skinny_kernel(GemmArgs p) {
+// skinny: M <= 16*MB.  Workgroup = WK waves splitting K; every wave owns NB column blocks of 16
+// (the same activation fragment feeds NB MFMAs, so the L2 traffic for A is 1/NB of the weight stream).
+template <int OUT_DTYPE, int MB, int NB, int WK>
+__global__ __launch_bounds__(64 * WK) void fp8_gemm_skinny_kernel(GemmArgs p) {
   using H = Half16<OUT_DTYPE>;
   using T = typename H::T;
-  constexpr int PB = 4;  // weight prefetch distance in k-steps
+  constexpr int PB = (MB * NB >= 8) ? 2 : 4;  // prefetch distance in k-steps (register budget)
+  constexpr int COLS = 16 * NB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* red = reinterpret_cast<float*>(smem);  // [WK][WN][MB*16][16]
+  float* red = reinterpret_cast<float*>(smem);  // [WK][MB*16][COLS]
 
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wn = wave % WN, wk = wave / WN;
+  const int wk = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r16 = lane & 15, g = lane >> 4;
-  const int n0 = (blockIdx.x * WN + wn) * 16;
-  const int n = n0 + r16;
-  const bool n_ok = n < p.N;
+  const int n0 = blockIdx.x * COLS;
 
   // this wave's K range, in 128-wide steps
   const int steps_total = (p.K + 127) >> 7;
   const int steps_per = (steps_total + WK - 1) / WK;
   const int s_begin = wk * steps_per;
   const int s_end = (s_begin + steps_per) < steps_total ? (s_begin + steps_per) : steps_total;
-  const int nsteps = s_end - s_begin;
+  const int nsteps = s_end > s_begin ? s_end - s_begin : 0;
 
-  const uint8_t* brow = p.b + (int64_t)(n_ok ? n : 0) * p.b_sn + 32 * g;
+  const uint8_t* brow[NB];
+  bool n_ok[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int n = n0 + 16 * nb + r16;
+    n_ok[nb] = n < p.N;
+    brow[nb] = p.b + (int64_t)(n_ok[nb] ? n : 0) * p.b_sn + 32 * g;
+  }
   const uint8_t* arow[MB];
   bool a_ok[MB];
 #pragma unroll
@@ -129,71 +138,92 @@ __global__ __launch_bounds__(64 * WN * WK) void fp8_gemm_skinny_kernel(GemmArgs 
     arow[mb] = p.a + (int64_t)(a_ok[mb] ? m : 0) * p.a_sm + 32 * g;
   }
 
-  f32x4 acc[MB];
+  f32x4 acc[MB][NB];
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // The k sum is order-free, so every column block starts its sweep at a different k-step:
   // weight rows are K bytes apart, and a chip full of waves all reading the same residue
   // mod 4 KiB would camp on a few HBM channels.
-  const int rot = nsteps > 0 ? (int)((blockIdx.x * 5u + wn * 3u) % (unsigned)nsteps) : 0;
+  const int rot = nsteps > 0 ? (int)((blockIdx.x * 5u) % (unsigned)nsteps) : 0;
   auto kof = [&](int s) {
     int t = s + rot;
     t = t >= nsteps ? t - nsteps : t;
     return (s_begin + t) << 7;
   };
+  const int kend = p.K - 32 * g;
 
-  Frag32 bq[PB];
+  // Software pipeline.  vmcnt retires IN ORDER, so consuming any load waits for every older one: the
+  // activation fragments (L2-fast) must therefore be issued together with the weights of the SAME
+  // future step -- otherwise using A(s) would drain the younger-than-needed weight prefetches and the
+  // effective prefetch distance collapses to one step.  Both operands are PB steps ahead.
+  Frag32 bq[PB][NB];
+  Frag32 aq[PB][MB];
 #pragma unroll
   for (int i = 0; i < PB; ++i)
-    if (i < nsteps) load32(bq[i], brow, kof(i), p.K - 32 * g, n_ok);
+    if (i < nsteps) {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) load32(aq[i][mb], arow[mb], kof(i), kend, a_ok[mb]);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) load32(bq[i][nb], brow[nb], kof(i), kend, n_ok[nb]);
+    }
 
   for (int s0 = 0; s0 < nsteps; s0 += PB) {
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
       const int s = s0 + i;
       if (s < nsteps) {
-        const int k = kof(s);
-        Frag32 af[MB];
+        Frag32 af[MB], bf[NB];
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) load32(af[mb], arow[mb], k, p.K - 32 * g, a_ok[mb]);
-        const Frag32 bf = bq[i];
-        if (s + PB < nsteps) load32(bq[i], brow, kof(s + PB), p.K - 32 * g, n_ok);
+        for (int mb = 0; mb < MB; ++mb) af[mb] = aq[i][mb];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int nb = 0; nb < NB; ++nb) bf[nb] = bq[i][nb];
+        if (s + PB < nsteps) {
+          const int kn = kof(s + PB);
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) load32(aq[i][mb], arow[mb], kn, kend, a_ok[mb]);
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) load32(bq[i][nb], brow[nb], kn, kend, n_ok[nb]);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
           for (int mb = 0; mb < MB; ++mb)
-            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(af[mb].l[ks], bf.l[ks], acc[mb], 0, 0, 0);
-        }
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+              acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(af[mb].l[ks], bf[nb].l[ks], acc[mb][nb], 0, 0, 0);
       }
     }
   }
 
   // ---- cross-wave K reduction + transposed epilogue through LDS
-  // acc[mb][r] = C[m = 16mb + 4g + r][n = n0 + r16]
+  // acc[mb][nb][r] = C[m = 16mb + 4g + r][n = n0 + 16nb + r16]
+  constexpr int ROWS = MB * 16;
   {
-    float* dst = red + ((wk * WN + wn) * MB * 16) * 16;
+    float* dst = red + wk * ROWS * COLS;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) dst[(16 * mb + 4 * g + r) * 16 + r16] = acc[mb][r];
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[(16 * mb + 4 * g + r) * COLS + 16 * nb + r16] = acc[mb][nb][r];
   }
   __syncthreads();
   // each thread finishes 8 consecutive columns of one row
-  constexpr int ROWS = MB * 16;
-  constexpr int CHUNKS = ROWS * WN * 2;
-  for (int c = threadIdx.x; c < CHUNKS; c += 64 * WN * WK) {
-    const int half = c & 1;
-    const int w = (c >> 1) % WN;
-    const int m = (c >> 1) / WN;
-    const int nn = (blockIdx.x * WN + w) * 16 + half * 8;
+  constexpr int CHUNKS = ROWS * (COLS / 8);
+  for (int c = threadIdx.x; c < CHUNKS; c += 64 * WK) {
+    const int m = c / (COLS / 8);
+    const int cc = (c - m * (COLS / 8)) * 8;
+    const int nn = n0 + cc;
     if (m >= p.M || nn >= p.N) continue;
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = 0.f;
 #pragma unroll
     for (int kk = 0; kk < WK; ++kk) {
-      const float* src = red + ((kk * WN + w) * ROWS + m) * 16 + half * 8;
+      const float* src = red + (kk * ROWS + m) * COLS + cc;
       const f32x4 lo = *reinterpret_cast<const f32x4*>(src);
       const f32x4 hi = *reinterpret_cast<const f32x4*>(src + 4);
 #pragma unroll
@@ -213,6 +243,202 @@ __global__ __launch_bounds__(64 * WN * WK) void fp8_gemm_skinny_kernel(GemmArgs 
     }
     *reinterpret_cast<typename H::x8*>(reinterpret_cast<T*>(p.out) + (int64_t)m * p.N + nn) = o;
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// A-stationary skinny GEMM (M <= 64): the decode-time weight streamer.
+//
+// Measured on the register-only kernel above: at M = 64 it is bound by the ACTIVATION loads, not by
+// HBM -- every wave re-fetches fragment-shaped pieces of A (16 rows x 16 B per instruction) from L2
+// and the texture-address path saturates long before the weight stream does.  160 KB of LDS per CU
+// changes the structure: one persistent workgroup per CU keeps its K-slice of A (<= 64 x 2048 B)
+// resident in LDS for the whole kernel, in the fragment-major image the MFMA wants, and its 16 waves
+// then do nothing but stream weights: each wave walks its own column blocks, 4 k-steps of 2 KB ahead
+// (full 128-B lines), reading A fragments by conflict-free ds_read_b128.  No cross-wave reduction, no
+// barrier after the fill.  K is split over SK workgroup classes (fp32 slabs, summed by the epilogue
+// kernel that also applies the scales / bias) so that the slice fits LDS and 256 CUs have work.
+constexpr int kAsWaves = 16;
+
+template <int MB>
+struct AStat {
+  static constexpr int ROWS = 16 * MB;
+  static constexpr int REGION = ROWS * 32 + 16;   // one 32-B k-chunk column of a step, +16 B skew
+  static constexpr int STEP_BYTES = 4 * REGION;   // 128 k per step
+  static constexpr int MAX_STEPS = (150 * 1024) / STEP_BYTES;
+};
+
+template <int MB>
+__global__ __launch_bounds__(64 * kAsWaves) void fp8_gemm_astat_kernel(GemmArgs p, float* slabs, int SK, int steps_per_slice) {
+  using L = AStat<MB>;
+  constexpr int PB = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g = lane >> 4;
+  const int ks = blockIdx.x % SK;
+  const int ng = blockIdx.x / SK;
+  const int ngroups = gridDim.x / SK;
+  const int nwaves = blockDim.x >> 6;
+  const int steps_total = (p.K + 127) >> 7;
+  const int st_begin = ks * steps_per_slice;
+  const int nsteps = (st_begin + steps_per_slice) <= steps_total ? steps_per_slice : (steps_total - st_begin);
+  if (nsteps <= 0) return;  // workgroup-uniform
+  const int k_begin = st_begin << 7;
+
+  // ---- this wave's flat work list: column blocks gw, gw + stride, ... times nsteps k-steps
+  const int nblocks = (p.N + 15) >> 4;
+  const int gw = ng * nwaves + wave;
+  const int stride = ngroups * nwaves;
+  const int my_blocks = gw < nblocks ? (nblocks - gw + stride - 1) / stride : 0;
+  const int total_f = my_blocks * nsteps;
+  const int kend = p.K - 32 * g;
+
+  auto issue = [&](Frag32& f, int fi) __attribute__((always_inline)) {
+    const int bi = fi / nsteps;
+    const int st = fi - bi * nsteps;
+    const int n = (gw + bi * stride) * 16 + r16;
+    const bool ok = n < p.N;
+    load32(f, p.b + (int64_t)(ok ? n : 0) * p.b_sn + 32 * g, k_begin + (st << 7), kend, ok);
+  };
+
+  // the first weight loads go out BEFORE the A fill: they do not depend on it and their HBM latency
+  // then overlaps the fill
+  Frag32 bq[PB];
+#pragma unroll
+  for (int i = 0; i < PB; ++i)
+    if (i < total_f) issue(bq[i], i);
+
+
+  // ---- fill: A[0:ROWS][k_begin : k_begin + nsteps*128] -> LDS, fragment-major
+  {
+    const int per_row = nsteps * 8;  // 16-B chunks per row
+    const int total = L::ROWS * per_row;
+    for (int idx = tid; idx < total; idx += blockDim.x) {
+      const int row = idx / per_row;
+      const int c = idx - row * per_row;
+      const int st = c >> 3, j = c & 7;
+      const int k = k_begin + c * 16;
+      uint4 v = uint4{0, 0, 0, 0};
+      if (row < p.M && k < p.K) v = *reinterpret_cast<const uint4*>(p.a + (int64_t)row * p.a_sm + k);
+      *reinterpret_cast<uint4*>(smem + st * L::STEP_BYTES + (j >> 1) * L::REGION + row * 32 + (j & 1) * 16) = v;
+    }
+  }
+  __syncthreads();
+
+  f32x4 acc[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const char* abase = smem + g * L::REGION + r16 * 32;
+  int st = 0, bi = 0;
+  for (int f0 = 0; f0 < total_f; f0 += PB) {
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      const int f = f0 + i;
+      if (f < total_f) {
+        const Frag32 bf = bq[i];
+        if (f + PB < total_f) issue(bq[i], f + PB);
+        const char* ap = abase + st * L::STEP_BYTES;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          Frag32 af;
+          af.v[0] = *reinterpret_cast<const uint4*>(ap + mb * 512);
+          af.v[1] = *reinterpret_cast<const uint4*>(ap + mb * 512 + 16);
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk)
+            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(af.l[kk], bf.l[kk], acc[mb], 0, 0, 0);
+        }
+        if (++st == nsteps) {
+          // column block finished: acc[mb][r] = C[m = 16mb + 4g + r][n]; store the fp32 partial
+          const int n = (gw + bi * stride) * 16 + r16;
+          if (n < p.N) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int m = 16 * mb + 4 * g + r;
+                if (m < p.M) slabs[((int64_t)ks * p.M + m) * p.N + n] = acc[mb][r];
+              }
+          }
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+          st = 0;
+          ++bi;
+        }
+      }
+    }
+  }
+}
+
+// epilogue of the A-stationary kernel: sum the K-slices, then the reference's epilogue
+// (fp8_gemm_kernel.cu:498-546): * w_scale[col], * x_scale[row], + bias, cast.
+template <int OUT_DTYPE>
+__global__ __launch_bounds__(256) void fp8_gemm_finalize_kernel(GemmArgs p, const float* slabs, int SK) {
+  using H = Half16<OUT_DTYPE>;
+  using T = typename H::T;
+  const int64_t total = (int64_t)p.M * p.N / 8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int s = 0; s < SK; ++s) {
+      const float* src = slabs + (int64_t)s * p.M * p.N + i * 8;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] += a[j];
+        v[4 + j] += b[j];
+      }
+    }
+    const int64_t e = i * 8;
+    const int m = (int)(e / p.N), n = (int)(e - (int64_t)m * p.N);
+    const float sa = p.sa[m];
+    typename H::x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float r = v[j] * p.sb[n + j] * sa;
+      if (p.bias) r += H::to_f32(reinterpret_cast<const T*>(p.bias)[n + j]);
+      o[j] = H::from_f32(r);
+    }
+    *reinterpret_cast<typename H::x8*>(reinterpret_cast<T*>(p.out) + e) = o;
+  }
+}
+
+template <int OUT_DTYPE, int MB>
+int launch_astat(const GemmArgs& p, float* slabs, int64_t slab_floats, hipStream_t s, bool& used) {
+  using L = AStat<MB>;
+  const int steps_total = (p.K + 127) >> 7;
+  const int nblocks = (p.N + 15) / 16;
+  // K-slices: at least enough for the slice of A to fit LDS; more when N is narrow, so that there are
+  // >= ~2048 (column block, slice) items for 256 CUs x 8+ waves -- but never below 4 k-steps per item.
+  int SK = (steps_total + L::MAX_STEPS - 1) / L::MAX_STEPS;
+  const int want = (2048 + nblocks - 1) / nblocks;
+  if (SK < want) SK = want;
+  if (SK > steps_total / 4) SK = steps_total / 4;
+  if (SK < 1) SK = 1;
+  const int steps_per_slice = (steps_total + SK - 1) / SK;
+  SK = (steps_total + steps_per_slice - 1) / steps_per_slice;
+  used = false;
+  if (steps_per_slice > L::MAX_STEPS) return 0;
+  if (slabs == nullptr || slab_floats < (int64_t)SK * p.M * p.N) return 0;
+  int ngroups = 256 / SK;
+  if (ngroups > nblocks) ngroups = nblocks;
+  if (ngroups < 1) ngroups = 1;
+  int nwaves = (nblocks + ngroups - 1) / ngroups;
+  if (nwaves > kAsWaves) nwaves = kAsWaves;
+  auto kern = fp8_gemm_astat_kernel<MB>;
+  const int lds = steps_per_slice * L::STEP_BYTES;
+  static int attr_rc = check_hip(
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+      "hipFuncSetAttribute");
+  if (attr_rc) return attr_rc;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(ngroups * SK)), dim3(64 * nwaves), lds, s, p, slabs, SK, steps_per_slice);
+  int rc = check_hip(hipGetLastError(), "fp8_gemm_astat launch");
+  if (rc) return rc;
+  const int64_t total = (int64_t)p.M * p.N / 8;
+  hipLaunchKernelGGL((fp8_gemm_finalize_kernel<OUT_DTYPE>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p,
+                     (const float*)slabs, SK);
+  used = true;
+  return check_hip(hipGetLastError(), "fp8_gemm_finalize launch");
 }
 
 // ------------------------------------------------------------------------------------------
@@ -362,28 +588,56 @@ __global__ __launch_bounds__(256) void fp8_gemm_tiled_kernel(GemmArgs p) {
   }
 }
 
-template <int OUT_DTYPE, int MB, int WN, int WK>
+template <int OUT_DTYPE, int MB, int NB, int WK>
 int launch_skinny(const GemmArgs& p, hipStream_t s) {
-  const int lds = WK * WN * MB * 16 * 16 * 4;
-  const unsigned grid = (unsigned)((p.N + 16 * WN - 1) / (16 * WN));
-  hipLaunchKernelGGL((fp8_gemm_skinny_kernel<OUT_DTYPE, MB, WN, WK>), dim3(grid), dim3(64 * WN * WK), lds, s, p);
+  auto kern = fp8_gemm_skinny_kernel<OUT_DTYPE, MB, NB, WK>;
+  constexpr int lds = WK * MB * 16 * 16 * NB * 4;
+  static int attr_rc = lds <= 65536 ? 0 : check_hip(
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
+      "hipFuncSetAttribute");
+  if (attr_rc) return attr_rc;
+  const unsigned grid = (unsigned)((p.N + 16 * NB - 1) / (16 * NB));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WK), lds, s, p);
   return check_hip(hipGetLastError(), "fp8_gemm_skinny launch");
+}
+
+// Tuning override: SGL_MI355_SKINNY="NB,WK" (NB in {1,2,4}, WK in {2,4,8}).
+inline void skinny_override(int& nb, int& wk) {
+  static const char* e = getenv("SGL_MI355_SKINNY");
+  if (e) sscanf(e, "%d,%d", &nb, &wk);
 }
 
 template <int OUT_DTYPE, int MB>
 int dispatch_skinny(const GemmArgs& p, hipStream_t s) {
-  // Aim for >= ~2 workgroups per CU; wide N needs no K split, narrow N splits K across waves.
-  const int nblk = (p.N + 15) / 16;
-  if (nblk >= 1024) return launch_skinny<OUT_DTYPE, MB, 2, 2>(p, s);
-  if (nblk >= 384) return launch_skinny<OUT_DTYPE, MB, 1, 4>(p, s);
-  return launch_skinny<OUT_DTYPE, MB, 1, 8>(p, s);
+  // Wide N: 64-column wave tiles (activation L2 traffic = 1x the weight stream), K split 4 ways.
+  // Narrow N: 32-column tiles and a deeper K split so that enough waves are in flight.
+  int nb = (p.N >= 12288) ? 4 : 2;
+  int wk = (p.N >= 12288) ? 4 : 8;
+  skinny_override(nb, wk);
+#define SK_GO(NB_, WK_) return launch_skinny<OUT_DTYPE, MB, NB_, WK_>(p, s)
+  if (nb == 4) { if (wk == 2) SK_GO(4, 2); if (wk == 8) SK_GO(4, 8); SK_GO(4, 4); }
+  if (nb == 1) { if (wk == 2) SK_GO(1, 2); if (wk == 4) SK_GO(1, 4); SK_GO(1, 8); }
+  if (wk == 2) SK_GO(2, 2);
+  if (wk == 4) SK_GO(2, 4);
+  SK_GO(2, 8);
+#undef SK_GO
 }
 
 template <int OUT_DTYPE>
-int run_gemm(const GemmArgs& p, hipStream_t s) {
-  if (p.M <= 16) return dispatch_skinny<OUT_DTYPE, 1>(p, s);
-  if (p.M <= 32) return dispatch_skinny<OUT_DTYPE, 2>(p, s);
-  if (p.M <= 64) return dispatch_skinny<OUT_DTYPE, 4>(p, s);
+int run_gemm(const GemmArgs& p, float* workspace, int64_t workspace_floats, hipStream_t s) {
+  if (p.M <= 64) {
+    static const bool no_astat = getenv("SGL_MI355_NO_ASTAT") != nullptr;  // tuning / A-B aid
+    if (!no_astat && workspace != nullptr && (int64_t)p.N * p.K >= (int64_t)40 * 1024 * 1024) {
+      bool used = false;
+      int rc = p.M <= 16   ? launch_astat<OUT_DTYPE, 1>(p, workspace, workspace_floats, s, used)
+               : p.M <= 32 ? launch_astat<OUT_DTYPE, 2>(p, workspace, workspace_floats, s, used)
+                           : launch_astat<OUT_DTYPE, 4>(p, workspace, workspace_floats, s, used);
+      if (rc || used) return rc;
+    }
+    if (p.M <= 16) return dispatch_skinny<OUT_DTYPE, 1>(p, s);
+    if (p.M <= 32) return dispatch_skinny<OUT_DTYPE, 2>(p, s);
+    return dispatch_skinny<OUT_DTYPE, 4>(p, s);
+  }
   auto kern = fp8_gemm_tiled_kernel<OUT_DTYPE>;
   constexpr int lds = 2 * kStageBytes;
   static int attr_rc = check_hip(
@@ -424,7 +678,8 @@ extern "C" int sgl_mi355_per_token_quant_fp8(
 
 extern "C" int sgl_mi355_fp8_scaled_mm(
     const void* mat_a, const void* mat_b, const float* scales_a, const float* scales_b, const void* bias, void* out,
-    int64_t M, int64_t N, int64_t K, int64_t a_stride_m, int64_t b_stride_n, int out_dtype, void* stream) {
+    float* workspace, int64_t workspace_floats, int64_t M, int64_t N, int64_t K, int64_t a_stride_m,
+    int64_t b_stride_n, int out_dtype, void* stream) {
   // preconditions of fp8_gemm_kernel.cu:1078-1108
   SGLM_CHECK_ARG(out_dtype == SGL_MI355_BF16 || out_dtype == SGL_MI355_FP16, "fp8_scaled_mm: out_dtype must be Half or BFloat16");
   SGLM_CHECK_ARG(M >= 0 && N > 0 && K > 0 && M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "fp8_scaled_mm: bad shape");
@@ -440,5 +695,6 @@ extern "C" int sgl_mi355_fp8_scaled_mm(
   GemmArgs p{(const uint8_t*)mat_a, a_stride_m, (const uint8_t*)mat_b, b_stride_n, scales_a, scales_b, bias, out,
              (int)M, (int)N, (int)K};
   hipStream_t s = as_stream(stream);
-  return out_dtype == SGL_MI355_BF16 ? run_gemm<SGL_MI355_BF16>(p, s) : run_gemm<SGL_MI355_FP16>(p, s);
+  return out_dtype == SGL_MI355_BF16 ? run_gemm<SGL_MI355_BF16>(p, workspace, workspace_floats, s)
+                                     : run_gemm<SGL_MI355_FP16>(p, workspace, workspace_floats, s);
 }

@@ -265,6 +265,9 @@ def sgl_per_token_quant_fp8(input: torch.Tensor, output_q: torch.Tensor, output_
         _I(_dtype_code(input)), _stream(input)))
 
 
+_fp8_workspace = {}
+
+
 def fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None) -> torch.Tensor:
     """sgl_kernel.fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None)
     -- sgl-kernel/python/sgl_kernel/gemm.py:34-42, fp8_gemm_kernel.cu:1071-1146 (same checks)."""
@@ -294,8 +297,16 @@ def fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None) -> tor
             raise RuntimeError("bias must be contiguous [N] in the output dtype")
     out = torch.empty((M, N), dtype=out_dtype, device=mat_a.device)
     b_stride_n = mat_b.stride(1) if N > 1 else K
+    ws = None
+    if 0 < M <= 64:  # split-K partials of the decode-time weight streamer
+        need = max(-(-K // 2048), min(K // 512, -(-2048 // max(1, N // 16)))) * M * N + M * N
+        ws = _fp8_workspace.get(mat_a.device)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(max(need, 7 * 64 * 28672), dtype=torch.float32, device=mat_a.device)
+            _fp8_workspace[mat_a.device] = ws
     _lib.check(_lib.lib().sgl_mi355_fp8_scaled_mm(
         _ptr(mat_a), _ptr(mat_b), _ptr(scales_a), _ptr(scales_b), _ptr(bias), _ptr(out),
+        _ptr(ws), _I64(ws.numel() if ws is not None else 0),
         _I64(M), _I64(N), _I64(K), _I64(mat_a.stride(0) if M > 1 else K), _I64(b_stride_n),
         _I(0 if out_dtype == torch.bfloat16 else 1), _stream(mat_a)))
     return out
