@@ -238,6 +238,16 @@ int sgl_mi355_rotary_embedding(const int64_t* positions, void* query, void* key,
                                int64_t rot_dim, int64_t q_stride_t, int64_t k_stride_t, int is_neox, int dtype,
                                void* stream);
 
+/* RoPE fused with the KV-pool write: rotary_embedding on query/key in place, then
+ * k_buffer[loc[t]] = key[t] (rotated), v_buffer[loc[t]] = value[t] -- replaces the pair
+ * apply_rope_with_cos_sin_cache_inplace + MHATokenToKVPool.set_kv_buffer (memory_pool.py:369-407). */
+int sgl_mi355_rotary_embedding_set_kv(const int64_t* positions, void* query, void* key, const void* value,
+                                      const float* cos_sin_cache, void* k_buffer, void* v_buffer, const void* loc,
+                                      int loc_is64, int64_t num_tokens, int64_t num_q_heads, int64_t num_k_heads,
+                                      int64_t head_size, int64_t rot_dim, int64_t q_stride_t, int64_t k_stride_t,
+                                      int64_t v_stride_t, int64_t kb_stride_n, int64_t kb_stride_h,
+                                      int64_t vb_stride_n, int64_t vb_stride_h, int is_neox, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

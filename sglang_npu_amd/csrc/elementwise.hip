@@ -202,6 +202,49 @@ __global__ __launch_bounds__(256) void rope_kernel(
   }
 }
 
+// Fused RoPE + KV-pool write: rotate q and k in place, then k (rotated) and v go to the
+// pool rows loc[t] in the same pass -- one launch instead of rope + set_kv_buffer, and k/v are not re-read.
+// One 64-thread wave per (token, head) over q heads, then k heads (which also carry v).
+template <int DTYPE, typename LocT>
+__global__ __launch_bounds__(256) void rope_kv_kernel(
+    typename Half16<DTYPE>::T* __restrict__ q, typename Half16<DTYPE>::T* __restrict__ k,
+    const typename Half16<DTYPE>::T* __restrict__ v, typename Half16<DTYPE>::T* __restrict__ kb,
+    typename Half16<DTYPE>::T* __restrict__ vb, const int64_t* __restrict__ positions, const LocT* __restrict__ loc,
+    const float* __restrict__ cache, int64_t T, int Hq, int Hk, int D, int rot_dim, int64_t q_st, int64_t k_st,
+    int64_t v_st, int64_t kb_sn, int64_t kb_sh, int64_t vb_sn, int64_t vb_sh, int neox) {
+  using Hh = Half16<DTYPE>;
+  const int lane = threadIdx.x & 63;
+  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t total = T * (int64_t)(Hq + Hk);
+  if (item >= total) return;
+  const int h = (int)(item % (Hq + Hk));
+  const int64_t t = item / (Hq + Hk);
+  const bool is_k = h >= Hq;
+  typename Hh::T* base = is_k ? k + t * k_st + (int64_t)(h - Hq) * D : q + t * q_st + (int64_t)h * D;
+  const float* cs = cache + positions[t] * rot_dim;
+  const int half = rot_dim >> 1;
+  typename Hh::T* kdst = nullptr;
+  if (is_k && kb) kdst = kb + (int64_t)loc[t] * kb_sn + (int64_t)(h - Hq) * kb_sh;
+  for (int p = lane; p < half; p += 64) {
+    const int i1 = neox ? p : 2 * p, i2 = neox ? p + half : 2 * p + 1;
+    const float c = cs[p], sn = cs[half + p];
+    const float x1 = Hh::to_f32(base[i1]), x2 = Hh::to_f32(base[i2]);
+    const typename Hh::T o1 = Hh::from_f32(x1 * c - x2 * sn), o2 = Hh::from_f32(x2 * c + x1 * sn);
+    base[i1] = o1;
+    base[i2] = o2;
+    if (kdst) {
+      kdst[i1] = o1;
+      kdst[i2] = o2;
+    }
+  }
+  if (kdst) {
+    for (int i = rot_dim + lane; i < D; i += 64) kdst[i] = base[i];  // pass-through dims
+    const typename Hh::T* vs = v + t * v_st + (int64_t)(h - Hq) * D;
+    typename Hh::T* vdst = vb + (int64_t)loc[t] * vb_sn + (int64_t)(h - Hq) * vb_sh;
+    for (int i = lane; i < D; i += 64) vdst[i] = vs[i];
+  }
+}
+
 template <int DTYPE>
 int launch_rmsnorm(const void* x, void* residual, const void* weight, void* out, void* out_q, float* out_s, int64_t T,
                    int64_t H, float eps, hipStream_t s) {
@@ -326,4 +369,34 @@ extern "C" int sgl_mi355_rotary_embedding(
                        positions, cos_sin_cache, num_tokens, (int)num_q_heads, (int)num_k_heads, (int)head_size,
                        (int)rot_dim, q_stride_t, k_stride_t, is_neox);
   return check_hip(hipGetLastError(), "rotary_embedding launch");
+}
+
+extern "C" int sgl_mi355_rotary_embedding_set_kv(
+    const int64_t* positions, void* query, void* key, const void* value, const float* cos_sin_cache,
+    void* k_buffer, void* v_buffer, const void* loc, int loc_is64, int64_t num_tokens, int64_t num_q_heads,
+    int64_t num_k_heads, int64_t head_size, int64_t rot_dim, int64_t q_stride_t, int64_t k_stride_t,
+    int64_t v_stride_t, int64_t kb_stride_n, int64_t kb_stride_h, int64_t vb_stride_n, int64_t vb_stride_h,
+    int is_neox, int dtype, void* stream) {
+  SGLM_CHECK_ARG(dtype == SGL_MI355_BF16 || dtype == SGL_MI355_FP16, "rotary_embedding_set_kv: bad dtype %d", dtype);
+  SGLM_CHECK_ARG(rot_dim > 0 && rot_dim % 2 == 0 && rot_dim <= head_size, "rotary_embedding_set_kv: bad rot_dim %ld", (long)rot_dim);
+  SGLM_CHECK_ARG(num_tokens >= 0 && num_q_heads >= 0 && num_k_heads > 0, "rotary_embedding_set_kv: bad sizes");
+  if (num_tokens == 0) return 0;
+  SGLM_CHECK_ARG(positions && query && key && value && cos_sin_cache && k_buffer && v_buffer && loc,
+                 "rotary_embedding_set_kv: null tensor pointer");
+  const int64_t items = num_tokens * (num_q_heads + num_k_heads);
+  SGLM_CHECK_ARG(items < (1ll << 32), "rotary_embedding_set_kv: too many rows");
+  const unsigned grid = (unsigned)((items + 3) / 4);
+  hipStream_t s = as_stream(stream);
+#define ROPEKV(DT, TT, LT)                                                                                             \
+  hipLaunchKernelGGL((rope_kv_kernel<DT, LT>), dim3(grid), dim3(256), 0, s, (TT*)query, (TT*)key, (const TT*)value,    \
+                     (TT*)k_buffer, (TT*)v_buffer, positions, (const LT*)loc, cos_sin_cache, num_tokens,               \
+                     (int)num_q_heads, (int)num_k_heads, (int)head_size, (int)rot_dim, q_stride_t, k_stride_t,          \
+                     v_stride_t, kb_stride_n, kb_stride_h, vb_stride_n, vb_stride_h, is_neox)
+  if (dtype == SGL_MI355_BF16) {
+    if (loc_is64) ROPEKV(SGL_MI355_BF16, __bf16, int64_t); else ROPEKV(SGL_MI355_BF16, __bf16, int32_t);
+  } else {
+    if (loc_is64) ROPEKV(SGL_MI355_FP16, _Float16, int64_t); else ROPEKV(SGL_MI355_FP16, _Float16, int32_t);
+  }
+#undef ROPEKV
+  return check_hip(hipGetLastError(), "rotary_embedding_set_kv launch");
 }

@@ -43,6 +43,9 @@ class ColumnParallelLinear(LinearBase):
     def forward(self, x):
         return self.quant_method.apply(self, x, self.bias), None
 
+    def forward_prequantized(self, qinput, x_scale, out_dtype):
+        return self.quant_method.apply_prequantized(self, qinput, x_scale, out_dtype, self.bias), None
+
 
 class MergedColumnParallelLinear(ColumnParallelLinear):
     """gate_up_proj: two column-parallel matrices stored as one."""
@@ -78,6 +81,13 @@ class RowParallelLinear(LinearBase):
     def forward(self, x):
         bias_ = None if (get_tensor_model_parallel_rank() > 0) else self.bias
         out = self.quant_method.apply(self, x, bias_)
+        if self.reduce_results and get_tensor_model_parallel_world_size() > 1:
+            out = tensor_model_parallel_all_reduce(out)
+        return out, None
+
+    def forward_prequantized(self, qinput, x_scale, out_dtype):
+        bias_ = None if (get_tensor_model_parallel_rank() > 0) else self.bias
+        out = self.quant_method.apply_prequantized(self, qinput, x_scale, out_dtype, bias_)
         if self.reduce_results and get_tensor_model_parallel_world_size() > 1:
             out = tensor_model_parallel_all_reduce(out)
         return out, None

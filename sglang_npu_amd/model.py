@@ -53,6 +53,13 @@ class LlamaMLP(torch.nn.Module):
         x, _ = self.down_proj(x)
         return x
 
+    def forward_fp8(self, xq, xs, out_dtype):
+        """Same computation with the activations kept in FP8 between the kernels (fused producers)."""
+        gate_up, _ = self.gate_up_proj.forward_prequantized(xq, xs, out_dtype)
+        aq, a_s = ops.silu_and_mul_quant_fp8(gate_up)
+        x, _ = self.down_proj.forward_prequantized(aq, a_s, out_dtype)
+        return x
+
 
 class LlamaAttention(torch.nn.Module):
     def __init__(self, cfg: ModelConfig, layer_id: int, quant_config, dtype, device):
@@ -80,6 +87,19 @@ class LlamaAttention(torch.nn.Module):
         output, _ = self.o_proj(attn_output)
         return output
 
+    def forward_fp8(self, positions, xq, xs, forward_batch: ForwardBatch, out_dtype):
+        """FP8-input variant: qkv GEMM on the pre-quantised activation, RoPE fused with the KV-pool write
+        (the backend is then called with save_kv_cache=False)."""
+        qkv, _ = self.qkv_proj.forward_prequantized(xq, xs, out_dtype)
+        q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
+        pool = forward_batch.token_to_kv_pool
+        ops.apply_rope_and_set_kv_buffer(positions, q, k, v, self.head_dim, self.rotary_emb.cos_sin_cache,
+                                         pool.get_key_buffer(self.attn.layer_id), pool.get_value_buffer(self.attn.layer_id),
+                                         forward_batch.out_cache_loc, self.rotary_emb.is_neox_style)
+        attn_output = self.attn(q, k, v, forward_batch, save_kv_cache=False)
+        output, _ = self.o_proj(attn_output)
+        return output
+
 
 class LlamaDecoderLayer(torch.nn.Module):
     def __init__(self, cfg: ModelConfig, layer_id: int, quant_config, dtype, device):
@@ -100,12 +120,30 @@ class LlamaDecoderLayer(torch.nn.Module):
         hidden_states = self.mlp(hidden_states)
         return hidden_states, residual
 
+    def forward_fp8(self, positions, hidden_states, forward_batch, residual):
+        """Fused-producer variant for the FP8 config: (add +) RMSNorm emits the per-token FP8 activation
+        directly, so no standalone quant kernel runs before qkv / gate_up / down."""
+        dt = hidden_states.dtype
+        if residual is None:
+            residual = hidden_states.clone()
+            xq, xs, _ = ops.rmsnorm_quant_fp8(hidden_states, self.input_layernorm.weight.data,
+                                              self.input_layernorm.variance_epsilon)
+        else:
+            xq, xs, _ = ops.rmsnorm_quant_fp8(hidden_states, self.input_layernorm.weight.data,
+                                              self.input_layernorm.variance_epsilon, residual=residual)
+        hidden_states = self.self_attn.forward_fp8(positions, xq, xs, forward_batch, dt)
+        xq, xs, _ = ops.rmsnorm_quant_fp8(hidden_states, self.post_attention_layernorm.weight.data,
+                                          self.post_attention_layernorm.variance_epsilon, residual=residual)
+        hidden_states = self.mlp.forward_fp8(xq, xs, dt)
+        return hidden_states, residual
+
 
 class LlamaForCausalLM(torch.nn.Module):
     def __init__(self, cfg: ModelConfig, quantization: Optional[str] = None, dtype=torch.bfloat16, device="cuda:0",
-                 num_layers: Optional[int] = None, with_lm_head: bool = True):
+                 num_layers: Optional[int] = None, with_lm_head: bool = True, fuse_quant: bool = True):
         super().__init__()
         self.cfg, self.dtype, self.device_str = cfg, dtype, device
+        self.fuse_quant = fuse_quant and quantization == "w8a8_fp8"
         self.quant_config = None
         if quantization == "w8a8_fp8":
             self.quant_config = W8A8Fp8Config(is_checkpoint_fp8_serialized=False)
@@ -192,8 +230,12 @@ class LlamaForCausalLM(torch.nn.Module):
     def forward(self, input_ids, positions, forward_batch: ForwardBatch):
         hidden_states = self.embed_tokens[input_ids]
         residual = None
+        fused = self.fuse_quant and forward_batch.forward_mode.is_decode()
         for layer in self.layers:
-            hidden_states, residual = layer(positions, hidden_states, forward_batch, residual)
+            if fused:
+                hidden_states, residual = layer.forward_fp8(positions, hidden_states, forward_batch, residual)
+            else:
+                hidden_states, residual = layer(positions, hidden_states, forward_batch, residual)
         hidden_states, _ = self.norm(hidden_states, residual)
         if not self.with_lm_head:
             return hidden_states

@@ -441,3 +441,25 @@ def apply_rope_with_cos_sin_cache_inplace(positions, query, key, head_size, cos_
         _I64(query.size(-1) // head_size), _I64(key.size(-1) // head_size), _I64(head_size),
         _I64(cos_sin_cache.size(1)), _I64(query.stride(0)), _I64(key.stride(0)), _I(1 if is_neox else 0),
         _I(_dtype_code(query)), _stream(query)))
+
+
+def apply_rope_and_set_kv_buffer(positions, query, key, value, head_size, cos_sin_cache, k_buffer, v_buffer, loc,
+                                 is_neox=True):
+    """RoPE on query/key (in place) fused with k_buffer[loc] = key, v_buffer[loc] = value."""
+    _need_gpu(positions, query, key, value, cos_sin_cache, k_buffer, v_buffer, loc)
+    if cos_sin_cache.dtype != torch.float32 or not cos_sin_cache.is_contiguous():
+        raise RuntimeError("cos_sin_cache should be float32")
+    if positions.dtype != torch.int64:
+        positions = positions.to(torch.int64)
+    for t in (query, key, value, k_buffer, v_buffer):
+        if t.stride(-1) != 1:
+            raise RuntimeError("apply_rope_and_set_kv_buffer: last dim must be contiguous")
+    if k_buffer.size(2) != head_size or v_buffer.size(2) != head_size:
+        raise RuntimeError("apply_rope_and_set_kv_buffer: pool head size must equal head_size")
+    _lib.check(_lib.lib().sgl_mi355_rotary_embedding_set_kv(
+        _ptr(positions), _ptr(query), _ptr(key), _ptr(value), _ptr(cos_sin_cache), _ptr(k_buffer), _ptr(v_buffer),
+        _ptr(loc), _I(_is64(loc, "loc")), _I64(positions.numel()), _I64(query.size(-1) // head_size),
+        _I64(key.size(-1) // head_size), _I64(head_size), _I64(cos_sin_cache.size(1)), _I64(query.stride(0)),
+        _I64(key.stride(0)), _I64(value.stride(0)), _I64(k_buffer.stride(0)), _I64(k_buffer.stride(1)),
+        _I64(v_buffer.stride(0)), _I64(v_buffer.stride(1)), _I(1 if is_neox else 0), _I(_dtype_code(query)),
+        _stream(query)))

@@ -170,6 +170,14 @@ class W8A8Fp8LinearMethod(LinearMethodBase):
     def apply(self, layer, x: torch.Tensor, bias: Optional[torch.Tensor] = None):
         return apply_fp8_linear(x, layer.weight, layer.weight_scale, input_scale=layer.input_scale, bias=bias)
 
+    def apply_prequantized(self, layer, qinput: torch.Tensor, x_scale: torch.Tensor, out_dtype: torch.dtype,
+                           bias: Optional[torch.Tensor] = None):
+        """The second half of apply_fp8_linear (fp8_utils.py:696-704) for callers whose producer already emitted
+        the per-token FP8 activation (fused norm+quant / silu+quant kernels of this backend)."""
+        q2 = qinput.view(-1, qinput.shape[-1])
+        out = ops.fp8_scaled_mm(q2, layer.weight, x_scale, layer.weight_scale, out_dtype=out_dtype, bias=bias)
+        return out.view(*qinput.shape[:-1], layer.weight.shape[1])
+
 
 # ----------------------------------------------------------------------------- AWQ INT4
 class AWQConfig(QuantizationConfig):

@@ -163,3 +163,31 @@ def test_tiny_model_decode_step_runs_and_is_deterministic(quant):
     l2 = net(ids, seq - 1, fb)
     assert l1.shape == (B, 512) and torch.isfinite(l1.float()).all()
     assert torch.equal(l1, l2)
+
+
+def test_fused_fp8_layer_path_equals_unfused():
+    """The fused-producer decode path (norm+quant, silu+quant, rope+KV-write) must give the same logits as the
+    reference-shaped unfused sequence (bit-identical FP8 activations -> identical GEMM inputs)."""
+    cfg = ModelConfig(8, 2, 64, 512, 1024, 2, 512, 128)
+    outs = []
+    for fuse in (False, True):
+        net = M.LlamaForCausalLM(cfg, "w8a8_fp8", torch.bfloat16, DEV, fuse_quant=fuse).load_dummy_weights()
+        B = 4
+        r2t = ReqToTokenPool(B, 128, DEV)
+        pool = MHATokenToKVPool(B * 128 + 1, 1, torch.bfloat16, 2, 64, 2, DEV)
+        g = torch.Generator(device=DEV).manual_seed(0)
+        for l in range(2):
+            pool.k_buffer[l].normal_(generator=g)
+            pool.v_buffer[l].normal_(generator=g)
+        r2t.req_to_token.copy_((torch.arange(B * 128, device=DEV) + 1).view(B, 128).to(torch.int32))
+        runner = ModelRunnerLike(cfg, r2t, pool, DEV, 0, 1, ServerArgs())
+        backend = install_attention_backend(runner)
+        seq = torch.tensor([5, 17, 64, 100], device=DEV)
+        ids = torch.tensor([1, 2, 3, 4], device=DEV)
+        fb = ForwardBatch(ForwardMode.DECODE, B, ids, torch.arange(B, device=DEV), seq,
+                          r2t.req_to_token[torch.arange(B, device=DEV), seq - 1].long(), int(seq.sum()), seq.cpu(), seq - 1,
+                          req_to_token_pool=r2t, token_to_kv_pool=pool, attn_backend=backend)
+        backend.init_forward_metadata(fb)
+        outs.append((net(ids, seq - 1, fb), pool.k_buffer[1].clone(), pool.v_buffer[0].clone()))
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2]), "KV pool contents must match"
+    assert torch.equal(outs[0][0], outs[1][0]), "fused and unfused paths must agree bit for bit"
