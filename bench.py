@@ -218,8 +218,25 @@ def main():
     if world != args.gpus:
         if args.gpus > 1 and world == 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    use_graph = not args.no_graph
+    if use_graph and world > 1:
+        # Ask a throw-away child per rank whether the communicator's all-reduce can be stream-captured
+        # (RCCL can; a failed capture would leave a sticky HIP error in THIS process, so we never try here).
+        import subprocess
+        env = dict(os.environ)
+        env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 17)
+        try:
+            rc = subprocess.run([sys.executable, "-m", "sglang_npu_amd._probe_graph_ar"], env=env, cwd=ROOT,
+                                timeout=240, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL).returncode
+        except Exception:
+            rc = 1
+        use_graph = rc == 0
+        if not use_graph and rank == 0:
+            print("[bench] all-reduce is not graph-capturable with this backend; running the step eagerly", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    if os.environ.get("SGL_MI355_SHARE_GPU"):  # rehearsal on a 1-GPU box: every rank uses device 0
+        local_rank = 0
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     from sglang_npu_amd import _lib
@@ -230,7 +247,7 @@ def main():
 
     net, cfg, runner, backend, max_len = build(args, device, tp)
     loop = DecodeLoop(net, runner, backend, args.batch, args.ctx, device)
-    if not args.no_graph:
+    if use_graph:
         loop.capture()
 
     def barrier():
@@ -267,7 +284,7 @@ def main():
         "dtype": "fp8_e4m3 (GEMM) / bf16 (attention, KV)" if args.quant == "w8a8_fp8" else args.quant,
         "data": "synthetic (dummy-loader random weights, N(0,1) KV, random-permutation page table)",
         "config": {"workload": f"{args.model} {args.quant} decode bs={args.batch} ctx={args.ctx} TP={tp} "
-                               f"(token-level paged KV, HIP graph replay)",
+                               f"(token-level paged KV, {'HIP graph replay' if loop.graph is not None else 'eager launches'})",
                    "global_batch": args.batch, "seq_len": args.ctx, "layers": len(net.layers),
                    "parallelism": f"tp{tp}"},
         "roofline": {"bound": "hbm", "kernel": "decode_mfma_kernel (paged decode attention)",

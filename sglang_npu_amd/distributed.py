@@ -101,7 +101,10 @@ def init_distributed_environment(backend: Optional[str] = None, device: Optional
         _TP = GroupCoordinator(None, 0, 1, device)
         return _TP
     if backend is None:
-        backend = "nccl" if (device is not None and device.type == "cuda") else "gloo"
+        # SGL_MI355_DIST_BACKEND is a rehearsal aid: "gloo" lets several ranks share ONE GPU (RCCL refuses
+        # duplicate devices), e.g. to exercise the N>1 code path on a 1-GPU box.
+        backend = os.environ.get("SGL_MI355_DIST_BACKEND") or (
+            "nccl" if (device is not None and device.type == "cuda") else "gloo")
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
