@@ -173,6 +173,37 @@ def time_attention_kernel(loop, steps):
     return sum(keep) / len(keep), len(durations)
 
 
+def time_ttft(net, runner, backend, device, input_len=1024, reps=7):
+    """p50 time-to-first-token at bs=1: one EXTEND (prefill) pass of `input_len` new tokens with an empty
+    prefix through the whole model + greedy sample, device-synchronised (bench_one_batch.py:380-405)."""
+    from sglang_npu_amd.harness import ForwardBatch, ForwardMode
+    r2t = runner.req_to_token_pool.req_to_token
+    input_len = min(input_len, r2t.size(1) - 1)
+    ids = torch.randint(0, 10000, (input_len,), device=device)
+    pos = torch.arange(input_len, device=device)
+    rpi = torch.zeros(1, dtype=torch.int64, device=device)
+    seq = torch.full((1,), input_len, dtype=torch.int64, device=device)
+    loc = r2t[0, :input_len].to(torch.int64)
+    zero = torch.zeros(1, dtype=torch.int64, device=device)
+    fb = ForwardBatch(ForwardMode.EXTEND, 1, ids, rpi, seq, loc, input_len, seq.cpu(), pos,
+                      extend_num_tokens=input_len, extend_seq_lens=seq.clone(), extend_prefix_lens=zero,
+                      extend_start_loc=zero.clone(), extend_prefix_lens_cpu=[0], extend_seq_lens_cpu=[input_len],
+                      req_to_token_pool=runner.req_to_token_pool, token_to_kv_pool=runner.token_to_kv_pool,
+                      attn_backend=backend)
+    times = []
+    for i in range(reps + 2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        backend.init_forward_metadata(fb)
+        logits = net(ids, pos, fb)
+        tok = torch.argmax(logits[-1:], dim=-1)
+        tok.item()
+        if i >= 2:
+            times.append((time.perf_counter() - t0) * 1e3)
+    times.sort()
+    return times[len(times) // 2], input_len
+
+
 def cpu_baseline(cfg, B, ctx, n_layers_full):
     """Time the CPU oracle on ONE layer's hot path (attention over ctx tokens + 4 quant-GEMMs), all host
     cores, and scale to the full step.  Bounded to tens of seconds."""
@@ -278,7 +309,7 @@ def main():
     alg_bytes = args.batch * ctx_mid * hkv * 2 * d * 2 + 4 * args.batch * ctx_mid + 2 * args.batch * hq * 2 * d
     achieved = alg_bytes / (attn_ms * 1e-3) / 1e9
     out = {
-        "metric": "output tokens/s (decode, whole model step)", "value": round(value, 1), "unit": "tokens/s",
+        "metric": "output tokens/s (decode, whole model step) + p50 TTFT", "value": round(value, 1), "unit": "tokens/s",
         "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "fp8_e4m3 (GEMM) / bf16 (attention, KV)" if args.quant == "w8a8_fp8" else args.quant,
@@ -293,6 +324,17 @@ def main():
                      "avg_launch_us": round(attn_ms * 1e3, 2), "launches_timed": n_launch,
                      "algorithmic_bytes_per_launch": int(alg_bytes)},
     }
+    try:
+        ttft_ms, ttft_len = time_ttft(net, runner, backend, device)
+        if tp > 1:
+            t = torch.tensor([ttft_ms], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            ttft_ms = float(t.item())
+        out["ttft_ms_p50"] = round(ttft_ms, 3)
+        out["config"]["ttft"] = f"bs=1, input_len={ttft_len}, empty prefix, eager"
+    except Exception as e:
+        out["ttft_ms_p50"] = None
+        out["config"]["ttft"] = f"failed: {type(e).__name__}: {e}"
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(cfg, args.batch, args.ctx, cfg.num_hidden_layers)
