@@ -92,10 +92,47 @@ union Frag32 {  // 32 contiguous K bytes of one row = four MFMA operands
   long l[4];
 };
 
-__device__ __forceinline__ void load32(Frag32& f, const uint8_t* p, int k, int kend, bool row_ok) {
-  // K % 16 == 0, so each 16-B half is entirely inside or outside [0, kend)
-  f.v[0] = (row_ok && k < kend) ? *reinterpret_cast<const uint4*>(p + k) : uint4{0, 0, 0, 0};
-  f.v[1] = (row_ok && k + 16 < kend) ? *reinterpret_cast<const uint4*>(p + k + 16) : uint4{0, 0, 0, 0};
+// Lane group g takes bytes [16g, 16g+16) and [64+16g, 64+16g+16) of each 128-wide k-step (`p` already
+// includes the 16g offset, `kend` = K - 16g): the first load instruction of a wave then covers bytes 0..63
+// of every row, the second 64..127 -- whole 64-B sectors instead of interleaved 16-B pieces.  The MFMA k
+// index is contracted, so any k permutation is fine as long as A and B use the same one.
+//
+// The loads are UNCONDITIONAL (address clamped into the row, data masked afterwards).  A guarded load
+// (`ok ? *p : 0`) makes hipcc branch around each load and put `s_waitcnt vmcnt(0)` right behind it, which
+// serialises the whole prefetch queue -- measured: every skinny-GEMM variant ran at one memory latency per
+// k-step until this was removed.  Rows beyond M / N need no masking at all: a garbage row of A (column of
+// B) only reaches output rows (columns) that are never stored.  Only the K tail must read as zero.
+// ld16 returns RAW data from a clamped (always valid) address; the K-tail zeroing is a separate mask
+// applied where the fragment is CONSUMED -- masking at the load site would itself be an immediate use
+// of the loaded value and pin a wait right behind the load.
+__device__ __forceinline__ uint4 ld16(const uint8_t* p, int k, int kend) {
+  const int kc = k < kend ? k : (kend - 16 > 0 ? kend - 16 : 0);  // stay inside the row
+  return *reinterpret_cast<const uint4*>(p + kc);
+}
+__device__ __forceinline__ uint4 mask16(uint4 v, int k, int kend) {
+  const uint32_t m = k < kend ? 0xFFFFFFFFu : 0u;
+  v.x &= m; v.y &= m; v.z &= m; v.w &= m;
+  return v;
+}
+__device__ __forceinline__ uint4 ld16_masked(const uint8_t* p, int k, int kend) {  // prologue-only use
+  return mask16(ld16(p, k, kend), k, kend);
+}
+__device__ __forceinline__ void load32(Frag32& f, const uint8_t* p, int k, int kend, bool /*row_ok*/) {
+  f.v[0] = ld16(p, k, kend);
+  f.v[1] = ld16(p, k + 64, kend);
+}
+// keep or zero a whole fragment (padding steps of a branch-free pipeline); a data select, not a branch
+__device__ __forceinline__ void keep32(Frag32& f, bool keep) {
+  const uint32_t m = keep ? 0xFFFFFFFFu : 0u;
+  f.v[0].x &= m; f.v[0].y &= m; f.v[0].z &= m; f.v[0].w &= m;
+  f.v[1].x &= m; f.v[1].y &= m; f.v[1].z &= m; f.v[1].w &= m;
+}
+// zero the part of a fragment that lies beyond K (only when K % 128 != 0; `ktail` is wave-uniform)
+__device__ __forceinline__ void mask32(Frag32& f, int k, int kend, bool ktail) {
+  if (ktail) {
+    f.v[0] = mask16(f.v[0], k, kend);
+    f.v[1] = mask16(f.v[1], k + 64, kend);
+  }
 }
 
 // skinny: M <= 16*MB.  Workgroup = WK waves splitting K; every wave owns NB column blocks of 16
@@ -127,7 +164,7 @@ __global__ __launch_bounds__(64 * WK) void fp8_gemm_skinny_kernel(GemmArgs p) {
   for (int nb = 0; nb < NB; ++nb) {
     const int n = n0 + 16 * nb + r16;
     n_ok[nb] = n < p.N;
-    brow[nb] = p.b + (int64_t)(n_ok[nb] ? n : 0) * p.b_sn + 32 * g;
+    brow[nb] = p.b + (int64_t)(n_ok[nb] ? n : 0) * p.b_sn + 16 * g;
   }
   const uint8_t* arow[MB];
   bool a_ok[MB];
@@ -135,7 +172,7 @@ __global__ __launch_bounds__(64 * WK) void fp8_gemm_skinny_kernel(GemmArgs p) {
   for (int mb = 0; mb < MB; ++mb) {
     const int m = 16 * mb + r16;
     a_ok[mb] = m < p.M;
-    arow[mb] = p.a + (int64_t)(a_ok[mb] ? m : 0) * p.a_sm + 32 * g;
+    arow[mb] = p.a + (int64_t)(a_ok[mb] ? m : 0) * p.a_sm + 16 * g;
   }
 
   f32x4 acc[MB][NB];
@@ -153,48 +190,61 @@ __global__ __launch_bounds__(64 * WK) void fp8_gemm_skinny_kernel(GemmArgs p) {
     t = t >= nsteps ? t - nsteps : t;
     return (s_begin + t) << 7;
   };
-  const int kend = p.K - 32 * g;
+  const int kend = p.K - 16 * g;
+  const bool ktail = (p.K & 127) != 0;
 
   // Software pipeline.  vmcnt retires IN ORDER, so consuming any load waits for every older one: the
   // activation fragments (L2-fast) must therefore be issued together with the weights of the SAME
   // future step -- otherwise using A(s) would drain the younger-than-needed weight prefetches and the
   // effective prefetch distance collapses to one step.  Both operands are PB steps ahead.
+  // The loop body is BRANCH-FREE: every reload is unconditional (step index clamped to the last real step)
+  // and padding steps are neutralised by zeroing the weight fragment where it is consumed.  A load under an
+  // `if` makes hipcc merge old/new registers with copies right behind the load -- an immediate use, i.e. a
+  // `vmcnt(0)` after every load and no prefetch at all (seen in the ISA of the first versions).
   Frag32 bq[PB][NB];
   Frag32 aq[PB][MB];
+  const int last = nsteps > 0 ? nsteps - 1 : 0;
 #pragma unroll
-  for (int i = 0; i < PB; ++i)
-    if (i < nsteps) {
+  for (int i = 0; i < PB; ++i) {
+    const int kk = kof(i < nsteps ? i : last);
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) load32(aq[i][mb], arow[mb], kof(i), kend, a_ok[mb]);
+    for (int mb = 0; mb < MB; ++mb) load32(aq[i][mb], arow[mb], kk, kend, true);
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) load32(bq[i][nb], brow[nb], kof(i), kend, n_ok[nb]);
-    }
+    for (int nb = 0; nb < NB; ++nb) load32(bq[i][nb], brow[nb], kk, kend, true);
+  }
 
   for (int s0 = 0; s0 < nsteps; s0 += PB) {
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
       const int s = s0 + i;
-      if (s < nsteps) {
-        Frag32 af[MB], bf[NB];
+      const int kcur = kof(s < nsteps ? s : last);
+      Frag32 af[MB], bf[NB];
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) af[mb] = aq[i][mb];
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) bf[nb] = bq[i][nb];
-        if (s + PB < nsteps) {
-          const int kn = kof(s + PB);
-#pragma unroll
-          for (int mb = 0; mb < MB; ++mb) load32(aq[i][mb], arow[mb], kn, kend, a_ok[mb]);
-#pragma unroll
-          for (int nb = 0; nb < NB; ++nb) load32(bq[i][nb], brow[nb], kn, kend, n_ok[nb]);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-          for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-              acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(af[mb].l[ks], bf[nb].l[ks], acc[mb][nb], 0, 0, 0);
+      for (int mb = 0; mb < MB; ++mb) {
+        af[mb] = aq[i][mb];
+        mask32(af[mb], kcur, kend, ktail);
       }
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        bf[nb] = bq[i][nb];
+        mask32(bf[nb], kcur, kend, ktail);
+        keep32(bf[nb], s < nsteps);
+      }
+      {
+        const int sn = s + PB;
+        const int kn = kof(sn < nsteps ? sn : last);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) load32(aq[i][mb], arow[mb], kn, kend, true);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) load32(bq[i][nb], brow[nb], kn, kend, true);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(af[mb].l[ks], bf[nb].l[ks], acc[mb][nb], 0, 0, 0);
     }
   }
 
@@ -267,6 +317,38 @@ struct AStat {
   static constexpr int MAX_STEPS = (150 * 1024) / STEP_BYTES;
 };
 
+// Cooperative fill of the A-stationary LDS image: rows [0,ROWS) x k in [k_begin, k_begin + nsteps*128).
+// Eight independent 16-B loads per thread are in flight before the first is consumed (a plain
+// load->store loop would pay one L2 round trip per 16 B).
+template <int ROWS, int REGION, int STEP_BYTES>
+__device__ __forceinline__ void astat_fill(char* smem, const GemmArgs& p, int k_begin, int nsteps, int tid, int nthreads) {
+  const int per_row = nsteps * 8;  // 16-B chunks per row
+  const int total = ROWS * per_row;
+  for (int base = tid; base < total; base += nthreads * 8) {
+    uint4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      int idx = base + u * nthreads;
+      idx = idx < total ? idx : total - 1;
+      const int row = idx / per_row;
+      const int c = idx - row * per_row;
+      const int rc = row < p.M ? row : p.M - 1;  // rows past M are never stored; keep the load unconditional
+      v[u] = ld16(p.a + (int64_t)rc * p.a_sm, k_begin + c * 16, p.K);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + u * nthreads;
+      if (idx < total) {
+        const int row = idx / per_row;
+        const int c = idx - row * per_row;
+        const int st = c >> 3, j = c & 7;
+        *reinterpret_cast<uint4*>(smem + st * STEP_BYTES + (j & 3) * REGION + row * 32 + (j >> 2) * 16) =
+            mask16(v[u], k_begin + c * 16, p.K);
+      }
+    }
+  }
+}
+
 template <int MB>
 __global__ __launch_bounds__(64 * kAsWaves) void fp8_gemm_astat_kernel(GemmArgs p, float* slabs, int SK, int steps_per_slice) {
   using L = AStat<MB>;
@@ -292,38 +374,26 @@ __global__ __launch_bounds__(64 * kAsWaves) void fp8_gemm_astat_kernel(GemmArgs 
   const int stride = ngroups * nwaves;
   const int my_blocks = gw < nblocks ? (nblocks - gw + stride - 1) / stride : 0;
   const int total_f = my_blocks * nsteps;
-  const int kend = p.K - 32 * g;
+  const int kend = p.K - 16 * g;
+  const bool ktail = (p.K & 127) != 0;
 
   auto issue = [&](Frag32& f, int fi) __attribute__((always_inline)) {
     const int bi = fi / nsteps;
     const int st = fi - bi * nsteps;
     const int n = (gw + bi * stride) * 16 + r16;
     const bool ok = n < p.N;
-    load32(f, p.b + (int64_t)(ok ? n : 0) * p.b_sn + 32 * g, k_begin + (st << 7), kend, ok);
+    load32(f, p.b + (int64_t)(ok ? n : 0) * p.b_sn + 16 * g, k_begin + (st << 7), kend, ok);
   };
 
   // the first weight loads go out BEFORE the A fill: they do not depend on it and their HBM latency
-  // then overlaps the fill
+  // then overlaps the fill.  All loads are unconditional (flat index clamped), see the skinny kernel.
+  const int last_f = total_f > 0 ? total_f - 1 : 0;
   Frag32 bq[PB];
 #pragma unroll
-  for (int i = 0; i < PB; ++i)
-    if (i < total_f) issue(bq[i], i);
-
+  for (int i = 0; i < PB; ++i) issue(bq[i], i < total_f ? i : last_f);
 
   // ---- fill: A[0:ROWS][k_begin : k_begin + nsteps*128] -> LDS, fragment-major
-  {
-    const int per_row = nsteps * 8;  // 16-B chunks per row
-    const int total = L::ROWS * per_row;
-    for (int idx = tid; idx < total; idx += blockDim.x) {
-      const int row = idx / per_row;
-      const int c = idx - row * per_row;
-      const int st = c >> 3, j = c & 7;
-      const int k = k_begin + c * 16;
-      uint4 v = uint4{0, 0, 0, 0};
-      if (row < p.M && k < p.K) v = *reinterpret_cast<const uint4*>(p.a + (int64_t)row * p.a_sm + k);
-      *reinterpret_cast<uint4*>(smem + st * L::STEP_BYTES + (j >> 1) * L::REGION + row * 32 + (j & 1) * 16) = v;
-    }
-  }
+  astat_fill<L::ROWS, L::REGION, L::STEP_BYTES>(smem, p, k_begin, nsteps, tid, (int)blockDim.x);
   __syncthreads();
 
   f32x4 acc[MB];
@@ -336,10 +406,112 @@ __global__ __launch_bounds__(64 * kAsWaves) void fp8_gemm_astat_kernel(GemmArgs 
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
       const int f = f0 + i;
-      if (f < total_f) {
-        const Frag32 bf = bq[i];
-        if (f + PB < total_f) issue(bq[i], f + PB);
-        const char* ap = abase + st * L::STEP_BYTES;
+      Frag32 bf = bq[i];
+      mask32(bf, k_begin + (st << 7), kend, ktail);  // A's tail is zero in LDS already; keep B finite too
+      keep32(bf, f < total_f);
+      {
+        const int fn = f + PB;
+        issue(bq[i], fn < total_f ? fn : last_f);
+      }
+      const char* ap = abase + st * L::STEP_BYTES;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        Frag32 af;
+        af.v[0] = *reinterpret_cast<const uint4*>(ap + mb * 512);
+        af.v[1] = *reinterpret_cast<const uint4*>(ap + mb * 512 + 16);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(af.l[kk], bf.l[kk], acc[mb], 0, 0, 0);
+      }
+      if (++st == nsteps) {
+        // column block finished: acc[mb][r] = C[m = 16mb + 4g + r][n]; store the fp32 partial
+        const int n = (gw + bi * stride) * 16 + r16;
+        if (bi < my_blocks && n < p.N) {
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int m = 16 * mb + 4 * g + r;
+              if (m < p.M) slabs[((int64_t)ks * p.M + m) * p.N + n] = acc[mb][r];
+            }
+        }
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        st = 0;
+        ++bi;
+      }
+    }
+  }
+}
+
+// A-stationary, DIRECT epilogue: for wide N there are enough column blocks that every wave can own ONE
+// block for the whole K range.  The workgroup then walks K in phases (each phase refills the LDS image of
+// A with the next K-slice), the accumulator never leaves registers, and the epilogue (scales, bias, cast)
+// happens in the same kernel -- no fp32 slabs, no second launch.  The next phase's first weight loads are
+// issued before the refill barrier so the HBM stream never drains.
+template <int OUT_DTYPE, int MB>
+__global__ __launch_bounds__(512) void fp8_gemm_astat_direct_kernel(GemmArgs p, int SK, int steps_per_slice) {
+  using H = Half16<OUT_DTYPE>;
+  using T = typename H::T;
+  using L = AStat<MB>;
+  constexpr int PB = 8;  // 16 KB of weights in flight per wave
+  constexpr int NW = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g = lane >> 4;
+  const int steps_total = (p.K + 127) >> 7;
+  const int nb = blockIdx.x * NW + wave;  // this wave's column block
+  const int n = nb * 16 + r16;
+  const bool n_ok = n < p.N;
+  const uint8_t* brow = p.b + (int64_t)(n_ok ? n : 0) * p.b_sn + 16 * g;
+  const int kend = p.K - 16 * g;
+  const bool ktail = (p.K & 127) != 0;
+
+  f32x4 acc[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // Flat step index f runs over all phases; inside a phase the sweep order is rotated per column block
+  // (the k sum is order-free): all waves reading the same residue mod 4 KiB would camp on a few HBM channels.
+  auto kstep = [&](int f) __attribute__((always_inline)) {
+    const int ph = f / steps_per_slice;
+    const int sl = f - ph * steps_per_slice;
+    const int st_begin = ph * steps_per_slice;
+    const int ns = (st_begin + steps_per_slice) <= steps_total ? steps_per_slice : (steps_total - st_begin);
+    int t = sl + (int)(((unsigned)(nb * 6) % (unsigned)ns) & ~1u);
+    t = t >= ns ? t - ns : t;
+    return st_begin + t;  // global k-step; sl >= ns (padding of the last phase) never happens: see loop bounds
+  };
+  const int total_f = steps_total;
+  const int last_f = total_f - 1;
+  Frag32 bq[PB];
+#pragma unroll
+  for (int i = 0; i < PB; ++i) load32(bq[i], brow, kstep(i < total_f ? i : last_f) << 7, kend, true);
+
+  const char* abase = smem + g * L::REGION + r16 * 32;
+  for (int ph = 0; ph < SK; ++ph) {
+    const int st_begin = ph * steps_per_slice;
+    const int nsteps = (st_begin + steps_per_slice) <= steps_total ? steps_per_slice : (steps_total - st_begin);
+    if (ph > 0) __syncthreads();  // everyone is done reading the previous slice
+    astat_fill<L::ROWS, L::REGION, L::STEP_BYTES>(smem, p, st_begin << 7, nsteps, tid, 64 * NW);
+    __syncthreads();
+    for (int s0 = 0; s0 < nsteps; s0 += PB) {
+#pragma unroll
+      for (int i = 0; i < PB; ++i) {  // steps_per_slice % PB == 0, so queue slot i == (flat step) % PB
+        const int sl = s0 + i;
+        const bool live = sl < nsteps;
+        const int f = st_begin + (live ? sl : nsteps - 1);  // flat index (phases are contiguous in f)
+        Frag32 bf = bq[i];
+        mask32(bf, kstep(f) << 7, kend, ktail);
+        keep32(bf, live);
+        if ((i & 1) == 1) {  // static: refill this slot and its partner together (they are both consumed now)
+          const int fn0 = st_begin + sl - 1 + PB, fn1 = fn0 + 1;
+          load32(bq[i - 1], brow, kstep(fn0 < total_f ? fn0 : last_f) << 7, kend, true);
+          load32(bq[i], brow, kstep(fn1 < total_f ? fn1 : last_f) << 7, kend, true);
+        }
+        const char* ap = abase + (kstep(f) - st_begin) * L::STEP_BYTES;
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
           Frag32 af;
@@ -349,26 +521,55 @@ __global__ __launch_bounds__(64 * kAsWaves) void fp8_gemm_astat_kernel(GemmArgs 
           for (int kk = 0; kk < 4; ++kk)
             acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(af.l[kk], bf.l[kk], acc[mb], 0, 0, 0);
         }
-        if (++st == nsteps) {
-          // column block finished: acc[mb][r] = C[m = 16mb + 4g + r][n]; store the fp32 partial
-          const int n = (gw + bi * stride) * 16 + r16;
-          if (n < p.N) {
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const int m = 16 * mb + 4 * g + r;
-                if (m < p.M) slabs[((int64_t)ks * p.M + m) * p.N + n] = acc[mb][r];
-              }
-          }
-#pragma unroll
-          for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-          st = 0;
-          ++bi;
-        }
       }
     }
   }
+
+  // ---- epilogue through a wave-private LDS patch (transposes to 16-B row segments)
+  __syncthreads();  // the A image is dead: reuse its memory
+  T* ep = reinterpret_cast<T*>(smem) + wave * (L::ROWS * 24);  // [ROWS][16] (+8 pad)
+  const float sbv = n_ok ? p.sb[n] : 0.f;
+  const float bv = (p.bias && n_ok) ? H::to_f32(reinterpret_cast<const T*>(p.bias)[n]) : 0.f;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = 16 * mb + 4 * g + r;
+      const float sa = m < p.M ? p.sa[m] : 0.f;
+      ep[m * 24 + r16] = H::from_f32(acc[mb][r] * sbv * sa + bv);
+    }
+  wait_lgkmcnt0();
+  for (int c = lane; c < L::ROWS * 2; c += 64) {
+    const int m = c >> 1, half = c & 1;
+    const int nn = nb * 16 + half * 8;
+    if (m < p.M && nn < p.N)
+      *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.out) + (int64_t)m * p.N + nn) =
+          *reinterpret_cast<const uint4*>(ep + m * 24 + half * 8);
+  }
+}
+
+template <int OUT_DTYPE, int MB>
+int launch_astat_direct(const GemmArgs& p, hipStream_t s, bool& used) {
+  using L = AStat<MB>;
+  used = false;
+  const int steps_total = (p.K + 127) >> 7;
+  const int nblocks = (p.N + 15) / 16;
+  int max_steps = L::MAX_STEPS & ~7;  // multiple of the prefetch depth
+  int SK = (steps_total + max_steps - 1) / max_steps;
+  int steps_per_slice = (((steps_total + SK - 1) / SK) + 7) & ~7;
+  if (steps_per_slice > max_steps) return 0;
+  SK = (steps_total + steps_per_slice - 1) / steps_per_slice;
+  auto kern = fp8_gemm_astat_direct_kernel<OUT_DTYPE, MB>;
+  static int attr_rc = check_hip(
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+      "hipFuncSetAttribute");
+  if (attr_rc) return attr_rc;
+  int lds = steps_per_slice * L::STEP_BYTES;
+  const int ep_bytes = 8 * L::ROWS * 24 * 2;
+  if (lds < ep_bytes) lds = ep_bytes;
+  hipLaunchKernelGGL(kern, dim3((unsigned)((nblocks + 7) / 8)), dim3(512), lds, s, p, SK, steps_per_slice);
+  used = true;
+  return check_hip(hipGetLastError(), "fp8_gemm_astat_direct launch");
 }
 
 // epilogue of the A-stationary kernel: sum the K-slices, then the reference's epilogue
@@ -496,19 +697,25 @@ __global__ __launch_bounds__(256) void fp8_gemm_tiled_kernel(GemmArgs p) {
   auto gload = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const bool ok = k0 + 16 * ld_j[i] < p.K;
-      ra[i] = ok ? *reinterpret_cast<const uint4*>(a_ptr[i] + k0) : uint4{0, 0, 0, 0};
-      rb[i] = ok ? *reinterpret_cast<const uint4*>(b_ptr[i] + k0) : uint4{0, 0, 0, 0};
+      // unconditional raw loads (see ld16); a_ptr/b_ptr already include 16*ld_j; masked in lstore
+      ra[i] = ld16(a_ptr[i], k0, p.K - 16 * ld_j[i]);
+      rb[i] = ld16(b_ptr[i], k0, p.K - 16 * ld_j[i]);
     }
   };
-  auto lstore = [&](int stage) {
+  const bool ktail = (p.K & 127) != 0;
+  auto lstore = [&](int stage, int k0) {
     char* sa_ = smem + stage * kStageBytes;
     char* sb_ = sa_ + kOperand;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int off = (ld_j[i] >> 1) * kRegion + ld_row[i] * 32 + (ld_j[i] & 1) * 16;
-      *reinterpret_cast<uint4*>(sa_ + off) = ra[i];
-      *reinterpret_cast<uint4*>(sb_ + off) = rb[i];
+      uint4 va = ra[i], vb = rb[i];
+      if (ktail) {
+        va = mask16(va, k0, p.K - 16 * ld_j[i]);
+        vb = mask16(vb, k0, p.K - 16 * ld_j[i]);
+      }
+      *reinterpret_cast<uint4*>(sa_ + off) = va;
+      *reinterpret_cast<uint4*>(sb_ + off) = vb;
     }
   };
 
@@ -520,7 +727,7 @@ __global__ __launch_bounds__(256) void fp8_gemm_tiled_kernel(GemmArgs p) {
 
   const int nk = (p.K + kTK - 1) / kTK;
   gload(0);
-  lstore(0);
+  lstore(0, 0);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int st = kt & 1;
@@ -544,7 +751,7 @@ __global__ __launch_bounds__(256) void fp8_gemm_tiled_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(af[i].l[ks], bf[j].l[ks], acc[i][j], 0, 0, 0);
-    if (kt + 1 < nk) lstore(st ^ 1);
+    if (kt + 1 < nk) lstore(st ^ 1, (kt + 1) * kTK);
     __syncthreads();
   }
 
@@ -627,6 +834,13 @@ template <int OUT_DTYPE>
 int run_gemm(const GemmArgs& p, float* workspace, int64_t workspace_floats, hipStream_t s) {
   if (p.M <= 64) {
     static const bool no_astat = getenv("SGL_MI355_NO_ASTAT") != nullptr;  // tuning / A-B aid
+    if (!no_astat && p.N >= 16 * 8 * 160) {  // >= ~160 workgroups of 8 column blocks: one block per wave, direct epilogue
+      bool used = false;
+      int rc = p.M <= 16   ? launch_astat_direct<OUT_DTYPE, 1>(p, s, used)
+               : p.M <= 32 ? launch_astat_direct<OUT_DTYPE, 2>(p, s, used)
+                           : launch_astat_direct<OUT_DTYPE, 4>(p, s, used);
+      if (rc || used) return rc;
+    }
     if (!no_astat && workspace != nullptr && (int64_t)p.N * p.K >= (int64_t)40 * 1024 * 1024) {
       bool used = false;
       int rc = p.M <= 16   ? launch_astat<OUT_DTYPE, 1>(p, workspace, workspace_floats, s, used)
