@@ -248,6 +248,23 @@ int sgl_mi355_rotary_embedding_set_kv(const int64_t* positions, void* query, voi
                                       int64_t v_stride_t, int64_t kb_stride_n, int64_t kb_stride_h,
                                       int64_t vb_stride_n, int64_t vb_stride_h, int is_neox, int dtype, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * P2P all-reduce over IPC-mapped peer buffers (one process per GPU, <= 8 ranks of one node).
+ * Replaces: the native half of CustomAllreduce -- init_custom_ar / allocate_meta_buffer /
+ *           get_meta_buffer_ipc_handle / register_buffer / all_reduce_reg / dispose
+ *           (sgl-kernel/csrc/torch_extension_rocm.cc:39-69, csrc/allreduce/custom_all_reduce_hip.cuh:261-568),
+ *           used by python/sglang/srt/distributed/device_communicators/custom_all_reduce.py:326-410.
+ *   ar_create allocates this rank's uncached comm buffer (signals + double-buffered payload of max_bytes);
+ *   ar_get_ipc_handle returns its 64-byte hipIpcMemHandle_t; the host all-gathers the handles and passes
+ *   the world_size x 64 bytes to ar_open_peers; ar_all_reduce(inp -> out, SUM) is then a single kernel on
+ *   `stream` (graph-capturable, out-of-place).  dtype: 0 bf16, 1 fp16, 2 fp32; nbytes % 16 == 0. */
+int sgl_mi355_ar_create(int rank, int world_size, int64_t max_bytes, void** comm_out);
+int sgl_mi355_ar_get_ipc_handle(void* comm, void* handle_out);
+int sgl_mi355_ar_open_peers(void* comm, const void* all_handles);
+int sgl_mi355_ar_all_reduce(void* comm, const void* inp, void* out, int64_t nbytes, int dtype, void* stream);
+int sgl_mi355_ar_timed_out(void* comm, int* flag_out);
+int sgl_mi355_ar_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,248 @@
+// P2P all-reduce over IPC-mapped peer buffers (xGMI) for small / medium TP messages.
+//
+// Role in the reference: sgl-kernel/csrc/allreduce/custom_all_reduce_hip.cuh:261-350,498-568
+// (one-shot / two-shot kernels over hipIpc buffers with Signal-flag barriers), driven by
+// python/sglang/srt/distributed/device_communicators/custom_all_reduce.py:326-410 from
+// GroupCoordinator.all_reduce (parallel_state.py:519-524).
+//
+// MI355X-first design ("Distributed comm backend"): the 8 GPUs of a node are fully
+// connected by 7 xGMI links each, so instead of a ring every rank talks to all 7 peers at once:
+//   one-shot  (<= 256 KiB): copy-in, barrier, every rank sums all peers' buffers;
+//   two-shot  (larger):     copy-in, barrier, rank r reduces slice r from all peers (reduce-scatter by
+//                           pull), barrier, every rank gathers the 8 reduced slices (all-gather by pull).
+// Buffers are double-buffered by call parity, so no trailing barrier is needed: a half is rewritten only
+// after the next call's first barrier proved that every peer left the previous call.
+// The sum order is rank 0..W-1 on every rank, so all ranks produce bit-identical results (and integer-
+// valued payloads are exact, the property test_custom_allreduce.py:118-146 relies on).
+// The call counter lives in device memory (kernel arguments are frozen under HIP-graph replay).
+// Every spin is bounded; a timeout sets a flag word that the host can read.
+#include <string.h>
+
+#include "common.h"
+
+namespace sglm {
+namespace {
+
+constexpr int kMaxRanks = 8;
+constexpr int kMaxBlocks = 64;
+constexpr int kThreads = 256;
+constexpr unsigned kSpinLimit = 1u << 27;
+
+struct ArComm {
+  int rank, world;
+  size_t max_bytes;      // payload capacity per half
+  char* base;            // own allocation: [signals | counter | timeout | pad][data half 0][data half 1]
+  size_t data_off, half_bytes;
+  char* peer[kMaxRanks]; // mapped bases of every rank (own entry = base)
+  bool opened[kMaxRanks];
+};
+
+struct ArArgs {
+  char* peer[kMaxRanks];
+  size_t data_off, half_bytes;
+  int rank, world;
+};
+
+// signals: uint32 [2 slots][world][kMaxBlocks] at offset 0; counter uint32[kMaxBlocks] after them; then timeout
+__device__ __forceinline__ uint32_t* sig_ptr(char* base, int slot, int from, int block) {
+  return reinterpret_cast<uint32_t*>(base) + (slot * kMaxRanks + from) * kMaxBlocks + block;
+}
+constexpr size_t kSigBytes = 2 * kMaxRanks * kMaxBlocks * 4;
+constexpr size_t kCounterOff = kSigBytes;
+constexpr size_t kTimeoutOff = kCounterOff + kMaxBlocks * 4;
+constexpr size_t kHeaderBytes = 8192;
+
+__device__ __forceinline__ void block_barrier(const ArArgs& a, int slot, uint32_t val) {
+  __syncthreads();
+  if (threadIdx.x < a.world) {
+    const int t = threadIdx.x;
+    __threadfence_system();
+    __hip_atomic_store(sig_ptr(a.peer[t], slot, a.rank, blockIdx.x), val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    uint32_t* mine = sig_ptr(a.peer[a.rank], slot, t, blockIdx.x);
+    unsigned spins = 0;
+    while (__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < val) {
+      if (++spins > kSpinLimit) {
+        *reinterpret_cast<uint32_t*>(a.peer[a.rank] + kTimeoutOff) = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  __syncthreads();
+}
+
+template <int DTYPE>
+struct Acc8 {
+  using H = Half16<DTYPE>;
+  static __device__ __forceinline__ void add(float* f, const uint4& v) {
+    const typename H::x8 x = __builtin_bit_cast(typename H::x8, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] += H::to_f32(x[j]);
+  }
+  static __device__ __forceinline__ uint4 pack(const float* f) {
+    typename H::x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = H::from_f32(f[j]);
+    return __builtin_bit_cast(uint4, o);
+  }
+};
+struct AccF32 {
+  static __device__ __forceinline__ void add(float* f, const uint4& v) {
+    const f32x4 x = __builtin_bit_cast(f32x4, v);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f[j] += x[j];
+  }
+  static __device__ __forceinline__ uint4 pack(const float* f) { return __builtin_bit_cast(uint4, f32x4{f[0], f[1], f[2], f[3]}); }
+};
+
+// A = accumulator policy; n16 = payload size in 16-byte vectors
+template <typename A>
+__global__ __launch_bounds__(kThreads) void all_reduce_kernel(ArArgs a, const uint4* __restrict__ inp, uint4* __restrict__ out,
+                                                              int64_t n16, int two_shot) {
+  uint32_t* counter = reinterpret_cast<uint32_t*>(a.peer[a.rank] + kCounterOff) + blockIdx.x;
+  const uint32_t call = *counter + 1;  // 1, 2, 3, ... ; every rank runs the same sequence of calls
+  const int half = call & 1;
+  const int64_t tid = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  const int64_t nthr = (int64_t)gridDim.x * kThreads;
+  char* my_data = a.peer[a.rank] + a.data_off + half * a.half_bytes;
+  // result area of the two-shot variant sits behind the payload area of the same half
+  const size_t res_off = a.half_bytes / 2;
+
+  // phase A: publish my input
+  for (int64_t i = tid; i < n16; i += nthr) reinterpret_cast<uint4*>(my_data)[i] = inp[i];
+  block_barrier(a, 0, call);
+
+  if (!two_shot) {
+    for (int64_t i = tid; i < n16; i += nthr) {
+      float f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int p = 0; p < a.world; ++p)
+        A::add(f, reinterpret_cast<const uint4*>(a.peer[p] + a.data_off + half * a.half_bytes)[i]);
+      out[i] = A::pack(f);
+    }
+  } else {
+    // phase B: reduce my slice from every peer
+    const int64_t per = (n16 + a.world - 1) / a.world;
+    const int64_t lo = (int64_t)a.rank * per, hi = (lo + per) < n16 ? (lo + per) : n16;
+    // The flag barriers pair block b of this rank with block b of every peer, so a block may only read
+    // what the SAME block index wrote elsewhere: element i is always handled by global thread i % nthr
+    // (phase A wrote it that way, phase C reads it that way), so walk the slice with that phase.
+    const int64_t first = lo + (((tid - lo) % nthr) + nthr) % nthr;
+    for (int64_t i = first; i < hi; i += nthr) {
+      float f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int p = 0; p < a.world; ++p)
+        A::add(f, reinterpret_cast<const uint4*>(a.peer[p] + a.data_off + half * a.half_bytes)[i]);
+      reinterpret_cast<uint4*>(my_data + res_off)[i] = A::pack(f);
+    }
+    block_barrier(a, 1, call);
+    // phase C: gather every rank's reduced slice
+    for (int64_t i = tid; i < n16; i += nthr) {
+      const int owner = (int)(i / per);
+      out[i] = reinterpret_cast<const uint4*>(a.peer[owner] + a.data_off + half * a.half_bytes + res_off)[i];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) *counter = call;
+}
+
+}  // namespace
+}  // namespace sglm
+
+using namespace sglm;
+
+extern "C" int sgl_mi355_ar_create(int rank, int world_size, int64_t max_bytes, void** comm_out) {
+  SGLM_CHECK_ARG(comm_out != nullptr, "ar_create: null output");
+  SGLM_CHECK_ARG(world_size >= 1 && world_size <= kMaxRanks && rank >= 0 && rank < world_size,
+                 "ar_create: bad rank/world (%d/%d), world must be <= %d", rank, world_size, kMaxRanks);
+  SGLM_CHECK_ARG(max_bytes > 0 && max_bytes % 16 == 0 && max_bytes <= (1ll << 30), "ar_create: bad max_bytes");
+  ArComm* c = new ArComm();
+  c->rank = rank; c->world = world_size; c->max_bytes = (size_t)max_bytes;
+  c->half_bytes = 2 * (size_t)max_bytes;  // payload + two-shot result area
+  c->data_off = kHeaderBytes;
+  const size_t total = kHeaderBytes + 2 * c->half_bytes;
+  void* p = nullptr;
+  // uncached (fine-grained) memory: flags and payload are read by peer GPUs while kernels run
+  hipError_t e = hipExtMallocWithFlags(&p, total, hipDeviceMallocUncached);
+  if (e != hipSuccess) {
+    delete c;
+    return check_hip(e, "hipExtMallocWithFlags(hipDeviceMallocUncached)");
+  }
+  e = hipMemset(p, 0, total);
+  if (e != hipSuccess) {
+    (void)hipFree(p);
+    delete c;
+    return check_hip(e, "hipMemset");
+  }
+  c->base = (char*)p;
+  for (int i = 0; i < kMaxRanks; ++i) { c->peer[i] = nullptr; c->opened[i] = false; }
+  c->peer[rank] = c->base;
+  *comm_out = c;
+  return 0;
+}
+
+extern "C" int sgl_mi355_ar_get_ipc_handle(void* comm, void* handle_out /* 64 bytes */) {
+  SGLM_CHECK_ARG(comm && handle_out, "ar_get_ipc_handle: null argument");
+  ArComm* c = (ArComm*)comm;
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is expected to be 64 bytes");
+  return check_hip(hipIpcGetMemHandle((hipIpcMemHandle_t*)handle_out, c->base), "hipIpcGetMemHandle");
+}
+
+extern "C" int sgl_mi355_ar_open_peers(void* comm, const void* all_handles /* world x 64 bytes */) {
+  SGLM_CHECK_ARG(comm && all_handles, "ar_open_peers: null argument");
+  ArComm* c = (ArComm*)comm;
+  for (int r = 0; r < c->world; ++r) {
+    if (r == c->rank) continue;
+    hipIpcMemHandle_t h;
+    memcpy(&h, (const char*)all_handles + 64 * r, 64);
+    void* p = nullptr;
+    SGLM_CHECK_HIP(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+    c->peer[r] = (char*)p;
+    c->opened[r] = true;
+  }
+  return 0;
+}
+
+extern "C" int sgl_mi355_ar_all_reduce(void* comm, const void* inp, void* out, int64_t nbytes, int dtype /* 0 bf16, 1 fp16, 2 fp32 */,
+                                        void* stream) {
+  SGLM_CHECK_ARG(comm, "ar_all_reduce: null communicator");
+  ArComm* c = (ArComm*)comm;
+  SGLM_CHECK_ARG(nbytes >= 0 && nbytes % 16 == 0, "ar_all_reduce: size (%ld B) must be a multiple of 16 bytes", (long)nbytes);
+  SGLM_CHECK_ARG((size_t)nbytes <= c->max_bytes, "ar_all_reduce: %ld B exceeds the registered capacity %ld B", (long)nbytes, (long)c->max_bytes);
+  SGLM_CHECK_ARG(dtype >= 0 && dtype <= 2, "ar_all_reduce: bad dtype %d", dtype);
+  if (nbytes == 0) return 0;
+  SGLM_CHECK_ARG(inp && out, "ar_all_reduce: null tensor pointer");
+  for (int r = 0; r < c->world; ++r) SGLM_CHECK_ARG(c->peer[r] != nullptr, "ar_all_reduce: peer %d not opened", r);
+  ArArgs a{};
+  for (int r = 0; r < c->world; ++r) a.peer[r] = c->peer[r];
+  a.data_off = c->data_off; a.half_bytes = c->half_bytes; a.rank = c->rank; a.world = c->world;
+  const int64_t n16 = nbytes / 16;
+  const int two_shot = nbytes > 256 * 1024 && c->world > 1;
+  int blocks = (int)((n16 + kThreads - 1) / kThreads);
+  blocks = blocks < 1 ? 1 : (blocks > kMaxBlocks ? kMaxBlocks : blocks);
+  hipStream_t s = as_stream(stream);
+  if (dtype == 0)
+    hipLaunchKernelGGL((all_reduce_kernel<Acc8<SGL_MI355_BF16>>), dim3(blocks), dim3(kThreads), 0, s, a, (const uint4*)inp, (uint4*)out, n16, two_shot);
+  else if (dtype == 1)
+    hipLaunchKernelGGL((all_reduce_kernel<Acc8<SGL_MI355_FP16>>), dim3(blocks), dim3(kThreads), 0, s, a, (const uint4*)inp, (uint4*)out, n16, two_shot);
+  else
+    hipLaunchKernelGGL((all_reduce_kernel<AccF32>), dim3(blocks), dim3(kThreads), 0, s, a, (const uint4*)inp, (uint4*)out, n16, two_shot);
+  return check_hip(hipGetLastError(), "all_reduce_kernel launch");
+}
+
+extern "C" int sgl_mi355_ar_timed_out(void* comm, int* flag_out) {
+  SGLM_CHECK_ARG(comm && flag_out, "ar_timed_out: null argument");
+  ArComm* c = (ArComm*)comm;
+  uint32_t v = 0;
+  SGLM_CHECK_HIP(hipMemcpy(&v, c->base + kTimeoutOff, 4, hipMemcpyDeviceToHost));
+  *flag_out = (int)v;
+  return 0;
+}
+
+extern "C" int sgl_mi355_ar_destroy(void* comm) {
+  if (!comm) return 0;
+  ArComm* c = (ArComm*)comm;
+  for (int r = 0; r < c->world; ++r)
+    if (c->opened[r]) (void)hipIpcCloseMemHandle(c->peer[r]);
+  (void)hipFree(c->base);
+  delete c;
+  return 0;
+}

@@ -32,6 +32,73 @@ class AllReduceHandle:
         return self.tensor
 
 
+class CustomAllreduce:
+    """P2P all-reduce over IPC buffers -- same role and method names as
+    python/sglang/srt/distributed/device_communicators/custom_all_reduce.py:35-421
+    (``disabled``, ``should_custom_ar(inp)``, ``custom_all_reduce(inp) -> Optional[Tensor]``, ``close()``).
+    Out of place, graph-capturable, bit-identical on every rank.  Opt-in (``SGL_MI355_CUSTOM_AR=1``): RCCL
+    stays the default data plane."""
+
+    _SUPPORTED_WORLD_SIZES = [2, 4, 6, 8]
+
+    def __init__(self, group, device: torch.device, max_size: int = 16 * 1024 * 1024, rank: Optional[int] = None,
+                 world_size: Optional[int] = None):
+        import ctypes
+        from . import _lib
+        self.disabled = True
+        self._comm = None
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world_size = dist.get_world_size(group) if world_size is None else world_size
+        self.max_size = max_size
+        self.device = device
+        if self.world_size == 1 or self.world_size > 8:
+            return
+        lib = _lib.lib()
+        comm = ctypes.c_void_p()
+        _lib.check(lib.sgl_mi355_ar_create(ctypes.c_int(self.rank), ctypes.c_int(self.world_size),
+                                           ctypes.c_int64(max_size), ctypes.byref(comm)))
+        handle = ctypes.create_string_buffer(64)
+        _lib.check(lib.sgl_mi355_ar_get_ipc_handle(comm, handle))
+        gathered = [None] * self.world_size
+        dist.all_gather_object(gathered, bytes(handle.raw), group=group)
+        blob = b"".join(gathered)
+        _lib.check(lib.sgl_mi355_ar_open_peers(comm, ctypes.c_char_p(blob)))
+        dist.barrier(group=group)
+        self._comm, self._lib, self._ct = comm, lib, ctypes
+        self.disabled = False
+
+    def should_custom_ar(self, inp: torch.Tensor) -> bool:
+        if self.disabled or not inp.is_cuda or not inp.is_contiguous():
+            return False
+        nbytes = inp.numel() * inp.element_size()
+        return nbytes % 16 == 0 and 0 < nbytes <= self.max_size and \
+            inp.dtype in (torch.bfloat16, torch.float16, torch.float32)
+
+    def custom_all_reduce(self, inp: torch.Tensor) -> Optional[torch.Tensor]:
+        if not self.should_custom_ar(inp):
+            return None
+        from . import _lib
+        out = torch.empty_like(inp)
+        code = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}[inp.dtype]
+        ct = self._ct
+        _lib.check(self._lib.sgl_mi355_ar_all_reduce(
+            self._comm, ct.c_void_p(inp.data_ptr()), ct.c_void_p(out.data_ptr()),
+            ct.c_int64(inp.numel() * inp.element_size()), ct.c_int(code),
+            ct.c_void_p(torch.cuda.current_stream(inp.device).cuda_stream)))
+        return out
+
+    def timed_out(self) -> bool:
+        flag = self._ct.c_int(0)
+        self._lib.sgl_mi355_ar_timed_out(self._comm, self._ct.byref(flag))
+        return bool(flag.value)
+
+    def close(self):
+        if self._comm is not None:
+            self._lib.sgl_mi355_ar_destroy(self._comm)
+            self._comm = None
+            self.disabled = True
+
+
 class GroupCoordinator:
     def __init__(self, group: Optional[dist.ProcessGroup], rank: int, world_size: int, device: Optional[torch.device]):
         self.device_group = group
@@ -39,6 +106,7 @@ class GroupCoordinator:
         self.world_size = world_size
         self.device = device
         self._side_stream = None
+        self.ca_comm: Optional[CustomAllreduce] = None
 
     @property
     def side_stream(self):
@@ -50,6 +118,11 @@ class GroupCoordinator:
         """SUM over the TP ranks (in place, like the pynccl path parallel_state.py:563-568)."""
         if self.world_size == 1:
             return input_
+        # dispatch order of parallel_state.py:519-542: custom P2P all-reduce if it accepts the tensor, else RCCL
+        if self.ca_comm is not None and not self.ca_comm.disabled:
+            out = self.ca_comm.custom_all_reduce(input_)
+            if out is not None:
+                return out
         dist.all_reduce(input_, group=self.device_group)
         return input_
 
@@ -113,6 +186,8 @@ def init_distributed_environment(backend: Optional[str] = None, device: Optional
             kwargs["device_id"] = device
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
     _TP = GroupCoordinator(dist.group.WORLD, rank, world, device)
+    if os.environ.get("SGL_MI355_CUSTOM_AR") == "1" and device is not None and device.type == "cuda":
+        _TP.ca_comm = CustomAllreduce(dist.group.WORLD, device)
     return _TP
 
 
