@@ -89,8 +89,24 @@ struct GemmArgs {
 
 union Frag32 {  // 32 contiguous K bytes of one row = four MFMA operands
   uint4 v[2];
+  i32x4 x[2];
   long l[4];
 };
+
+// Hand-scheduled weight loads for the EXACT A-stationary loop.  hipcc does not track inline-asm loads in its
+// s_waitcnt pass, so the loop owns the counts: a slot is refilled right after its MFMAs, and the wait in
+// front of slot i's MFMAs is vmcnt(2 * (PB - 1)) -- loads retire in order, and any compiler-issued VMEM in
+// between only makes the count stricter, never wrong.  (With ordinary loads hipcc put a single vmcnt(0) at
+// the loop head and sank the refills to the loop end: no load/MFMA overlap inside a wave.)
+// Address = scalar base (saddr) + 32-bit per-lane offset: zero VALU per load.
+__device__ __forceinline__ void gload32_asm(Frag32& f, const uint8_t* sbase, uint32_t voff) {
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(f.x[0]) : "v"(voff), "s"(sbase) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=v"(f.x[1]) : "v"(voff), "s"(sbase) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_frag(Frag32& f) {
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(f.x[0]), "+v"(f.x[1]) : "n"(N) : "memory");
+}
 
 // Lane group g takes bytes [16g, 16g+16) and [64+16g, 64+16g+16) of each 128-wide k-step (`p` already
 // includes the 16g offset, `kend` = K - 16g): the first load instruction of a wave then covers bytes 0..63
@@ -296,6 +312,149 @@ __global__ __launch_bounds__(64 * WK) void fp8_gemm_skinny_kernel(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// One-shot skinny GEMM: K small enough (<= 8 waves x 4 k-steps, K % 128 == 0) that a wave can put its WHOLE
+// K-slice in flight at once.  Workgroup = one 16-column block, WK waves splitting K, S (compile-time) k-steps
+// per wave.  Every weight load of the wave is issued first (HBM latency), then every activation load (L2),
+// all through inline asm with scalar-base addressing (no VALU, no compiler-placed waits); the MFMAs of step
+// s then wait on an explicit count.  The whole kernel is one memory latency + the transfer time, where the
+// pipelined kernel above pays one latency per PB steps plus ~100 VALU per step of address / mask work.
+template <int N, int MB>
+__device__ __forceinline__ void wait_step(Frag32& b, Frag32 (&a)[MB]) {
+  if constexpr (MB == 1)
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(b.x[0]), "+v"(b.x[1]), "+v"(a[0].x[0]), "+v"(a[0].x[1]) : "n"(N) : "memory");
+  else if constexpr (MB == 2)
+    asm volatile("s_waitcnt vmcnt(%6)"
+                 : "+v"(b.x[0]), "+v"(b.x[1]), "+v"(a[0].x[0]), "+v"(a[0].x[1]), "+v"(a[1].x[0]), "+v"(a[1].x[1])
+                 : "n"(N) : "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(%10)"
+                 : "+v"(b.x[0]), "+v"(b.x[1]), "+v"(a[0].x[0]), "+v"(a[0].x[1]), "+v"(a[1].x[0]), "+v"(a[1].x[1]),
+                   "+v"(a[2].x[0]), "+v"(a[2].x[1]), "+v"(a[3].x[0]), "+v"(a[3].x[1])
+                 : "n"(N) : "memory");
+}
+
+template <int OUT_DTYPE, int MB, int S>
+__global__ __launch_bounds__(512) void fp8_gemm_oneshot_kernel(GemmArgs p) {
+  static_assert(MB == 1 || MB == 2 || MB == 4, "MB");
+  using H = Half16<OUT_DTYPE>;
+  using T = typename H::T;
+  constexpr int ROWS = MB * 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = reinterpret_cast<float*>(smem);  // [WK][ROWS][16]
+
+  const int lane = threadIdx.x & 63;
+  const int wk = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int WK = blockDim.x >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * 16;
+  const int n = n0 + r16;
+  const uint32_t boff = (uint32_t)((int64_t)(n < p.N ? n : p.N - 1) * p.b_sn + 16 * g);
+  uint32_t aoff[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int m = 16 * mb + r16;
+    aoff[mb] = (uint32_t)((int64_t)(m < p.M ? m : p.M - 1) * p.a_sm + 16 * g);  // rows past M are never stored
+  }
+  const int k0 = (wk * S) << 7;
+
+  Frag32 bq[S];
+  Frag32 aq[S][MB];
+#pragma unroll
+  for (int s = 0; s < S; ++s) gload32_asm(bq[s], p.b + k0 + (s << 7), boff);
+#pragma unroll
+  for (int s = 0; s < S; ++s)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) gload32_asm(aq[s][mb], p.a + k0 + (s << 7), aoff[mb]);
+
+  f32x4 acc[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // step s may run once at most the activation loads of the later steps are outstanding (in-order retirement)
+#define SGLM_ONESHOT_STEP(s_)                                                                              \
+  if constexpr (s_ < S) {                                                                                  \
+    wait_step<(S - 1 - s_) * 2 * MB, MB>(bq[s_ < S ? s_ : 0], aq[s_ < S ? s_ : 0]);                         \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                        \
+    _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                                       \
+      acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(aq[s_ < S ? s_ : 0][mb].l[kk],                   \
+                                                            bq[s_ < S ? s_ : 0].l[kk], acc[mb], 0, 0, 0);    \
+    __builtin_amdgcn_sched_barrier(0); /* or hipcc hoists the later waits above these MFMAs */             \
+  }
+  SGLM_ONESHOT_STEP(0)
+  SGLM_ONESHOT_STEP(1)
+  SGLM_ONESHOT_STEP(2)
+  SGLM_ONESHOT_STEP(3)
+#undef SGLM_ONESHOT_STEP
+
+  // ---- cross-wave K reduction + epilogue through LDS: acc[mb][r] = C[16mb + 4g + r][n0 + r16]
+  {
+    float* dst = red + wk * ROWS * 16;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst[(16 * mb + 4 * g + r) * 16 + r16] = acc[mb][r];
+  }
+  __syncthreads();
+  // each thread finishes 8 consecutive columns of one row
+  for (int c = threadIdx.x; c < ROWS * 2; c += blockDim.x) {
+    const int m = c >> 1;
+    const int cc = (c & 1) * 8;
+    const int nn = n0 + cc;
+    if (m >= p.M || nn >= p.N) continue;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    for (int kk = 0; kk < WK; ++kk) {
+      const float* src = red + (kk * ROWS + m) * 16 + cc;
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(src);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] += lo[j];
+        v[4 + j] += hi[j];
+      }
+    }
+    const float sa = p.sa[m];
+    typename H::x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      // epilogue order of fp8_gemm_kernel.cu:498-546: acc * w_scale[col], then * x_scale[row], then + bias
+      float r = v[j] * p.sb[nn + j] * sa;
+      if (p.bias) r += H::to_f32(reinterpret_cast<const T*>(p.bias)[nn + j]);
+      o[j] = H::from_f32(r);
+    }
+    *reinterpret_cast<typename H::x8*>(reinterpret_cast<T*>(p.out) + (int64_t)m * p.N + nn) = o;
+  }
+}
+
+// picks (S, WK) with WK * S == K / 128, S <= 4, WK <= 8; `used` false when the shape does not qualify
+template <int OUT_DTYPE, int MB>
+int launch_oneshot(const GemmArgs& p, hipStream_t s, bool& used) {
+  used = false;
+  if ((p.K & 127) != 0 || (p.N & 7) != 0) return 0;
+  if ((int64_t)p.N * p.b_sn >= ((int64_t)1 << 32) || (int64_t)p.M * p.a_sm >= ((int64_t)1 << 32)) return 0;
+  const int steps = p.K >> 7;
+  int S = 0;
+  for (int c = 1; c <= 4; ++c)
+    if (steps % c == 0 && steps / c <= 8) { S = c; break; }
+  if (S == 0) return 0;
+  const int WK = steps / S;
+  const unsigned grid = (unsigned)((p.N + 15) / 16);
+  // M > 32: 167 VGPRs -> one workgroup per CU; a second round of workgroups (N = 6144: 384) costs more than the
+  // pipelined kernel's 32-column tiles (measured 23.0 vs 20.6 us), so only take shapes that fit one round.
+  if (MB == 4 && grid > 256) return 0;
+  const int lds = WK * MB * 16 * 16 * 4;
+#define OS_GO(S_)                                                                                          \
+  hipLaunchKernelGGL((fp8_gemm_oneshot_kernel<OUT_DTYPE, MB, S_>), dim3(grid), dim3(64 * WK), lds, s, p)
+  if (S == 1) OS_GO(1);
+  else if (S == 2) OS_GO(2);
+  else if (S == 3) OS_GO(3);
+  else OS_GO(4);
+#undef OS_GO
+  used = true;
+  return check_hip(hipGetLastError(), "fp8_gemm_oneshot launch");
+}
+
+// ------------------------------------------------------------------------------------------
 // A-stationary skinny GEMM (M <= 64): the decode-time weight streamer.
 //
 // Measured on the register-only kernel above: at M = 64 it is bound by the ACTIVATION loads, not by
@@ -449,13 +608,13 @@ __global__ __launch_bounds__(64 * kAsWaves) void fp8_gemm_astat_kernel(GemmArgs 
 // A with the next K-slice), the accumulator never leaves registers, and the epilogue (scales, bias, cast)
 // happens in the same kernel -- no fp32 slabs, no second launch.  The next phase's first weight loads are
 // issued before the refill barrier so the HBM stream never drains.
-template <int OUT_DTYPE, int MB>
+template <int OUT_DTYPE, int MB, bool EXACT>
 __global__ __launch_bounds__(512) void fp8_gemm_astat_direct_kernel(GemmArgs p, int SK, int steps_per_slice) {
   using H = Half16<OUT_DTYPE>;
   using T = typename H::T;
   using L = AStat<MB>;
   constexpr int PB = 8;  // 16 KB of weights in flight per wave
-  constexpr int NW = 8;
+  const int NW = blockDim.x >> 6;  // 4..8 waves, chosen by the launcher so the grid fills the CUs evenly
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -465,53 +624,76 @@ __global__ __launch_bounds__(512) void fp8_gemm_astat_direct_kernel(GemmArgs p, 
   const int nb = blockIdx.x * NW + wave;  // this wave's column block
   const int n = nb * 16 + r16;
   const bool n_ok = n < p.N;
-  const uint8_t* brow = p.b + (int64_t)(n_ok ? n : 0) * p.b_sn + 16 * g;
+  // Weight address = (scalar) base + k  +  (per-lane, 32-bit) row offset: the per-step address math stays
+  // on the scalar unit and the load uses the saddr form -- no VALU per load.
+  const uint32_t lane_off = (uint32_t)((int64_t)(n_ok ? n : 0) * p.b_sn + 16 * g);
   const int kend = p.K - 16 * g;
-  const bool ktail = (p.K & 127) != 0;
+  // EXACT (compile time): K % 128 == 0 and every phase length is a multiple of PB -> no masks at all.
 
   f32x4 acc[MB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // Flat step index f runs over all phases; inside a phase the sweep order is rotated per column block
-  // (the k sum is order-free): all waves reading the same residue mod 4 KiB would camp on a few HBM channels.
-  auto kstep = [&](int f) __attribute__((always_inline)) {
-    const int ph = f / steps_per_slice;
-    const int sl = f - ph * steps_per_slice;
-    const int st_begin = ph * steps_per_slice;
-    const int ns = (st_begin + steps_per_slice) <= steps_total ? steps_per_slice : (steps_total - st_begin);
-    int t = sl + (int)(((unsigned)(nb * 6) % (unsigned)ns) & ~1u);
-    t = t >= ns ? t - ns : t;
-    return st_begin + t;  // global k-step; sl >= ns (padding of the last phase) never happens: see loop bounds
+  // Phases are contiguous runs of k-steps; inside a phase the sweep is rotated per column block (the sum
+  // is order-free) so that waves do not all read the same residue mod 4 KiB at the same time. Only two
+  // phase lengths exist (full / last), so rotation and length are scalar selects, no division in the loop.
+  const int ns_last = steps_total - (SK - 1) * steps_per_slice;
+  const int rot_full = (int)(((unsigned)(nb * 6) % (unsigned)steps_per_slice) & ~1u);
+  const int rot_last = (int)(((unsigned)(nb * 6) % (unsigned)ns_last) & ~1u);
+  auto ldw = [&](Frag32& f, int kstep_) __attribute__((always_inline)) {
+    const int k = kstep_ << 7;
+    if constexpr (EXACT) {
+      gload32_asm(f, p.b + k, lane_off);  // scalar base
+    } else {
+      f.v[0] = ld16(p.b + lane_off, k, kend);
+      f.v[1] = ld16(p.b + lane_off, k + 64, kend);
+    }
   };
-  const int total_f = steps_total;
-  const int last_f = total_f - 1;
+
+  // prefetch cursor: (phase, local step) of the NEXT load to issue; branch-free scalar updates
+  int pf_ph = 0, pf_sl = 0;
+  auto next_kstep = [&]() __attribute__((always_inline)) {
+    const bool last = pf_ph == SK - 1;
+    const int ns = last ? ns_last : steps_per_slice;
+    const int rot = last ? rot_last : rot_full;
+    int t = pf_sl + rot;
+    t = t >= ns ? t - ns : t;
+    const int ks = pf_ph * steps_per_slice + t;
+    const bool wrap = pf_sl + 1 >= ns;
+    // after the very last step stay on it: the extra loads are harmless and never consumed
+    pf_sl = wrap ? (last ? pf_sl : 0) : pf_sl + 1;
+    pf_ph = (wrap && !last) ? pf_ph + 1 : pf_ph;
+    return ks;
+  };
+
   Frag32 bq[PB];
 #pragma unroll
-  for (int i = 0; i < PB; ++i) load32(bq[i], brow, kstep(i < total_f ? i : last_f) << 7, kend, true);
+  for (int i = 0; i < PB; ++i) ldw(bq[i], next_kstep());
 
   const char* abase = smem + g * L::REGION + r16 * 32;
   for (int ph = 0; ph < SK; ++ph) {
     const int st_begin = ph * steps_per_slice;
-    const int nsteps = (st_begin + steps_per_slice) <= steps_total ? steps_per_slice : (steps_total - st_begin);
+    const int nsteps = ph == SK - 1 ? ns_last : steps_per_slice;
+    const int rot = ph == SK - 1 ? rot_last : rot_full;
     if (ph > 0) __syncthreads();  // everyone is done reading the previous slice
     astat_fill<L::ROWS, L::REGION, L::STEP_BYTES>(smem, p, st_begin << 7, nsteps, tid, 64 * NW);
+    // vmcnt(0), visible to hipcc's waitcnt pass (the fill just drained everything anyway): otherwise a
+    // "maybe pending" fill load survives into the loop and costs a vmcnt(0) per 8 steps.
+    if constexpr (EXACT) __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
     for (int s0 = 0; s0 < nsteps; s0 += PB) {
 #pragma unroll
-      for (int i = 0; i < PB; ++i) {  // steps_per_slice % PB == 0, so queue slot i == (flat step) % PB
-        const int sl = s0 + i;
-        const bool live = sl < nsteps;
-        const int f = st_begin + (live ? sl : nsteps - 1);  // flat index (phases are contiguous in f)
-        Frag32 bf = bq[i];
-        mask32(bf, kstep(f) << 7, kend, ktail);
-        keep32(bf, live);
-        if ((i & 1) == 1) {  // static: refill this slot and its partner together (they are both consumed now)
-          const int fn0 = st_begin + sl - 1 + PB, fn1 = fn0 + 1;
-          load32(bq[i - 1], brow, kstep(fn0 < total_f ? fn0 : last_f) << 7, kend, true);
-          load32(bq[i], brow, kstep(fn1 < total_f ? fn1 : last_f) << 7, kend, true);
+      for (int i = 0; i < PB; ++i) {  // queue slot i == (flat step) % PB (phase lengths are multiples of PB
+        const int sl = s0 + i;        //  except possibly the last one, whose padding steps are zeroed)
+        int t = (sl < nsteps ? sl : nsteps - 1) + rot;
+        t = t >= nsteps ? t - nsteps : t;  // local (rotated) step inside the LDS image
+        if constexpr (EXACT) {
+          wait_frag<2 * (PB - 1)>(bq[i]);
+        } else {
+          mask32(bq[i], (st_begin + t) << 7, kend, true);
+          keep32(bq[i], sl < nsteps);
         }
-        const char* ap = abase + (kstep(f) - st_begin) * L::STEP_BYTES;
+        const char* ap = abase + t * L::STEP_BYTES;
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
           Frag32 af;
@@ -519,13 +701,16 @@ __global__ __launch_bounds__(512) void fp8_gemm_astat_direct_kernel(GemmArgs p, 
           af.v[1] = *reinterpret_cast<const uint4*>(ap + mb * 512 + 16);
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk)
-            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(af.l[kk], bf.l[kk], acc[mb], 0, 0, 0);
+            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(af.l[kk], bq[i].l[kk], acc[mb], 0, 0, 0);
         }
+        ldw(bq[i], next_kstep());  // refill the slot AFTER its MFMAs consumed it: no register copy
+        __builtin_amdgcn_sched_barrier(0);  // keep the refill here (the scheduler would sink all 8 to the loop end)
       }
     }
   }
 
   // ---- epilogue through a wave-private LDS patch (transposes to 16-B row segments)
+  if constexpr (EXACT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the never-consumed tail loads
   __syncthreads();  // the A image is dead: reuse its memory
   T* ep = reinterpret_cast<T*>(smem) + wave * (L::ROWS * 24);  // [ROWS][16] (+8 pad)
   const float sbv = n_ok ? p.sb[n] : 0.f;
@@ -559,15 +744,33 @@ int launch_astat_direct(const GemmArgs& p, hipStream_t s, bool& used) {
   int steps_per_slice = (((steps_total + SK - 1) / SK) + 7) & ~7;
   if (steps_per_slice > max_steps) return 0;
   SK = (steps_total + steps_per_slice - 1) / steps_per_slice;
-  auto kern = fp8_gemm_astat_direct_kernel<OUT_DTYPE, MB>;
-  static int attr_rc = check_hip(
-      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-      "hipFuncSetAttribute");
+  if ((int64_t)p.N * p.b_sn >= ((int64_t)1 << 32)) return 0;  // per-lane weight offsets are 32-bit
+  const int ns_last = steps_total - (SK - 1) * steps_per_slice;
+  const bool exact = (p.K & 127) == 0 && (ns_last & 7) == 0;
+  auto kern = exact ? fp8_gemm_astat_direct_kernel<OUT_DTYPE, MB, true> : fp8_gemm_astat_direct_kernel<OUT_DTYPE, MB, false>;
+  static int attr_rc = [] {
+    int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(fp8_gemm_astat_direct_kernel<OUT_DTYPE, MB, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                       "hipFuncSetAttribute");
+    if (rc) return rc;
+    return check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(fp8_gemm_astat_direct_kernel<OUT_DTYPE, MB, false>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                     "hipFuncSetAttribute");
+  }();
   if (attr_rc) return attr_rc;
   int lds = steps_per_slice * L::STEP_BYTES;
   const int ep_bytes = 8 * L::ROWS * 24 * 2;
   if (lds < ep_bytes) lds = ep_bytes;
-  hipLaunchKernelGGL(kern, dim3((unsigned)((nblocks + 7) / 8)), dim3(512), lds, s, p, SK, steps_per_slice);
+  // waves per workgroup: one workgroup per CU (the A image fills the LDS), so pick the count that leaves
+  // the fewest column blocks on the busiest CU (N = 28672: 7 waves -> 256 workgroups, 8 -> only 224).
+  // (measured at N = 28672: M = 16 28.0 us with 7 waves vs 29.0 with 8; M = 64 prefers 8 waves: 39.9 vs 42.3)
+  int nw = 8, best = 1 << 30;
+  for (int c = 8; c >= (MB == 4 ? 8 : 4); --c) {
+    const int blocks = (nblocks + c - 1) / c;
+    const int cost = ((blocks + 255) / 256) * c;
+    if (cost < best) { best = cost; nw = c; }
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)((nblocks + nw - 1) / nw)), dim3(64 * nw), lds, s, p, SK, steps_per_slice);
   used = true;
   return check_hip(hipGetLastError(), "fp8_gemm_astat_direct launch");
 }
@@ -846,6 +1049,14 @@ int run_gemm(const GemmArgs& p, float* workspace, int64_t workspace_floats, hipS
       int rc = p.M <= 16   ? launch_astat<OUT_DTYPE, 1>(p, workspace, workspace_floats, s, used)
                : p.M <= 32 ? launch_astat<OUT_DTYPE, 2>(p, workspace, workspace_floats, s, used)
                            : launch_astat<OUT_DTYPE, 4>(p, workspace, workspace_floats, s, used);
+      if (rc || used) return rc;
+    }
+    static const bool no_oneshot = getenv("SGL_MI355_NO_ONESHOT") != nullptr;  // tuning / A-B aid
+    if (!no_oneshot) {
+      bool used = false;
+      int rc = p.M <= 16   ? launch_oneshot<OUT_DTYPE, 1>(p, s, used)
+               : p.M <= 32 ? launch_oneshot<OUT_DTYPE, 2>(p, s, used)
+                           : launch_oneshot<OUT_DTYPE, 4>(p, s, used);
       if (rc || used) return rc;
     }
     if (p.M <= 16) return dispatch_skinny<OUT_DTYPE, 1>(p, s);
