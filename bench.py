@@ -308,6 +308,18 @@ def main():
     ctx_mid = args.ctx + args.warmup + args.steps + min(args.steps, 8) / 2
     alg_bytes = args.batch * ctx_mid * hkv * 2 * d * 2 + 4 * args.batch * ctx_mid + 2 * args.batch * hq * 2 * d
     achieved = alg_bytes / (attn_ms * 1e-3) / 1e9
+    # HBM traffic of that kernel from the committed rocprofv3 --pmc passes (bench.py cannot run the profiler on
+    # itself): measured bytes / algorithmic bytes of the same kernel at the same geometry, applied to this launch.
+    traffic, traffic_src = None, None
+    try:
+        pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                                          "r01_decode_pmc_summary.json")))
+        if tp == 1 and args.batch == 64 and (hq, hkv, d) == (32, 8, 128):
+            traffic = int(alg_bytes * pmc["traffic_over_algorithmic"])
+            traffic_src = ("profiles/r01_decode_pmc_summary.json: FETCH_SIZE x2 (gfx950) + WRITE_SIZE, separate --pmc "
+                           f"passes, ratio {pmc['traffic_over_algorithmic']} to algorithmic bytes at bs=64 ctx=2048")
+    except (OSError, KeyError, ValueError):
+        pass
     out = {
         "metric": "output tokens/s (decode, whole model step) + p50 TTFT", "value": round(value, 1), "unit": "tokens/s",
         "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -320,7 +332,8 @@ def main():
                    "parallelism": f"tp{tp}"},
         "roofline": {"bound": "hbm", "kernel": "decode_mfma_kernel (paged decode attention)",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                     "traffic_source": traffic_src,
                      "avg_launch_us": round(attn_ms * 1e3, 2), "launches_timed": n_launch,
                      "algorithmic_bytes_per_launch": int(alg_bytes)},
     }

@@ -85,6 +85,7 @@ struct GemmArgs {
   const void* bias;
   void* out;
   int M, N, K;
+  int nt;  // weight loads carry the non-temporal hint (each weight byte is read once per step by one CU)
 };
 
 union Frag32 {  // 32 contiguous K bytes of one row = four MFMA operands
@@ -102,6 +103,10 @@ union Frag32 {  // 32 contiguous K bytes of one row = four MFMA operands
 __device__ __forceinline__ void gload32_asm(Frag32& f, const uint8_t* sbase, uint32_t voff) {
   asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(f.x[0]) : "v"(voff), "s"(sbase) : "memory");
   asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=v"(f.x[1]) : "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void gload32_asm_nt(Frag32& f, const uint8_t* sbase, uint32_t voff) {
+  asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(f.x[0]) : "v"(voff), "s"(sbase) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:64 nt" : "=v"(f.x[1]) : "v"(voff), "s"(sbase) : "memory");
 }
 template <int N>
 __device__ __forceinline__ void wait_frag(Frag32& f) {
@@ -360,7 +365,13 @@ __global__ __launch_bounds__(512) void fp8_gemm_oneshot_kernel(GemmArgs p) {
   Frag32 bq[S];
   Frag32 aq[S][MB];
 #pragma unroll
-  for (int s = 0; s < S; ++s) gload32_asm(bq[s], p.b + k0 + (s << 7), boff);
+  if (p.nt) {
+#pragma unroll
+    for (int s = 0; s < S; ++s) gload32_asm_nt(bq[s], p.b + k0 + (s << 7), boff);
+  } else {
+#pragma unroll
+    for (int s = 0; s < S; ++s) gload32_asm(bq[s], p.b + k0 + (s << 7), boff);
+  }
 #pragma unroll
   for (int s = 0; s < S; ++s)
 #pragma unroll
@@ -643,7 +654,8 @@ __global__ __launch_bounds__(512) void fp8_gemm_astat_direct_kernel(GemmArgs p, 
   auto ldw = [&](Frag32& f, int kstep_) __attribute__((always_inline)) {
     const int k = kstep_ << 7;
     if constexpr (EXACT) {
-      gload32_asm(f, p.b + k, lane_off);  // scalar base
+      if (p.nt) gload32_asm_nt(f, p.b + k, lane_off);  // scalar base; uniform branch
+      else gload32_asm(f, p.b + k, lane_off);
     } else {
       f.v[0] = ld16(p.b + lane_off, k, kend);
       f.v[1] = ld16(p.b + lane_off, k + 64, kend);
@@ -1118,7 +1130,9 @@ extern "C" int sgl_mi355_fp8_scaled_mm(
                      reinterpret_cast<uintptr_t>(out) % 16 == 0,
                  "fp8_scaled_mm: operands must be 16-byte aligned");
   GemmArgs p{(const uint8_t*)mat_a, a_stride_m, (const uint8_t*)mat_b, b_stride_n, scales_a, scales_b, bias, out,
-             (int)M, (int)N, (int)K};
+             (int)M, (int)N, (int)K, 0};
+  static const int nt_env = [] { const char* e = getenv("SGL_MI355_WEIGHT_NT"); return e ? atoi(e) : 0; }();
+  p.nt = nt_env;
   hipStream_t s = as_stream(stream);
   return out_dtype == SGL_MI355_BF16 ? run_gemm<SGL_MI355_BF16>(p, workspace, workspace_floats, s)
                                      : run_gemm<SGL_MI355_FP16>(p, workspace, workspace_floats, s);
