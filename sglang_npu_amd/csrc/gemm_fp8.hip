@@ -28,6 +28,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <type_traits>
 #include "common.h"
 
 namespace sglm {
@@ -85,7 +86,6 @@ struct GemmArgs {
   const void* bias;
   void* out;
   int M, N, K;
-  int nt;  // weight loads carry the non-temporal hint (each weight byte is read once per step by one CU)
 };
 
 union Frag32 {  // 32 contiguous K bytes of one row = four MFMA operands
@@ -104,9 +104,16 @@ __device__ __forceinline__ void gload32_asm(Frag32& f, const uint8_t* sbase, uin
   asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(f.x[0]) : "v"(voff), "s"(sbase) : "memory");
   asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=v"(f.x[1]) : "v"(voff), "s"(sbase) : "memory");
 }
-__device__ __forceinline__ void gload32_asm_nt(Frag32& f, const uint8_t* sbase, uint32_t voff) {
-  asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(f.x[0]) : "v"(voff), "s"(sbase) : "memory");
-  asm volatile("global_load_dwordx4 %0, %1, %2 offset:64 nt" : "=v"(f.x[1]) : "v"(voff), "s"(sbase) : "memory");
+// (a non-temporal hint on these loads was measured: no difference on any decode shape, profiles/README.md)
+// End of a hand-scheduled loop: the tail refills are never consumed, so hipcc considers their destination
+// registers free right after the asm that issued them and may place epilogue address arithmetic there --
+// which the load, landing later, overwrites (seen as a GPU memory fault).  Wait for everything, THEN "use"
+// every queue register so that they stay allocated across the wait.
+template <int PB>
+__device__ __forceinline__ void drain_frags(Frag32 (&q)[PB]) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < PB; ++i) asm volatile("" ::"v"(q[i].x[0]), "v"(q[i].x[1]));
 }
 template <int N>
 __device__ __forceinline__ void wait_frag(Frag32& f) {
@@ -365,13 +372,7 @@ __global__ __launch_bounds__(512) void fp8_gemm_oneshot_kernel(GemmArgs p) {
   Frag32 bq[S];
   Frag32 aq[S][MB];
 #pragma unroll
-  if (p.nt) {
-#pragma unroll
-    for (int s = 0; s < S; ++s) gload32_asm_nt(bq[s], p.b + k0 + (s << 7), boff);
-  } else {
-#pragma unroll
-    for (int s = 0; s < S; ++s) gload32_asm(bq[s], p.b + k0 + (s << 7), boff);
-  }
+  for (int s = 0; s < S; ++s) gload32_asm(bq[s], p.b + k0 + (s << 7), boff);
 #pragma unroll
   for (int s = 0; s < S; ++s)
 #pragma unroll
@@ -654,8 +655,7 @@ __global__ __launch_bounds__(512) void fp8_gemm_astat_direct_kernel(GemmArgs p, 
   auto ldw = [&](Frag32& f, int kstep_) __attribute__((always_inline)) {
     const int k = kstep_ << 7;
     if constexpr (EXACT) {
-      if (p.nt) gload32_asm_nt(f, p.b + k, lane_off);  // scalar base; uniform branch
-      else gload32_asm(f, p.b + k, lane_off);
+      gload32_asm(f, p.b + k, lane_off);  // scalar base
     } else {
       f.v[0] = ld16(p.b + lane_off, k, kend);
       f.v[1] = ld16(p.b + lane_off, k + 64, kend);
@@ -722,18 +722,27 @@ __global__ __launch_bounds__(512) void fp8_gemm_astat_direct_kernel(GemmArgs p, 
   }
 
   // ---- epilogue through a wave-private LDS patch (transposes to 16-B row segments)
-  if constexpr (EXACT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the never-consumed tail loads
+  if constexpr (EXACT) drain_frags(bq);  // the never-consumed tail loads
   __syncthreads();  // the A image is dead: reuse its memory
   T* ep = reinterpret_cast<T*>(smem) + wave * (L::ROWS * 24);  // [ROWS][16] (+8 pad)
-  const float sbv = n_ok ? p.sb[n] : 0.f;
-  const float bv = (p.bias && n_ok) ? H::to_f32(reinterpret_cast<const T*>(p.bias)[n]) : 0.f;
+  const float sbv = p.sb[n_ok ? n : p.N - 1];
+  const float bv = p.bias ? H::to_f32(reinterpret_cast<const T*>(p.bias)[n_ok ? n : p.N - 1]) : 0.f;
+  // unconditional (clamped) scale loads, all in flight together: `m < M ? sa[m] : 0` compiles to a branch
+  // plus vmcnt(0) per row -- 16 serial L2 round trips at M = 64
+  float sav[MB][4];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int m = 16 * mb + 4 * g + r;
-      const float sa = m < p.M ? p.sa[m] : 0.f;
-      ep[m * 24 + r16] = H::from_f32(acc[mb][r] * sbv * sa + bv);
+      sav[mb][r] = p.sa[m < p.M ? m : p.M - 1];
+    }
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = 16 * mb + 4 * g + r;
+      ep[m * 24 + r16] = H::from_f32(acc[mb][r] * sbv * sav[mb][r] + bv);
     }
   wait_lgkmcnt0();
   for (int c = lane; c < L::ROWS * 2; c += 64) {
@@ -743,6 +752,175 @@ __global__ __launch_bounds__(512) void fp8_gemm_astat_direct_kernel(GemmArgs p, 
       *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.out) + (int64_t)m * p.N + nn) =
           *reinterpret_cast<const uint4*>(ep + m * 24 + half * 8);
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight-streaming skinny GEMM for wide N (gate_up at decode): one column block per wave over ALL of K,
+// activations double-buffered through LDS by LDS-DMA while the weights stream through registers.
+//
+// What the phase-filled kernel above loses at M = 64: its A image is rebuilt per phase by a
+// load -> mask -> ds_write loop of ~40 VALU per 16 B behind two barriers, during which no new weight load is
+// issued (2 x 128 KB per workgroup at K = 4096; gate_up: 41 us at M = 64 vs 28 us at M = 16).  Here
+//   * the image is [step][row][128 B] with the 16-B chunk index XOR-swizzled by (row >> 1) & 7: a DMA
+//     instruction lands 8 rows x 128 B = 1 KiB contiguous in LDS from 8 fully coalesced 128-B row segments
+//     (the swizzle is applied on the SOURCE side, inside one 128-B line), and the MFMA-fragment
+//     ds_read_b128 of 16 rows x 16 B hits 16 distinct bank groups;
+//   * phase p+1 (PH = 32 / MB steps, 64 KiB) is DMA'd into the other buffer right after the barrier that
+//     opens phase p: one barrier per phase, no VGPR round trip, 8 DMA instructions per wave per phase;
+//   * DMA and weight loads share the in-order vmcnt queue, so the first 8 steps of a phase wait on
+//     vmcnt(14 + 8) and the rest on vmcnt(14); `vmcnt(16)` in front of the barrier proves the wave's own
+//     DMAs (older than the last 8 refills) have landed.
+template <int OUT_DTYPE, int MB>
+__global__ __launch_bounds__(512) void fp8_gemm_wstream_kernel(GemmArgs p) {
+  using H = Half16<OUT_DTYPE>;
+  using T = typename H::T;
+  constexpr int ROWS = 16 * MB;
+  constexpr int PH = 32 / MB;               // k-steps per phase
+  constexpr int STEP_BYTES = ROWS * 128;
+  constexpr int BUF_BYTES = PH * STEP_BYTES;  // 64 KiB
+  constexpr int PB = 8;                     // weight steps in flight per wave (16 KiB)
+  constexpr int FD = 8;                     // DMA instructions per wave per phase (64 units / 8 waves)
+  constexpr int UPS = 2 * MB;               // 1-KiB DMA units per k-step
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g = lane >> 4;
+  const int steps_total = p.K >> 7;
+  const int P = steps_total / PH;
+  const int nb = blockIdx.x * 8 + wave;  // this wave's column block
+  const int n = nb * 16 + r16;
+  const bool n_ok = n < p.N;
+  const uint32_t lane_off = (uint32_t)((int64_t)(n_ok ? n : 0) * p.b_sn + 16 * g);
+  const int rot = (nb * 3) & (PH - 1);   // per-column-block rotation of the sweep inside a phase
+  const int last = steps_total - 1;
+
+  // A fragment offsets inside a k-step: row r16 (+16 mb), chunks g and 4 + g, swizzled
+  const int sw = (r16 >> 1) & 7;
+  const uint32_t smem_base = lds_addr_of(smem);
+  const uint32_t o0 = r16 * 128 + 16 * (g ^ sw);
+  const uint32_t o1 = r16 * 128 + 16 * ((4 + g) ^ sw);
+
+  // DMA source offset of this lane: unit u = wave + 8 i -> (step u / UPS, row group u % UPS); the row group
+  // only depends on the wave, so one per-lane offset serves all of the wave's DMA instructions.
+  const int rg = wave % UPS;
+  const int drow = rg * 8 + (lane >> 3);
+  const int dj = (lane & 7) ^ ((drow >> 1) & 7);
+  const uint32_t a_voff = (uint32_t)((int64_t)(drow < p.M ? drow : p.M - 1) * p.a_sm + 16 * dj);
+  // the wave's share of phase `ph`'s image that is issued in 8-step group `gi` of the previous phase
+  constexpr int G = PH / PB;    // 8-step groups per phase
+  constexpr int FDG = FD / G;   // DMA instructions per wave per group
+  auto dma_part = [&](int ph, int buf, int gi) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < FDG; ++i) {
+      const int sl = (wave + 8 * (gi * FDG + i)) / UPS;
+      lds_dma16(p.a + ((ph * PH + sl) << 7) + a_voff, smem_base + buf * BUF_BYTES + sl * STEP_BYTES + rg * 1024);
+    }
+  };
+
+  int f_pf = 0;  // next flat step to prefetch; phases are contiguous runs of PH flat steps
+  auto refill = [&](Frag32& fr) __attribute__((always_inline)) {
+    const int f = f_pf < last ? f_pf : last;  // tail refills re-read the last step, never consumed
+    const int ks = (f & ~(PH - 1)) + ((f + rot) & (PH - 1));
+    gload32_asm(fr, p.b + (ks << 7), lane_off);
+    ++f_pf;
+  };
+
+  f32x4 acc[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int gi = 0; gi < G; ++gi) dma_part(0, 0, gi);
+  Frag32 bq[PB];
+#pragma unroll
+  for (int i = 0; i < PB; ++i) refill(bq[i]);
+
+  // ONE loop body for every 8-step group (a second copy of it -- e.g. a variant with another wait count --
+  // makes hipcc merge the in-flight weight registers of the two paths with v_mov copies placed in front of
+  // the wait, i.e. reads of registers whose loads have not landed).  Every group therefore issues the same
+  // number of DMAs: its 1/G share of the NEXT phase (the last phase re-sends itself into the idle buffer).
+  const int ngroups = steps_total / PB;
+  for (int gq = 0; gq < ngroups; ++gq) {
+    const int ph = gq / G, gi = gq % G;  // G is a power of two
+    if (gi == 0) {
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // this wave's DMAs of phase ph landed (older than 16 refills)
+      __syncthreads();                                   // ... everyone's; and buffer (ph+1)&1 is free again
+    }
+    const int nph = ph + 1 < P ? ph + 1 : ph;
+    dma_part(nph, (ph + 1) & 1, gi);
+    const uint32_t abuf = (ph & 1) * BUF_BYTES;
+    const int s0 = gi * PB;
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      const int t = (s0 + i + rot) & (PH - 1);  // local step held by slot i
+      wait_frag<2 * (PB - 1) + FDG>(bq[i]);
+      const char* a0 = smem + abuf + t * STEP_BYTES + o0;
+      const char* a1 = smem + abuf + t * STEP_BYTES + o1;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        Frag32 af;
+        af.v[0] = *reinterpret_cast<const uint4*>(a0 + mb * 2048);
+        af.v[1] = *reinterpret_cast<const uint4*>(a1 + mb * 2048);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(af.l[kk], bq[i].l[kk], acc[mb], 0, 0, 0);
+      }
+      refill(bq[i]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- epilogue through a wave-private LDS patch (transposes to 16-B row segments)
+  drain_frags(bq);  // the never-consumed tail refills
+  __syncthreads();                                  // the A buffers are dead: reuse their memory
+  T* ep = reinterpret_cast<T*>(smem) + wave * (ROWS * 24);  // [ROWS][16] (+8 pad)
+  const float sbv = p.sb[n_ok ? n : p.N - 1];
+  const float bv = p.bias ? H::to_f32(reinterpret_cast<const T*>(p.bias)[n_ok ? n : p.N - 1]) : 0.f;
+  // unconditional (clamped) scale loads, all in flight together: `m < M ? sa[m] : 0` compiles to a branch
+  // plus vmcnt(0) per row -- 16 serial L2 round trips at M = 64
+  float sav[MB][4];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = 16 * mb + 4 * g + r;
+      sav[mb][r] = p.sa[m < p.M ? m : p.M - 1];
+    }
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = 16 * mb + 4 * g + r;
+      ep[m * 24 + r16] = H::from_f32(acc[mb][r] * sbv * sav[mb][r] + bv);
+    }
+  wait_lgkmcnt0();
+  for (int c = lane; c < ROWS * 2; c += 64) {
+    const int m = c >> 1, half = c & 1;
+    const int nn = nb * 16 + half * 8;
+    if (m < p.M && nn < p.N)
+      *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.out) + (int64_t)m * p.N + nn) =
+          *reinterpret_cast<const uint4*>(ep + m * 24 + half * 8);
+  }
+}
+
+template <int OUT_DTYPE, int MB>
+int launch_wstream(const GemmArgs& p, hipStream_t s, bool& used) {
+  used = false;
+  constexpr int PH = 32 / MB;
+  if ((p.K & 127) != 0 || ((p.K >> 7) % PH) != 0 || (p.N & 7) != 0) return 0;
+  if ((int64_t)p.N * p.b_sn >= ((int64_t)1 << 32) || (int64_t)p.M * p.a_sm >= ((int64_t)1 << 32)) return 0;
+  if ((p.a_sm & 15) != 0) return 0;
+  auto kern = fp8_gemm_wstream_kernel<OUT_DTYPE, MB>;
+  constexpr int lds = 2 * 64 * 1024;
+  static int attr_rc = check_hip(
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
+      "hipFuncSetAttribute");
+  if (attr_rc) return attr_rc;
+  const int nblocks = (p.N + 15) / 16;
+  hipLaunchKernelGGL(kern, dim3((unsigned)((nblocks + 7) / 8)), dim3(512), lds, s, p);
+  used = true;
+  return check_hip(hipGetLastError(), "fp8_gemm_wstream launch");
 }
 
 template <int OUT_DTYPE, int MB>
@@ -1049,7 +1227,15 @@ template <int OUT_DTYPE>
 int run_gemm(const GemmArgs& p, float* workspace, int64_t workspace_floats, hipStream_t s) {
   if (p.M <= 64) {
     static const bool no_astat = getenv("SGL_MI355_NO_ASTAT") != nullptr;  // tuning / A-B aid
-    if (!no_astat && p.N >= 16 * 8 * 160) {  // >= ~160 workgroups of 8 column blocks: one block per wave, direct epilogue
+    static const bool no_wstream = getenv("SGL_MI355_NO_WSTREAM") != nullptr;  // tuning / A-B aid
+    if (!no_wstream && p.N >= 16 * 8 * 160) {  // >= ~160 workgroups of 8 column blocks
+      bool used = false;
+      int rc = p.M <= 16   ? launch_wstream<OUT_DTYPE, 1>(p, s, used)
+               : p.M <= 32 ? launch_wstream<OUT_DTYPE, 2>(p, s, used)
+                           : launch_wstream<OUT_DTYPE, 4>(p, s, used);
+      if (rc || used) return rc;
+    }
+    if (!no_astat && p.N >= 16 * 8 * 160) {  // same shapes, K tails / odd step counts: phase-filled A image
       bool used = false;
       int rc = p.M <= 16   ? launch_astat_direct<OUT_DTYPE, 1>(p, s, used)
                : p.M <= 32 ? launch_astat_direct<OUT_DTYPE, 2>(p, s, used)
@@ -1130,9 +1316,7 @@ extern "C" int sgl_mi355_fp8_scaled_mm(
                      reinterpret_cast<uintptr_t>(out) % 16 == 0,
                  "fp8_scaled_mm: operands must be 16-byte aligned");
   GemmArgs p{(const uint8_t*)mat_a, a_stride_m, (const uint8_t*)mat_b, b_stride_n, scales_a, scales_b, bias, out,
-             (int)M, (int)N, (int)K, 0};
-  static const int nt_env = [] { const char* e = getenv("SGL_MI355_WEIGHT_NT"); return e ? atoi(e) : 0; }();
-  p.nt = nt_env;
+             (int)M, (int)N, (int)K};
   hipStream_t s = as_stream(stream);
   return out_dtype == SGL_MI355_BF16 ? run_gemm<SGL_MI355_BF16>(p, workspace, workspace_floats, s)
                                      : run_gemm<SGL_MI355_FP16>(p, workspace, workspace_floats, s);

@@ -112,6 +112,27 @@ def test_fp8_scaled_mm_full_size_properties():
         torch.testing.assert_close(small[rows][:, cols].double(), ref, rtol=2.0 ** -7, atol=1e-6)
 
 
+@pytest.mark.parametrize("M", [1, 5, 16, 17, 32, 48, 64])
+@pytest.mark.parametrize("N,K", [(28672, 4096), (20480, 1024), (20488, 2048), (24576, 4224), (28672, 512)])
+def test_fp8_scaled_mm_wide_n_decode_kernels(M, N, K):
+    """Wide-N decode shapes take the weight-streaming kernels (LDS-DMA double-buffered A / phase-filled A,
+    depending on K): every M bucket (16/32/64 rows), ragged N, K with and without a 128 tail, bias on odd M.
+    Checked against an fp64 matmul of the same fp8 values (order-free up to fp32 accumulation -> 1 ulp)."""
+    g = torch.Generator(device=DEV).manual_seed(M * 7 + N + K)
+    dt = torch.bfloat16 if M % 2 == 0 else torch.float16
+    a = ((torch.rand(M, K, device=DEV, generator=g) - 0.5) * 16).to(torch.float8_e4m3fn)
+    w = ((torch.rand(N, K, device=DEV, generator=g) - 0.5) * 16).to(torch.float8_e4m3fn)
+    sa = torch.rand(M, device=DEV, generator=g) * 1e-2 + 1e-3
+    sb = torch.rand(N, device=DEV, generator=g) * 1e-2 + 1e-3
+    bias = torch.randn(N, device=DEV, generator=g).to(dt) if M % 2 else None
+    out = ops.fp8_scaled_mm(a, w.t(), sa, sb, dt, bias)
+    ref = (a.double() @ w.double().t()) * sb.double() * sa.double()[:, None]
+    if bias is not None:
+        ref = ref + bias.double()
+    ulp = 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10
+    torch.testing.assert_close(out.double(), ref, rtol=ulp, atol=ulp * float(ref.abs().max()) * 0.05)
+
+
 def test_fp8_scaled_mm_checks():
     a = torch.zeros(4, 24, dtype=torch.float8_e4m3fn, device=DEV)
     w = torch.zeros(16, 24, dtype=torch.float8_e4m3fn, device=DEV)
