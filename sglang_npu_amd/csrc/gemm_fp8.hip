@@ -765,162 +765,237 @@ __global__ __launch_bounds__(512) void fp8_gemm_astat_direct_kernel(GemmArgs p, 
 //     instruction lands 8 rows x 128 B = 1 KiB contiguous in LDS from 8 fully coalesced 128-B row segments
 //     (the swizzle is applied on the SOURCE side, inside one 128-B line), and the MFMA-fragment
 //     ds_read_b128 of 16 rows x 16 B hits 16 distinct bank groups;
-//   * phase p+1 (PH = 32 / MB steps, 64 KiB) is DMA'd into the other buffer right after the barrier that
-//     opens phase p: one barrier per phase, no VGPR round trip, 8 DMA instructions per wave per phase;
-//   * DMA and weight loads share the in-order vmcnt queue, so the first 8 steps of a phase wait on
-//     vmcnt(14 + 8) and the rest on vmcnt(14); `vmcnt(16)` in front of the barrier proves the wave's own
-//     DMAs (older than the last 8 refills) have landed.
-template <int OUT_DTYPE, int MB>
-__global__ __launch_bounds__(512) void fp8_gemm_wstream_kernel(GemmArgs p) {
+//   * a dedicated PRODUCER wave (the last one of the workgroup) DMAs phase p+1 (PH k-steps, <= 64 KiB) into the
+//     other buffer right after the barrier that opens phase p: one barrier per phase, no VGPR round trip,
+//     and the 4..8 consumer waves run a pure weight loop with a single wait count (vmcnt(14));
+//   * the consumer count is chosen per shape so that the workgroups fill the 256 CUs evenly (a CU moves
+//     only ~10 B/clk from HBM, so an idle CU is lost bandwidth: N = 28672 -> 7 consumers x 256 workgroups).
+template <int OUT_DTYPE, int MB, int PH, bool SLAB>
+__global__ __launch_bounds__(576) void fp8_gemm_wstream_kernel(GemmArgs p, float* slabs, int phases_per_slice) {
+  static_assert(PH == 8 || PH == 16 || PH == 32, "PH");
+  static_assert(PH * MB <= 32, "one A buffer is at most 64 KiB");
   using H = Half16<OUT_DTYPE>;
   using T = typename H::T;
   constexpr int ROWS = 16 * MB;
-  constexpr int PH = 32 / MB;               // k-steps per phase
   constexpr int STEP_BYTES = ROWS * 128;
-  constexpr int BUF_BYTES = PH * STEP_BYTES;  // 64 KiB
-  constexpr int PB = 8;                     // weight steps in flight per wave (16 KiB)
-  constexpr int FD = 8;                     // DMA instructions per wave per phase (64 units / 8 waves)
-  constexpr int UPS = 2 * MB;               // 1-KiB DMA units per k-step
+  constexpr int BUF_BYTES = PH * STEP_BYTES;  // <= 64 KiB
+  constexpr int PB = 8;                       // weight steps in flight per wave (16 KiB)
+  constexpr int UPS = 2 * MB;                 // 1-KiB DMA units per k-step
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int NC = (int)(blockDim.x >> 6) - 1;  // consumer waves; wave NC is the DMA producer
   const int r16 = lane & 15, g = lane >> 4;
-  const int steps_total = p.K >> 7;
-  const int P = steps_total / PH;
-  const int nb = blockIdx.x * 8 + wave;  // this wave's column block
+  const int P_total = (p.K >> 7) / PH;
+  // SLAB: blockIdx.y owns phases [ph0, ph1) and writes an fp32 partial; otherwise all of K
+  const int ph0 = SLAB ? (int)blockIdx.y * phases_per_slice : 0;
+  const int ph1 = SLAB ? (ph0 + phases_per_slice < P_total ? ph0 + phases_per_slice : P_total) : P_total;
+  const int nph = ph1 - ph0;
+  const int nb = blockIdx.x * NC + wave;  // a consumer wave's column block
   const int n = nb * 16 + r16;
   const bool n_ok = n < p.N;
+  const uint32_t smem_base = lds_addr_of(smem);
+
+  f32x4 acc[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (wave == NC) {
+    // ---------------- producer: the A image of every phase, one 1-KiB unit (8 rows x 128 B) per instruction.
+    // Lane i of a unit lands at LDS chunk i & 7 of row i >> 3 and therefore fetches source chunk
+    // (i & 7) ^ ((row >> 1) & 7) of that row: the swizzle is applied inside one coalesced 128-B line.
+    const uint8_t* a_lane[UPS];
+#pragma unroll
+    for (int rg = 0; rg < UPS; ++rg) {
+      const int drow = rg * 8 + (lane >> 3);
+      const int dj = (lane & 7) ^ ((drow >> 1) & 7);
+      a_lane[rg] = p.a + (int64_t)(drow < p.M ? drow : p.M - 1) * p.a_sm + 16 * dj;  // rows past M: never stored
+    }
+    auto dma_phase = [&](int ph, int buf) __attribute__((always_inline)) {
+      for (int sl = 0; sl < PH; ++sl) {
+#pragma unroll
+        for (int rg = 0; rg < UPS; ++rg)
+          lds_dma16(a_lane[rg] + ((ph * PH + sl) << 7), smem_base + buf * BUF_BYTES + sl * STEP_BYTES + rg * 1024);
+      }
+    };
+    // One workgroup barrier per phase.  (LDS flags instead of barriers were tried -- they would let the waves
+    // drift apart -- and are NOT valid: LDS-DMA data is ordered for another wave's ds_read only by the issuing
+    // wave's vmcnt followed by a barrier the reader has passed; with a ds_write flag the M = 7 down_proj case
+    // read stale rows.  They were not faster either.)
+    dma_phase(ph0, 0);
+    for (int lp = 0; lp < nph; ++lp) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // phase lp has landed
+      __syncthreads();                                   // barrier #lp: consumers may read it; the other buffer is free
+      if (lp + 1 < nph) dma_phase(ph0 + lp + 1, (lp + 1) & 1);
+    }
+    __syncthreads();  // the consumers' final barrier
+    return;
+  }
+
+  // ---------------- consumers: one column block each, weights through registers, A fragments from LDS
   const uint32_t lane_off = (uint32_t)((int64_t)(n_ok ? n : 0) * p.b_sn + 16 * g);
   const int rot = (nb * 3) & (PH - 1);   // per-column-block rotation of the sweep inside a phase
-  const int last = steps_total - 1;
-
+  const int last = ph1 * PH - 1;
   // A fragment offsets inside a k-step: row r16 (+16 mb), chunks g and 4 + g, swizzled
   const int sw = (r16 >> 1) & 7;
-  const uint32_t smem_base = lds_addr_of(smem);
   const uint32_t o0 = r16 * 128 + 16 * (g ^ sw);
   const uint32_t o1 = r16 * 128 + 16 * ((4 + g) ^ sw);
 
-  // DMA source offset of this lane: unit u = wave + 8 i -> (step u / UPS, row group u % UPS); the row group
-  // only depends on the wave, so one per-lane offset serves all of the wave's DMA instructions.
-  const int rg = wave % UPS;
-  const int drow = rg * 8 + (lane >> 3);
-  const int dj = (lane & 7) ^ ((drow >> 1) & 7);
-  const uint32_t a_voff = (uint32_t)((int64_t)(drow < p.M ? drow : p.M - 1) * p.a_sm + 16 * dj);
-  // the wave's share of phase `ph`'s image that is issued in 8-step group `gi` of the previous phase
-  constexpr int G = PH / PB;    // 8-step groups per phase
-  constexpr int FDG = FD / G;   // DMA instructions per wave per group
-  auto dma_part = [&](int ph, int buf, int gi) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < FDG; ++i) {
-      const int sl = (wave + 8 * (gi * FDG + i)) / UPS;
-      lds_dma16(p.a + ((ph * PH + sl) << 7) + a_voff, smem_base + buf * BUF_BYTES + sl * STEP_BYTES + rg * 1024);
-    }
-  };
-
-  int f_pf = 0;  // next flat step to prefetch; phases are contiguous runs of PH flat steps
+  int f_pf = ph0 * PH;  // next flat step to prefetch; phases are contiguous runs of PH flat steps
   auto refill = [&](Frag32& fr) __attribute__((always_inline)) {
     const int f = f_pf < last ? f_pf : last;  // tail refills re-read the last step, never consumed
     const int ks = (f & ~(PH - 1)) + ((f + rot) & (PH - 1));
     gload32_asm(fr, p.b + (ks << 7), lane_off);
     ++f_pf;
   };
-
-  f32x4 acc[MB];
-#pragma unroll
-  for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll
-  for (int gi = 0; gi < G; ++gi) dma_part(0, 0, gi);
   Frag32 bq[PB];
 #pragma unroll
   for (int i = 0; i < PB; ++i) refill(bq[i]);
 
-  // ONE loop body for every 8-step group (a second copy of it -- e.g. a variant with another wait count --
-  // makes hipcc merge the in-flight weight registers of the two paths with v_mov copies placed in front of
-  // the wait, i.e. reads of registers whose loads have not landed).  Every group therefore issues the same
-  // number of DMAs: its 1/G share of the NEXT phase (the last phase re-sends itself into the idle buffer).
-  const int ngroups = steps_total / PB;
-  for (int gq = 0; gq < ngroups; ++gq) {
-    const int ph = gq / G, gi = gq % G;  // G is a power of two
-    if (gi == 0) {
-      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // this wave's DMAs of phase ph landed (older than 16 refills)
-      __syncthreads();                                   // ... everyone's; and buffer (ph+1)&1 is free again
-    }
-    const int nph = ph + 1 < P ? ph + 1 : ph;
-    dma_part(nph, (ph + 1) & 1, gi);
-    const uint32_t abuf = (ph & 1) * BUF_BYTES;
-    const int s0 = gi * PB;
+  // ONE copy of the 8-step body (a second copy -- e.g. a variant with another wait count -- makes hipcc merge
+  // the in-flight weight registers of the two paths with v_mov copies placed in front of the wait, i.e. reads
+  // of registers whose loads have not landed).
+#pragma clang loop unroll(disable)  // no peeled copies either: see above
+  for (int lp = 0; lp < nph; ++lp) {
+    __syncthreads();  // barrier #lp: phase lp is in LDS
+    const uint32_t abuf = (lp & 1) * BUF_BYTES;
+    for (int s0 = 0; s0 < PH; s0 += PB) {
 #pragma unroll
-    for (int i = 0; i < PB; ++i) {
-      const int t = (s0 + i + rot) & (PH - 1);  // local step held by slot i
-      wait_frag<2 * (PB - 1) + FDG>(bq[i]);
-      const char* a0 = smem + abuf + t * STEP_BYTES + o0;
-      const char* a1 = smem + abuf + t * STEP_BYTES + o1;
+      for (int i = 0; i < PB; ++i) {
+        const int t = (s0 + i + rot) & (PH - 1);  // local step held by slot i
+        wait_frag<2 * (PB - 1)>(bq[i]);
+        const char* a0 = smem + abuf + t * STEP_BYTES + o0;
+        const char* a1 = smem + abuf + t * STEP_BYTES + o1;
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
-        Frag32 af;
-        af.v[0] = *reinterpret_cast<const uint4*>(a0 + mb * 2048);
-        af.v[1] = *reinterpret_cast<const uint4*>(a1 + mb * 2048);
+        for (int mb = 0; mb < MB; ++mb) {
+          Frag32 af;
+          af.v[0] = *reinterpret_cast<const uint4*>(a0 + mb * 2048);
+          af.v[1] = *reinterpret_cast<const uint4*>(a1 + mb * 2048);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(af.l[kk], bq[i].l[kk], acc[mb], 0, 0, 0);
+          for (int kk = 0; kk < 4; ++kk)
+            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(af.l[kk], bq[i].l[kk], acc[mb], 0, 0, 0);
+        }
+        refill(bq[i]);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      refill(bq[i]);
-      __builtin_amdgcn_sched_barrier(0);
     }
   }
 
-  // ---- epilogue through a wave-private LDS patch (transposes to 16-B row segments)
   drain_frags(bq);  // the never-consumed tail refills
-  __syncthreads();                                  // the A buffers are dead: reuse their memory
-  T* ep = reinterpret_cast<T*>(smem) + wave * (ROWS * 24);  // [ROWS][16] (+8 pad)
-  const float sbv = p.sb[n_ok ? n : p.N - 1];
-  const float bv = p.bias ? H::to_f32(reinterpret_cast<const T*>(p.bias)[n_ok ? n : p.N - 1]) : 0.f;
-  // unconditional (clamped) scale loads, all in flight together: `m < M ? sa[m] : 0` compiles to a branch
-  // plus vmcnt(0) per row -- 16 serial L2 round trips at M = 64
-  float sav[MB][4];
+  __syncthreads();  // the A buffers are dead: reuse their memory
+  if constexpr (SLAB) {
+    // ---- fp32 partial of this K slice -> slabs[blockIdx.y][m][n], 16-B stores through a wave-private patch
+    float* ep = reinterpret_cast<float*>(smem) + wave * (ROWS * 20);  // [ROWS][16] (+4 pad)
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb)
+    for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = 16 * mb + 4 * g + r;
-      sav[mb][r] = p.sa[m < p.M ? m : p.M - 1];
+      for (int r = 0; r < 4; ++r) ep[(16 * mb + 4 * g + r) * 20 + r16] = acc[mb][r];
+    wait_lgkmcnt0();
+    float* dst = slabs + (int64_t)blockIdx.y * p.M * p.N;
+    for (int c = lane; c < ROWS * 4; c += 64) {
+      const int m = c >> 2, q = c & 3;
+      const int nn = nb * 16 + q * 4;
+      if (m < p.M && nn < p.N)
+        *reinterpret_cast<f32x4*>(dst + (int64_t)m * p.N + nn) = *reinterpret_cast<const f32x4*>(ep + m * 20 + q * 4);
     }
+  } else {
+    // ---- epilogue through a wave-private LDS patch (transposes to 16-B row segments)
+    T* ep = reinterpret_cast<T*>(smem) + wave * (ROWS * 24);  // [ROWS][16] (+8 pad)
+    const float sbv = p.sb[n_ok ? n : p.N - 1];
+    const float bv = p.bias ? H::to_f32(reinterpret_cast<const T*>(p.bias)[n_ok ? n : p.N - 1]) : 0.f;
+    // unconditional (clamped) scale loads, all in flight together: `m < M ? sa[m] : 0` compiles to a branch
+    // plus vmcnt(0) per row -- 16 serial L2 round trips at M = 64
+    float sav[MB][4];
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb)
+    for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = 16 * mb + 4 * g + r;
-      ep[m * 24 + r16] = H::from_f32(acc[mb][r] * sbv * sav[mb][r] + bv);
+      for (int r = 0; r < 4; ++r) {
+        const int m = 16 * mb + 4 * g + r;
+        sav[mb][r] = p.sa[m < p.M ? m : p.M - 1];
+      }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = 16 * mb + 4 * g + r;
+        ep[m * 24 + r16] = H::from_f32(acc[mb][r] * sbv * sav[mb][r] + bv);
+      }
+    wait_lgkmcnt0();
+    for (int c = lane; c < ROWS * 2; c += 64) {
+      const int m = c >> 1, half = c & 1;
+      const int nn = nb * 16 + half * 8;
+      if (m < p.M && nn < p.N)
+        *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.out) + (int64_t)m * p.N + nn) =
+            *reinterpret_cast<const uint4*>(ep + m * 24 + half * 8);
     }
-  wait_lgkmcnt0();
-  for (int c = lane; c < ROWS * 2; c += 64) {
-    const int m = c >> 1, half = c & 1;
-    const int nn = nb * 16 + half * 8;
-    if (m < p.M && nn < p.N)
-      *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.out) + (int64_t)m * p.N + nn) =
-          *reinterpret_cast<const uint4*>(ep + m * 24 + half * 8);
   }
 }
 
-template <int OUT_DTYPE, int MB>
-int launch_wstream(const GemmArgs& p, hipStream_t s, bool& used) {
-  used = false;
-  constexpr int PH = 32 / MB;
-  if ((p.K & 127) != 0 || ((p.K >> 7) % PH) != 0 || (p.N & 7) != 0) return 0;
-  if ((int64_t)p.N * p.b_sn >= ((int64_t)1 << 32) || (int64_t)p.M * p.a_sm >= ((int64_t)1 << 32)) return 0;
-  if ((p.a_sm & 15) != 0) return 0;
-  auto kern = fp8_gemm_wstream_kernel<OUT_DTYPE, MB>;
-  constexpr int lds = 2 * 64 * 1024;
+// finalize of the slab variants (defined below)
+template <int OUT_DTYPE>
+__global__ void fp8_gemm_finalize_kernel(GemmArgs p, const float* slabs, int SK);
+
+template <int OUT_DTYPE, int MB, int PH, bool SLAB>
+int launch_wstream_ph(const GemmArgs& p, float* slabs, int SK, int phases_per_slice, int nc, int groups, hipStream_t s) {
+  auto kern = fp8_gemm_wstream_kernel<OUT_DTYPE, MB, PH, SLAB>;
+  constexpr int lds = 2 * PH * 16 * MB * 128;
   static int attr_rc = check_hip(
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
       "hipFuncSetAttribute");
   if (attr_rc) return attr_rc;
+  hipLaunchKernelGGL(kern, dim3((unsigned)groups, (unsigned)SK), dim3(64 * (nc + 1)), lds, s, p, slabs,
+                     phases_per_slice);
+  int rc = check_hip(hipGetLastError(), "fp8_gemm_wstream launch");
+  if (rc || !SLAB) return rc;
+  const int64_t total = (int64_t)p.M * p.N / 8;
+  hipLaunchKernelGGL((fp8_gemm_finalize_kernel<OUT_DTYPE>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p,
+                     (const float*)slabs, SK);
+  return check_hip(hipGetLastError(), "fp8_gemm_finalize launch");
+}
+
+// Shapes: K % 128 == 0 and K / 128 a multiple of a phase length PH in {32, 16, 8} (PH * MB <= 32).
+// slabs == nullptr: one workgroup per 8 column blocks over all of K (wide N).  Otherwise K is split into SK
+// slices of whole phases so that ~256 workgroups exist, partials go to fp32 slabs and a finalize kernel applies
+// the reference epilogue (narrow N, long K: down_proj).
+template <int OUT_DTYPE, int MB>
+int launch_wstream(const GemmArgs& p, float* slabs, int64_t slab_floats, hipStream_t s, bool& used) {
+  used = false;
+  if ((p.K & 127) != 0 || (p.N & 7) != 0 || (p.a_sm & 15) != 0) return 0;
+  if ((int64_t)p.N * p.b_sn >= ((int64_t)1 << 32)) return 0;  // per-lane weight offsets are 32-bit
+  const int steps = p.K >> 7;
+  static const int ph_cap = [] { const char* e = getenv("SGL_MI355_WSTREAM_PH"); return e ? atoi(e) : 32; }();  // tuning aid
+  int PH = 32 / MB;
+  while (PH > ph_cap && PH > 8) PH >>= 1;
+  while (PH >= 8 && steps % PH != 0) PH >>= 1;
+  if (PH < 8) return 0;
+  const int P_total = steps / PH;
+  // consumer waves per workgroup (+1 producer wave): the count that leaves the fewest column blocks on the
+  // busiest CU -- one workgroup per CU, the A buffers fill most of the LDS (N = 28672: 7 -> exactly 256).
   const int nblocks = (p.N + 15) / 16;
-  hipLaunchKernelGGL(kern, dim3((unsigned)((nblocks + 7) / 8)), dim3(512), lds, s, p);
+  int nc = 8, best = 1 << 30;
+  for (int c = 8; c >= 4; --c) {
+    const int cost = (((nblocks + c - 1) / c + 255) / 256) * c;
+    if (cost < best) { best = cost; nc = c; }
+  }
+  const int groups = (nblocks + nc - 1) / nc;
+  int SK = 1, pps = P_total;
+  if (slabs != nullptr) {
+    int sk_max = 256 / groups;
+    if (sk_max < 1) sk_max = 1;
+    if (sk_max > P_total) sk_max = P_total;
+    pps = (P_total + sk_max - 1) / sk_max;
+    SK = (P_total + pps - 1) / pps;
+    if (SK < 2 || slab_floats < (int64_t)SK * p.M * p.N) return 0;
+  }
   used = true;
-  return check_hip(hipGetLastError(), "fp8_gemm_wstream launch");
+#define WS_GO(PH_)                                                                                         \
+  return slabs ? launch_wstream_ph<OUT_DTYPE, MB, PH_, true>(p, slabs, SK, pps, nc, groups, s)              \
+               : launch_wstream_ph<OUT_DTYPE, MB, PH_, false>(p, nullptr, 1, pps, nc, groups, s)
+  if constexpr (MB == 1) { if (PH == 32) WS_GO(32); }
+  if constexpr (MB <= 2) { if (PH == 16) WS_GO(16); }
+  WS_GO(8);
+#undef WS_GO
 }
 
 template <int OUT_DTYPE, int MB>
@@ -1230,9 +1305,9 @@ int run_gemm(const GemmArgs& p, float* workspace, int64_t workspace_floats, hipS
     static const bool no_wstream = getenv("SGL_MI355_NO_WSTREAM") != nullptr;  // tuning / A-B aid
     if (!no_wstream && p.N >= 16 * 8 * 160) {  // >= ~160 workgroups of 8 column blocks
       bool used = false;
-      int rc = p.M <= 16   ? launch_wstream<OUT_DTYPE, 1>(p, s, used)
-               : p.M <= 32 ? launch_wstream<OUT_DTYPE, 2>(p, s, used)
-                           : launch_wstream<OUT_DTYPE, 4>(p, s, used);
+      int rc = p.M <= 16   ? launch_wstream<OUT_DTYPE, 1>(p, nullptr, 0, s, used)
+               : p.M <= 32 ? launch_wstream<OUT_DTYPE, 2>(p, nullptr, 0, s, used)
+                           : launch_wstream<OUT_DTYPE, 4>(p, nullptr, 0, s, used);
       if (rc || used) return rc;
     }
     if (!no_astat && p.N >= 16 * 8 * 160) {  // same shapes, K tails / odd step counts: phase-filled A image
@@ -1240,6 +1315,13 @@ int run_gemm(const GemmArgs& p, float* workspace, int64_t workspace_floats, hipS
       int rc = p.M <= 16   ? launch_astat_direct<OUT_DTYPE, 1>(p, s, used)
                : p.M <= 32 ? launch_astat_direct<OUT_DTYPE, 2>(p, s, used)
                            : launch_astat_direct<OUT_DTYPE, 4>(p, s, used);
+      if (rc || used) return rc;
+    }
+    if (!no_wstream && workspace != nullptr && (int64_t)p.N * p.K >= (int64_t)40 * 1024 * 1024) {
+      bool used = false;  // narrow N, long K: K split over workgroups, fp32 slabs
+      int rc = p.M <= 16   ? launch_wstream<OUT_DTYPE, 1>(p, workspace, workspace_floats, s, used)
+               : p.M <= 32 ? launch_wstream<OUT_DTYPE, 2>(p, workspace, workspace_floats, s, used)
+                           : launch_wstream<OUT_DTYPE, 4>(p, workspace, workspace_floats, s, used);
       if (rc || used) return rc;
     }
     if (!no_astat && workspace != nullptr && (int64_t)p.N * p.K >= (int64_t)40 * 1024 * 1024) {
