@@ -33,7 +33,7 @@ extern "C" {
 #define SGL_MI355_ERR_RUNTIME 3          /* a HIP runtime call failed                */
 
 /* ABI version of this header; bumped on any signature change. */
-#define SGL_MI355_ABI_VERSION 2
+#define SGL_MI355_ABI_VERSION 3
 int sgl_mi355_abi_version(void);
 
 /* Copies the calling thread's last error message (NUL-terminated) into buf. Returns its length. */
@@ -129,7 +129,13 @@ int sgl_mi355_decode_attention_fwd(
  *   q_extend [T,Hq,D], k_extend [T,Hkv,D], v_extend [T,Hkv,Dv], o_extend [T,Hq,Dv]: the new tokens of all
  *   requests back to back; qo_indptr int32 [B+1] = cumulative extend lengths; kv_indptr int32 [B+1] =
  *   cumulative PREFIX lengths; kv_indices int32 = pool slots of the prefix tokens; k_buffer/v_buffer the
- *   KV pool.  custom_mask / sliding window are not supported (pass the plain causal case). */
+ *   KV pool.
+ *   custom_mask (nullable): uint8/bool, per request [ext][prefix+ext] flattened back to back, mask_indptr int64
+ *   [B+1]; applied to the extend part INSTEAD of the causal test and, unless skip_prefix_custom_mask, to the
+ *   prefix part too (extend_attention.py:171-183, 246-259).  With is_causal the reference still stops at the end of
+ *   its query block (:199-203), so masks must be subsets of the causal mask (tree attention) to be block-size
+ *   independent; the same holds here.  sliding_window_size > 0: prefix key n is visible to extend row q iff
+ *   q <= n + sliding_window_size (:184-189; the caller passes the window's kv_indices). <= 0: off. */
 int sgl_mi355_extend_attention_fwd(
     const void* q_extend, const void* k_extend, const void* v_extend, void* o_extend,
     const void* k_buffer, const void* v_buffer,
@@ -139,7 +145,9 @@ int sgl_mi355_extend_attention_fwd(
     int64_t q_stride_t, int64_t q_stride_h, int64_t ke_stride_t, int64_t ke_stride_h,
     int64_t ve_stride_t, int64_t ve_stride_h, int64_t o_stride_t, int64_t o_stride_h,
     int64_t kb_stride_n, int64_t kb_stride_h, int64_t vb_stride_n, int64_t vb_stride_h,
-    float sm_scale, float logit_cap, int dtype, void* stream);
+    float sm_scale, float logit_cap,
+    const uint8_t* custom_mask, const int64_t* mask_indptr, int skip_prefix_custom_mask, int64_t sliding_window_size,
+    int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Ragged prefix + extend attention, op-level form.

@@ -156,9 +156,15 @@ def decode_attention(query, k_buffer, v_buffer, output, key, value, loc, attn_lo
 
 def extend_attention(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, req_to_token, req_pool_indices,
                      seq_lens, extend_seq_lens, extend_start_loc, max_len_extend, sm_scale, logit_cap,
-                     p_round: bool = True, causal: bool = True, lib=None):
-    """extend_attention_cpu (sgl-kernel/csrc/cpu/extend.cpp:579-723), same argument list."""
+                     p_round: bool = True, causal: bool = True, custom_mask=None, mask_indptr=None,
+                     skip_prefix_custom_mask: bool = True, sliding_window_size: int = -1, lib=None):
+    """extend_attention_cpu (sgl-kernel/csrc/cpu/extend.cpp:579-723), same argument list; the keyword masks
+    are those of the Triton kernel (extend_attention.py:171-189, 246-259)."""
     lib = lib or load()
+    cm = mi = None
+    if custom_mask is not None:
+        cm = custom_mask.to(torch.uint8).contiguous()
+        mi = _i64(mask_indptr).contiguous()
     del max_len_extend  # a launch-shape hint in the reference (extend.cpp:670-672); not needed here
     rpi = _i64(req_pool_indices).contiguous()
     sl = _i64(seq_lens).contiguous()
@@ -172,7 +178,8 @@ def extend_attention(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer,
         _I64(q_extend.stride(0)), _I64(q_extend.stride(1)), _I64(k_extend.stride(0)), _I64(k_extend.stride(1)),
         _I64(v_extend.stride(0)), _I64(v_extend.stride(1)), _I64(k_buffer.stride(0)), _I64(k_buffer.stride(1)),
         _I64(v_buffer.stride(0)), _I64(v_buffer.stride(1)), _I64(o_extend.stride(0)), _I64(o_extend.stride(1)),
-        _F(sm_scale), _F(logit_cap), _I(_dt(q_extend)), _I(1 if p_round else 0), _I(1 if causal else 0))
+        _F(sm_scale), _F(logit_cap), _I(_dt(q_extend)), _I(1 if p_round else 0), _I(1 if causal else 0),
+        _ptr(cm), _ptr(mi), _I(1 if skip_prefix_custom_mask else 0), _I64(int(sliding_window_size)))
     return o_extend
 
 

@@ -377,7 +377,13 @@ void orc_extend_attention(
     int64_t q_strideM, int64_t q_strideH, int64_t ke_strideN, int64_t ke_strideH,
     int64_t ve_strideN, int64_t ve_strideH, int64_t k_strideN, int64_t k_strideH,
     int64_t v_strideN, int64_t v_strideH, int64_t o_strideM, int64_t o_strideH,
-    float sm_scale, float logit_cap, int dtype, int p_round, int causal) {
+    float sm_scale, float logit_cap, int dtype, int p_round, int causal,
+    const uint8_t* custom_mask, const int64_t* mask_indptr, int skip_prefix_mask, int64_t window) {
+  /* custom_mask / mask_indptr / skip_prefix_mask / window: the optional masks of the Triton kernel,
+   * extend_attention.py:171-189 (prefix stage: `mask[q * seq_len + n]` unless SKIP_PREFIX_CUSTOM_MASK, and
+   * `q <= n + SLIDING_WINDOW_SIZE` with q the row inside the extend part and n the index inside the PASSED prefix)
+   * and :246-259 (extend stage: `mask[q * seq_len + prefix + j]` replaces the causal test).  custom_mask == NULL and
+   * window <= 0 is the plain kernel. */
   const int64_t group = num_heads / num_heads_kv;
   /* flatten (b, r) rows so OpenMP balances ragged batches */
   int64_t total_rows = 0;
@@ -421,6 +427,12 @@ void orc_extend_attention(
           } else {
             kp = k_extend + (start + n - prefix) * ke_strideN + hkv * ke_strideH;
             vp = v_extend + (start + n - prefix) * ve_strideN + hkv * ve_strideH;
+          }
+          if (n < prefix) {
+            if (window > 0 && !(r <= n + window)) continue;
+            if (custom_mask && !skip_prefix_mask && !custom_mask[mask_indptr[b] + r * seq_len + n]) continue;
+          } else if (custom_mask && !custom_mask[mask_indptr[b] + r * seq_len + n]) {
+            continue;
           }
           float s = 0.f;
           for (int64_t d = 0; d < head_size; ++d) s += qf[d] * h_to_f32(kp[d], dtype);

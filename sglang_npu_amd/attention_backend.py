@@ -43,6 +43,12 @@ class ForwardMetadata:
     qo_indptr: Optional[torch.Tensor]
     custom_mask: Optional[torch.Tensor] = None
     mask_indptr: Optional[torch.Tensor] = None
+    # sliding-window layers (triton_backend.py:45-52): the last W+1 tokens of every request, flattened
+    window_kv_indptr: Optional[torch.Tensor] = None
+    window_kv_indices: Optional[torch.Tensor] = None
+    window_num_kv_splits: int = 1
+    window_attn_logits: Optional[torch.Tensor] = None
+    window_attn_lse: Optional[torch.Tensor] = None
 
 
 class AttentionBackend:
@@ -98,9 +104,11 @@ class MI355AttnBackend(AttentionBackend):
         self.max_kv_splits = model_runner.server_args.triton_attention_num_kv_splits
         self.v_head_dim = model_runner.token_to_kv_pool.get_value_buffer(0).shape[-1]
         self.max_context_len = model_runner.model_config.context_len
-        if getattr(model_runner, "sliding_window_size", None):
-            raise NotImplementedError("MI355AttnBackend: sliding-window attention is not implemented yet")
+        sw = getattr(model_runner, "sliding_window_size", None)
+        self.sliding_window_size = sw if (sw is not None and sw > 0) else None  # triton_backend.py:64-68
         self.kv_indptr = torch.zeros((max_bs + 1,), dtype=torch.int32, device=self.device)
+        if self.sliding_window_size is not None:  # triton_backend.py:81-82
+            self.window_kv_indptr = torch.zeros_like(self.kv_indptr)
         if not skip_prefill:
             self.qo_indptr = torch.zeros((max_bs + 1,), dtype=torch.int32, device=self.device)
         self.forward_metadata: Optional[ForwardMetadata] = None
@@ -129,6 +137,26 @@ class MI355AttnBackend(AttentionBackend):
         lse = torch.empty((bs, self.num_head, splits), dtype=torch.float32, device=self.device)
         return logits, lse
 
+    def _window_buffer(self, lens: torch.Tensor, req_pool_indices: torch.Tensor, bs: int,
+                       out: Optional[torch.Tensor] = None):
+        """update_sliding_window_buffer[_cuda_graph] (triton_backend.py:927-983): per request the last
+        min(len, W + 1) page-table entries, flattened; `out` = the static graph buffer when capturing/replaying."""
+        window_lens = torch.clamp(lens, max=self.sliding_window_size + 1)
+        indptr = self.window_kv_indptr
+        indptr[1:bs + 1] = torch.cumsum(window_lens, dim=0)
+        indptr = indptr[:bs + 1]
+        if out is None:
+            out = torch.empty(max(int(indptr[-1].item()), 1), dtype=torch.int32, device=self.device)
+        start = (lens - window_lens).to(torch.int32)
+        ops.create_kv_indices(self.req_to_token, req_pool_indices, window_lens, indptr, start, out)
+        return indptr, out, window_lens
+
+    def _flat_scratch(self, bs: int, splits: int):
+        if splits == 1:
+            return None, None
+        return (torch.empty((bs, self.num_head, splits, self.v_head_dim), dtype=torch.float32, device=self.device),
+                torch.empty((bs, self.num_head, splits), dtype=torch.float32, device=self.device))
+
     # ---------------------------------------------------------------- metadata
     def init_forward_metadata(self, forward_batch: ForwardBatch):
         """Once per step (model_runner.py:1553-1554 / :1572-1573), as triton_backend.py:160-336."""
@@ -147,7 +175,14 @@ class MI355AttnBackend(AttentionBackend):
                 ops.create_kv_indices(self.req_to_token, forward_batch.req_pool_indices, forward_batch.seq_lens,
                                       kv_indptr, None, kv_indices)
             logits, lse = self._scratch(bs, splits)
-            self.forward_metadata = ForwardMetadata(logits, lse, None, splits, kv_indptr, kv_indices, None)
+            md = ForwardMetadata(logits, lse, None, splits, kv_indptr, kv_indices, None)
+            if self.sliding_window_size is not None:  # triton_backend.py:187-203
+                md.window_kv_indptr, md.window_kv_indices, _ = self._window_buffer(
+                    forward_batch.seq_lens, forward_batch.req_pool_indices, bs)
+                md.window_num_kv_splits = self.choose_num_kv_splits(bs, min(max_len or 1 << 30,
+                                                                            self.sliding_window_size + 1))
+                md.window_attn_logits, md.window_attn_lse = self._flat_scratch(bs, md.window_num_kv_splits)
+            self.forward_metadata = md
         else:
             kv_indptr = self.kv_indptr
             kv_indptr[1:bs + 1] = torch.cumsum(forward_batch.extend_prefix_lens, dim=0)
@@ -162,7 +197,11 @@ class MI355AttnBackend(AttentionBackend):
             qo_indptr = qo_indptr[:bs + 1]
             max_extend_len = (max(forward_batch.extend_seq_lens_cpu) if forward_batch.extend_seq_lens_cpu is not None
                               else int(torch.max(forward_batch.extend_seq_lens).item()))
-            self.forward_metadata = ForwardMetadata(None, None, max_extend_len, 1, kv_indptr, kv_indices, qo_indptr)
+            md = ForwardMetadata(None, None, max_extend_len, 1, kv_indptr, kv_indices, qo_indptr)
+            if self.sliding_window_size is not None:  # triton_backend.py:301-311
+                md.window_kv_indptr, md.window_kv_indices, _ = self._window_buffer(
+                    forward_batch.extend_prefix_lens, forward_batch.req_pool_indices, bs)
+            self.forward_metadata = md
 
     # ---------------------------------------------------------------- graph capture / replay
     def init_cuda_graph_state(self, max_bs: int, max_num_tokens: int, kv_indices_buf: Optional[torch.Tensor] = None):
@@ -176,6 +215,11 @@ class MI355AttnBackend(AttentionBackend):
         if self.flat_kv_indices:
             g["kv_indices"] = kv_indices_buf if kv_indices_buf is not None else torch.zeros(
                 (max_num_tokens * self.max_context_len,), dtype=torch.int32, device=self.device)
+        if self.sliding_window_size is not None:  # triton_backend.py:373-381
+            g["window_kv_indices"] = torch.zeros((max_num_tokens * (self.sliding_window_size + 1),), dtype=torch.int32,
+                                                 device=self.device)
+            g["window_attn_logits"] = torch.zeros((max_num_tokens, self.num_head, splits, self.v_head_dim),
+                                                  dtype=torch.float32, device=self.device)
         self._graph = g
 
     def init_forward_metadata_capture_cuda_graph(self, bs, num_tokens, req_pool_indices, seq_lens, encoder_lens,
@@ -198,7 +242,16 @@ class MI355AttnBackend(AttentionBackend):
             kv_indptr = kv_indptr[:bs + 1]
             kv_indices = g["kv_indices"]
             ops.create_kv_indices(self.req_to_token, req_pool_indices, seq_lens, kv_indptr, None, kv_indices)
-        self.forward_metadata = ForwardMetadata(logits, lse, None, splits, kv_indptr, kv_indices, None)
+        md = ForwardMetadata(logits, lse, None, splits, kv_indptr, kv_indices, None)
+        if self.sliding_window_size is not None:  # triton_backend.py:420-434
+            md.window_kv_indptr, md.window_kv_indices, _ = self._window_buffer(
+                seq_lens, req_pool_indices, bs, out=g["window_kv_indices"])
+            md.window_num_kv_splits = splits
+            if splits > 1:
+                md.window_attn_logits = g["window_attn_logits"].view(-1)[: bs * self.num_head * splits * self.v_head_dim] \
+                    .view(bs, self.num_head, splits, self.v_head_dim)
+                md.window_attn_lse = g["attn_lse"].view(-1)[: bs * self.num_head * splits].view(bs, self.num_head, splits)
+        self.forward_metadata = md
 
     def init_forward_metadata_replay_cuda_graph(self, bs, req_pool_indices, seq_lens, seq_lens_sum, encoder_lens,
                                                 forward_mode, spec_info, seq_lens_cpu):
@@ -211,6 +264,8 @@ class MI355AttnBackend(AttentionBackend):
                                   self._graph["kv_indices"])
         # the direct form reads req_to_token / req_pool_indices / seq_lens, all graph inputs updated by the
         # graph runner itself: nothing to do here.
+        if self.sliding_window_size is not None:  # triton_backend.py:554-568
+            self._window_buffer(seq_lens[:bs], req_pool_indices[:bs], bs, out=self._graph["window_kv_indices"])
 
     def get_cuda_graph_seq_len_fill_value(self):
         return 1
@@ -229,7 +284,11 @@ class MI355AttnBackend(AttentionBackend):
         vb = forward_batch.token_to_kv_pool.get_value_buffer(layer.layer_id)
         q3 = q.view(-1, layer.tp_q_head_num, layer.qk_head_dim)
         o3 = o.view(-1, layer.tp_q_head_num, layer.v_head_dim)
-        if md.kv_indices is not None:
+        sw = getattr(layer, "sliding_window_size", None)
+        if sw is not None and sw > -1 and md.window_kv_indices is not None:  # triton_backend.py:711-713
+            ops.decode_attention_fwd(q3, kb, vb, o3, md.window_kv_indptr, md.window_kv_indices, md.window_attn_logits,
+                                     md.window_attn_lse, None, md.window_num_kv_splits, layer.scaling, layer.logit_cap)
+        elif md.kv_indices is not None:
             ops.decode_attention_fwd(q3, kb, vb, o3, md.kv_indptr, md.kv_indices, md.attn_logits, md.attn_lse, None,
                                      md.num_kv_splits, layer.scaling, layer.logit_cap)
         else:
@@ -247,11 +306,20 @@ class MI355AttnBackend(AttentionBackend):
             forward_batch.token_to_kv_pool.set_kv_buffer(layer, forward_batch.out_cache_loc, k, v)
         causal = layer.attn_type != AttentionType.ENCODER_ONLY
         md = self.forward_metadata
+        sw = getattr(layer, "sliding_window_size", None)
+        if sw is not None and sw > -1 and md.window_kv_indices is not None:  # triton_backend.py:656-665
+            sliding_window_size, kv_indptr, kv_indices = sw, md.window_kv_indptr, md.window_kv_indices
+        else:
+            sliding_window_size, kv_indptr, kv_indices = -1, md.kv_indptr, md.kv_indices
+        # Positional call exactly as triton_backend.py:666-684: the 16th positional argument of
+        # extend_attention_fwd is `skip_prefix_custom_mask` (extend_attention.py:306-324), so in this reference
+        # snapshot the window size never reaches the kernel's SLIDING_WINDOW_SIZE -- the window acts through
+        # window_kv_indices only.  Kept identical on purpose (same inputs -> same results).
         ops.extend_attention_fwd(
             q.view(-1, layer.tp_q_head_num, layer.qk_head_dim), k.contiguous(), v.contiguous(),
             o.view(-1, layer.tp_q_head_num, layer.v_head_dim),
             forward_batch.token_to_kv_pool.get_key_buffer(layer.layer_id),
             forward_batch.token_to_kv_pool.get_value_buffer(layer.layer_id),
-            md.qo_indptr, md.kv_indptr, md.kv_indices, md.custom_mask, causal, md.mask_indptr, md.max_extend_len,
-            layer.scaling, layer.logit_cap)
+            md.qo_indptr, kv_indptr, kv_indices, md.custom_mask, causal, md.mask_indptr, md.max_extend_len,
+            layer.scaling, layer.logit_cap, sliding_window_size)
         return o

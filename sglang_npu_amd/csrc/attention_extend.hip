@@ -55,6 +55,11 @@ struct ExtendArgs {
   int num_mblocks;      // grid extent along query blocks
   float sm_scale, logit_cap;
   int causal, mode;
+  // optional masks of the Triton kernel (extend_attention.py:171-189, 246-259); mask == nullptr && window <= 0: none
+  const uint8_t* mask;         // per sequence [ext][prefix + ext] bytes, flattened back to back
+  const int64_t* mask_indptr;  // [B+1]
+  int skip_prefix_mask;        // SKIP_PREFIX_CUSTOM_MASK
+  int window;                  // SLIDING_WINDOW_SIZE (prefix stage only: q <= n + window)
 };
 
 __device__ __forceinline__ void seq_info(const ExtendArgs& a, int b, int64_t& idx_base, int& prefix, int& ext,
@@ -83,7 +88,7 @@ __device__ __forceinline__ int swz_v(int c, int row) {  // ds_read_b64_tr_b16: k
 }
 
 // GH = q heads per workgroup (1, 2 or 4); the other 4/GH waves take further 32-row position blocks.
-template <int DTYPE, int D, typename IdxT, int GH>
+template <int DTYPE, int D, typename IdxT, int GH, bool MASKED>
 __global__ __launch_bounds__(256) void extend_mfma_kernel(ExtendArgs a) {
   using H = Half16<DTYPE>;
   using T = typename H::T;
@@ -146,7 +151,13 @@ __global__ __launch_bounds__(256) void extend_mfma_kernel(ExtendArgs a) {
     for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(qf[s]));  // keep hipcc's wait for these loads out of the loop
   }
 
+  // (with a custom mask AND is_causal the reference still stops at the end of the query block,
+  //  extend_attention.py:199-203; masks that are subsets of the causal mask -- tree attention -- do not notice)
   const int n_ext_keys = a.causal ? ((p0 + BP) < ext ? (p0 + BP) : ext) : ext;
+  const uint8_t* mrow = nullptr;  // this lane's row of the custom mask
+  if constexpr (MASKED) {
+    if (a.mask != nullptr && q_ok) mrow = a.mask + a.mask_indptr[b] + (int64_t)qpos * (prefix + ext);
+  }
   const int nt1 = (prefix + kBN - 1) / kBN;
   const int nt2 = (n_ext_keys + kBN - 1) / kBN;
 
@@ -228,7 +239,20 @@ __global__ __launch_bounds__(256) void extend_mfma_kernel(ExtendArgs a) {
         }
         const int key = t * kBN + 32 * th + (r & 3) + 8 * (r >> 2) + 4 * hh;
         bool ok = key < n_keys;
-        if (phase == 1 && a.causal) ok = ok && (key <= qpos);
+        if constexpr (MASKED) {
+          if (phase == 0) {
+            if (a.window > 0) ok = ok && (qpos <= key + a.window);
+            if (a.mask != nullptr && !a.skip_prefix_mask && ok && q_ok) ok = mrow[key] != 0;
+          } else {
+            if (a.mask != nullptr) {
+              if (ok && q_ok) ok = mrow[prefix + key] != 0;
+            } else if (a.causal) {
+              ok = ok && (key <= qpos);
+            }
+          }
+        } else {
+          if (phase == 1 && a.causal) ok = ok && (key <= qpos);
+        }
         s = ok ? s : -INFINITY;
         s_acc[th][r] = s;
         m_tile = fmaxf(m_tile, s);
@@ -358,7 +382,14 @@ __global__ __launch_bounds__(64) void extend_generic_kernel(ExtendArgs a, int D,
   float m_run = -INFINITY, l_run = 0.f;
   const IdxT* idx = reinterpret_cast<const IdxT*>(a.indices) + idx_base;
   const int n_new = a.causal ? r + 1 : ext;
+  const uint8_t* mrow = a.mask ? a.mask + a.mask_indptr[b] + (int64_t)r * (prefix + ext) : nullptr;
   for (int n = 0; n < prefix + n_new; ++n) {
+    if (n < prefix) {
+      if (a.window > 0 && !(r <= n + a.window)) continue;
+      if (mrow && !a.skip_prefix_mask && !mrow[n]) continue;
+    } else if (mrow && !mrow[n]) {
+      continue;
+    }
     const T *kp, *vp;
     if (n < prefix) {
       const int64_t tok = (int64_t)idx[n];
@@ -399,9 +430,9 @@ __global__ __launch_bounds__(64) void extend_generic_kernel(ExtendArgs a, int D,
   }
 }
 
-template <int DTYPE, int D, typename IdxT, int GH>
+template <int DTYPE, int D, typename IdxT, int GH, bool MASKED>
 int launch_mfma(ExtendArgs a, int64_t batch, int max_len_extend, hipStream_t s) {
-  auto kern = extend_mfma_kernel<DTYPE, D, IdxT, GH>;
+  auto kern = extend_mfma_kernel<DTYPE, D, IdxT, GH, MASKED>;
   constexpr int lds = 2 * 2 * kBN * D * 2 + kIdxCap * 4;
   static int attr_rc = check_hip(
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
@@ -429,7 +460,10 @@ int dispatch(ExtendArgs a, int64_t batch, int D, int Dv, int max_len_extend, hip
                        (reinterpret_cast<uintptr_t>(a.vb) % 16 == 0) && (reinterpret_cast<uintptr_t>(a.o) % 8 == 0);
   if (D == Dv && aligned && (D == 128 || D == 64)) {
     const int gh = (a.group % 4 == 0) ? 4 : (a.group % 2 == 0 ? 2 : 1);
-#define EXT_LAUNCH(DD, GG) return launch_mfma<DTYPE, DD, IdxT, GG>(a, batch, max_len_extend, s)
+    const bool masked = a.mask != nullptr || a.window > 0;
+#define EXT_LAUNCH(DD, GG)                                                             \
+  return masked ? launch_mfma<DTYPE, DD, IdxT, GG, true>(a, batch, max_len_extend, s)   \
+                : launch_mfma<DTYPE, DD, IdxT, GG, false>(a, batch, max_len_extend, s)
     if (D == 128) {
       if (gh == 4) EXT_LAUNCH(128, 4);
       if (gh == 2) EXT_LAUNCH(128, 2);
@@ -470,13 +504,16 @@ extern "C" int sgl_mi355_extend_attention_fwd(
     int64_t max_len_extend, int64_t batch, int64_t num_heads, int64_t num_kv_heads, int64_t head_size,
     int64_t head_size_v, int64_t q_stride_t, int64_t q_stride_h, int64_t ke_stride_t, int64_t ke_stride_h,
     int64_t ve_stride_t, int64_t ve_stride_h, int64_t o_stride_t, int64_t o_stride_h, int64_t kb_stride_n,
-    int64_t kb_stride_h, int64_t vb_stride_n, int64_t vb_stride_h, float sm_scale, float logit_cap, int dtype,
-    void* stream) {
+    int64_t kb_stride_h, int64_t vb_stride_n, int64_t vb_stride_h, float sm_scale, float logit_cap,
+    const uint8_t* custom_mask, const int64_t* mask_indptr, int skip_prefix_custom_mask, int64_t sliding_window_size,
+    int dtype, void* stream) {
   int rc = check_common(batch, num_heads, num_kv_heads, head_size, head_size_v, max_len_extend, dtype);
   if (rc) return rc;
   if (batch == 0 || max_len_extend == 0) return 0;
   SGLM_CHECK_ARG(q_extend && k_extend && v_extend && o_extend && qo_indptr && kv_indptr,
                  "extend_attention_fwd: null tensor pointer");
+  SGLM_CHECK_ARG(custom_mask == nullptr || mask_indptr != nullptr, "extend_attention_fwd: custom_mask needs mask_indptr");
+  SGLM_CHECK_ARG(sliding_window_size < (1ll << 30), "extend_attention_fwd: bad sliding_window_size");
   ExtendArgs a{};
   a.q = q_extend; a.q_st = q_stride_t; a.q_sh = q_stride_h;
   a.ke = k_extend; a.ke_st = ke_stride_t; a.ke_sh = ke_stride_h;
@@ -487,6 +524,8 @@ extern "C" int sgl_mi355_extend_attention_fwd(
   a.qo_indptr = qo_indptr; a.kv_indptr = kv_indptr; a.indices = kv_indices; a.mode = 0;
   a.num_heads = (int)num_heads; a.num_kv_heads = (int)num_kv_heads; a.group = (int)(num_heads / num_kv_heads);
   a.sm_scale = sm_scale; a.logit_cap = logit_cap; a.causal = is_causal;
+  a.mask = custom_mask; a.mask_indptr = mask_indptr; a.skip_prefix_mask = skip_prefix_custom_mask;
+  a.window = sliding_window_size > 0 ? (int)sliding_window_size : 0;
   hipStream_t s = as_stream(stream);
   return dtype == SGL_MI355_BF16
              ? dispatch<SGL_MI355_BF16, int32_t>(a, batch, (int)head_size, (int)head_size_v, (int)max_len_extend, s)

@@ -1317,7 +1317,11 @@ int run_gemm(const GemmArgs& p, float* workspace, int64_t workspace_floats, hipS
                            : launch_astat_direct<OUT_DTYPE, 4>(p, s, used);
       if (rc || used) return rc;
     }
-    if (!no_wstream && workspace != nullptr && (int64_t)p.N * p.K >= (int64_t)40 * 1024 * 1024) {
+    // split-K slabs pay a finalize launch (~4 us): worth it from 40 Mi weights, and from 20 Mi at M > 32 where
+    // the alternative re-reads the activations from L2 per wave (qkv 4096x6144: 12.6 + 4.2 us vs 21.2)
+    static const int slab_env = [] { const char* e = getenv("SGL_MI355_SLAB_MIN_MI"); return e ? atoi(e) : 0; }();  // tuning aid
+    const int64_t slab_min = (int64_t)(slab_env ? slab_env : (p.M > 32 ? 20 : 40)) << 20;
+    if (!no_wstream && workspace != nullptr && (int64_t)p.N * p.K >= slab_min) {
       bool used = false;  // narrow N, long K: K split over workgroups, fp32 slabs
       int rc = p.M <= 16   ? launch_wstream<OUT_DTYPE, 1>(p, workspace, workspace_floats, s, used)
                : p.M <= 32 ? launch_wstream<OUT_DTYPE, 2>(p, workspace, workspace_floats, s, used)

@@ -199,13 +199,20 @@ def _check3(name, t):
 
 def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices,
                          custom_mask, is_causal, mask_indptr, max_len_extend, sm_scale=None, logit_cap=0.0,
-                         sliding_window_size=-1):
+                         skip_prefix_custom_mask=True, sliding_window_size=-1):
     """extend_attention_fwd(...) -- python/sglang/srt/layers/attention/triton_ops/extend_attention.py:306-438,
-    same positional arguments.  custom_mask / sliding window: not implemented (NotImplementedError)."""
-    if custom_mask is not None or mask_indptr is not None:
-        raise NotImplementedError("extend_attention_fwd: custom_mask is not implemented in the MI355X backend")
-    if sliding_window_size is not None and sliding_window_size > 0:
-        raise NotImplementedError("extend_attention_fwd: sliding window is not implemented in the MI355X backend")
+    same arguments in the same order (custom_mask: bool/uint8 [sum ext*(prefix+ext)], mask_indptr int64 [B+1])."""
+    cm = mi = None
+    if custom_mask is not None:
+        if mask_indptr is None:
+            raise RuntimeError("extend_attention_fwd: custom_mask needs mask_indptr")
+        cm = custom_mask if custom_mask.dtype == torch.uint8 else custom_mask.view(torch.uint8) \
+            if custom_mask.dtype == torch.bool else custom_mask.to(torch.uint8)
+        mi = mask_indptr if mask_indptr.dtype == torch.int64 else mask_indptr.to(torch.int64)
+        if not cm.is_contiguous() or not mi.is_contiguous():
+            raise RuntimeError("extend_attention_fwd: custom_mask and mask_indptr must be contiguous")
+        _need_gpu(cm, mi)
+    window = int(sliding_window_size) if sliding_window_size is not None else -1
     _need_gpu(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr, kv_indptr)
     for n, t in (("q_extend", q_extend), ("k_extend", k_extend), ("v_extend", v_extend), ("o_extend", o_extend),
                  ("k_buffer", k_buffer), ("v_buffer", v_buffer)):
@@ -222,7 +229,8 @@ def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buf
         _I64(q_extend.stride(0)), _I64(q_extend.stride(1)), _I64(k_extend.stride(0)), _I64(k_extend.stride(1)),
         _I64(v_extend.stride(0)), _I64(v_extend.stride(1)), _I64(o_extend.stride(0)), _I64(o_extend.stride(1)),
         _I64(k_buffer.stride(0)), _I64(k_buffer.stride(1)), _I64(v_buffer.stride(0)), _I64(v_buffer.stride(1)),
-        _F(sm_scale), _F(logit_cap), _I(_dtype_code(q_extend)), _stream(q_extend)))
+        _F(sm_scale), _F(logit_cap), _ptr(cm), _ptr(mi), _I(1 if skip_prefix_custom_mask else 0), _I64(window),
+        _I(_dtype_code(q_extend)), _stream(q_extend)))
 
 
 def extend_attention(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, req_to_token, req_pool_indices,

@@ -87,6 +87,75 @@ def test_backend_prefill_then_decode_matches_oracle(flat):
         assert (od.float().cpu().view(B, Hq, D) - od_ref.float()).abs().max().item() <= tol_pair(torch.bfloat16, od_ref)
 
 
+def test_backend_sliding_window_layers_use_window_indices():
+    """A model with sliding_window_size: layers that carry it attend the last W+1 cached tokens only
+    (triton_backend.py:187-203, 301-311, 656-665, 711-713; window built by update_sliding_window_buffer :927-955),
+    other layers the full context.  Checked against the oracle run on a page table holding just the window."""
+    B, Hq, Hkv, D, max_len, W = 3, 8, 2, 128, 300, 31
+    cfg, r2t, pool, runner, _ = _setup(B, Hq, Hkv, D, max_len)
+    runner.sliding_window_size = W
+    from sglang_npu_amd.attention_backend import MI355AttnBackend
+    backend = MI355AttnBackend(runner)
+    win_layer = RadixAttention(Hq, D, D ** -0.5, Hkv, layer_id=0, sliding_window_size=W)
+    full_layer = RadixAttention(Hq, D, D ** -0.5, Hkv, layer_id=1)
+    g = torch.Generator(device=DEV).manual_seed(2)
+    for l in range(2):
+        pool.k_buffer[l].normal_(generator=g)
+        pool.v_buffer[l].normal_(generator=g)
+    rpi = torch.tensor([1, 3, 0], device=DEV)
+    # ---- decode: seq_lens straddle the window length
+    seq = torch.tensor([200, 20, W + 1], device=DEV)
+    loc = r2t.req_to_token[rpi, seq - 1].long()
+    fb = ForwardBatch(ForwardMode.DECODE, B, None, rpi, seq, loc, int(seq.sum()), seq.cpu(), seq - 1,
+                      req_to_token_pool=r2t, token_to_kv_pool=pool, attn_backend=backend)
+    backend.init_forward_metadata(fb)
+    qd = torch.randn(B, Hq * D, device=DEV, generator=g).bfloat16()
+    kd = torch.randn(B, Hkv * D, device=DEV, generator=g).bfloat16()
+    vd = torch.randn(B, Hkv * D, device=DEV, generator=g).bfloat16()
+    for layer, windowed in ((win_layer, True), (full_layer, False)):
+        od = layer(qd, kd, vd, fb)
+        lid = layer.layer_id
+        kb_cpu, vb_cpu = pool.k_buffer[lid].cpu(), pool.v_buffer[lid].cpu()
+        lens = torch.clamp(seq, max=W + 1) if windowed else seq
+        tab = torch.zeros(B, max_len, dtype=torch.int32)
+        for b in range(B):
+            n, L = int(lens[b]), int(seq[b])
+            tab[b, :n] = r2t.req_to_token[rpi[b], L - n:L].cpu()
+        od_ref = torch.zeros(B, Hq, D, dtype=torch.bfloat16)
+        oracle.decode_attention(qd.cpu().view(B, Hq, D), kb_cpu, vb_cpu, od_ref, None, None, None,
+                                torch.zeros(B, Hq, 2, D + 1), tab, torch.arange(B), lens.cpu(), D ** -0.5, 0.0, p_round=True)
+        assert (od.float().cpu().view(B, Hq, D) - od_ref.float()).abs().max().item() <= tol_pair(torch.bfloat16, od_ref)
+    # ---- extend with a cached prefix longer than the window: prefix part = last W+1 cached tokens
+    prefix = torch.tensor([100, 0, 10], device=DEV)
+    ext = torch.tensor([40, 25, 7], device=DEV)
+    seq = prefix + ext
+    T = int(ext.sum())
+    q = torch.randn(T, Hq * D, device=DEV, generator=g).bfloat16()
+    k = torch.randn(T, Hkv * D, device=DEV, generator=g).bfloat16()
+    v = torch.randn(T, Hkv * D, device=DEV, generator=g).bfloat16()
+    start = torch.zeros(B, dtype=torch.int64, device=DEV)
+    start[1:] = torch.cumsum(ext[:-1], 0)
+    loc = torch.cat([r2t.req_to_token[rpi[b], prefix[b]:seq[b]] for b in range(B)]).long()
+    fb = ForwardBatch(ForwardMode.EXTEND, B, None, rpi, seq, loc, int(seq.sum()), seq.cpu(), None,
+                      extend_num_tokens=T, extend_seq_lens=ext, extend_prefix_lens=prefix, extend_start_loc=start,
+                      extend_prefix_lens_cpu=prefix.tolist(), extend_seq_lens_cpu=ext.tolist(),
+                      req_to_token_pool=r2t, token_to_kv_pool=pool, attn_backend=backend)
+    backend.init_forward_metadata(fb)
+    o = win_layer(q, k, v, fb)
+    kb_cpu, vb_cpu = pool.k_buffer[0].cpu(), pool.v_buffer[0].cpu()
+    wp = torch.clamp(prefix, max=W + 1).cpu()
+    tab = torch.zeros(B, max_len, dtype=torch.int32)
+    for b in range(B):
+        n, P, L = int(wp[b]), int(prefix[b]), int(seq[b])
+        tab[b, :n] = r2t.req_to_token[rpi[b], P - n:P].cpu()
+        tab[b, n:n + int(ext[b])] = r2t.req_to_token[rpi[b], P:L].cpu()
+    o_ref = torch.zeros(T, Hq, D, dtype=torch.bfloat16)
+    oracle.extend_attention(q.cpu().view(T, Hq, D), k.cpu().view(T, Hkv, D), v.cpu().view(T, Hkv, D), o_ref, kb_cpu,
+                            vb_cpu, tab, torch.arange(B), wp + ext.cpu(), ext.cpu(), start.cpu(), int(ext.max()),
+                            D ** -0.5, 0.0)
+    assert (o.float().cpu().view(T, Hq, D) - o_ref.float()).abs().max().item() <= tol_pair(torch.bfloat16, o_ref)
+
+
 def test_idle_mode_returns_empty_like_reference():
     cfg, r2t, pool, runner, backend = _setup(2, 8, 2, 64, 64)
     layer = RadixAttention(8, 64, 0.125, 2, 0)

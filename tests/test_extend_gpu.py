@@ -148,8 +148,107 @@ def test_extend_full_size_properties():
     assert (o_full[L:L + rows].float().cpu() - o_ref.float()).abs().max().item() <= tol_pair(dtype, o_ref)
 
 
-def test_extend_rejects_custom_mask():
+def _triton_meta(d, B):
+    kv_indptr = torch.zeros(B + 1, dtype=torch.int32, device=DEV)
+    kv_indptr[1:] = torch.cumsum(d["prefix"], 0)
+    kv_indices = torch.empty(max(int(d["prefix"].sum()), 1), dtype=torch.int32, device=DEV)
+    ops.create_kv_indices(d["r2t"], d["rpi"], d["prefix"], kv_indptr, None, kv_indices)
+    qo_indptr = torch.zeros(B + 1, dtype=torch.int32, device=DEV)
+    qo_indptr[1:] = torch.cumsum(d["ext"], 0)
+    return qo_indptr, kv_indptr, kv_indices
+
+
+def _masks(c, kind, g):
+    """custom_mask as the reference's own test builds it (test_triton_attention_kernels.py:125-141): per request
+    [ext][prefix+ext] flattened; `causal` = all-ones prefix + lower triangle, `tree` = a random subset of it that keeps
+    the diagonal (every row sees itself, like a token-tree ancestor mask)."""
+    B = c["seq"].numel()
+    lens = c["ext"] * c["seq"]
+    indptr = torch.zeros(B + 1, dtype=torch.int64)
+    indptr[1:] = torch.cumsum(lens, 0)
+    mask = torch.zeros(int(lens.sum()), dtype=torch.bool)
+    for b in range(B):
+        e, p = int(c["ext"][b]), int(c["prefix"][b])
+        tri = torch.tril(torch.ones(e, e, dtype=torch.bool))
+        pre = torch.ones(e, p, dtype=torch.bool)
+        if kind == "tree":
+            tri = tri & (torch.rand(e, e, generator=g) < 0.6) | torch.eye(e, dtype=torch.bool)
+            pre = pre & (torch.rand(e, p, generator=g) < 0.7)
+        mask[indptr[b]:indptr[b + 1]] = torch.cat([pre, tri], 1).flatten()
+    return mask, indptr
+
+
+@pytest.mark.parametrize("Hq,Hkv,D", [(32, 8, 128), (14, 2, 64), (4, 4, 80)])  # MFMA x2, generic kernel
+@pytest.mark.parametrize("kind,skip_prefix", [("causal", True), ("causal", False), ("tree", True), ("tree", False)])
+def test_extend_custom_mask(Hq, Hkv, D, kind, skip_prefix):
+    """custom_mask (extend_attention.py:171-183, 246-259).  A mask equal to the causal mask must reproduce the unmasked
+    result (the reference's own check, test_triton_attention_kernels.py:153-172); random tree masks are checked
+    against the oracle's restatement."""
+    B, dtype = 3, torch.bfloat16
+    c = _case(B, Hq, Hkv, D, 150, 90, dtype, seed=Hq + D + len(kind) + int(skip_prefix))
+    g = torch.Generator().manual_seed(5)
+    mask, mask_indptr = _masks(c, kind, g)
+    T = c["q"].size(0)
+    o_ref = torch.zeros(T, Hq, D, dtype=dtype)
+    oracle.extend_attention(c["q"], c["ke"], c["ve"], o_ref, c["kb"], c["vb"], c["r2t"], c["rpi"], c["seq"], c["ext"],
+                            c["start"], int(c["ext"].max()), D ** -0.5, 0.0, custom_mask=mask, mask_indptr=mask_indptr,
+                            skip_prefix_custom_mask=skip_prefix)
+    d = {k: v.to(DEV) for k, v in c.items()}
+    qo_indptr, kv_indptr, kv_indices = _triton_meta(d, B)
+    o = torch.zeros(T, Hq, D, dtype=dtype, device=DEV)
+    ops.extend_attention_fwd(d["q"], d["ke"], d["ve"], o, d["kb"], d["vb"], qo_indptr, kv_indptr, kv_indices,
+                             mask.to(DEV), True, mask_indptr.to(DEV), int(c["ext"].max()), D ** -0.5, 0.0, skip_prefix)
+    bound = tol_pair(dtype, o_ref)
+    assert (o.float().cpu() - o_ref.float()).abs().max().item() <= bound
+    if kind == "causal":
+        o_plain = torch.zeros_like(o)
+        ops.extend_attention_fwd(d["q"], d["ke"], d["ve"], o_plain, d["kb"], d["vb"], qo_indptr, kv_indptr, kv_indices,
+                                 None, True, None, int(c["ext"].max()), D ** -0.5, 0.0)
+        assert torch.equal(o, o_plain)
+
+
+@pytest.mark.parametrize("Hq,Hkv,D", [(32, 8, 128), (6, 2, 128), (4, 4, 80)])
+@pytest.mark.parametrize("window", [1, 37, 100000])
+def test_extend_sliding_window(Hq, Hkv, D, window):
+    """SLIDING_WINDOW_SIZE (extend_attention.py:184-189): prefix key n is visible to extend row q iff q <= n + W.
+    A window larger than every extend length changes nothing."""
+    B, dtype = 3, torch.float16
+    c = _case(B, Hq, Hkv, D, 200, 120, dtype, seed=window % 97 + D)
+    T = c["q"].size(0)
+    o_ref = torch.zeros(T, Hq, D, dtype=dtype)
+    oracle.extend_attention(c["q"], c["ke"], c["ve"], o_ref, c["kb"], c["vb"], c["r2t"], c["rpi"], c["seq"], c["ext"],
+                            c["start"], int(c["ext"].max()), D ** -0.5, 0.0, sliding_window_size=window)
+    d = {k: v.to(DEV) for k, v in c.items()}
+    qo_indptr, kv_indptr, kv_indices = _triton_meta(d, B)
+    o = torch.zeros(T, Hq, D, dtype=dtype, device=DEV)
+    ops.extend_attention_fwd(d["q"], d["ke"], d["ve"], o, d["kb"], d["vb"], qo_indptr, kv_indptr, kv_indices, None,
+                             True, None, int(c["ext"].max()), D ** -0.5, 0.0, True, window)
+    assert (o.float().cpu() - o_ref.float()).abs().max().item() <= tol_pair(dtype, o_ref)
+    if window >= 100000:
+        o_plain = torch.zeros_like(o)
+        ops.extend_attention_fwd(d["q"], d["ke"], d["ve"], o_plain, d["kb"], d["vb"], qo_indptr, kv_indptr, kv_indices,
+                                 None, True, None, int(c["ext"].max()), D ** -0.5, 0.0)
+        assert torch.equal(o, o_plain)
+
+
+def test_extend_non_causal_vs_oracle():
+    """is_causal=False (ENCODER_ONLY, triton_backend.py:651-653): every extend key is visible."""
+    B, Hq, Hkv, D, dtype = 2, 8, 2, 128, torch.bfloat16
+    c = _case(B, Hq, Hkv, D, 60, 100, dtype, seed=11)
+    T = c["q"].size(0)
+    o_ref = torch.zeros(T, Hq, D, dtype=dtype)
+    oracle.extend_attention(c["q"], c["ke"], c["ve"], o_ref, c["kb"], c["vb"], c["r2t"], c["rpi"], c["seq"], c["ext"],
+                            c["start"], int(c["ext"].max()), D ** -0.5, 0.0, causal=False)
+    d = {k: v.to(DEV) for k, v in c.items()}
+    qo_indptr, kv_indptr, kv_indices = _triton_meta(d, B)
+    o = torch.zeros(T, Hq, D, dtype=dtype, device=DEV)
+    ops.extend_attention_fwd(d["q"], d["ke"], d["ve"], o, d["kb"], d["vb"], qo_indptr, kv_indptr, kv_indices, None,
+                             False, None, int(c["ext"].max()), D ** -0.5, 0.0)
+    assert (o.float().cpu() - o_ref.float()).abs().max().item() <= tol_pair(dtype, o_ref)
+
+
+def test_extend_mask_argument_checks():
     x = torch.zeros(1, 1, 64, dtype=torch.bfloat16, device=DEV)
     i = torch.zeros(2, dtype=torch.int32, device=DEV)
-    with pytest.raises(NotImplementedError):
-        ops.extend_attention_fwd(x, x, x, x, x, x, i, i, i, torch.zeros(1, device=DEV), True, None, 1)
+    with pytest.raises(RuntimeError, match="mask_indptr"):
+        ops.extend_attention_fwd(x, x, x, x, x, x, i, i, i, torch.zeros(1, dtype=torch.bool, device=DEV), True, None, 1)

@@ -123,3 +123,46 @@ def test_scalar_converters_match_torch():
         lib.orc_cvt_f32_to_h(ctypes.c_void_p(xs.data_ptr()), ctypes.c_void_p(h.data_ptr()), ctypes.c_int64(x.numel()),
                              ctypes.c_int(code))
         assert torch.equal(h, xs.to(dt).view(torch.int16))
+
+
+@pytest.mark.parametrize("mode", ["mask_skip_prefix", "mask_full", "window", "non_causal"])
+def test_extend_oracle_masks_vs_dense_torch(mode):
+    """The optional masks of the Triton extend kernel (extend_attention.py:171-189, 246-259) as restated by the oracle,
+    against a dense fp32 softmax with an explicit boolean visibility matrix built straight from those rules."""
+    g = torch.Generator().manual_seed(len(mode))
+    Hq, Hkv, D, P, E = 4, 2, 32, 23, 17
+    dtype = torch.bfloat16
+    n_tok = P + E + 3
+    kb = torch.randn(n_tok, Hkv, D, generator=g).to(dtype)
+    vb = torch.randn(n_tok, Hkv, D, generator=g).to(dtype)
+    q = torch.randn(E, Hq, D, generator=g).to(dtype)
+    toks = torch.randperm(n_tok - 1, generator=g)[:P + E] + 1
+    r2t = toks.to(torch.int32).view(1, -1)
+    ke, ve = kb[toks[P:]].clone(), vb[toks[P:]].clone()
+    vis = torch.cat([torch.ones(E, P, dtype=torch.bool), torch.tril(torch.ones(E, E, dtype=torch.bool))], 1)
+    kw = {}
+    if mode.startswith("mask"):
+        m = vis & (torch.rand(E, P + E, generator=g) < 0.6)
+        m[:, P:] |= torch.eye(E, dtype=torch.bool)
+        kw = dict(custom_mask=m.flatten(), mask_indptr=torch.tensor([0, E * (P + E)]),
+                  skip_prefix_custom_mask=(mode == "mask_skip_prefix"))
+        vis = m.clone()
+        if mode == "mask_skip_prefix":
+            vis[:, :P] = True
+    elif mode == "window":
+        W = 5
+        kw = dict(sliding_window_size=W)
+        qi, ni = torch.arange(E)[:, None], torch.arange(P)[None, :]
+        vis[:, :P] = qi <= ni + W
+    else:
+        kw = dict(causal=False)
+        vis[:, P:] = True
+    o = torch.zeros(E, Hq, D, dtype=dtype)
+    oracle.extend_attention(q, ke, ve, o, kb, vb, r2t, torch.tensor([0]), torch.tensor([P + E]), torch.tensor([E]),
+                            torch.tensor([0]), E, D ** -0.5, 0.0, **kw)
+    K = kb[toks].float().repeat_interleave(Hq // Hkv, 1)  # [P+E, Hq, D]
+    V = vb[toks].float().repeat_interleave(Hq // Hkv, 1)
+    s = torch.einsum("ehd,nhd->hen", q.float(), K) * D ** -0.5
+    s = s.masked_fill(~vis[None], float("-inf"))
+    ref = torch.einsum("hen,nhd->ehd", torch.softmax(s, -1), V)
+    assert (o.float() - ref).abs().max().item() <= tol_for("bf16", ref)
