@@ -218,6 +218,22 @@ int sgl_mi355_awq_gemm(const void* x, const int32_t* qweight, const void* scales
                        const void* bias, void* out, float* workspace, int64_t workspace_floats,
                        int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, void* stream);
 
+/* Decode-time AWQ GEMM on a k-packed copy of the weights (csrc/awq_packed.hip).
+ * Replaces: the same AWQLinearMethod.apply (awq.py:401-418) for M <= 64, fp16.  sgl_mi355_awq_repack is what
+ * AWQLinearMethod.process_weights_after_loading (awq.py:396-399; "may repack freely", base_config.py) runs once:
+ *   wp uint32 [N][K/8]: the 8 nibbles of column n for k = 8kk..8kk+7 per dword; sz uint32 [N][K/G]: {fp16 scale,
+ *   fp16 (1024 + zero)}.  Values are bit-identical to awq_dequantize (same (w - z) * s in fp16).
+ *   K is padded to sgl_mi355_awq_packed_k(K) (next multiple of 512) with weights that dequantise to exactly 0, so
+ *   wp is [N][Kp/8] and sz [N][ceil(Kp/G)].
+ * awq_gemm_packed: x fp16 [M<=64][K] (row stride x_stride_m elements), out fp16 [M][N]; K % 128 == 0, N % 8 == 0,
+ *   group_size a power of two >= 128; workspace as for awq_gemm (nullable: disables split-K). */
+int64_t sgl_mi355_awq_packed_k(int64_t K);
+int sgl_mi355_awq_repack(const int32_t* qweight, const void* scales, const int32_t* qzeros, uint32_t* wp, uint32_t* sz,
+                         int64_t K, int64_t N, int64_t group_size, int dtype, void* stream);
+int sgl_mi355_awq_gemm_packed(const void* x, const uint32_t* wp, const uint32_t* sz, const void* bias, void* out,
+                              float* workspace, int64_t workspace_floats, int64_t M, int64_t N, int64_t K,
+                              int64_t group_size, int64_t x_stride_m, int dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Elementwise ops around the hot path.
  * Replace: sgl_kernel.rmsnorm / fused_add_rmsnorm / silu_and_mul /

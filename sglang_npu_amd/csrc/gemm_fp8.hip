@@ -965,29 +965,34 @@ int launch_wstream(const GemmArgs& p, float* slabs, int64_t slab_floats, hipStre
   if ((int64_t)p.N * p.b_sn >= ((int64_t)1 << 32)) return 0;  // per-lane weight offsets are 32-bit
   const int steps = p.K >> 7;
   static const int ph_cap = [] { const char* e = getenv("SGL_MI355_WSTREAM_PH"); return e ? atoi(e) : 32; }();  // tuning aid
-  int PH = 32 / MB;
-  while (PH > ph_cap && PH > 8) PH >>= 1;
-  while (PH >= 8 && steps % PH != 0) PH >>= 1;
-  if (PH < 8) return 0;
-  const int P_total = steps / PH;
-  // consumer waves per workgroup (+1 producer wave): the count that leaves the fewest column blocks on the
-  // busiest CU -- one workgroup per CU, the A buffers fill most of the LDS (N = 28672: 7 -> exactly 256).
   const int nblocks = (p.N + 15) / 16;
-  int nc = 8, best = 1 << 30;
-  for (int c = 8; c >= 4; --c) {
-    const int cost = (((nblocks + c - 1) / c + 255) / 256) * c;
-    if (cost < best) { best = cost; nc = c; }
+  // Pick (PH, consumer waves, K slices): one workgroup per CU (the A buffers fill most of the LDS) and a CU draws
+  // only ~10 B/clk from HBM, so minimise the k-steps on the busiest CU (+ ~4 steps' worth of barrier per phase).
+  // Without slabs: all of K per workgroup, longest phase (N = 28672: 7 consumers -> exactly 256 workgroups).
+  int PH = 0, nc = 8, SK = 1, pps = 0, best = 1 << 30;
+  for (int ph = 32 / MB; ph >= 8; ph >>= 1) {
+    if (ph > ph_cap && ph > 8) continue;
+    if (steps % ph != 0) continue;
+    const int P = steps / ph;
+    for (int c = 8; c >= 4; --c) {
+      const int groups_c = (nblocks + c - 1) / c;
+      int sk = 1, pp = P;
+      if (slabs != nullptr) {
+        int sk_max = 256 / groups_c;
+        if (sk_max < 1) sk_max = 1;
+        if (sk_max > P) sk_max = P;
+        pp = (P + sk_max - 1) / sk_max;
+        sk = (P + pp - 1) / pp;
+      }
+      const int rounds = (groups_c * sk + 255) / 256;
+      const int cost = rounds * c * pp * (ph + 4);
+      if (cost < best) { best = cost; PH = ph; nc = c; SK = sk; pps = pp; }
+    }
+    if (slabs == nullptr) break;  // the longest phase that divides K
   }
+  if (PH == 0) return 0;
   const int groups = (nblocks + nc - 1) / nc;
-  int SK = 1, pps = P_total;
-  if (slabs != nullptr) {
-    int sk_max = 256 / groups;
-    if (sk_max < 1) sk_max = 1;
-    if (sk_max > P_total) sk_max = P_total;
-    pps = (P_total + sk_max - 1) / sk_max;
-    SK = (P_total + pps - 1) / pps;
-    if (SK < 2 || slab_floats < (int64_t)SK * p.M * p.N) return 0;
-  }
+  if (slabs != nullptr && (SK < 2 || slab_floats < (int64_t)SK * p.M * p.N)) return 0;
   used = true;
 #define WS_GO(PH_)                                                                                         \
   return slabs ? launch_wstream_ph<OUT_DTYPE, MB, PH_, true>(p, slabs, SK, pps, nc, groups, s)              \
@@ -1320,7 +1325,10 @@ int run_gemm(const GemmArgs& p, float* workspace, int64_t workspace_floats, hipS
     // split-K slabs pay a finalize launch (~4 us): worth it from 40 Mi weights, and from 20 Mi at M > 32 where
     // the alternative re-reads the activations from L2 per wave (qkv 4096x6144: 12.6 + 4.2 us vs 21.2)
     static const int slab_env = [] { const char* e = getenv("SGL_MI355_SLAB_MIN_MI"); return e ? atoi(e) : 0; }();  // tuning aid
-    const int64_t slab_min = (int64_t)(slab_env ? slab_env : (p.M > 32 ? 20 : 40)) << 20;
+    const int steps128 = p.K >> 7;  // the one-shot kernel takes K/128 = WK * S with S <= 4, WK <= 8
+    const bool oneshot_ok = (p.K & 127) == 0 && (steps128 <= 8 || (steps128 <= 32 && (steps128 % 4 == 0 || steps128 % 3 == 0 ||
+                                                                                        (steps128 % 2 == 0 && steps128 <= 16))));
+    const int64_t slab_min = (int64_t)(slab_env ? slab_env : (p.M > 32 ? (oneshot_ok ? 20 : 8) : 40)) << 20;
     if (!no_wstream && workspace != nullptr && (int64_t)p.N * p.K >= slab_min) {
       bool used = false;  // narrow N, long K: K split over workgroups, fp32 slabs
       int rc = p.M <= 16   ? launch_wstream<OUT_DTYPE, 1>(p, workspace, workspace_floats, s, used)

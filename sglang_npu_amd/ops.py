@@ -370,6 +370,54 @@ def awq_gemm(x: torch.Tensor, qweight, scales, qzeros, bias=None) -> torch.Tenso
     return out
 
 
+def awq_packable(K: int, N: int, G: int, dtype) -> bool:
+    """Shapes the k-packed decode kernel takes (csrc/awq_packed.hip)."""
+    return (dtype == torch.float16 and K % 128 == 0 and N % 8 == 0 and G >= 128 and (G & (G - 1)) == 0 and K % G == 0
+            and N * (_awq_kp(K) // 2) < (1 << 32))
+
+
+def _awq_kp(K: int) -> int:
+    return (K + 511) // 512 * 512  # sgl_mi355_awq_packed_k
+
+
+def awq_repack(qweight, scales, qzeros):
+    """One-off repack for the decode GEMM (what AWQLinearMethod.process_weights_after_loading may do):
+    returns (wp uint32 [N, K/8], sz uint32 [N, K/G]) -- k-packed nibbles and {scale, 1024+zero} pairs."""
+    _need_gpu(qweight, scales, qzeros)
+    K, N = qweight.size(0), qweight.size(1) * 8
+    G = K // scales.size(0)
+    if qweight.dtype != torch.int32 or qzeros.dtype != torch.int32 or not (qweight.is_contiguous() and
+                                                                         qzeros.is_contiguous() and scales.is_contiguous()):
+        raise RuntimeError("awq_repack: qweight/qzeros must be contiguous int32, scales contiguous")
+    Kp = _awq_kp(K)
+    wp = torch.empty((N, Kp // 8), dtype=torch.int32, device=qweight.device)
+    sz = torch.empty((N, -(-Kp // G)), dtype=torch.int32, device=qweight.device)
+    _lib.check(_lib.lib().sgl_mi355_awq_repack(_ptr(qweight), _ptr(scales), _ptr(qzeros), _ptr(wp), _ptr(sz), _I64(K),
+                                               _I64(N), _I64(G), _I(_dtype_code(scales)), _stream(qweight)))
+    return wp, sz
+
+
+def awq_gemm_packed(x: torch.Tensor, wp: torch.Tensor, sz: torch.Tensor, group_size: int, bias=None) -> torch.Tensor:
+    """x [M<=64, K] fp16 @ dequant(W) (+ bias) on the repacked weights of awq_repack."""
+    _need_gpu(x, wp, sz, bias)
+    if x.dim() != 2 or x.stride(1) != 1 or x.dtype != torch.float16:
+        raise RuntimeError("awq_gemm_packed: x must be a row-major fp16 [M,K] tensor")
+    M, K = x.shape
+    N = wp.size(0)
+    if wp.size(1) * 8 != _awq_kp(K) or sz.size(0) != N:
+        raise RuntimeError("awq_gemm_packed: x and the packed weight shapes cannot be multiplied")
+    out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    need = 16 * M * N
+    ws = _awq_workspace.get(x.device)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 16 * 64 * 4096), dtype=torch.float32, device=x.device)
+        _awq_workspace[x.device] = ws
+    _lib.check(_lib.lib().sgl_mi355_awq_gemm_packed(
+        _ptr(x), _ptr(wp), _ptr(sz), _ptr(bias), _ptr(out), _ptr(ws), _I64(ws.numel()), _I64(M), _I64(N), _I64(K),
+        _I64(group_size), _I64(x.stride(0) if M > 1 else K), _I(_dtype_code(x)), _stream(x)))
+    return out
+
+
 # --------------------------------------------------------------------------- elementwise ("next" rows)
 def _rows(x):
     if x.dim() < 1 or not x.is_contiguous():

@@ -17,6 +17,8 @@ from __future__ import annotations
 
 from typing import Any, Dict, List, Optional
 
+import os
+
 import torch
 
 from . import ops
@@ -252,6 +254,15 @@ class AWQLinearMethod(LinearMethodBase):
         layer.qweight = torch.nn.Parameter(layer.qweight.data, requires_grad=False)
         layer.qzeros = torch.nn.Parameter(layer.qzeros.data, requires_grad=False)
         layer.scales = torch.nn.Parameter(layer.scales.data, requires_grad=False)
+        # Decode-time copy in the k-packed layout (csrc/awq_packed.hip): the reference's own hook for "transpose /
+        # repack freely" (base_config.py process_weights_after_loading).  Costs K*N/2 + K*N/32 extra bytes per
+        # layer; SGL_MI355_AWQ_NO_REPACK=1 keeps only the checkpoint layout.
+        layer.awq_packed = None
+        K, N = layer.qweight.shape[0], layer.qweight.shape[1] * self.quant_config.pack_factor
+        G = K // layer.scales.shape[0]
+        if layer.qweight.is_cuda and not os.environ.get("SGL_MI355_AWQ_NO_REPACK") and \
+                ops.awq_packable(K, N, G, layer.scales.dtype):
+            layer.awq_packed = ops.awq_repack(layer.qweight.data, layer.scales.data, layer.qzeros.data) + (G,)
 
     def apply(self, layer, x: torch.Tensor, bias: Optional[torch.Tensor] = None):
         # awq.py:401-418 computes awq_dequantize(...) then x @ W; here the dequant is fused into the GEMM
@@ -259,7 +270,11 @@ class AWQLinearMethod(LinearMethodBase):
         pack_factor = self.quant_config.pack_factor
         out_shape = x.shape[:-1] + (qweight.shape[-1] * pack_factor,)
         reshaped_x = x.reshape(-1, x.shape[-1])
-        out = ops.awq_gemm(reshaped_x, qweight, scales, qzeros, bias)
+        packed = getattr(layer, "awq_packed", None)
+        if packed is not None and reshaped_x.shape[0] <= 64 and reshaped_x.dtype == torch.float16:
+            out = ops.awq_gemm_packed(reshaped_x, packed[0], packed[1], packed[2], bias)
+        else:
+            out = ops.awq_gemm(reshaped_x, qweight, scales, qzeros, bias)
         return out.reshape(out_shape)
 
 

@@ -62,3 +62,72 @@ def test_awq_gemm_vs_oracle(M, K, N):
     out = ops.awq_gemm(x.to(DEV), qw.to(DEV), sc.to(DEV), qz.to(DEV), bias.to(DEV) if bias is not None else None)
     # fp32 accumulation of identical fp16 operands: summation order only -> 1 output ulp (+ bias rounding)
     torch.testing.assert_close(out.float().cpu(), ref.float(), rtol=2.0 ** -10, atol=2e-3 * float(ref.float().abs().max()))
+
+
+def _awq_case(K, N, G, g):
+    imax = torch.iinfo(torch.int32).max
+    qw = torch.randint(0, imax, (K, N // 8), dtype=torch.int32, generator=g)
+    qz = torch.randint(0, imax, (K // G, N // 8), dtype=torch.int32, generator=g)
+    sc = ((torch.rand(K // G, N, generator=g) - 0.3) * 2e-2).half()  # negative scales too
+    return qw, qz, sc
+
+
+@pytest.mark.parametrize("K,N,G", [(512, 16, 128), (1024, 72, 256), (4096, 4096, 128), (11008, 1000, 128), (640, 64, 128)])
+def test_awq_packed_dequant_is_bit_exact(K, N, G):
+    """The k-packed decode path must produce the SAME fp16 weights as awq_dequantize (integer unpack exact, one fp16
+    rounding in `(w - z) * s`): with one-hot activation rows x[m] = e_{k_m} the GEMM output row m is W[k_m, :] exactly
+    (a single product by 1.0, fp32 accumulate, exact back-conversion)."""
+    g = torch.Generator().manual_seed(K + N)
+    qw, qz, sc = _awq_case(K, N, G, g)
+    w_ref = oracle.awq_dequantize(qw, sc, qz)  # [K, N] fp16, pinned bit-exact to the reference by the golden test
+    wp, sz = ops.awq_repack(qw.to(DEV), sc.to(DEV), qz.to(DEV))
+    rows = torch.randperm(K, generator=g)[:192]
+    for c in range(0, 192, 64):
+        ks = rows[c:c + 64]
+        x = torch.zeros(64, K, dtype=torch.float16)
+        x[torch.arange(64), ks] = 1.0
+        out = ops.awq_gemm_packed(x.to(DEV), wp, sz, G)
+        # a sum cannot return -0.0 (nib == zero with a negative scale): compare modulo the sign of zero
+        assert torch.equal((out.cpu() + 0.0).view(torch.int16), (w_ref[ks] + 0.0).view(torch.int16))
+
+
+@pytest.mark.parametrize("M", [1, 7, 16, 17, 32, 33, 64])
+@pytest.mark.parametrize("K,N", [(4096, 4096), (4096, 12288), (11008, 4096), (512, 128), (4096, 22016), (2176, 1000)])
+def test_awq_gemm_packed_vs_oracle(M, K, N):
+    """Every M bucket (16/32/64 rows), wide and narrow N (direct and split-K slabs), ragged N, bias on odd M."""
+    if M > 16 and K * N > 5e7:
+        pytest.skip("oracle too slow")
+    g = torch.Generator().manual_seed(M * 3 + K + N)
+    G = 128
+    qw, qz, sc = _awq_case(K, N, G, g)
+    x = torch.randn(M, K, generator=g).half()
+    bias = torch.randn(N, generator=g).half() if M % 2 else None
+    ref = oracle.awq_gemm(x, qw, sc, qz, bias)
+    wp, sz = ops.awq_repack(qw.to(DEV), sc.to(DEV), qz.to(DEV))
+    out = ops.awq_gemm_packed(x.to(DEV), wp, sz, G, bias.to(DEV) if bias is not None else None)
+    torch.testing.assert_close(out.float().cpu(), ref.float(), rtol=2.0 ** -10, atol=2e-3 * float(ref.float().abs().max()))
+    # and the same numbers as the checkpoint-layout kernel up to summation order
+    out2 = ops.awq_gemm(x.to(DEV), qw.to(DEV), sc.to(DEV), qz.to(DEV), bias.to(DEV) if bias is not None else None)
+    torch.testing.assert_close(out.float(), out2.float(), rtol=2.0 ** -9, atol=2e-3 * float(ref.float().abs().max()))
+
+
+def test_awq_linear_method_repacks_and_matches_unpacked(monkeypatch):
+    from sglang_npu_amd.quantization import AWQConfig
+    from sglang_npu_amd.linear import ColumnParallelLinear
+    g = torch.Generator().manual_seed(9)
+    K, N = 1024, 512
+    outs = []
+    for no_repack in ("", "1"):
+        if no_repack:
+            monkeypatch.setenv("SGL_MI355_AWQ_NO_REPACK", "1")
+        layer = ColumnParallelLinear(K, [N], bias=False, params_dtype=torch.float16,
+                                     quant_config=AWQConfig(4, 128, True)).to(DEV)
+        gg = torch.Generator().manual_seed(10)
+        qw, qz, sc = _awq_case(K, N, 128, gg)
+        layer.qweight.data.copy_(qw), layer.qzeros.data.copy_(qz), layer.scales.data.copy_(sc)
+        layer.quant_method.process_weights_after_loading(layer)
+        assert (layer.awq_packed is None) == bool(no_repack)
+        x = torch.randn(20, K, generator=torch.Generator().manual_seed(9)).half().to(DEV)
+        y = layer(x)
+        outs.append(y[0] if isinstance(y, tuple) else y)
+    torch.testing.assert_close(outs[0].float(), outs[1].float(), rtol=2.0 ** -9, atol=1e-2)
