@@ -301,6 +301,41 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = args.batch * args.steps / elapsed
 
+    # ---- all-reduce overhead (N > 1): the same step with the TP all-reduce stubbed to identity, outside the timed
+    # region above ((t_with - t_without) / t_with)
+    ar_info = None
+    if tp > 1:
+        try:
+            tp_group.stub_all_reduce = True
+            seq_after = loop.seq_lens.clone()
+            loop.seq_lens.fill_(args.ctx)  # the page table has room for ctx + steps + warmup + 8 positions only
+            loop._refresh()
+            if loop.graph is not None:
+                loop.capture()
+            n_stub = min(args.steps, 6)
+            for _ in range(2):
+                loop.step()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(n_stub):
+                loop.step()
+            barrier()
+            stub_s = time.perf_counter() - t1
+            t = torch.tensor([stub_s], device=device, dtype=torch.float64)
+            tp_group.stub_all_reduce = False
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            stub_ms = float(t.item()) / n_stub * 1e3
+            ar_info = {"ms_per_step_allreduce_stubbed": round(stub_ms, 4),
+                       "overhead_frac": round(max(0.0, (ms_per_step - stub_ms) / ms_per_step), 4),
+                       "collectives_per_step": 2 * len(net.layers) + 1,
+                       "message_bytes": args.batch * cfg.hidden_size * 2}
+        finally:
+            tp_group.stub_all_reduce = False
+            loop.seq_lens.copy_(seq_after)
+            loop._refresh()
+        if loop.graph is not None:
+            loop.capture()  # the instrumented passes below run the real step again
+
     # ---- roofline of the dominant kernel: paged decode attention (HBM-bound)
     ctx_mid = args.ctx + args.warmup + args.steps + args.steps // 2  # mean sequence length of the instrumented pass
     hq, hkv, d = cfg.num_attention_heads // tp, cfg.get_num_kv_heads(tp), cfg.head_dim
@@ -337,6 +372,8 @@ def main():
                      "avg_launch_us": round(attn_ms * 1e3, 2), "launches_timed": n_launch,
                      "algorithmic_bytes_per_launch": int(alg_bytes)},
     }
+    if ar_info is not None:
+        out["allreduce"] = ar_info
     try:
         ttft_ms, ttft_len = time_ttft(net, runner, backend, device)
         if tp > 1:

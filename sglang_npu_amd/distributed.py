@@ -114,6 +114,8 @@ class GroupCoordinator:
         self.device = device
         self._side_stream = None
         self.ca_comm: Optional[CustomAllreduce] = None
+        # measurement aid (overhead = (step with AR - step with AR stubbed to identity) / step)
+        self.stub_all_reduce = False
 
     @property
     def side_stream(self):
@@ -123,7 +125,7 @@ class GroupCoordinator:
 
     def all_reduce(self, input_: torch.Tensor) -> torch.Tensor:
         """SUM over the TP ranks (in place, like the pynccl path parallel_state.py:563-568)."""
-        if self.world_size == 1:
+        if self.world_size == 1 or self.stub_all_reduce:
             return input_
         # dispatch order of parallel_state.py:519-542: custom P2P all-reduce if it accepts the tensor, else RCCL
         if self.ca_comm is not None and not self.ca_comm.disabled:
