@@ -69,12 +69,14 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(
   const int64_t row = blockIdx.x;
   const int nv = H >> 3;
   float v[VPT][8];
+  x8 wq[VPT];  // weights fetched with the row, not behind the first reduction (one memory round trip less)
   float ss = 0.f;
 #pragma unroll
   for (int i = 0; i < VPT; ++i) {
     const int vi = threadIdx.x + 256 * i;
     if (vi < nv) {
       const x8 xv = reinterpret_cast<const x8*>(x + row * H)[vi];
+      wq[i] = reinterpret_cast<const x8*>(weight)[vi];
       if (residual) {
         const x8 rv = reinterpret_cast<const x8*>(residual + row * H)[vi];
         x8 nr;
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(
   for (int i = 0; i < VPT; ++i) {
     const int vi = threadIdx.x + 256 * i;
     if (vi < nv) {
-      const x8 wv = reinterpret_cast<const x8*>(weight)[vi];
+      const x8 wv = wq[i];
       x8 o;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -129,20 +131,22 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(
 }
 
 // out[t, :d] = silu(x[t, :d]) * x[t, d:2d]  (+ optional per-row FP8 quant of the result)
-template <int DTYPE, int VPT>
-__global__ __launch_bounds__(256) void silu_mul_kernel(
+// NT threads per row: decode batches have few, long rows (64 x 14336), so the launcher takes 1024 threads there --
+// the row is latency- and ALU-bound (an exp and a divide per element), not bandwidth-bound.
+template <int DTYPE, int VPT, int NT>
+__global__ __launch_bounds__(NT) void silu_mul_kernel(
     const typename Half16<DTYPE>::T* __restrict__ x, typename Half16<DTYPE>::T* __restrict__ out,
     uint8_t* __restrict__ out_q, float* __restrict__ out_s, int d) {
   using Hh = Half16<DTYPE>;
   using x8 = typename Hh::x8;
-  __shared__ float red[4];
+  __shared__ float red[NT / 64];
   const int64_t row = blockIdx.x;
   const int nv = d >> 3;
   float v[VPT][8];
   float amax = 0.f;
 #pragma unroll
   for (int i = 0; i < VPT; ++i) {
-    const int vi = threadIdx.x + 256 * i;
+    const int vi = threadIdx.x + NT * i;
     if (vi < nv) {
       const x8 a = reinterpret_cast<const x8*>(x + row * 2 * d)[vi];
       const x8 b = reinterpret_cast<const x8*>(x + row * 2 * d + d)[vi];
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(
     const float sinv = scale == 0.f ? 0.f : 1.0f / scale;
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
-      const int vi = threadIdx.x + 256 * i;
+      const int vi = threadIdx.x + NT * i;
       if (vi < nv) {
         float f[8];
 #pragma unroll
@@ -266,15 +270,23 @@ template <int DTYPE>
 int launch_silu(const void* x, void* out, void* out_q, float* out_s, int64_t T, int64_t d, hipStream_t s) {
   using T16 = typename Half16<DTYPE>::T;
   const int nv = (int)(d >> 3);
-  const int vpt = (nv + 255) / 256;
-#define SILU_LAUNCH(V)                                                                                     \
-  hipLaunchKernelGGL((silu_mul_kernel<DTYPE, V>), dim3((unsigned)T), dim3(256), 0, s, (const T16*)x, (T16*)out, \
+#define SILU_LAUNCH(V, NT_)                                                                                      \
+  hipLaunchKernelGGL((silu_mul_kernel<DTYPE, V, NT_>), dim3((unsigned)T), dim3(NT_), 0, s, (const T16*)x, (T16*)out, \
                      (uint8_t*)out_q, out_s, (int)d)
-  if (vpt <= 1) SILU_LAUNCH(1);
-  else if (vpt <= 2) SILU_LAUNCH(2);
-  else if (vpt <= 4) SILU_LAUNCH(4);
-  else if (vpt <= 8) SILU_LAUNCH(8);
-  else SILU_LAUNCH(16);
+  if (T <= 512 && nv >= 1024) {  // few long rows
+    const int vpt = (nv + 1023) / 1024;
+    if (vpt <= 1) SILU_LAUNCH(1, 1024);
+    else if (vpt <= 2) SILU_LAUNCH(2, 1024);
+    else if (vpt <= 4) SILU_LAUNCH(4, 1024);
+    else SILU_LAUNCH(8, 1024);
+  } else {
+    const int vpt = (nv + 255) / 256;
+    if (vpt <= 1) SILU_LAUNCH(1, 256);
+    else if (vpt <= 2) SILU_LAUNCH(2, 256);
+    else if (vpt <= 4) SILU_LAUNCH(4, 256);
+    else if (vpt <= 8) SILU_LAUNCH(8, 256);
+    else SILU_LAUNCH(16, 256);
+  }
 #undef SILU_LAUNCH
   return check_hip(hipGetLastError(), "silu_and_mul launch");
 }
