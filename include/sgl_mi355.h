@@ -26,6 +26,7 @@ extern "C" {
 
 #define SGL_MI355_BF16 0
 #define SGL_MI355_FP16 1
+#define SGL_MI355_FP32 2 /* merge_state only */
 
 #define SGL_MI355_OK 0
 #define SGL_MI355_ERR_INVALID_ARGUMENT 1 /* TORCH_CHECK-class precondition failure   */
@@ -148,6 +149,16 @@ int sgl_mi355_extend_attention_fwd(
     float sm_scale, float logit_cap,
     const uint8_t* custom_mask, const int64_t* mask_indptr, int skip_prefix_custom_mask, int64_t sliding_window_size,
     int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * merge_state: combine two partial attention results of the same queries by their log-sum-exp.
+ * Replaces: merge_state_triton(prefix_output, prefix_lse, suffix_output, suffix_lse, output, output_lse)
+ *           python/sglang/srt/layers/attention/triton_ops/merge_state.py:8-96, and sgl_kernel.merge_state /
+ *           merge_state_v2 (sgl-kernel/csrc/attention/merge_attn_states.cu).
+ *   outputs [N,H,D] contiguous in `dtype` (bf16 / fp16 / fp32), lse [N,H] fp32; output_lse nullable. */
+int sgl_mi355_merge_state(const void* prefix_output, const float* prefix_lse, const void* suffix_output,
+                          const float* suffix_lse, void* output, float* output_lse, int64_t num_tokens,
+                          int64_t num_heads, int64_t head_size, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Ragged prefix + extend attention, op-level form.

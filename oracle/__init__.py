@@ -263,3 +263,16 @@ def rope_neox(x, positions, cos_sin_cache, rot_dim=None, lib=None):
     lib.orc_rope_neox(_ptr(x), _ptr(pos), _ptr(cos_sin_cache.contiguous()), _I64(x.size(0)), _I64(x.size(1)),
                       _I64(x.size(2)), _I64(rot_dim), _I64(x.stride(0)), _I64(x.stride(1)), _I(_dt(x)))
     return x
+
+
+def merge_state(prefix_output, prefix_lse, suffix_output, suffix_lse, lib=None):
+    """merge_state_triton (triton_ops/merge_state.py:68-96): returns (output, output_lse)."""
+    lib = lib or load()
+    code = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}[prefix_output.dtype]
+    po, so = prefix_output.contiguous(), suffix_output.contiguous()
+    out = torch.empty_like(po)
+    out_lse = torch.empty_like(prefix_lse)
+    N, H, D = po.shape
+    lib.orc_merge_state(_ptr(po), _ptr(prefix_lse.contiguous()), _ptr(so), _ptr(suffix_lse.contiguous()), _ptr(out),
+                        _ptr(out_lse), _I64(N * H), _I64(D), _I(code))
+    return out, out_lse

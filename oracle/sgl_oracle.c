@@ -661,3 +661,33 @@ void orc_rope_neox(
   }
   (void)D;
 }
+
+
+/* ------------------------------------------------------------------ merge_state
+ * merge_state_kernel, python/sglang/srt/layers/attention/triton_ops/merge_state.py:8-65:
+ *   lse == +inf -> -inf (:29-30); max; out_se = exp(p - max) + exp(s - max); out_lse = log(out_se) + max (:38);
+ *   out = p_out * exp(p - max) / out_se + s_out * exp(s - max) / out_se in fp32, stored in the output dtype.
+ * dtype: 0 bf16, 1 fp16, 2 fp32. */
+void orc_merge_state(const void* p_out, const float* p_lse, const void* s_out, const float* s_lse, void* out,
+                     float* out_lse, int64_t pairs, int64_t D, int dtype) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < pairs; ++i) {
+    float pl = p_lse[i], sl = s_lse[i];
+    if (pl == INFINITY) pl = -INFINITY;
+    if (sl == INFINITY) sl = -INFINITY;
+    const float mx = pl > sl ? pl : sl;
+    const float pe = expf(pl - mx), se = expf(sl - mx);
+    const float ose = pe + se;
+    if (out_lse) out_lse[i] = logf(ose) + mx;
+    const float ps = pe / ose, ss = se / ose;
+    for (int64_t d = 0; d < D; ++d) {
+      if (dtype == 2) {
+        ((float*)out)[i * D + d] = ((const float*)p_out)[i * D + d] * ps + ((const float*)s_out)[i * D + d] * ss;
+      } else {
+        const float a = h_to_f32(((const uint16_t*)p_out)[i * D + d], dtype);
+        const float b = h_to_f32(((const uint16_t*)s_out)[i * D + d], dtype);
+        ((uint16_t*)out)[i * D + d] = f32_to_h(a * ps + b * ss, dtype);
+      }
+    }
+  }
+}

@@ -233,6 +233,30 @@ def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buf
         _I(_dtype_code(q_extend)), _stream(q_extend)))
 
 
+def merge_state(prefix_output, prefix_lse, suffix_output, suffix_lse, output=None, output_lse=None):
+    """merge_state_triton(prefix_output, prefix_lse, suffix_output, suffix_lse, output=None, output_lse=None)
+    -- python/sglang/srt/layers/attention/triton_ops/merge_state.py:68-96 (same defaults and return value)."""
+    _need_gpu(prefix_output, prefix_lse, suffix_output, suffix_lse, output, output_lse)
+    if output is None:
+        output = torch.empty(prefix_output.shape, dtype=prefix_output.dtype, device=prefix_output.device)
+    if output_lse is None:
+        output_lse = torch.empty(prefix_lse.shape, dtype=prefix_lse.dtype, device=prefix_lse.device)
+    for t in (prefix_output, suffix_output, output):
+        if t.dim() != 3 or not t.is_contiguous() or t.shape != prefix_output.shape or t.dtype != prefix_output.dtype:
+            raise RuntimeError("merge_state: outputs must be contiguous [N,H,D] tensors of one dtype")
+    for t in (prefix_lse, suffix_lse, output_lse):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.shape != prefix_output.shape[:2]:
+            raise RuntimeError("merge_state: lse tensors must be contiguous float32 [N,H]")
+    code = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}.get(prefix_output.dtype)
+    if code is None:
+        raise RuntimeError("merge_state: dtype must be bfloat16, float16 or float32")
+    N, H, D = prefix_output.shape
+    _lib.check(_lib.lib().sgl_mi355_merge_state(_ptr(prefix_output), _ptr(prefix_lse), _ptr(suffix_output),
+                                                _ptr(suffix_lse), _ptr(output), _ptr(output_lse), _I64(N), _I64(H), _I64(D),
+                                                _I(code), _stream(prefix_output)))
+    return output, output_lse
+
+
 def extend_attention(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, req_to_token, req_pool_indices,
                      seq_lens, extend_seq_lens, extend_start_loc, max_len_extend, sm_scale, logit_cap):
     """torch.ops.sgl_kernel.extend_attention_cpu(...) argument for argument
