@@ -229,6 +229,34 @@ int sgl_mi355_awq_gemm(const void* x, const int32_t* qweight, const void* scales
                        const void* bias, void* out, float* workspace, int64_t workspace_floats,
                        int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, void* stream);
 
+/* Split-K form of fp8_scaled_mm for fused consumers (decode, M <= 64).
+ *   fp8_scaled_mm_partials leaves raw fp32 partial sums workspace[slice][M][N] and reports the slice count
+ *   (SGL_MI355_ERR_UNSUPPORTED when the shape is not on the split-K weight-streaming path: the caller then uses
+ *   sgl_mi355_fp8_scaled_mm).  The epilogue of fp8_gemm_kernel.cu:498-546 (x w_scale, x x_scale, + bias, one rounding)
+ *   is applied by the consumer, which sums the slices in slice order -- results are bit-identical to the unfused op:
+ *     sgl_mi355_fp8_scaled_mm_finalize                      -> out [M,N] (plain completion)
+ *     sgl_mi355_rmsnorm_quant_fp8_from_partials             -> GEMM epilogue + fused_add_rmsnorm + per-token FP8 quant
+ *                                                              (layernorm.py:59-172 then per_token_quant_fp8.cu)
+ *     sgl_mi355_rotary_embedding_set_kv_from_partials       -> GEMM epilogue (qkv) + RoPE + KV-pool write
+ *                                                              (rotary_embedding.py:79-260 + memory_pool.py:369-407)
+ *   They exist to remove the finalize launch and one activation round trip per GEMM at decode. */
+int sgl_mi355_fp8_scaled_mm_partials(const void* mat_a, const void* mat_b, float* workspace, int64_t workspace_floats,
+                                     int64_t M, int64_t N, int64_t K, int64_t a_stride_m, int64_t b_stride_n,
+                                     int32_t* num_slices, void* stream);
+int sgl_mi355_fp8_scaled_mm_finalize(const float* partials, int64_t num_slices, const float* scales_a,
+                                     const float* scales_b, const void* bias, void* out, int64_t M, int64_t N,
+                                     int out_dtype, void* stream);
+int sgl_mi355_rmsnorm_quant_fp8_from_partials(void* out_q, float* out_s, void* residual, const float* partials,
+                                              int64_t num_slices, const float* scales_a, const float* scales_b,
+                                              const void* bias, const void* weight, int64_t num_tokens, int64_t hidden,
+                                              float eps, int dtype, void* stream);
+int sgl_mi355_rotary_embedding_set_kv_from_partials(
+    void* q_out, void* k_buffer, void* v_buffer, const int64_t* positions, const void* loc, int loc_is64,
+    const float* cos_sin_cache, const float* partials, int64_t num_slices, const float* scales_a, const float* scales_b,
+    const void* bias, int64_t num_tokens, int64_t num_q_heads, int64_t num_k_heads, int64_t head_size, int64_t rot_dim,
+    int64_t q_out_stride_t, int64_t kb_stride_n, int64_t kb_stride_h, int64_t vb_stride_n, int64_t vb_stride_h,
+    int is_neox, int dtype, void* stream);
+
 /* Decode-time AWQ GEMM on a k-packed copy of the weights (csrc/awq_packed.hip).
  * Replaces: the same AWQLinearMethod.apply (awq.py:401-418) for M <= 64, fp16.  sgl_mi355_awq_repack is what
  * AWQLinearMethod.process_weights_after_loading (awq.py:396-399; "may repack freely", base_config.py) runs once:

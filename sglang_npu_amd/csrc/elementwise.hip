@@ -55,14 +55,82 @@ __device__ __forceinline__ uint2 pack8_fp8(const float* f) {
   return uint2{(unsigned)lo, (unsigned)hi};
 }
 
+// Source of a row that is still a split-K GEMM in flight (sgl_mi355_fp8_scaled_mm_partials): the consumer applies the
+// fp8_scaled_mm epilogue itself -- slices summed in slice order, x w_scale[col], x x_scale[row], + bias, ONE rounding to
+// the 16-bit dtype (fp8_gemm_finalize_kernel, gemm_fp8.hip) -- and continues with the rounded value, so the result is
+// bit-identical to running the GEMM to completion first.  Saves the finalize launch and one activation round trip.
+struct PartialSrc {
+  const float* partials;  // [num_slices][M][N] fp32
+  int num_slices;
+  int64_t slice_stride;   // M * N
+  const float* sa;        // x_scale [M]
+  const float* sb;        // w_scale [N]
+  const void* bias;       // 16-bit [N] or null
+  int N;
+};
+
+template <int DTYPE>
+__device__ __forceinline__ typename Half16<DTYPE>::x8 gemm_row8(const PartialSrc& ps, int64_t row, int col) {
+  using Hh = Half16<DTYPE>;
+  float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const float* src = ps.partials + row * ps.N + col;
+  // four slices' loads in flight at a time (a plain slice loop serialises one L2 round trip per slice); the sums
+  // still run in slice order, as in fp8_gemm_finalize_kernel
+  for (int s0 = 0; s0 < ps.num_slices; s0 += 4) {
+    f32x4 a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int si = s0 + u < ps.num_slices ? s0 + u : ps.num_slices - 1;
+      a[u] = *reinterpret_cast<const f32x4*>(src + si * ps.slice_stride);
+      b[u] = *reinterpret_cast<const f32x4*>(src + si * ps.slice_stride + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (s0 + u < ps.num_slices) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] += a[u][j];
+          v[4 + j] += b[u][j];
+        }
+      }
+  }
+  const float sa = ps.sa[row];
+  typename Hh::x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    // explicit roundings (no fma contraction): must match fp8_gemm_finalize_kernel bit for bit
+    float r = __fmul_rn(__fmul_rn(v[j], ps.sb[col + j]), sa);
+    if (ps.bias) r = __fadd_rn(r, Hh::to_f32(reinterpret_cast<const typename Hh::T*>(ps.bias)[col + j]));
+    o[j] = Hh::from_f32(r);
+  }
+  return o;
+}
+template <int DTYPE>
+__device__ __forceinline__ typename Half16<DTYPE>::T gemm_elem(const PartialSrc& ps, int64_t row, int col) {
+  using Hh = Half16<DTYPE>;
+  float v = 0.f;
+  const float* src = ps.partials + row * ps.N + col;
+  for (int s0 = 0; s0 < ps.num_slices; s0 += 4) {
+    float a[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a[u] = src[(s0 + u < ps.num_slices ? s0 + u : ps.num_slices - 1) * ps.slice_stride];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (s0 + u < ps.num_slices) v += a[u];
+  }
+  float r = __fmul_rn(__fmul_rn(v, ps.sb[col]), ps.sa[row]);
+  if (ps.bias) r = __fadd_rn(r, Hh::to_f32(reinterpret_cast<const typename Hh::T*>(ps.bias)[col]));
+  return Hh::from_f32(r);
+}
+
 // (residual-add +) RMSNorm (+ FP8 quant).  H % 8 == 0, H <= 256 * 8 * VPT.
 //   x: [T,H] input; residual: nullable, in/out (residual = x + residual, rounded to dtype);
 //   out: nullable 16-bit output; out_q/out_s: nullable FP8 output + per-row scale.
-template <int DTYPE, int VPT>
+template <int DTYPE, int VPT, bool FROM_PARTIALS = false>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(
     const typename Half16<DTYPE>::T* x /* may alias out */, typename Half16<DTYPE>::T* residual,
     const typename Half16<DTYPE>::T* __restrict__ weight, typename Half16<DTYPE>::T* out,
-    uint8_t* __restrict__ out_q, float* __restrict__ out_s, int H, float eps) {
+    uint8_t* __restrict__ out_q, float* __restrict__ out_s, int H, float eps, PartialSrc ps = PartialSrc{}) {
   using Hh = Half16<DTYPE>;
   using x8 = typename Hh::x8;
   __shared__ float red[4];
@@ -75,7 +143,9 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(
   for (int i = 0; i < VPT; ++i) {
     const int vi = threadIdx.x + 256 * i;
     if (vi < nv) {
-      const x8 xv = reinterpret_cast<const x8*>(x + row * H)[vi];
+      x8 xv;
+      if constexpr (FROM_PARTIALS) xv = gemm_row8<DTYPE>(ps, row, 8 * vi);
+      else xv = reinterpret_cast<const x8*>(x + row * H)[vi];
       wq[i] = reinterpret_cast<const x8*>(weight)[vi];
       if (residual) {
         const x8 rv = reinterpret_cast<const x8*>(residual + row * H)[vi];
@@ -209,6 +279,41 @@ __global__ __launch_bounds__(256) void rope_kernel(
 // Fused RoPE + KV-pool write: rotate q and k in place, then k (rotated) and v go to the
 // pool rows loc[t] in the same pass -- one launch instead of rope + set_kv_buffer, and k/v are not re-read.
 // One 64-thread wave per (token, head) over q heads, then k heads (which also carry v).
+// RoPE + KV write straight from the split-K partials of the qkv GEMM: column c of the [T, (Hq + 2 Hk) D] qkv row is
+// produced on the fly (gemm_elem), q goes (rotated) to q_out [T, Hq D], k (rotated) and v to the pool.
+template <int DTYPE, typename LocT>
+__global__ __launch_bounds__(256) void rope_kv_from_partials_kernel(
+    typename Half16<DTYPE>::T* __restrict__ q_out, typename Half16<DTYPE>::T* __restrict__ kb,
+    typename Half16<DTYPE>::T* __restrict__ vb, const int64_t* __restrict__ positions, const LocT* __restrict__ loc,
+    const float* __restrict__ cache, int64_t T, int Hq, int Hk, int D, int rot_dim, int64_t q_st, int64_t kb_sn,
+    int64_t kb_sh, int64_t vb_sn, int64_t vb_sh, int neox, PartialSrc ps) {
+  using Hh = Half16<DTYPE>;
+  const int lane = threadIdx.x & 63;
+  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t total = T * (int64_t)(Hq + Hk);
+  if (item >= total) return;
+  const int h = (int)(item % (Hq + Hk));
+  const int64_t t = item / (Hq + Hk);
+  const bool is_k = h >= Hq;
+  const int col0 = h * D;  // q heads then k heads are contiguous in the qkv row
+  const float* cs = cache + positions[t] * rot_dim;
+  const int half = rot_dim >> 1;
+  typename Hh::T* dst = is_k ? kb + (int64_t)loc[t] * kb_sn + (int64_t)(h - Hq) * kb_sh : q_out + t * q_st + (int64_t)h * D;
+  for (int p = lane; p < half; p += 64) {
+    const int i1 = neox ? p : 2 * p, i2 = neox ? p + half : 2 * p + 1;
+    const float c = cs[p], sn = cs[half + p];
+    const float x1 = Hh::to_f32(gemm_elem<DTYPE>(ps, t, col0 + i1)), x2 = Hh::to_f32(gemm_elem<DTYPE>(ps, t, col0 + i2));
+    dst[i1] = Hh::from_f32(x1 * c - x2 * sn);
+    dst[i2] = Hh::from_f32(x2 * c + x1 * sn);
+  }
+  for (int i = rot_dim + lane; i < D; i += 64) dst[i] = gemm_elem<DTYPE>(ps, t, col0 + i);  // pass-through dims
+  if (is_k) {
+    const int vcol0 = (Hq + Hk) * D + (h - Hq) * D;
+    typename Hh::T* vdst = vb + (int64_t)loc[t] * vb_sn + (int64_t)(h - Hq) * vb_sh;
+    for (int i = lane; i < D; i += 64) vdst[i] = gemm_elem<DTYPE>(ps, t, vcol0 + i);
+  }
+}
+
 template <int DTYPE, typename LocT>
 __global__ __launch_bounds__(256) void rope_kv_kernel(
     typename Half16<DTYPE>::T* __restrict__ q, typename Half16<DTYPE>::T* __restrict__ k,
@@ -264,6 +369,23 @@ int launch_rmsnorm(const void* x, void* residual, const void* weight, void* out,
   else RMS_LAUNCH(8);
 #undef RMS_LAUNCH
   return check_hip(hipGetLastError(), "rmsnorm launch");
+}
+
+template <int DTYPE>
+int launch_rmsnorm_partials(const PartialSrc& ps, void* residual, const void* weight, void* out_q, float* out_s, int64_t T,
+                            int64_t H, float eps, hipStream_t s) {
+  using T16 = typename Half16<DTYPE>::T;
+  const int nv = (int)(H >> 3);
+  const int vpt = (nv + 255) / 256;
+#define RMSP_LAUNCH(V)                                                                                              \
+  hipLaunchKernelGGL((rmsnorm_kernel<DTYPE, V, true>), dim3((unsigned)T), dim3(256), 0, s, (const T16*)nullptr,       \
+                     (T16*)residual, (const T16*)weight, (T16*)nullptr, (uint8_t*)out_q, out_s, (int)H, eps, ps)
+  if (vpt <= 1) RMSP_LAUNCH(1);
+  else if (vpt <= 2) RMSP_LAUNCH(2);
+  else if (vpt <= 4) RMSP_LAUNCH(4);
+  else RMSP_LAUNCH(8);
+#undef RMSP_LAUNCH
+  return check_hip(hipGetLastError(), "rmsnorm_from_partials launch");
 }
 
 template <int DTYPE>
@@ -411,4 +533,52 @@ extern "C" int sgl_mi355_rotary_embedding_set_kv(
   }
 #undef ROPEKV
   return check_hip(hipGetLastError(), "rotary_embedding_set_kv launch");
+}
+
+extern "C" int sgl_mi355_rmsnorm_quant_fp8_from_partials(
+    void* out_q, float* out_s, void* residual /* in/out, required */, const float* partials, int64_t num_slices,
+    const float* scales_a, const float* scales_b, const void* bias /* nullable */, const void* weight,
+    int64_t num_tokens, int64_t hidden, float eps, int dtype, void* stream) {
+  int rc = check_rows("rmsnorm_quant_fp8_from_partials", num_tokens, hidden, 16384, dtype);
+  if (rc) return rc;
+  if (num_tokens == 0) return 0;
+  SGLM_CHECK_ARG(out_q && out_s && residual && partials && scales_a && scales_b && weight && num_slices >= 1,
+                 "rmsnorm_quant_fp8_from_partials: null tensor pointer / bad slice count");
+  PartialSrc ps{partials, (int)num_slices, num_tokens * hidden, scales_a, scales_b, bias, (int)hidden};
+  return dtype == SGL_MI355_BF16
+             ? launch_rmsnorm_partials<SGL_MI355_BF16>(ps, residual, weight, out_q, out_s, num_tokens, hidden, eps, as_stream(stream))
+             : launch_rmsnorm_partials<SGL_MI355_FP16>(ps, residual, weight, out_q, out_s, num_tokens, hidden, eps, as_stream(stream));
+}
+
+extern "C" int sgl_mi355_rotary_embedding_set_kv_from_partials(
+    void* q_out, void* k_buffer, void* v_buffer, const int64_t* positions, const void* loc, int loc_is64,
+    const float* cos_sin_cache, const float* partials, int64_t num_slices, const float* scales_a, const float* scales_b,
+    const void* bias /* nullable */, int64_t num_tokens, int64_t num_q_heads, int64_t num_k_heads, int64_t head_size,
+    int64_t rot_dim, int64_t q_out_stride_t, int64_t kb_stride_n, int64_t kb_stride_h, int64_t vb_stride_n,
+    int64_t vb_stride_h, int is_neox, int dtype, void* stream) {
+  SGLM_CHECK_ARG(dtype == SGL_MI355_BF16 || dtype == SGL_MI355_FP16, "rotary_embedding_set_kv_from_partials: bad dtype %d", dtype);
+  SGLM_CHECK_ARG(num_tokens >= 0 && num_q_heads > 0 && num_k_heads > 0 && head_size > 0 && rot_dim > 0 && rot_dim <= head_size &&
+                     rot_dim % 2 == 0 && num_slices >= 1,
+                 "rotary_embedding_set_kv_from_partials: bad shape");
+  if (num_tokens == 0) return 0;
+  SGLM_CHECK_ARG(q_out && k_buffer && v_buffer && positions && loc && cos_sin_cache && partials && scales_a && scales_b,
+                 "rotary_embedding_set_kv_from_partials: null tensor pointer");
+  const int64_t N = (num_q_heads + 2 * num_k_heads) * head_size;
+  PartialSrc ps{partials, (int)num_slices, num_tokens * N, scales_a, scales_b, bias, (int)N};
+  const int64_t items = num_tokens * (num_q_heads + num_k_heads);
+  SGLM_CHECK_ARG(items < (1ll << 32), "rotary_embedding_set_kv_from_partials: too many rows");
+  const unsigned grid = (unsigned)((items + 3) / 4);
+  hipStream_t s = as_stream(stream);
+#define ROPEKVP(DT, TT, LT)                                                                                              \
+  hipLaunchKernelGGL((rope_kv_from_partials_kernel<DT, LT>), dim3(grid), dim3(256), 0, s, (TT*)q_out, (TT*)k_buffer,       \
+                     (TT*)v_buffer, positions, (const LT*)loc, cos_sin_cache, num_tokens, (int)num_q_heads,               \
+                     (int)num_k_heads, (int)head_size, (int)rot_dim, q_out_stride_t, kb_stride_n, kb_stride_h,            \
+                     vb_stride_n, vb_stride_h, is_neox, ps)
+  if (dtype == SGL_MI355_BF16) {
+    if (loc_is64) ROPEKVP(SGL_MI355_BF16, __bf16, int64_t); else ROPEKVP(SGL_MI355_BF16, __bf16, int32_t);
+  } else {
+    if (loc_is64) ROPEKVP(SGL_MI355_FP16, _Float16, int64_t); else ROPEKVP(SGL_MI355_FP16, _Float16, int32_t);
+  }
+#undef ROPEKVP
+  return check_hip(hipGetLastError(), "rotary_embedding_set_kv_from_partials launch");
 }

@@ -937,7 +937,8 @@ template <int OUT_DTYPE>
 __global__ void fp8_gemm_finalize_kernel(GemmArgs p, const float* slabs, int SK);
 
 template <int OUT_DTYPE, int MB, int PH, bool SLAB>
-int launch_wstream_ph(const GemmArgs& p, float* slabs, int SK, int phases_per_slice, int nc, int groups, hipStream_t s) {
+int launch_wstream_ph(const GemmArgs& p, float* slabs, int SK, int phases_per_slice, int nc, int groups, hipStream_t s,
+                      bool finalize = true) {
   auto kern = fp8_gemm_wstream_kernel<OUT_DTYPE, MB, PH, SLAB>;
   constexpr int lds = 2 * PH * 16 * MB * 128;
   static int attr_rc = check_hip(
@@ -947,7 +948,7 @@ int launch_wstream_ph(const GemmArgs& p, float* slabs, int SK, int phases_per_sl
   hipLaunchKernelGGL(kern, dim3((unsigned)groups, (unsigned)SK), dim3(64 * (nc + 1)), lds, s, p, slabs,
                      phases_per_slice);
   int rc = check_hip(hipGetLastError(), "fp8_gemm_wstream launch");
-  if (rc || !SLAB) return rc;
+  if (rc || !SLAB || !finalize) return rc;
   const int64_t total = (int64_t)p.M * p.N / 8;
   hipLaunchKernelGGL((fp8_gemm_finalize_kernel<OUT_DTYPE>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p,
                      (const float*)slabs, SK);
@@ -959,7 +960,10 @@ int launch_wstream_ph(const GemmArgs& p, float* slabs, int SK, int phases_per_sl
 // slices of whole phases so that ~256 workgroups exist, partials go to fp32 slabs and a finalize kernel applies
 // the reference epilogue (narrow N, long K: down_proj).
 template <int OUT_DTYPE, int MB>
-int launch_wstream(const GemmArgs& p, float* slabs, int64_t slab_floats, hipStream_t s, bool& used) {
+int launch_wstream(const GemmArgs& p, float* slabs, int64_t slab_floats, hipStream_t s, bool& used,
+                   int* partial_slices = nullptr) {
+  // partial_slices != nullptr: leave the raw fp32 partial sums in `slabs` (any slice count >= 1) and report the
+  // count; the epilogue runs inside the consumer kernel (sgl_mi355_*_from_partials).
   used = false;
   if ((p.K & 127) != 0 || (p.N & 7) != 0 || (p.a_sm & 15) != 0) return 0;
   if ((int64_t)p.N * p.b_sn >= ((int64_t)1 << 32)) return 0;  // per-lane weight offsets are 32-bit
@@ -992,10 +996,12 @@ int launch_wstream(const GemmArgs& p, float* slabs, int64_t slab_floats, hipStre
   }
   if (PH == 0) return 0;
   const int groups = (nblocks + nc - 1) / nc;
-  if (slabs != nullptr && (SK < 2 || slab_floats < (int64_t)SK * p.M * p.N)) return 0;
+  if (slabs != nullptr && ((SK < 2 && partial_slices == nullptr) || slab_floats < (int64_t)SK * p.M * p.N)) return 0;
+  if (partial_slices != nullptr) *partial_slices = SK;
+  const bool finalize = partial_slices == nullptr;
   used = true;
 #define WS_GO(PH_)                                                                                         \
-  return slabs ? launch_wstream_ph<OUT_DTYPE, MB, PH_, true>(p, slabs, SK, pps, nc, groups, s)              \
+  return slabs ? launch_wstream_ph<OUT_DTYPE, MB, PH_, true>(p, slabs, SK, pps, nc, groups, s, finalize)    \
                : launch_wstream_ph<OUT_DTYPE, MB, PH_, false>(p, nullptr, 1, pps, nc, groups, s)
   if constexpr (MB == 1) { if (PH == 32) WS_GO(32); }
   if constexpr (MB <= 2) { if (PH == 16) WS_GO(16); }
@@ -1054,14 +1060,24 @@ __global__ __launch_bounds__(256) void fp8_gemm_finalize_kernel(GemmArgs p, cons
   const int64_t total = (int64_t)p.M * p.N / 8;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int s = 0; s < SK; ++s) {
-      const float* src = slabs + (int64_t)s * p.M * p.N + i * 8;
-      const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+    const int64_t sstride = (int64_t)p.M * p.N;
+    for (int s0 = 0; s0 < SK; s0 += 4) {  // four slices in flight; sums in slice order
+      f32x4 a[4], b[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        v[j] += a[j];
-        v[4 + j] += b[j];
+      for (int u = 0; u < 4; ++u) {
+        const float* src = slabs + (int64_t)(s0 + u < SK ? s0 + u : SK - 1) * sstride + i * 8;
+        a[u] = *reinterpret_cast<const f32x4*>(src);
+        b[u] = *reinterpret_cast<const f32x4*>(src + 4);
       }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (s0 + u < SK) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[j] += a[u][j];
+            v[4 + j] += b[u][j];
+          }
+        }
     }
     const int64_t e = i * 8;
     const int m = (int)(e / p.N), n = (int)(e - (int64_t)m * p.N);
@@ -1069,8 +1085,9 @@ __global__ __launch_bounds__(256) void fp8_gemm_finalize_kernel(GemmArgs p, cons
     typename H::x8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float r = v[j] * p.sb[n + j] * sa;
-      if (p.bias) r += H::to_f32(reinterpret_cast<const T*>(p.bias)[n + j]);
+      // explicit roundings (no fma contraction): the fused *_from_partials consumers repeat exactly this
+      float r = __fmul_rn(__fmul_rn(v[j], p.sb[n + j]), sa);
+      if (p.bias) r = __fadd_rn(r, H::to_f32(reinterpret_cast<const T*>(p.bias)[n + j]));
       o[j] = H::from_f32(r);
     }
     *reinterpret_cast<typename H::x8*>(reinterpret_cast<T*>(p.out) + e) = o;
@@ -1414,4 +1431,59 @@ extern "C" int sgl_mi355_fp8_scaled_mm(
   hipStream_t s = as_stream(stream);
   return out_dtype == SGL_MI355_BF16 ? run_gemm<SGL_MI355_BF16>(p, workspace, workspace_floats, s)
                                      : run_gemm<SGL_MI355_FP16>(p, workspace, workspace_floats, s);
+}
+
+// Split-K partial sums only: workspace[slice][m][n] = sum over the slice's k of a[m][k] * b[n][k] (raw fp32, no
+// scales).  The epilogue (x w_scale, x x_scale, + bias, round) is applied by the consumer: sgl_mi355_fp8_scaled_mm_finalize
+// or one of the fused *_from_partials kernels, which sum the slices in the same order -- bit-identical to
+// sgl_mi355_fp8_scaled_mm on the split-K path.  UNSUPPORTED when the shape has no split-K path (caller falls back).
+extern "C" int sgl_mi355_fp8_scaled_mm_partials(const void* mat_a, const void* mat_b, float* workspace,
+                                                int64_t workspace_floats, int64_t M, int64_t N, int64_t K,
+                                                int64_t a_stride_m, int64_t b_stride_n, int32_t* num_slices,
+                                                void* stream) {
+  SGLM_CHECK_ARG(num_slices != nullptr && workspace != nullptr, "fp8_scaled_mm_partials: null workspace / num_slices");
+  SGLM_CHECK_ARG(M > 0 && N > 0 && K > 0 && N < (1ll << 31) && K < (1ll << 31), "fp8_scaled_mm_partials: bad shape");
+  SGLM_CHECK_ARG(a_stride_m % 16 == 0 && b_stride_n % 16 == 0 && a_stride_m >= K && b_stride_n >= K,
+                 "fp8_scaled_mm_partials: row strides must be >= K and multiples of 16 bytes");
+  SGLM_CHECK_ARG(mat_a && mat_b && reinterpret_cast<uintptr_t>(mat_a) % 16 == 0 && reinterpret_cast<uintptr_t>(mat_b) % 16 == 0,
+                 "fp8_scaled_mm_partials: operands must be 16-byte aligned");
+  *num_slices = 0;
+  if (M > 64) {
+    set_error("fp8_scaled_mm_partials: only the decode kernels (M <= 64) have a split-K form");
+    return SGL_MI355_ERR_UNSUPPORTED;
+  }
+  GemmArgs p{(const uint8_t*)mat_a, a_stride_m, (const uint8_t*)mat_b, b_stride_n, nullptr, nullptr, nullptr, nullptr,
+             (int)M, (int)N, (int)K};
+  hipStream_t s = as_stream(stream);
+  bool used = false;
+  int sk = 0;
+  int rc = M <= 16   ? launch_wstream<SGL_MI355_BF16, 1>(p, workspace, workspace_floats, s, used, &sk)
+           : M <= 32 ? launch_wstream<SGL_MI355_BF16, 2>(p, workspace, workspace_floats, s, used, &sk)
+                     : launch_wstream<SGL_MI355_BF16, 4>(p, workspace, workspace_floats, s, used, &sk);
+  if (rc) return rc;
+  if (!used) {
+    set_error("fp8_scaled_mm_partials: shape (M=%ld N=%ld K=%ld) is not on the split-K weight-streaming path", (long)M,
+              (long)N, (long)K);
+    return SGL_MI355_ERR_UNSUPPORTED;
+  }
+  *num_slices = sk;
+  return 0;
+}
+
+extern "C" int sgl_mi355_fp8_scaled_mm_finalize(const float* partials, int64_t num_slices, const float* scales_a,
+                                                const float* scales_b, const void* bias, void* out, int64_t M, int64_t N,
+                                                int out_dtype, void* stream) {
+  SGLM_CHECK_ARG(out_dtype == SGL_MI355_BF16 || out_dtype == SGL_MI355_FP16, "fp8_scaled_mm_finalize: bad out_dtype");
+  SGLM_CHECK_ARG(M > 0 && N > 0 && N % 8 == 0 && num_slices >= 1, "fp8_scaled_mm_finalize: bad shape");
+  SGLM_CHECK_ARG(partials && scales_a && scales_b && out, "fp8_scaled_mm_finalize: null tensor pointer");
+  GemmArgs p{nullptr, 0, nullptr, 0, scales_a, scales_b, bias, out, (int)M, (int)N, 0};
+  const int64_t total = M * N / 8;
+  hipStream_t s = as_stream(stream);
+  if (out_dtype == SGL_MI355_BF16)
+    hipLaunchKernelGGL((fp8_gemm_finalize_kernel<SGL_MI355_BF16>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p,
+                       partials, (int)num_slices);
+  else
+    hipLaunchKernelGGL((fp8_gemm_finalize_kernel<SGL_MI355_FP16>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p,
+                       partials, (int)num_slices);
+  return check_hip(hipGetLastError(), "fp8_gemm_finalize launch");
 }

@@ -46,6 +46,11 @@ class ColumnParallelLinear(LinearBase):
     def forward_prequantized(self, qinput, x_scale, out_dtype):
         return self.quant_method.apply_prequantized(self, qinput, x_scale, out_dtype, self.bias), None
 
+    def forward_prequantized_partials(self, qinput, x_scale, out_dtype):
+        """Split-K partials for a fused consumer (ops.GemmPartials) or None."""
+        fn = getattr(self.quant_method, "apply_prequantized_partials", None)
+        return fn(self, qinput, x_scale, out_dtype, self.bias) if fn is not None else None
+
 
 class MergedColumnParallelLinear(ColumnParallelLinear):
     """gate_up_proj: two column-parallel matrices stored as one."""
@@ -84,6 +89,14 @@ class RowParallelLinear(LinearBase):
         if self.reduce_results and get_tensor_model_parallel_world_size() > 1:
             out = tensor_model_parallel_all_reduce(out)
         return out, None
+
+    def forward_prequantized_partials(self, qinput, x_scale, out_dtype):
+        """Split-K partials for a fused consumer; only without tensor parallelism (the all-reduce needs the
+        completed output)."""
+        fn = getattr(self.quant_method, "apply_prequantized_partials", None)
+        if fn is None or get_tensor_model_parallel_world_size() > 1:
+            return None
+        return fn(self, qinput, x_scale, out_dtype, self.bias)
 
     def forward_prequantized(self, qinput, x_scale, out_dtype):
         bias_ = None if (get_tensor_model_parallel_rank() > 0) else self.bias

@@ -19,6 +19,8 @@ from __future__ import annotations
 
 from typing import Optional
 
+import os
+
 import torch
 
 from . import ops
@@ -53,10 +55,14 @@ class LlamaMLP(torch.nn.Module):
         x, _ = self.down_proj(x)
         return x
 
-    def forward_fp8(self, xq, xs, out_dtype):
+    def forward_fp8(self, xq, xs, out_dtype, defer: bool = False):
         """Same computation with the activations kept in FP8 between the kernels (fused producers)."""
         gate_up, _ = self.gate_up_proj.forward_prequantized(xq, xs, out_dtype)
         aq, a_s = ops.silu_and_mul_quant_fp8(gate_up)
+        if defer:  # leave the down_proj epilogue to the next norm (ops.GemmPartials)
+            part = self.down_proj.forward_prequantized_partials(aq, a_s, out_dtype)
+            if part is not None:
+                return part
         x, _ = self.down_proj.forward_prequantized(aq, a_s, out_dtype)
         return x
 
@@ -87,16 +93,35 @@ class LlamaAttention(torch.nn.Module):
         output, _ = self.o_proj(attn_output)
         return output
 
-    def forward_fp8(self, positions, xq, xs, forward_batch: ForwardBatch, out_dtype):
+    def forward_fp8(self, positions, xq, xs, forward_batch: ForwardBatch, out_dtype, defer: bool = False):
         """FP8-input variant: qkv GEMM on the pre-quantised activation, RoPE fused with the KV-pool write
-        (the backend is then called with save_kv_cache=False)."""
-        qkv, _ = self.qkv_proj.forward_prequantized(xq, xs, out_dtype)
-        q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
+        (the backend is then called with save_kv_cache=False).  defer=True additionally leaves GEMM epilogues to
+        the consumer kernel where a split-K form exists (ops.GemmPartials): qkv -> RoPE/KV write, o_proj -> the next
+        norm; the returned hidden state may then be a GemmPartials."""
         pool = forward_batch.token_to_kv_pool
-        ops.apply_rope_and_set_kv_buffer(positions, q, k, v, self.head_dim, self.rotary_emb.cos_sin_cache,
-                                         pool.get_key_buffer(self.attn.layer_id), pool.get_value_buffer(self.attn.layer_id),
-                                         forward_batch.out_cache_loc, self.rotary_emb.is_neox_style)
+        kb, vb = pool.get_key_buffer(self.attn.layer_id), pool.get_value_buffer(self.attn.layer_id)
+        part = self.qkv_proj.forward_prequantized_partials(xq, xs, out_dtype) if defer else None
+        if part is not None:  # qkv epilogue + RoPE + KV write in one kernel
+            q = ops.rope_set_kv_from_partials(part, positions, self.num_heads, self.num_kv_heads, self.head_dim,
+                                              self.rotary_emb.cos_sin_cache, kb, vb, forward_batch.out_cache_loc,
+                                              self.rotary_emb.is_neox_style)
+            k = v = None
+        else:
+            qkv, _ = self.qkv_proj.forward_prequantized(xq, xs, out_dtype)
+            q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
+            ops.apply_rope_and_set_kv_buffer(positions, q, k, v, self.head_dim, self.rotary_emb.cos_sin_cache, kb, vb,
+                                             forward_batch.out_cache_loc, self.rotary_emb.is_neox_style)
         attn_output = self.attn(q, k, v, forward_batch, save_kv_cache=False)
+        if defer:  # leave the o_proj epilogue to post_attention_layernorm
+            a2 = attn_output.view(-1, attn_output.shape[-1]).contiguous()  # apply_fp8_linear's own quant step
+            aq = torch.empty_like(a2, dtype=torch.float8_e4m3fn)
+            a_s = torch.empty((a2.shape[0], 1), dtype=torch.float32, device=a2.device)
+            ops.sgl_per_token_quant_fp8(a2, aq, a_s)
+            part = self.o_proj.forward_prequantized_partials(aq, a_s, out_dtype)
+            if part is not None:
+                return part
+            output, _ = self.o_proj.forward_prequantized(aq, a_s, out_dtype)
+            return output
         output, _ = self.o_proj(attn_output)
         return output
 
@@ -120,21 +145,25 @@ class LlamaDecoderLayer(torch.nn.Module):
         hidden_states = self.mlp(hidden_states)
         return hidden_states, residual
 
-    def forward_fp8(self, positions, hidden_states, forward_batch, residual):
+    def forward_fp8(self, positions, hidden_states, forward_batch, residual, defer: bool = False):
         """Fused-producer variant for the FP8 config: (add +) RMSNorm emits the per-token FP8 activation
-        directly, so no standalone quant kernel runs before qkv / gate_up / down."""
-        dt = hidden_states.dtype
+        directly, so no standalone quant kernel runs before qkv / gate_up / down.  `hidden_states` may be an
+        ops.GemmPartials left by the previous layer's down_proj (defer=True)."""
+        def norm_quant(norm, h, res):
+            if isinstance(h, ops.GemmPartials):  # the producer GEMM left its epilogue to this kernel
+                return ops.rmsnorm_quant_fp8_from_partials(h, res, norm.weight.data, norm.variance_epsilon)
+            q, s_, _ = ops.rmsnorm_quant_fp8(h, norm.weight.data, norm.variance_epsilon, residual=res)
+            return q, s_
+
+        dt = residual.dtype if residual is not None else hidden_states.dtype
         if residual is None:
             residual = hidden_states.clone()
-            xq, xs, _ = ops.rmsnorm_quant_fp8(hidden_states, self.input_layernorm.weight.data,
-                                              self.input_layernorm.variance_epsilon)
+            xq, xs = norm_quant(self.input_layernorm, hidden_states, None)
         else:
-            xq, xs, _ = ops.rmsnorm_quant_fp8(hidden_states, self.input_layernorm.weight.data,
-                                              self.input_layernorm.variance_epsilon, residual=residual)
-        hidden_states = self.self_attn.forward_fp8(positions, xq, xs, forward_batch, dt)
-        xq, xs, _ = ops.rmsnorm_quant_fp8(hidden_states, self.post_attention_layernorm.weight.data,
-                                          self.post_attention_layernorm.variance_epsilon, residual=residual)
-        hidden_states = self.mlp.forward_fp8(xq, xs, dt)
+            xq, xs = norm_quant(self.input_layernorm, hidden_states, residual)
+        hidden_states = self.self_attn.forward_fp8(positions, xq, xs, forward_batch, dt, defer)
+        xq, xs = norm_quant(self.post_attention_layernorm, hidden_states, residual)
+        hidden_states = self.mlp.forward_fp8(xq, xs, dt, defer)
         return hidden_states, residual
 
 
@@ -144,6 +173,7 @@ class LlamaForCausalLM(torch.nn.Module):
         super().__init__()
         self.cfg, self.dtype, self.device_str = cfg, dtype, device
         self.fuse_quant = fuse_quant and quantization == "w8a8_fp8"
+        self.defer_epilogues = not os.environ.get("SGL_MI355_NO_DEFER")  # GEMM epilogues inside the consumer kernels
         self.quant_config = None
         if quantization == "w8a8_fp8":
             self.quant_config = W8A8Fp8Config(is_checkpoint_fp8_serialized=False)
@@ -231,11 +261,14 @@ class LlamaForCausalLM(torch.nn.Module):
         hidden_states = self.embed_tokens[input_ids]
         residual = None
         fused = self.fuse_quant and forward_batch.forward_mode.is_decode()
+        defer = fused and self.defer_epilogues and get_tensor_model_parallel_world_size() == 1
         for layer in self.layers:
             if fused:
-                hidden_states, residual = layer.forward_fp8(positions, hidden_states, forward_batch, residual)
+                hidden_states, residual = layer.forward_fp8(positions, hidden_states, forward_batch, residual, defer)
             else:
                 hidden_states, residual = layer(positions, hidden_states, forward_batch, residual)
+        if isinstance(hidden_states, ops.GemmPartials):
+            hidden_states = hidden_states.finalize()
         hidden_states, _ = self.norm(hidden_states, residual)
         if not self.with_lm_head:
             return hidden_states

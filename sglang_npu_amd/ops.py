@@ -344,6 +344,80 @@ def fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None) -> tor
     return out
 
 
+class GemmPartials:
+    """An fp8_scaled_mm whose epilogue has not run yet: raw fp32 split-K partial sums in the shared workspace
+    (sgl_mi355_fp8_scaled_mm_partials).  Must be consumed -- finalize() or one of the *_from_partials ops -- before the
+    next decode GEMM on this device, which reuses the workspace."""
+    __slots__ = ("ws", "num_slices", "x_scale", "w_scale", "bias", "M", "N", "out_dtype")
+
+    def __init__(self, ws, num_slices, x_scale, w_scale, bias, M, N, out_dtype):
+        self.ws, self.num_slices, self.x_scale, self.w_scale, self.bias = ws, num_slices, x_scale, w_scale, bias
+        self.M, self.N, self.out_dtype = M, N, out_dtype
+
+    def finalize(self) -> torch.Tensor:
+        out = torch.empty((self.M, self.N), dtype=self.out_dtype, device=self.ws.device)
+        _lib.check(_lib.lib().sgl_mi355_fp8_scaled_mm_finalize(
+            _ptr(self.ws), _I64(self.num_slices), _ptr(self.x_scale), _ptr(self.w_scale), _ptr(self.bias), _ptr(out),
+            _I64(self.M), _I64(self.N), _I(0 if self.out_dtype == torch.bfloat16 else 1), _stream(self.ws)))
+        return out
+
+
+def fp8_scaled_mm_partials(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None) -> Optional[GemmPartials]:
+    """Split-K half of fp8_scaled_mm (same arguments); None when the shape has no split-K decode path."""
+    _need_gpu(mat_a, mat_b, scales_a, scales_b, bias)
+    M, K = mat_a.shape
+    N = mat_b.size(1)
+    if not (0 < M <= 64) or mat_a.stride(1) != 1 or mat_b.stride(0) != 1 or mat_b.size(0) != K:
+        return None
+    need = 32 * M * N
+    ws = _fp8_workspace.get(mat_a.device)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 7 * 64 * 28672), dtype=torch.float32, device=mat_a.device)
+        _fp8_workspace[mat_a.device] = ws
+    sk = ctypes.c_int32(0)
+    rc = _lib.lib().sgl_mi355_fp8_scaled_mm_partials(
+        _ptr(mat_a), _ptr(mat_b), _ptr(ws), _I64(ws.numel()), _I64(M), _I64(N), _I64(K),
+        _I64(mat_a.stride(0) if M > 1 else K), _I64(mat_b.stride(1) if N > 1 else K), ctypes.byref(sk), _stream(mat_a))
+    if rc == 2:  # SGL_MI355_ERR_UNSUPPORTED
+        return None
+    _lib.check(rc)
+    return GemmPartials(ws, sk.value, scales_a.reshape(-1), scales_b.reshape(-1), bias, M, N, out_dtype)
+
+
+def rmsnorm_quant_fp8_from_partials(part: GemmPartials, residual: torch.Tensor, weight: torch.Tensor, eps: float):
+    """fused_add_rmsnorm + per-token FP8 quant of (GEMM output + residual), the GEMM epilogue included.
+    Returns (q [M,H] e4m3fn, scale [M,1] f32); `residual` is updated in place (layernorm.py:82-85)."""
+    _need_gpu(residual, weight)
+    if residual.shape != (part.M, part.N) or not residual.is_contiguous() or residual.dtype != part.out_dtype:
+        raise RuntimeError("rmsnorm_quant_fp8_from_partials: residual must be a contiguous [M,N] tensor in the GEMM's out dtype")
+    q = torch.empty((part.M, part.N), dtype=torch.float8_e4m3fn, device=residual.device)
+    s = torch.empty((part.M, 1), dtype=torch.float32, device=residual.device)
+    _lib.check(_lib.lib().sgl_mi355_rmsnorm_quant_fp8_from_partials(
+        _ptr(q), _ptr(s), _ptr(residual), _ptr(part.ws), _I64(part.num_slices), _ptr(part.x_scale), _ptr(part.w_scale),
+        _ptr(part.bias), _ptr(weight), _I64(part.M), _I64(part.N), _F(eps), _I(_dtype_code(residual)), _stream(residual)))
+    return q, s
+
+
+def rope_set_kv_from_partials(part: GemmPartials, positions, num_q_heads, num_k_heads, head_size, cos_sin_cache,
+                              k_buffer, v_buffer, loc, is_neox=True) -> torch.Tensor:
+    """qkv GEMM epilogue + RoPE + KV-pool write; returns the rotated q [M, Hq*D]."""
+    _need_gpu(positions, cos_sin_cache, k_buffer, v_buffer, loc)
+    if cos_sin_cache.dtype != torch.float32 or not cos_sin_cache.is_contiguous():
+        raise RuntimeError("cos_sin_cache should be float32")
+    if part.N != (num_q_heads + 2 * num_k_heads) * head_size:
+        raise RuntimeError("rope_set_kv_from_partials: the GEMM is not a [T, (Hq + 2 Hk) D] qkv projection")
+    if positions.dtype != torch.int64:
+        positions = positions.to(torch.int64)
+    q = torch.empty((part.M, num_q_heads * head_size), dtype=part.out_dtype, device=k_buffer.device)
+    _lib.check(_lib.lib().sgl_mi355_rotary_embedding_set_kv_from_partials(
+        _ptr(q), _ptr(k_buffer), _ptr(v_buffer), _ptr(positions), _ptr(loc), _I(_is64(loc, "loc")), _ptr(cos_sin_cache),
+        _ptr(part.ws), _I64(part.num_slices), _ptr(part.x_scale), _ptr(part.w_scale), _ptr(part.bias), _I64(part.M),
+        _I64(num_q_heads), _I64(num_k_heads), _I64(head_size), _I64(cos_sin_cache.size(1)), _I64(q.stride(0)),
+        _I64(k_buffer.stride(0)), _I64(k_buffer.stride(1)), _I64(v_buffer.stride(0)), _I64(v_buffer.stride(1)),
+        _I(1 if is_neox else 0), _I(_dtype_code(q)), _stream(q)))
+    return q
+
+
 # --------------------------------------------------------------------------- AWQ INT4
 def awq_dequantize(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tensor) -> torch.Tensor:
     """sgl_kernel.awq_dequantize(qweight, scales, qzeros) -- sgl-kernel/python/sgl_kernel/gemm.py:7-12,

@@ -181,6 +181,14 @@ class W8A8Fp8LinearMethod(LinearMethodBase):
         return out.view(*qinput.shape[:-1], layer.weight.shape[1])
 
 
+    def apply_prequantized_partials(self, layer, qinput: torch.Tensor, x_scale: torch.Tensor, out_dtype: torch.dtype,
+                                    bias: Optional[torch.Tensor] = None):
+        """apply_prequantized without the epilogue: ops.GemmPartials for a fused consumer, or None when the shape has
+        no split-K decode path (the caller then uses apply_prequantized)."""
+        q2 = qinput.view(-1, qinput.shape[-1])
+        return ops.fp8_scaled_mm_partials(q2, layer.weight, x_scale, layer.weight_scale, out_dtype, bias)
+
+
 # ----------------------------------------------------------------------------- AWQ INT4
 class AWQConfig(QuantizationConfig):
     """awq.py:75-150."""

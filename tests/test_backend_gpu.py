@@ -260,3 +260,76 @@ def test_fused_fp8_layer_path_equals_unfused():
         outs.append((net(ids, seq - 1, fb), pool.k_buffer[1].clone(), pool.v_buffer[0].clone()))
     assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2]), "KV pool contents must match"
     assert torch.equal(outs[0][0], outs[1][0]), "fused and unfused paths must agree bit for bit"
+
+
+def test_deferred_gemm_epilogues_are_bit_identical():
+    """defer=True leaves the qkv / o_proj / down_proj epilogues to the consumer kernels (RoPE + KV write, add + RMSNorm +
+    quant) on split-K partials.  Same slice order, same roundings -> logits and pool contents identical to the
+    fused-producer path without deferral, bit for bit."""
+    cfg = ModelConfig(8, 2, 128, 1024, 2048, 3, 512, 256)  # K = 1024 / 2048: on the split-K weight-streaming path
+    outs = []
+    for defer in (False, True):
+        net = M.LlamaForCausalLM(cfg, "w8a8_fp8", torch.bfloat16, DEV).load_dummy_weights()
+        net.defer_epilogues = defer
+        B = 5
+        r2t = ReqToTokenPool(B, 256, DEV)
+        pool = MHATokenToKVPool(B * 256 + 1, 1, torch.bfloat16, 2, 128, 3, DEV)
+        g = torch.Generator(device=DEV).manual_seed(0)
+        for l in range(3):
+            pool.k_buffer[l].normal_(generator=g)
+            pool.v_buffer[l].normal_(generator=g)
+        r2t.req_to_token.copy_((torch.randperm(B * 256, device=DEV, generator=g) + 1).view(B, 256).to(torch.int32))
+        runner = ModelRunnerLike(cfg, r2t, pool, DEV, 0, 1, ServerArgs())
+        backend = install_attention_backend(runner)
+        seq = torch.tensor([5, 17, 64, 100, 255], device=DEV)
+        ids = torch.tensor([1, 2, 3, 4, 5], device=DEV)
+        rows = torch.arange(B, device=DEV)
+        fb = ForwardBatch(ForwardMode.DECODE, B, ids, rows, seq, r2t.req_to_token[rows, seq - 1].long(), int(seq.sum()),
+                          seq.cpu(), seq - 1, req_to_token_pool=r2t, token_to_kv_pool=pool, attn_backend=backend)
+        backend.init_forward_metadata(fb)
+        outs.append((net(ids, seq - 1, fb), [pool.k_buffer[l].clone() for l in range(3)],
+                     [pool.v_buffer[l].clone() for l in range(3)]))
+    assert torch.isfinite(outs[0][0].float()).all()
+    assert torch.equal(outs[0][0], outs[1][0]), "logits differ"
+    for l in range(3):
+        assert torch.equal(outs[0][1][l], outs[1][1][l]) and torch.equal(outs[0][2][l], outs[1][2][l]), f"pool layer {l}"
+
+
+@pytest.mark.parametrize("M", [1, 16, 33, 64])
+@pytest.mark.parametrize("with_bias", [False, True])
+def test_from_partials_ops_equal_unfused_sequence(M, with_bias):
+    """sgl_mi355_fp8_scaled_mm_partials + {finalize, rmsnorm_quant_fp8_from_partials, rope_set_kv_from_partials}
+    against fp8_scaled_mm followed by the unfused op: bit-identical."""
+    from sglang_npu_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(M + int(with_bias))
+    K, H = 2048, 1024
+    a = ((torch.rand(M, K, device=DEV, generator=g) - 0.5) * 8).to(torch.float8_e4m3fn)
+    w = ((torch.rand(H, K, device=DEV, generator=g) - 0.5) * 8).to(torch.float8_e4m3fn)
+    sa = torch.rand(M, 1, device=DEV, generator=g) * 1e-2 + 1e-3
+    sb = torch.rand(H, 1, device=DEV, generator=g) * 1e-2 + 1e-3
+    bias = torch.randn(H, device=DEV, generator=g).bfloat16() if with_bias else None
+    full = ops.fp8_scaled_mm(a, w.t(), sa, sb, torch.bfloat16, bias)
+    part = ops.fp8_scaled_mm_partials(a, w.t(), sa, sb, torch.bfloat16, bias)
+    assert part is not None and part.num_slices >= 1
+    assert torch.equal(part.finalize(), full)
+    # add + rmsnorm + quant
+    wn = (torch.rand(H, device=DEV, generator=g) + 0.5).bfloat16()
+    res0 = torch.randn(M, H, device=DEV, generator=g).bfloat16()
+    r1, r2 = res0.clone(), res0.clone()
+    q_ref, s_ref, _ = ops.rmsnorm_quant_fp8(full.clone(), wn, 1e-5, residual=r1)
+    part = ops.fp8_scaled_mm_partials(a, w.t(), sa, sb, torch.bfloat16, bias)
+    q, s = ops.rmsnorm_quant_fp8_from_partials(part, r2, wn, 1e-5)
+    assert torch.equal(q.view(torch.uint8), q_ref.view(torch.uint8)) and torch.equal(s, s_ref) and torch.equal(r1, r2)
+    # RoPE + KV write: treat the H = 1024 outputs as qkv of Hq = 4, Hk = 2, D = 128
+    Hq, Hk, D = 4, 2, 128
+    pos = torch.randint(0, 500, (M,), device=DEV, generator=g)
+    cache = torch.randn(512, D, device=DEV, generator=g)
+    loc = (torch.randperm(200, device=DEV, generator=g)[:M] + 1).long()
+    kb1, vb1 = torch.zeros(201, Hk, D, dtype=torch.bfloat16, device=DEV), torch.zeros(201, Hk, D, dtype=torch.bfloat16, device=DEV)
+    kb2, vb2 = torch.zeros_like(kb1), torch.zeros_like(vb1)
+    qkv = full.clone()
+    q1, k1, v1 = qkv.split([Hq * D, Hk * D, Hk * D], dim=-1)
+    ops.apply_rope_and_set_kv_buffer(pos, q1, k1, v1, D, cache, kb1, vb1, loc, True)
+    part = ops.fp8_scaled_mm_partials(a, w.t(), sa, sb, torch.bfloat16, bias)
+    q2 = ops.rope_set_kv_from_partials(part, pos, Hq, Hk, D, cache, kb2, vb2, loc, True)
+    assert torch.equal(q2, q1) and torch.equal(kb1, kb2) and torch.equal(vb1, vb2)
