@@ -1139,7 +1139,13 @@ constexpr int kRegion = kTM * 32 + 16;      // one 32-B k-chunk column of the ti
 constexpr int kOperand = 4 * kRegion + 48;  // 16512 B, keeps 16-B alignment
 constexpr int kStageBytes = 2 * kOperand;   // A + B
 
-template <int OUT_DTYPE>
+// SCALED: one v_mfma_scale_f32_16x16x128_f8f6f4 (e4m3 x e4m3, E8M0 block scales fixed at 2^0) per 128-k step instead of
+// four v_mfma_f32_16x16x32_fp8_fp8.  Same products and fp32 accumulation, but the block-scaled instruction runs at twice
+// the FP8 rate on gfx950 (MI355X_MICROARCH.md: non-scaled FP8 MFMA = the BF16 rate, 2.5 PFLOP/s; scaled = 5 PFLOP/s).
+// The lane's 32 contiguous k-bytes of the fragment-major LDS image are exactly one operand of it.
+typedef int v8i32_t __attribute__((ext_vector_type(8)));
+
+template <int OUT_DTYPE, bool SCALED>
 __global__ __launch_bounds__(256) void fp8_gemm_tiled_kernel(GemmArgs p) {
   using H = Half16<OUT_DTYPE>;
   using T = typename H::T;
@@ -1234,13 +1240,23 @@ __global__ __launch_bounds__(256) void fp8_gemm_tiled_kernel(GemmArgs p) {
       bf[i].v[0] = *reinterpret_cast<const uint4*>(pb);
       bf[i].v[1] = *reinterpret_cast<const uint4*>(pb + 16);
     }
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
+    if constexpr (SCALED) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(af[i].l[ks], bf[j].l[ks], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+              __builtin_bit_cast(v8i32_t, af[i]), __builtin_bit_cast(v8i32_t, bf[j]), acc[i][j], 0 /* A: e4m3 */,
+              0 /* B: e4m3 */, 0, 0x7F7F7F7F /* scale 2^0 */, 0, 0x7F7F7F7F);
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(af[i].l[ks], bf[j].l[ks], acc[i][j], 0, 0, 0);
+    }
     if (kt + 1 < nk) lstore(st ^ 1, (kt + 1) * kTK);
     __syncthreads();
   }
@@ -1280,6 +1296,138 @@ __global__ __launch_bounds__(256) void fp8_gemm_tiled_kernel(GemmArgs p) {
     const int ml = c >> 3, nl = (c & 7) * 8;
     const int m = m0 + wm * 64 + ml, n = n0 + wn * 64 + nl;
     if (m < p.M && n < p.N)  // N % 8 == 0, so a chunk is all-in or all-out
+      *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.out) + (int64_t)m * p.N + n) =
+          *reinterpret_cast<const uint4*>(ep + ml * 72 + nl);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// tiled v2 (K % 128 == 0): the same 128x128x128 tile and 2x2 waves, but
+//   * operands go global -> LDS by LDS-DMA (no VGPR staging, no ds_write), NSTAGE stages, prefetch distance NSTAGE-1;
+//   * the LDS image is [row][128 B] with the 16-B chunk index XOR-swizzled by (row >> 1) & 7 -- a DMA instruction
+//     lands 8 rows x 128 B from 8 coalesced row segments (swizzle on the source side), and the fragment
+//     ds_read_b128 of 16 rows hits 16 distinct bank groups;
+//   * one block-scaled v_mfma_scale_f32_16x16x128_f8f6f4 (scales 2^0) per fragment pair and k-step.
+template <int OUT_DTYPE, int NSTAGE>
+__global__ __launch_bounds__(256) void fp8_gemm_tiled2_kernel(GemmArgs p) {
+  using H = Half16<OUT_DTYPE>;
+  using T = typename H::T;
+  constexpr int OPB = kTM * 128;        // one operand tile: 128 rows x 128 B
+  constexpr int STAGE = 2 * OPB;        // A + B
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r16 = lane & 15, g = lane >> 4;
+
+  const int tiles_m = (p.M + kTM - 1) / kTM, tiles_n = (p.N + kTN - 1) / kTN;
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tm = bid % tiles_m, tn = bid / tiles_m;
+  const int m0 = tm * kTM, n0 = tn * kTN;
+
+  // DMA units: operand tile = 16 units of 8 rows; wave w moves units 4w .. 4w+3 of A and of B
+  const uint8_t* a_src[4];
+  const uint8_t* b_src[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int row = (4 * wave + u) * 8 + (lane >> 3);  // tile-local row
+    const int j = (lane & 7) ^ ((row >> 1) & 7);
+    int m = m0 + row, n = n0 + row;
+    m = m < p.M ? m : p.M - 1;  // rows past the edge re-read a valid row; never stored
+    n = n < p.N ? n : p.N - 1;
+    a_src[u] = p.a + (int64_t)m * p.a_sm + 16 * j;
+    b_src[u] = p.b + (int64_t)n * p.b_sn + 16 * j;
+  }
+  const uint32_t smem_base = lds_addr_of(smem);
+  auto dma_stage = [&](int stage, int kt) __attribute__((always_inline)) {
+    const uint32_t dst = smem_base + stage * STAGE + (4 * wave) * 1024;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) lds_dma16(a_src[u] + (int64_t)kt * 128, dst + u * 1024);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) lds_dma16(b_src[u] + (int64_t)kt * 128, dst + OPB + u * 1024);
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment byte offsets inside an operand tile: row (64 w + 16 i + r16), chunks 2g and 2g+1
+  const int sw = (r16 >> 1) & 7;  // (row >> 1) & 7 with row = 16 x + r16
+  const uint32_t c0 = 16 * ((2 * g) ^ sw), c1 = 16 * ((2 * g + 1) ^ sw);
+  const uint32_t a_row = (wm * 64 + r16) * 128, b_row = (wn * 64 + r16) * 128;
+
+  const int nk = p.K >> 7;
+#pragma unroll
+  for (int st = 0; st < NSTAGE - 1; ++st)
+    if (st < nk) dma_stage(st, st);
+  for (int kt = 0; kt < nk; ++kt) {
+    // this wave's DMAs of stage kt have landed when at most the younger stages' (8 each) are outstanding
+    const int younger = (nk - 1 - kt) < (NSTAGE - 2) ? (nk - 1 - kt) : (NSTAGE - 2);
+    if (younger >= 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // NSTAGE == 3
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // everyone's DMAs of stage kt landed; everyone finished reading the stage refilled below
+    if (kt + NSTAGE - 1 < nk) dma_stage((kt + NSTAGE - 1) % NSTAGE, kt + NSTAGE - 1);
+    const char* sa_ = smem + (kt % NSTAGE) * STAGE;
+    const char* sb_ = sa_ + OPB;
+    Frag32 af[4], bf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      af[i].v[0] = *reinterpret_cast<const uint4*>(sa_ + a_row + i * 2048 + c0);
+      af[i].v[1] = *reinterpret_cast<const uint4*>(sa_ + a_row + i * 2048 + c1);
+      bf[i].v[0] = *reinterpret_cast<const uint4*>(sb_ + b_row + i * 2048 + c0);
+      bf[i].v[1] = *reinterpret_cast<const uint4*>(sb_ + b_row + i * 2048 + c1);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+            __builtin_bit_cast(v8i32_t, af[i]), __builtin_bit_cast(v8i32_t, bf[j]), acc[i][j], 0, 0, 0, 0x7F7F7F7F, 0,
+            0x7F7F7F7F);
+  }
+  __syncthreads();  // all stages dead: the epilogue reuses the memory
+
+  // ---- epilogue (as fp8_gemm_tiled_kernel)
+  T* ep = reinterpret_cast<T*>(smem) + wave * (64 * 72);
+  float sbv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + wn * 64 + 16 * j + r16;
+    sbv[j] = p.sb[n < p.N ? n : p.N - 1];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ml = 16 * i + 4 * g + r;
+      const int m = m0 + wm * 64 + ml;
+      const float sa = p.sa[m < p.M ? m : p.M - 1];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int nl = 16 * j + r16;
+        float v = acc[i][j][r] * sbv[j] * sa;
+        if (p.bias) {
+          const int n = n0 + wn * 64 + nl;
+          v += H::to_f32(reinterpret_cast<const T*>(p.bias)[n < p.N ? n : p.N - 1]);
+        }
+        ep[ml * 72 + nl] = H::from_f32(v);
+      }
+    }
+  wait_lgkmcnt0();
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int c = lane + 64 * it;
+    const int ml = c >> 3, nl = (c & 7) * 8;
+    const int m = m0 + wm * 64 + ml, n = n0 + wn * 64 + nl;
+    if (m < p.M && n < p.N)
       *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.out) + (int64_t)m * p.N + n) =
           *reinterpret_cast<const uint4*>(ep + ml * 72 + nl);
   }
@@ -1372,11 +1520,37 @@ int run_gemm(const GemmArgs& p, float* workspace, int64_t workspace_floats, hipS
     if (p.M <= 32) return dispatch_skinny<OUT_DTYPE, 2>(p, s);
     return dispatch_skinny<OUT_DTYPE, 4>(p, s);
   }
-  auto kern = fp8_gemm_tiled_kernel<OUT_DTYPE>;
+  // v2 (LDS-DMA + block-scaled MFMA) whenever K has no tail.  Two stages leave room for two workgroups per CU, which
+  // hide each other's barriers when there are more tiles than CUs (M = 4096: 1.51-1.71 PFLOP/s vs 1.18-1.49 with three
+  // stages); with at most one tile per CU the deeper prefetch of three stages wins (M = 512: 26-28 us vs 32).
+  static const int v2_env = [] { const char* e = getenv("SGL_MI355_TILED_V2"); return e ? atoi(e) : -1; }();  // 0 off, 2 / 3 force
+  const unsigned grid2 = (unsigned)(((p.M + kTM - 1) / kTM) * ((p.N + kTN - 1) / kTN));
+  const int v2 = v2_env >= 0 ? v2_env : (grid2 <= 256 ? 3 : 2);
+  if (v2 && (p.K & 127) == 0) {
+    if (v2 == 2) {
+      auto k2 = fp8_gemm_tiled2_kernel<OUT_DTYPE, 2>;
+      static int a2 = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                    2 * 2 * kTM * 128), "hipFuncSetAttribute");
+      if (a2) return a2;
+      hipLaunchKernelGGL(k2, dim3(grid2), dim3(256), 2 * 2 * kTM * 128, s, p);
+    } else {
+      auto k3 = fp8_gemm_tiled2_kernel<OUT_DTYPE, 3>;
+      static int a3 = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(k3), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                    3 * 2 * kTM * 128), "hipFuncSetAttribute");
+      if (a3) return a3;
+      hipLaunchKernelGGL(k3, dim3(grid2), dim3(256), 3 * 2 * kTM * 128, s, p);
+    }
+    return check_hip(hipGetLastError(), "fp8_gemm_tiled2 launch");
+  }
+  static const bool scaled = [] { const char* e = getenv("SGL_MI355_TILED_SCALED"); return e ? atoi(e) != 0 : true; }();  // A-B aid
+  auto kern = scaled ? fp8_gemm_tiled_kernel<OUT_DTYPE, true> : fp8_gemm_tiled_kernel<OUT_DTYPE, false>;
   constexpr int lds = 2 * kStageBytes;
-  static int attr_rc = check_hip(
-      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
-      "hipFuncSetAttribute");
+  static int attr_rc = [] {
+    int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(fp8_gemm_tiled_kernel<OUT_DTYPE, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds), "hipFuncSetAttribute");
+    return rc ? rc : check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(fp8_gemm_tiled_kernel<OUT_DTYPE, false>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds), "hipFuncSetAttribute");
+  }();
   if (attr_rc) return attr_rc;
   const unsigned grid = (unsigned)(((p.M + kTM - 1) / kTM) * ((p.N + kTN - 1) / kTN));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, p);
