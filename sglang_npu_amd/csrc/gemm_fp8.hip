@@ -1308,12 +1308,16 @@ __global__ __launch_bounds__(256) void fp8_gemm_tiled_kernel(GemmArgs p) {
 //     lands 8 rows x 128 B from 8 coalesced row segments (swizzle on the source side), and the fragment
 //     ds_read_b128 of 16 rows hits 16 distinct bank groups;
 //   * one block-scaled v_mfma_scale_f32_16x16x128_f8f6f4 (scales 2^0) per fragment pair and k-step.
-template <int OUT_DTYPE, int NSTAGE>
+// RI = 16-row fragments per wave along M: 4 -> 128x128 block tile (64x64 per wave), 8 -> 256x128 (128x64 per wave: 0.75x
+// the LDS fragment reads per flop; for shapes with several tiles per CU).
+template <int OUT_DTYPE, int NSTAGE, int RI>
 __global__ __launch_bounds__(256) void fp8_gemm_tiled2_kernel(GemmArgs p) {
   using H = Half16<OUT_DTYPE>;
   using T = typename H::T;
-  constexpr int OPB = kTM * 128;        // one operand tile: 128 rows x 128 B
-  constexpr int STAGE = 2 * OPB;        // A + B
+  constexpr int TMB = 32 * RI;          // block rows
+  constexpr int OPA = TMB * 128;        // A tile: TMB rows x 128 B
+  constexpr int OPB = kTN * 128;        // B tile: 128 rows x 128 B
+  constexpr int STAGE = OPA + OPB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1321,7 +1325,7 @@ __global__ __launch_bounds__(256) void fp8_gemm_tiled2_kernel(GemmArgs p) {
   const int wm = wave >> 1, wn = wave & 1;
   const int r16 = lane & 15, g = lane >> 4;
 
-  const int tiles_m = (p.M + kTM - 1) / kTM, tiles_n = (p.N + kTN - 1) / kTN;
+  const int tiles_m = (p.M + TMB - 1) / TMB, tiles_n = (p.N + kTN - 1) / kTN;
   const int nwg = tiles_m * tiles_n;
   int bid = blockIdx.x;
   {
@@ -1329,64 +1333,73 @@ __global__ __launch_bounds__(256) void fp8_gemm_tiled2_kernel(GemmArgs p) {
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
   const int tm = bid % tiles_m, tn = bid / tiles_m;
-  const int m0 = tm * kTM, n0 = tn * kTN;
+  const int m0 = tm * TMB, n0 = tn * kTN;
 
-  // DMA units: operand tile = 16 units of 8 rows; wave w moves units 4w .. 4w+3 of A and of B
-  const uint8_t* a_src[4];
+  // DMA units of 8 rows: wave w moves units RI*w .. RI*w+RI-1 of A and 4w .. 4w+3 of B
+  const uint8_t* a_src[RI];
   const uint8_t* b_src[4];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int row = (4 * wave + u) * 8 + (lane >> 3);  // tile-local row
+  for (int u = 0; u < RI; ++u) {
+    const int row = (RI * wave + u) * 8 + (lane >> 3);  // tile-local row
     const int j = (lane & 7) ^ ((row >> 1) & 7);
-    int m = m0 + row, n = n0 + row;
+    int m = m0 + row;
     m = m < p.M ? m : p.M - 1;  // rows past the edge re-read a valid row; never stored
-    n = n < p.N ? n : p.N - 1;
     a_src[u] = p.a + (int64_t)m * p.a_sm + 16 * j;
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int row = (4 * wave + u) * 8 + (lane >> 3);
+    const int j = (lane & 7) ^ ((row >> 1) & 7);
+    int n = n0 + row;
+    n = n < p.N ? n : p.N - 1;
     b_src[u] = p.b + (int64_t)n * p.b_sn + 16 * j;
   }
   const uint32_t smem_base = lds_addr_of(smem);
   auto dma_stage = [&](int stage, int kt) __attribute__((always_inline)) {
-    const uint32_t dst = smem_base + stage * STAGE + (4 * wave) * 1024;
+    const uint32_t dst = smem_base + stage * STAGE;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) lds_dma16(a_src[u] + (int64_t)kt * 128, dst + u * 1024);
+    for (int u = 0; u < RI; ++u) lds_dma16(a_src[u] + (int64_t)kt * 128, dst + (RI * wave + u) * 1024);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) lds_dma16(b_src[u] + (int64_t)kt * 128, dst + OPB + u * 1024);
+    for (int u = 0; u < 4; ++u) lds_dma16(b_src[u] + (int64_t)kt * 128, dst + OPA + (4 * wave + u) * 1024);
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[RI][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < RI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // fragment byte offsets inside an operand tile: row (64 w + 16 i + r16), chunks 2g and 2g+1
+  // fragment byte offsets inside an operand tile: row (16 RI w + 16 i + r16), chunks 2g and 2g+1
   const int sw = (r16 >> 1) & 7;  // (row >> 1) & 7 with row = 16 x + r16
   const uint32_t c0 = 16 * ((2 * g) ^ sw), c1 = 16 * ((2 * g + 1) ^ sw);
-  const uint32_t a_row = (wm * 64 + r16) * 128, b_row = (wn * 64 + r16) * 128;
+  const uint32_t a_row = (wm * 16 * RI + r16) * 128, b_row = (wn * 64 + r16) * 128;
 
   const int nk = p.K >> 7;
 #pragma unroll
   for (int st = 0; st < NSTAGE - 1; ++st)
     if (st < nk) dma_stage(st, st);
   for (int kt = 0; kt < nk; ++kt) {
-    // this wave's DMAs of stage kt have landed when at most the younger stages' (8 each) are outstanding
+    // this wave's DMAs of stage kt have landed when at most the younger stage's (RI + 4) are outstanding
     const int younger = (nk - 1 - kt) < (NSTAGE - 2) ? (nk - 1 - kt) : (NSTAGE - 2);
-    if (younger >= 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // NSTAGE == 3
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (younger >= 1) wait_vmcnt<RI + 4>();  // NSTAGE == 3
+    else wait_vmcnt<0>();
     __syncthreads();  // everyone's DMAs of stage kt landed; everyone finished reading the stage refilled below
     if (kt + NSTAGE - 1 < nk) dma_stage((kt + NSTAGE - 1) % NSTAGE, kt + NSTAGE - 1);
     const char* sa_ = smem + (kt % NSTAGE) * STAGE;
-    const char* sb_ = sa_ + OPB;
-    Frag32 af[4], bf[4];
+    const char* sb_ = sa_ + OPA;
+    Frag32 af[RI], bf[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      af[i].v[0] = *reinterpret_cast<const uint4*>(sa_ + a_row + i * 2048 + c0);
-      af[i].v[1] = *reinterpret_cast<const uint4*>(sa_ + a_row + i * 2048 + c1);
       bf[i].v[0] = *reinterpret_cast<const uint4*>(sb_ + b_row + i * 2048 + c0);
       bf[i].v[1] = *reinterpret_cast<const uint4*>(sb_ + b_row + i * 2048 + c1);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < RI; ++i) {
+      af[i].v[0] = *reinterpret_cast<const uint4*>(sa_ + a_row + i * 2048 + c0);
+      af[i].v[1] = *reinterpret_cast<const uint4*>(sa_ + a_row + i * 2048 + c1);
+    }
+#pragma unroll
+    for (int i = 0; i < RI; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
@@ -1396,7 +1409,7 @@ __global__ __launch_bounds__(256) void fp8_gemm_tiled2_kernel(GemmArgs p) {
   __syncthreads();  // all stages dead: the epilogue reuses the memory
 
   // ---- epilogue (as fp8_gemm_tiled_kernel)
-  T* ep = reinterpret_cast<T*>(smem) + wave * (64 * 72);
+  T* ep = reinterpret_cast<T*>(smem) + wave * (16 * RI * 72);  // per wave [16 RI][64] (+8 pad)
   float sbv[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -1404,11 +1417,11 @@ __global__ __launch_bounds__(256) void fp8_gemm_tiled2_kernel(GemmArgs p) {
     sbv[j] = p.sb[n < p.N ? n : p.N - 1];
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < RI; ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int ml = 16 * i + 4 * g + r;
-      const int m = m0 + wm * 64 + ml;
+      const int m = m0 + wm * 16 * RI + ml;
       const float sa = p.sa[m < p.M ? m : p.M - 1];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -1423,10 +1436,10 @@ __global__ __launch_bounds__(256) void fp8_gemm_tiled2_kernel(GemmArgs p) {
     }
   wait_lgkmcnt0();
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
+  for (int it = 0; it < 2 * RI; ++it) {
     const int c = lane + 64 * it;
     const int ml = c >> 3, nl = (c & 7) * 8;
-    const int m = m0 + wm * 64 + ml, n = n0 + wn * 64 + nl;
+    const int m = m0 + wm * 16 * RI + ml, n = n0 + wn * 64 + nl;
     if (m < p.M && n < p.N)
       *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.out) + (int64_t)m * p.N + n) =
           *reinterpret_cast<const uint4*>(ep + ml * 72 + nl);
@@ -1520,27 +1533,31 @@ int run_gemm(const GemmArgs& p, float* workspace, int64_t workspace_floats, hipS
     if (p.M <= 32) return dispatch_skinny<OUT_DTYPE, 2>(p, s);
     return dispatch_skinny<OUT_DTYPE, 4>(p, s);
   }
-  // v2 (LDS-DMA + block-scaled MFMA) whenever K has no tail.  Two stages leave room for two workgroups per CU, which
-  // hide each other's barriers when there are more tiles than CUs (M = 4096: 1.51-1.71 PFLOP/s vs 1.18-1.49 with three
-  // stages); with at most one tile per CU the deeper prefetch of three stages wins (M = 512: 26-28 us vs 32).
-  static const int v2_env = [] { const char* e = getenv("SGL_MI355_TILED_V2"); return e ? atoi(e) : -1; }();  // 0 off, 2 / 3 force
-  const unsigned grid2 = (unsigned)(((p.M + kTM - 1) / kTM) * ((p.N + kTN - 1) / kTN));
-  const int v2 = v2_env >= 0 ? v2_env : (grid2 <= 256 ? 3 : 2);
+  // v2 (LDS-DMA + block-scaled MFMA) whenever K has no tail.  128x128 tiles: two stages leave room for two workgroups
+  // per CU, which hide each other's barriers when there are more tiles than CUs; with at most one tile per CU the deeper
+  // prefetch of three stages wins (M = 512: 26-28 us vs 32).  256x128 tiles (128x64 per wave, three stages, one
+  // workgroup per CU) once there are >= 8 of the small tiles per CU, or >= 4 with a long K.
+  static const int v2_env = [] { const char* e = getenv("SGL_MI355_TILED_V2"); return e ? atoi(e) : -1; }();  // 0 off; 2, 3, 8 force
+  const unsigned grid_s = (unsigned)(((p.M + kTM - 1) / kTM) * ((p.N + kTN - 1) / kTN));
+  // (measured at M = 4096: 256x128 tiles 1.64 / 1.80-1.89 PFLOP/s at N = 28672 / K = 14336 vs 1.54 / 1.71 with
+  //  128x128 x 2 stages, but 1.45-1.49 vs 1.51-1.56 at N = 6144 / 4096, K = 4096)
+  const int v2 = v2_env >= 0 ? v2_env : (grid_s <= 256 ? 3 : ((grid_s >= 2048 || (grid_s >= 1024 && p.K >= 8192)) ? 8 : 2));
   if (v2 && (p.K & 127) == 0) {
-    if (v2 == 2) {
-      auto k2 = fp8_gemm_tiled2_kernel<OUT_DTYPE, 2>;
-      static int a2 = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                    2 * 2 * kTM * 128), "hipFuncSetAttribute");
-      if (a2) return a2;
-      hipLaunchKernelGGL(k2, dim3(grid2), dim3(256), 2 * 2 * kTM * 128, s, p);
-    } else {
-      auto k3 = fp8_gemm_tiled2_kernel<OUT_DTYPE, 3>;
-      static int a3 = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(k3), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                    3 * 2 * kTM * 128), "hipFuncSetAttribute");
-      if (a3) return a3;
-      hipLaunchKernelGGL(k3, dim3(grid2), dim3(256), 3 * 2 * kTM * 128, s, p);
-    }
-    return check_hip(hipGetLastError(), "fp8_gemm_tiled2 launch");
+#define TILED2_GO(NST, RI_)                                                                                       \
+  {                                                                                                               \
+    auto k2 = fp8_gemm_tiled2_kernel<OUT_DTYPE, NST, RI_>;                                                        \
+    constexpr int lds2 = NST * (32 * RI_ + kTN) * 128;                                                            \
+    static int a2 = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(k2),                              \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds2), "hipFuncSetAttribute"); \
+    if (a2) return a2;                                                                                            \
+    const unsigned g2 = (unsigned)(((p.M + 32 * RI_ - 1) / (32 * RI_)) * ((p.N + kTN - 1) / kTN));               \
+    hipLaunchKernelGGL(k2, dim3(g2), dim3(256), lds2, s, p);                                                      \
+    return check_hip(hipGetLastError(), "fp8_gemm_tiled2 launch");                                                \
+  }
+    if (v2 == 8) TILED2_GO(3, 8)
+    if (v2 == 2) TILED2_GO(2, 4)
+    TILED2_GO(3, 4)
+#undef TILED2_GO
   }
   static const bool scaled = [] { const char* e = getenv("SGL_MI355_TILED_SCALED"); return e ? atoi(e) != 0 : true; }();  // A-B aid
   auto kern = scaled ? fp8_gemm_tiled_kernel<OUT_DTYPE, true> : fp8_gemm_tiled_kernel<OUT_DTYPE, false>;

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Kernel-level measurements for BASELINE configs 2-5: one JSON line per point with the roofline
-fraction against the bound that applies (HBM 8 TB/s; dense FP8/BF16 MFMA 2.5 PFLOP/s non-scaled).
+fraction against the bound that applies (HBM 8 TB/s; dense FP8 MFMA 5 PFLOP/s -- the block-scaled f8f6f4 rate of
+MI355X_MICROARCH.md; the non-scaled fp8 instructions run at the 2.5 PFLOP/s BF16 rate).
 Times are HIP-event means over back-to-back launches with rotating operands (nothing stays in the Infinity Cache).
     python tools/bench_configs.py [decode] [fp8] [awq] [tp8]"""
 import json
@@ -13,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sglang_npu_amd import ops  # noqa: E402
 
 dev = "cuda:0"
-HBM, MFMA = 8000.0, 2500.0  # GB/s, TFLOP/s
+HBM, MFMA = 8000.0, 5000.0  # GB/s, TFLOP/s (dense FP8)
 
 
 def bench(fn, iters=30):
