@@ -1308,24 +1308,32 @@ __global__ __launch_bounds__(256) void fp8_gemm_tiled_kernel(GemmArgs p) {
 //     lands 8 rows x 128 B from 8 coalesced row segments (swizzle on the source side), and the fragment
 //     ds_read_b128 of 16 rows hits 16 distinct bank groups;
 //   * one block-scaled v_mfma_scale_f32_16x16x128_f8f6f4 (scales 2^0) per fragment pair and k-step.
-// RI = 16-row fragments per wave along M: 4 -> 128x128 block tile (64x64 per wave), 8 -> 256x128 (128x64 per wave: 0.75x
-// the LDS fragment reads per flop; for shapes with several tiles per CU).
-template <int OUT_DTYPE, int NSTAGE, int RI>
-__global__ __launch_bounds__(256) void fp8_gemm_tiled2_kernel(GemmArgs p) {
+// Block tile = (16 RI WM) x (64 WN) x 128 with WM x WN waves, each wave 16 RI rows x 64 columns:
+//   RI 4, 2x2 waves: 128x128 (2 stages -> two workgroups per CU; 3 stages when there is at most one tile per CU)
+//   RI 8, 2x2 waves: 256x128, 3 stages
+//   RI 4, 4x2 waves: 256x128 with 8 waves, 3 stages (B staged once per 256 rows)
+//   RI 8, 2x4 waves: 256x256 with 8 waves, 2 stages (0.75x the LDS fragment reads per flop of the 64x64 wave tile)
+template <int OUT_DTYPE, int NSTAGE, int RI, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void fp8_gemm_tiled2_kernel(GemmArgs p) {
   using H = Half16<OUT_DTYPE>;
   using T = typename H::T;
-  constexpr int TMB = 32 * RI;          // block rows
+  constexpr int NW = WM * WN;
+  constexpr int TMB = 16 * RI * WM;     // block rows
+  constexpr int TNB = 64 * WN;          // block columns
   constexpr int OPA = TMB * 128;        // A tile: TMB rows x 128 B
-  constexpr int OPB = kTN * 128;        // B tile: 128 rows x 128 B
+  constexpr int OPB = TNB * 128;
   constexpr int STAGE = OPA + OPB;
+  constexpr int UA = TMB / 8 / NW;      // 1-KiB DMA units (8 rows x 128 B) per wave and stage
+  constexpr int UB = TNB / 8 / NW;
+  static_assert((TMB / 8) % NW == 0 && (TNB / 8) % NW == 0, "DMA units must divide over the waves");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int r16 = lane & 15, g = lane >> 4;
 
-  const int tiles_m = (p.M + TMB - 1) / TMB, tiles_n = (p.N + kTN - 1) / kTN;
+  const int tiles_m = (p.M + TMB - 1) / TMB, tiles_n = (p.N + TNB - 1) / TNB;
   const int nwg = tiles_m * tiles_n;
   int bid = blockIdx.x;
   {
@@ -1333,22 +1341,23 @@ __global__ __launch_bounds__(256) void fp8_gemm_tiled2_kernel(GemmArgs p) {
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
   const int tm = bid % tiles_m, tn = bid / tiles_m;
-  const int m0 = tm * TMB, n0 = tn * kTN;
+  const int m0 = tm * TMB, n0 = tn * TNB;
 
-  // DMA units of 8 rows: wave w moves units RI*w .. RI*w+RI-1 of A and 4w .. 4w+3 of B
-  const uint8_t* a_src[RI];
-  const uint8_t* b_src[4];
+  // DMA: wave w moves units UA*w .. of A and UB*w .. of B; lane i of a unit lands at chunk i & 7 of row i >> 3 and
+  // fetches source chunk (i & 7) ^ ((row >> 1) & 7) of that row
+  const uint8_t* a_src[UA];
+  const uint8_t* b_src[UB];
 #pragma unroll
-  for (int u = 0; u < RI; ++u) {
-    const int row = (RI * wave + u) * 8 + (lane >> 3);  // tile-local row
+  for (int u = 0; u < UA; ++u) {
+    const int row = (UA * wave + u) * 8 + (lane >> 3);  // tile-local row
     const int j = (lane & 7) ^ ((row >> 1) & 7);
     int m = m0 + row;
     m = m < p.M ? m : p.M - 1;  // rows past the edge re-read a valid row; never stored
     a_src[u] = p.a + (int64_t)m * p.a_sm + 16 * j;
   }
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int row = (4 * wave + u) * 8 + (lane >> 3);
+  for (int u = 0; u < UB; ++u) {
+    const int row = (UB * wave + u) * 8 + (lane >> 3);
     const int j = (lane & 7) ^ ((row >> 1) & 7);
     int n = n0 + row;
     n = n < p.N ? n : p.N - 1;
@@ -1358,9 +1367,9 @@ __global__ __launch_bounds__(256) void fp8_gemm_tiled2_kernel(GemmArgs p) {
   auto dma_stage = [&](int stage, int kt) __attribute__((always_inline)) {
     const uint32_t dst = smem_base + stage * STAGE;
 #pragma unroll
-    for (int u = 0; u < RI; ++u) lds_dma16(a_src[u] + (int64_t)kt * 128, dst + (RI * wave + u) * 1024);
+    for (int u = 0; u < UA; ++u) lds_dma16(a_src[u] + (int64_t)kt * 128, dst + (UA * wave + u) * 1024);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) lds_dma16(b_src[u] + (int64_t)kt * 128, dst + OPA + (4 * wave + u) * 1024);
+    for (int u = 0; u < UB; ++u) lds_dma16(b_src[u] + (int64_t)kt * 128, dst + OPA + (UB * wave + u) * 1024);
   };
 
   f32x4 acc[RI][4];
@@ -1369,7 +1378,7 @@ __global__ __launch_bounds__(256) void fp8_gemm_tiled2_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // fragment byte offsets inside an operand tile: row (16 RI w + 16 i + r16), chunks 2g and 2g+1
+  // fragment byte offsets inside an operand tile: row (.. + 16 i + r16), chunks 2g and 2g+1
   const int sw = (r16 >> 1) & 7;  // (row >> 1) & 7 with row = 16 x + r16
   const uint32_t c0 = 16 * ((2 * g) ^ sw), c1 = 16 * ((2 * g + 1) ^ sw);
   const uint32_t a_row = (wm * 16 * RI + r16) * 128, b_row = (wn * 64 + r16) * 128;
@@ -1379,22 +1388,28 @@ __global__ __launch_bounds__(256) void fp8_gemm_tiled2_kernel(GemmArgs p) {
   for (int st = 0; st < NSTAGE - 1; ++st)
     if (st < nk) dma_stage(st, st);
   for (int kt = 0; kt < nk; ++kt) {
-    // this wave's DMAs of stage kt have landed when at most the younger stage's (RI + 4) are outstanding
+    // this wave's DMAs of stage kt have landed when at most the younger stage's (UA + UB) are outstanding
     const int younger = (nk - 1 - kt) < (NSTAGE - 2) ? (nk - 1 - kt) : (NSTAGE - 2);
-    if (younger >= 1) wait_vmcnt<RI + 4>();  // NSTAGE == 3
+    if (younger >= 1) wait_vmcnt<UA + UB>();  // NSTAGE == 3
     else wait_vmcnt<0>();
     __syncthreads();  // everyone's DMAs of stage kt landed; everyone finished reading the stage refilled below
     if (kt + NSTAGE - 1 < nk) dma_stage((kt + NSTAGE - 1) % NSTAGE, kt + NSTAGE - 1);
     const char* sa_ = smem + (kt % NSTAGE) * STAGE;
     const char* sb_ = sa_ + OPA;
+    // fragment pipeline: B (4 frags) and the first two A frags up front, then the reads of A frag i+2 are issued
+    // behind the MFMAs of A frag i (sched_group_barrier pins that interleave; left alone, hipcc loads each A frag
+    // right before its MFMAs and exposes one LDS latency per 8 MFMAs)
     Frag32 af[RI], bf[4];
+    // source order = the order the scheduling groups below consume the reads: A0, B0..B3, A1, A2, ...
+    af[0].v[0] = *reinterpret_cast<const uint4*>(sa_ + a_row + c0);
+    af[0].v[1] = *reinterpret_cast<const uint4*>(sa_ + a_row + c1);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       bf[i].v[0] = *reinterpret_cast<const uint4*>(sb_ + b_row + i * 2048 + c0);
       bf[i].v[1] = *reinterpret_cast<const uint4*>(sb_ + b_row + i * 2048 + c1);
     }
 #pragma unroll
-    for (int i = 0; i < RI; ++i) {
+    for (int i = 1; i < RI; ++i) {
       af[i].v[0] = *reinterpret_cast<const uint4*>(sa_ + a_row + i * 2048 + c0);
       af[i].v[1] = *reinterpret_cast<const uint4*>(sa_ + a_row + i * 2048 + c1);
     }
@@ -1405,11 +1420,23 @@ __global__ __launch_bounds__(256) void fp8_gemm_tiled2_kernel(GemmArgs p) {
         acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
             __builtin_bit_cast(v8i32_t, af[i]), __builtin_bit_cast(v8i32_t, bf[j]), acc[i][j], 0, 0, 0, 0x7F7F7F7F, 0,
             0x7F7F7F7F);
+    // the first MFMA starts after 3 fragments (A0, B0, B1), not after all 6 of the step's first burst
+    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);  // A0, B0, B1
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                        // row 0: one MFMA, then the reads of B2, B3, A1, A2
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    }
+#pragma unroll
+    for (int i = 1; i < RI; ++i) {                       // rows 1..: the A fragment two rows ahead, then the row's MFMAs
+      if (i + 2 < RI) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    }
   }
   __syncthreads();  // all stages dead: the epilogue reuses the memory
 
-  // ---- epilogue (as fp8_gemm_tiled_kernel)
-  T* ep = reinterpret_cast<T*>(smem) + wave * (16 * RI * 72);  // per wave [16 RI][64] (+8 pad)
+  // ---- epilogue in passes of 64 rows per wave through a wave-private [64][64] (+8 pad) patch (9216 B)
+  T* ep = reinterpret_cast<T*>(smem) + wave * (64 * 72);
   float sbv[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -1417,32 +1444,37 @@ __global__ __launch_bounds__(256) void fp8_gemm_tiled2_kernel(GemmArgs p) {
     sbv[j] = p.sb[n < p.N ? n : p.N - 1];
   }
 #pragma unroll
-  for (int i = 0; i < RI; ++i)
+  for (int pass = 0; pass < RI / 4; ++pass) {
+    const int mw0 = m0 + wm * 16 * RI + 64 * pass;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int ml = 16 * i + 4 * g + r;
-      const int m = m0 + wm * 16 * RI + ml;
-      const float sa = p.sa[m < p.M ? m : p.M - 1];
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int nl = 16 * j + r16;
-        float v = acc[i][j][r] * sbv[j] * sa;
-        if (p.bias) {
-          const int n = n0 + wn * 64 + nl;
-          v += H::to_f32(reinterpret_cast<const T*>(p.bias)[n < p.N ? n : p.N - 1]);
+      for (int r = 0; r < 4; ++r) {
+        const int ml = 16 * i + 4 * g + r;
+        const int m = mw0 + ml;
+        const float sa = p.sa[m < p.M ? m : p.M - 1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int nl = 16 * j + r16;
+          float v = acc[4 * pass + i][j][r] * sbv[j] * sa;
+          if (p.bias) {
+            const int n = n0 + wn * 64 + nl;
+            v += H::to_f32(reinterpret_cast<const T*>(p.bias)[n < p.N ? n : p.N - 1]);
+          }
+          ep[ml * 72 + nl] = H::from_f32(v);
         }
-        ep[ml * 72 + nl] = H::from_f32(v);
       }
-    }
-  wait_lgkmcnt0();
+    wait_lgkmcnt0();  // wave-private patch: a wave-level LDS wait is enough
 #pragma unroll
-  for (int it = 0; it < 2 * RI; ++it) {
-    const int c = lane + 64 * it;
-    const int ml = c >> 3, nl = (c & 7) * 8;
-    const int m = m0 + wm * 16 * RI + ml, n = n0 + wn * 64 + nl;
-    if (m < p.M && n < p.N)
-      *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.out) + (int64_t)m * p.N + n) =
-          *reinterpret_cast<const uint4*>(ep + ml * 72 + nl);
+    for (int it = 0; it < 8; ++it) {
+      const int c = lane + 64 * it;
+      const int ml = c >> 3, nl = (c & 7) * 8;
+      const int m = mw0 + ml, n = n0 + wn * 64 + nl;
+      if (m < p.M && n < p.N)
+        *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.out) + (int64_t)m * p.N + n) =
+            *reinterpret_cast<const uint4*>(ep + ml * 72 + nl);
+    }
+    wait_lgkmcnt0();  // the patch is rewritten by the next pass
   }
 }
 
@@ -1533,30 +1565,35 @@ int run_gemm(const GemmArgs& p, float* workspace, int64_t workspace_floats, hipS
     if (p.M <= 32) return dispatch_skinny<OUT_DTYPE, 2>(p, s);
     return dispatch_skinny<OUT_DTYPE, 4>(p, s);
   }
-  // v2 (LDS-DMA + block-scaled MFMA) whenever K has no tail.  128x128 tiles: two stages leave room for two workgroups
-  // per CU, which hide each other's barriers when there are more tiles than CUs; with at most one tile per CU the deeper
-  // prefetch of three stages wins (M = 512: 26-28 us vs 32).  256x128 tiles (128x64 per wave, three stages, one
-  // workgroup per CU) once there are >= 8 of the small tiles per CU, or >= 4 with a long K.
-  static const int v2_env = [] { const char* e = getenv("SGL_MI355_TILED_V2"); return e ? atoi(e) : -1; }();  // 0 off; 2, 3, 8 force
+  // v2 (LDS-DMA + block-scaled MFMA) whenever K has no tail; variant by tile count (see the kernel's comment).
+  static const int v2_env = [] { const char* e = getenv("SGL_MI355_TILED_V2"); return e ? atoi(e) : -1; }();  // 0 off; 2, 3, 8, 48, 84 force a variant
   const unsigned grid_s = (unsigned)(((p.M + kTM - 1) / kTM) * ((p.N + kTN - 1) / kTN));
-  // (measured at M = 4096: 256x128 tiles 1.64 / 1.80-1.89 PFLOP/s at N = 28672 / K = 14336 vs 1.54 / 1.71 with
-  //  128x128 x 2 stages, but 1.45-1.49 vs 1.51-1.56 at N = 6144 / 4096, K = 4096)
-  const int v2 = v2_env >= 0 ? v2_env : (grid_s <= 256 ? 3 : ((grid_s >= 2048 || (grid_s >= 1024 && p.K >= 8192)) ? 8 : 2));
+  // Selection (measured, M = 4096 / 512, PFLOP/s): 256x256 x 8 waves 1.62-2.26 wherever there are enough of the big
+  // tiles (>= 192: three quarters of the CUs) -- e.g. 2.05 vs 1.57 at 4096x4096x4096; 128x128: three stages when there
+  // is at most one tile per CU (M = 512: 26-28 us vs 32), else two stages x two workgroups per CU.
+  // (A 4-wave 256x256 with 128x128 wave tiles -- MFMA-bound on paper -- reached only 1.47-2.12: with one wave per SIMD
+  //  every barrier and first-fragment latency is exposed.)
+  const unsigned grid_b = (unsigned)(((p.M + 255) / 256) * ((p.N + 255) / 256));
+  const int v2 = v2_env >= 0 ? v2_env : (grid_b >= 192 ? 84 : (grid_s <= 256 ? 3 : 2));
   if (v2 && (p.K & 127) == 0) {
-#define TILED2_GO(NST, RI_)                                                                                       \
+#define TILED2_GO(NST, RI_, WM_, WN_)                                                                             \
   {                                                                                                               \
-    auto k2 = fp8_gemm_tiled2_kernel<OUT_DTYPE, NST, RI_>;                                                        \
-    constexpr int lds2 = NST * (32 * RI_ + kTN) * 128;                                                            \
+    auto k2 = fp8_gemm_tiled2_kernel<OUT_DTYPE, NST, RI_, WM_, WN_>;                                              \
+    constexpr int tmb = 16 * RI_ * WM_, tnb = 64 * WN_;                                                           \
+    constexpr int lds_st = NST * (tmb + tnb) * 128, lds_ep = WM_ * WN_ * 64 * 72 * 2;                             \
+    constexpr int lds2 = lds_st > lds_ep ? lds_st : lds_ep;                                                       \
     static int a2 = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(k2),                              \
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds2), "hipFuncSetAttribute"); \
     if (a2) return a2;                                                                                            \
-    const unsigned g2 = (unsigned)(((p.M + 32 * RI_ - 1) / (32 * RI_)) * ((p.N + kTN - 1) / kTN));               \
-    hipLaunchKernelGGL(k2, dim3(g2), dim3(256), lds2, s, p);                                                      \
+    const unsigned g2 = (unsigned)(((p.M + tmb - 1) / tmb) * ((p.N + tnb - 1) / tnb));                            \
+    hipLaunchKernelGGL(k2, dim3(g2), dim3(64 * WM_ * WN_), lds2, s, p);                                           \
     return check_hip(hipGetLastError(), "fp8_gemm_tiled2 launch");                                                \
   }
-    if (v2 == 8) TILED2_GO(3, 8)
-    if (v2 == 2) TILED2_GO(2, 4)
-    TILED2_GO(3, 4)
+    if (v2 == 84) TILED2_GO(2, 8, 2, 4)
+    if (v2 == 48) TILED2_GO(3, 4, 4, 2)
+    if (v2 == 8) TILED2_GO(3, 8, 2, 2)
+    if (v2 == 2) TILED2_GO(2, 4, 2, 2)
+    TILED2_GO(3, 4, 2, 2)
 #undef TILED2_GO
   }
   static const bool scaled = [] { const char* e = getenv("SGL_MI355_TILED_SCALED"); return e ? atoi(e) != 0 : true; }();  // A-B aid
