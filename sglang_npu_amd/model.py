@@ -260,8 +260,9 @@ class LlamaForCausalLM(torch.nn.Module):
     def forward(self, input_ids, positions, forward_batch: ForwardBatch):
         hidden_states = self.embed_tokens[input_ids]
         residual = None
-        fused = self.fuse_quant and forward_batch.forward_mode.is_decode()
-        defer = fused and self.defer_epilogues and get_tensor_model_parallel_world_size() == 1
+        fused = self.fuse_quant and (forward_batch.forward_mode.is_decode() or forward_batch.forward_mode.is_extend())
+        defer = (fused and self.defer_epilogues and forward_batch.forward_mode.is_decode()
+                 and get_tensor_model_parallel_world_size() == 1)
         for layer in self.layers:
             if fused:
                 hidden_states, residual = layer.forward_fp8(positions, hidden_states, forward_batch, residual, defer)
@@ -269,6 +270,11 @@ class LlamaForCausalLM(torch.nn.Module):
                 hidden_states, residual = layer(positions, hidden_states, forward_batch, residual)
         if isinstance(hidden_states, ops.GemmPartials):
             hidden_states = hidden_states.finalize()
+        if forward_batch.forward_mode.is_extend() and forward_batch.extend_seq_lens is not None:
+            # LogitsProcessor (logits_processor.py:430-470): prefill only needs the last position of every request
+            last = torch.cumsum(forward_batch.extend_seq_lens, dim=0) - 1
+            hidden_states = hidden_states[last]
+            residual = residual[last] if residual is not None else None
         hidden_states, _ = self.norm(hidden_states, residual)
         if not self.with_lm_head:
             return hidden_states

@@ -262,6 +262,43 @@ def test_fused_fp8_layer_path_equals_unfused():
     assert torch.equal(outs[0][0], outs[1][0]), "fused and unfused paths must agree bit for bit"
 
 
+def test_fused_fp8_path_equals_unfused_in_prefill():
+    """The same fused producers run in EXTEND mode (ragged prefill with a cached prefix): logits and the written K/V
+    must equal the unfused sequence bit for bit."""
+    cfg = ModelConfig(8, 2, 64, 512, 1024, 2, 512, 256)
+    outs = []
+    for fuse in (False, True):
+        net = M.LlamaForCausalLM(cfg, "w8a8_fp8", torch.bfloat16, DEV, fuse_quant=fuse).load_dummy_weights()
+        B = 3
+        r2t = ReqToTokenPool(B, 256, DEV)
+        pool = MHATokenToKVPool(B * 256 + 1, 1, torch.bfloat16, 2, 64, 2, DEV)
+        g = torch.Generator(device=DEV).manual_seed(0)
+        for l in range(2):
+            pool.k_buffer[l].normal_(generator=g)
+            pool.v_buffer[l].normal_(generator=g)
+        r2t.req_to_token.copy_((torch.randperm(B * 256, device=DEV, generator=g) + 1).view(B, 256).to(torch.int32))
+        runner = ModelRunnerLike(cfg, r2t, pool, DEV, 0, 1, ServerArgs())
+        backend = install_attention_backend(runner)
+        prefix = torch.tensor([0, 20, 3], device=DEV)
+        ext = torch.tensor([70, 33, 1], device=DEV)
+        seq = prefix + ext
+        T = int(ext.sum())
+        rows = torch.arange(B, device=DEV)
+        ids = torch.randint(0, 500, (T,), device=DEV, generator=g)
+        positions = torch.cat([torch.arange(int(prefix[b]), int(seq[b]), device=DEV) for b in range(B)])
+        loc = torch.cat([r2t.req_to_token[b, prefix[b]:seq[b]] for b in range(B)]).long()
+        start = torch.zeros(B, dtype=torch.int64, device=DEV)
+        start[1:] = torch.cumsum(ext[:-1], 0)
+        fb = ForwardBatch(ForwardMode.EXTEND, B, ids, rows, seq, loc, int(seq.sum()), seq.cpu(), positions,
+                          extend_num_tokens=T, extend_seq_lens=ext, extend_prefix_lens=prefix, extend_start_loc=start,
+                          extend_prefix_lens_cpu=prefix.tolist(), extend_seq_lens_cpu=ext.tolist(),
+                          req_to_token_pool=r2t, token_to_kv_pool=pool, attn_backend=backend)
+        backend.init_forward_metadata(fb)
+        outs.append((net(ids, positions, fb), pool.k_buffer[1].clone(), pool.v_buffer[0].clone()))
+    assert outs[0][0].shape == (3, 512)  # one row of logits per request (LogitsProcessor pruning)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+
+
 def test_deferred_gemm_epilogues_are_bit_identical():
     """defer=True leaves the qkv / o_proj / down_proj epilogues to the consumer kernels (RoPE + KV write, add + RMSNorm +
     quant) on split-K partials.  Same slice order, same roundings -> logits and pool contents identical to the
