@@ -17,7 +17,7 @@ def _backend(num_heads, num_kv_heads, max_splits=8):
 def test_split_policy_fills_the_chip_without_over_splitting():
     assert _backend(32, 8).choose_num_kv_splits(64) == 1           # 512 workgroups already
     assert _backend(32, 8).choose_num_kv_splits(32) == 1           # 256 = one per CU
-    assert _backend(8, 1).choose_num_kv_splits(64) == 8            # 70B TP8: 64 workgroups -> split 8
+    assert _backend(8, 1).choose_num_kv_splits(64) == 4            # 70B TP8: 64 workgroups -> 4 splits = one per CU
     assert _backend(32, 8).choose_num_kv_splits(1, max_seq_len=600) == 2    # keep >= 256 tokens per split
     assert _backend(32, 8).choose_num_kv_splits(1, max_seq_len=100000) == 8
     assert _backend(128, 1).choose_num_kv_splits(4) == 8           # 8 head blocks x 4 = 32 workgroups
