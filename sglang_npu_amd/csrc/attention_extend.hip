@@ -89,7 +89,7 @@ __device__ __forceinline__ int swz_v(int c, int row) {  // ds_read_b64_tr_b16: k
 
 // GH = q heads per workgroup (1, 2 or 4); the other 4/GH waves take further 32-row position blocks.
 template <int DTYPE, int D, typename IdxT, int GH, bool MASKED>
-__global__ __launch_bounds__(256) void extend_mfma_kernel(ExtendArgs a) {
+__global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
   using H = Half16<DTYPE>;
   using T = typename H::T;
   using x8 = typename H::x8;
@@ -113,11 +113,13 @@ __global__ __launch_bounds__(256) void extend_mfma_kernel(ExtendArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 31, hh = lane >> 5;
 
-  // blockIdx.x = ((b * (Hq/GH)) + hgrp) * num_mblocks + mblk ; heavy (late) query blocks first
-  int bid = blockIdx.x;
-  const int mblk = a.num_mblocks - 1 - (bid % a.num_mblocks);
-  bid /= a.num_mblocks;
+  // blockIdx.x = mblk' * (B * Hq/GH) + (b * Hq/GH + hgrp): ALL the heavy (late, long-prefix) query blocks of every
+  // request and head group are dispatched before any lighter one (longest-processing-time-first over the whole grid)
   const int hgroups = a.num_heads / GH;
+  const int nbh = (int)(gridDim.x / a.num_mblocks);  // B * hgroups
+  int bid = blockIdx.x;
+  const int mblk = a.num_mblocks - 1 - (bid / nbh);
+  bid %= nbh;
   const int hgrp = bid % hgroups;
   const int b = bid / hgroups;
   const int head0 = hgrp * GH;
