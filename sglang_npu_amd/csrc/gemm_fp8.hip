@@ -1425,7 +1425,7 @@ __global__ __launch_bounds__(64 * WM * WN) void fp8_gemm_tiled2_kernel(GemmArgs 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {                        // row 0: one MFMA, then the reads of B2, B3, A1, A2
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      if (j < 2 || j - 1 < RI) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
     }
 #pragma unroll
     for (int i = 1; i < RI; ++i) {                       // rows 1..: the A fragment two rows ahead, then the row's MFMAs
@@ -1443,11 +1443,12 @@ __global__ __launch_bounds__(64 * WM * WN) void fp8_gemm_tiled2_kernel(GemmArgs 
     const int n = n0 + wn * 64 + 16 * j + r16;
     sbv[j] = p.sb[n < p.N ? n : p.N - 1];
   }
+  constexpr int RP = RI < 4 ? RI : 4;  // 16-row fragments per epilogue pass
 #pragma unroll
-  for (int pass = 0; pass < RI / 4; ++pass) {
-    const int mw0 = m0 + wm * 16 * RI + 64 * pass;
+  for (int pass = 0; pass < RI / RP; ++pass) {
+    const int mw0 = m0 + wm * 16 * RI + 16 * RP * pass;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < RP; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int ml = 16 * i + 4 * g + r;
@@ -1456,7 +1457,7 @@ __global__ __launch_bounds__(64 * WM * WN) void fp8_gemm_tiled2_kernel(GemmArgs 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int nl = 16 * j + r16;
-          float v = acc[4 * pass + i][j][r] * sbv[j] * sa;
+          float v = acc[RP * pass + i][j][r] * sbv[j] * sa;
           if (p.bias) {
             const int n = n0 + wn * 64 + nl;
             v += H::to_f32(reinterpret_cast<const T*>(p.bias)[n < p.N ? n : p.N - 1]);
@@ -1466,7 +1467,7 @@ __global__ __launch_bounds__(64 * WM * WN) void fp8_gemm_tiled2_kernel(GemmArgs 
       }
     wait_lgkmcnt0();  // wave-private patch: a wave-level LDS wait is enough
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
+    for (int it = 0; it < 2 * RP; ++it) {
       const int c = lane + 64 * it;
       const int ml = c >> 3, nl = (c & 7) * 8;
       const int m = mw0 + ml, n = n0 + wn * 64 + nl;
@@ -1569,12 +1570,13 @@ int run_gemm(const GemmArgs& p, float* workspace, int64_t workspace_floats, hipS
   static const int v2_env = [] { const char* e = getenv("SGL_MI355_TILED_V2"); return e ? atoi(e) : -1; }();  // 0 off; 2, 3, 8, 48, 84 force a variant
   const unsigned grid_s = (unsigned)(((p.M + kTM - 1) / kTM) * ((p.N + kTN - 1) / kTN));
   // Selection (measured, M = 4096 / 512, PFLOP/s): 256x256 x 8 waves 1.62-2.26 wherever there are enough of the big
-  // tiles (>= 192: three quarters of the CUs) -- e.g. 2.05 vs 1.57 at 4096x4096x4096; 128x128: three stages when there
-  // is at most one tile per CU (M = 512: 26-28 us vs 32), else two stages x two workgroups per CU.
+  // tiles (>= 192: three quarters of the CUs) -- e.g. 2.05 vs 1.57 at 4096x4096x4096; 128x128: with at most one tile per
+  // CU three stages and EIGHT waves (32x64 per wave: two waves per SIMD hide each other's latency; M = 1024 o/down
+  // 26.7 / 74.4 us vs 29.0 / 81.9 with four waves), else two stages x two workgroups per CU.
   // (A 4-wave 256x256 with 128x128 wave tiles -- MFMA-bound on paper -- reached only 1.47-2.12: with one wave per SIMD
   //  every barrier and first-fragment latency is exposed.)
   const unsigned grid_b = (unsigned)(((p.M + 255) / 256) * ((p.N + 255) / 256));
-  const int v2 = v2_env >= 0 ? v2_env : (grid_b >= 192 ? 84 : (grid_s <= 256 ? 3 : 2));
+  const int v2 = v2_env >= 0 ? v2_env : (grid_b >= 192 ? 84 : (grid_s <= 256 ? 22 : 2));
   if (v2 && (p.K & 127) == 0) {
 #define TILED2_GO(NST, RI_, WM_, WN_)                                                                             \
   {                                                                                                               \
@@ -1589,6 +1591,7 @@ int run_gemm(const GemmArgs& p, float* workspace, int64_t workspace_floats, hipS
     hipLaunchKernelGGL(k2, dim3(g2), dim3(64 * WM_ * WN_), lds2, s, p);                                           \
     return check_hip(hipGetLastError(), "fp8_gemm_tiled2 launch");                                                \
   }
+    if (v2 == 22) TILED2_GO(3, 2, 4, 2)  // 128x128 with 8 waves (32x64 per wave)
     if (v2 == 84) TILED2_GO(2, 8, 2, 4)
     if (v2 == 48) TILED2_GO(3, 4, 4, 2)
     if (v2 == 8) TILED2_GO(3, 8, 2, 2)
