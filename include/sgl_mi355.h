@@ -151,6 +151,34 @@ int sgl_mi355_extend_attention_fwd(
     int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * FP8 (e4m3fn) KV cache, `--kv-cache-dtype fp8_e4m3` (server_args.py:829-833).
+ * Replaces: MHATokenToKVPool.set_kv_buffer with dtype float8_e4m3fn (memory_pool.py:114-118, 369-407: optional
+ *           x.div_(scale) in the 16-bit dtype, .to(fp8), uint8 storage) and the Triton decode kernels reading such a
+ *           pool (decode_attention.py:336 `k.to(q.dtype)`, :373 `p.to(v.dtype)`: P is rounded to FP8 before P.V).
+ *   k/v pool pointers address bytes; their strides are in bytes (= elements).  k_scale / v_scale <= 0: none.
+ *   decode_*_fp8kv take the argument lists of the 16-bit entry points (without the fused KV write of the op form).
+ *   Head sizes 64 / 128 only (SGL_MI355_ERR_UNSUPPORTED otherwise).  Values beyond +-448 saturate. */
+int sgl_mi355_set_kv_buffer_fp8(void* k_buffer, void* v_buffer, const void* loc, int loc_is64, const void* key,
+                                const void* value, int64_t num_tokens, int64_t num_kv_heads, int64_t head_size,
+                                int64_t head_size_v, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n,
+                                int64_t v_stride_h, int64_t key_stride_n, int64_t key_stride_h, int64_t value_stride_n,
+                                int64_t value_stride_h, float k_scale, float v_scale, int dtype, void* stream);
+int sgl_mi355_decode_attention_fp8kv(
+    const void* query, void* k_cache, void* v_cache, void* output, float* attn_logits, const void* req_to_token,
+    int req_to_token_is64, const int64_t* req_pool_indices, const int64_t* seq_lens, int64_t num_seqs,
+    int64_t max_context_len, int64_t num_heads, int64_t num_kv_heads, int64_t head_size, int64_t head_size_v,
+    int64_t num_kv_splits, int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h,
+    int64_t v_stride_n, int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h, float sm_scale, float logit_cap,
+    int dtype, void* stream);
+int sgl_mi355_decode_attention_fwd_fp8kv(
+    const void* q, const void* k_buffer, const void* v_buffer, void* o, const int32_t* kv_indptr,
+    const int32_t* kv_indices, float* attn_logits, float* attn_lse, const int32_t* num_kv_splits,
+    int64_t max_kv_splits, int64_t batch, int64_t num_heads, int64_t num_kv_heads, int64_t head_size,
+    int64_t head_size_v, int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h,
+    int64_t v_stride_n, int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h, float sm_scale, float logit_cap,
+    int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * merge_state: combine two partial attention results of the same queries by their log-sum-exp.
  * Replaces: merge_state_triton(prefix_output, prefix_lse, suffix_output, suffix_lse, output, output_lse)
  *           python/sglang/srt/layers/attention/triton_ops/merge_state.py:8-96, and sgl_kernel.merge_state /

@@ -276,3 +276,32 @@ def merge_state(prefix_output, prefix_lse, suffix_output, suffix_lse, lib=None):
     lib.orc_merge_state(_ptr(po), _ptr(prefix_lse.contiguous()), _ptr(so), _ptr(suffix_lse.contiguous()), _ptr(out),
                         _ptr(out_lse), _I64(N * H), _I64(D), _I(code))
     return out, out_lse
+
+
+# ----------------------------------------------------------------------------- FP8 (e4m3) KV cache
+def set_kv_buffer_fp8(k_buffer, v_buffer, key, value, loc, k_scale=None, v_scale=None, lib=None):
+    """MHATokenToKVPool.set_kv_buffer with dtype float8_e4m3fn (memory_pool.py:369-407): pools are uint8/e4m3
+    [N,Hkv,D], key/value the 16-bit new entries [T,Hkv,D]."""
+    lib = lib or load()
+    T, Hkv, D = key.shape
+    lib.orc_set_kv_buffer_fp8(
+        _ptr(k_buffer), _ptr(v_buffer), _ptr(key), _ptr(value), _ptr(_i64(loc).contiguous()), _I64(T), _I64(Hkv), _I64(D),
+        _I64(value.size(2)), _I64(k_buffer.stride(0)), _I64(k_buffer.stride(1)), _I64(v_buffer.stride(0)),
+        _I64(v_buffer.stride(1)), _I64(key.stride(0)), _I64(key.stride(1)), _I64(value.stride(0)), _I64(value.stride(1)),
+        _F(k_scale if k_scale else 0.0), _F(v_scale if v_scale else 0.0), _I(_dt(key)))
+
+
+def decode_attention_fp8kv(query, k_buffer, v_buffer, output, attn_logits, req_to_token, req_pool_indices, seq_lens,
+                           sm_scale, logit_cap=0.0, p_fp8: bool = True, lib=None):
+    """Triton decode over an e4m3 KV pool (decode_attention.py:240-488): K upcast, P rounded to FP8 per 32-token block.
+    attn_logits [B,Hq,splits,Dv+1] fp32 scratch; p_fp8=False keeps P in fp32 (the truth for noise measurements)."""
+    lib = lib or load()
+    B = seq_lens.numel()
+    lib.orc_decode_attention_fp8kv(
+        _ptr(query), _ptr(k_buffer), _ptr(v_buffer), _ptr(output), _ptr(attn_logits), _ptr(req_to_token),
+        _I(_is64(req_to_token)), _ptr(_i64(req_pool_indices).contiguous()), _ptr(_i64(seq_lens).contiguous()), _I64(B),
+        _I64(req_to_token.size(1)), _I64(query.size(1)), _I64(k_buffer.size(1)), _I64(query.size(2)),
+        _I64(v_buffer.size(2)), _I64(attn_logits.size(2)), _I64(query.stride(0)), _I64(query.stride(1)),
+        _I64(k_buffer.stride(0)), _I64(k_buffer.stride(1)), _I64(v_buffer.stride(0)), _I64(v_buffer.stride(1)),
+        _I64(output.stride(0)), _I64(output.stride(1)), _F(sm_scale), _F(logit_cap), _I(_dt(query)), _I(1 if p_fp8 else 0))
+    return output

@@ -691,3 +691,118 @@ void orc_merge_state(const void* p_out, const float* p_lse, const void* s_out, c
     }
   }
 }
+
+/* ------------------------------------------------------------------ FP8 (e4m3fn) KV cache
+ * set_kv_buffer with a pool dtype of float8_e4m3fn, python/sglang/srt/mem_cache/memory_pool.py:369-407:
+ *   if cache_k.dtype != self.dtype: (optional) cache_k.div_(k_scale) -- IN the 16-bit dtype --, then .to(fp8)
+ *   (:385-391); stored through a uint8 view (:114-118, :392-394).  The Triton backend passes no scale
+ *   (triton_backend.py:647-650, 706-709).  Values beyond +-448 saturate here (torch's cast gives NaN there). */
+void orc_set_kv_buffer_fp8(uint8_t* k_buffer, uint8_t* v_buffer, const uint16_t* key, const uint16_t* value,
+                           const int64_t* loc, int64_t T, int64_t Hkv, int64_t D, int64_t Dv, int64_t k_strideN,
+                           int64_t k_strideH, int64_t v_strideN, int64_t v_strideH, int64_t nk_strideN,
+                           int64_t nk_strideH, int64_t nv_strideN, int64_t nv_strideH, float k_scale, float v_scale,
+                           int dtype) {
+  for (int64_t t = 0; t < T; ++t)
+    for (int64_t h = 0; h < Hkv; ++h) {
+      for (int64_t d = 0; d < D; ++d) {
+        float x = h_to_f32(key[t * nk_strideN + h * nk_strideH + d], dtype);
+        if (k_scale > 0.f) x = h_to_f32(f32_to_h(x / k_scale, dtype), dtype);
+        k_buffer[loc[t] * k_strideN + h * k_strideH + d] = f32_to_e4m3(x);
+      }
+      for (int64_t d = 0; d < Dv; ++d) {
+        float x = h_to_f32(value[t * nv_strideN + h * nv_strideH + d], dtype);
+        if (v_scale > 0.f) x = h_to_f32(f32_to_h(x / v_scale, dtype), dtype);
+        v_buffer[loc[t] * v_strideN + h * v_strideH + d] = f32_to_e4m3(x);
+      }
+    }
+}
+
+/* Paged decode over an e4m3 KV pool as the Triton kernels do it (_fwd_grouped_kernel_stage1 / _fwd_kernel_stage1,
+ * decode_attention.py:240-401, 44-169; stage 2 :404-488):
+ *   per split (length ceil(ceil(S/splits)/32)*32, :303-307), in blocks of BLOCK_N = 32 tokens:
+ *   qk = dot(q, k.to(q.dtype)) * sm_scale (:336, K upcast: exact); n_e_max = max(max(qk), e_max);
+ *   p = exp(qk - n_e_max); acc = acc * exp(e_max - n_e_max) + dot(p.to(v.dtype), v) -- P IS ROUNDED TO FP8 (:373);
+ *   e_sum uses the unrounded p (:375).  Split outputs acc / e_sum and lse = e_max + log(e_sum) are merged by LSE.
+ * p_fp8 = 0: keep p in fp32 (the "truth" the tests measure the fp8-P noise against). */
+void orc_decode_attention_fp8kv(
+    const uint16_t* query, const uint8_t* k_buffer, const uint8_t* v_buffer, uint16_t* output, float* attn_logits,
+    const void* req_to_token, int idx64, const int64_t* req_pool_indices, const int64_t* seq_lens, int64_t num_seqs,
+    int64_t max_context_len, int64_t num_heads, int64_t num_heads_kv, int64_t head_size, int64_t head_size_v,
+    int64_t num_kv_splits, int64_t q_strideM, int64_t q_strideH, int64_t k_strideN, int64_t k_strideH,
+    int64_t v_strideN, int64_t v_strideH, int64_t o_strideM, int64_t o_strideH, float sm_scale, float logit_cap,
+    int dtype, int p_fp8) {
+  float lut[256];
+  for (int i = 0; i < 256; ++i) lut[i] = e4m3_to_f32((uint8_t)i);
+  const int64_t group = num_heads / num_heads_kv;
+  const int64_t ls2 = head_size_v + 1, ls1 = num_kv_splits * ls2, ls0 = num_heads * ls1;
+#pragma omp parallel for schedule(dynamic, 1) collapse(2)
+  for (int64_t b = 0; b < num_seqs; ++b)
+    for (int64_t h = 0; h < num_heads; ++h) {
+      const int64_t hkv = h / group, S = seq_lens[b], req = req_pool_indices[b];
+      const uint16_t* q = query + b * q_strideM + h * q_strideH;
+      float* acc = (float*)malloc(sizeof(float) * (size_t)head_size_v);
+      float qk[32], p[32];
+      int64_t per = (S + num_kv_splits - 1) / num_kv_splits;
+      per = (per + 31) / 32 * 32;
+      for (int64_t sp = 0; sp < num_kv_splits; ++sp) {
+        const int64_t s0 = per * sp, s1 = s0 + per < S ? s0 + per : S;
+        float* out = attn_logits + b * ls0 + h * ls1 + sp * ls2;
+        if (s0 >= s1) {
+          for (int64_t d = 0; d < head_size_v; ++d) out[d] = 0.f;
+          out[head_size_v] = -INFINITY;
+          continue;
+        }
+        float e_max = -INFINITY, e_sum = 0.f;
+        for (int64_t d = 0; d < head_size_v; ++d) acc[d] = 0.f;
+        for (int64_t n0 = s0; n0 < s1; n0 += 32) {
+          const int64_t nb = s1 - n0 < 32 ? s1 - n0 : 32;
+          float bm = -INFINITY;
+          for (int64_t j = 0; j < nb; ++j) {
+            const int64_t tok = load_index(req_to_token, req * max_context_len + n0 + j, idx64);
+            const uint8_t* kp = k_buffer + tok * k_strideN + hkv * k_strideH;
+            float s = 0.f;
+            for (int64_t d = 0; d < head_size; ++d) s += h_to_f32(q[d], dtype) * lut[kp[d]];
+            s *= sm_scale;
+            if (logit_cap > 0.f) s = logit_cap * tanhf(s / logit_cap);
+            qk[j] = s;
+            bm = s > bm ? s : bm;
+          }
+          const float n_e_max = bm > e_max ? bm : e_max;
+          const float re = expf(e_max - n_e_max);
+          for (int64_t d = 0; d < head_size_v; ++d) acc[d] *= re;
+          float psum = 0.f;
+          for (int64_t j = 0; j < nb; ++j) {
+            p[j] = expf(qk[j] - n_e_max);
+            psum += p[j];
+            if (p_fp8) p[j] = lut[f32_to_e4m3(p[j])];
+          }
+          for (int64_t j = 0; j < nb; ++j) {
+            const int64_t tok = load_index(req_to_token, req * max_context_len + n0 + j, idx64);
+            const uint8_t* vp = v_buffer + tok * v_strideN + hkv * v_strideH;
+            for (int64_t d = 0; d < head_size_v; ++d) acc[d] += p[j] * lut[vp[d]];
+          }
+          e_sum = e_sum * re + psum;
+          e_max = n_e_max;
+        }
+        for (int64_t d = 0; d < head_size_v; ++d) out[d] = acc[d] / e_sum;
+        out[head_size_v] = e_max + logf(e_sum);
+      }
+      /* stage 2 (:404-488): LSE merge of the splits */
+      const float* lg = attn_logits + b * ls0 + h * ls1;
+      float mx = -INFINITY;
+      for (int64_t sp = 0; sp < num_kv_splits; ++sp) mx = lg[sp * ls2 + head_size_v] > mx ? lg[sp * ls2 + head_size_v] : mx;
+      float den = 0.f;
+      for (int64_t sp = 0; sp < num_kv_splits; ++sp)
+        if (lg[sp * ls2 + head_size_v] != -INFINITY) den += expf(lg[sp * ls2 + head_size_v] - mx);
+      uint16_t* o = output + b * o_strideM + h * o_strideH;
+      for (int64_t d = 0; d < head_size_v; ++d) {
+        float v = 0.f;
+        for (int64_t sp = 0; sp < num_kv_splits; ++sp) {
+          const float lse = lg[sp * ls2 + head_size_v];
+          if (lse != -INFINITY) v += lg[sp * ls2 + d] * (expf(lse - mx) / den);
+        }
+        o[d] = f32_to_h(den > 0.f ? v : 0.f, dtype);
+      }
+      free(acc);
+    }
+}

@@ -67,6 +67,7 @@ struct DecodeArgs {
   int num_heads, num_kv_heads, group;
   float sm_scale, logit_cap;
   int mode;
+  int kv8;  // 1: the pool is e4m3fn bytes (strides in elements = bytes); K is upcast, P is rounded to FP8 before PV
 };
 
 __device__ __forceinline__ void split_range(const DecodeArgs& a, int b, int split, int64_t& base, int& s0, int& s1) {
@@ -95,7 +96,37 @@ __device__ __forceinline__ int swz_chunk(int c, int row) {
   return (((c >> 1) ^ f) << 1) | (c & 1);
 }
 
-template <int DTYPE, int D, typename IdxT, bool DIRECT_OUT, int kWaves>
+// 16 e4m3 bytes -> 16 values of the 16-bit dtype (exact: e4m3 fits both bf16 and fp16)
+template <int DTYPE>
+__device__ __forceinline__ void cvt16_fp8(const uint4& raw, typename Half16<DTYPE>::x8& lo, typename Half16<DTYPE>::x8& hi) {
+  using Hh = Half16<DTYPE>;
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f32x2_t a = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[i], false);
+    const f32x2_t b = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[i], true);
+    typename Hh::x8& dst = i < 2 ? lo : hi;
+    const int o = (i & 1) * 4;
+    dst[o + 0] = Hh::from_f32(a[0]);
+    dst[o + 1] = Hh::from_f32(a[1]);
+    dst[o + 2] = Hh::from_f32(b[0]);
+    dst[o + 3] = Hh::from_f32(b[1]);
+  }
+}
+// p (fp32, in [0, 1]) rounded to e4m3 and back: what `p.to(v.dtype)` does with an FP8 V (decode_attention.py:373)
+__device__ __forceinline__ float round_fp8(float p) {
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  const int pk = __builtin_amdgcn_cvt_pk_fp8_f32(p, 0.f, 0, false);
+  const f32x2_t r = __builtin_amdgcn_cvt_pk_f32_fp8(pk, false);
+  return r[0];
+}
+
+// KV8 = 1: the pool holds e4m3 bytes.  Tiles are DMA'd as bytes into a two-stage staging area of the wave's ring and
+// converted (exactly) into ONE 16-bit K tile and ONE 16-bit V tile in the ring's usual swizzled layout; everything
+// behind that (QK^T fragments, transposed V reads, both MFMAs) is the 16-bit code path.  HBM traffic halves; the
+// conversion is ~130 VALU and 24 LDS instructions per 32-token tile and wave, hidden under the byte stream.
+template <int DTYPE, int D, typename IdxT, bool DIRECT_OUT, int kWaves, int KV8 = 0>
 __global__ __launch_bounds__(kWaves * 64) void decode_mfma_kernel(DecodeArgs a) {
   using H = Half16<DTYPE>;
   using T = typename H::T;
@@ -110,6 +141,14 @@ __global__ __launch_bounds__(kWaves * 64) void decode_mfma_kernel(DecodeArgs a) 
   constexpr int WAVE_BYTES = kStages * STAGE_BYTES;
   constexpr int KS = D / 32;                // MFMA k-steps for QK^T
   constexpr int NDV = D / 16;               // 16-wide output column blocks
+  // KV8: byte rows of D bytes; 1024 / D rows per DMA instruction; staging tile = kTile * D bytes
+  constexpr int KVB = KV8 ? 1 : 2;          // bytes per pool element
+  constexpr int CH8 = D / 16;               // 16-B chunks per byte row
+  constexpr int ROWS8 = 1024 / D;
+  constexpr int NI8 = kTile / ROWS8;
+  constexpr int TILE8 = kTile * D;
+  constexpr int NIQ = KV8 ? NI8 : NI;       // DMA instructions per K (or V) tile in the vmcnt queue
+  static_assert(!KV8 || 2 * TILE_BYTES + 4 * TILE8 <= WAVE_BYTES, "KV8 ring layout");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int kIdxCap = (kWaves == 4) ? 4 * kMaxIdx : kMaxIdx;
@@ -171,10 +210,10 @@ __global__ __launch_bounds__(kWaves * 64) void decode_mfma_kernel(DecodeArgs a) 
     for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
   }
 
-  const char* kbase = reinterpret_cast<const char*>(a.k) + (int64_t)kvh * a.k_sh * 2;
-  const char* vbase = reinterpret_cast<const char*>(a.v) + (int64_t)kvh * a.v_sh * 2;
-  const int64_t k_row_bytes = a.k_sn * 2;
-  const int64_t v_row_bytes = a.v_sn * 2;
+  const char* kbase = reinterpret_cast<const char*>(a.k) + (int64_t)kvh * a.k_sh * KVB;
+  const char* vbase = reinterpret_cast<const char*>(a.v) + (int64_t)kvh * a.v_sh * KVB;
+  const int64_t k_row_bytes = a.k_sn * KVB;
+  const int64_t v_row_bytes = a.v_sn * KVB;
   char* wave_lds = smem + wave * WAVE_BYTES;
 
   // DMA source mapping of this lane: row within a piece and the (unswizzled) chunk it fetches
@@ -205,10 +244,24 @@ __global__ __launch_bounds__(kWaves * 64) void decode_mfma_kernel(DecodeArgs a) 
 
     auto issue = [&](int jt, int stage, bool is_v) {
       const int tok0 = (wave + kWaves * jt) * kTile;
-      const uint32_t dst = __builtin_amdgcn_readfirstlane(
-          lds_addr_of(wave_lds + stage * STAGE_BYTES + (is_v ? TILE_BYTES : 0)));
       const char* gb = is_v ? vbase : kbase;
       const int64_t rb = is_v ? v_row_bytes : k_row_bytes;
+      if constexpr (KV8) {  // byte rows, linear staging image: lane i of an instruction = row i / CH8, chunk i % CH8
+        const uint32_t dst8 = __builtin_amdgcn_readfirstlane(
+            lds_addr_of(wave_lds + 2 * TILE_BYTES + stage * 2 * TILE8 + (is_v ? TILE8 : 0)));
+        int32_t tok8[NI8];
+#pragma unroll
+        for (int i = 0; i < NI8; ++i) {
+          int tp = tok0 + i * ROWS8 + lane / CH8;
+          tp = tp < n_pass ? tp : n_pass - 1;
+          tok8[i] = idx_lds[tp];
+        }
+#pragma unroll
+        for (int i = 0; i < NI8; ++i) lds_dma16(gb + (int64_t)tok8[i] * rb + (lane % CH8) * 16, dst8 + i * 1024);
+        return;
+      }
+      const uint32_t dst = __builtin_amdgcn_readfirstlane(
+          lds_addr_of(wave_lds + stage * STAGE_BYTES + (is_v ? TILE_BYTES : 0)));
       int32_t tok[NI];
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
@@ -232,16 +285,45 @@ __global__ __launch_bounds__(kWaves * 64) void decode_mfma_kernel(DecodeArgs a) 
       issue(1, 1, true);
     }
 
+    // KV8: staged byte tile -> the 16-bit tile in the ring's swizzled layout (same wave writes and reads it: LDS
+    // operations of a wave execute in order, no barrier)
+    auto convert = [&](int stage, bool is_v) {
+      const char* src = wave_lds + 2 * TILE_BYTES + stage * 2 * TILE8 + (is_v ? TILE8 : 0);
+      char* dst = wave_lds + (is_v ? TILE_BYTES : 0);
+#pragma unroll
+      for (int i = 0; i < NI8; ++i) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(src + i * 1024 + lane * 16);
+        x8 lo, hi;
+        cvt16_fp8<DTYPE>(raw, lo, hi);
+        const int row = i * ROWS8 + lane / CH8, pos = lane % CH8;
+        *reinterpret_cast<x8*>(dst + row * ROWB + swz_chunk<D>(2 * pos, row) * 16) = lo;
+        *reinterpret_cast<x8*>(dst + row * ROWB + swz_chunk<D>(2 * pos + 1, row) * 16) = hi;
+      }
+    };
+
     for (int jt = 0; jt < nt; ++jt) {
       const int st = jt & 1;
-      const char* kst = wave_lds + st * STAGE_BYTES;
+      const char* kst = KV8 ? wave_lds : wave_lds + st * STAGE_BYTES;
       const char* vst = kst + TILE_BYTES;
       const int tok0 = (wave + kWaves * jt) * kTile;
       const bool more1 = jt + 1 < nt;
       const bool more2 = jt + 2 < nt;
 
-      // ---- wait for K(jt): younger ops allowed in flight = V(jt) [+ K,V(jt+1)]
-      if (more1) wait_vmcnt<3 * NI>(); else wait_vmcnt<NI>();
+      if constexpr (KV8) {
+        // one wave per SIMD: every dependent LDS phase is exposed, so K and V of the tile are converted together
+        // (one read phase, one write phase) and the two refills go out right behind them
+        if (more1) wait_vmcnt<2 * NIQ>(); else wait_vmcnt<0>();  // K8(jt) and V8(jt) landed
+        convert(st, false);
+        convert(st, true);
+        wait_lgkmcnt0();  // the staging slots are free
+        if (more2) {
+          issue(jt + 2, st, false);
+          issue(jt + 2, st, true);
+        }
+      } else {
+        // ---- wait for K(jt): younger ops allowed in flight = V(jt) [+ K,V(jt+1)]
+        if (more1) wait_vmcnt<3 * NIQ>(); else wait_vmcnt<NIQ>();
+      }
 
       // ---- S^T = K Q^T  (rows = tokens, cols = heads)
       f32x4 s_acc[2];
@@ -257,7 +339,9 @@ __global__ __launch_bounds__(kWaves * 64) void decode_mfma_kernel(DecodeArgs a) 
         }
       }
       wait_lgkmcnt0();  // K fragments are in registers: the K buffer may be refilled
-      if (more2) issue(jt + 2, st, false);
+      if constexpr (!KV8) {
+        if (more2) issue(jt + 2, st, false);
+      }
 
       // ---- online softmax (log2 domain); token of (th, r) = tok0 + 16*th + 4*g + r
       float sv[8];
@@ -288,8 +372,8 @@ __global__ __launch_bounds__(kWaves * 64) void decode_mfma_kernel(DecodeArgs a) 
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const float p = exp2f(sv[i] - m_new);
-        psum += p;
-        pf[i] = H::from_f32(p);
+        psum += p;  // the row sum keeps the unrounded p (decode_attention.py:375)
+        pf[i] = H::from_f32(KV8 ? round_fp8(p) : p);
       }
       l_run = l_run * alpha + psum;
       m_run = m_new;
@@ -297,7 +381,9 @@ __global__ __launch_bounds__(kWaves * 64) void decode_mfma_kernel(DecodeArgs a) 
       for (int i = 0; i < NDV; ++i) o_acc[i] *= alpha;
 
       // ---- wait for V(jt): younger ops allowed = [K,V(jt+1)] [+ K(jt+2)]
-      if (more2) wait_vmcnt<3 * NI>(); else if (more1) wait_vmcnt<2 * NI>(); else wait_vmcnt<0>();
+      if constexpr (!KV8) {
+        if (more2) wait_vmcnt<3 * NIQ>(); else if (more1) wait_vmcnt<2 * NIQ>(); else wait_vmcnt<0>();
+      }
 
       // ---- O^T += V^T P^T ; k-slot (g, j): j<4 -> token 4g+j, j>=4 -> token 16+4g+(j-4)
       {
@@ -320,7 +406,9 @@ __global__ __launch_bounds__(kWaves * 64) void decode_mfma_kernel(DecodeArgs a) 
         }
       }
       wait_lgkmcnt0();  // V fragments are in registers: the V buffer may be refilled
-      if (more2) issue(jt + 2, st, true);
+      if constexpr (!KV8) {
+        if (more2) issue(jt + 2, st, true);
+      }
     }
   }
 
@@ -505,9 +593,9 @@ int set_max_lds(K kernel, int bytes) {
       "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
 }
 
-template <int DTYPE, int D, typename IdxT, bool DIRECT, int kWaves>
+template <int DTYPE, int D, typename IdxT, bool DIRECT, int kWaves, int KV8 = 0>
 int launch_mfma_w(const DecodeArgs& a, int64_t grid, hipStream_t stream) {
-  auto kern = decode_mfma_kernel<DTYPE, D, IdxT, DIRECT, kWaves>;
+  auto kern = decode_mfma_kernel<DTYPE, D, IdxT, DIRECT, kWaves, KV8>;
   constexpr int lds = mfma_lds_bytes<D, kWaves>();
   static int attr_rc = set_max_lds(kern, lds);
   if (attr_rc != 0) return attr_rc;
@@ -519,6 +607,7 @@ template <int DTYPE, int D, typename IdxT, bool DIRECT>
 int launch_mfma(const DecodeArgs& a, int64_t batch, hipStream_t stream) {
   const int nhb = (a.group + 15) / 16;
   const int64_t grid = batch * a.num_kv_heads * nhb * a.num_splits;
+  if (a.kv8) return launch_mfma_w<DTYPE, D, IdxT, DIRECT, 4, 1>(a, grid, stream);
   return pick_waves(grid) == 2 ? launch_mfma_w<DTYPE, D, IdxT, DIRECT, 2>(a, grid, stream)
                                : launch_mfma_w<DTYPE, D, IdxT, DIRECT, 4>(a, grid, stream);
 }
@@ -536,6 +625,11 @@ int dispatch_stage1(const DecodeArgs& a, int64_t batch, int D, int Dv, bool dire
                        (a.v_sn % 8 == 0) && (a.v_sh % 8 == 0) &&
                        (reinterpret_cast<uintptr_t>(a.q) % 16 == 0) && (reinterpret_cast<uintptr_t>(a.k) % 16 == 0) &&
                        (reinterpret_cast<uintptr_t>(a.v) % 16 == 0);
+  if (a.kv8 && !(D == Dv && (D == 128 || D == 64) && (a.k_sn % 16 == 0) && (a.k_sh % 16 == 0) && (a.v_sn % 16 == 0) &&
+                 (a.v_sh % 16 == 0) && aligned)) {
+    set_error("decode_attention: the FP8 KV cache path needs head sizes 64 / 128 (D == Dv) and 16-byte aligned rows");
+    return SGL_MI355_ERR_UNSUPPORTED;
+  }
   if (D == Dv && aligned && (D == 128 || D == 64)) {
     if (D == 128)
       return direct ? launch_mfma<DTYPE, 128, IdxT, true>(a, batch, stream)
@@ -576,6 +670,9 @@ int check_common(
 
 using namespace sglm;
 
+// set by the *_fp8kv entry points around a call of the regular ones (same argument list, pool = e4m3 bytes)
+static thread_local int tl_kv8 = 0;
+
 extern "C" int sgl_mi355_decode_attention(
     const void* query, void* k_cache, void* v_cache, void* output, const void* key, const void* value,
     const int64_t* loc, float* attn_logits, const void* req_to_token, int req_to_token_is64,
@@ -590,6 +687,7 @@ extern "C" int sgl_mi355_decode_attention(
   SGLM_CHECK_ARG(query && k_cache && v_cache && output && req_to_token && req_pool_indices && seq_lens,
                  "decode_attention: null tensor pointer");
   SGLM_CHECK_ARG(attn_logits != nullptr || num_kv_splits == 1, "decode_attention: attn_logits is required when num_kv_splits > 1");
+  SGLM_CHECK_ARG(!(tl_kv8 && loc != nullptr), "decode_attention_fp8kv: write the pool with set_kv_buffer_fp8 (loc must be null)");
   if (loc != nullptr) {
     SGLM_CHECK_ARG(key && value, "decode_attention: key/value are required when loc is given");
     rc = sgl_mi355_set_kv_buffer(k_cache, v_cache, key, value, loc, 1, num_seqs, num_kv_heads, head_size, head_size_v,
@@ -611,7 +709,7 @@ extern "C" int sgl_mi355_decode_attention(
   a.num_kv_splits = nullptr; a.num_splits = (int)num_kv_splits;
   a.split_align = 1;  // SPLIT_SIZE = div_up(seq_len, num_kv_splits) (decode.cpp:916)
   a.num_heads = (int)num_heads; a.num_kv_heads = (int)num_kv_heads; a.group = (int)(num_heads / num_kv_heads);
-  a.sm_scale = sm_scale; a.logit_cap = logit_cap;
+  a.sm_scale = sm_scale; a.logit_cap = logit_cap; a.kv8 = tl_kv8;
   hipStream_t s = as_stream(stream);
   return dtype == SGL_MI355_BF16
              ? run_decode<SGL_MI355_BF16>(a, num_seqs, (int)head_size, (int)head_size_v, req_to_token_is64 != 0, s)
@@ -643,8 +741,43 @@ extern "C" int sgl_mi355_decode_attention_fwd(
   a.num_kv_splits = num_kv_splits; a.num_splits = (int)max_kv_splits;
   a.split_align = 32;  // _MIN_BLOCK_KV (decode_attention.py:303-307)
   a.num_heads = (int)num_heads; a.num_kv_heads = (int)num_kv_heads; a.group = (int)(num_heads / num_kv_heads);
-  a.sm_scale = sm_scale; a.logit_cap = logit_cap;
+  a.sm_scale = sm_scale; a.logit_cap = logit_cap; a.kv8 = tl_kv8;
   hipStream_t s = as_stream(stream);
   return dtype == SGL_MI355_BF16 ? run_decode<SGL_MI355_BF16>(a, batch, (int)head_size, (int)head_size_v, false, s)
                                  : run_decode<SGL_MI355_FP16>(a, batch, (int)head_size, (int)head_size_v, false, s);
+}
+
+// FP8 (e4m3fn) KV pool: identical argument lists, k/v pointers address bytes and their strides count bytes.
+extern "C" int sgl_mi355_decode_attention_fp8kv(
+    const void* query, void* k_cache, void* v_cache, void* output, float* attn_logits, const void* req_to_token,
+    int req_to_token_is64, const int64_t* req_pool_indices, const int64_t* seq_lens, int64_t num_seqs,
+    int64_t max_context_len, int64_t num_heads, int64_t num_kv_heads, int64_t head_size, int64_t head_size_v,
+    int64_t num_kv_splits, int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h,
+    int64_t v_stride_n, int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h, float sm_scale, float logit_cap,
+    int dtype, void* stream) {
+  tl_kv8 = 1;
+  const int rc = sgl_mi355_decode_attention(query, k_cache, v_cache, output, nullptr, nullptr, nullptr, attn_logits,
+                                            req_to_token, req_to_token_is64, req_pool_indices, seq_lens, num_seqs,
+                                            max_context_len, num_heads, num_kv_heads, head_size, head_size_v,
+                                            num_kv_splits, q_stride_b, q_stride_h, k_stride_n, k_stride_h, v_stride_n,
+                                            v_stride_h, 0, 0, 0, 0, o_stride_b, o_stride_h, sm_scale, logit_cap, dtype,
+                                            stream);
+  tl_kv8 = 0;
+  return rc;
+}
+
+extern "C" int sgl_mi355_decode_attention_fwd_fp8kv(
+    const void* q, const void* k_buffer, const void* v_buffer, void* o, const int32_t* kv_indptr,
+    const int32_t* kv_indices, float* attn_logits, float* attn_lse, const int32_t* num_kv_splits,
+    int64_t max_kv_splits, int64_t batch, int64_t num_heads, int64_t num_kv_heads, int64_t head_size,
+    int64_t head_size_v, int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h,
+    int64_t v_stride_n, int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h, float sm_scale, float logit_cap,
+    int dtype, void* stream) {
+  tl_kv8 = 1;
+  const int rc = sgl_mi355_decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_logits, attn_lse,
+                                                num_kv_splits, max_kv_splits, batch, num_heads, num_kv_heads, head_size,
+                                                head_size_v, q_stride_b, q_stride_h, k_stride_n, k_stride_h, v_stride_n,
+                                                v_stride_h, o_stride_b, o_stride_h, sm_scale, logit_cap, dtype, stream);
+  tl_kv8 = 0;
+  return rc;
 }

@@ -53,6 +53,38 @@ __global__ __launch_bounds__(256) void set_kv_kernel_u16(
   for (int i = lane; i < Dv; i += 64) vb[slot * v_sn + h * v_sh + i] = val[t * nv_sn + h * nv_sh + i];
 }
 
+// FP8 (e4m3fn) pool: cast of the 16-bit new entries (memory_pool.py:385-394: optional x.div_(scale) in the 16-bit
+// dtype, then .to(fp8), stored through a uint8 view).  Saturating RNE cast (v_cvt_pk_fp8_f32); one wave per row.
+template <int DTYPE, typename LocT>
+__global__ __launch_bounds__(256) void set_kv_fp8_kernel(
+    uint8_t* __restrict__ kb, uint8_t* __restrict__ vb, const typename Half16<DTYPE>::T* __restrict__ key,
+    const typename Half16<DTYPE>::T* __restrict__ val, const LocT* __restrict__ loc, int64_t rows, int num_kv_heads,
+    int D, int Dv, int64_t k_sn, int64_t k_sh, int64_t v_sn, int64_t v_sh, int64_t nk_sn, int64_t nk_sh, int64_t nv_sn,
+    int64_t nv_sh, float k_scale, float v_scale) {
+  using Hh = Half16<DTYPE>;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int64_t t = row / num_kv_heads;
+  const int h = (int)(row - t * num_kv_heads);
+  const int64_t slot = (int64_t)loc[t];
+  auto cast_row = [&](const typename Hh::T* src, uint8_t* dst, int n, float scale) {
+    for (int i = 2 * lane; i < n; i += 128) {  // two elements per lane and step (n is even)
+      float a = Hh::to_f32(src[i]), b = Hh::to_f32(src[i + 1]);
+      if (scale > 0.f) {
+        a = Hh::to_f32(Hh::from_f32(a / scale));
+        b = Hh::to_f32(Hh::from_f32(b / scale));
+      }
+      a = fminf(fmaxf(a, -448.f), 448.f);
+      b = fminf(fmaxf(b, -448.f), 448.f);
+      const int pk = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+      *reinterpret_cast<uint16_t*>(dst + i) = (uint16_t)(pk & 0xFFFF);
+    }
+  };
+  cast_row(key + t * nk_sn + h * nk_sh, kb + slot * k_sn + h * k_sh, D, k_scale);
+  cast_row(val + t * nv_sn + h * nv_sh, vb + slot * v_sn + h * v_sh, Dv, v_scale);
+}
+
 template <typename T>
 __device__ __forceinline__ int64_t ld_idx(const void* p, int64_t i, int is64) {
   return is64 ? reinterpret_cast<const int64_t*>(p)[i] : (int64_t) reinterpret_cast<const int32_t*>(p)[i];
@@ -141,4 +173,35 @@ extern "C" int sgl_mi355_create_kv_indices(
                      req_to_token_stride, req_pool_indices, req_pool_indices_is64, page_kernel_lens,
                      page_kernel_lens_is64, kv_indptr, kv_start_idx, kv_start_idx_is64, kv_indices);
   return check_hip(hipGetLastError(), "create_kv_indices launch");
+}
+
+extern "C" int sgl_mi355_set_kv_buffer_fp8(
+    void* k_buffer, void* v_buffer, const void* loc, int loc_is64, const void* key, const void* value,
+    int64_t num_tokens, int64_t num_kv_heads, int64_t head_size, int64_t head_size_v, int64_t k_stride_n,
+    int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h, int64_t key_stride_n, int64_t key_stride_h,
+    int64_t value_stride_n, int64_t value_stride_h, float k_scale, float v_scale, int dtype, void* stream) {
+  SGLM_CHECK_ARG(dtype == SGL_MI355_BF16 || dtype == SGL_MI355_FP16, "set_kv_buffer_fp8: source dtype must be bf16 or fp16");
+  SGLM_CHECK_ARG(num_tokens >= 0 && num_kv_heads > 0 && head_size > 0 && head_size_v > 0 && head_size % 2 == 0 &&
+                     head_size_v % 2 == 0,
+                 "set_kv_buffer_fp8: bad shape (head sizes must be even)");
+  SGLM_CHECK_ARG(k_stride_n % 2 == 0 && k_stride_h % 2 == 0 && v_stride_n % 2 == 0 && v_stride_h % 2 == 0,
+                 "set_kv_buffer_fp8: pool strides must be even");
+  if (num_tokens == 0) return 0;
+  SGLM_CHECK_ARG(k_buffer && v_buffer && loc && key && value, "set_kv_buffer_fp8: null tensor pointer");
+  const int64_t rows = num_tokens * num_kv_heads;
+  SGLM_CHECK_ARG(rows < (1ll << 33), "set_kv_buffer_fp8: too many rows");
+  const unsigned grid = (unsigned)((rows + 3) / 4);
+  hipStream_t s = as_stream(stream);
+#define SETKV8(DT, TT, LT)                                                                                            \
+  hipLaunchKernelGGL((set_kv_fp8_kernel<DT, LT>), dim3(grid), dim3(256), 0, s, (uint8_t*)k_buffer, (uint8_t*)v_buffer, \
+                     (const TT*)key, (const TT*)value, (const LT*)loc, rows, (int)num_kv_heads, (int)head_size,        \
+                     (int)head_size_v, k_stride_n, k_stride_h, v_stride_n, v_stride_h, key_stride_n, key_stride_h,    \
+                     value_stride_n, value_stride_h, k_scale, v_scale)
+  if (dtype == SGL_MI355_BF16) {
+    if (loc_is64) SETKV8(SGL_MI355_BF16, __bf16, int64_t); else SETKV8(SGL_MI355_BF16, __bf16, int32_t);
+  } else {
+    if (loc_is64) SETKV8(SGL_MI355_FP16, _Float16, int64_t); else SETKV8(SGL_MI355_FP16, _Float16, int32_t);
+  }
+#undef SETKV8
+  return check_hip(hipGetLastError(), "set_kv_buffer_fp8 launch");
 }

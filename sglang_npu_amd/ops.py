@@ -133,6 +133,37 @@ def decode_attention(query, k_cache, v_cache, output, key, value, loc, attn_logi
         _F(sm_scale), _F(logit_cap), _I(_dtype_code(query)), _stream(query)))
 
 
+_FP8_KV = (torch.float8_e4m3fn, torch.uint8)  # an e4m3 pool is stored through a uint8 view (memory_pool.py:114-118)
+
+
+def _is_fp8_pool(k_buffer, v_buffer, q) -> bool:
+    """FP8 (e4m3fn) KV pool next to 16-bit queries; float8_e5m2 pools are not supported."""
+    if k_buffer.dtype == q.dtype and v_buffer.dtype == q.dtype:
+        return False
+    if k_buffer.dtype in _FP8_KV and v_buffer.dtype in _FP8_KV:
+        return True
+    raise NotImplementedError(f"KV pool dtype {k_buffer.dtype}/{v_buffer.dtype} with {q.dtype} queries is not "
+                              "supported (16-bit pools, or float8_e4m3fn / its uint8 view)")
+
+
+def set_kv_buffer_fp8(k_buffer, v_buffer, loc, cache_k, cache_v, k_scale=None, v_scale=None):
+    """MHATokenToKVPool.set_kv_buffer for a float8_e4m3fn pool (memory_pool.py:385-394): optional x.div_(scale) in the
+    16-bit dtype, cast to e4m3 (saturating), store."""
+    _need_gpu(k_buffer, v_buffer, loc, cache_k, cache_v)
+    if k_buffer.dtype not in _FP8_KV or v_buffer.dtype not in _FP8_KV:
+        raise RuntimeError("set_kv_buffer_fp8: the pool must be float8_e4m3fn (or its uint8 view)")
+    for t in (k_buffer, v_buffer, cache_k, cache_v):
+        if t.dim() != 3 or t.stride(-1) != 1:
+            raise RuntimeError("set_kv_buffer_fp8: expected [N,H,D] pool and [T,H,D] new entries, last dim contiguous")
+    T, Hkv, D = cache_k.shape
+    _lib.check(_lib.lib().sgl_mi355_set_kv_buffer_fp8(
+        _ptr(k_buffer), _ptr(v_buffer), _ptr(loc), _I(_is64(loc, "loc")), _ptr(cache_k), _ptr(cache_v), _I64(T),
+        _I64(Hkv), _I64(D), _I64(cache_v.size(2)), _I64(k_buffer.stride(0)), _I64(k_buffer.stride(1)),
+        _I64(v_buffer.stride(0)), _I64(v_buffer.stride(1)), _I64(cache_k.stride(0)), _I64(cache_k.stride(1)),
+        _I64(cache_v.stride(0)), _I64(cache_v.stride(1)), _F(float(k_scale) if k_scale else 0.0),
+        _F(float(v_scale) if v_scale else 0.0), _I(_dtype_code(cache_k)), _stream(cache_k)))
+
+
 def decode_attention_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens, attn_logits,
                            num_kv_splits, sm_scale, logit_cap=0.0):
     """Decode straight from the request page table (no flattened kv_indices, no KV write): the form
@@ -154,6 +185,15 @@ def decode_attention_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_indi
                                "[B, Hq, num_kv_splits, Dv+1]")
     if req_to_token.dim() != 2 or req_to_token.stride(1) != 1 or req_to_token.stride(0) != req_to_token.size(1):
         raise RuntimeError("decode_attention_paged: req_to_token must be a contiguous 2-D tensor")
+    if _is_fp8_pool(k_buffer, v_buffer, q):
+        _lib.check(_lib.lib().sgl_mi355_decode_attention_fp8kv(
+            _ptr(q), _ptr(k_buffer), _ptr(v_buffer), _ptr(o), _ptr(attn_logits), _ptr(req_to_token),
+            _I(_is64(req_to_token, "req_to_token")), _ptr(req_pool_indices), _ptr(seq_lens), _I64(B),
+            _I64(req_to_token.size(1)), _I64(Hq), _I64(k_buffer.size(1)), _I64(D), _I64(Dv), _I64(num_kv_splits),
+            _I64(q.stride(0)), _I64(q.stride(1)), _I64(k_buffer.stride(0)), _I64(k_buffer.stride(1)),
+            _I64(v_buffer.stride(0)), _I64(v_buffer.stride(1)), _I64(o.stride(0)), _I64(o.stride(1)),
+            _F(sm_scale), _F(logit_cap), _I(_dtype_code(q)), _stream(q)))
+        return
     _lib.check(_lib.lib().sgl_mi355_decode_attention(
         _ptr(q), _ptr(k_buffer), _ptr(v_buffer), _ptr(o), None, None, None,
         _ptr(attn_logits), _ptr(req_to_token), _I(_is64(req_to_token, "req_to_token")),
@@ -182,7 +222,9 @@ def decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_l
     for name, t in (("q", q), ("k_buffer", k_buffer), ("v_buffer", v_buffer), ("o", o)):
         if t.dim() != 3 or t.stride(-1) != 1:
             raise RuntimeError(f"decode_attention_fwd: {name} must be 3-D, contiguous at the last dimension")
-    _lib.check(_lib.lib().sgl_mi355_decode_attention_fwd(
+    fn = _lib.lib().sgl_mi355_decode_attention_fwd_fp8kv if _is_fp8_pool(k_buffer, v_buffer, q) \
+        else _lib.lib().sgl_mi355_decode_attention_fwd
+    _lib.check(fn(
         _ptr(q), _ptr(k_buffer), _ptr(v_buffer), _ptr(o), _ptr(kv_indptr), _ptr(kv_indices),
         _ptr(attn_logits), _ptr(attn_lse), _ptr(num_kv_splits), _I64(max_kv_splits),
         _I64(q.size(0)), _I64(q.size(1)), _I64(k_buffer.size(1)), _I64(q.size(2)), _I64(v_buffer.size(2)),
@@ -222,6 +264,12 @@ def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buf
         raise RuntimeError("extend_attention_fwd: qo_indptr, kv_indptr and kv_indices must be int32")
     D = q_extend.size(2)
     sm_scale = sm_scale if sm_scale is not None else 1.0 / (D ** 0.5)
+    if k_buffer.dtype != q_extend.dtype and _is_fp8_pool(k_buffer, v_buffer, q_extend):
+        # FP8 KV pool: the prefix stage over FP8 rows (q and p rounded to FP8, extend_attention.py:149,199) is not built
+        # yet; prefills without a cached prefix never touch the pool, so they run on the 16-bit kernel as they are
+        if int(kv_indptr[-1].item()) != 0:
+            raise NotImplementedError("extend_attention_fwd: a cached prefix in an FP8 KV pool is not supported yet")
+        k_buffer, v_buffer = k_extend, v_extend  # placeholders, never dereferenced (no prefix rows)
     _lib.check(_lib.lib().sgl_mi355_extend_attention_fwd(
         _ptr(q_extend), _ptr(k_extend), _ptr(v_extend), _ptr(o_extend), _ptr(k_buffer), _ptr(v_buffer),
         _ptr(qo_indptr), _ptr(kv_indptr), _ptr(kv_indices), _I(1 if is_causal else 0), _I64(max_len_extend),
