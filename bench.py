@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--model", default="llama3-8b", choices=["llama3-8b", "llama3-70b", "llama2-7b", "qwen2-0.5b"])
     ap.add_argument("--quant", default="w8a8_fp8", choices=["w8a8_fp8", "awq", "none"])
     ap.add_argument("--layers", type=int, default=None, help="override the layer count (debug only; invalidates the number)")
+    ap.add_argument("--kv-dtype", default="auto", choices=["auto", "fp8_e4m3"],
+                    help="KV pool dtype (server_args.py --kv-cache-dtype); the headline number is 'auto' = the model dtype")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -67,11 +69,17 @@ def build(args, device, tp):
     n_tok = B * max_len + 1
     hkv = cfg.get_num_kv_heads(tp)
     r2t_pool = ReqToTokenPool(B, max_len, str(device))
-    kv_pool = MHATokenToKVPool(n_tok, 1, dtype, hkv, cfg.head_dim, n_layers, str(device))
+    kv_dtype = torch.float8_e4m3fn if args.kv_dtype == "fp8_e4m3" else dtype
+    kv_pool = MHATokenToKVPool(n_tok, 1, kv_dtype, hkv, cfg.head_dim, n_layers, str(device))
     g = torch.Generator(device=device).manual_seed(1234)
     for l in range(n_layers):  # KV of the already-decoded context: N(0,1) like the reference's kernel tests
-        kv_pool.k_buffer[l].normal_(generator=g)
-        kv_pool.v_buffer[l].normal_(generator=g)
+        if kv_dtype == dtype:
+            kv_pool.k_buffer[l].normal_(generator=g)
+            kv_pool.v_buffer[l].normal_(generator=g)
+        else:  # uint8 storage of e4m3 values
+            for buf in (kv_pool.k_buffer[l], kv_pool.v_buffer[l]):
+                buf.copy_(torch.randn(buf.shape, device=device, generator=g, dtype=torch.bfloat16)
+                          .to(torch.float8_e4m3fn).view(torch.uint8))
     # token-level page table = one random permutation of the pool (slot 0 stays the padding slot)
     perm = (torch.randperm(n_tok - 1, device=device, generator=g) + 1).to(torch.int32)
     r2t_pool.req_to_token.copy_(perm[: B * max_len].view(B, max_len))
@@ -341,7 +349,8 @@ def main():
     hq, hkv, d = cfg.num_attention_heads // tp, cfg.get_num_kv_heads(tp), cfg.head_dim
     attn_ms, n_launch = time_attention_kernel(loop, min(args.steps, 8))
     ctx_mid = args.ctx + args.warmup + args.steps + min(args.steps, 8) / 2
-    alg_bytes = args.batch * ctx_mid * hkv * 2 * d * 2 + 4 * args.batch * ctx_mid + 2 * args.batch * hq * 2 * d
+    kv_esz = 1 if args.kv_dtype == "fp8_e4m3" else 2
+    alg_bytes = args.batch * ctx_mid * hkv * 2 * d * kv_esz + 4 * args.batch * ctx_mid + 2 * args.batch * hq * 2 * d
     achieved = alg_bytes / (attn_ms * 1e-3) / 1e9
     # HBM traffic of that kernel from the committed rocprofv3 --pmc passes (bench.py cannot run the profiler on
     # itself): measured bytes / algorithmic bytes of the same kernel at the same geometry, applied to this launch.
@@ -349,7 +358,7 @@ def main():
     try:
         pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
                                           "r01_decode_pmc_summary.json")))
-        if tp == 1 and args.batch == 64 and (hq, hkv, d) == (32, 8, 128):
+        if tp == 1 and args.batch == 64 and (hq, hkv, d) == (32, 8, 128) and kv_esz == 2:
             traffic = int(alg_bytes * pmc["traffic_over_algorithmic"])
             traffic_src = ("profiles/r01_decode_pmc_summary.json: FETCH_SIZE x2 (gfx950) + WRITE_SIZE, separate --pmc "
                            f"passes, ratio {pmc['traffic_over_algorithmic']} to algorithmic bytes at bs=64 ctx=2048")
@@ -359,7 +368,8 @@ def main():
         "metric": "output tokens/s (decode, whole model step) + p50 TTFT", "value": round(value, 1), "unit": "tokens/s",
         "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "fp8_e4m3 (GEMM) / bf16 (attention, KV)" if args.quant == "w8a8_fp8" else args.quant,
+        "dtype": ("fp8_e4m3 (GEMM) / bf16 (attention" + (", KV)" if kv_esz == 2 else "), fp8_e4m3 KV"))
+        if args.quant == "w8a8_fp8" else args.quant,
         "data": "synthetic (dummy-loader random weights, N(0,1) KV, random-permutation page table)",
         "config": {"workload": f"{args.model} {args.quant} decode bs={args.batch} ctx={args.ctx} TP={tp} "
                                f"(token-level paged KV, {'HIP graph replay' if loop.graph is not None else 'eager launches'})",
