@@ -83,6 +83,8 @@ def set_kv_buffer(k_buffer, v_buffer, loc, cache_k, cache_v):
             raise RuntimeError("set_kv_buffer: last dim must be contiguous")
     if cache_k.dtype != k_buffer.dtype or cache_v.dtype != v_buffer.dtype:
         raise RuntimeError("set_kv_buffer: dtype of new entries must match the pool")
+    if loc.dim() != 1 or loc.numel() > cache_k.size(0) or loc.numel() > cache_v.size(0):
+        raise RuntimeError("set_kv_buffer: loc must be 1-D with at most one slot per new token")
     _lib.check(_lib.lib().sgl_mi355_set_kv_buffer(
         _ptr(k_buffer), _ptr(v_buffer), _ptr(cache_k), _ptr(cache_v), _ptr(loc), _I(_is64(loc, "loc")),
         _I64(loc.numel()), _I64(k_buffer.size(1)), _I64(k_buffer.size(2)), _I64(v_buffer.size(2)),
@@ -156,6 +158,8 @@ def set_kv_buffer_fp8(k_buffer, v_buffer, loc, cache_k, cache_v, k_scale=None, v
         if t.dim() != 3 or t.stride(-1) != 1:
             raise RuntimeError("set_kv_buffer_fp8: expected [N,H,D] pool and [T,H,D] new entries, last dim contiguous")
     T, Hkv, D = cache_k.shape
+    if loc.dim() != 1 or loc.numel() != T or cache_v.size(0) != T:
+        raise RuntimeError("set_kv_buffer_fp8: loc must hold one slot per new token")
     _lib.check(_lib.lib().sgl_mi355_set_kv_buffer_fp8(
         _ptr(k_buffer), _ptr(v_buffer), _ptr(loc), _I(_is64(loc, "loc")), _ptr(cache_k), _ptr(cache_v), _I64(T),
         _I64(Hkv), _I64(D), _I64(cache_v.size(2)), _I64(k_buffer.stride(0)), _I64(k_buffer.stride(1)),

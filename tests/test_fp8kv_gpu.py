@@ -88,3 +88,71 @@ def test_fp8_pool_unsupported_shapes_raise():
                                    torch.zeros(1, 2, 128, dtype=torch.bfloat16, device=DEV),
                                    torch.zeros(1, 4, dtype=torch.int32, device=DEV), torch.zeros(1, dtype=torch.int64, device=DEV),
                                    torch.ones(1, dtype=torch.int64, device=DEV), None, 1, 1.0, 0.0)
+
+
+def test_backend_prefill_then_decode_with_fp8_pool():
+    """MI355AttnBackend on an FP8 pool: EXTEND without a cached prefix (16-bit kernel on the new tokens, K/V cast into
+    the pool), then DECODE steps reading the byte rows; a cached prefix is refused for now."""
+    from sglang_npu_amd.attention_backend import MI355AttnBackend
+    from sglang_npu_amd.harness import (ForwardBatch, ForwardMode, MHATokenToKVPool, ModelConfig, ModelRunnerLike,
+                                        RadixAttention, ReqToTokenPool, ServerArgs)
+    B, Hq, Hkv, D, max_len = 2, 8, 2, 128, 200
+    cfg = ModelConfig(Hq, Hkv, D, Hq * D, 4 * Hq * D, 1, 1000, max_len)
+    r2t = ReqToTokenPool(B, max_len, DEV)
+    n_tok = B * max_len + 1
+    pool = MHATokenToKVPool(n_tok, 1, torch.float8_e4m3fn, Hkv, D, 1, DEV)
+    assert pool.k_buffer[0].dtype == torch.uint8 and pool.get_key_buffer(0).dtype == torch.float8_e4m3fn
+    g = torch.Generator(device=DEV).manual_seed(0)
+    r2t.req_to_token.copy_((torch.randperm(n_tok - 1, device=DEV, generator=g) + 1)[: B * max_len].view(B, max_len).int())
+    backend = MI355AttnBackend(ModelRunnerLike(cfg, r2t, pool, DEV, 0, 1, ServerArgs()))
+    layer = RadixAttention(Hq, D, D ** -0.5, Hkv, layer_id=0)
+    ext = torch.tensor([90, 41], device=DEV)
+    seq, prefix = ext.clone(), torch.zeros_like(ext)
+    T = int(ext.sum())
+    q = torch.randn(T, Hq * D, device=DEV, generator=g).bfloat16()
+    k = torch.randn(T, Hkv * D, device=DEV, generator=g).bfloat16()
+    v = torch.randn(T, Hkv * D, device=DEV, generator=g).bfloat16()
+    rpi = torch.arange(B, device=DEV)
+    start = torch.tensor([0, 90], device=DEV)
+    loc = torch.cat([r2t.req_to_token[b, :seq[b]] for b in range(B)]).long()
+    fb = ForwardBatch(ForwardMode.EXTEND, B, None, rpi, seq, loc, int(seq.sum()), seq.cpu(), None, extend_num_tokens=T,
+                      extend_seq_lens=ext, extend_prefix_lens=prefix, extend_start_loc=start,
+                      extend_prefix_lens_cpu=[0, 0], extend_seq_lens_cpu=ext.tolist(), req_to_token_pool=r2t,
+                      token_to_kv_pool=pool, attn_backend=backend)
+    backend.init_forward_metadata(fb)
+    o = layer(q, k, v, fb)
+    assert torch.isfinite(o.float()).all()
+    kb_ref = torch.zeros(n_tok + 1, Hkv, D, dtype=torch.uint8)
+    vb_ref = torch.zeros_like(kb_ref)
+    oracle.set_kv_buffer_fp8(kb_ref, vb_ref, k.cpu().view(T, Hkv, D), v.cpu().view(T, Hkv, D), loc.cpu())
+    assert torch.equal(pool.k_buffer[0].cpu(), kb_ref) and torch.equal(pool.v_buffer[0].cpu(), vb_ref)
+    # decode
+    seq = seq + 1
+    locd = r2t.req_to_token[rpi, seq - 1].long()
+    qd = torch.randn(B, Hq * D, device=DEV, generator=g).bfloat16()
+    kd = torch.randn(B, Hkv * D, device=DEV, generator=g).bfloat16()
+    vd = torch.randn(B, Hkv * D, device=DEV, generator=g).bfloat16()
+    fb = ForwardBatch(ForwardMode.DECODE, B, None, rpi, seq, locd, int(seq.sum()), seq.cpu(), seq - 1,
+                      req_to_token_pool=r2t, token_to_kv_pool=pool, attn_backend=backend)
+    backend.init_forward_metadata(fb)
+    od = layer(qd, kd, vd, fb)
+    oracle.set_kv_buffer_fp8(kb_ref, vb_ref, kd.cpu().view(B, Hkv, D), vd.cpu().view(B, Hkv, D), locd.cpu())
+    assert torch.equal(pool.k_buffer[0].cpu(), kb_ref)
+    truth, ref = torch.zeros(B, Hq, D, dtype=torch.bfloat16), torch.zeros(B, Hq, D, dtype=torch.bfloat16)
+    args = (qd.cpu().view(B, Hq, D), kb_ref, vb_ref)
+    oracle.decode_attention_fp8kv(*args, truth, torch.zeros(B, Hq, 1, D + 1), r2t.req_to_token.cpu(), rpi.cpu(), seq.cpu(),
+                                  D ** -0.5, p_fp8=False)
+    oracle.decode_attention_fp8kv(*args, ref, torch.zeros(B, Hq, 1, D + 1), r2t.req_to_token.cpu(), rpi.cpu(), seq.cpu(),
+                                  D ** -0.5, p_fp8=True)
+    err = float((od.float().cpu().view(B, Hq, D) - truth.float()).abs().max())
+    assert err <= 1.5 * float((ref.float() - truth.float()).abs().max()) + 2.0 ** -8 * float(truth.float().abs().max())
+    # a cached prefix in an FP8 pool: refused until the FP8 prefix stage exists
+    loc4 = r2t.req_to_token[0, 91:95].long()
+    fb = ForwardBatch(ForwardMode.EXTEND, 1, None, rpi[:1], torch.tensor([95], device=DEV), loc4, 95, torch.tensor([95]),
+                      None, extend_num_tokens=4, extend_seq_lens=torch.tensor([4], device=DEV),
+                      extend_prefix_lens=torch.tensor([91], device=DEV), extend_start_loc=torch.tensor([0], device=DEV),
+                      extend_prefix_lens_cpu=[91], extend_seq_lens_cpu=[4], req_to_token_pool=r2t, token_to_kv_pool=pool,
+                      attn_backend=backend)
+    backend.init_forward_metadata(fb)
+    with pytest.raises(NotImplementedError):
+        layer(q[:4], k[:4], v[:4], fb)
