@@ -177,6 +177,22 @@ int sgl_mi355_decode_attention_fwd_fp8kv(
     int64_t head_size_v, int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h,
     int64_t v_stride_n, int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h, float sm_scale, float logit_cap,
     int dtype, void* stream);
+/* extend_attention_fwd over an e4m3 pool (same argument list as sgl_mi355_extend_attention_fwd; pool strides in
+ * elements = bytes).  As the Triton kernel computes it (extend_attention.py:149, :200): in the PREFIX stage Q and P are
+ * rounded to e4m3 (blocks of 64 keys), products are fp8 x fp8 with fp32 accumulation; the extend stage is the 16-bit
+ * path.  head_size == head_size_v in {64, 128}, 16-byte aligned pool rows; anything else SGL_MI355_ERR_UNSUPPORTED. */
+int sgl_mi355_extend_attention_fwd_fp8kv(
+    const void* q_extend, const void* k_extend, const void* v_extend, void* o_extend,
+    const void* k_buffer, const void* v_buffer,
+    const int32_t* qo_indptr, const int32_t* kv_indptr, const int32_t* kv_indices, int is_causal,
+    int64_t max_len_extend, int64_t batch, int64_t num_heads, int64_t num_kv_heads,
+    int64_t head_size, int64_t head_size_v,
+    int64_t q_stride_t, int64_t q_stride_h, int64_t ke_stride_t, int64_t ke_stride_h,
+    int64_t ve_stride_t, int64_t ve_stride_h, int64_t o_stride_t, int64_t o_stride_h,
+    int64_t kb_stride_n, int64_t kb_stride_h, int64_t vb_stride_n, int64_t vb_stride_h,
+    float sm_scale, float logit_cap,
+    const uint8_t* custom_mask, const int64_t* mask_indptr, int skip_prefix_custom_mask, int64_t sliding_window_size,
+    int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * merge_state: combine two partial attention results of the same queries by their log-sum-exp.

@@ -305,3 +305,33 @@ def decode_attention_fp8kv(query, k_buffer, v_buffer, output, attn_logits, req_t
         _I64(k_buffer.stride(0)), _I64(k_buffer.stride(1)), _I64(v_buffer.stride(0)), _I64(v_buffer.stride(1)),
         _I64(output.stride(0)), _I64(output.stride(1)), _F(sm_scale), _F(logit_cap), _I(_dt(query)), _I(1 if p_fp8 else 0))
     return output
+
+
+def extend_attention_fp8kv(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, req_to_token, req_pool_indices,
+                           seq_lens, extend_seq_lens, extend_start_loc, sm_scale, logit_cap=0.0, p_round: bool = True,
+                           causal: bool = True, custom_mask=None, mask_indptr=None, skip_prefix_custom_mask: bool = True,
+                           sliding_window_size: int = -1, q_fp8: bool = True, p_fp8: bool = True, lib=None):
+    """Extend attention over an e4m3 pool (uint8 / float8_e4m3fn k_buffer, v_buffer), Triton-kernel semantics
+    (extend_attention.py:124-303: Q and P rounded to FP8 in the prefix stage, blocks of 64 keys)."""
+    lib = lib or load()
+    assert k_buffer.element_size() == 1 and v_buffer.element_size() == 1
+    cm = mi = None
+    if custom_mask is not None:
+        cm = custom_mask.to(torch.uint8).contiguous()
+        mi = _i64(mask_indptr).contiguous()
+    rpi = _i64(req_pool_indices).contiguous()
+    sl = _i64(seq_lens).contiguous()
+    esl = _i64(extend_seq_lens).contiguous()
+    est = _i64(extend_start_loc).contiguous()
+    lib.orc_extend_attention_fp8kv(
+        _ptr(q_extend), _ptr(k_extend), _ptr(v_extend), _ptr(o_extend), _ptr(k_buffer), _ptr(v_buffer),
+        _ptr(req_to_token), _I(_is64(req_to_token)), _ptr(rpi), _ptr(sl), _ptr(esl), _ptr(est),
+        _I64(sl.numel()), _I64(req_to_token.size(1)), _I64(q_extend.size(1)), _I64(k_extend.size(1)),
+        _I64(q_extend.size(2)), _I64(v_extend.size(2)),
+        _I64(q_extend.stride(0)), _I64(q_extend.stride(1)), _I64(k_extend.stride(0)), _I64(k_extend.stride(1)),
+        _I64(v_extend.stride(0)), _I64(v_extend.stride(1)), _I64(k_buffer.stride(0)), _I64(k_buffer.stride(1)),
+        _I64(v_buffer.stride(0)), _I64(v_buffer.stride(1)), _I64(o_extend.stride(0)), _I64(o_extend.stride(1)),
+        _F(sm_scale), _F(logit_cap), _I(_dt(q_extend)), _I(1 if p_round else 0), _I(1 if causal else 0),
+        _ptr(cm), _ptr(mi), _I(1 if skip_prefix_custom_mask else 0), _I64(int(sliding_window_size)),
+        _I(1 if q_fp8 else 0), _I(1 if p_fp8 else 0))
+    return o_extend

@@ -806,3 +806,110 @@ void orc_decode_attention_fp8kv(
       free(acc);
     }
 }
+
+/* Extend attention with an e4m3 KV pool as the Triton kernel does it (_fwd_kernel, extend_attention.py:124-303):
+ *   stage 1 (cached prefix, :131-208), in blocks of BLOCK_N = 64 keys (the HIP tuning, :350-352):
+ *     qk = dot(q.to(k.dtype), k) -- Q IS ROUNDED TO FP8, fp8 x fp8 products, fp32 accumulate (:149);
+ *     * sm_scale, logit cap, window / custom masks -> -inf; n_e_max = max(max(qk), e_max);
+ *     p = exp(qk - n_e_max); deno = deno * re_scale + sum(p) (unrounded, :197);
+ *     acc = acc * re_scale + dot(p.to(v.dtype), v) -- P IS ROUNDED TO FP8 (:200-201);
+ *   stage 2 (the new tokens, 16-bit k_extend / v_extend, :210-294): as orc_extend_attention.
+ * q_fp8 / p_fp8 = 0 keep the respective operand unrounded (the "truth" the tests measure the rounding noise against).
+ * A block whose keys are all masked is skipped (the reference would produce exp(-inf - -inf) = NaN there). */
+void orc_extend_attention_fp8kv(
+    const uint16_t* q_extend, const uint16_t* k_extend, const uint16_t* v_extend, uint16_t* o_extend,
+    const uint8_t* k_buffer, const uint8_t* v_buffer, const void* req_to_token, int idx64,
+    const int64_t* req_pool_indices, const int64_t* seq_lens, const int64_t* extend_seq_lens,
+    const int64_t* extend_start_loc, int64_t num_seqs, int64_t max_context_len, int64_t num_heads,
+    int64_t num_heads_kv, int64_t head_size, int64_t head_size_v,
+    int64_t q_strideM, int64_t q_strideH, int64_t ke_strideN, int64_t ke_strideH,
+    int64_t ve_strideN, int64_t ve_strideH, int64_t k_strideN, int64_t k_strideH,
+    int64_t v_strideN, int64_t v_strideH, int64_t o_strideM, int64_t o_strideH,
+    float sm_scale, float logit_cap, int dtype, int p_round, int causal,
+    const uint8_t* custom_mask, const int64_t* mask_indptr, int skip_prefix_mask, int64_t window,
+    int q_fp8, int p_fp8) {
+  float lut[256];
+  for (int i = 0; i < 256; ++i) lut[i] = e4m3_to_f32((uint8_t)i);
+  const int64_t group = num_heads / num_heads_kv;
+#pragma omp parallel for schedule(dynamic, 1) collapse(2)
+  for (int64_t b = 0; b < num_seqs; ++b)
+    for (int64_t h = 0; h < num_heads; ++h) {
+      const int64_t hkv = h / group, seq_len = seq_lens[b], ext = extend_seq_lens[b];
+      const int64_t prefix = seq_len - ext, start = extend_start_loc[b], req = req_pool_indices[b];
+      float* qf = (float*)malloc(sizeof(float) * (size_t)head_size);
+      float* q8 = (float*)malloc(sizeof(float) * (size_t)head_size);
+      float* acc = (float*)malloc(sizeof(float) * (size_t)head_size_v);
+      float qk[64], p[64];
+      for (int64_t r = 0; r < ext; ++r) {
+        const uint16_t* q = q_extend + (start + r) * q_strideM + h * q_strideH;
+        for (int64_t d = 0; d < head_size; ++d) {
+          qf[d] = h_to_f32(q[d], dtype);
+          q8[d] = q_fp8 ? lut[f32_to_e4m3(qf[d])] : qf[d];
+        }
+        for (int64_t d = 0; d < head_size_v; ++d) acc[d] = 0.f;
+        float e_max = -INFINITY, deno = 0.f;
+        for (int64_t n0 = 0; n0 < prefix; n0 += 64) {
+          const int64_t nb = prefix - n0 < 64 ? prefix - n0 : 64;
+          float bm = -INFINITY;
+          for (int64_t j = 0; j < nb; ++j) {
+            const int64_t n = n0 + j;
+            int ok = 1;
+            if (window > 0 && !(r <= n + window)) ok = 0;
+            if (ok && custom_mask && !skip_prefix_mask && !custom_mask[mask_indptr[b] + r * seq_len + n]) ok = 0;
+            float s = -INFINITY;
+            if (ok) {
+              const int64_t tok = load_index(req_to_token, req * max_context_len + n, idx64);
+              const uint8_t* kp = k_buffer + tok * k_strideN + hkv * k_strideH;
+              s = 0.f;
+              for (int64_t d = 0; d < head_size; ++d) s += q8[d] * lut[kp[d]];
+              s *= sm_scale;
+              if (logit_cap > 0.f) s = logit_cap * tanhf(s / logit_cap);
+            }
+            qk[j] = s;
+            bm = s > bm ? s : bm;
+          }
+          if (bm == -INFINITY) continue;
+          const float n_e_max = bm > e_max ? bm : e_max;
+          const float re = expf(e_max - n_e_max);
+          for (int64_t d = 0; d < head_size_v; ++d) acc[d] *= re;
+          float psum = 0.f;
+          for (int64_t j = 0; j < nb; ++j) {
+            p[j] = expf(qk[j] - n_e_max);
+            psum += p[j];
+            if (p_fp8) p[j] = lut[f32_to_e4m3(p[j])];
+          }
+          for (int64_t j = 0; j < nb; ++j) {
+            if (p[j] == 0.f) continue;
+            const int64_t tok = load_index(req_to_token, req * max_context_len + n0 + j, idx64);
+            const uint8_t* vp = v_buffer + tok * v_strideN + hkv * v_strideH;
+            for (int64_t d = 0; d < head_size_v; ++d) acc[d] += p[j] * lut[vp[d]];
+          }
+          deno = deno * re + psum;
+          e_max = n_e_max;
+        }
+        const int64_t n_new = causal ? r + 1 : ext;
+        for (int64_t j = 0; j < n_new; ++j) {
+          if (custom_mask && !custom_mask[mask_indptr[b] + r * seq_len + prefix + j]) continue;
+          const uint16_t* kp = k_extend + (start + j) * ke_strideN + hkv * ke_strideH;
+          const uint16_t* vp = v_extend + (start + j) * ve_strideN + hkv * ve_strideH;
+          float s = 0.f;
+          for (int64_t d = 0; d < head_size; ++d) s += qf[d] * h_to_f32(kp[d], dtype);
+          s *= sm_scale;
+          if (logit_cap > 0.f) s = logit_cap * tanhf(s / logit_cap);
+          const float m_i = s > e_max ? s : e_max;
+          const float m_delta = expf(e_max - m_i);
+          const float pj = expf(s - m_i);
+          deno = deno * m_delta + pj;
+          e_max = m_i;
+          const float pv = p_round ? h_to_f32(f32_to_h(pj, dtype), dtype) : pj;
+          for (int64_t d = 0; d < head_size_v; ++d) acc[d] = acc[d] * m_delta + pv * h_to_f32(vp[d], dtype);
+        }
+        uint16_t* o = o_extend + (start + r) * o_strideM + h * o_strideH;
+        const float inv = deno > 0.f ? 1.f / deno : 0.f;
+        for (int64_t d = 0; d < head_size_v; ++d) o[d] = f32_to_h(acc[d] * inv, dtype);
+      }
+      free(qf);
+      free(q8);
+      free(acc);
+    }
+}

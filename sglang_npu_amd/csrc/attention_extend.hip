@@ -24,6 +24,7 @@
 //     ds_read_b64_tr_b16 and P^T taken straight from the S^T accumulator registers (no LDS round trip).
 //   * Head sizes other than 64/128 (e.g. the reference test's D=128, Dv=96) use a generic kernel.
 #include <math.h>
+#include <type_traits>
 
 #include "common.h"
 
@@ -60,6 +61,7 @@ struct ExtendArgs {
   const int64_t* mask_indptr;  // [B+1]
   int skip_prefix_mask;        // SKIP_PREFIX_CUSTOM_MASK
   int window;                  // SLIDING_WINDOW_SIZE (prefix stage only: q <= n + window)
+  int kv8;                     // pool rows are e4m3 bytes (strides in elements = bytes)
 };
 
 __device__ __forceinline__ void seq_info(const ExtendArgs& a, int b, int64_t& idx_base, int& prefix, int& ext,
@@ -87,8 +89,38 @@ __device__ __forceinline__ int swz_v(int c, int row) {  // ds_read_b64_tr_b16: k
   return (((c >> 1) ^ f) << 1) | (c & 1);
 }
 
+// 8 e4m3 bytes -> 8 values of the 16-bit dtype (exact)
+template <int DTYPE>
+__device__ __forceinline__ typename Half16<DTYPE>::x8 cvt8_fp8(const uint2& raw) {
+  using Hh = Half16<DTYPE>;
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typename Hh::x8 out;
+  const uint32_t w[2] = {raw.x, raw.y};
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const f32x2_t lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[i], false);
+    const f32x2_t hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[i], true);
+    out[4 * i + 0] = Hh::from_f32(lo[0]);
+    out[4 * i + 1] = Hh::from_f32(lo[1]);
+    out[4 * i + 2] = Hh::from_f32(hi[0]);
+    out[4 * i + 3] = Hh::from_f32(hi[1]);
+  }
+  return out;
+}
+// fp32 rounded to e4m3 (saturating) and back: `x.to(fp8)` of the Triton kernel for Q (extend_attention.py:149) and P (:200)
+__device__ __forceinline__ float round_fp8(float x) {
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  const int pk = __builtin_amdgcn_cvt_pk_fp8_f32(x, 0.f, 0, false);
+  const f32x2_t r = __builtin_amdgcn_cvt_pk_f32_fp8(pk, false);
+  return r[0];
+}
+
 // GH = q heads per workgroup (1, 2 or 4); the other 4/GH waves take further 32-row position blocks.
-template <int DTYPE, int D, typename IdxT, int GH, bool MASKED>
+// KV8: the pool holds e4m3 bytes.  The prefix stage DMAs byte tiles into a two-deep staging area (the LDS of stage 1),
+// converts each (exactly) into the 16-bit tile image of stage 0 and runs the usual MFMAs on it with Q and P rounded to
+// FP8 first, which is what the Triton kernel computes (fp8 x fp8 products are exact in the 16-bit MFMA as well); the
+// extend stage is the 16-bit code unchanged.
+template <int DTYPE, int D, typename IdxT, int GH, bool MASKED, bool KV8 = false>
 __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
   using H = Half16<DTYPE>;
   using T = typename H::T;
@@ -138,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
 
   // ---- Q^T fragments: lane (col, hh) holds Q[qpos][head][16s + 8hh .. +8]
   x8 qf[KS];
-  {
+  auto load_q = [&](bool to_fp8) __attribute__((always_inline)) {
     const T* qp = reinterpret_cast<const T*>(a.q) + (q_start + (q_ok ? qpos : 0)) * a.q_st + (int64_t)head * a.q_sh;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -149,9 +181,16 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
         for (int j = 0; j < 8; ++j) qf[s][j] = (T)0.f;
       }
     }
+    if (to_fp8) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[s][j] = H::from_f32(round_fp8(H::to_f32(qf[s][j])));
+    }
 #pragma unroll
     for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(qf[s]));  // keep hipcc's wait for these loads out of the loop
-  }
+  };
+  load_q(KV8 && prefix > 0);
 
   // (with a custom mask AND is_causal the reference still stops at the end of the query block,
   //  extend_attention.py:199-203; masks that are subsets of the causal mask -- tree attention -- do not notice)
@@ -272,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
       for (int r = 0; r < 16; ++r) {
         const float p = __builtin_amdgcn_exp2f(s_acc[th][r] - m_safe);
         psum += p;
-        pf[th][r >> 3][r & 7] = H::from_f32(p);
+        pf[th][r >> 3][r & 7] = H::from_f32((KV8 && phase == 0) ? round_fp8(p) : p);
       }
     l_run = l_run * alpha + psum;
     m_run = m_new;
@@ -326,6 +365,68 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
     }
   };
 
+  // ---- KV8 prefix stage: byte tiles -> staging (stage 1's LDS, two buffers of K+V) -> 16-bit image in stage 0
+  constexpr int TILE8 = kBN * D;                 // bytes of one e4m3 K (or V) tile
+  constexpr int CH8 = D / 16;                    // 16-B chunks per e4m3 row
+  constexpr int ROWS8 = 1024 / D;                // rows per 1-KB DMA piece
+  constexpr int PPW8 = (kBN / ROWS8) / 4;        // pieces per wave
+  static_assert(2 * 2 * TILE8 <= STAGE_BYTES, "staging must fit the second stage");
+  auto issue8 = [&](int t, int sb, int idx_off, int n_keys) __attribute__((always_inline)) {
+    const uint32_t kdst = __builtin_amdgcn_readfirstlane(lds_addr_of(smem + STAGE_BYTES + sb * 2 * TILE8));
+    const uint32_t vdst = kdst + TILE8;
+    const char* kp8 = reinterpret_cast<const char*>(a.kb) + (int64_t)kvh * a.kb_sh;
+    const char* vp8 = reinterpret_cast<const char*>(a.vb) + (int64_t)kvh * a.vb_sh;
+    const int r8 = lane / CH8, c8 = lane % CH8;
+    int64_t koff[PPW8], voff[PPW8];
+#pragma unroll
+    for (int i = 0; i < PPW8; ++i) {
+      int kidx = t * kBN + (wave * PPW8 + i) * ROWS8 + r8;
+      kidx = kidx < n_keys ? kidx : n_keys - 1;
+      const int64_t slot = idx_lds[kidx - idx_off];
+      koff[i] = slot * a.kb_sn + c8 * 16;
+      voff[i] = slot * a.vb_sn + c8 * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < PPW8; ++i) lds_dma16(kp8 + koff[i], kdst + (wave * PPW8 + i) * 1024);
+#pragma unroll
+    for (int i = 0; i < PPW8; ++i) lds_dma16(vp8 + voff[i], vdst + (wave * PPW8 + i) * 1024);
+  };
+  auto convert8 = [&](int sb) __attribute__((always_inline)) {
+    const char* ks8 = smem + STAGE_BYTES + sb * 2 * TILE8;
+    const char* vs8 = ks8 + TILE8;
+    char* kst = smem;
+    char* vst = smem + TILE_BYTES;
+    constexpr int CPR = D / 8;                   // 8-element chunks per row
+    constexpr int NCH = kBN * CPR / 256;         // chunks per thread
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = tid + 256 * i, row = c / CPR, ch = c % CPR;
+      const uint2 kr = *reinterpret_cast<const uint2*>(ks8 + row * D + ch * 8);
+      const uint2 vr = *reinterpret_cast<const uint2*>(vs8 + row * D + ch * 8);
+      *reinterpret_cast<x8*>(kst + row * ROWB + swz_k<D>(ch, row) * 16) = cvt8_fp8<DTYPE>(kr);
+      *reinterpret_cast<x8*>(vst + row * ROWB + swz_v<D>(ch, row) * 16) = cvt8_fp8<DTYPE>(vr);
+    }
+  };
+  auto run_phase8 = [&](int t_begin, int t_end, int idx_off, int n_keys) __attribute__((always_inline)) {
+    if (t_begin >= t_end) return;
+    issue8(t_begin, 0, idx_off, n_keys);
+    for (int t = t_begin; t < t_end; ++t) {
+      const int sb = (t - t_begin) & 1;
+      if (t + 1 < t_end) {
+        issue8(t + 1, sb ^ 1, idx_off, n_keys);
+        wait_vmcnt<2 * PPW8>();
+      } else {
+        wait_vmcnt<0>();
+      }
+      __builtin_amdgcn_s_barrier();  // byte tile t has landed; every wave is done with the 16-bit image of tile t-1
+      convert8(sb);
+      wait_lgkmcnt0();
+      __builtin_amdgcn_s_barrier();  // the 16-bit image of tile t is complete; staging sb may be refilled
+      compute(0, t, 0, n_keys);
+    }
+    wait_lgkmcnt0();
+  };
+
   for (int i0 = 0; i0 < prefix; i0 += kIdxCap) {
     const int n = (prefix - i0) < kIdxCap ? (prefix - i0) : kIdxCap;
     {
@@ -333,8 +434,15 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
       for (int i = tid; i < n; i += 256) idx_lds[i] = (int32_t)src[i];
     }
     __syncthreads();
-    run_phase(0, i0 / kBN, (i0 + n + kBN - 1) / kBN, i0, i0 + n);  // kIdxCap is a multiple of kBN
+    if constexpr (KV8) {
+      run_phase8(i0 / kBN, (i0 + n + kBN - 1) / kBN, i0, i0 + n);
+    } else {
+      run_phase(0, i0 / kBN, (i0 + n + kBN - 1) / kBN, i0, i0 + n);  // kIdxCap is a multiple of kBN
+    }
     __syncthreads();
+  }
+  if constexpr (KV8) {
+    if (prefix > 0) load_q(false);
   }
   (void)nt1;
   run_phase(1, 0, nt2, 0, n_ext_keys);
@@ -432,9 +540,9 @@ __global__ __launch_bounds__(64) void extend_generic_kernel(ExtendArgs a, int D,
   }
 }
 
-template <int DTYPE, int D, typename IdxT, int GH, bool MASKED>
+template <int DTYPE, int D, typename IdxT, int GH, bool MASKED, bool KV8 = false>
 int launch_mfma(ExtendArgs a, int64_t batch, int max_len_extend, hipStream_t s) {
-  auto kern = extend_mfma_kernel<DTYPE, D, IdxT, GH, MASKED>;
+  auto kern = extend_mfma_kernel<DTYPE, D, IdxT, GH, MASKED, KV8>;
   constexpr int lds = 2 * 2 * kBN * D * 2 + kIdxCap * 4;
   static int attr_rc = check_hip(
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
@@ -460,6 +568,37 @@ int dispatch(ExtendArgs a, int64_t batch, int D, int Dv, int max_len_extend, hip
                        (reinterpret_cast<uintptr_t>(a.q) % 16 == 0) && (reinterpret_cast<uintptr_t>(a.ke) % 16 == 0) &&
                        (reinterpret_cast<uintptr_t>(a.ve) % 16 == 0) && (reinterpret_cast<uintptr_t>(a.kb) % 16 == 0) &&
                        (reinterpret_cast<uintptr_t>(a.vb) % 16 == 0) && (reinterpret_cast<uintptr_t>(a.o) % 8 == 0);
+  if (a.kv8) {
+    // e4m3 pool: Triton form only (the CPU op has no FP8 pool), MFMA kernel only
+    if constexpr (std::is_same<IdxT, int32_t>::value) {
+      const bool ok8 = D == Dv && (D == 128 || D == 64) && (a.q_st % 8 == 0) && (a.q_sh % 8 == 0) && (a.ke_st % 8 == 0) &&
+                       (a.ke_sh % 8 == 0) && (a.ve_st % 8 == 0) && (a.ve_sh % 8 == 0) && (a.kb_sn % 16 == 0) &&
+                       (a.kb_sh % 16 == 0) && (a.vb_sn % 16 == 0) && (a.vb_sh % 16 == 0) && (a.o_st % 4 == 0) &&
+                       (a.o_sh % 4 == 0) && (reinterpret_cast<uintptr_t>(a.q) % 16 == 0) &&
+                       (reinterpret_cast<uintptr_t>(a.ke) % 16 == 0) && (reinterpret_cast<uintptr_t>(a.ve) % 16 == 0) &&
+                       (reinterpret_cast<uintptr_t>(a.kb) % 16 == 0) && (reinterpret_cast<uintptr_t>(a.vb) % 16 == 0) &&
+                       (reinterpret_cast<uintptr_t>(a.o) % 8 == 0) && a.mode == 0;
+      if (!ok8) {
+        set_error("extend_attention_fwd_fp8kv: needs head_size == head_size_v in {64, 128} and 16-byte aligned rows");
+        return SGL_MI355_ERR_UNSUPPORTED;
+      }
+      const int gh = (a.group % 4 == 0) ? 4 : (a.group % 2 == 0 ? 2 : 1);
+#define EXT_LAUNCH8(DD, GG) return launch_mfma<DTYPE, DD, int32_t, GG, true, true>(a, batch, max_len_extend, s)
+      if (D == 128) {
+        if (gh == 4) EXT_LAUNCH8(128, 4);
+        if (gh == 2) EXT_LAUNCH8(128, 2);
+        EXT_LAUNCH8(128, 1);
+      } else {
+        if (gh == 4) EXT_LAUNCH8(64, 4);
+        if (gh == 2) EXT_LAUNCH8(64, 2);
+        EXT_LAUNCH8(64, 1);
+      }
+#undef EXT_LAUNCH8
+    } else {
+      set_error("extend_attention: e4m3 pools are supported by the kv_indices form only");
+      return SGL_MI355_ERR_UNSUPPORTED;
+    }
+  }
   if (D == Dv && aligned && (D == 128 || D == 64)) {
     const int gh = (a.group % 4 == 0) ? 4 : (a.group % 2 == 0 ? 2 : 1);
     const bool masked = a.mask != nullptr || a.window > 0;
@@ -500,7 +639,8 @@ int check_common(int64_t batch, int64_t Hq, int64_t Hkv, int64_t D, int64_t Dv, 
 
 using namespace sglm;
 
-extern "C" int sgl_mi355_extend_attention_fwd(
+static int extend_fwd_impl(int kv8,
+    
     const void* q_extend, const void* k_extend, const void* v_extend, void* o_extend, const void* k_buffer,
     const void* v_buffer, const int32_t* qo_indptr, const int32_t* kv_indptr, const int32_t* kv_indices, int is_causal,
     int64_t max_len_extend, int64_t batch, int64_t num_heads, int64_t num_kv_heads, int64_t head_size,
@@ -512,6 +652,7 @@ extern "C" int sgl_mi355_extend_attention_fwd(
   int rc = check_common(batch, num_heads, num_kv_heads, head_size, head_size_v, max_len_extend, dtype);
   if (rc) return rc;
   if (batch == 0 || max_len_extend == 0) return 0;
+  SGLM_CHECK_ARG(!kv8 || (k_buffer && v_buffer && kv_indices), "extend_attention_fwd_fp8kv: null pool pointer");
   SGLM_CHECK_ARG(q_extend && k_extend && v_extend && o_extend && qo_indptr && kv_indptr,
                  "extend_attention_fwd: null tensor pointer");
   SGLM_CHECK_ARG(custom_mask == nullptr || mask_indptr != nullptr, "extend_attention_fwd: custom_mask needs mask_indptr");
@@ -528,10 +669,44 @@ extern "C" int sgl_mi355_extend_attention_fwd(
   a.sm_scale = sm_scale; a.logit_cap = logit_cap; a.causal = is_causal;
   a.mask = custom_mask; a.mask_indptr = mask_indptr; a.skip_prefix_mask = skip_prefix_custom_mask;
   a.window = sliding_window_size > 0 ? (int)sliding_window_size : 0;
+  a.kv8 = kv8;
   hipStream_t s = as_stream(stream);
   return dtype == SGL_MI355_BF16
              ? dispatch<SGL_MI355_BF16, int32_t>(a, batch, (int)head_size, (int)head_size_v, (int)max_len_extend, s)
              : dispatch<SGL_MI355_FP16, int32_t>(a, batch, (int)head_size, (int)head_size_v, (int)max_len_extend, s);
+}
+
+extern "C" int sgl_mi355_extend_attention_fwd(
+    const void* q_extend, const void* k_extend, const void* v_extend, void* o_extend, const void* k_buffer,
+    const void* v_buffer, const int32_t* qo_indptr, const int32_t* kv_indptr, const int32_t* kv_indices, int is_causal,
+    int64_t max_len_extend, int64_t batch, int64_t num_heads, int64_t num_kv_heads, int64_t head_size,
+    int64_t head_size_v, int64_t q_stride_t, int64_t q_stride_h, int64_t ke_stride_t, int64_t ke_stride_h,
+    int64_t ve_stride_t, int64_t ve_stride_h, int64_t o_stride_t, int64_t o_stride_h, int64_t kb_stride_n,
+    int64_t kb_stride_h, int64_t vb_stride_n, int64_t vb_stride_h, float sm_scale, float logit_cap,
+    const uint8_t* custom_mask, const int64_t* mask_indptr, int skip_prefix_custom_mask, int64_t sliding_window_size,
+    int dtype, void* stream) {
+  return extend_fwd_impl(0, q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices,
+                         is_causal, max_len_extend, batch, num_heads, num_kv_heads, head_size, head_size_v, q_stride_t,
+                         q_stride_h, ke_stride_t, ke_stride_h, ve_stride_t, ve_stride_h, o_stride_t, o_stride_h,
+                         kb_stride_n, kb_stride_h, vb_stride_n, vb_stride_h, sm_scale, logit_cap, custom_mask, mask_indptr,
+                         skip_prefix_custom_mask, sliding_window_size, dtype, stream);
+}
+
+// Same contract with k_buffer / v_buffer holding e4m3 bytes (pool strides in elements = bytes).
+extern "C" int sgl_mi355_extend_attention_fwd_fp8kv(
+    const void* q_extend, const void* k_extend, const void* v_extend, void* o_extend, const void* k_buffer,
+    const void* v_buffer, const int32_t* qo_indptr, const int32_t* kv_indptr, const int32_t* kv_indices, int is_causal,
+    int64_t max_len_extend, int64_t batch, int64_t num_heads, int64_t num_kv_heads, int64_t head_size,
+    int64_t head_size_v, int64_t q_stride_t, int64_t q_stride_h, int64_t ke_stride_t, int64_t ke_stride_h,
+    int64_t ve_stride_t, int64_t ve_stride_h, int64_t o_stride_t, int64_t o_stride_h, int64_t kb_stride_n,
+    int64_t kb_stride_h, int64_t vb_stride_n, int64_t vb_stride_h, float sm_scale, float logit_cap,
+    const uint8_t* custom_mask, const int64_t* mask_indptr, int skip_prefix_custom_mask, int64_t sliding_window_size,
+    int dtype, void* stream) {
+  return extend_fwd_impl(1, q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices,
+                         is_causal, max_len_extend, batch, num_heads, num_kv_heads, head_size, head_size_v, q_stride_t,
+                         q_stride_h, ke_stride_t, ke_stride_h, ve_stride_t, ve_stride_h, o_stride_t, o_stride_h,
+                         kb_stride_n, kb_stride_h, vb_stride_n, vb_stride_h, sm_scale, logit_cap, custom_mask, mask_indptr,
+                         skip_prefix_custom_mask, sliding_window_size, dtype, stream);
 }
 
 extern "C" int sgl_mi355_extend_attention(

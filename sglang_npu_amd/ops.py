@@ -268,13 +268,10 @@ def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buf
         raise RuntimeError("extend_attention_fwd: qo_indptr, kv_indptr and kv_indices must be int32")
     D = q_extend.size(2)
     sm_scale = sm_scale if sm_scale is not None else 1.0 / (D ** 0.5)
-    if k_buffer.dtype != q_extend.dtype and _is_fp8_pool(k_buffer, v_buffer, q_extend):
-        # FP8 KV pool: the prefix stage over FP8 rows (q and p rounded to FP8, extend_attention.py:149,199) is not built
-        # yet; prefills without a cached prefix never touch the pool, so they run on the 16-bit kernel as they are
-        if int(kv_indptr[-1].item()) != 0:
-            raise NotImplementedError("extend_attention_fwd: a cached prefix in an FP8 KV pool is not supported yet")
-        k_buffer, v_buffer = k_extend, v_extend  # placeholders, never dereferenced (no prefix rows)
-    _lib.check(_lib.lib().sgl_mi355_extend_attention_fwd(
+    # FP8 (e4m3) KV pool: the prefix stage reads FP8 rows with q and p rounded to FP8 (extend_attention.py:149, :200)
+    fn = _lib.lib().sgl_mi355_extend_attention_fwd_fp8kv if _is_fp8_pool(k_buffer, v_buffer, q_extend) \
+        else _lib.lib().sgl_mi355_extend_attention_fwd
+    _lib.check(fn(
         _ptr(q_extend), _ptr(k_extend), _ptr(v_extend), _ptr(o_extend), _ptr(k_buffer), _ptr(v_buffer),
         _ptr(qo_indptr), _ptr(kv_indptr), _ptr(kv_indices), _I(1 if is_causal else 0), _I64(max_len_extend),
         _I64(qo_indptr.numel() - 1), _I64(q_extend.size(1)), _I64(k_extend.size(1)), _I64(D), _I64(v_extend.size(2)),

@@ -1,4 +1,4 @@
-"""GPU: FP8 (e4m3fn) KV cache -- pool write and paged decode over byte rows.
+"""GPU: FP8 (e4m3fn) KV cache -- pool write, paged decode and the extend prefix stage over byte rows.
 P is rounded to FP8 before P.V (decode_attention.py:373), so results carry fp8-P noise (relative 2^-4 per probability);
 which probabilities round up or down depends on the running max they are scaled by, i.e. on the tile order, and the
 reference itself changes with num_kv_splits.  The bar therefore is statistical and stated next to each assert: the HIP
@@ -92,7 +92,7 @@ def test_fp8_pool_unsupported_shapes_raise():
 
 def test_backend_prefill_then_decode_with_fp8_pool():
     """MI355AttnBackend on an FP8 pool: EXTEND without a cached prefix (16-bit kernel on the new tokens, K/V cast into
-    the pool), then DECODE steps reading the byte rows; a cached prefix is refused for now."""
+    the pool), DECODE steps reading the byte rows, then an EXTEND over a cached prefix in the pool."""
     from sglang_npu_amd.attention_backend import MI355AttnBackend
     from sglang_npu_amd.harness import (ForwardBatch, ForwardMode, MHATokenToKVPool, ModelConfig, ModelRunnerLike,
                                         RadixAttention, ReqToTokenPool, ServerArgs)
@@ -146,7 +146,7 @@ def test_backend_prefill_then_decode_with_fp8_pool():
                                   D ** -0.5, p_fp8=True)
     err = float((od.float().cpu().view(B, Hq, D) - truth.float()).abs().max())
     assert err <= 1.5 * float((ref.float() - truth.float()).abs().max()) + 2.0 ** -8 * float(truth.float().abs().max())
-    # a cached prefix in an FP8 pool: refused until the FP8 prefix stage exists
+    # a cached prefix in the FP8 pool: the prefix stage reads the byte rows (q and p rounded to FP8)
     loc4 = r2t.req_to_token[0, 91:95].long()
     fb = ForwardBatch(ForwardMode.EXTEND, 1, None, rpi[:1], torch.tensor([95], device=DEV), loc4, 95, torch.tensor([95]),
                       None, extend_num_tokens=4, extend_seq_lens=torch.tensor([4], device=DEV),
@@ -154,5 +154,114 @@ def test_backend_prefill_then_decode_with_fp8_pool():
                       extend_prefix_lens_cpu=[91], extend_seq_lens_cpu=[4], req_to_token_pool=r2t, token_to_kv_pool=pool,
                       attn_backend=backend)
     backend.init_forward_metadata(fb)
-    with pytest.raises(NotImplementedError):
-        layer(q[:4], k[:4], v[:4], fb)
+    oe = layer(q[:4], k[:4], v[:4], fb)
+    oracle.set_kv_buffer_fp8(kb_ref, vb_ref, k[:4].cpu().view(4, Hkv, D), v[:4].cpu().view(4, Hkv, D), loc4.cpu())
+    assert torch.equal(pool.k_buffer[0].cpu(), kb_ref)
+    outs = []
+    for p_fp8 in (False, True):
+        o_ref = torch.zeros(4, Hq, D, dtype=torch.bfloat16)
+        oracle.extend_attention_fp8kv(q[:4].cpu().view(4, Hq, D), k[:4].cpu().view(4, Hkv, D), v[:4].cpu().view(4, Hkv, D),
+                                      o_ref, kb_ref, vb_ref, r2t.req_to_token.cpu(), torch.tensor([0]), torch.tensor([95]),
+                                      torch.tensor([4]), torch.tensor([0]), D ** -0.5, p_fp8=p_fp8)
+        outs.append(o_ref.float())
+    err = float((oe.float().cpu().view(4, Hq, D) - outs[0]).abs().max())
+    assert err <= 1.5 * float((outs[1] - outs[0]).abs().max()) + 2.0 ** -8 * float(outs[0].abs().max())
+
+
+def _extend_case(g, B, Hq, Hkv, D, prefix, ext, dtype=torch.bfloat16):
+    max_len = int(max(p + e for p, e in zip(prefix, ext)))
+    n_tok = B * max_len + 1
+    kb = torch.randn(n_tok, Hkv, D, generator=g).to(torch.float8_e4m3fn)
+    vb = torch.randn(n_tok, Hkv, D, generator=g).to(torch.float8_e4m3fn)
+    r2t = (torch.randperm(n_tok - 1, generator=g) + 1).view(B, max_len).int()
+    T = int(sum(ext))
+    q = torch.randn(T, Hq, D, generator=g).to(dtype)
+    k = torch.randn(T, Hkv, D, generator=g).to(dtype)
+    v = torch.randn(T, Hkv, D, generator=g).to(dtype)
+    ext_t, pre_t = torch.tensor(ext), torch.tensor(prefix)
+    start = torch.cumsum(ext_t, 0) - ext_t
+    qo_indptr = torch.zeros(B + 1, dtype=torch.int32)
+    qo_indptr[1:] = torch.cumsum(ext_t, 0)
+    kv_indptr = torch.zeros(B + 1, dtype=torch.int32)
+    kv_indptr[1:] = torch.cumsum(pre_t, 0)
+    kv_indices = torch.cat([r2t[b, :prefix[b]] for b in range(B)] + [torch.zeros(0, dtype=torch.int32)])
+    return dict(kb=kb, vb=vb, r2t=r2t, q=q, k=k, v=v, ext=ext_t, seq=ext_t + pre_t, start=start, qo_indptr=qo_indptr,
+                kv_indptr=kv_indptr, kv_indices=kv_indices, rpi=torch.arange(B))
+
+
+def _run_extend(c, D, **kw):
+    o = torch.zeros(c["q"].shape, dtype=c["q"].dtype, device=DEV)
+    d = lambda t: t.to(DEV)
+    mask = kw.pop("custom_mask", None)
+    mi = kw.pop("mask_indptr", None)
+    ops.extend_attention_fwd(d(c["q"]), d(c["k"]), d(c["v"]), o, d(c["kb"]), d(c["vb"]), d(c["qo_indptr"]), d(c["kv_indptr"]),
+                             d(c["kv_indices"]), d(mask) if mask is not None else None, True,
+                             d(mi) if mi is not None else None, int(c["ext"].max()), D ** -0.5, **kw)
+    return o.float().cpu()
+
+
+def _oracle_extend(c, D, **kw):
+    o = torch.zeros(c["q"].shape, dtype=c["q"].dtype)
+    oracle.extend_attention_fp8kv(c["q"], c["k"], c["v"], o, c["kb"].view(torch.uint8), c["vb"].view(torch.uint8), c["r2t"],
+                                  c["rpi"], c["seq"], c["ext"], c["start"], D ** -0.5, **kw)
+    return o.float()
+
+
+@pytest.mark.parametrize("Hq,Hkv,D", [(32, 8, 128), (8, 1, 128), (14, 2, 64), (6, 6, 128)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_extend_fp8_prefix_vs_oracle(Hq, Hkv, D, dtype):
+    g = torch.Generator().manual_seed(Hq * 3 + D)
+    c = _extend_case(g, 4, Hq, Hkv, D, prefix=[300, 0, 64, 517], ext=[70, 33, 1, 129], dtype=dtype)
+    o = _run_extend(c, D)
+    truth = _oracle_extend(c, D, p_fp8=False)
+    ref = _oracle_extend(c, D, p_fp8=True)
+    err_hip, err_ref = (o - truth).abs(), (ref - truth).abs()
+    scale = float(truth.abs().max())
+    # same rounding points as the oracle (Q -> fp8, P -> fp8 per 64-key block); exp2 vs expf decide single roundings
+    assert float(err_hip.pow(2).mean().sqrt()) <= 1.5 * float(err_ref.pow(2).mean().sqrt()) + 2.0 ** -9 * scale
+    assert float(err_hip.max()) <= 1.5 * float(err_ref.max()) + 2.0 ** -8 * scale
+    # the request without a prefix never touches the pool: plain 16-bit accuracy
+    rows = slice(70, 103)
+    assert float(err_hip[rows].max()) <= 2.0 ** -7 * scale
+
+
+def test_extend_fp8_rounds_q_like_the_reference():
+    """One cached key (p = 1 exactly, so no fp8-P noise): the result depends on the prefix logit q8 . k alone and must
+    follow the oracle WITH Q rounded to FP8 (extend_attention.py:149), not the unrounded one."""
+    g = torch.Generator().manual_seed(5)
+    Hq, Hkv, D = 8, 2, 128
+    c = _extend_case(g, 3, Hq, Hkv, D, prefix=[1, 1, 1], ext=[1, 2, 40])
+    c["q"] = (c["q"].float() * 1.7).bfloat16()
+    o = _run_extend(c, D)
+    with_q8 = _oracle_extend(c, D, q_fp8=True, p_fp8=True)
+    without = _oracle_extend(c, D, q_fp8=False, p_fp8=True)
+    e_with, e_without = float((o - with_q8).abs().max()), float((o - without).abs().max())
+    assert e_with <= 2.0 ** -7 * float(with_q8.abs().max())  # 16-bit output rounding only
+    assert e_without > 4 * e_with
+
+
+def test_extend_fp8_long_prefix_window_and_mask():
+    """Prefix longer than one page-table pass (4096 entries), sliding window on the prefix, custom mask on both parts."""
+    g = torch.Generator().manual_seed(9)
+    Hq, Hkv, D = 4, 1, 128
+    c = _extend_case(g, 2, Hq, Hkv, D, prefix=[4300, 130], ext=[40, 70])
+    for kw in (dict(), dict(sliding_window_size=100)):
+        o = _run_extend(c, D, **kw)
+        truth, ref = _oracle_extend(c, D, p_fp8=False, **kw), _oracle_extend(c, D, p_fp8=True, **kw)
+        scale = float(truth.abs().max())
+        assert float((o - truth).abs().max()) <= 1.5 * float((ref - truth).abs().max()) + 2.0 ** -8 * scale
+    # custom mask over [ext][prefix + ext], a random subset of the causal mask that keeps the diagonal
+    masks, indptr = [], [0]
+    for b in range(2):
+        pre, ext = int(c["seq"][b] - c["ext"][b]), int(c["ext"][b])
+        m = torch.rand(ext, pre + ext, generator=g) < 0.6
+        m[:, pre:] &= torch.tril(torch.ones(ext, ext, dtype=torch.bool))
+        m[torch.arange(ext), pre + torch.arange(ext)] = True
+        masks.append(m.reshape(-1))
+        indptr.append(indptr[-1] + m.numel())
+    mask, mi = torch.cat(masks), torch.tensor(indptr, dtype=torch.int64)
+    kw = dict(custom_mask=mask, mask_indptr=mi, skip_prefix_custom_mask=False)
+    o = _run_extend(c, D, **kw)
+    truth, ref = _oracle_extend(c, D, p_fp8=False, **kw), _oracle_extend(c, D, p_fp8=True, **kw)
+    scale = float(truth.abs().max())
+    assert float((o - truth).abs().max()) <= 1.5 * float((ref - truth).abs().max()) + 2.0 ** -8 * scale

@@ -166,3 +166,34 @@ def test_extend_oracle_masks_vs_dense_torch(mode):
     s = s.masked_fill(~vis[None], float("-inf"))
     ref = torch.einsum("hen,nhd->ehd", torch.softmax(s, -1), V)
     assert (o.float() - ref).abs().max().item() <= tol_for("bf16", ref)
+
+
+def test_extend_fp8kv_oracle_reduces_to_the_16bit_oracle():
+    """With the roundings switched off, the FP8-pool restatement (blocks of 64 prefix keys) is the 16-bit extend oracle
+    on the upcast pool (e4m3 -> bf16 is exact); with them on it differs by fp8 noise only, and Q rounding matters."""
+    g = torch.Generator().manual_seed(3)
+    B, Hq, Hkv, D = 2, 4, 2, 64
+    prefix, ext = torch.tensor([150, 7]), torch.tensor([9, 20])
+    seq = prefix + ext
+    n_tok = 400
+    kb = torch.randn(n_tok, Hkv, D, generator=g).to(torch.float8_e4m3fn)
+    vb = torch.randn(n_tok, Hkv, D, generator=g).to(torch.float8_e4m3fn)
+    r2t = (torch.randperm(n_tok - 1, generator=g) + 1)[: B * 170].view(B, 170).int()
+    T = int(ext.sum())
+    q = torch.randn(T, Hq, D, generator=g).bfloat16()
+    k = torch.randn(T, Hkv, D, generator=g).bfloat16()
+    v = torch.randn(T, Hkv, D, generator=g).bfloat16()
+    rpi, start = torch.arange(B), torch.tensor([0, 9])
+    o16 = torch.zeros_like(q)
+    oracle.extend_attention(q, k, v, o16, kb.bfloat16(), vb.bfloat16(), r2t, rpi, seq, ext, start, int(ext.max()), D ** -0.5, 0.0)
+    outs = {}
+    for q_fp8, p_fp8 in ((False, False), (True, False), (True, True)):
+        o = torch.zeros_like(q)
+        oracle.extend_attention_fp8kv(q, k, v, o, kb.view(torch.uint8), vb.view(torch.uint8), r2t, rpi, seq, ext, start,
+                                      D ** -0.5, q_fp8=q_fp8, p_fp8=p_fp8)
+        outs[(q_fp8, p_fp8)] = o.float()
+    scale = float(o16.float().abs().max())
+    assert float((outs[(False, False)] - o16.float()).abs().max()) <= 2.0 ** -7 * scale
+    d_q = float((outs[(True, False)] - outs[(False, False)]).abs().max())
+    d_p = float((outs[(True, True)] - outs[(True, False)]).abs().max())
+    assert 0 < d_q < 0.25 * scale and 0 < d_p < 0.1 * scale
