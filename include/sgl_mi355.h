@@ -300,6 +300,13 @@ int sgl_mi355_rotary_embedding_set_kv_from_partials(
     const void* bias, int64_t num_tokens, int64_t num_q_heads, int64_t num_k_heads, int64_t head_size, int64_t rot_dim,
     int64_t q_out_stride_t, int64_t kb_stride_n, int64_t kb_stride_h, int64_t vb_stride_n, int64_t vb_stride_h,
     int is_neox, int dtype, void* stream);
+/* same, k_buffer / v_buffer an e4m3 pool (cast as sgl_mi355_set_kv_buffer_fp8 without scales; strides in elements) */
+int sgl_mi355_rotary_embedding_set_kv_from_partials_fp8kv(
+    void* q_out, void* k_buffer, void* v_buffer, const int64_t* positions, const void* loc, int loc_is64,
+    const float* cos_sin_cache, const float* partials, int64_t num_slices, const float* scales_a, const float* scales_b,
+    const void* bias, int64_t num_tokens, int64_t num_q_heads, int64_t num_k_heads, int64_t head_size, int64_t rot_dim,
+    int64_t q_out_stride_t, int64_t kb_stride_n, int64_t kb_stride_h, int64_t vb_stride_n, int64_t vb_stride_h,
+    int is_neox, int dtype, void* stream);
 
 /* Decode-time AWQ GEMM on a k-packed copy of the weights (csrc/awq_packed.hip).
  * Replaces: the same AWQLinearMethod.apply (awq.py:401-418) for M <= 64, fp16.  sgl_mi355_awq_repack is what
@@ -354,6 +361,15 @@ int sgl_mi355_rotary_embedding_set_kv(const int64_t* positions, void* query, voi
                                       int64_t head_size, int64_t rot_dim, int64_t q_stride_t, int64_t k_stride_t,
                                       int64_t v_stride_t, int64_t kb_stride_n, int64_t kb_stride_h,
                                       int64_t vb_stride_n, int64_t vb_stride_h, int is_neox, int dtype, void* stream);
+/* same, k_buffer / v_buffer an e4m3 pool: the rotated key and the value are cast as sgl_mi355_set_kv_buffer_fp8 does
+ * (memory_pool.py:385-394, no scales -- the Triton backend passes none); pool strides in elements (= bytes). */
+int sgl_mi355_rotary_embedding_set_kv_fp8kv(const int64_t* positions, void* query, void* key, const void* value,
+                                            const float* cos_sin_cache, void* k_buffer, void* v_buffer, const void* loc,
+                                            int loc_is64, int64_t num_tokens, int64_t num_q_heads, int64_t num_k_heads,
+                                            int64_t head_size, int64_t rot_dim, int64_t q_stride_t, int64_t k_stride_t,
+                                            int64_t v_stride_t, int64_t kb_stride_n, int64_t kb_stride_h,
+                                            int64_t vb_stride_n, int64_t vb_stride_h, int is_neox, int dtype,
+                                            void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * P2P all-reduce over IPC-mapped peer buffers (one process per GPU, <= 8 ranks of one node).

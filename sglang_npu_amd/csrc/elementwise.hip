@@ -276,15 +276,26 @@ __global__ __launch_bounds__(256) void rope_kernel(
   }
 }
 
+// One element into a KV-pool row: 16-bit as is, or (KV8) cast to e4m3 as set_kv_buffer_fp8 does (saturating RNE).
+template <int DTYPE, bool KV8>
+__device__ __forceinline__ void pool_store(char* row, int i, typename Half16<DTYPE>::T v) {
+  if constexpr (KV8) {
+    const float a = fminf(fmaxf(Half16<DTYPE>::to_f32(v), -448.f), 448.f);
+    reinterpret_cast<uint8_t*>(row)[i] = (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32(a, 0.f, 0, false) & 0xFF);
+  } else {
+    reinterpret_cast<typename Half16<DTYPE>::T*>(row)[i] = v;
+  }
+}
+
 // Fused RoPE + KV-pool write: rotate q and k in place, then k (rotated) and v go to the
 // pool rows loc[t] in the same pass -- one launch instead of rope + set_kv_buffer, and k/v are not re-read.
 // One 64-thread wave per (token, head) over q heads, then k heads (which also carry v).
 // RoPE + KV write straight from the split-K partials of the qkv GEMM: column c of the [T, (Hq + 2 Hk) D] qkv row is
 // produced on the fly (gemm_elem), q goes (rotated) to q_out [T, Hq D], k (rotated) and v to the pool.
-template <int DTYPE, typename LocT>
+template <int DTYPE, typename LocT, bool KV8>
 __global__ __launch_bounds__(256) void rope_kv_from_partials_kernel(
-    typename Half16<DTYPE>::T* __restrict__ q_out, typename Half16<DTYPE>::T* __restrict__ kb,
-    typename Half16<DTYPE>::T* __restrict__ vb, const int64_t* __restrict__ positions, const LocT* __restrict__ loc,
+    typename Half16<DTYPE>::T* __restrict__ q_out, char* __restrict__ kb,
+    char* __restrict__ vb, const int64_t* __restrict__ positions, const LocT* __restrict__ loc,
     const float* __restrict__ cache, int64_t T, int Hq, int Hk, int D, int rot_dim, int64_t q_st, int64_t kb_sn,
     int64_t kb_sh, int64_t vb_sn, int64_t vb_sh, int neox, PartialSrc ps) {
   using Hh = Half16<DTYPE>;
@@ -298,27 +309,38 @@ __global__ __launch_bounds__(256) void rope_kv_from_partials_kernel(
   const int col0 = h * D;  // q heads then k heads are contiguous in the qkv row
   const float* cs = cache + positions[t] * rot_dim;
   const int half = rot_dim >> 1;
-  typename Hh::T* dst = is_k ? kb + (int64_t)loc[t] * kb_sn + (int64_t)(h - Hq) * kb_sh : q_out + t * q_st + (int64_t)h * D;
+  constexpr int ES = KV8 ? 1 : 2;  // bytes per pool element
+  typename Hh::T* qdst = q_out + t * q_st + (int64_t)h * D;
+  char* kdst = is_k ? kb + ((int64_t)loc[t] * kb_sn + (int64_t)(h - Hq) * kb_sh) * ES : nullptr;
   for (int p = lane; p < half; p += 64) {
     const int i1 = neox ? p : 2 * p, i2 = neox ? p + half : 2 * p + 1;
     const float c = cs[p], sn = cs[half + p];
     const float x1 = Hh::to_f32(gemm_elem<DTYPE>(ps, t, col0 + i1)), x2 = Hh::to_f32(gemm_elem<DTYPE>(ps, t, col0 + i2));
-    dst[i1] = Hh::from_f32(x1 * c - x2 * sn);
-    dst[i2] = Hh::from_f32(x2 * c + x1 * sn);
+    const typename Hh::T o1 = Hh::from_f32(x1 * c - x2 * sn), o2 = Hh::from_f32(x2 * c + x1 * sn);
+    if (is_k) {
+      pool_store<DTYPE, KV8>(kdst, i1, o1);
+      pool_store<DTYPE, KV8>(kdst, i2, o2);
+    } else {
+      qdst[i1] = o1;
+      qdst[i2] = o2;
+    }
   }
-  for (int i = rot_dim + lane; i < D; i += 64) dst[i] = gemm_elem<DTYPE>(ps, t, col0 + i);  // pass-through dims
+  for (int i = rot_dim + lane; i < D; i += 64) {  // pass-through dims
+    const typename Hh::T x = gemm_elem<DTYPE>(ps, t, col0 + i);
+    if (is_k) pool_store<DTYPE, KV8>(kdst, i, x); else qdst[i] = x;
+  }
   if (is_k) {
     const int vcol0 = (Hq + Hk) * D + (h - Hq) * D;
-    typename Hh::T* vdst = vb + (int64_t)loc[t] * vb_sn + (int64_t)(h - Hq) * vb_sh;
-    for (int i = lane; i < D; i += 64) vdst[i] = gemm_elem<DTYPE>(ps, t, vcol0 + i);
+    char* vdst = vb + ((int64_t)loc[t] * vb_sn + (int64_t)(h - Hq) * vb_sh) * ES;
+    for (int i = lane; i < D; i += 64) pool_store<DTYPE, KV8>(vdst, i, gemm_elem<DTYPE>(ps, t, vcol0 + i));
   }
 }
 
-template <int DTYPE, typename LocT>
+template <int DTYPE, typename LocT, bool KV8>
 __global__ __launch_bounds__(256) void rope_kv_kernel(
     typename Half16<DTYPE>::T* __restrict__ q, typename Half16<DTYPE>::T* __restrict__ k,
-    const typename Half16<DTYPE>::T* __restrict__ v, typename Half16<DTYPE>::T* __restrict__ kb,
-    typename Half16<DTYPE>::T* __restrict__ vb, const int64_t* __restrict__ positions, const LocT* __restrict__ loc,
+    const typename Half16<DTYPE>::T* __restrict__ v, char* __restrict__ kb,
+    char* __restrict__ vb, const int64_t* __restrict__ positions, const LocT* __restrict__ loc,
     const float* __restrict__ cache, int64_t T, int Hq, int Hk, int D, int rot_dim, int64_t q_st, int64_t k_st,
     int64_t v_st, int64_t kb_sn, int64_t kb_sh, int64_t vb_sn, int64_t vb_sh, int neox) {
   using Hh = Half16<DTYPE>;
@@ -332,8 +354,9 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(
   typename Hh::T* base = is_k ? k + t * k_st + (int64_t)(h - Hq) * D : q + t * q_st + (int64_t)h * D;
   const float* cs = cache + positions[t] * rot_dim;
   const int half = rot_dim >> 1;
-  typename Hh::T* kdst = nullptr;
-  if (is_k && kb) kdst = kb + (int64_t)loc[t] * kb_sn + (int64_t)(h - Hq) * kb_sh;
+  constexpr int ES = KV8 ? 1 : 2;  // bytes per pool element
+  char* kdst = nullptr;
+  if (is_k && kb) kdst = kb + ((int64_t)loc[t] * kb_sn + (int64_t)(h - Hq) * kb_sh) * ES;
   for (int p = lane; p < half; p += 64) {
     const int i1 = neox ? p : 2 * p, i2 = neox ? p + half : 2 * p + 1;
     const float c = cs[p], sn = cs[half + p];
@@ -342,15 +365,15 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(
     base[i1] = o1;
     base[i2] = o2;
     if (kdst) {
-      kdst[i1] = o1;
-      kdst[i2] = o2;
+      pool_store<DTYPE, KV8>(kdst, i1, o1);
+      pool_store<DTYPE, KV8>(kdst, i2, o2);
     }
   }
   if (kdst) {
-    for (int i = rot_dim + lane; i < D; i += 64) kdst[i] = base[i];  // pass-through dims
+    for (int i = rot_dim + lane; i < D; i += 64) pool_store<DTYPE, KV8>(kdst, i, base[i]);  // pass-through dims
     const typename Hh::T* vs = v + t * v_st + (int64_t)(h - Hq) * D;
-    typename Hh::T* vdst = vb + (int64_t)loc[t] * vb_sn + (int64_t)(h - Hq) * vb_sh;
-    for (int i = lane; i < D; i += 64) vdst[i] = vs[i];
+    char* vdst = vb + ((int64_t)loc[t] * vb_sn + (int64_t)(h - Hq) * vb_sh) * ES;
+    for (int i = lane; i < D; i += 64) pool_store<DTYPE, KV8>(vdst, i, vs[i]);
   }
 }
 
@@ -505,7 +528,8 @@ extern "C" int sgl_mi355_rotary_embedding(
   return check_hip(hipGetLastError(), "rotary_embedding launch");
 }
 
-extern "C" int sgl_mi355_rotary_embedding_set_kv(
+static int rope_set_kv_impl(bool kv8,
+    
     const int64_t* positions, void* query, void* key, const void* value, const float* cos_sin_cache,
     void* k_buffer, void* v_buffer, const void* loc, int loc_is64, int64_t num_tokens, int64_t num_q_heads,
     int64_t num_k_heads, int64_t head_size, int64_t rot_dim, int64_t q_stride_t, int64_t k_stride_t,
@@ -521,18 +545,47 @@ extern "C" int sgl_mi355_rotary_embedding_set_kv(
   SGLM_CHECK_ARG(items < (1ll << 32), "rotary_embedding_set_kv: too many rows");
   const unsigned grid = (unsigned)((items + 3) / 4);
   hipStream_t s = as_stream(stream);
-#define ROPEKV(DT, TT, LT)                                                                                             \
-  hipLaunchKernelGGL((rope_kv_kernel<DT, LT>), dim3(grid), dim3(256), 0, s, (TT*)query, (TT*)key, (const TT*)value,    \
-                     (TT*)k_buffer, (TT*)v_buffer, positions, (const LT*)loc, cos_sin_cache, num_tokens,               \
+#define ROPEKV_(DT, TT, LT, K8)                                                                                        \
+  hipLaunchKernelGGL((rope_kv_kernel<DT, LT, K8>), dim3(grid), dim3(256), 0, s, (TT*)query, (TT*)key, (const TT*)value, \
+                     (char*)k_buffer, (char*)v_buffer, positions, (const LT*)loc, cos_sin_cache, num_tokens,           \
                      (int)num_q_heads, (int)num_k_heads, (int)head_size, (int)rot_dim, q_stride_t, k_stride_t,          \
                      v_stride_t, kb_stride_n, kb_stride_h, vb_stride_n, vb_stride_h, is_neox)
+#define ROPEKV(DT, TT, LT)                  \
+  do {                                      \
+    if (kv8) ROPEKV_(DT, TT, LT, true);     \
+    else ROPEKV_(DT, TT, LT, false);        \
+  } while (0)
   if (dtype == SGL_MI355_BF16) {
     if (loc_is64) ROPEKV(SGL_MI355_BF16, __bf16, int64_t); else ROPEKV(SGL_MI355_BF16, __bf16, int32_t);
   } else {
     if (loc_is64) ROPEKV(SGL_MI355_FP16, _Float16, int64_t); else ROPEKV(SGL_MI355_FP16, _Float16, int32_t);
   }
 #undef ROPEKV
+#undef ROPEKV_
   return check_hip(hipGetLastError(), "rotary_embedding_set_kv launch");
+}
+
+extern "C" int sgl_mi355_rotary_embedding_set_kv(
+    const int64_t* positions, void* query, void* key, const void* value, const float* cos_sin_cache,
+    void* k_buffer, void* v_buffer, const void* loc, int loc_is64, int64_t num_tokens, int64_t num_q_heads,
+    int64_t num_k_heads, int64_t head_size, int64_t rot_dim, int64_t q_stride_t, int64_t k_stride_t,
+    int64_t v_stride_t, int64_t kb_stride_n, int64_t kb_stride_h, int64_t vb_stride_n, int64_t vb_stride_h,
+    int is_neox, int dtype, void* stream) {
+  return rope_set_kv_impl(false, positions, query, key, value, cos_sin_cache, k_buffer, v_buffer, loc, loc_is64, num_tokens, num_q_heads,
+                          num_k_heads, head_size, rot_dim, q_stride_t, k_stride_t, v_stride_t, kb_stride_n, kb_stride_h,
+                          vb_stride_n, vb_stride_h, is_neox, dtype, stream);
+}
+
+// Same with an e4m3 pool: the rotated k and v are cast as sgl_mi355_set_kv_buffer_fp8 does (no scales).
+extern "C" int sgl_mi355_rotary_embedding_set_kv_fp8kv(
+    const int64_t* positions, void* query, void* key, const void* value, const float* cos_sin_cache,
+    void* k_buffer, void* v_buffer, const void* loc, int loc_is64, int64_t num_tokens, int64_t num_q_heads,
+    int64_t num_k_heads, int64_t head_size, int64_t rot_dim, int64_t q_stride_t, int64_t k_stride_t,
+    int64_t v_stride_t, int64_t kb_stride_n, int64_t kb_stride_h, int64_t vb_stride_n, int64_t vb_stride_h,
+    int is_neox, int dtype, void* stream) {
+  return rope_set_kv_impl(true, positions, query, key, value, cos_sin_cache, k_buffer, v_buffer, loc, loc_is64, num_tokens, num_q_heads,
+                          num_k_heads, head_size, rot_dim, q_stride_t, k_stride_t, v_stride_t, kb_stride_n, kb_stride_h,
+                          vb_stride_n, vb_stride_h, is_neox, dtype, stream);
 }
 
 extern "C" int sgl_mi355_rmsnorm_quant_fp8_from_partials(
@@ -550,7 +603,8 @@ extern "C" int sgl_mi355_rmsnorm_quant_fp8_from_partials(
              : launch_rmsnorm_partials<SGL_MI355_FP16>(ps, residual, weight, out_q, out_s, num_tokens, hidden, eps, as_stream(stream));
 }
 
-extern "C" int sgl_mi355_rotary_embedding_set_kv_from_partials(
+static int rope_set_kv_partials_impl(bool kv8,
+    
     void* q_out, void* k_buffer, void* v_buffer, const int64_t* positions, const void* loc, int loc_is64,
     const float* cos_sin_cache, const float* partials, int64_t num_slices, const float* scales_a, const float* scales_b,
     const void* bias /* nullable */, int64_t num_tokens, int64_t num_q_heads, int64_t num_k_heads, int64_t head_size,
@@ -569,16 +623,44 @@ extern "C" int sgl_mi355_rotary_embedding_set_kv_from_partials(
   SGLM_CHECK_ARG(items < (1ll << 32), "rotary_embedding_set_kv_from_partials: too many rows");
   const unsigned grid = (unsigned)((items + 3) / 4);
   hipStream_t s = as_stream(stream);
-#define ROPEKVP(DT, TT, LT)                                                                                              \
-  hipLaunchKernelGGL((rope_kv_from_partials_kernel<DT, LT>), dim3(grid), dim3(256), 0, s, (TT*)q_out, (TT*)k_buffer,       \
-                     (TT*)v_buffer, positions, (const LT*)loc, cos_sin_cache, num_tokens, (int)num_q_heads,               \
+#define ROPEKVP_(DT, TT, LT, K8)                                                                                         \
+  hipLaunchKernelGGL((rope_kv_from_partials_kernel<DT, LT, K8>), dim3(grid), dim3(256), 0, s, (TT*)q_out, (char*)k_buffer, \
+                     (char*)v_buffer, positions, (const LT*)loc, cos_sin_cache, num_tokens, (int)num_q_heads,             \
                      (int)num_k_heads, (int)head_size, (int)rot_dim, q_out_stride_t, kb_stride_n, kb_stride_h,            \
                      vb_stride_n, vb_stride_h, is_neox, ps)
+#define ROPEKVP(DT, TT, LT)                 \
+  do {                                      \
+    if (kv8) ROPEKVP_(DT, TT, LT, true);    \
+    else ROPEKVP_(DT, TT, LT, false);       \
+  } while (0)
   if (dtype == SGL_MI355_BF16) {
     if (loc_is64) ROPEKVP(SGL_MI355_BF16, __bf16, int64_t); else ROPEKVP(SGL_MI355_BF16, __bf16, int32_t);
   } else {
     if (loc_is64) ROPEKVP(SGL_MI355_FP16, _Float16, int64_t); else ROPEKVP(SGL_MI355_FP16, _Float16, int32_t);
   }
 #undef ROPEKVP
+#undef ROPEKVP_
   return check_hip(hipGetLastError(), "rotary_embedding_set_kv_from_partials launch");
+}
+
+extern "C" int sgl_mi355_rotary_embedding_set_kv_from_partials(
+    void* q_out, void* k_buffer, void* v_buffer, const int64_t* positions, const void* loc, int loc_is64,
+    const float* cos_sin_cache, const float* partials, int64_t num_slices, const float* scales_a, const float* scales_b,
+    const void* bias /* nullable */, int64_t num_tokens, int64_t num_q_heads, int64_t num_k_heads, int64_t head_size,
+    int64_t rot_dim, int64_t q_out_stride_t, int64_t kb_stride_n, int64_t kb_stride_h, int64_t vb_stride_n,
+    int64_t vb_stride_h, int is_neox, int dtype, void* stream) {
+  return rope_set_kv_partials_impl(false, q_out, k_buffer, v_buffer, positions, loc, loc_is64, cos_sin_cache, partials, num_slices, scales_a,
+                                    scales_b, bias, num_tokens, num_q_heads, num_k_heads, head_size, rot_dim, q_out_stride_t,
+                                    kb_stride_n, kb_stride_h, vb_stride_n, vb_stride_h, is_neox, dtype, stream);
+}
+
+extern "C" int sgl_mi355_rotary_embedding_set_kv_from_partials_fp8kv(
+    void* q_out, void* k_buffer, void* v_buffer, const int64_t* positions, const void* loc, int loc_is64,
+    const float* cos_sin_cache, const float* partials, int64_t num_slices, const float* scales_a, const float* scales_b,
+    const void* bias /* nullable */, int64_t num_tokens, int64_t num_q_heads, int64_t num_k_heads, int64_t head_size,
+    int64_t rot_dim, int64_t q_out_stride_t, int64_t kb_stride_n, int64_t kb_stride_h, int64_t vb_stride_n,
+    int64_t vb_stride_h, int is_neox, int dtype, void* stream) {
+  return rope_set_kv_partials_impl(true, q_out, k_buffer, v_buffer, positions, loc, loc_is64, cos_sin_cache, partials, num_slices, scales_a,
+                                    scales_b, bias, num_tokens, num_q_heads, num_k_heads, head_size, rot_dim, q_out_stride_t,
+                                    kb_stride_n, kb_stride_h, vb_stride_n, vb_stride_h, is_neox, dtype, stream);
 }

@@ -100,13 +100,6 @@ class LlamaAttention(torch.nn.Module):
         norm; the returned hidden state may then be a GemmPartials."""
         pool = forward_batch.token_to_kv_pool
         kb, vb = pool.get_key_buffer(self.attn.layer_id), pool.get_value_buffer(self.attn.layer_id)
-        if kb.dtype != out_dtype:  # FP8 KV pool: the fused RoPE + KV-write kernels store 16-bit rows; unfused here
-            qkv, _ = self.qkv_proj.forward_prequantized(xq, xs, out_dtype)
-            q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
-            q, k = self.rotary_emb(positions, q, k)
-            attn_output = self.attn(q, k, v, forward_batch)
-            output, _ = self.o_proj(attn_output)
-            return output
         part = self.qkv_proj.forward_prequantized_partials(xq, xs, out_dtype) if defer else None
         if part is not None:  # qkv epilogue + RoPE + KV write in one kernel
             q = ops.rope_set_kv_from_partials(part, positions, self.num_heads, self.num_kv_heads, self.head_dim,

@@ -458,7 +458,11 @@ def rope_set_kv_from_partials(part: GemmPartials, positions, num_q_heads, num_k_
     if positions.dtype != torch.int64:
         positions = positions.to(torch.int64)
     q = torch.empty((part.M, num_q_heads * head_size), dtype=part.out_dtype, device=k_buffer.device)
-    _lib.check(_lib.lib().sgl_mi355_rotary_embedding_set_kv_from_partials(
+    if loc.numel() != part.M:
+        raise RuntimeError("rope_set_kv_from_partials: loc must hold one pool slot per token")
+    fn = _lib.lib().sgl_mi355_rotary_embedding_set_kv_from_partials_fp8kv if _is_fp8_pool(k_buffer, v_buffer, q) \
+        else _lib.lib().sgl_mi355_rotary_embedding_set_kv_from_partials
+    _lib.check(fn(
         _ptr(q), _ptr(k_buffer), _ptr(v_buffer), _ptr(positions), _ptr(loc), _I(_is64(loc, "loc")), _ptr(cos_sin_cache),
         _ptr(part.ws), _I64(part.num_slices), _ptr(part.x_scale), _ptr(part.w_scale), _ptr(part.bias), _I64(part.M),
         _I64(num_q_heads), _I64(num_k_heads), _I64(head_size), _I64(cos_sin_cache.size(1)), _I64(q.stride(0)),
@@ -648,7 +652,8 @@ def apply_rope_with_cos_sin_cache_inplace(positions, query, key, head_size, cos_
 
 def apply_rope_and_set_kv_buffer(positions, query, key, value, head_size, cos_sin_cache, k_buffer, v_buffer, loc,
                                  is_neox=True):
-    """RoPE on query/key (in place) fused with k_buffer[loc] = key, v_buffer[loc] = value."""
+    """RoPE on query/key (in place) fused with k_buffer[loc] = key, v_buffer[loc] = value (cast to e4m3 when the pool
+    is an FP8 one, as set_kv_buffer_fp8 without scales)."""
     _need_gpu(positions, query, key, value, cos_sin_cache, k_buffer, v_buffer, loc)
     if cos_sin_cache.dtype != torch.float32 or not cos_sin_cache.is_contiguous():
         raise RuntimeError("cos_sin_cache should be float32")
@@ -659,7 +664,11 @@ def apply_rope_and_set_kv_buffer(positions, query, key, value, head_size, cos_si
             raise RuntimeError("apply_rope_and_set_kv_buffer: last dim must be contiguous")
     if k_buffer.size(2) != head_size or v_buffer.size(2) != head_size:
         raise RuntimeError("apply_rope_and_set_kv_buffer: pool head size must equal head_size")
-    _lib.check(_lib.lib().sgl_mi355_rotary_embedding_set_kv(
+    if loc.numel() != positions.numel():
+        raise RuntimeError("apply_rope_and_set_kv_buffer: loc must hold one pool slot per token")
+    fn = _lib.lib().sgl_mi355_rotary_embedding_set_kv_fp8kv if _is_fp8_pool(k_buffer, v_buffer, query) \
+        else _lib.lib().sgl_mi355_rotary_embedding_set_kv
+    _lib.check(fn(
         _ptr(positions), _ptr(query), _ptr(key), _ptr(value), _ptr(cos_sin_cache), _ptr(k_buffer), _ptr(v_buffer),
         _ptr(loc), _I(_is64(loc, "loc")), _I64(positions.numel()), _I64(query.size(-1) // head_size),
         _I64(key.size(-1) // head_size), _I64(head_size), _I64(cos_sin_cache.size(1)), _I64(query.stride(0)),

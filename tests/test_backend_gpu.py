@@ -370,3 +370,15 @@ def test_from_partials_ops_equal_unfused_sequence(M, with_bias):
     part = ops.fp8_scaled_mm_partials(a, w.t(), sa, sb, torch.bfloat16, bias)
     q2 = ops.rope_set_kv_from_partials(part, pos, Hq, Hk, D, cache, kb2, vb2, loc, True)
     assert torch.equal(q2, q1) and torch.equal(kb1, kb2) and torch.equal(vb1, vb2)
+    # the same two fused writes into an FP8 (e4m3) pool == 16-bit result cast by set_kv_buffer_fp8: bit-identical
+    kb8_ref, vb8_ref = torch.zeros(201, Hk, D, dtype=torch.uint8, device=DEV), torch.zeros(201, Hk, D, dtype=torch.uint8, device=DEV)
+    ops.set_kv_buffer_fp8(kb8_ref, vb8_ref, loc, k1.reshape(M, Hk, D), v1.reshape(M, Hk, D))  # k1 is rotated by now
+    kb8, vb8 = torch.zeros_like(kb8_ref), torch.zeros_like(vb8_ref)
+    qkv = full.clone()
+    q3, k3, v3 = qkv.split([Hq * D, Hk * D, Hk * D], dim=-1)
+    ops.apply_rope_and_set_kv_buffer(pos, q3, k3, v3, D, cache, kb8, vb8, loc, True)
+    assert torch.equal(q3, q1) and torch.equal(kb8, kb8_ref) and torch.equal(vb8, vb8_ref)
+    kb8.zero_(), vb8.zero_()
+    part = ops.fp8_scaled_mm_partials(a, w.t(), sa, sb, torch.bfloat16, bias)
+    q4 = ops.rope_set_kv_from_partials(part, pos, Hq, Hk, D, cache, kb8.view(torch.float8_e4m3fn), vb8.view(torch.float8_e4m3fn), loc, True)
+    assert torch.equal(q4, q1) and torch.equal(kb8, kb8_ref) and torch.equal(vb8, vb8_ref)
