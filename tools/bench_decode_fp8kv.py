@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Paged decode attention over an FP8 (e4m3) KV pool vs the bf16 pool, bs=64, random page table."""
+"""Paged decode attention over an FP8 (e4m3) KV pool vs the bf16 pool, bs=64, random page table
+(IDENTITY=1: consecutive slots per request)."""
 import json, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,9 +8,11 @@ from sglang_npu_amd import ops
 dev = "cuda:0"
 g = torch.Generator(device=dev).manual_seed(0)
 B, Hq, Hkv, D = 64, 32, 8, 128
-for S in (2048, 8192):
+for S in [int(x) for x in os.environ.get("S_LIST", "2048,8192").split(",")]:
     n_tok = B * S + 1
     r2t = (torch.randperm(n_tok - 1, device=dev, generator=g) + 1).view(B, S).to(torch.int32).contiguous()
+    if os.environ.get("IDENTITY") == "1":
+        r2t = (torch.arange(n_tok - 1, device=dev) + 1).view(B, S).to(torch.int32).contiguous()
     rpi, seq = torch.arange(B, device=dev), torch.full((B,), S, device=dev)
     q = torch.randn(B, Hq, D, device=dev, generator=g).to(torch.bfloat16)
     o = torch.zeros(B, Hq, D, dtype=torch.bfloat16, device=dev)
