@@ -96,36 +96,17 @@ __device__ __forceinline__ int swz_chunk(int c, int row) {
   return (((c >> 1) ^ f) << 1) | (c & 1);
 }
 
-// 16 e4m3 bytes -> 16 values of the 16-bit dtype (exact: e4m3 fits both bf16 and fp16)
-template <int DTYPE>
-__device__ __forceinline__ void cvt16_fp8(const uint4& raw, typename Half16<DTYPE>::x8& lo, typename Half16<DTYPE>::x8& hi) {
-  using Hh = Half16<DTYPE>;
-  typedef float f32x2_t __attribute__((ext_vector_type(2)));
-  const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const f32x2_t a = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[i], false);
-    const f32x2_t b = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[i], true);
-    typename Hh::x8& dst = i < 2 ? lo : hi;
-    const int o = (i & 1) * 4;
-    dst[o + 0] = Hh::from_f32(a[0]);
-    dst[o + 1] = Hh::from_f32(a[1]);
-    dst[o + 2] = Hh::from_f32(b[0]);
-    dst[o + 3] = Hh::from_f32(b[1]);
-  }
-}
-// p (fp32, in [0, 1]) rounded to e4m3 and back: what `p.to(v.dtype)` does with an FP8 V (decode_attention.py:373)
-__device__ __forceinline__ float round_fp8(float p) {
-  typedef float f32x2_t __attribute__((ext_vector_type(2)));
-  const int pk = __builtin_amdgcn_cvt_pk_fp8_f32(p, 0.f, 0, false);
-  const f32x2_t r = __builtin_amdgcn_cvt_pk_f32_fp8(pk, false);
-  return r[0];
+// KV8 byte tiles: XOR applied to the 16-B chunk index of byte row `row` (D bytes per row).  With it the ds_read_b64
+// K-fragment reads (16 rows x 16 B per half-wave) and the ds_read_b64_tr_b8 V reads (16 rows x 16 B per half-wave)
+// each touch all 64 banks once.
+template <int D>
+__device__ __forceinline__ int swz8(int row) {
+  return (D == 128) ? ((row >> 1) & 7) : ((row >> 2) & 3);
 }
 
-// KV8 = 1: the pool holds e4m3 bytes.  Tiles are DMA'd as bytes into a two-stage staging area of the wave's ring and
-// converted (exactly) into ONE 16-bit K tile and ONE 16-bit V tile in the ring's usual swizzled layout; everything
-// behind that (QK^T fragments, transposed V reads, both MFMAs) is the 16-bit code path.  HBM traffic halves; the
-// conversion is ~130 VALU and 24 LDS instructions per 32-token tile and wave, hidden under the byte stream.
+// KV8 = 1: the pool holds e4m3 bytes.  Tiles are DMA'd as bytes (four stages per wave); K fragments are upcast in
+// registers on their way into the 16-bit QK^T MFMA, P is packed to e4m3 and P.V runs on the FP8 MFMA with V^T taken by
+// ds_read_b64_tr_b8 (profiles/r01_tr_b8_probe.txt) -- no 16-bit copy of the tile, no LDS writes.  HBM traffic halves.
 template <int DTYPE, int D, typename IdxT, bool DIRECT_OUT, int kWaves, int KV8 = 0>
 __global__ __launch_bounds__(kWaves * 64) void decode_mfma_kernel(DecodeArgs a) {
   using H = Half16<DTYPE>;
@@ -138,7 +119,11 @@ __global__ __launch_bounds__(kWaves * 64) void decode_mfma_kernel(DecodeArgs a) 
   constexpr int NI = kTile / ROWS_PER_DMA;  // DMA instructions per K (or V) tile
   constexpr int TILE_BYTES = kTile * ROWB;
   constexpr int STAGE_BYTES = 2 * TILE_BYTES;
-  constexpr int WAVE_BYTES = kStages * STAGE_BYTES;
+  // KV8 == 1: byte tiles only, so the 32 KB ring of a wave holds four stages (one workgroup per CU, deepest pipeline);
+  // KV8 == 2: two stages and a 16 KB page-table window, 80 KB in all, so that two workgroups share a CU and one's
+  //           prologue / merge overlaps the other's streaming (what a grid of more than one workgroup per CU wants).
+  constexpr int kStages8 = (KV8 == 2) ? 2 : 4;
+  constexpr int WAVE_BYTES = KV8 ? kStages8 * 2 * kTile * D : kStages * STAGE_BYTES;
   constexpr int KS = D / 32;                // MFMA k-steps for QK^T
   constexpr int NDV = D / 16;               // 16-wide output column blocks
   // KV8: byte rows of D bytes; 1024 / D rows per DMA instruction; staging tile = kTile * D bytes
@@ -148,10 +133,9 @@ __global__ __launch_bounds__(kWaves * 64) void decode_mfma_kernel(DecodeArgs a) 
   constexpr int NI8 = kTile / ROWS8;
   constexpr int TILE8 = kTile * D;
   constexpr int NIQ = KV8 ? NI8 : NI;       // DMA instructions per K (or V) tile in the vmcnt queue
-  static_assert(!KV8 || 2 * TILE_BYTES + 4 * TILE8 <= WAVE_BYTES, "KV8 ring layout");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int kIdxCap = (kWaves == 4) ? 4 * kMaxIdx : kMaxIdx;
+  constexpr int kIdxCap = (KV8 == 2) ? 2 * kMaxIdx : (kWaves >= 4) ? 4 * kMaxIdx : kMaxIdx;
   int32_t* idx_lds = reinterpret_cast<int32_t*>(smem + kWaves * WAVE_BYTES);
 
   const int tid = threadIdx.x;
@@ -246,18 +230,26 @@ __global__ __launch_bounds__(kWaves * 64) void decode_mfma_kernel(DecodeArgs a) 
       const int tok0 = (wave + kWaves * jt) * kTile;
       const char* gb = is_v ? vbase : kbase;
       const int64_t rb = is_v ? v_row_bytes : k_row_bytes;
-      if constexpr (KV8) {  // byte rows, linear staging image: lane i of an instruction = row i / CH8, chunk i % CH8
+      if constexpr (KV8) {
+        // byte rows of D bytes; lane i of an instruction fills chunk position i % CH8 of LDS row i / CH8 with source
+        // chunk (i % CH8) ^ swz8(row).  K rows are the tile's tokens in order; V rows are the PV k-slots:
+        // row 8g + j holds token 4g + j (j < 4) or 16 + 4g + (j - 4), so that ds_read_b64_tr_b8 hands lane group g
+        // the 8 tokens its P fragment is ordered by.
         const uint32_t dst8 = __builtin_amdgcn_readfirstlane(
-            lds_addr_of(wave_lds + 2 * TILE_BYTES + stage * 2 * TILE8 + (is_v ? TILE8 : 0)));
+            lds_addr_of(wave_lds + stage * 2 * TILE8 + (is_v ? TILE8 : 0)));
         int32_t tok8[NI8];
+        int src_off[NI8];
 #pragma unroll
         for (int i = 0; i < NI8; ++i) {
-          int tp = tok0 + i * ROWS8 + lane / CH8;
+          const int row = i * ROWS8 + lane / CH8;
+          const int slot = is_v ? ((row & 4) ? 16 + 4 * (row >> 3) + (row & 3) : 4 * (row >> 3) + (row & 3)) : row;
+          int tp = tok0 + slot;
           tp = tp < n_pass ? tp : n_pass - 1;
           tok8[i] = idx_lds[tp];
+          src_off[i] = ((lane % CH8) ^ swz8<D>(row)) * 16;
         }
 #pragma unroll
-        for (int i = 0; i < NI8; ++i) lds_dma16(gb + (int64_t)tok8[i] * rb + (lane % CH8) * 16, dst8 + i * 1024);
+        for (int i = 0; i < NI8; ++i) lds_dma16(gb + (int64_t)tok8[i] * rb + src_off[i], dst8 + i * 1024);
         return;
       }
       const uint32_t dst = __builtin_amdgcn_readfirstlane(
@@ -276,6 +268,122 @@ __global__ __launch_bounds__(kWaves * 64) void decode_mfma_kernel(DecodeArgs a) 
       }
     };
 
+    if constexpr (KV8) {
+      // ---- e4m3 pool: K fragments are converted in registers straight from the byte tile (K is upcast,
+      // decode_attention.py:336), P is packed to e4m3 (:373) and P.V runs on the FP8 MFMA with V^T read by
+      // ds_read_b64_tr_b8: no 16-bit copy of the tile, four byte stages in flight per wave.
+      typedef float f32x2_t __attribute__((ext_vector_type(2)));
+      // `units` DMA groups of NI8 instructions may stay in flight (K or V tile = one unit)
+      auto wait_units = [&](int units) __attribute__((always_inline)) {
+        switch (units) {
+          case 0: wait_vmcnt<0>(); break;
+          case 1: wait_vmcnt<NI8>(); break;
+          case 2: wait_vmcnt<2 * NI8>(); break;
+          case 3: wait_vmcnt<3 * NI8>(); break;
+          case 4: wait_vmcnt<4 * NI8>(); break;
+          case 5: wait_vmcnt<5 * NI8>(); break;
+          case 6: wait_vmcnt<6 * NI8>(); break;
+          default: wait_vmcnt<7 * NI8>(); break;
+        }
+      };
+#pragma unroll
+      for (int pj = 0; pj < kStages8; ++pj)
+        if (pj < nt) {
+          issue(pj, pj, false);
+          issue(pj, pj, true);
+        }
+      for (int jt = 0; jt < nt; ++jt) {
+        const int st = jt & (kStages8 - 1);
+        const char* kst = wave_lds + st * 2 * TILE8;
+        const char* vst = kst + TILE8;
+        const int tok0 = (wave + kWaves * jt) * kTile;
+        // in the queue behind K(jt): V(jt), K,V of the next `after` tiles
+        const int after = (nt - 1 - jt) < (kStages8 - 1) ? (nt - 1 - jt) : (kStages8 - 1);
+        const bool refill = jt + kStages8 < nt;
+        wait_units(1 + 2 * after);
+
+        // ---- S^T = K Q^T: lane (hl, g) reads bytes 32ks + 8g .. +8 of row 16th + hl
+        f32x4 s_acc[2];
+#pragma unroll
+        for (int th = 0; th < 2; ++th) {
+          s_acc[th] = f32x4{0.f, 0.f, 0.f, 0.f};
+          const int row = 16 * th + hl;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const int c = (2 * ks + (g >> 1)) ^ swz8<D>(row);
+            const uint2 raw = *reinterpret_cast<const uint2*>(kst + row * D + c * 16 + 8 * (g & 1));
+            x8 kf;
+            const f32x2_t a0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)raw.x, false), a1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)raw.x, true);
+            const f32x2_t b0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)raw.y, false), b1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)raw.y, true);
+            kf[0] = H::from_f32(a0[0]); kf[1] = H::from_f32(a0[1]); kf[2] = H::from_f32(a1[0]); kf[3] = H::from_f32(a1[1]);
+            kf[4] = H::from_f32(b0[0]); kf[5] = H::from_f32(b0[1]); kf[6] = H::from_f32(b1[0]); kf[7] = H::from_f32(b1[1]);
+            s_acc[th] = H::mfma16(kf, qf[ks], s_acc[th]);
+          }
+        }
+        wait_lgkmcnt0();  // the K bytes are in registers: refill the slot
+        if (refill) issue(jt + kStages8, st, false);
+
+        // ---- online softmax (log2 domain); token of (th, r) = tok0 + 16*th + 4*g + r
+        float sv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sv[i] = s_acc[i >> 2][i & 3] * (has_cap ? a.sm_scale : scale_log2);
+        if (has_cap) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) sv[i] = a.logit_cap * tanhf(sv[i] / a.logit_cap) * kLog2e;
+        }
+        float m_tile = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const bool valid = (tok0 + 16 * (i >> 2) + 4 * g + (i & 3)) < n_pass;
+          sv[i] = valid ? sv[i] : -INFINITY;
+          m_tile = fmaxf(m_tile, sv[i]);
+        }
+        m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 16));
+        m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32));
+        const float m_new = fmaxf(m_run, m_tile);  // finite: every tile holds >= 1 valid token
+        const float alpha = exp2f(m_run - m_new);
+        float psum = 0.f;
+        float pv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          pv[i] = exp2f(sv[i] - m_new);
+          psum += pv[i];  // the row sum keeps the unrounded p (decode_attention.py:375)
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+        // P^T as e4m3 bytes, k-slot order j = 0..7 (decode_attention.py:373: p.to(v.dtype))
+        int p_lo = __builtin_amdgcn_cvt_pk_fp8_f32(pv[0], pv[1], 0, false);
+        p_lo = __builtin_amdgcn_cvt_pk_fp8_f32(pv[2], pv[3], p_lo, true);
+        int p_hi = __builtin_amdgcn_cvt_pk_fp8_f32(pv[4], pv[5], 0, false);
+        p_hi = __builtin_amdgcn_cvt_pk_fp8_f32(pv[6], pv[7], p_hi, true);
+        const long pf8 = (long)(((unsigned long)(unsigned)p_hi << 32) | (unsigned long)(unsigned)p_lo);
+        if (__ballot(alpha != 1.f) != 0) {  // the running max of some head moved: rescale (exact no-op otherwise)
+#pragma unroll
+          for (int i = 0; i < NDV; ++i) o_acc[i] *= alpha;
+        }
+
+        // ---- wait for V(jt): behind it the next `after` tiles [+ K(jt + stages)]
+        wait_units(2 * after + (refill ? 1 : 0));
+        // ---- O^T += V^T P^T on the FP8 MFMA; lane 2q+p of group g points at row 8g+q, bytes 8p.. of the block
+        {
+          const int vrow = 8 * g + ((lane & 15) >> 1);
+          const char* vrp = vst + vrow * D + 8 * (lane & 1);
+          const int vsw = swz8<D>(vrow);
+#pragma unroll
+          for (int dvb = 0; dvb < NDV; ++dvb) {
+            typedef int v2i_t __attribute__((ext_vector_type(2)));
+            const v2i_t vr = __builtin_amdgcn_ds_read_tr8_b64_v2i32(
+                (__attribute__((address_space(3))) v2i_t*)(vrp + ((dvb ^ vsw) * 16)));
+            const long vf8 = (long)(((unsigned long)(unsigned)vr[1] << 32) | (unsigned long)(unsigned)vr[0]);
+            o_acc[dvb] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(vf8, pf8, o_acc[dvb], 0, 0, 0);
+          }
+        }
+        wait_lgkmcnt0();  // the V bytes are in registers: refill the slot
+        if (refill) issue(jt + kStages8, st, true);
+      }
+      continue;  // next page-table pass
+    }
+
     if (nt > 0) {
       issue(0, 0, false);
       issue(0, 0, true);
@@ -285,45 +393,16 @@ __global__ __launch_bounds__(kWaves * 64) void decode_mfma_kernel(DecodeArgs a) 
       issue(1, 1, true);
     }
 
-    // KV8: staged byte tile -> the 16-bit tile in the ring's swizzled layout (same wave writes and reads it: LDS
-    // operations of a wave execute in order, no barrier)
-    auto convert = [&](int stage, bool is_v) {
-      const char* src = wave_lds + 2 * TILE_BYTES + stage * 2 * TILE8 + (is_v ? TILE8 : 0);
-      char* dst = wave_lds + (is_v ? TILE_BYTES : 0);
-#pragma unroll
-      for (int i = 0; i < NI8; ++i) {
-        const uint4 raw = *reinterpret_cast<const uint4*>(src + i * 1024 + lane * 16);
-        x8 lo, hi;
-        cvt16_fp8<DTYPE>(raw, lo, hi);
-        const int row = i * ROWS8 + lane / CH8, pos = lane % CH8;
-        *reinterpret_cast<x8*>(dst + row * ROWB + swz_chunk<D>(2 * pos, row) * 16) = lo;
-        *reinterpret_cast<x8*>(dst + row * ROWB + swz_chunk<D>(2 * pos + 1, row) * 16) = hi;
-      }
-    };
-
     for (int jt = 0; jt < nt; ++jt) {
       const int st = jt & 1;
-      const char* kst = KV8 ? wave_lds : wave_lds + st * STAGE_BYTES;
+      const char* kst = wave_lds + st * STAGE_BYTES;
       const char* vst = kst + TILE_BYTES;
       const int tok0 = (wave + kWaves * jt) * kTile;
       const bool more1 = jt + 1 < nt;
       const bool more2 = jt + 2 < nt;
 
-      if constexpr (KV8) {
-        // one wave per SIMD: every dependent LDS phase is exposed, so K and V of the tile are converted together
-        // (one read phase, one write phase) and the two refills go out right behind them
-        if (more1) wait_vmcnt<2 * NIQ>(); else wait_vmcnt<0>();  // K8(jt) and V8(jt) landed
-        convert(st, false);
-        convert(st, true);
-        wait_lgkmcnt0();  // the staging slots are free
-        if (more2) {
-          issue(jt + 2, st, false);
-          issue(jt + 2, st, true);
-        }
-      } else {
-        // ---- wait for K(jt): younger ops allowed in flight = V(jt) [+ K,V(jt+1)]
-        if (more1) wait_vmcnt<3 * NIQ>(); else wait_vmcnt<NIQ>();
-      }
+      // ---- wait for K(jt): younger ops allowed in flight = V(jt) [+ K,V(jt+1)]
+      if (more1) wait_vmcnt<3 * NIQ>(); else wait_vmcnt<NIQ>();
 
       // ---- S^T = K Q^T  (rows = tokens, cols = heads)
       f32x4 s_acc[2];
@@ -339,9 +418,7 @@ __global__ __launch_bounds__(kWaves * 64) void decode_mfma_kernel(DecodeArgs a) 
         }
       }
       wait_lgkmcnt0();  // K fragments are in registers: the K buffer may be refilled
-      if constexpr (!KV8) {
-        if (more2) issue(jt + 2, st, false);
-      }
+      if (more2) issue(jt + 2, st, false);
 
       // ---- online softmax (log2 domain); token of (th, r) = tok0 + 16*th + 4*g + r
       float sv[8];
@@ -373,7 +450,7 @@ __global__ __launch_bounds__(kWaves * 64) void decode_mfma_kernel(DecodeArgs a) 
       for (int i = 0; i < 8; ++i) {
         const float p = exp2f(sv[i] - m_new);
         psum += p;  // the row sum keeps the unrounded p (decode_attention.py:375)
-        pf[i] = H::from_f32(KV8 ? round_fp8(p) : p);
+        pf[i] = H::from_f32(p);
       }
       l_run = l_run * alpha + psum;
       m_run = m_new;
@@ -381,9 +458,7 @@ __global__ __launch_bounds__(kWaves * 64) void decode_mfma_kernel(DecodeArgs a) 
       for (int i = 0; i < NDV; ++i) o_acc[i] *= alpha;
 
       // ---- wait for V(jt): younger ops allowed = [K,V(jt+1)] [+ K(jt+2)]
-      if constexpr (!KV8) {
-        if (more2) wait_vmcnt<3 * NIQ>(); else if (more1) wait_vmcnt<2 * NIQ>(); else wait_vmcnt<0>();
-      }
+      if (more2) wait_vmcnt<3 * NIQ>(); else if (more1) wait_vmcnt<2 * NIQ>(); else wait_vmcnt<0>();
 
       // ---- O^T += V^T P^T ; k-slot (g, j): j<4 -> token 4g+j, j>=4 -> token 16+4g+(j-4)
       {
@@ -406,9 +481,7 @@ __global__ __launch_bounds__(kWaves * 64) void decode_mfma_kernel(DecodeArgs a) 
         }
       }
       wait_lgkmcnt0();  // V fragments are in registers: the V buffer may be refilled
-      if constexpr (!KV8) {
-        if (more2) issue(jt + 2, st, true);
-      }
+      if (more2) issue(jt + 2, st, true);
     }
   }
 
@@ -569,9 +642,10 @@ __global__ __launch_bounds__(64) void decode_merge_kernel(DecodeArgs a, int Dv) 
   }
 }
 
-template <int D, int kWaves>
+template <int D, int kWaves, int KV8 = 0>
 constexpr int mfma_lds_bytes() {
-  return kWaves * kStages * 2 * kTile * D * 2 + ((kWaves == 4) ? 4 * kMaxIdx : kMaxIdx) * 4;
+  const int ring = KV8 ? ((KV8 == 2) ? 2 : 4) * 2 * kTile * D : kStages * 2 * kTile * D * 2;
+  return kWaves * ring + ((KV8 == 2) ? 2 * kMaxIdx : (kWaves >= 4) ? 4 * kMaxIdx : kMaxIdx) * 4;
 }
 
 // Waves per workgroup.  2-wave workgroups need <= 72 KB of LDS, so two of them share a CU and
@@ -596,7 +670,7 @@ int set_max_lds(K kernel, int bytes) {
 template <int DTYPE, int D, typename IdxT, bool DIRECT, int kWaves, int KV8 = 0>
 int launch_mfma_w(const DecodeArgs& a, int64_t grid, hipStream_t stream) {
   auto kern = decode_mfma_kernel<DTYPE, D, IdxT, DIRECT, kWaves, KV8>;
-  constexpr int lds = mfma_lds_bytes<D, kWaves>();
+  constexpr int lds = mfma_lds_bytes<D, kWaves, KV8>();
   static int attr_rc = set_max_lds(kern, lds);
   if (attr_rc != 0) return attr_rc;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kWaves * 64), lds, stream, a);
@@ -607,7 +681,17 @@ template <int DTYPE, int D, typename IdxT, bool DIRECT>
 int launch_mfma(const DecodeArgs& a, int64_t batch, hipStream_t stream) {
   const int nhb = (a.group + 15) / 16;
   const int64_t grid = batch * a.num_kv_heads * nhb * a.num_splits;
-  if (a.kv8) return launch_mfma_w<DTYPE, D, IdxT, DIRECT, 4, 1>(a, grid, stream);
+  if (a.kv8) {
+    // measured at bs=64 x 8 kv heads (512 workgroups), S = 512 / 2048 / 8192: two per CU 22 / 64 / 224 us, one per CU
+    // with four stages 30 / 70 / 205 us.  SGL_MI355_DECODE_KV8_STAGES=2|4 overrides (tuning aid).
+    static const int forced = [] {
+      const char* e = getenv("SGL_MI355_DECODE_KV8_STAGES");
+      return e ? atoi(e) : 0;
+    }();
+    const bool two_per_cu = forced == 2 || (forced != 4 && grid > 256);
+    return two_per_cu ? launch_mfma_w<DTYPE, D, IdxT, DIRECT, 4, 2>(a, grid, stream)
+                      : launch_mfma_w<DTYPE, D, IdxT, DIRECT, 4, 1>(a, grid, stream);
+  }
   return pick_waves(grid) == 2 ? launch_mfma_w<DTYPE, D, IdxT, DIRECT, 2>(a, grid, stream)
                                : launch_mfma_w<DTYPE, D, IdxT, DIRECT, 4>(a, grid, stream);
 }
