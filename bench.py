@@ -118,7 +118,8 @@ class DecodeLoop:
 
     def _forward(self):
         logits = self.net(self.input_ids, self.positions, self.fb)
-        self.next_ids.copy_(torch.argmax(logits, dim=-1))
+        from sglang_npu_amd.layers import greedy_sample
+        self.next_ids.copy_(greedy_sample(logits))
 
     def capture(self):
         self.backend.init_cuda_graph_state(self.B, self.B)
@@ -185,6 +186,7 @@ def time_ttft(net, runner, backend, device, input_len=1024, reps=7):
     """p50 time-to-first-token at bs=1: one EXTEND (prefill) pass of `input_len` new tokens with an empty
     prefix through the whole model + greedy sample, device-synchronised (bench_one_batch.py:380-405)."""
     from sglang_npu_amd.harness import ForwardBatch, ForwardMode
+    from sglang_npu_amd.layers import greedy_sample
     r2t = runner.req_to_token_pool.req_to_token
     input_len = min(input_len, r2t.size(1) - 1)
     ids = torch.randint(0, 10000, (input_len,), device=device)
@@ -204,7 +206,7 @@ def time_ttft(net, runner, backend, device, input_len=1024, reps=7):
         t0 = time.perf_counter()
         backend.init_forward_metadata(fb)
         logits = net(ids, pos, fb)
-        tok = torch.argmax(logits[-1:], dim=-1)
+        tok = greedy_sample(logits[-1:])
         tok.item()
         if i >= 2:
             times.append((time.perf_counter() - t0) * 1e3)

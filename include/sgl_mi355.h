@@ -352,6 +352,14 @@ int sgl_mi355_rotary_embedding(const int64_t* positions, void* query, void* key,
                                int64_t rot_dim, int64_t q_stride_t, int64_t k_stride_t, int is_neox, int dtype,
                                void* stream);
 
+/* Greedy sampling.
+ * Replaces: torch.argmax(logits, -1) of Sampler.forward, python/sglang/srt/layers/sampler.py:72-75.
+ *   logits [rows, cols] in `dtype` (0 bf16, 1 fp16, 2 fp32), rows `row_stride` elements apart; out int64 [rows].
+ *   torch's rule: first index of the maximal value, NaN counts as the maximum.  workspace: rows * 12 bytes (8-byte
+ *   aligned), zero-initialised ONCE by the caller; every call returns it to zero (one workspace per stream). */
+int sgl_mi355_argmax(const void* logits, int64_t* out, void* workspace, int64_t rows, int64_t cols, int64_t row_stride,
+                     int dtype, void* stream);
+
 /* RoPE fused with the KV-pool write: rotary_embedding on query/key in place, then
  * k_buffer[loc[t]] = key[t] (rotated), v_buffer[loc[t]] = value[t] -- replaces the pair
  * apply_rope_with_cos_sin_cache_inplace + MHATokenToKVPool.set_kv_buffer (memory_pool.py:369-407). */

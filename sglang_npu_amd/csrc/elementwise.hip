@@ -377,6 +377,88 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Row-wise argmax (greedy sampling, layers/sampler.py:72-75: torch.argmax(logits, -1)).  torch's rule: the FIRST index
+// of the maximal value, NaN counts as the maximum (ATen ArgMaxOps).  Every element becomes a 64-bit key
+// (order-preserving image of the value << 32 | ~index); the maximum key is the answer.  grid (chunks, rows): each
+// workgroup reduces its chunk, merges into keys[row] with one atomicMax, and the last workgroup of a row (ticket
+// counter) writes the index and returns the two workspace words to zero.
+template <int DTYPE>
+struct ArgElem;
+template <>
+struct ArgElem<SGL_MI355_BF16> { using T = __bf16; };
+template <>
+struct ArgElem<SGL_MI355_FP16> { using T = _Float16; };
+template <>
+struct ArgElem<2> { using T = float; };
+
+__device__ __forceinline__ uint32_t arg_order(float v) {
+  v = v + 0.f;  // -0 -> +0: they compare equal in torch
+  const uint32_t u = __builtin_bit_cast(uint32_t, v);
+  if (v != v) return 0xFFFFFFFFu;
+  return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+
+template <int DTYPE>
+__global__ __launch_bounds__(256) void argmax_kernel(const typename ArgElem<DTYPE>::T* __restrict__ x, int64_t row_stride,
+                                                     int64_t* __restrict__ out, unsigned long long* __restrict__ keys,
+                                                     uint32_t* __restrict__ counts, int cols, int chunk_len) {
+  using T = typename ArgElem<DTYPE>::T;
+  constexpr int VEC = 16 / (int)sizeof(T);
+  const int row = blockIdx.y;
+  const T* xr = x + (int64_t)row * row_stride;
+  const int c0 = blockIdx.x * chunk_len;
+  const int c1 = (c0 + chunk_len) < cols ? (c0 + chunk_len) : cols;
+  uint32_t best_o = 0, best_i = 0xFFFFFFFFu;  // below every real key
+  bool any = false;
+  auto take = [&](float v, int i) __attribute__((always_inline)) {
+    const uint32_t o = arg_order(v);
+    if (!any || o > best_o) {  // indices grow within a thread: strict > keeps the first one
+      best_o = o;
+      best_i = (uint32_t)i;
+      any = true;
+    }
+  };
+  const bool vec_ok = (reinterpret_cast<uintptr_t>(xr) % 16 == 0) && (c0 % VEC == 0);
+  int i = c0;
+  if (vec_ok) {
+    const int nv = (c1 - c0) / VEC;
+    for (int v = threadIdx.x; v < nv; v += 256) {
+      const uint4 raw = *reinterpret_cast<const uint4*>(xr + c0 + v * VEC);
+      const T* e = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) take((float)e[j], c0 + v * VEC + j);
+    }
+    i = c0 + nv * VEC;
+  }
+  for (int k = i + threadIdx.x; k < c1; k += 256) take((float)xr[k], k);
+
+  unsigned long long key = any ? (((unsigned long long)best_o << 32) | (0xFFFFFFFFu - best_i)) : 0ull;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const uint32_t lo = __shfl_xor((uint32_t)key, off), hi = __shfl_xor((uint32_t)(key >> 32), off);
+    const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+    key = other > key ? other : key;
+  }
+  __shared__ unsigned long long wkeys[4];
+  if ((threadIdx.x & 63) == 0) wkeys[threadIdx.x >> 6] = key;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) key = wkeys[w] > key ? wkeys[w] : key;
+    atomicMax(&keys[row], key);
+    __threadfence();
+    const uint32_t ticket = atomicAdd(&counts[row], 1u);
+    if (ticket == gridDim.x - 1) {
+      __threadfence();
+      const unsigned long long best = atomicMax(&keys[row], 0ull);  // coherent read
+      out[row] = (int64_t)(0xFFFFFFFFu - (uint32_t)best);
+      atomicExch(&keys[row], 0ull);
+      atomicExch(&counts[row], 0u);
+    }
+  }
+}
+
 template <int DTYPE>
 int launch_rmsnorm(const void* x, void* residual, const void* weight, void* out, void* out_q, float* out_s, int64_t T,
                    int64_t H, float eps, hipStream_t s) {
@@ -663,4 +745,34 @@ extern "C" int sgl_mi355_rotary_embedding_set_kv_from_partials_fp8kv(
   return rope_set_kv_partials_impl(true, q_out, k_buffer, v_buffer, positions, loc, loc_is64, cos_sin_cache, partials, num_slices, scales_a,
                                     scales_b, bias, num_tokens, num_q_heads, num_k_heads, head_size, rot_dim, q_out_stride_t,
                                     kb_stride_n, kb_stride_h, vb_stride_n, vb_stride_h, is_neox, dtype, stream);
+}
+
+extern "C" int sgl_mi355_argmax(const void* logits, int64_t* out, void* workspace, int64_t rows, int64_t cols,
+                                int64_t row_stride, int dtype, void* stream) {
+  SGLM_CHECK_ARG(dtype == SGL_MI355_BF16 || dtype == SGL_MI355_FP16 || dtype == 2, "argmax: dtype must be bf16 (0), fp16 (1) or fp32 (2)");
+  SGLM_CHECK_ARG(rows >= 0 && rows < 65536 && cols >= 1 && cols < (1ll << 31), "argmax: bad shape [%ld, %ld]", (long)rows, (long)cols);
+  if (rows == 0) return 0;
+  SGLM_CHECK_ARG(logits && out && workspace, "argmax: null tensor pointer");
+  int chunks = (int)((1024 + rows - 1) / rows);
+  const int by_len = (int)((cols + 2047) / 2048);
+  if (chunks > by_len) chunks = by_len;
+  if (chunks > 64) chunks = 64;
+  if (chunks < 1) chunks = 1;
+  int chunk_len = (int)((cols + chunks - 1) / chunks);
+  chunk_len = (chunk_len + 7) / 8 * 8;
+  chunks = (int)((cols + chunk_len - 1) / chunk_len);
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(workspace);
+  uint32_t* counts = reinterpret_cast<uint32_t*>(keys + rows);
+  hipStream_t s = as_stream(stream);
+  const dim3 grid((unsigned)chunks, (unsigned)rows);
+  if (dtype == SGL_MI355_BF16)
+    hipLaunchKernelGGL((argmax_kernel<SGL_MI355_BF16>), grid, dim3(256), 0, s, (const __bf16*)logits, row_stride, out, keys,
+                       counts, (int)cols, chunk_len);
+  else if (dtype == SGL_MI355_FP16)
+    hipLaunchKernelGGL((argmax_kernel<SGL_MI355_FP16>), grid, dim3(256), 0, s, (const _Float16*)logits, row_stride, out,
+                       keys, counts, (int)cols, chunk_len);
+  else
+    hipLaunchKernelGGL((argmax_kernel<2>), grid, dim3(256), 0, s, (const float*)logits, row_stride, out, keys, counts,
+                       (int)cols, chunk_len);
+  return check_hip(hipGetLastError(), "argmax launch");
 }

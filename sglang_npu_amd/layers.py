@@ -3,7 +3,7 @@
   RMSNorm          python/sglang/srt/layers/layernorm.py:59-172   (forward(x, residual=None))
   SiluAndMul       python/sglang/srt/layers/activation.py:59-83
   RotaryEmbedding  python/sglang/srt/layers/rotary_embedding.py:79-260 (fp32 cos/sin cache, neox)
-  Sampler (greedy) python/sglang/srt/layers/sampler.py:72-75       (torch.argmax -- plumbing)
+  Sampler (greedy) python/sglang/srt/layers/sampler.py:72-75       (ops.argmax: first maximal index, like torch.argmax)
 """
 from __future__ import annotations
 
@@ -57,4 +57,5 @@ class RotaryEmbedding(torch.nn.Module):
 
 
 def greedy_sample(logits: torch.Tensor) -> torch.Tensor:
-    return torch.argmax(logits, dim=-1)
+    """Sampler.forward with temperature 0 (sampler.py:72-75): argmax over the vocabulary."""
+    return ops.argmax(logits.view(-1, logits.shape[-1]))

@@ -632,6 +632,33 @@ def silu_and_mul_quant_fp8(x: torch.Tensor):
     return q, s
 
 
+_ARGMAX_WS = {}
+
+
+def argmax(logits: torch.Tensor) -> torch.Tensor:
+    """torch.argmax(logits, dim=-1) of the greedy sampler (layers/sampler.py:72-75): first index of the maximum, NaN
+    counts as the maximum; int64 [rows].  logits: 2-D, last dim contiguous, bf16 / fp16 / fp32."""
+    _need_gpu(logits)
+    if logits.dim() != 2 or logits.stride(1) != 1:
+        raise RuntimeError("argmax: logits must be [rows, cols] with a contiguous last dimension")
+    code = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}.get(logits.dtype)
+    if code is None:
+        raise RuntimeError(f"argmax: unsupported dtype {logits.dtype}")
+    rows, cols = logits.shape
+    out = torch.empty((rows,), dtype=torch.int64, device=logits.device)
+    if rows == 0:
+        return out
+    stream = torch.cuda.current_stream(logits.device).cuda_stream
+    key = (logits.device.index, stream)
+    ws = _ARGMAX_WS.get(key)
+    if ws is None or ws.numel() < 2 * rows:  # 16 bytes per row, zeroed once; the kernel leaves it zeroed
+        ws = torch.zeros((2 * max(rows, 256),), dtype=torch.int64, device=logits.device)
+        _ARGMAX_WS[key] = ws
+    _lib.check(_lib.lib().sgl_mi355_argmax(_ptr(logits), _ptr(out), _ptr(ws), _I64(rows), _I64(cols),
+                                           _I64(logits.stride(0)), _I(code), _stream(logits)))
+    return out
+
+
 def apply_rope_with_cos_sin_cache_inplace(positions, query, key, head_size, cos_sin_cache, is_neox=True):
     """sgl_kernel.apply_rope_with_cos_sin_cache_inplace(positions, query, key, head_size, cos_sin_cache, is_neox)
     (rotary_embedding.py:236-247).  query [T, Hq*D], key [T, Hk*D], rows may be strided views."""

@@ -81,3 +81,29 @@ def test_fused_norm_quant_equals_unfused_pair():
     ops.sgl_per_token_quant_fp8(a, qa_ref, sa_ref)
     qa, sa = ops.silu_and_mul_quant_fp8(y)
     assert torch.equal(sa, sa_ref) and torch.equal(qa.view(torch.uint8), qa_ref.view(torch.uint8))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("rows,cols", [(64, 128256), (1, 32000), (7, 151936), (3, 5), (130, 4099)])
+def test_argmax_equals_torch_argmax(dtype, rows, cols):
+    """Greedy sampling (sampler.py:72-75): the same index as torch.argmax -- first maximal value, NaN counts as the
+    maximum -- on rows full of ties (coarse values), with -0/+0, infinities and NaNs."""
+    from sglang_npu_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(rows + cols)
+    x = (torch.randn(rows, cols, device=DEV, generator=g) * 3).round().to(dtype)  # few distinct values: ties everywhere
+    assert torch.equal(ops.argmax(x), torch.argmax(x, dim=-1))
+    y = torch.randn(rows, cols, device=DEV, generator=g).to(dtype)
+    assert torch.equal(ops.argmax(y), torch.argmax(y, dim=-1))
+    z = torch.zeros(rows, cols, device=DEV, dtype=dtype)
+    z[:, cols // 2:] = -0.0
+    z[0, 0] = -0.0
+    assert torch.equal(ops.argmax(z), torch.argmax(z, dim=-1))
+    y[0, cols - 1] = float("inf")
+    y[rows - 1, cols // 3] = float("nan")
+    y[rows - 1, cols - 1] = float("nan")
+    y[rows // 2, 0] = float("-inf")
+    assert torch.equal(ops.argmax(y), torch.argmax(y, dim=-1))
+    # a strided view (rows of a wider matrix) and repeated calls on the self-resetting workspace
+    wide = torch.randn(rows, cols + 24, device=DEV, generator=g).to(dtype)
+    for _ in range(3):
+        assert torch.equal(ops.argmax(wide[:, 8:8 + cols]), torch.argmax(wide[:, 8:8 + cols], dim=-1))
