@@ -120,7 +120,11 @@ __device__ __forceinline__ float round_fp8(float x) {
 // converts each (exactly) into the 16-bit tile image of stage 0 and runs the usual MFMAs on it with Q and P rounded to
 // FP8 first, which is what the Triton kernel computes (fp8 x fp8 products are exact in the 16-bit MFMA as well); the
 // extend stage is the 16-bit code unchanged.
-template <int DTYPE, int D, typename IdxT, int GH, bool MASKED, bool KV8 = false>
+// KSPLIT = 2: the 64 keys of every tile are shared by TWO waves per (head, position block) -- each takes one 32-key half
+// through QK^T, softmax and P.V and the two partial (m, l, O) are merged through LDS at the end.  Per-wave work per tile
+// halves, so the longest query block (the critical path of a short single-request prefill, where there is one
+// workgroup per CU or less) finishes in half the time; the workgroup covers 2 (GH = 2) or 1 head(s).
+template <int DTYPE, int D, typename IdxT, int GH, bool MASKED, bool KV8 = false, int KSPLIT = 1>
 __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
   using H = Half16<DTYPE>;
   using T = typename H::T;
@@ -135,7 +139,9 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
   constexpr int STAGE_BYTES = 2 * TILE_BYTES;
   constexpr int KS = D / 16;                    // 32x32x16 k-steps over the head dim
   constexpr int NDVB = D / 32;                  // 32-wide output blocks
-  constexpr int NPB = 4 / GH;                   // position blocks per workgroup
+  constexpr int NPB = 4 / (GH * KSPLIT);        // position blocks per workgroup
+  constexpr int NTH = 2 / KSPLIT;               // 32-key halves of a tile this wave works on
+  static_assert(GH * KSPLIT <= 4 && (KSPLIT == 1 || KSPLIT == 2), "4 waves = heads x position blocks x key halves");
   constexpr int BP = 32 * NPB;                  // query positions per workgroup
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -164,7 +170,8 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
   if (p0 >= ext) return;
 
   const int head = head0 + (wave % GH);
-  const int pw0 = p0 + 32 * (wave / GH);  // first query position of this wave
+  const int pw0 = p0 + 32 * ((wave / GH) % NPB);  // first query position of this wave
+  const int kh = wave / (GH * NPB);                // KSPLIT == 2: the key half of every tile this wave takes
   const int qpos = pw0 + col;             // this lane's query position within the extend part
   const bool q_ok = qpos < ext;
 
@@ -253,25 +260,27 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
     const char* kst = smem + stage * STAGE_BYTES;
     const char* vst = kst + TILE_BYTES;
     // ---- S^T = K Q^T for the two 32-key halves
-    f32x16 s_acc[2];
+    f32x16 s_acc[NTH];
 #pragma unroll
-    for (int th = 0; th < 2; ++th) {
+    for (int ti = 0; ti < NTH; ++ti) {
+      const int th = KSPLIT == 2 ? kh : ti;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s_acc[th][r] = 0.f;
+      for (int r = 0; r < 16; ++r) s_acc[ti][r] = 0.f;
       const int row = 32 * th + col;
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
         const x8 kf = *reinterpret_cast<const x8*>(kst + row * ROWB + swz_k<D>(2 * s + hh, row) * 16);
-        s_acc[th] = H::mfma32(kf, qf[s], s_acc[th]);
+        s_acc[ti] = H::mfma32(kf, qf[s], s_acc[ti]);
       }
     }
     // ---- online softmax; key of (th, r) = t*64 + 32th + (r&3) + 8(r>>2) + 4hh
     float m_tile = -INFINITY;
 #pragma unroll
-    for (int th = 0; th < 2; ++th)
+    for (int ti = 0; ti < NTH; ++ti)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float s = s_acc[th][r];
+        const int th = KSPLIT == 2 ? kh : ti;
+        float s = s_acc[ti][r];
         if (has_cap) {
           s = s * a.sm_scale;
           s = a.logit_cap * tanhf(s / a.logit_cap) * kLog2e;
@@ -295,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
           if (phase == 1 && a.causal) ok = ok && (key <= qpos);
         }
         s = ok ? s : -INFINITY;
-        s_acc[th][r] = s;
+        s_acc[ti][r] = s;
         m_tile = fmaxf(m_tile, s);
       }
     m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32));
@@ -304,14 +313,14 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
     const float m_safe = m_new == -INFINITY ? 0.f : m_new;
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);
     float psum = 0.f;
-    x8 pf[2][2];
+    x8 pf[NTH][2];
 #pragma unroll
-    for (int th = 0; th < 2; ++th)
+    for (int ti = 0; ti < NTH; ++ti)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(s_acc[th][r] - m_safe);
+        const float p = __builtin_amdgcn_exp2f(s_acc[ti][r] - m_safe);
         psum += p;
-        pf[th][r >> 3][r & 7] = H::from_f32((KV8 && phase == 0) ? round_fp8(p) : p);
+        pf[ti][r >> 3][r & 7] = H::from_f32((KV8 && phase == 0) ? round_fp8(p) : p);
       }
     l_run = l_run * alpha + psum;
     m_run = m_new;
@@ -324,9 +333,10 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
     const int q4 = (lane >> 2) & 3;  // row within a 4-row transposed block
     const int p4 = lane & 3;         // 8-B piece of the 32-B column block
 #pragma unroll
-    for (int th = 0; th < 2; ++th)
+    for (int ti = 0; ti < NTH; ++ti)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
+        const int th = KSPLIT == 2 ? kh : ti;
         const int r_lo = 32 * th + 16 * s2 + 4 * hh + q4;
         const int r_hi = r_lo + 8;
 #pragma unroll
@@ -340,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
             vf[j] = v_lo[j];
             vf[4 + j] = v_hi[j];
           }
-          o_acc[dvb] = H::mfma32(vf, pf[th][s2], o_acc[dvb]);
+          o_acc[dvb] = H::mfma32(vf, pf[ti][s2], o_acc[dvb]);
         }
       }
   };
@@ -449,6 +459,30 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
 
   // ---- epilogue: out = acc / l ; lane (col = qrow, hh), reg r -> dv = 32*dvb + (r&3) + 8(r>>2) + 4hh
   l_run += __shfl_xor(l_run, 32);
+  if constexpr (KSPLIT == 2) {
+    // merge the two key halves: wave kh = 1 hands (O, m, l) to its partner through LDS, element i of lane l at [i][l]
+    __syncthreads();  // every wave is past its last tile: the stages are dead
+    float* mo = reinterpret_cast<float*>(smem) + (wave % (GH * NPB)) * ((NDVB * 16 + 2) * 64);
+    if (kh == 1) {
+#pragma unroll
+      for (int i = 0; i < NDVB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mo[(16 * i + r) * 64 + lane] = o_acc[i][r];
+      mo[(NDVB * 16) * 64 + lane] = m_run;
+      mo[(NDVB * 16 + 1) * 64 + lane] = l_run;
+    }
+    __syncthreads();
+    if (kh == 1) return;
+    const float m_b = mo[(NDVB * 16) * 64 + lane], l_b = mo[(NDVB * 16 + 1) * 64 + lane];
+    const float m_new = fmaxf(m_run, m_b);
+    const float m_safe = m_new == -INFINITY ? 0.f : m_new;
+    const float fa = __builtin_amdgcn_exp2f(m_run - m_safe), fb = __builtin_amdgcn_exp2f(m_b - m_safe);
+    l_run = l_run * fa + l_b * fb;
+#pragma unroll
+    for (int i = 0; i < NDVB; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o_acc[i][r] = o_acc[i][r] * fa + mo[(16 * i + r) * 64 + lane] * fb;
+  }
   if (q_ok) {
     const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
     T* op = reinterpret_cast<T*>(a.o) + (q_start + qpos) * a.o_st + (int64_t)head * a.o_sh;
@@ -540,15 +574,15 @@ __global__ __launch_bounds__(64) void extend_generic_kernel(ExtendArgs a, int D,
   }
 }
 
-template <int DTYPE, int D, typename IdxT, int GH, bool MASKED, bool KV8 = false>
+template <int DTYPE, int D, typename IdxT, int GH, bool MASKED, bool KV8 = false, int KSPLIT = 1>
 int launch_mfma(ExtendArgs a, int64_t batch, int max_len_extend, hipStream_t s) {
-  auto kern = extend_mfma_kernel<DTYPE, D, IdxT, GH, MASKED, KV8>;
+  auto kern = extend_mfma_kernel<DTYPE, D, IdxT, GH, MASKED, KV8, KSPLIT>;
   constexpr int lds = 2 * 2 * kBN * D * 2 + kIdxCap * 4;
   static int attr_rc = check_hip(
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
       "hipFuncSetAttribute");
   if (attr_rc) return attr_rc;
-  constexpr int BP = 32 * (4 / GH);
+  constexpr int BP = 32 * (4 / (GH * KSPLIT));
   a.num_mblocks = (max_len_extend + BP - 1) / BP;
   const int64_t grid = batch * (a.num_heads / GH) * a.num_mblocks;
   if (grid <= 0) return 0;
@@ -602,6 +636,24 @@ int dispatch(ExtendArgs a, int64_t batch, int D, int Dv, int max_len_extend, hip
   if (D == Dv && aligned && (D == 128 || D == 64)) {
     const int gh = (a.group % 4 == 0) ? 4 : (a.group % 2 == 0 ? 2 : 1);
     const bool masked = a.mask != nullptr || a.window > 0;
+    if constexpr (std::is_same<IdxT, int32_t>::value) {
+      // few workgroups (a short prefill of one or two requests): split every tile's keys over wave pairs so that the
+      // longest query block, which sets the kernel time when there are at most about two workgroups per CU, takes half
+      // as long.  Measured, bs=1 Llama-3-8B heads, L = 512 / 1024 / 2048 / 4096 tokens: 19 / 35 / 82 / 295 us split,
+      // 28 / 51 / 100 / 242 us unsplit.  SGL_MI355_EXTEND_KSPLIT=0|1 overrides (tuning aid).
+      static const int ks_env = [] { const char* e = getenv("SGL_MI355_EXTEND_KSPLIT"); return e ? atoi(e) : -1; }();
+      const int bp1 = 32 * (4 / gh);
+      const int64_t grid1 = batch * (a.num_heads / gh) * ((max_len_extend + bp1 - 1) / bp1);
+      const bool ksplit = ks_env >= 0 ? ks_env != 0 : (grid1 <= 512 && max_len_extend >= 256);
+      if (ksplit && !masked) {
+        if (D == 128) {
+          if (gh == 4) return launch_mfma<DTYPE, 128, int32_t, 2, false, false, 2>(a, batch, max_len_extend, s);
+          return launch_mfma<DTYPE, 128, int32_t, 1, false, false, 2>(a, batch, max_len_extend, s);
+        }
+        if (gh == 4) return launch_mfma<DTYPE, 64, int32_t, 2, false, false, 2>(a, batch, max_len_extend, s);
+        return launch_mfma<DTYPE, 64, int32_t, 1, false, false, 2>(a, batch, max_len_extend, s);
+      }
+    }
 #define EXT_LAUNCH(DD, GG)                                                             \
   return masked ? launch_mfma<DTYPE, DD, IdxT, GG, true>(a, batch, max_len_extend, s)   \
                 : launch_mfma<DTYPE, DD, IdxT, GG, false>(a, batch, max_len_extend, s)

@@ -204,7 +204,8 @@ def test_extend_custom_mask(Hq, Hkv, D, kind, skip_prefix):
         o_plain = torch.zeros_like(o)
         ops.extend_attention_fwd(d["q"], d["ke"], d["ve"], o_plain, d["kb"], d["vb"], qo_indptr, kv_indptr, kv_indices,
                                  None, True, None, int(c["ext"].max()), D ** -0.5, 0.0)
-        assert torch.equal(o, o_plain)
+        # same math; the unmasked launch may take the key-split variant (other summation order), so not bit-equal
+        assert (o.float() - o_plain.float()).abs().max().item() <= 2.0 ** -7 * float(o_plain.float().abs().max())
 
 
 @pytest.mark.parametrize("Hq,Hkv,D", [(32, 8, 128), (6, 2, 128), (4, 4, 80)])
@@ -228,7 +229,7 @@ def test_extend_sliding_window(Hq, Hkv, D, window):
         o_plain = torch.zeros_like(o)
         ops.extend_attention_fwd(d["q"], d["ke"], d["ve"], o_plain, d["kb"], d["vb"], qo_indptr, kv_indptr, kv_indices,
                                  None, True, None, int(c["ext"].max()), D ** -0.5, 0.0)
-        assert torch.equal(o, o_plain)
+        assert (o.float() - o_plain.float()).abs().max().item() <= 2.0 ** -7 * float(o_plain.float().abs().max())
 
 
 def test_extend_non_causal_vs_oracle():
