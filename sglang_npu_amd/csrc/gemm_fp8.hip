@@ -1519,7 +1519,10 @@ int run_gemm(const GemmArgs& p, float* workspace, int64_t workspace_floats, hipS
   if (p.M <= 64) {
     static const bool no_astat = getenv("SGL_MI355_NO_ASTAT") != nullptr;  // tuning / A-B aid
     static const bool no_wstream = getenv("SGL_MI355_NO_WSTREAM") != nullptr;  // tuning / A-B aid
-    if (!no_wstream && p.N >= 16 * 8 * 160) {  // >= ~160 workgroups of 8 column blocks
+    static const int direct_min_n = [] { const char* e = getenv("SGL_MI355_WSTREAM_MIN_N"); return e ? atoi(e) : 16 * 8 * 100; }();  // tuning aid
+    // >= ~100 workgroups of 8 column blocks (M = 64, K = 4096: N = 14336 21.6 us here vs 24.1 one-shot; at N = 7168 and
+    // below the two tie or the one-shot kernel wins -- those shapes are latency-, not bandwidth-bound)
+    if (!no_wstream && p.N >= direct_min_n) {
       bool used = false;
       int rc = p.M <= 16   ? launch_wstream<OUT_DTYPE, 1>(p, nullptr, 0, s, used)
                : p.M <= 32 ? launch_wstream<OUT_DTYPE, 2>(p, nullptr, 0, s, used)

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Graph-timed FP8 decode GEMMs (M = 64) at the per-rank shapes of Llama-3-8B under TP = 1, 2, 4, 8 -- what the
+driver's scaling run launches.  Weights rotate through > 256 MB so the Infinity Cache does not flatter the numbers."""
+import json, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sglang_npu_amd import ops
+dev = "cuda:0"
+g = torch.Generator(device=dev).manual_seed(0)
+M = int(os.environ.get("M", "64"))
+H, I, Hq, Hkv, D = 4096, 14336, 32, 8, 128
+for tp in (1, 2, 4, 8):
+    shapes = {"qkv": (H, (Hq + 2 * Hkv) * D // tp), "o": (Hq * D // tp, H), "gate_up": (H, 2 * I // tp), "down": (I // tp, H)}
+    for name, (K, N) in shapes.items():
+        nw = max(2, int(600e6 // (K * N)))
+        nw = min(nw, 64)
+        ws = [((torch.rand(N, K, device=dev, generator=g) - 0.5) * 8).to(torch.float8_e4m3fn) for _ in range(nw)]
+        sb = torch.rand(N, 1, device=dev, generator=g) * 1e-2
+        a = ((torch.rand(M, K, device=dev, generator=g) - 0.5) * 8).to(torch.float8_e4m3fn)
+        sa = torch.rand(M, 1, device=dev, generator=g) * 1e-2
+        run = lambda i: ops.fp8_scaled_mm(a, ws[i % nw].t(), sa, sb, torch.bfloat16)
+        for i in range(3): run(i)
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        reps = 2 * nw
+        with torch.cuda.graph(gr):
+            for i in range(reps): out = run(i)
+        gr.replay(); torch.cuda.synchronize()
+        st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        st.record()
+        for _ in range(3): gr.replay()
+        en.record(); torch.cuda.synchronize()
+        us = st.elapsed_time(en) * 1e3 / (3 * reps)
+        nbytes = K * N + M * K + 2 * M * N
+        print(json.dumps(dict(tp=tp, op=name, K=K, N=N, M=M, us=round(us, 2), GBps=round(nbytes / us / 1e3),
+                              floor_us=round(nbytes / 6.0e6, 2))), flush=True)
+        del ws
