@@ -98,22 +98,6 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, uint32_t lds_addr) {
       : "memory");
 }
 
-// Same, with the global address split into a wave-uniform base (SGPR pair) and a 32-bit per-lane offset:
-// per-instruction address arithmetic stays on the scalar unit.
-__device__ __forceinline__ void lds_dma16_s(const void* sbase, uint32_t voff, uint32_t lds_addr) {
-  lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
-  uint32_t keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %3\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, %2\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(voff), "s"(sbase), "s"(lds_addr)
-      : "memory");
-}
-
 __device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
   return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
 }
