@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--layers", type=int, default=None, help="override the layer count (debug only; invalidates the number)")
     ap.add_argument("--kv-dtype", default="auto", choices=["auto", "fp8_e4m3"],
                     help="KV pool dtype (server_args.py --kv-cache-dtype); the headline number is 'auto' = the model dtype")
+    ap.add_argument("--emulate-tp", type=int, default=0,
+                    help="debug only: run ONE rank's share of a TP=N step on this GPU with the all-reduce stubbed to "
+                         "identity (per-rank kernel rehearsal on a 1-GPU box; invalidates the number)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -284,7 +287,13 @@ def main():
     from sglang_npu_amd.distributed import init_distributed_environment
     _lib.lib()  # fail loudly if the HIP library is missing
     tp_group = init_distributed_environment(device=device)
+    if args.emulate_tp > 1 and world == 1:
+        from sglang_npu_amd.distributed import GroupCoordinator, set_tp_group
+        tp_group = GroupCoordinator(None, 0, args.emulate_tp, device)
+        tp_group.stub_all_reduce = True  # all-reduce and all-gather become identities
+        set_tp_group(tp_group)
     tp = tp_group.world_size
+    dist_on = world > 1  # a real multi-process job (false under --emulate-tp)
 
     net, cfg, runner, backend, max_len = build(args, device, tp)
     loop = DecodeLoop(net, runner, backend, args.batch, args.ctx, device)
@@ -292,7 +301,7 @@ def main():
         loop.capture()
 
     def barrier():
-        if tp > 1:
+        if dist_on:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -304,7 +313,7 @@ def main():
         loop.step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if tp > 1:
+    if dist_on:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -314,7 +323,7 @@ def main():
     # ---- all-reduce overhead (N > 1): the same step with the TP all-reduce stubbed to identity, outside the timed
     # region above ((t_with - t_without) / t_with)
     ar_info = None
-    if tp > 1:
+    if dist_on:
         try:
             tp_group.stub_all_reduce = True
             seq_after = loop.seq_lens.clone()
@@ -376,7 +385,8 @@ def main():
         "config": {"workload": f"{args.model} {args.quant} decode bs={args.batch} ctx={args.ctx} TP={tp} "
                                f"(token-level paged KV, {'HIP graph replay' if loop.graph is not None else 'eager launches'})",
                    "global_batch": args.batch, "seq_len": args.ctx, "layers": len(net.layers),
-                   "parallelism": f"tp{tp}"},
+                   "parallelism": f"tp{tp}" + (" (ONE rank emulated on one GPU, collectives stubbed: not a job number)"
+                                               if args.emulate_tp > 1 and not dist_on else "")},
         "roofline": {"bound": "hbm", "kernel": "decode_mfma_kernel (paged decode attention)",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
@@ -388,7 +398,7 @@ def main():
         out["allreduce"] = ar_info
     try:
         ttft_ms, ttft_len = time_ttft(net, runner, backend, device)
-        if tp > 1:
+        if dist_on:
             t = torch.tensor([ttft_ms], device=device, dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             ttft_ms = float(t.item())
@@ -404,7 +414,7 @@ def main():
             out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if tp > 1:
+    if dist_on:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

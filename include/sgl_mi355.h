@@ -294,6 +294,10 @@ int sgl_mi355_rmsnorm_quant_fp8_from_partials(void* out_q, float* out_s, void* r
                                               int64_t num_slices, const float* scales_a, const float* scales_b,
                                               const void* bias, const void* weight, int64_t num_tokens, int64_t hidden,
                                               float eps, int dtype, void* stream);
+/* silu(gate) * up + per-token FP8 quant with the gate_up GEMM's epilogue folded in: partials [num_slices][T][2d] */
+int sgl_mi355_silu_and_mul_quant_fp8_from_partials(void* out_q, float* out_s, const float* partials, int64_t num_slices,
+                                                   const float* scales_a, const float* scales_b, const void* bias,
+                                                   int64_t num_tokens, int64_t d, int dtype, void* stream);
 int sgl_mi355_rotary_embedding_set_kv_from_partials(
     void* q_out, void* k_buffer, void* v_buffer, const int64_t* positions, const void* loc, int loc_is64,
     const float* cos_sin_cache, const float* partials, int64_t num_slices, const float* scales_a, const float* scales_b,

@@ -203,10 +203,12 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(
 // out[t, :d] = silu(x[t, :d]) * x[t, d:2d]  (+ optional per-row FP8 quant of the result)
 // NT threads per row: decode batches have few, long rows (64 x 14336), so the launcher takes 1024 threads there --
 // the row is latency- and ALU-bound (an exp and a divide per element), not bandwidth-bound.
-template <int DTYPE, int VPT, int NT>
+// FROM_PARTIALS: x is not materialised -- gate and up columns come from the split-K partials of the gate_up GEMM
+// (gemm_row8: slice sums + the reference epilogue, rounded to the 16-bit dtype first, so bit-identical to the unfused path).
+template <int DTYPE, int VPT, int NT, bool FROM_PARTIALS = false>
 __global__ __launch_bounds__(NT) void silu_mul_kernel(
     const typename Half16<DTYPE>::T* __restrict__ x, typename Half16<DTYPE>::T* __restrict__ out,
-    uint8_t* __restrict__ out_q, float* __restrict__ out_s, int d) {
+    uint8_t* __restrict__ out_q, float* __restrict__ out_s, int d, PartialSrc ps = PartialSrc{}) {
   using Hh = Half16<DTYPE>;
   using x8 = typename Hh::x8;
   __shared__ float red[NT / 64];
@@ -218,8 +220,14 @@ __global__ __launch_bounds__(NT) void silu_mul_kernel(
   for (int i = 0; i < VPT; ++i) {
     const int vi = threadIdx.x + NT * i;
     if (vi < nv) {
-      const x8 a = reinterpret_cast<const x8*>(x + row * 2 * d)[vi];
-      const x8 b = reinterpret_cast<const x8*>(x + row * 2 * d + d)[vi];
+      x8 a, b;
+      if constexpr (FROM_PARTIALS) {
+        a = gemm_row8<DTYPE>(ps, row, vi * 8);
+        b = gemm_row8<DTYPE>(ps, row, d + vi * 8);
+      } else {
+        a = reinterpret_cast<const x8*>(x + row * 2 * d)[vi];
+        b = reinterpret_cast<const x8*>(x + row * 2 * d + d)[vi];
+      }
       x8 o;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -518,6 +526,28 @@ int launch_silu(const void* x, void* out, void* out_q, float* out_s, int64_t T, 
   return check_hip(hipGetLastError(), "silu_and_mul launch");
 }
 
+template <int DTYPE>
+int launch_silu_partials(const PartialSrc& ps, void* out_q, float* out_s, int64_t T, int64_t d, hipStream_t s) {
+  using T16 = typename Half16<DTYPE>::T;
+  const int nv = (int)(d >> 3);
+#define SILU_P(V, NT_)                                                                                              \
+  hipLaunchKernelGGL((silu_mul_kernel<DTYPE, V, NT_, true>), dim3((unsigned)T), dim3(NT_), 0, s, (const T16*)nullptr, \
+                     (T16*)nullptr, (uint8_t*)out_q, out_s, (int)d, ps)
+  if (nv >= 1024) {
+    const int vpt = (nv + 1023) / 1024;
+    if (vpt <= 1) SILU_P(1, 1024);
+    else if (vpt <= 2) SILU_P(2, 1024);
+    else SILU_P(4, 1024);
+  } else {
+    const int vpt = (nv + 255) / 256;
+    if (vpt <= 1) SILU_P(1, 256);
+    else if (vpt <= 2) SILU_P(2, 256);
+    else SILU_P(4, 256);
+  }
+#undef SILU_P
+  return check_hip(hipGetLastError(), "silu_and_mul_quant_fp8_from_partials launch");
+}
+
 int check_rows(const char* op, int64_t T, int64_t H, int64_t max_h, int dtype) {
   SGLM_CHECK_ARG(dtype == SGL_MI355_BF16 || dtype == SGL_MI355_FP16, "%s: bad dtype %d", op, dtype);
   SGLM_CHECK_ARG(T >= 0 && T < (1ll << 31), "%s: bad number of rows %ld", op, (long)T);
@@ -775,4 +805,17 @@ extern "C" int sgl_mi355_argmax(const void* logits, int64_t* out, void* workspac
     hipLaunchKernelGGL((argmax_kernel<2>), grid, dim3(256), 0, s, (const float*)logits, row_stride, out, keys, counts,
                        (int)cols, chunk_len);
   return check_hip(hipGetLastError(), "argmax launch");
+}
+
+extern "C" int sgl_mi355_silu_and_mul_quant_fp8_from_partials(
+    void* out_q, float* out_s, const float* partials, int64_t num_slices, const float* scales_a, const float* scales_b,
+    const void* bias /* nullable */, int64_t num_tokens, int64_t d, int dtype, void* stream) {
+  int rc = check_rows("silu_and_mul_quant_fp8_from_partials", num_tokens, d, 32768, dtype);
+  if (rc) return rc;
+  if (num_tokens == 0) return 0;
+  SGLM_CHECK_ARG(out_q && out_s && partials && scales_a && scales_b && num_slices >= 1,
+                 "silu_and_mul_quant_fp8_from_partials: null tensor pointer / bad slice count");
+  PartialSrc ps{partials, (int)num_slices, num_tokens * 2 * d, scales_a, scales_b, bias, (int)(2 * d)};
+  return dtype == SGL_MI355_BF16 ? launch_silu_partials<SGL_MI355_BF16>(ps, out_q, out_s, num_tokens, d, as_stream(stream))
+                                 : launch_silu_partials<SGL_MI355_FP16>(ps, out_q, out_s, num_tokens, d, as_stream(stream));
 }

@@ -41,6 +41,10 @@ def _dummy(shape, dtype, device, low=-1e-3, high=1e-3, seed=1234):
     return t.to(dtype)
 
 
+# widest per-rank gate_up (2 * intermediate / tp) that goes through split-K partials + fused SiLU (tuning: SGL_MI355_GATE_UP_PARTIALS_MAX_N)
+GATE_UP_PARTIALS_MAX_N = int(os.environ.get("SGL_MI355_GATE_UP_PARTIALS_MAX_N", "4096"))
+
+
 class LlamaMLP(torch.nn.Module):
     def __init__(self, hidden_size, intermediate_size, quant_config, dtype):
         super().__init__()
@@ -57,8 +61,16 @@ class LlamaMLP(torch.nn.Module):
 
     def forward_fp8(self, xq, xs, out_dtype, defer: bool = False):
         """Same computation with the activations kept in FP8 between the kernels (fused producers)."""
-        gate_up, _ = self.gate_up_proj.forward_prequantized(xq, xs, out_dtype)
-        aq, a_s = ops.silu_and_mul_quant_fp8(gate_up)
+        part = None
+        if defer and xq.shape[0] <= 64 and self.gate_up_proj.output_size_per_partition <= GATE_UP_PARTIALS_MAX_N:
+            # narrow per-rank gate_up (Llama-3-8B at TP = 8: 4096 -> 3584): the split-K kernel + the epilogue inside
+            # silu.mul beats the latency-bound single-pass GEMM (one rank's step 2.61 -> 2.57 ms); at 7168 columns it loses
+            part = self.gate_up_proj.forward_prequantized_partials(xq, xs, out_dtype)
+        if part is not None:
+            aq, a_s = ops.silu_and_mul_quant_fp8_from_partials(part)
+        else:
+            gate_up, _ = self.gate_up_proj.forward_prequantized(xq, xs, out_dtype)
+            aq, a_s = ops.silu_and_mul_quant_fp8(gate_up)
         if defer:  # leave the down_proj epilogue to the next norm (ops.GemmPartials)
             part = self.down_proj.forward_prequantized_partials(aq, a_s, out_dtype)
             if part is not None:
@@ -261,8 +273,9 @@ class LlamaForCausalLM(torch.nn.Module):
         hidden_states = self.embed_tokens[input_ids]
         residual = None
         fused = self.fuse_quant and (forward_batch.forward_mode.is_decode() or forward_batch.forward_mode.is_extend())
-        defer = (fused and self.defer_epilogues and forward_batch.forward_mode.is_decode()
-                 and get_tensor_model_parallel_world_size() == 1)
+        # (under tensor parallelism the row-parallel GEMMs decline -- the all-reduce needs their finished output --
+        #  while the column-parallel qkv / gate_up still hand their partials to RoPE / SiLU)
+        defer = fused and self.defer_epilogues and forward_batch.forward_mode.is_decode()
         for layer in self.layers:
             if fused:
                 hidden_states, residual = layer.forward_fp8(positions, hidden_states, forward_batch, residual, defer)

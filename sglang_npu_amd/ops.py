@@ -447,6 +447,20 @@ def rmsnorm_quant_fp8_from_partials(part: GemmPartials, residual: torch.Tensor, 
     return q, s
 
 
+def silu_and_mul_quant_fp8_from_partials(part: GemmPartials):
+    """SiLU(gate) * up + per-token FP8 quant of a gate_up GEMM left as split-K partials (its epilogue included).
+    Returns (q [M, N/2] e4m3fn, scale [M,1] f32) -- bit-identical to silu_and_mul_quant_fp8(part.finalize())."""
+    if part.N % 16 != 0:
+        raise RuntimeError("silu_and_mul_quant_fp8_from_partials: the GEMM is not a [T, 2d] gate_up projection")
+    d = part.N // 2
+    q = torch.empty((part.M, d), dtype=torch.float8_e4m3fn, device=part.ws.device)
+    s = torch.empty((part.M, 1), dtype=torch.float32, device=part.ws.device)
+    _lib.check(_lib.lib().sgl_mi355_silu_and_mul_quant_fp8_from_partials(
+        _ptr(q), _ptr(s), _ptr(part.ws), _I64(part.num_slices), _ptr(part.x_scale), _ptr(part.w_scale), _ptr(part.bias),
+        _I64(part.M), _I64(d), _I(0 if part.out_dtype == torch.bfloat16 else 1), _stream(q)))
+    return q, s
+
+
 def rope_set_kv_from_partials(part: GemmPartials, positions, num_q_heads, num_k_heads, head_size, cos_sin_cache,
                               k_buffer, v_buffer, loc, is_neox=True) -> torch.Tensor:
     """qkv GEMM epilogue + RoPE + KV-pool write; returns the rotated q [M, Hq*D]."""

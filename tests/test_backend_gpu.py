@@ -335,7 +335,8 @@ def test_deferred_gemm_epilogues_are_bit_identical():
 @pytest.mark.parametrize("M", [1, 16, 33, 64])
 @pytest.mark.parametrize("with_bias", [False, True])
 def test_from_partials_ops_equal_unfused_sequence(M, with_bias):
-    """sgl_mi355_fp8_scaled_mm_partials + {finalize, rmsnorm_quant_fp8_from_partials, rope_set_kv_from_partials}
+    """sgl_mi355_fp8_scaled_mm_partials + {finalize, rmsnorm_quant_fp8_from_partials, silu_and_mul_quant_fp8_from_partials,
+    rope_set_kv_from_partials}
     against fp8_scaled_mm followed by the unfused op: bit-identical."""
     from sglang_npu_amd import ops
     g = torch.Generator(device=DEV).manual_seed(M + int(with_bias))
@@ -357,6 +358,11 @@ def test_from_partials_ops_equal_unfused_sequence(M, with_bias):
     part = ops.fp8_scaled_mm_partials(a, w.t(), sa, sb, torch.bfloat16, bias)
     q, s = ops.rmsnorm_quant_fp8_from_partials(part, r2, wn, 1e-5)
     assert torch.equal(q.view(torch.uint8), q_ref.view(torch.uint8)) and torch.equal(s, s_ref) and torch.equal(r1, r2)
+    # SiLU * mul + quant: treat the H = 1024 outputs as [gate | up] with d = 512
+    q_ref, s_ref = ops.silu_and_mul_quant_fp8(full)
+    part = ops.fp8_scaled_mm_partials(a, w.t(), sa, sb, torch.bfloat16, bias)
+    q, s = ops.silu_and_mul_quant_fp8_from_partials(part)
+    assert torch.equal(q.view(torch.uint8), q_ref.view(torch.uint8)) and torch.equal(s, s_ref)
     # RoPE + KV write: treat the H = 1024 outputs as qkv of Hq = 4, Hk = 2, D = 128
     Hq, Hk, D = 4, 2, 128
     pos = torch.randint(0, 500, (M,), device=DEV, generator=g)
