@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(
 // of the maximal value, NaN counts as the maximum (ATen ArgMaxOps).  Every element becomes a 64-bit key
 // (order-preserving image of the value << 32 | ~index); the maximum key is the answer.  grid (chunks, rows): each
 // workgroup reduces its chunk, merges into keys[row] with one atomicMax, and the last workgroup of a row (ticket
-// counter) writes the index and returns the two workspace words to zero.
+// counter) writes the index and returns the two workspace words to zero.  Atomics only, no fences.
 template <int DTYPE>
 struct ArgElem;
 template <>
@@ -454,11 +454,13 @@ __global__ __launch_bounds__(256) void argmax_kernel(const typename ArgElem<DTYP
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int w = 1; w < 4; ++w) key = wkeys[w] > key ? wkeys[w] : key;
-    atomicMax(&keys[row], key);
-    __threadfence();
+    // Ordering without fences (an agent-scope __threadfence is an L2 write-back + invalidate across the XCDs, ~10 us):
+    // everything handed between workgroups goes through RETURNING device-scope atomics, and each later atomic is
+    // issued only after the previous one's result has come back -- i.e. after it was performed at the coherence point.
+    const unsigned long long seen = atomicMax(&keys[row], key);
+    asm volatile("" ::"v"((uint32_t)seen), "v"((uint32_t)(seen >> 32)) : "memory");  // wait for the result
     const uint32_t ticket = atomicAdd(&counts[row], 1u);
     if (ticket == gridDim.x - 1) {
-      __threadfence();
       const unsigned long long best = atomicMax(&keys[row], 0ull);  // coherent read
       out[row] = (int64_t)(0xFFFFFFFFu - (uint32_t)best);
       atomicExch(&keys[row], 0ull);
