@@ -194,6 +194,16 @@ int sgl_mi355_extend_attention_fwd_fp8kv(
     const uint8_t* custom_mask, const int64_t* mask_indptr, int skip_prefix_custom_mask, int64_t sliding_window_size,
     int dtype, void* stream);
 
+/* Split merge fused with the per-token FP8 quant of the attention output (the input of o_proj in the w8a8 model).
+ * Replaces: stage 2 of the decode (decode.cpp:812-860 / decode_attention.py:491-548) followed by sgl_per_token_quant_fp8
+ *           (per_token_quant_fp8.cu:15-87) on the [num_seqs, num_heads * head_size_v] result -- bit-identical to the pair.
+ *   attn_logits [B][Hq][splits][Dv+1] as left by sgl_mi355_decode_attention(_fp8kv) called with output == NULL (stage 1
+ *   only; attn_logits is then required even for one split); output (nullable) receives the 16-bit rows as well;
+ *   out_q e4m3 [B, Hq * Dv] contiguous, out_s fp32 [B].  Hq * Dv % 8 == 0, <= 16384. */
+int sgl_mi355_decode_merge_quant_fp8(const float* attn_logits, int64_t num_seqs, int64_t num_heads, int64_t head_size_v,
+                                     int64_t num_kv_splits, void* output, int64_t o_stride_b, int64_t o_stride_h,
+                                     void* out_q, float* out_s, int dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * merge_state: combine two partial attention results of the same queries by their log-sum-exp.
  * Replaces: merge_state_triton(prefix_output, prefix_lse, suffix_output, suffix_lse, output, output_lse)

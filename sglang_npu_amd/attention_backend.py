@@ -274,8 +274,27 @@ class MI355AttnBackend(AttentionBackend):
         return 1
 
     # ---------------------------------------------------------------- forward
-    def forward_decode(self, q, k, v, layer, forward_batch: ForwardBatch, save_kv_cache=True):
+    def forward_decode(self, q, k, v, layer, forward_batch: ForwardBatch, save_kv_cache=True, fp8_out: bool = False):
+        """fp8_out (MI355X extension, passed through RadixAttention's **kwargs): the caller wants the per-token FP8
+        quantisation of the output (the w8a8 o_proj input).  When the kv-splits are merged anyway, the merge kernel
+        quantises in the same pass and (q_fp8, scale) is returned instead of the 16-bit tensor; otherwise the flag is
+        ignored and the caller quantises."""
         q = q.reshape(-1, layer.tp_q_head_num * layer.qk_head_dim)
+        md = self.forward_metadata
+        if (fp8_out and not self.flat_kv_indices and isinstance(md.num_kv_splits, int) and md.num_kv_splits > 1
+                and md.attn_logits is not None and layer.qk_head_dim == layer.v_head_dim
+                and (layer.tp_q_head_num * layer.v_head_dim) % 8 == 0
+                and not (getattr(layer, "sliding_window_size", None) is not None and layer.sliding_window_size > -1
+                         and md.window_kv_indices is not None)):
+            if save_kv_cache:
+                forward_batch.token_to_kv_pool.set_kv_buffer(layer, forward_batch.out_cache_loc, k, v)
+            kb = forward_batch.token_to_kv_pool.get_key_buffer(layer.layer_id)
+            vb = forward_batch.token_to_kv_pool.get_value_buffer(layer.layer_id)
+            q3 = q.view(-1, layer.tp_q_head_num, layer.qk_head_dim)
+            ops.decode_attention_paged(q3, kb, vb, None, self.req_to_token, forward_batch.req_pool_indices,
+                                       forward_batch.seq_lens, md.attn_logits[:q3.shape[0]], md.num_kv_splits,
+                                       layer.scaling, layer.logit_cap)
+            return ops.decode_merge_quant_fp8(md.attn_logits[:q3.shape[0]], md.num_kv_splits, q.dtype)
         if layer.qk_head_dim != layer.v_head_dim:
             o = q.new_empty((q.shape[0], layer.tp_q_head_num * layer.v_head_dim))
         else:
@@ -300,7 +319,7 @@ class MI355AttnBackend(AttentionBackend):
                                        layer.logit_cap)
         return o
 
-    def forward_extend(self, q, k, v, layer, forward_batch: ForwardBatch, save_kv_cache=True):
+    def forward_extend(self, q, k, v, layer, forward_batch: ForwardBatch, save_kv_cache=True, **kwargs):
         if layer.qk_head_dim != layer.v_head_dim:
             o = q.new_empty((q.shape[0], layer.tp_q_head_num * layer.v_head_dim))
         else:

@@ -642,6 +642,82 @@ __global__ __launch_bounds__(64) void decode_merge_kernel(DecodeArgs a, int Dv) 
   }
 }
 
+
+// Merge of the kv-splits fused with the per-token FP8 quant of the attention output (what feeds o_proj in the w8a8
+// model): one workgroup per request merges all heads with decode_merge_kernel's arithmetic, rounds to the 16-bit
+// dtype, takes the row absmax and writes e4m3 + scale exactly as sgl_per_token_quant_fp8 would on that 16-bit row
+// (per_token_quant_fp8.cu:15-87: scale = absmax / 448, q = clamp(x * (1 / scale))) -- bit-identical to the two
+// launches it replaces.  The 16-bit row itself is written only if `a.out` is given.
+template <int DTYPE, int NT>
+__global__ __launch_bounds__(NT) void decode_merge_quant_kernel(DecodeArgs a, int Dv, uint8_t* __restrict__ out_q,
+                                                                float* __restrict__ out_s) {
+  using H = Half16<DTYPE>;
+  using T = typename H::T;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int Hq = a.num_heads, S = a.num_splits, R = Hq * Dv;
+  T* row = reinterpret_cast<T*>(smem);                                   // [R] merged output, 16-bit
+  float* ew = reinterpret_cast<float*>(smem + ((R * 2 + 15) & ~15));     // [Hq][S] exp(lse - M); then [Hq] 1 / L
+  float* inv = ew + Hq * S;
+  __shared__ float red[NT / 64];
+  for (int h = tid; h < Hq; h += NT) {
+    const float* lse = a.mid_lse + (int64_t)b * a.ml_sb + (int64_t)h * a.ml_sh;
+    float M = -INFINITY;
+    for (int s = 0; s < S; ++s) M = fmaxf(M, lse[(int64_t)s * a.ml_ss]);
+    float L = 0.f;
+    for (int s = 0; s < S; ++s) {
+      const float l = lse[(int64_t)s * a.ml_ss];
+      const float e = (M == -INFINITY || l == -INFINITY) ? 0.f : expf(l - M);  // 0: an empty split, partial undefined
+      ew[h * S + s] = e;
+      if (M != -INFINITY) L += expf(l - M);
+    }
+    inv[h] = M == -INFINITY ? 0.f : 1.f / L;  // empty sequence: zero row
+  }
+  __syncthreads();
+  float amax = 0.f;
+  for (int e = tid; e < R; e += NT) {
+    const int h = e / Dv, d = e - h * Dv;
+    const float* mo = a.mid_o + (int64_t)b * a.mo_sb + (int64_t)h * a.mo_sh + d;
+    const float* w = ew + h * S;
+    float acc = 0.f;
+    for (int s0 = 0; s0 < S; s0 += 8) {  // eight splits' loads in flight; the sum stays in split order
+      float m[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) m[u] = mo[(int64_t)(s0 + u < S ? s0 + u : S - 1) * a.mo_ss];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (s0 + u < S) {
+          const float wu = w[s0 + u];
+          if (wu != 0.f) acc += wu * m[u];
+        }
+    }
+    const T o = H::from_f32(acc * inv[h]);
+    row[e] = o;
+    amax = fmaxf(amax, fabsf(H::to_f32(o)));
+    if (a.out) reinterpret_cast<T*>(a.out)[(int64_t)b * a.o_sb + (int64_t)h * a.o_sh + d] = o;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+  if ((tid & 63) == 0) red[tid >> 6] = amax;
+  __syncthreads();
+  amax = red[0];
+#pragma unroll
+  for (int i = 1; i < NT / 64; ++i) amax = fmaxf(amax, red[i]);
+  const float scale = amax / 448.0f;
+  if (tid == 0) out_s[b] = scale;
+  const float sinv = scale == 0.f ? 0.f : 1.0f / scale;
+  for (int v = tid; v < (R >> 3); v += NT) {
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = fminf(fmaxf(H::to_f32(row[8 * v + j]) * sinv, -448.0f), 448.0f);
+    int lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+    int hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+    reinterpret_cast<uint2*>(out_q + (int64_t)b * R)[v] = uint2{(unsigned)lo, (unsigned)hi};
+  }
+}
+
 template <int D, int kWaves, int KV8 = 0>
 constexpr int mfma_lds_bytes() {
   const int ring = KV8 ? ((KV8 == 2) ? 2 : 4) * 2 * kTile * D : kStages * 2 * kTile * D * 2;
@@ -727,10 +803,11 @@ int dispatch_stage1(const DecodeArgs& a, int64_t batch, int D, int Dv, bool dire
 
 template <int DTYPE>
 int run_decode(DecodeArgs a, int64_t batch, int D, int Dv, bool idx64, hipStream_t stream) {
-  const bool direct = (a.num_splits == 1 && a.num_kv_splits == nullptr);
+  // a.out == nullptr: stage 1 only -- the caller merges (sgl_mi355_decode_merge_quant_fp8)
+  const bool direct = (a.num_splits == 1 && a.num_kv_splits == nullptr && a.out != nullptr);
   int rc = idx64 ? dispatch_stage1<DTYPE, int64_t>(a, batch, D, Dv, direct, stream)
                  : dispatch_stage1<DTYPE, int32_t>(a, batch, D, Dv, direct, stream);
-  if (rc != 0 || direct) return rc;
+  if (rc != 0 || direct || a.out == nullptr) return rc;
   hipLaunchKernelGGL((decode_merge_kernel<DTYPE>), dim3((unsigned)(batch * a.num_heads)), dim3(64), 0, stream, a, Dv);
   return check_hip(hipGetLastError(), "decode_merge_kernel launch");
 }
@@ -768,9 +845,10 @@ extern "C" int sgl_mi355_decode_attention(
   int rc = check_common(num_seqs, num_heads, num_kv_heads, head_size, head_size_v, num_kv_splits, dtype);
   if (rc) return rc;
   if (num_seqs == 0) return 0;
-  SGLM_CHECK_ARG(query && k_cache && v_cache && output && req_to_token && req_pool_indices && seq_lens,
+  SGLM_CHECK_ARG(query && k_cache && v_cache && req_to_token && req_pool_indices && seq_lens,
                  "decode_attention: null tensor pointer");
-  SGLM_CHECK_ARG(attn_logits != nullptr || num_kv_splits == 1, "decode_attention: attn_logits is required when num_kv_splits > 1");
+  SGLM_CHECK_ARG(attn_logits != nullptr || (num_kv_splits == 1 && output != nullptr),
+                 "decode_attention: attn_logits is required when num_kv_splits > 1 or output is null (stage 1 only)");
   SGLM_CHECK_ARG(!(tl_kv8 && loc != nullptr), "decode_attention_fp8kv: write the pool with set_kv_buffer_fp8 (loc must be null)");
   if (loc != nullptr) {
     SGLM_CHECK_ARG(key && value, "decode_attention: key/value are required when loc is given");
@@ -864,4 +942,38 @@ extern "C" int sgl_mi355_decode_attention_fwd_fp8kv(
                                                 v_stride_h, o_stride_b, o_stride_h, sm_scale, logit_cap, dtype, stream);
   tl_kv8 = 0;
   return rc;
+}
+
+extern "C" int sgl_mi355_decode_merge_quant_fp8(const float* attn_logits, int64_t num_seqs, int64_t num_heads,
+                                                int64_t head_size_v, int64_t num_kv_splits, void* output,
+                                                int64_t o_stride_b, int64_t o_stride_h, void* out_q, float* out_s,
+                                                int dtype, void* stream) {
+  SGLM_CHECK_ARG(dtype == SGL_MI355_BF16 || dtype == SGL_MI355_FP16, "decode_merge_quant_fp8: dtype must be bf16 (0) or fp16 (1)");
+  SGLM_CHECK_ARG(num_seqs >= 0 && num_heads > 0 && head_size_v > 0 && num_kv_splits >= 1 && num_kv_splits <= 65535,
+                 "decode_merge_quant_fp8: bad shape");
+  SGLM_CHECK_ARG((num_heads * head_size_v) % 8 == 0 && num_heads * head_size_v <= 16384 && num_heads * num_kv_splits <= 4096,
+                 "decode_merge_quant_fp8: num_heads * head_size_v must be a multiple of 8 and <= 16384");
+  if (num_seqs == 0) return 0;
+  SGLM_CHECK_ARG(attn_logits && out_q && out_s, "decode_merge_quant_fp8: null tensor pointer");
+  DecodeArgs a{};
+  const int64_t l2 = head_size_v + 1, l1 = num_kv_splits * l2, l0 = num_heads * l1;
+  a.mid_o = const_cast<float*>(attn_logits); a.mo_sb = l0; a.mo_sh = l1; a.mo_ss = l2;
+  a.mid_lse = const_cast<float*>(attn_logits) + head_size_v; a.ml_sb = l0; a.ml_sh = l1; a.ml_ss = l2;
+  a.out = output; a.o_sb = o_stride_b; a.o_sh = o_stride_h;
+  a.num_heads = (int)num_heads; a.num_splits = (int)num_kv_splits;
+  const int R = (int)(num_heads * head_size_v);
+  const int lds = ((R * 2 + 15) & ~15) + (int)(num_heads * num_kv_splits + num_heads) * 4;
+  hipStream_t s = as_stream(stream);
+  // few requests: 1024 threads per row (the row is a chain of dependent memory round trips, not bandwidth)
+#define MQ_GO(DT, NT_)                                                                                              \
+  hipLaunchKernelGGL((decode_merge_quant_kernel<DT, NT_>), dim3((unsigned)num_seqs), dim3(NT_), lds, s, a,            \
+                     (int)head_size_v, (uint8_t*)out_q, out_s)
+  const bool wide = num_seqs <= 128 && R >= 2048;
+  if (dtype == SGL_MI355_BF16) {
+    if (wide) MQ_GO(SGL_MI355_BF16, 1024); else MQ_GO(SGL_MI355_BF16, 256);
+  } else {
+    if (wide) MQ_GO(SGL_MI355_FP16, 1024); else MQ_GO(SGL_MI355_FP16, 256);
+  }
+#undef MQ_GO
+  return check_hip(hipGetLastError(), "decode_merge_quant launch");
 }

@@ -41,6 +41,8 @@ def _dummy(shape, dtype, device, low=-1e-3, high=1e-3, seed=1234):
     return t.to(dtype)
 
 
+# fewest decode rows for which GEMM epilogues are deferred into the consumer kernels (tuning: SGL_MI355_DEFER_MIN_ROWS)
+DEFER_MIN_ROWS = int(os.environ.get("SGL_MI355_DEFER_MIN_ROWS", "32"))
 # widest per-rank gate_up (2 * intermediate / tp) that goes through split-K partials + fused SiLU (tuning: SGL_MI355_GATE_UP_PARTIALS_MAX_N)
 GATE_UP_PARTIALS_MAX_N = int(os.environ.get("SGL_MI355_GATE_UP_PARTIALS_MAX_N", "4096"))
 
@@ -123,18 +125,24 @@ class LlamaAttention(torch.nn.Module):
             q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
             ops.apply_rope_and_set_kv_buffer(positions, q, k, v, self.head_dim, self.rotary_emb.cos_sin_cache, kb, vb,
                                              forward_batch.out_cache_loc, self.rotary_emb.is_neox_style)
-        attn_output = self.attn(q, k, v, forward_batch, save_kv_cache=False)
-        if defer:  # leave the o_proj epilogue to post_attention_layernorm
+        # fp8_out: when the backend merges kv-splits anyway, the merge kernel also does o_proj's input quant
+        attn_output = self.attn(q, k, v, forward_batch, save_kv_cache=False,
+                                fp8_out=forward_batch.forward_mode.is_decode())
+        if isinstance(attn_output, tuple):
+            aq, a_s = attn_output
+        elif defer:
             a2 = attn_output.view(-1, attn_output.shape[-1]).contiguous()  # apply_fp8_linear's own quant step
             aq = torch.empty_like(a2, dtype=torch.float8_e4m3fn)
             a_s = torch.empty((a2.shape[0], 1), dtype=torch.float32, device=a2.device)
             ops.sgl_per_token_quant_fp8(a2, aq, a_s)
+        else:
+            output, _ = self.o_proj(attn_output)
+            return output
+        if defer:  # leave the o_proj epilogue to post_attention_layernorm
             part = self.o_proj.forward_prequantized_partials(aq, a_s, out_dtype)
             if part is not None:
                 return part
-            output, _ = self.o_proj.forward_prequantized(aq, a_s, out_dtype)
-            return output
-        output, _ = self.o_proj(attn_output)
+        output, _ = self.o_proj.forward_prequantized(aq, a_s, out_dtype)
         return output
 
 
@@ -275,7 +283,11 @@ class LlamaForCausalLM(torch.nn.Module):
         fused = self.fuse_quant and (forward_batch.forward_mode.is_decode() or forward_batch.forward_mode.is_extend())
         # (under tensor parallelism the row-parallel GEMMs decline -- the all-reduce needs their finished output --
         #  while the column-parallel qkv / gate_up still hand their partials to RoPE / SiLU)
-        defer = fused and self.defer_epilogues and forward_batch.forward_mode.is_decode()
+        # ... and only for more than 32 rows: the split-K kernels the partials come from are the best GEMM there, while
+        # smaller batches have faster single-pass kernels (whole step, ms: bs=1 3.59 vs 4.88 deferred, bs=16 4.24 vs 4.62,
+        # bs=32 5.24 vs 5.23, bs=48 6.58 vs 6.44, bs=64 7.17 vs 7.06)
+        defer = (fused and self.defer_epilogues and forward_batch.forward_mode.is_decode()
+                 and input_ids.shape[0] > DEFER_MIN_ROWS)
         for layer in self.layers:
             if fused:
                 hidden_states, residual = layer.forward_fp8(positions, hidden_states, forward_batch, residual, defer)

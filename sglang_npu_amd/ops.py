@@ -178,11 +178,12 @@ def decode_attention_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_indi
     if req_pool_indices.dtype != torch.int64 or seq_lens.dtype != torch.int64:
         raise RuntimeError("decode_attention_paged: req_pool_indices and seq_lens must be int64")
     for name, t in (("q", q), ("k_buffer", k_buffer), ("v_buffer", v_buffer), ("o", o)):
-        if t.dim() != 3 or t.stride(-1) != 1:
+        if t is not None and (t.dim() != 3 or t.stride(-1) != 1):
             raise RuntimeError(f"decode_attention_paged: {name} must be 3-D, contiguous at the last dimension")
     B, Hq, D = q.shape
     Dv = v_buffer.size(2)
-    if num_kv_splits > 1:
+    o_sb, o_sh = (o.stride(0), o.stride(1)) if o is not None else (0, 0)  # o None: stage 1 only (decode_merge_quant_fp8)
+    if num_kv_splits > 1 or o is None:
         if attn_logits is None or attn_logits.dtype != torch.float32 or not attn_logits.is_contiguous() or \
                 attn_logits.numel() < B * Hq * num_kv_splits * (Dv + 1):
             raise RuntimeError("decode_attention_paged: attn_logits must be contiguous float32 "
@@ -195,7 +196,7 @@ def decode_attention_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_indi
             _I(_is64(req_to_token, "req_to_token")), _ptr(req_pool_indices), _ptr(seq_lens), _I64(B),
             _I64(req_to_token.size(1)), _I64(Hq), _I64(k_buffer.size(1)), _I64(D), _I64(Dv), _I64(num_kv_splits),
             _I64(q.stride(0)), _I64(q.stride(1)), _I64(k_buffer.stride(0)), _I64(k_buffer.stride(1)),
-            _I64(v_buffer.stride(0)), _I64(v_buffer.stride(1)), _I64(o.stride(0)), _I64(o.stride(1)),
+            _I64(v_buffer.stride(0)), _I64(v_buffer.stride(1)), _I64(o_sb), _I64(o_sh),
             _F(sm_scale), _F(logit_cap), _I(_dtype_code(q)), _stream(q)))
         return
     _lib.check(_lib.lib().sgl_mi355_decode_attention(
@@ -205,8 +206,28 @@ def decode_attention_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_indi
         _I64(B), _I64(req_to_token.size(1)), _I64(Hq), _I64(k_buffer.size(1)), _I64(D), _I64(Dv), _I64(num_kv_splits),
         _I64(q.stride(0)), _I64(q.stride(1)), _I64(k_buffer.stride(0)), _I64(k_buffer.stride(1)),
         _I64(v_buffer.stride(0)), _I64(v_buffer.stride(1)), _I64(0), _I64(0), _I64(0), _I64(0),
-        _I64(o.stride(0)), _I64(o.stride(1)),
+        _I64(o_sb), _I64(o_sh),
         _F(sm_scale), _F(logit_cap), _I(_dtype_code(q)), _stream(q)))
+
+
+def decode_merge_quant_fp8(attn_logits, num_kv_splits, out_dtype, o=None):
+    """Merge the kv-split partials left by decode_attention_paged(..., o=None) and quantise the result per token to FP8
+    in the same pass: (q [B, Hq*Dv] e4m3fn, scale [B,1] f32), bit-identical to the merge followed by
+    per_token_quant_fp8.  attn_logits fp32 [B, Hq, num_kv_splits, Dv+1]; o (optional [B,Hq,Dv]) also gets the 16-bit rows."""
+    _need_gpu(attn_logits, o)
+    if attn_logits.dim() != 4 or attn_logits.dtype != torch.float32 or not attn_logits.is_contiguous() or \
+            attn_logits.size(2) != num_kv_splits:
+        raise RuntimeError("decode_merge_quant_fp8: attn_logits must be contiguous float32 [B, Hq, num_kv_splits, Dv+1]")
+    B, Hq, _, Dv1 = attn_logits.shape
+    Dv = Dv1 - 1
+    q = torch.empty((B, Hq * Dv), dtype=torch.float8_e4m3fn, device=attn_logits.device)
+    s = torch.empty((B, 1), dtype=torch.float32, device=attn_logits.device)
+    code = {torch.bfloat16: 0, torch.float16: 1}[out_dtype]
+    o_sb, o_sh = (o.stride(0), o.stride(1)) if o is not None else (0, 0)
+    _lib.check(_lib.lib().sgl_mi355_decode_merge_quant_fp8(
+        _ptr(attn_logits), _I64(B), _I64(Hq), _I64(Dv), _I64(num_kv_splits), _ptr(o), _I64(o_sb), _I64(o_sh), _ptr(q),
+        _ptr(s), _I(code), _stream(attn_logits)))
+    return q, s
 
 
 def decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_logits, attn_lse, num_kv_splits,

@@ -299,12 +299,13 @@ def test_fused_fp8_path_equals_unfused_in_prefill():
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
 
 
-def test_deferred_gemm_epilogues_are_bit_identical():
+def test_deferred_gemm_epilogues_are_bit_identical(monkeypatch):
     """defer=True leaves the qkv / o_proj / down_proj epilogues to the consumer kernels (RoPE + KV write, add + RMSNorm +
     quant) on split-K partials.  Same slice order, same roundings -> logits and pool contents identical to the
     fused-producer path without deferral, bit for bit."""
     cfg = ModelConfig(8, 2, 128, 1024, 2048, 3, 512, 256)  # K = 1024 / 2048: on the split-K weight-streaming path
     outs = []
+    monkeypatch.setattr(M, "DEFER_MIN_ROWS", 0)  # the model only defers above 32 rows (a speed policy); test it at 5
     for defer in (False, True):
         net = M.LlamaForCausalLM(cfg, "w8a8_fp8", torch.bfloat16, DEV).load_dummy_weights()
         net.defer_epilogues = defer

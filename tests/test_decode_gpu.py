@@ -186,3 +186,35 @@ def test_decode_empty_batch_and_zero_length():
     assert (o[0] == 0).all()  # empty sequence -> zero row
     ops.decode_attention(q[:0], kb, kb, o[:0], None, None, None, torch.zeros(0, 32, 2, 129, device=DEV), r2t,
                          torch.arange(0, device=DEV), seq[:0], 0.1, 0.0)  # empty batch: no-op
+
+
+@pytest.mark.parametrize("Hq,Hkv,D", [(8, 1, 128), (32, 8, 128), (14, 2, 64)])
+@pytest.mark.parametrize("splits", [2, 4])
+@pytest.mark.parametrize("fp8_pool", [False, True])
+def test_merge_fused_with_fp8_quant_is_bit_identical(Hq, Hkv, D, splits, fp8_pool):
+    """sgl_mi355_decode_attention with output = NULL (stage 1 only) + sgl_mi355_decode_merge_quant_fp8 against the full
+    decode followed by sgl_per_token_quant_fp8 of the [B, Hq*D] result: same bytes, same scales, same 16-bit rows."""
+    g = torch.Generator(device=DEV).manual_seed(Hq + D + splits)
+    B, max_len = 6, 600
+    seq = torch.tensor([600, 1, 33, 256, 417, 0], device=DEV)  # one empty request: zero row, scale 0
+    n_tok = B * max_len + 1
+    kv_dt = torch.float8_e4m3fn if fp8_pool else torch.bfloat16
+    kb = torch.randn(n_tok, Hkv, D, device=DEV, generator=g).to(kv_dt)
+    vb = torch.randn(n_tok, Hkv, D, device=DEV, generator=g).to(kv_dt)
+    r2t = (torch.randperm(n_tok - 1, device=DEV, generator=g) + 1).view(B, max_len).int()
+    q = torch.randn(B, Hq, D, device=DEV, generator=g).bfloat16()
+    rpi = torch.arange(B, device=DEV)
+    logits = torch.zeros(B, Hq, splits, D + 1, device=DEV)
+    o_ref = torch.zeros(B, Hq, D, dtype=torch.bfloat16, device=DEV)
+    ops.decode_attention_paged(q, kb, vb, o_ref, r2t, rpi, seq, logits, splits, D ** -0.5, 0.0)
+    q_ref = torch.empty(B, Hq * D, dtype=torch.float8_e4m3fn, device=DEV)
+    s_ref = torch.empty(B, 1, device=DEV)
+    ops.sgl_per_token_quant_fp8(o_ref.view(B, Hq * D), q_ref, s_ref)
+    logits2 = torch.full_like(logits, float("nan"))
+    ops.decode_attention_paged(q, kb, vb, None, r2t, rpi, seq, logits2, splits, D ** -0.5, 0.0)
+    o2 = torch.zeros_like(o_ref)
+    qq, ss = ops.decode_merge_quant_fp8(logits2, splits, torch.bfloat16, o2)
+    assert torch.equal(o2, o_ref)
+    assert torch.equal(ss, s_ref) and torch.equal(qq.view(torch.uint8), q_ref.view(torch.uint8))
+    qq2, ss2 = ops.decode_merge_quant_fp8(logits2, splits, torch.bfloat16)  # without the 16-bit copy
+    assert torch.equal(ss2, s_ref) and torch.equal(qq2.view(torch.uint8), q_ref.view(torch.uint8))
