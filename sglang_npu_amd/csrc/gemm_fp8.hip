@@ -453,7 +453,9 @@ int launch_oneshot(const GemmArgs& p, hipStream_t s, bool& used) {
   const unsigned grid = (unsigned)((p.N + 15) / 16);
   // M > 32: 167 VGPRs -> one workgroup per CU; a second round of workgroups (N = 6144: 384) costs more than the
   // pipelined kernel's 32-column tiles (measured 23.0 vs 20.6 us), so only take shapes that fit one round.
-  if (MB == 4 && grid > 256) return 0;
+  static const unsigned max_grid4 = [] { const char* e = getenv("SGL_MI355_ONESHOT_MAX_GRID"); return e ? (unsigned)atoi(e) : 256u; }();  // tuning aid
+  // (one k-step per wave is cheap enough for several rounds: K = 1024, N = 8192 -- 512 workgroups -- 8.2 us vs 14.4)
+  if (MB == 4 && grid > max_grid4 && !(S == 1 && grid <= 1024)) return 0;
   const int lds = WK * MB * 16 * 16 * 4;
 #define OS_GO(S_)                                                                                          \
   hipLaunchKernelGGL((fp8_gemm_oneshot_kernel<OUT_DTYPE, MB, S_>), dim3(grid), dim3(64 * WK), lds, s, p)
@@ -772,14 +774,14 @@ __global__ __launch_bounds__(512) void fp8_gemm_astat_direct_kernel(GemmArgs p, 
 //     only ~10 B/clk from HBM, so an idle CU is lost bandwidth: N = 28672 -> 7 consumers x 256 workgroups).
 template <int OUT_DTYPE, int MB, int PH, bool SLAB>
 __global__ __launch_bounds__(576) void fp8_gemm_wstream_kernel(GemmArgs p, float* slabs, int phases_per_slice) {
-  static_assert(PH == 8 || PH == 16 || PH == 32, "PH");
+  static_assert(PH == 4 || PH == 8 || PH == 16 || PH == 32, "PH");
   static_assert(PH * MB <= 32, "one A buffer is at most 64 KiB");
   using H = Half16<OUT_DTYPE>;
   using T = typename H::T;
   constexpr int ROWS = 16 * MB;
   constexpr int STEP_BYTES = ROWS * 128;
   constexpr int BUF_BYTES = PH * STEP_BYTES;  // <= 64 KiB
-  constexpr int PB = 8;                       // weight steps in flight per wave (16 KiB)
+  constexpr int PB = PH < 8 ? PH : 8;         // weight steps in flight per wave (16 KiB)
   constexpr int UPS = 2 * MB;                 // 1-KiB DMA units per k-step
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -974,7 +976,9 @@ int launch_wstream(const GemmArgs& p, float* slabs, int64_t slab_floats, hipStre
   // only ~10 B/clk from HBM, so minimise the k-steps on the busiest CU (+ ~4 steps' worth of barrier per phase).
   // Without slabs: all of K per workgroup, longest phase (N = 28672: 7 consumers -> exactly 256 workgroups).
   int PH = 0, nc = 8, SK = 1, pps = 0, best = 1 << 30;
-  for (int ph = 32 / MB; ph >= 8; ph >>= 1) {
+  // K / 128 not a multiple of 8 (e.g. 3584 = 28 steps): phases of 4 steps, four weight steps in flight
+  const int ph_min = (steps % 8 == 0) ? 8 : 4;
+  for (int ph = 32 / MB; ph >= ph_min; ph >>= 1) {
     if (ph > ph_cap && ph > 8) continue;
     if (steps % ph != 0) continue;
     const int P = steps / ph;
@@ -1005,6 +1009,7 @@ int launch_wstream(const GemmArgs& p, float* slabs, int64_t slab_floats, hipStre
                : launch_wstream_ph<OUT_DTYPE, MB, PH_, false>(p, nullptr, 1, pps, nc, groups, s)
   if constexpr (MB == 1) { if (PH == 32) WS_GO(32); }
   if constexpr (MB <= 2) { if (PH == 16) WS_GO(16); }
+  if (PH == 4) WS_GO(4);
   WS_GO(8);
 #undef WS_GO
 }
@@ -1550,7 +1555,8 @@ int run_gemm(const GemmArgs& p, float* workspace, int64_t workspace_floats, hipS
                            : launch_wstream<OUT_DTYPE, 4>(p, workspace, workspace_floats, s, used);
       if (rc || used) return rc;
     }
-    if (!no_astat && workspace != nullptr && (int64_t)p.N * p.K >= (int64_t)40 * 1024 * 1024) {
+    static const int astat_min = [] { const char* e = getenv("SGL_MI355_ASTAT_MIN_MI"); return e ? atoi(e) : 40; }();  // tuning aid
+    if (!no_astat && workspace != nullptr && (int64_t)p.N * p.K >= ((int64_t)astat_min << 20)) {
       bool used = false;
       int rc = p.M <= 16   ? launch_astat<OUT_DTYPE, 1>(p, workspace, workspace_floats, s, used)
                : p.M <= 32 ? launch_astat<OUT_DTYPE, 2>(p, workspace, workspace_floats, s, used)

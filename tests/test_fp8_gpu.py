@@ -141,3 +141,21 @@ def test_fp8_scaled_mm_checks():
         ops.fp8_scaled_mm(a, w.t(), s[:4], s, torch.bfloat16)
     with pytest.raises(RuntimeError, match="column major"):
         ops.fp8_scaled_mm(a, torch.zeros(24, 16, dtype=torch.float8_e4m3fn, device=DEV), s[:4], s, torch.bfloat16)
+
+
+@pytest.mark.parametrize("M", [1, 16, 33, 64])
+@pytest.mark.parametrize("K,N", [(3584, 8192), (1536, 4096), (3584, 28672)])
+def test_k_steps_not_multiple_of_eight(M, K, N):
+    """K / 128 = 28 or 12 (Llama-3-70B down_proj per TP-8 rank: 3584): the weight streamer runs phases of four k-steps."""
+    g = torch.Generator(device=DEV).manual_seed(M + K)
+    a = ((torch.rand(M, K, device=DEV, generator=g) - 0.5) * 8).to(torch.float8_e4m3fn)
+    w = ((torch.rand(N, K, device=DEV, generator=g) - 0.5) * 8).to(torch.float8_e4m3fn)
+    sa = torch.rand(M, 1, device=DEV, generator=g) * 1e-2 + 1e-3
+    sb = torch.rand(N, 1, device=DEV, generator=g) * 1e-2 + 1e-3
+    bias = torch.randn(N, device=DEV, generator=g).bfloat16()
+    out = ops.fp8_scaled_mm(a, w.t(), sa, sb, torch.bfloat16, bias)
+    ref = (a.float() @ w.float().t()) * sb.view(1, -1) * sa + bias.float()
+    assert torch.allclose(out.float(), ref, rtol=2 ** -7, atol=2 ** -7 * float(ref.abs().max()))
+    part = ops.fp8_scaled_mm_partials(a, w.t(), sa, sb, torch.bfloat16, bias)
+    if part is not None:
+        assert torch.allclose(part.finalize().float(), ref, rtol=2 ** -7, atol=2 ** -7 * float(ref.abs().max()))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Graph-timed FP8 decode GEMMs (M = 64) at the per-rank shapes of Llama-3-8B under TP = 1, 2, 4, 8 -- what the
+"""Graph-timed FP8 decode GEMMs (M = 64) at the per-rank shapes of Llama-3-8B (MODEL=llama3-70b: the 70B) under TP = 1, 2, 4, 8 -- what the
 driver's scaling run launches.  Weights rotate through > 256 MB so the Infinity Cache does not flatter the numbers."""
 import json, os, sys
 import torch
@@ -9,8 +9,10 @@ dev = "cuda:0"
 g = torch.Generator(device=dev).manual_seed(0)
 M = int(os.environ.get("M", "64"))
 H, I, Hq, Hkv, D = 4096, 14336, 32, 8, 128
-for tp in (1, 2, 4, 8):
-    shapes = {"qkv": (H, (Hq + 2 * Hkv) * D // tp), "o": (Hq * D // tp, H), "gate_up": (H, 2 * I // tp), "down": (I // tp, H)}
+if os.environ.get("MODEL") == "llama3-70b":
+    H, I, Hq, Hkv, D = 8192, 28672, 64, 8, 128
+for tp in [int(x) for x in os.environ.get("TP_LIST", "1,2,4,8").split(",")]:
+    shapes = {"qkv": (H, (Hq + 2 * max(Hkv, tp)) * D // tp), "o": (Hq * D // tp, H), "gate_up": (H, 2 * I // tp), "down": (I // tp, H)}
     for name, (K, N) in shapes.items():
         nw = max(2, int(600e6 // (K * N)))
         nw = min(nw, 64)
