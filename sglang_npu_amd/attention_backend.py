@@ -338,7 +338,10 @@ class MI355AttnBackend(AttentionBackend):
         # snapshot the window size never reaches the kernel's SLIDING_WINDOW_SIZE -- the window acts through
         # window_kv_indices only.  Kept identical on purpose (same inputs -> same results).
         ops.extend_attention_fwd(
-            q.view(-1, layer.tp_q_head_num, layer.qk_head_dim), k.contiguous(), v.contiguous(),
+            q.view(-1, layer.tp_q_head_num, layer.qk_head_dim),
+            # (the reference makes k and v contiguous here, triton_backend.py:667-668; the HIP kernel takes the token /
+            #  head strides of the qkv split as they are -- two copies less per layer)
+            k if k.stride(-1) == 1 else k.contiguous(), v if v.stride(-1) == 1 else v.contiguous(),
             o.view(-1, layer.tp_q_head_num, layer.v_head_dim),
             forward_batch.token_to_kv_pool.get_key_buffer(layer.layer_id),
             forward_batch.token_to_kv_pool.get_value_buffer(layer.layer_id),

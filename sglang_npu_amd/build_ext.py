@@ -25,7 +25,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
-            "-ffp-contract=fast", "-I", os.path.join(ROOT, "include")]
+            "-ffp-contract=fast-honor-pragmas", "-I", os.path.join(ROOT, "include")]
 
 
 def _deps():

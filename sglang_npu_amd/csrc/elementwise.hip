@@ -98,9 +98,9 @@ __device__ __forceinline__ typename Half16<DTYPE>::x8 gemm_row8(const PartialSrc
   typename Hh::x8 o;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    // explicit roundings (no fma contraction): must match fp8_gemm_finalize_kernel bit for bit
-    float r = __fmul_rn(__fmul_rn(v[j], ps.sb[col + j]), sa);
-    if (ps.bias) r = __fadd_rn(r, Hh::to_f32(reinterpret_cast<const typename Hh::T*>(ps.bias)[col + j]));
+#pragma clang fp contract(off)  // explicit roundings (no fma contraction): must match fp8_gemm_finalize_kernel bit for bit
+    float r = (v[j] * ps.sb[col + j]) * sa;
+    if (ps.bias) r = r + Hh::to_f32(reinterpret_cast<const typename Hh::T*>(ps.bias)[col + j]);
     o[j] = Hh::from_f32(r);
   }
   return o;
@@ -118,8 +118,12 @@ __device__ __forceinline__ typename Half16<DTYPE>::T gemm_elem(const PartialSrc&
     for (int u = 0; u < 4; ++u)
       if (s0 + u < ps.num_slices) v += a[u];
   }
-  float r = __fmul_rn(__fmul_rn(v, ps.sb[col]), ps.sa[row]);
-  if (ps.bias) r = __fadd_rn(r, Hh::to_f32(reinterpret_cast<const typename Hh::T*>(ps.bias)[col]));
+  float r;
+  {
+#pragma clang fp contract(off)
+    r = (v * ps.sb[col]) * ps.sa[row];
+    if (ps.bias) r = r + Hh::to_f32(reinterpret_cast<const typename Hh::T*>(ps.bias)[col]);
+  }
   return Hh::from_f32(r);
 }
 
@@ -258,6 +262,15 @@ __global__ __launch_bounds__(NT) void silu_mul_kernel(
   }
 }
 
+// One rotation, every product and sum rounded on its own (no fma contraction): the four RoPE kernels below must agree
+// bit for bit -- the fused paths are tested against the unfused sequence with torch.equal.
+__device__ __forceinline__ void rope_pair(float x1, float x2, float c, float s, float& o1, float& o2) {
+#pragma clang fp contract(off)  // __fmul_rn & co. are plain operators in the HIP headers and DO get fused otherwise
+  const float a = x1 * c, b = x2 * s, d = x2 * c, e = x1 * s;
+  o1 = a - b;
+  o2 = d + e;
+}
+
 // In-place rotary embedding on q [T,Hq,D] and k [T,Hk,D] (row strides given), fp32 cos/sin cache
 // [max_pos, rot_dim] = [cos | sin].  One thread per (token, head, pair).
 template <int DTYPE>
@@ -279,8 +292,10 @@ __global__ __launch_bounds__(256) void rope_kernel(
     const int i1 = neox ? p : 2 * p;
     const int i2 = neox ? p + half : 2 * p + 1;
     const float x1 = Hh::to_f32(base[i1]), x2 = Hh::to_f32(base[i2]);
-    base[i1] = Hh::from_f32(x1 * c - x2 * s);
-    base[i2] = Hh::from_f32(x2 * c + x1 * s);
+    float r1, r2;
+    rope_pair(x1, x2, c, s, r1, r2);
+    base[i1] = Hh::from_f32(r1);
+    base[i2] = Hh::from_f32(r2);
   }
 }
 
@@ -324,7 +339,9 @@ __global__ __launch_bounds__(256) void rope_kv_from_partials_kernel(
     const int i1 = neox ? p : 2 * p, i2 = neox ? p + half : 2 * p + 1;
     const float c = cs[p], sn = cs[half + p];
     const float x1 = Hh::to_f32(gemm_elem<DTYPE>(ps, t, col0 + i1)), x2 = Hh::to_f32(gemm_elem<DTYPE>(ps, t, col0 + i2));
-    const typename Hh::T o1 = Hh::from_f32(x1 * c - x2 * sn), o2 = Hh::from_f32(x2 * c + x1 * sn);
+    float r1, r2;
+    rope_pair(x1, x2, c, sn, r1, r2);
+    const typename Hh::T o1 = Hh::from_f32(r1), o2 = Hh::from_f32(r2);
     if (is_k) {
       pool_store<DTYPE, KV8>(kdst, i1, o1);
       pool_store<DTYPE, KV8>(kdst, i2, o2);
@@ -369,7 +386,9 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(
     const int i1 = neox ? p : 2 * p, i2 = neox ? p + half : 2 * p + 1;
     const float c = cs[p], sn = cs[half + p];
     const float x1 = Hh::to_f32(base[i1]), x2 = Hh::to_f32(base[i2]);
-    const typename Hh::T o1 = Hh::from_f32(x1 * c - x2 * sn), o2 = Hh::from_f32(x2 * c + x1 * sn);
+    float r1, r2;
+    rope_pair(x1, x2, c, sn, r1, r2);
+    const typename Hh::T o1 = Hh::from_f32(r1), o2 = Hh::from_f32(r2);
     base[i1] = o1;
     base[i2] = o2;
     if (kdst) {
@@ -465,6 +484,67 @@ __global__ __launch_bounds__(256) void argmax_kernel(const typename ArgElem<DTYP
       out[row] = (int64_t)(0xFFFFFFFFu - (uint32_t)best);
       atomicExch(&keys[row], 0ull);
       atomicExch(&counts[row], 0u);
+    }
+  }
+}
+
+
+// Vectorised form of rope_kv_kernel for the common case (neox style, rot_dim == D, D = 128 or 64): D/4 lanes per
+// (token, head) -- each lane rotates two adjacent pairs with 4-byte accesses and copies four value elements -- so a wave
+// covers 2 or 4 heads.  At 1024 prefill tokens the one-pair-per-lane kernel was bound by its 2-byte accesses (14 us
+// for 25 MB).  Same arithmetic, same roundings.
+template <int DTYPE, typename LocT, bool KV8, int D>
+__global__ __launch_bounds__(256) void rope_kv_neox_kernel(
+    typename Half16<DTYPE>::T* __restrict__ q, typename Half16<DTYPE>::T* __restrict__ k,
+    const typename Half16<DTYPE>::T* __restrict__ v, char* __restrict__ kb, char* __restrict__ vb,
+    const int64_t* __restrict__ positions, const LocT* __restrict__ loc, const float* __restrict__ cache, int64_t T,
+    int Hq, int Hk, int64_t q_st, int64_t k_st, int64_t v_st, int64_t kb_sn, int64_t kb_sh, int64_t vb_sn,
+    int64_t vb_sh) {
+  using Hh = Half16<DTYPE>;
+  using T16 = typename Hh::T;
+  typedef T16 t16x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  constexpr int LPH = D / 4, HPW = 64 / LPH, half = D / 2;
+  constexpr int ES = KV8 ? 1 : 2;
+  const int lane = threadIdx.x & 63, sub = lane / LPH, l = lane % LPH;
+  const int64_t item = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * HPW + sub;
+  if (item >= T * (int64_t)(Hq + Hk)) return;
+  const int h = (int)(item % (Hq + Hk));
+  const int64_t t = item / (Hq + Hk);
+  const bool is_k = h >= Hq;
+  T16* base = is_k ? k + t * k_st + (int64_t)(h - Hq) * D : q + t * q_st + (int64_t)h * D;
+  const float* cs = cache + positions[t] * D;
+  const f32x2 c = *reinterpret_cast<const f32x2*>(cs + 2 * l), sn = *reinterpret_cast<const f32x2*>(cs + half + 2 * l);
+  const t16x2 x1 = *reinterpret_cast<const t16x2*>(base + 2 * l), x2 = *reinterpret_cast<const t16x2*>(base + half + 2 * l);
+  t16x2 o1, o2;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    float r1, r2;
+    rope_pair(Hh::to_f32(x1[j]), Hh::to_f32(x2[j]), c[j], sn[j], r1, r2);
+    o1[j] = Hh::from_f32(r1);
+    o2[j] = Hh::from_f32(r2);
+  }
+  *reinterpret_cast<t16x2*>(base + 2 * l) = o1;
+  *reinterpret_cast<t16x2*>(base + half + 2 * l) = o2;
+  if (is_k && kb) {
+    char* kdst = kb + ((int64_t)loc[t] * kb_sn + (int64_t)(h - Hq) * kb_sh) * ES;
+    char* vdst = vb + ((int64_t)loc[t] * vb_sn + (int64_t)(h - Hq) * vb_sh) * ES;
+    const T16* vs = v + t * v_st + (int64_t)(h - Hq) * D;
+    const t16x2 v0 = *reinterpret_cast<const t16x2*>(vs + 4 * l), v1 = *reinterpret_cast<const t16x2*>(vs + 4 * l + 2);
+    if constexpr (KV8) {
+      auto sat = [](float x) { return fminf(fmaxf(x, -448.f), 448.f); };
+      const int p1 = __builtin_amdgcn_cvt_pk_fp8_f32(sat(Hh::to_f32(o1[0])), sat(Hh::to_f32(o1[1])), 0, false);
+      const int p2 = __builtin_amdgcn_cvt_pk_fp8_f32(sat(Hh::to_f32(o2[0])), sat(Hh::to_f32(o2[1])), 0, false);
+      *reinterpret_cast<uint16_t*>(kdst + 2 * l) = (uint16_t)(p1 & 0xFFFF);
+      *reinterpret_cast<uint16_t*>(kdst + half + 2 * l) = (uint16_t)(p2 & 0xFFFF);
+      int pv = __builtin_amdgcn_cvt_pk_fp8_f32(sat(Hh::to_f32(v0[0])), sat(Hh::to_f32(v0[1])), 0, false);
+      pv = __builtin_amdgcn_cvt_pk_fp8_f32(sat(Hh::to_f32(v1[0])), sat(Hh::to_f32(v1[1])), pv, true);
+      *reinterpret_cast<uint32_t*>(vdst + 4 * l) = (uint32_t)pv;
+    } else {
+      *reinterpret_cast<t16x2*>(kdst + 2 * (2 * l)) = o1;
+      *reinterpret_cast<t16x2*>(kdst + 2 * (half + 2 * l)) = o2;
+      *reinterpret_cast<t16x2*>(vdst + 2 * (4 * l)) = v0;
+      *reinterpret_cast<t16x2*>(vdst + 2 * (4 * l + 2)) = v1;
     }
   }
 }
@@ -659,6 +739,42 @@ static int rope_set_kv_impl(bool kv8,
   SGLM_CHECK_ARG(items < (1ll << 32), "rotary_embedding_set_kv: too many rows");
   const unsigned grid = (unsigned)((items + 3) / 4);
   hipStream_t s = as_stream(stream);
+  // vectorised kernel: neox, full rotation, D = 128 / 64, 4-byte aligned rows (pool rows 4-byte aligned in bytes)
+  const int pes = kv8 ? 1 : 2;
+  const bool fast = is_neox && rot_dim == head_size && (head_size == 128 || head_size == 64) && q_stride_t % 2 == 0 &&
+                    k_stride_t % 2 == 0 && v_stride_t % 2 == 0 && (kb_stride_n * pes) % 4 == 0 && (kb_stride_h * pes) % 4 == 0 &&
+                    (vb_stride_n * pes) % 4 == 0 && (vb_stride_h * pes) % 4 == 0 &&
+                    reinterpret_cast<uintptr_t>(query) % 4 == 0 && reinterpret_cast<uintptr_t>(key) % 4 == 0 &&
+                    reinterpret_cast<uintptr_t>(value) % 4 == 0 && reinterpret_cast<uintptr_t>(k_buffer) % 4 == 0 &&
+                    reinterpret_cast<uintptr_t>(v_buffer) % 4 == 0 && reinterpret_cast<uintptr_t>(cos_sin_cache) % 8 == 0;
+  if (fast) {
+    const int hpw = head_size == 128 ? 2 : 4;
+    const unsigned gridf = (unsigned)((items + 4 * hpw - 1) / (4 * hpw));
+#define ROPEF(DT, TT, LT, K8, DD)                                                                                       \
+  hipLaunchKernelGGL((rope_kv_neox_kernel<DT, LT, K8, DD>), dim3(gridf), dim3(256), 0, s, (TT*)query, (TT*)key,          \
+                     (const TT*)value, (char*)k_buffer, (char*)v_buffer, positions, (const LT*)loc, cos_sin_cache,       \
+                     num_tokens, (int)num_q_heads, (int)num_k_heads, q_stride_t, k_stride_t, v_stride_t, kb_stride_n,    \
+                     kb_stride_h, vb_stride_n, vb_stride_h)
+#define ROPEF_D(DT, TT, LT, K8)                          \
+  do {                                                   \
+    if (head_size == 128) ROPEF(DT, TT, LT, K8, 128);    \
+    else ROPEF(DT, TT, LT, K8, 64);                      \
+  } while (0)
+#define ROPEF_K(DT, TT, LT)                  \
+  do {                                       \
+    if (kv8) ROPEF_D(DT, TT, LT, true);      \
+    else ROPEF_D(DT, TT, LT, false);         \
+  } while (0)
+    if (dtype == SGL_MI355_BF16) {
+      if (loc_is64) ROPEF_K(SGL_MI355_BF16, __bf16, int64_t); else ROPEF_K(SGL_MI355_BF16, __bf16, int32_t);
+    } else {
+      if (loc_is64) ROPEF_K(SGL_MI355_FP16, _Float16, int64_t); else ROPEF_K(SGL_MI355_FP16, _Float16, int32_t);
+    }
+#undef ROPEF_K
+#undef ROPEF_D
+#undef ROPEF
+    return check_hip(hipGetLastError(), "rotary_embedding_set_kv launch");
+  }
 #define ROPEKV_(DT, TT, LT, K8)                                                                                        \
   hipLaunchKernelGGL((rope_kv_kernel<DT, LT, K8>), dim3(grid), dim3(256), 0, s, (TT*)query, (TT*)key, (const TT*)value, \
                      (char*)k_buffer, (char*)v_buffer, positions, (const LT*)loc, cos_sin_cache, num_tokens,           \

@@ -1091,8 +1091,9 @@ __global__ __launch_bounds__(256) void fp8_gemm_finalize_kernel(GemmArgs p, cons
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       // explicit roundings (no fma contraction): the fused *_from_partials consumers repeat exactly this
-      float r = __fmul_rn(__fmul_rn(v[j], p.sb[n + j]), sa);
-      if (p.bias) r = __fadd_rn(r, H::to_f32(reinterpret_cast<const T*>(p.bias)[n + j]));
+#pragma clang fp contract(off)
+      float r = (v[j] * p.sb[n + j]) * sa;
+      if (p.bias) r = r + H::to_f32(reinterpret_cast<const T*>(p.bias)[n + j]);
       o[j] = H::from_f32(r);
     }
     *reinterpret_cast<typename H::x8*>(reinterpret_cast<T*>(p.out) + e) = o;
