@@ -127,17 +127,19 @@ __device__ __forceinline__ typename Half16<DTYPE>::T gemm_elem(const PartialSrc&
   return Hh::from_f32(r);
 }
 
-// (residual-add +) RMSNorm (+ FP8 quant).  H % 8 == 0, H <= 256 * 8 * VPT.
+// (residual-add +) RMSNorm (+ FP8 quant).  H % 8 == 0, H <= NT * 8 * VPT.  NT threads per row: the launchers take 512 or
+// 1024 for few, long rows (decode: 64 x 4096 is a chain of memory round trips, not bandwidth) -- the SAME rule for the
+// plain and the from-partials form, so that both reduce the sum of squares in the same order (bit-identical results).
 //   x: [T,H] input; residual: nullable, in/out (residual = x + residual, rounded to dtype);
 //   out: nullable 16-bit output; out_q/out_s: nullable FP8 output + per-row scale.
-template <int DTYPE, int VPT, bool FROM_PARTIALS = false>
-__global__ __launch_bounds__(256) void rmsnorm_kernel(
+template <int DTYPE, int VPT, bool FROM_PARTIALS = false, int NT = 256>
+__global__ __launch_bounds__(NT) void rmsnorm_kernel(
     const typename Half16<DTYPE>::T* x /* may alias out */, typename Half16<DTYPE>::T* residual,
     const typename Half16<DTYPE>::T* __restrict__ weight, typename Half16<DTYPE>::T* out,
     uint8_t* __restrict__ out_q, float* __restrict__ out_s, int H, float eps, PartialSrc ps = PartialSrc{}) {
   using Hh = Half16<DTYPE>;
   using x8 = typename Hh::x8;
-  __shared__ float red[4];
+  __shared__ float red[NT / 64];
   const int64_t row = blockIdx.x;
   const int nv = H >> 3;
   float v[VPT][8];
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(
   float ss = 0.f;
 #pragma unroll
   for (int i = 0; i < VPT; ++i) {
-    const int vi = threadIdx.x + 256 * i;
+    const int vi = threadIdx.x + NT * i;
     if (vi < nv) {
       x8 xv;
       if constexpr (FROM_PARTIALS) xv = gemm_row8<DTYPE>(ps, row, 8 * vi);
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(
   float amax = 0.f;
 #pragma unroll
   for (int i = 0; i < VPT; ++i) {
-    const int vi = threadIdx.x + 256 * i;
+    const int vi = threadIdx.x + NT * i;
     if (vi < nv) {
       const x8 wv = wq[i];
       x8 o;
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(
     const float sinv = scale == 0.f ? 0.f : 1.0f / scale;
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
-      const int vi = threadIdx.x + 256 * i;
+      const int vi = threadIdx.x + NT * i;
       if (vi < nv) {
         float f[8];
 #pragma unroll
@@ -549,6 +551,9 @@ __global__ __launch_bounds__(256) void rope_kv_neox_kernel(
   }
 }
 
+// few long rows (decode batches, H >= 4096, at most 2048 vectors of 8): 512 / 1024 threads per row
+inline bool rms_wide(int64_t T, int nv) { return T <= 512 && nv >= 512 && nv <= 2048; }
+
 template <int DTYPE>
 int launch_rmsnorm(const void* x, void* residual, const void* weight, void* out, void* out_q, float* out_s, int64_t T,
                    int64_t H, float eps, hipStream_t s) {
@@ -558,10 +563,18 @@ int launch_rmsnorm(const void* x, void* residual, const void* weight, void* out,
 #define RMS_LAUNCH(V)                                                                                        \
   hipLaunchKernelGGL((rmsnorm_kernel<DTYPE, V>), dim3((unsigned)T), dim3(256), 0, s, (const T16*)x, (T16*)residual, \
                      (const T16*)weight, (T16*)out, (uint8_t*)out_q, out_s, (int)H, eps)
-  if (vpt <= 1) RMS_LAUNCH(1);
+#define RMS_LAUNCH_W(V, NT_)                                                                                  \
+  hipLaunchKernelGGL((rmsnorm_kernel<DTYPE, V, false, NT_>), dim3((unsigned)T), dim3(NT_), 0, s, (const T16*)x, \
+                     (T16*)residual, (const T16*)weight, (T16*)out, (uint8_t*)out_q, out_s, (int)H, eps)
+  if (rms_wide(T, nv)) {  // few long rows (same rule as launch_rmsnorm_partials)
+    if (nv <= 512) RMS_LAUNCH_W(1, 512);
+    else if (nv <= 1024) RMS_LAUNCH_W(1, 1024);
+    else RMS_LAUNCH_W(2, 1024);
+  } else if (vpt <= 1) RMS_LAUNCH(1);
   else if (vpt <= 2) RMS_LAUNCH(2);
   else if (vpt <= 4) RMS_LAUNCH(4);
   else RMS_LAUNCH(8);
+#undef RMS_LAUNCH_W
 #undef RMS_LAUNCH
   return check_hip(hipGetLastError(), "rmsnorm launch");
 }
@@ -575,6 +588,15 @@ int launch_rmsnorm_partials(const PartialSrc& ps, void* residual, const void* we
 #define RMSP_LAUNCH(V)                                                                                              \
   hipLaunchKernelGGL((rmsnorm_kernel<DTYPE, V, true>), dim3((unsigned)T), dim3(256), 0, s, (const T16*)nullptr,       \
                      (T16*)residual, (const T16*)weight, (T16*)nullptr, (uint8_t*)out_q, out_s, (int)H, eps, ps)
+#define RMSP_LAUNCH_W(V, NT_)                                                                                        \
+  hipLaunchKernelGGL((rmsnorm_kernel<DTYPE, V, true, NT_>), dim3((unsigned)T), dim3(NT_), 0, s, (const T16*)nullptr,  \
+                     (T16*)residual, (const T16*)weight, (T16*)nullptr, (uint8_t*)out_q, out_s, (int)H, eps, ps)
+  if (rms_wide(T, nv)) {
+    if (nv <= 512) RMSP_LAUNCH_W(1, 512);
+    else if (nv <= 1024) RMSP_LAUNCH_W(1, 1024);
+    else RMSP_LAUNCH_W(2, 1024);
+    return check_hip(hipGetLastError(), "rmsnorm_from_partials launch");
+  }
   if (vpt <= 1) RMSP_LAUNCH(1);
   else if (vpt <= 2) RMSP_LAUNCH(2);
   else if (vpt <= 4) RMSP_LAUNCH(4);
