@@ -38,17 +38,17 @@ constexpr float kFp8Max = 448.0f;
 
 // ------------------------------------------------------------------------------------------
 // per-token quant: one workgroup (256 threads) per row; two passes (second read is L2-hot)
-template <int DTYPE>
-__global__ __launch_bounds__(256) void per_token_quant_fp8_kernel(
+template <int DTYPE, int NT = 256>
+__global__ __launch_bounds__(NT) void per_token_quant_fp8_kernel(
     const typename Half16<DTYPE>::T* __restrict__ x, uint8_t* __restrict__ q, float* __restrict__ s, int K) {
   using H = Half16<DTYPE>;
   using x8 = typename H::x8;
-  __shared__ float red[4];
+  __shared__ float red[NT / 64];
   const int t = blockIdx.x;
   const x8* xr = reinterpret_cast<const x8*>(x + (int64_t)t * K);
   const int nv = K >> 3;
   float amax = 0.f;
-  for (int i = threadIdx.x; i < nv; i += 256) {
+  for (int i = threadIdx.x; i < nv; i += NT) {
     const x8 v = xr[i];
 #pragma unroll
     for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(H::to_f32(v[j])));
@@ -57,12 +57,14 @@ __global__ __launch_bounds__(256) void per_token_quant_fp8_kernel(
   for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
   __syncthreads();
-  amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  amax = red[0];
+#pragma unroll
+  for (int w = 1; w < NT / 64; ++w) amax = fmaxf(amax, red[w]);
   const float scale = amax / kFp8Max;
   if (threadIdx.x == 0) s[t] = scale;
   const float inv = scale == 0.f ? 0.f : 1.0f / scale;
   uint2* qr = reinterpret_cast<uint2*>(q + (int64_t)t * K);
-  for (int i = threadIdx.x; i < nv; i += 256) {
+  for (int i = threadIdx.x; i < nv; i += NT) {
     const x8 v = xr[i];
     float f[8];
 #pragma unroll
@@ -1642,12 +1644,17 @@ extern "C" int sgl_mi355_per_token_quant_fp8(
   SGLM_CHECK_ARG(reinterpret_cast<uintptr_t>(input) % 16 == 0 && reinterpret_cast<uintptr_t>(output_q) % 8 == 0,
                  "per_token_quant_fp8: input must be 16-byte and output 8-byte aligned");
   hipStream_t s = as_stream(stream);
-  if (dtype == SGL_MI355_BF16)
-    hipLaunchKernelGGL((per_token_quant_fp8_kernel<SGL_MI355_BF16>), dim3((unsigned)num_tokens), dim3(256), 0, s,
-                       (const __bf16*)input, (uint8_t*)output_q, output_s, (int)hidden_dim);
-  else
-    hipLaunchKernelGGL((per_token_quant_fp8_kernel<SGL_MI355_FP16>), dim3((unsigned)num_tokens), dim3(256), 0, s,
-                       (const _Float16*)input, (uint8_t*)output_q, output_s, (int)hidden_dim);
+  // few long rows (decode): 512 threads per row -- the row is a chain of memory round trips, not bandwidth
+  const bool wide = num_tokens <= 512 && hidden_dim >= 4096;
+#define PTQ_GO(DT, TT, NT_)                                                                                         \
+  hipLaunchKernelGGL((per_token_quant_fp8_kernel<DT, NT_>), dim3((unsigned)num_tokens), dim3(NT_), 0, s, (const TT*)input, \
+                     (uint8_t*)output_q, output_s, (int)hidden_dim)
+  if (dtype == SGL_MI355_BF16) {
+    if (wide) PTQ_GO(SGL_MI355_BF16, __bf16, 512); else PTQ_GO(SGL_MI355_BF16, __bf16, 256);
+  } else {
+    if (wide) PTQ_GO(SGL_MI355_FP16, _Float16, 512); else PTQ_GO(SGL_MI355_FP16, _Float16, 256);
+  }
+#undef PTQ_GO
   return check_hip(hipGetLastError(), "per_token_quant_fp8 launch");
 }
 
