@@ -387,7 +387,7 @@ def main():
                    "global_batch": args.batch, "seq_len": args.ctx, "layers": len(net.layers),
                    "parallelism": f"tp{tp}" + (" (ONE rank emulated on one GPU, collectives stubbed: not a job number)"
                                                if args.emulate_tp > 1 and not dist_on else "")},
-        "roofline": {"bound": "hbm", "kernel": "decode_mfma_kernel (paged decode attention)",
+        "roofline": {"bound": "hbm", "kernel": "decode_mfma_pair_kernel / decode_mfma_kernel (paged decode attention)",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                      "traffic_source": traffic_src,

@@ -529,6 +529,326 @@ __global__ __launch_bounds__(kWaves * 64) void decode_mfma_kernel(DecodeArgs a) 
 }
 
 // --------------------------------------------------------------------------------------
+// Two (request, kv-head block) items per workgroup, back to back in ONE DMA stream.
+//
+// With more items than CUs the kernel above runs them in rounds, and on every CU the second workgroup's prologue (page
+// table + Q, then the first tiles: two dependent memory round trips, ~5 us under load) and the first one's merge cannot
+// overlap anything -- the LDS rings leave room for one workgroup.  Here a workgroup owns items 2i and 2i+1: both page
+// tables and both Q blocks are fetched in the one prologue, every wave walks its tiles of the first item and continues
+// straight into its tiles of the second (the two-stage ring keeps prefetching across the boundary), and both merges run
+// at the end.  16-bit pools, one split, 4 waves; items longer than the staged window fall back to one item at a time.
+template <int DTYPE, int D, typename IdxT>
+__global__ __launch_bounds__(256) void decode_mfma_pair_kernel(DecodeArgs a, int num_items) {
+  using H = Half16<DTYPE>;
+  using T = typename H::T;
+  using x8 = typename H::x8;
+  using x4 = typename H::x4;
+  constexpr int kWaves = 4;
+  constexpr int ROWB = D * 2;
+  constexpr int CH = ROWB / 16;
+  constexpr int ROWS_PER_DMA = 1024 / ROWB;
+  constexpr int NI = kTile / ROWS_PER_DMA;
+  constexpr int TILE_BYTES = kTile * ROWB;
+  constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+  constexpr int WAVE_BYTES = kStages * STAGE_BYTES;
+  constexpr int KS = D / 32;
+  constexpr int NDV = D / 16;
+  constexpr int CAP = 2 * kMaxIdx;  // page-table entries staged per item (the two halves of the 32 KB window)
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int32_t* idx_lds = reinterpret_cast<int32_t*>(smem + kWaves * WAVE_BYTES);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hl = lane & 15;
+  const int g = lane >> 4;
+  const int nhb = (a.group + 15) >> 4;
+  const int dma_row = lane / CH, dma_pos = lane % CH;
+  const int64_t k_row_bytes = a.k_sn * 2, v_row_bytes = a.v_sn * 2;
+  char* wave_lds = smem + wave * WAVE_BYTES;
+  const float scale_log2 = a.sm_scale * kLog2e;
+  const bool has_cap = a.logit_cap > 0.f;
+
+  // ---- the two items
+  struct Item {
+    int b, h0, nh, len;
+    int64_t base;
+    const char *kbase, *vbase;
+  } it[2];
+  x8 qfs[2][KS];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int item = 2 * (int)blockIdx.x + i;
+    const bool ok = item < num_items;
+    const int id = ok ? item : num_items - 1;
+    const int hblk = id % (a.num_kv_heads * nhb);
+    const int b = id / (a.num_kv_heads * nhb);
+    const int kvh = hblk / nhb, hb = hblk - kvh * nhb;
+    it[i].b = b;
+    it[i].h0 = kvh * a.group + hb * 16;
+    it[i].nh = (a.group - hb * 16) < 16 ? (a.group - hb * 16) : 16;
+    int s0, s1;
+    split_range(a, b, 0, it[i].base, s0, s1);
+    it[i].len = ok ? s1 : -1;  // -1: no such item
+    it[i].kbase = reinterpret_cast<const char*>(a.k) + (int64_t)kvh * a.k_sh * 2;
+    it[i].vbase = reinterpret_cast<const char*>(a.v) + (int64_t)kvh * a.v_sh * 2;
+    const T* qp = reinterpret_cast<const T*>(a.q) + (int64_t)b * a.q_sb + (int64_t)(it[i].h0 + hl) * a.q_sh;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (hl < it[i].nh) {
+        qfs[i][ks] = *reinterpret_cast<const x8*>(qp + 32 * ks + 8 * g);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qfs[i][ks][j] = (T)0.f;
+      }
+    }
+  }
+  // page tables: the first window of both items goes in with the one prologue
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int n = it[i].len < CAP ? it[i].len : CAP;
+    const IdxT* src = reinterpret_cast<const IdxT*>(a.indices) + it[i].base;
+    for (int e = tid; e < n; e += 256) idx_lds[i * CAP + e] = (int32_t)src[e];
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qfs[i][ks]));  // waits for these loads stay out of the loop
+  __syncthreads();
+
+  // online-softmax state of the item being streamed, and the finished first item
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x4 o_acc[NDV];
+#pragma unroll
+  for (int i = 0; i < NDV; ++i) o_acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_first = -INFINITY, l_first = 0.f;
+  f32x4 o_first[NDV];
+#pragma unroll
+  for (int i = 0; i < NDV; ++i) o_first[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  x8 qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) qf[ks] = qfs[0][ks];
+
+  bool parked = false;  // the first item's result sits in *_first, the Q fragments are the second item's
+  auto park_first = [&]() __attribute__((always_inline)) {
+    m_first = m_run;
+    l_first = l_run;
+    m_run = -INFINITY;
+    l_run = 0.f;
+#pragma unroll
+    for (int k = 0; k < NDV; ++k) {
+      o_first[k] = o_acc[k];
+      o_acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = qfs[1][ks];
+    parked = true;
+  };
+
+  // One stream over up to two segments: (sel0: idx window off0, n0 tokens, nt0 tiles of this wave) then (sel1: ...).
+  // At the boundary the running state moves to *_first and the Q fragments switch.
+  auto stream = [&](int sel0, int off0, int n0, int sel1, int off1, int n1) __attribute__((always_inline)) {
+    const int nt0 = n0 > 0 ? (ceil_div(n0, kTile) - wave + kWaves - 1) / kWaves : 0;
+    const int nt1 = n1 > 0 ? (ceil_div(n1, kTile) - wave + kWaves - 1) / kWaves : 0;
+    const int nvt = nt0 + nt1;
+    auto issue = [&](int vt, int stage, bool is_v) __attribute__((always_inline)) {
+      const bool second = vt >= nt0;
+      const int jt = second ? vt - nt0 : vt;
+      const int sel = second ? sel1 : sel0;
+      const int off = second ? off1 : off0;
+      const int n = second ? n1 : n0;
+      const int tok0 = (wave + kWaves * jt) * kTile;
+      const char* gb = sel ? (is_v ? it[1].vbase : it[1].kbase) : (is_v ? it[0].vbase : it[0].kbase);
+      const int64_t rb = is_v ? v_row_bytes : k_row_bytes;
+      const uint32_t dst = __builtin_amdgcn_readfirstlane(
+          lds_addr_of(wave_lds + stage * STAGE_BYTES + (is_v ? TILE_BYTES : 0)));
+      int32_t tok[NI];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        int tp = tok0 + i * ROWS_PER_DMA + dma_row;
+        tp = tp < n ? tp : n - 1;
+        tok[i] = idx_lds[off + tp];
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int c = swz_chunk<D>(dma_pos, i * ROWS_PER_DMA + dma_row);
+        lds_dma16(gb + (int64_t)tok[i] * rb + c * 16, dst + i * 1024);
+      }
+    };
+    if (nvt > 0) {
+      issue(0, 0, false);
+      issue(0, 0, true);
+    }
+    if (nvt > 1) {
+      issue(1, 1, false);
+      issue(1, 1, true);
+    }
+    for (int vt = 0; vt < nvt; ++vt) {
+      if (vt == nt0 && nt1 > 0 && sel1 != sel0) park_first();  // the second item starts
+      const bool second = vt >= nt0;
+      const int jt = second ? vt - nt0 : vt;
+      const int n_pass = second ? n1 : n0;
+      const int st = vt & 1;
+      const char* kst = wave_lds + st * STAGE_BYTES;
+      const char* vst = kst + TILE_BYTES;
+      const int tok0 = (wave + kWaves * jt) * kTile;
+      const bool more1 = vt + 1 < nvt;
+      const bool more2 = vt + 2 < nvt;
+
+      if (more1) wait_vmcnt<3 * NI>(); else wait_vmcnt<NI>();
+      f32x4 s_acc[2];
+#pragma unroll
+      for (int th = 0; th < 2; ++th) {
+        s_acc[th] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int row = 16 * th + hl;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const int c = swz_chunk<D>(4 * ks + g, row);
+          const x8 kf = *reinterpret_cast<const x8*>(kst + row * ROWB + c * 16);
+          s_acc[th] = H::mfma16(kf, qf[ks], s_acc[th]);
+        }
+      }
+      wait_lgkmcnt0();
+      if (more2) issue(vt + 2, st, false);
+
+      float sv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sv[i] = s_acc[i >> 2][i & 3] * (has_cap ? a.sm_scale : scale_log2);
+      if (has_cap) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sv[i] = a.logit_cap * tanhf(sv[i] / a.logit_cap) * kLog2e;
+      }
+      float m_tile = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const bool valid = (tok0 + 16 * (i >> 2) + 4 * g + (i & 3)) < n_pass;
+        sv[i] = valid ? sv[i] : -INFINITY;
+        m_tile = fmaxf(m_tile, sv[i]);
+      }
+      m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 16));
+      m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32));
+      const float m_new = fmaxf(m_run, m_tile);
+      const float alpha = exp2f(m_run - m_new);
+      float psum = 0.f;
+      x8 pf;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float p = exp2f(sv[i] - m_new);
+        psum += p;
+        pf[i] = H::from_f32(p);
+      }
+      l_run = l_run * alpha + psum;
+      m_run = m_new;
+#pragma unroll
+      for (int i = 0; i < NDV; ++i) o_acc[i] *= alpha;
+
+      if (more2) wait_vmcnt<3 * NI>(); else if (more1) wait_vmcnt<2 * NI>(); else wait_vmcnt<0>();
+      {
+        const int q4 = (lane >> 2) & 3;
+        const int p4 = lane & 3;
+        const int row_lo = 4 * g + q4;
+#pragma unroll
+        for (int dvb = 0; dvb < NDV; ++dvb) {
+          const int c = 2 * dvb + (p4 >> 1);
+          const int off = swz_chunk<D>(c, row_lo) * 16 + 8 * (p4 & 1);
+          const x4 v_lo = H::ds_read_tr(vst + row_lo * ROWB + off);
+          const x4 v_hi = H::ds_read_tr(vst + (row_lo + 16) * ROWB + off);
+          x8 vf;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            vf[j] = v_lo[j];
+            vf[4 + j] = v_hi[j];
+          }
+          o_acc[dvb] = H::mfma16(vf, pf, o_acc[dvb]);
+        }
+      }
+      wait_lgkmcnt0();
+      if (more2) issue(vt + 2, st, true);
+    }
+  };
+
+  // One call site for `stream` (a second inlined copy of the loop would double the kernel): either the fused pair,
+  // or, for contexts longer than the staged window, one item at a time in windows of the whole LDS window.
+  const int len0 = it[0].len, len1 = it[1].len;  // len1 may be -1 (no second item)
+  const bool fused = len0 <= CAP && len1 <= CAP;
+  int cur = 0, p0 = 0;  // long path: item and window start
+  for (;;) {
+    int sel0, off0, n0, sel1, off1, n1;
+    if (fused) {
+      sel0 = 0, off0 = 0, n0 = len0 > 0 ? len0 : 0, sel1 = 1, off1 = CAP, n1 = len1 > 0 ? len1 : 0;
+    } else {
+      while (cur < 2 && p0 >= (cur ? len1 : len0)) {  // next item (lengths are workgroup-uniform)
+        ++cur;
+        p0 = 0;
+      }
+      if (cur >= 2) break;
+      if (cur == 1 && !parked) park_first();
+      const int len_c = cur ? len1 : len0;
+      const int n = (len_c - p0) < 2 * CAP ? (len_c - p0) : 2 * CAP;
+      __syncthreads();  // the previous window is no longer read
+      const IdxT* src = reinterpret_cast<const IdxT*>(a.indices) + (cur ? it[1].base : it[0].base) + p0;
+      for (int e = tid; e < n; e += 256) idx_lds[e] = (int32_t)src[e];
+      __syncthreads();
+      sel0 = sel1 = cur, off0 = off1 = 0, n0 = n, n1 = 0;
+      p0 += n;
+    }
+    stream(sel0, off0, n0, sel1, off1, n1);
+    if (fused) break;
+  }
+  if (!parked) park_first();  // this wave never crossed into a second item: what it streamed belongs to the first
+
+  // ---- merges: first item from *_first, second from the running state
+  l_run += __shfl_xor(l_run, 16);
+  l_run += __shfl_xor(l_run, 32);
+  l_first += __shfl_xor(l_first, 16);
+  l_first += __shfl_xor(l_first, 32);
+  float* mrg_o = reinterpret_cast<float*>(smem);
+  float* mrg_m = mrg_o + kWaves * 16 * D;
+  float* mrg_l = mrg_m + kWaves * 16;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int len = it[i].len;
+    if (len < 0) break;  // no such item (workgroup-uniform)
+    const int nh = it[i].nh;
+    if (len == 0) {  // empty sequence: zero rows
+      if (tid < nh) {
+        T* o = reinterpret_cast<T*>(a.out) + (int64_t)it[i].b * a.o_sb + (int64_t)(it[i].h0 + tid) * a.o_sh;
+        for (int d = 0; d < D; ++d) o[d] = H::from_f32(0.f);
+      }
+      continue;
+    }
+    __syncthreads();  // rings (first merge) or the previous merge's scratch are dead
+    if (hl < nh) {
+      float* dst = mrg_o + (wave * 16 + hl) * D;
+#pragma unroll
+      for (int dvb = 0; dvb < NDV; ++dvb)
+        *reinterpret_cast<f32x4*>(dst + dvb * 16 + 4 * g) = i == 0 ? o_first[dvb] : o_acc[dvb];
+      if (g == 0) {
+        mrg_m[wave * 16 + hl] = i == 0 ? m_first : m_run;
+        mrg_l[wave * 16 + hl] = i == 0 ? l_first : l_run;
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < nh * D; e += kWaves * 64) {
+      const int h = e / D;
+      const int dv = e - h * D;
+      float M = -INFINITY;
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w) M = fmaxf(M, mrg_m[w * 16 + h]);
+      float L = 0.f, val = 0.f;
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w) {
+        const float f = exp2f(mrg_m[w * 16 + h] - M);
+        L += mrg_l[w * 16 + h] * f;
+        val += mrg_o[(w * 16 + h) * D + dv] * f;
+      }
+      reinterpret_cast<T*>(a.out)[(int64_t)it[i].b * a.o_sb + (int64_t)(it[i].h0 + h) * a.o_sh + dv] = H::from_f32(val / L);
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------
 // Generic fallback: one wave per (request, head, split); any head sizes up to 1024.
 // Lane l owns elements l, l+64, ...  Correctness path for the odd shapes the reference
 // tests (D = 13, 33/55, 80, 512, 576/512 ...), not a performance path.
@@ -757,6 +1077,23 @@ template <int DTYPE, int D, typename IdxT, bool DIRECT>
 int launch_mfma(const DecodeArgs& a, int64_t batch, hipStream_t stream) {
   const int nhb = (a.group + 15) / 16;
   const int64_t grid = batch * a.num_kv_heads * nhb * a.num_splits;
+  if constexpr (DIRECT) {
+    // More items than CUs, one split, 16-bit pool: pairs of items per workgroup in one DMA stream (see
+    // decode_mfma_pair_kernel).  Measured, bs=64 x 8 kv heads, S = 256 / 1024 / 2048 / 8192: 20.2 / 53.4 / 99.0 / 352 us
+    // vs 25.6 / 57.5 / 103.0 / 375 one item per workgroup; 2048 items (MHA, 32 kv heads): 363 vs 375 us with the 2-wave
+    // workgroups.  SGL_MI355_DECODE_PAIR=0|1 overrides (tuning aid).
+    static const int pair_env = [] { const char* e = getenv("SGL_MI355_DECODE_PAIR"); return e ? atoi(e) : -1; }();
+    const bool pair = !a.kv8 && a.num_splits == 1 && a.num_kv_splits == nullptr &&
+                      (pair_env >= 0 ? pair_env != 0 : grid > 256);
+    if (pair) {
+      auto kern = decode_mfma_pair_kernel<DTYPE, D, IdxT>;
+      constexpr int lds = mfma_lds_bytes<D, 4, 0>();
+      static int attr_rc = set_max_lds(kern, lds);
+      if (attr_rc != 0) return attr_rc;
+      hipLaunchKernelGGL(kern, dim3((unsigned)((grid + 1) / 2)), dim3(256), lds, stream, a, (int)grid);
+      return check_hip(hipGetLastError(), "decode_mfma_pair_kernel launch");
+    }
+  }
   if (a.kv8) {
     // measured at bs=64 x 8 kv heads (512 workgroups), S = 512 / 2048 / 8192: two per CU 22 / 64 / 224 us, one per CU
     // with four stages 30 / 70 / 205 us.  SGL_MI355_DECODE_KV8_STAGES=2|4 overrides (tuning aid).

@@ -218,3 +218,42 @@ def test_merge_fused_with_fp8_quant_is_bit_identical(Hq, Hkv, D, splits, fp8_poo
     assert torch.equal(ss, s_ref) and torch.equal(qq.view(torch.uint8), q_ref.view(torch.uint8))
     qq2, ss2 = ops.decode_merge_quant_fp8(logits2, splits, torch.bfloat16)  # without the 16-bit copy
     assert torch.equal(ss2, s_ref) and torch.equal(qq2.view(torch.uint8), q_ref.view(torch.uint8))
+
+
+@pytest.mark.parametrize("Hq,Hkv,D,dtype", [(32, 8, 128, torch.bfloat16), (8, 8, 64, torch.float16), (40, 2, 128, torch.bfloat16)])
+def test_decode_pairs_of_items_per_workgroup(Hq, Hkv, D, dtype):
+    """More (request, kv-head block) items than CUs with one split: decode_mfma_pair_kernel streams two items per
+    workgroup.  Ragged lengths incl. empty, one token, exactly / just over the staged window (4096 entries: the fused
+    pair needs both items inside it, longer ones go one item at a time), an odd item count -- against the oracle."""
+    nhb = (Hq // Hkv + 15) // 16
+    B = 260 // (Hkv * nhb) + 1  # > 256 items, so the pair kernel is chosen
+    if (B * Hkv * nhb) % 2 == 0 and Hkv * nhb % 2 == 1:
+        B += 1
+    g = torch.Generator().manual_seed(Hq + D)
+    lens = [0, 1, 33, 4096, 4097, 5000, 700, 64]
+    seq = torch.tensor([lens[b % len(lens)] if b < 16 else int(torch.randint(1, 300, (1,), generator=g)) for b in range(B)])
+    S = int(seq.max())
+    n_tok = int(seq.sum()) + 8
+    kb = torch.randn(n_tok, Hkv, D, generator=g).to(dtype)
+    vb = torch.randn(n_tok, Hkv, D, generator=g).to(dtype)
+    q = torch.randn(B, Hq, D, generator=g).to(dtype)
+    perm = torch.randperm(n_tok - 1, generator=g) + 1
+    r2t = torch.zeros(B, S, dtype=torch.int32)
+    off = 0
+    for b in range(B):
+        L = int(seq[b])
+        r2t[b, :L] = perm[off:off + L].int()
+        off += L
+    rpi = torch.arange(B)
+    o_ref = torch.zeros(B, Hq, D, dtype=dtype)
+    oracle.decode_attention(q, kb.clone(), vb.clone(), o_ref, None, None, None, torch.zeros(B, Hq, 1, D + 1), r2t, rpi,
+                            seq, 1.0 / D ** 0.5, 0.0, p_round=True)
+    o = torch.full((B, Hq, D), float("nan"), dtype=dtype, device=DEV)
+    ops.decode_attention_paged(q.to(DEV), kb.to(DEV), vb.to(DEV), o, r2t.to(DEV), rpi.to(DEV), seq.to(DEV), None, 1,
+                               1.0 / D ** 0.5, 0.0)
+    torch.cuda.synchronize()
+    assert torch.isfinite(o.float()).all()
+    err = (o.float().cpu() - o_ref.float()).abs()
+    bound = tol_for(dtype, o_ref.float())
+    assert float(err.max()) <= bound, f"|hip - oracle| = {float(err.max()):.3e} > {bound:.3e} at request {int(err.amax((1, 2)).argmax())}"
+    assert float(o[seq == 0].float().abs().max()) == 0.0
