@@ -281,9 +281,31 @@ class AWQLinearMethod(LinearMethodBase):
         packed = getattr(layer, "awq_packed", None)
         if packed is not None and reshaped_x.shape[0] <= 64 and reshaped_x.dtype == torch.float16:
             out = ops.awq_gemm_packed(reshaped_x, packed[0], packed[1], packed[2], bias)
+        elif reshaped_x.shape[0] > 64 and reshaped_x.is_cuda and reshaped_x.dtype == scales.dtype and \
+                self._prefill_weight(layer) is not None:
+            # prefill: x @ awq_dequantize(...) exactly as awq.py:413-417, with the dequantised weight kept from the first
+            # call on (288 GB of HBM: K * N * 2 bytes per layer buys back the dequant pass of every prefill)
+            out = torch.matmul(reshaped_x, layer.awq_dequant_cache)
+            if bias is not None:
+                out.add_(bias)
         else:
             out = ops.awq_gemm(reshaped_x, qweight, scales, qzeros, bias)
         return out.reshape(out_shape)
+
+    @staticmethod
+    def _prefill_weight(layer):
+        """The dequantised [K, N] weight for prefill GEMMs, built on first use; None when disabled
+        (SGL_MI355_AWQ_PREFILL_CACHE=0) or when less than 32 GB of device memory would remain."""
+        cache = getattr(layer, "awq_dequant_cache", None)
+        if cache is not None or getattr(layer, "_awq_cache_refused", False):
+            return cache
+        K, N = layer.qweight.shape[0], layer.qweight.shape[1] * 8
+        free, _ = torch.cuda.mem_get_info(layer.qweight.device)
+        if os.environ.get("SGL_MI355_AWQ_PREFILL_CACHE") == "0" or free - K * N * 2 < (32 << 30):
+            layer._awq_cache_refused = True
+            return None
+        layer.awq_dequant_cache = ops.awq_dequantize(layer.qweight.data, layer.scales.data, layer.qzeros.data)
+        return layer.awq_dequant_cache
 
 
 QUANTIZATION_METHODS = {

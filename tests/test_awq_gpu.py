@@ -131,3 +131,28 @@ def test_awq_linear_method_repacks_and_matches_unpacked(monkeypatch):
         y = layer(x)
         outs.append(y[0] if isinstance(y, tuple) else y)
     torch.testing.assert_close(outs[0].float(), outs[1].float(), rtol=2.0 ** -9, atol=1e-2)
+
+
+def test_awq_prefill_weight_cache_is_the_reference_computation(monkeypatch):
+    """M > 64: x @ awq_dequantize(...) (awq.py:413-417).  The linear method keeps the dequantised weight after the first
+    prefill; with and without the cache the output is the same tensor bit for bit."""
+    from sglang_npu_amd.quantization import AWQConfig
+    from sglang_npu_amd.linear import ColumnParallelLinear
+    K, N, M = 1024, 512, 200
+    outs = []
+    for cache in ("1", "0"):
+        monkeypatch.setenv("SGL_MI355_AWQ_PREFILL_CACHE", cache)
+        layer = ColumnParallelLinear(K, [N], bias=False, params_dtype=torch.float16,
+                                     quant_config=AWQConfig(4, 128, True)).to(DEV)
+        qw, qz, sc = _awq_case(K, N, 128, torch.Generator().manual_seed(10))
+        layer.qweight.data.copy_(qw), layer.qzeros.data.copy_(qz), layer.scales.data.copy_(sc)
+        layer.quant_method.process_weights_after_loading(layer)
+        x = torch.randn(M, K, generator=torch.Generator().manual_seed(9)).half().to(DEV)
+        ys = [layer(x), layer(x)]  # second call: served from the cache (or dequantised again)
+        ys = [y[0] if isinstance(y, tuple) else y for y in ys]
+        assert torch.equal(ys[0], ys[1])
+        assert (getattr(layer, "awq_dequant_cache", None) is not None) == (cache == "1")
+        outs.append(ys[0])
+    assert torch.equal(outs[0], outs[1])
+    ref = x @ ops.awq_dequantize(qw.to(DEV), sc.to(DEV), qz.to(DEV))
+    assert torch.equal(outs[0], ref)
