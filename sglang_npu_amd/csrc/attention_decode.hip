@@ -537,7 +537,7 @@ __global__ __launch_bounds__(kWaves * 64) void decode_mfma_kernel(DecodeArgs a) 
 // tables and both Q blocks are fetched in the one prologue, every wave walks its tiles of the first item and continues
 // straight into its tiles of the second (the two-stage ring keeps prefetching across the boundary), and both merges run
 // at the end.  16-bit pools, one split, 4 waves; items longer than the staged window fall back to one item at a time.
-template <int DTYPE, int D, typename IdxT>
+template <int DTYPE, int D, typename IdxT, bool KV8 = false>
 __global__ __launch_bounds__(256) void decode_mfma_pair_kernel(DecodeArgs a, int num_items) {
   using H = Half16<DTYPE>;
   using T = typename H::T;
@@ -550,7 +550,10 @@ __global__ __launch_bounds__(256) void decode_mfma_pair_kernel(DecodeArgs a, int
   constexpr int NI = kTile / ROWS_PER_DMA;
   constexpr int TILE_BYTES = kTile * ROWB;
   constexpr int STAGE_BYTES = 2 * TILE_BYTES;
-  constexpr int WAVE_BYTES = kStages * STAGE_BYTES;
+  // KV8 (e4m3 pool): byte tiles, four stages per wave, K upcast in registers, P.V on the FP8 MFMA (see decode_mfma_kernel)
+  constexpr int KVB = KV8 ? 1 : 2;
+  constexpr int CH8 = D / 16, ROWS8 = 1024 / D, NI8 = kTile / ROWS8, TILE8 = kTile * D, kStages8 = 4;
+  constexpr int WAVE_BYTES = KV8 ? kStages8 * 2 * TILE8 : kStages * STAGE_BYTES;
   constexpr int KS = D / 32;
   constexpr int NDV = D / 16;
   constexpr int CAP = 2 * kMaxIdx;  // page-table entries staged per item (the two halves of the 32 KB window)
@@ -565,7 +568,7 @@ __global__ __launch_bounds__(256) void decode_mfma_pair_kernel(DecodeArgs a, int
   const int g = lane >> 4;
   const int nhb = (a.group + 15) >> 4;
   const int dma_row = lane / CH, dma_pos = lane % CH;
-  const int64_t k_row_bytes = a.k_sn * 2, v_row_bytes = a.v_sn * 2;
+  const int64_t k_row_bytes = a.k_sn * KVB, v_row_bytes = a.v_sn * KVB;
   char* wave_lds = smem + wave * WAVE_BYTES;
   const float scale_log2 = a.sm_scale * kLog2e;
   const bool has_cap = a.logit_cap > 0.f;
@@ -591,8 +594,8 @@ __global__ __launch_bounds__(256) void decode_mfma_pair_kernel(DecodeArgs a, int
     int s0, s1;
     split_range(a, b, 0, it[i].base, s0, s1);
     it[i].len = ok ? s1 : -1;  // -1: no such item
-    it[i].kbase = reinterpret_cast<const char*>(a.k) + (int64_t)kvh * a.k_sh * 2;
-    it[i].vbase = reinterpret_cast<const char*>(a.v) + (int64_t)kvh * a.v_sh * 2;
+    it[i].kbase = reinterpret_cast<const char*>(a.k) + (int64_t)kvh * a.k_sh * KVB;
+    it[i].vbase = reinterpret_cast<const char*>(a.v) + (int64_t)kvh * a.v_sh * KVB;
     const T* qp = reinterpret_cast<const T*>(a.q) + (int64_t)b * a.q_sb + (int64_t)(it[i].h0 + hl) * a.q_sh;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -652,6 +655,137 @@ __global__ __launch_bounds__(256) void decode_mfma_pair_kernel(DecodeArgs a, int
     const int nt0 = n0 > 0 ? (ceil_div(n0, kTile) - wave + kWaves - 1) / kWaves : 0;
     const int nt1 = n1 > 0 ? (ceil_div(n1, kTile) - wave + kWaves - 1) / kWaves : 0;
     const int nvt = nt0 + nt1;
+    if constexpr (KV8) {
+      typedef float f32x2_t __attribute__((ext_vector_type(2)));
+      auto issue8 = [&](int vt, int stage, bool is_v) __attribute__((always_inline)) {
+        const bool second = vt >= nt0;
+        const int jt = second ? vt - nt0 : vt;
+        const int sel = second ? sel1 : sel0;
+        const int off = second ? off1 : off0;
+        const int n = second ? n1 : n0;
+        const int tok0 = (wave + kWaves * jt) * kTile;
+        const char* gb = sel ? (is_v ? it[1].vbase : it[1].kbase) : (is_v ? it[0].vbase : it[0].kbase);
+        const int64_t rb = is_v ? v_row_bytes : k_row_bytes;
+        const uint32_t dst8 = __builtin_amdgcn_readfirstlane(
+            lds_addr_of(wave_lds + stage * 2 * TILE8 + (is_v ? TILE8 : 0)));
+        int32_t tok8[NI8];
+        int src_off[NI8];
+#pragma unroll
+        for (int i = 0; i < NI8; ++i) {
+          const int row = i * ROWS8 + lane / CH8;
+          const int slot = is_v ? ((row & 4) ? 16 + 4 * (row >> 3) + (row & 3) : 4 * (row >> 3) + (row & 3)) : row;
+          int tp = tok0 + slot;
+          tp = tp < n ? tp : n - 1;
+          tok8[i] = idx_lds[off + tp];
+          src_off[i] = ((lane % CH8) ^ swz8<D>(row)) * 16;
+        }
+#pragma unroll
+        for (int i = 0; i < NI8; ++i) lds_dma16(gb + (int64_t)tok8[i] * rb + src_off[i], dst8 + i * 1024);
+      };
+      auto wait_units = [&](int units) __attribute__((always_inline)) {
+        switch (units) {
+          case 0: wait_vmcnt<0>(); break;
+          case 1: wait_vmcnt<NI8>(); break;
+          case 2: wait_vmcnt<2 * NI8>(); break;
+          case 3: wait_vmcnt<3 * NI8>(); break;
+          case 4: wait_vmcnt<4 * NI8>(); break;
+          case 5: wait_vmcnt<5 * NI8>(); break;
+          case 6: wait_vmcnt<6 * NI8>(); break;
+          default: wait_vmcnt<7 * NI8>(); break;
+        }
+      };
+#pragma unroll
+      for (int pj = 0; pj < kStages8; ++pj)
+        if (pj < nvt) {
+          issue8(pj, pj, false);
+          issue8(pj, pj, true);
+        }
+      for (int vt = 0; vt < nvt; ++vt) {
+        if (vt == nt0 && nt1 > 0 && sel1 != sel0) park_first();  // the second item starts
+        const bool second = vt >= nt0;
+        const int jt = second ? vt - nt0 : vt;
+        const int n_pass = second ? n1 : n0;
+        const int st = vt & (kStages8 - 1);
+        const char* kst = wave_lds + st * 2 * TILE8;
+        const char* vst = kst + TILE8;
+        const int tok0 = (wave + kWaves * jt) * kTile;
+        const int after = (nvt - 1 - vt) < (kStages8 - 1) ? (nvt - 1 - vt) : (kStages8 - 1);
+        const bool refill = vt + kStages8 < nvt;
+        wait_units(1 + 2 * after);
+        f32x4 s_acc[2];
+#pragma unroll
+        for (int th = 0; th < 2; ++th) {
+          s_acc[th] = f32x4{0.f, 0.f, 0.f, 0.f};
+          const int row = 16 * th + hl;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const int c = (2 * ks + (g >> 1)) ^ swz8<D>(row);
+            const uint2 raw = *reinterpret_cast<const uint2*>(kst + row * D + c * 16 + 8 * (g & 1));
+            x8 kf;
+            const f32x2_t a0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)raw.x, false), a1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)raw.x, true);
+            const f32x2_t b0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)raw.y, false), b1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)raw.y, true);
+            kf[0] = H::from_f32(a0[0]); kf[1] = H::from_f32(a0[1]); kf[2] = H::from_f32(a1[0]); kf[3] = H::from_f32(a1[1]);
+            kf[4] = H::from_f32(b0[0]); kf[5] = H::from_f32(b0[1]); kf[6] = H::from_f32(b1[0]); kf[7] = H::from_f32(b1[1]);
+            s_acc[th] = H::mfma16(kf, qf[ks], s_acc[th]);
+          }
+        }
+        wait_lgkmcnt0();
+        if (refill) issue8(vt + kStages8, st, false);
+        float sv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sv[i] = s_acc[i >> 2][i & 3] * (has_cap ? a.sm_scale : scale_log2);
+        if (has_cap) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) sv[i] = a.logit_cap * tanhf(sv[i] / a.logit_cap) * kLog2e;
+        }
+        float m_tile = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const bool valid = (tok0 + 16 * (i >> 2) + 4 * g + (i & 3)) < n_pass;
+          sv[i] = valid ? sv[i] : -INFINITY;
+          m_tile = fmaxf(m_tile, sv[i]);
+        }
+        m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 16));
+        m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32));
+        const float m_new = fmaxf(m_run, m_tile);
+        const float alpha = exp2f(m_run - m_new);
+        float psum = 0.f;
+        float pv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          pv[i] = exp2f(sv[i] - m_new);
+          psum += pv[i];
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+        int p_lo = __builtin_amdgcn_cvt_pk_fp8_f32(pv[0], pv[1], 0, false);
+        p_lo = __builtin_amdgcn_cvt_pk_fp8_f32(pv[2], pv[3], p_lo, true);
+        int p_hi = __builtin_amdgcn_cvt_pk_fp8_f32(pv[4], pv[5], 0, false);
+        p_hi = __builtin_amdgcn_cvt_pk_fp8_f32(pv[6], pv[7], p_hi, true);
+        const long pf8 = (long)(((unsigned long)(unsigned)p_hi << 32) | (unsigned long)(unsigned)p_lo);
+        if (__ballot(alpha != 1.f) != 0) {
+#pragma unroll
+          for (int i = 0; i < NDV; ++i) o_acc[i] *= alpha;
+        }
+        wait_units(2 * after + (refill ? 1 : 0));
+        {
+          const int vrow = 8 * g + ((lane & 15) >> 1);
+          const char* vrp = vst + vrow * D + 8 * (lane & 1);
+          const int vsw = swz8<D>(vrow);
+#pragma unroll
+          for (int dvb = 0; dvb < NDV; ++dvb) {
+            typedef int v2i_t __attribute__((ext_vector_type(2)));
+            const v2i_t vr = __builtin_amdgcn_ds_read_tr8_b64_v2i32(
+                (__attribute__((address_space(3))) v2i_t*)(vrp + ((dvb ^ vsw) * 16)));
+            const long vf8 = (long)(((unsigned long)(unsigned)vr[1] << 32) | (unsigned long)(unsigned)vr[0]);
+            o_acc[dvb] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(vf8, pf8, o_acc[dvb], 0, 0, 0);
+          }
+        }
+        wait_lgkmcnt0();
+        if (refill) issue8(vt + kStages8, st, true);
+      }
+      return;
+    }
     auto issue = [&](int vt, int stage, bool is_v) __attribute__((always_inline)) {
       const bool second = vt >= nt0;
       const int jt = second ? vt - nt0 : vt;
@@ -1083,15 +1217,27 @@ int launch_mfma(const DecodeArgs& a, int64_t batch, hipStream_t stream) {
     // vs 25.6 / 57.5 / 103.0 / 375 one item per workgroup; 2048 items (MHA, 32 kv heads): 363 vs 375 us with the 2-wave
     // workgroups.  SGL_MI355_DECODE_PAIR=0|1 overrides (tuning aid).
     static const int pair_env = [] { const char* e = getenv("SGL_MI355_DECODE_PAIR"); return e ? atoi(e) : -1; }();
-    const bool pair = !a.kv8 && a.num_splits == 1 && a.num_kv_splits == nullptr &&
+    const bool pair = a.num_splits == 1 && a.num_kv_splits == nullptr &&
                       (pair_env >= 0 ? pair_env != 0 : grid > 256);
-    if (pair) {
+    if (pair && !a.kv8) {
       auto kern = decode_mfma_pair_kernel<DTYPE, D, IdxT>;
       constexpr int lds = mfma_lds_bytes<D, 4, 0>();
       static int attr_rc = set_max_lds(kern, lds);
       if (attr_rc != 0) return attr_rc;
       hipLaunchKernelGGL(kern, dim3((unsigned)((grid + 1) / 2)), dim3(256), lds, stream, a, (int)grid);
       return check_hip(hipGetLastError(), "decode_mfma_pair_kernel launch");
+    }
+    static const int pair8_env = [] { const char* e = getenv("SGL_MI355_DECODE_PAIR_KV8"); return e ? atoi(e) : 0; }();
+    // e4m3 pool: opt-in (SGL_MI355_DECODE_PAIR_KV8=1).  Measured against the two-workgroups-per-CU layout at bs=64 x 8 kv
+    // heads, S = 512 / 1024 / 2048 / 4096: 28.0 / 38.2 / 63.2 / 112.4 us vs 22.5 / 35.7 / 65.1 / 122.6 -- better only
+    // from ~2k tokens, and the launcher cannot see the lengths.
+    if (pair && a.kv8 && pair8_env) {
+      auto kern = decode_mfma_pair_kernel<DTYPE, D, IdxT, true>;
+      constexpr int lds = mfma_lds_bytes<D, 4, 1>();
+      static int attr_rc = set_max_lds(kern, lds);
+      if (attr_rc != 0) return attr_rc;
+      hipLaunchKernelGGL(kern, dim3((unsigned)((grid + 1) / 2)), dim3(256), lds, stream, a, (int)grid);
+      return check_hip(hipGetLastError(), "decode_mfma_pair_kernel (e4m3 pool) launch");
     }
   }
   if (a.kv8) {
