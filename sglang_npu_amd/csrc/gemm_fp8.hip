@@ -1000,6 +1000,23 @@ int launch_wstream(const GemmArgs& p, float* slabs, int64_t slab_floats, hipStre
     }
     if (slabs == nullptr) break;  // the longest phase that divides K
   }
+  // ... except at M > 32 without slabs (gate_up): phases of FOUR steps (2 x 32 KB of LDS instead of 2 x 64 KB) measured
+  // 31.7 us vs 33.2 at 4096 -> 28672 -- shorter phases, less skew to wait out at each barrier
+  if (MB == 4 && slabs == nullptr && PH == 8 && steps % 4 == 0) {
+    PH = 4;
+    pps = steps / 4;
+  }
+  {  // tuning aid: SGL_MI355_WSTREAM_FORCE="PH,nc" for the unsplit (no-slab) form
+    static const char* force = getenv("SGL_MI355_WSTREAM_FORCE");
+    int fph = 0, fnc = 0;
+    if (force && slabs == nullptr && sscanf(force, "%d,%d", &fph, &fnc) == 2 && (fph == 4 || fph == 8 || fph == 16 || fph == 32) &&
+        fph * MB <= 32 && steps % fph == 0 && fnc >= 1 && fnc <= 8) {
+      PH = fph;
+      nc = fnc;
+      SK = 1;
+      pps = steps / fph;
+    }
+  }
   if (PH == 0) return 0;
   const int groups = (nblocks + nc - 1) / nc;
   if (slabs != nullptr && ((SK < 2 && partial_slices == nullptr) || slab_floats < (int64_t)SK * p.M * p.N)) return 0;
