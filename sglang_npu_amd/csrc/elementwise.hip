@@ -552,7 +552,7 @@ __global__ __launch_bounds__(256) void rope_kv_neox_kernel(
 }
 
 // few long rows (decode batches, H >= 4096, at most 2048 vectors of 8): 512 / 1024 threads per row
-inline bool rms_wide(int64_t T, int nv) { return T <= 512 && nv >= 512 && nv <= 2048; }
+inline bool rms_wide(int64_t T, int nv) { return T <= 2048 && nv >= 512 && nv <= 2048; }
 
 template <int DTYPE>
 int launch_rmsnorm(const void* x, void* residual, const void* weight, void* out, void* out_q, float* out_s, int64_t T,

@@ -1662,7 +1662,7 @@ extern "C" int sgl_mi355_per_token_quant_fp8(
                  "per_token_quant_fp8: input must be 16-byte and output 8-byte aligned");
   hipStream_t s = as_stream(stream);
   // few long rows (decode): 512 threads per row -- the row is a chain of memory round trips, not bandwidth
-  const bool wide = num_tokens <= 512 && hidden_dim >= 4096;
+  const bool wide = num_tokens <= 2048 && hidden_dim >= 4096;
 #define PTQ_GO(DT, TT, NT_)                                                                                         \
   hipLaunchKernelGGL((per_token_quant_fp8_kernel<DT, NT_>), dim3((unsigned)num_tokens), dim3(NT_), 0, s, (const TT*)input, \
                      (uint8_t*)output_q, output_s, (int)hidden_dim)
