@@ -937,9 +937,29 @@ __global__ __launch_bounds__(256) void decode_mfma_pair_kernel(DecodeArgs a, int
   l_run += __shfl_xor(l_run, 32);
   l_first += __shfl_xor(l_first, 16);
   l_first += __shfl_xor(l_first, 32);
-  float* mrg_o = reinterpret_cast<float*>(smem);
-  float* mrg_m = mrg_o + kWaves * 16 * D;
-  float* mrg_l = mrg_m + kWaves * 16;
+  // both items' partials go to LDS behind ONE barrier (the dead rings hold 2 x [wave][16][D] floats + m, l), then every
+  // thread finishes output elements of both
+  constexpr int MRG = kWaves * 16 * D + 2 * kWaves * 16;  // floats per item
+  float* mrg = reinterpret_cast<float*>(smem);
+  __syncthreads();  // every wave is done with its ring
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (it[i].len <= 0) continue;
+    float* mrg_o = mrg + i * MRG;
+    float* mrg_m = mrg_o + kWaves * 16 * D;
+    float* mrg_l = mrg_m + kWaves * 16;
+    if (hl < it[i].nh) {
+      float* dst = mrg_o + (wave * 16 + hl) * D;
+#pragma unroll
+      for (int dvb = 0; dvb < NDV; ++dvb)
+        *reinterpret_cast<f32x4*>(dst + dvb * 16 + 4 * g) = i == 0 ? o_first[dvb] : o_acc[dvb];
+      if (g == 0) {
+        mrg_m[wave * 16 + hl] = i == 0 ? m_first : m_run;
+        mrg_l[wave * 16 + hl] = i == 0 ? l_first : l_run;
+      }
+    }
+  }
+  __syncthreads();
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int len = it[i].len;
@@ -952,18 +972,9 @@ __global__ __launch_bounds__(256) void decode_mfma_pair_kernel(DecodeArgs a, int
       }
       continue;
     }
-    __syncthreads();  // rings (first merge) or the previous merge's scratch are dead
-    if (hl < nh) {
-      float* dst = mrg_o + (wave * 16 + hl) * D;
-#pragma unroll
-      for (int dvb = 0; dvb < NDV; ++dvb)
-        *reinterpret_cast<f32x4*>(dst + dvb * 16 + 4 * g) = i == 0 ? o_first[dvb] : o_acc[dvb];
-      if (g == 0) {
-        mrg_m[wave * 16 + hl] = i == 0 ? m_first : m_run;
-        mrg_l[wave * 16 + hl] = i == 0 ? l_first : l_run;
-      }
-    }
-    __syncthreads();
+    const float* mrg_o = mrg + i * MRG;
+    const float* mrg_m = mrg_o + kWaves * 16 * D;
+    const float* mrg_l = mrg_m + kWaves * 16;
     for (int e = tid; e < nh * D; e += kWaves * 64) {
       const int h = e / D;
       const int dv = e - h * D;
