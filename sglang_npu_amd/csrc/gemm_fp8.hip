@@ -783,7 +783,11 @@ __global__ __launch_bounds__(576) void fp8_gemm_wstream_kernel(GemmArgs p, float
   constexpr int ROWS = 16 * MB;
   constexpr int STEP_BYTES = ROWS * 128;
   constexpr int BUF_BYTES = PH * STEP_BYTES;  // <= 64 KiB
-  constexpr int PB = PH < 8 ? PH : 8;         // weight steps in flight per wave (16 KiB)
+  // Weight k-steps in flight per wave.  TWO, not more: same-box A/B of 8 / 4 / 2 / 1 (M = 64: gate_up 33.1 / 32.4 / 30.8 /
+  // 37.8 us, down 24.6 / 23.4 / 22.6 / 26.5, qkv 16.6 / 15.7 / 15.0 / 16.6; M = 16: gate_up 26.3 / 25.5 / 25.0 / 30.4, down
+  // 21.9 / 20.9 / 19.5 / 22.5) -- with 7-8 consumer waves per CU a deeper per-wave queue only lets the waves drift apart
+  // (more to wait out at every phase barrier) and oversubscribes the CU's ~10 B/clk HBM path.
+  constexpr int PB = 2;
   constexpr int UPS = 2 * MB;                 // 1-KiB DMA units per k-step
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -999,12 +1003,6 @@ int launch_wstream(const GemmArgs& p, float* slabs, int64_t slab_floats, hipStre
       if (cost < best) { best = cost; PH = ph; nc = c; SK = sk; pps = pp; }
     }
     if (slabs == nullptr) break;  // the longest phase that divides K
-  }
-  // ... except at M > 32 without slabs (gate_up): phases of FOUR steps (2 x 32 KB of LDS instead of 2 x 64 KB) measured
-  // 31.7 us vs 33.2 at 4096 -> 28672 -- shorter phases, less skew to wait out at each barrier
-  if (MB == 4 && slabs == nullptr && PH == 8 && steps % 4 == 0) {
-    PH = 4;
-    pps = steps / 4;
   }
   {  // tuning aid: SGL_MI355_WSTREAM_FORCE="PH,nc" for the unsplit (no-slab) form
     static const char* force = getenv("SGL_MI355_WSTREAM_FORCE");
