@@ -124,7 +124,10 @@ __global__ __launch_bounds__(576) void awq_wstream_kernel(AwqPArgs p, float* sla
   constexpr int ROWS = 16 * MB;
   constexpr int STEP_BYTES = ROWS * 256;      // 128 k x 2 B per row
   constexpr int BUF_BYTES = PH * STEP_BYTES;  // <= 64 KiB
-  constexpr int PB = PH >= 8 ? 8 : PH;        // weight steps in flight per wave
+  // weight k-steps in flight per wave: shallow, as in gemm_fp8.hip (deeper queues only let the waves drift apart).
+  // Same-box A/B of 8 / 4 / 2: M = 64 qkv 22.0 / 22.0 / 21.3, gate_up 30.7 / 30.3 / 29.3, down 24.2 / 24.0 / 22.8 us;
+  // M = 1 qkv 15.8 / 14.7 / 14.9, down 15.7 / 14.0 / 16.1 us.
+  constexpr int PB = MB == 4 ? 2 : (PH >= 4 ? 4 : PH);
   constexpr int UPS = 4 * MB;                 // 1-KiB DMA units (4 rows x 256 B) per k-step
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
