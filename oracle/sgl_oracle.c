@@ -641,7 +641,11 @@ void orc_silu_and_mul(const uint16_t* x, uint16_t* out, int64_t T, int64_t d, in
 /* RotaryEmbedding.forward_native (neox style), python/sglang/srt/layers/rotary_embedding.py:79-260:
  *   cos_sin = cos_sin_cache[positions]; x1,x2 = halves of the rotary dims;
  *   o1 = x1*cos - x2*sin; o2 = x2*cos + x1*sin, computed in fp32, stored in dtype.
- * cos_sin_cache: float32 [max_pos, rot_dim] = [cos(rot_dim/2) | sin(rot_dim/2)]. */
+ * cos_sin_cache: float32 [max_pos, rot_dim] = [cos(rot_dim/2) | sin(rot_dim/2)].
+ * torch evaluates x1*cos, x2*sin and the difference as three separately rounded fp32 operations, so the
+ * products must not be contracted into FMAs here (gcc's default is -ffp-contract=fast): with contraction
+ * one element in ~1e4 differs from the reference's torch result (tests/golden/rope_neox.npz pins this). */
+__attribute__((optimize("-ffp-contract=off")))
 void orc_rope_neox(
     uint16_t* x /* [T, H, D] in place */, const int64_t* positions, const float* cos_sin_cache,
     int64_t T, int64_t H, int64_t D, int64_t rot_dim, int64_t x_strideT, int64_t x_strideH, int dtype) {

@@ -10,6 +10,10 @@ What it does
   (``awq_dequantize_torch``, ``torch_scaled_mm``, ``torch_per_token_quant_fp8``) by file
   path, with a placeholder for the un-installed ``sgl_kernel``/``sglang`` imports those
   test files make at module import (the helpers themselves are plain torch);
+* for the "next" rows runs the reference's compiled ``rmsnorm_cpu`` /
+  ``fused_add_rmsnorm_cpu`` / ``silu_and_mul_cpu`` / ``rotary_embedding_cpu`` (same .so) and the
+  torch references of ``sgl-kernel/tests/test_{norm,rotary_embedding,merge_state_v2}.py`` and
+  ``test/srt/cpu/utils.py`` (``SiluAndMul``), loaded by file path;
 * also computes an fp32 SDPA-style ground truth with plain torch;
 * asserts that ``oracle/`` (our C restatement) agrees with all of the above, then writes
   inputs + expected outputs as small .npz fixtures.
@@ -418,9 +422,180 @@ def run_kvindices_cases():
     return out
 
 
+# ----------------------------------------------------------------------------- "next" rows: norm / act / rope / merge
+def _ref_elementwise_helpers():
+    t_norm = _load_by_path("ref_test_norm", f"{REF}/sgl-kernel/tests/test_norm.py", {"sgl_kernel": []})
+    t_rope = _load_by_path("ref_test_rope", f"{REF}/sgl-kernel/tests/test_rotary_embedding.py",
+                           {"sgl_kernel": ["apply_rope_with_cos_sin_cache_inplace"]})
+    t_ms = _load_by_path("ref_test_merge_state", f"{REF}/sgl-kernel/tests/test_merge_state_v2.py",
+                         {"sgl_kernel": ["merge_state", "merge_state_v2"]})
+    t_cpu = _load_by_path("ref_test_cpu_utils", f"{REF}/test/srt/cpu/utils.py", {})
+    return t_norm, t_rope, t_ms, t_cpu
+
+
+def _ulp16(a, b):
+    """Distance in 16-bit encodings (same-sign neighbours): 0 = bit-equal, 1 = adjacent values."""
+    return (a.contiguous().view(torch.int16).int() - b.contiguous().view(torch.int16).int()).abs()
+
+
+def run_norm_cases(ref, t_norm):
+    """rmsnorm / fused_add_rmsnorm: the torch references of sgl-kernel/tests/test_norm.py:8-16,39-49 (the
+    arithmetic of RMSNorm.forward_native, layernorm.py:135-172) and the compiled rmsnorm_cpu /
+    fused_add_rmsnorm_cpu (norm.cpp:244-306).  Expected = the torch reference; oracle and compiled kernel
+    may differ from it by one 16-bit ulp on a few elements (fp32 reduction order, rsqrt vs 1/sqrt)."""
+    out = {}
+    cases = [(7, 896, "bf16"), (16, 4096, "bf16"), (19, 3584, "fp16"), (3, 111, "bf16"), (9, 8192, "fp16"),
+             (1, 1024, "bf16")]
+    for i, (T, H, dtype) in enumerate(cases):
+        g = torch.Generator().manual_seed(400 + i)
+        dt = torch.bfloat16 if dtype == "bf16" else torch.float16
+        x = torch.randn(T, H, generator=g).to(dt)
+        w = torch.randn(H, generator=g).to(dt)
+        r = torch.randn(T, H, generator=g).to(dt)
+        eps = 1e-6
+        y_t = t_norm.llama_rms_norm(x, w, eps)
+        y_c = ref.rmsnorm_cpu(x, w, eps)
+        y_o = oracle.rmsnorm(x, w, eps)
+        xa_t, ra_t = t_norm.fused_add_rms_norm(x, r, w, eps)
+        xc, rc = x.clone(), r.clone()
+        ref.fused_add_rmsnorm_cpu(xc, rc, w, eps)
+        r_o = r.clone()
+        xa_o = oracle.rmsnorm(x, w, eps, residual=r_o)
+        d = [_ulp16(y_t, y_o), _ulp16(y_c, y_o), _ulp16(xa_t, xa_o), _ulp16(xc, xa_o)]
+        print(f"norm T={T} H={H} {dtype}: oracle vs torch ref / compiled ref, plain: "
+              f"{(d[0] > 0).float().mean().item():.1e}/{(d[1] > 0).float().mean().item():.1e} of elements differ, "
+              f"fused-add: {(d[2] > 0).float().mean().item():.1e}/{(d[3] > 0).float().mean().item():.1e}; "
+              f"max ulp {max(int(v.max()) for v in d)}")
+        assert all(int(v.max()) <= 1 for v in d), "norm: more than one ulp"
+        assert all((v > 0).float().mean().item() < 5e-3 for v in d), "norm: too many one-ulp differences"
+        # the residual update is one rounding of an exact fp32 sum: bit-exact everywhere
+        assert torch.equal(ra_t.view(torch.int16), r_o.view(torch.int16))
+        assert torch.equal(rc.view(torch.int16), r_o.view(torch.int16))
+        out[f"x{i}"], out[f"w{i}"], out[f"r{i}"] = u16(x), u16(w), u16(r)
+        out[f"y{i}"], out[f"y_add{i}"], out[f"r_out{i}"] = u16(y_t), u16(xa_t), u16(ra_t)
+        out[f"y_cpu{i}"], out[f"y_add_cpu{i}"] = u16(y_c), u16(xc)
+        out[f"dtype{i}"] = np.bytes_(dtype)
+    out["n"], out["eps"] = np.int64(len(cases)), np.float32(1e-6)
+    return out
+
+
+def run_silu_cases(ref, t_cpu):
+    """silu_and_mul: SiluAndMul of test/srt/cpu/utils.py:17-19 (= SiluAndMul.forward_native, activation.py:59-62:
+    silu rounds to the 16-bit dtype, the product rounds again) -- the oracle is bit-exact with it -- and the
+    compiled silu_and_mul_cpu (activation.cpp:59-79), which rounds once and so differs by one ulp on about a quarter of the elements (two at most)."""
+    out = {}
+    cases = [(5, 128, "bf16"), (8, 14336, "bf16"), (3, 4864, "fp16"), (4, 11008, "fp16"), (1, 2048, "bf16")]
+    for i, (T, d, dtype) in enumerate(cases):
+        g = torch.Generator().manual_seed(500 + i)
+        dt = torch.bfloat16 if dtype == "bf16" else torch.float16
+        x = (torch.randn(T, 2 * d, generator=g) * 2).to(dt)
+        y_t = t_cpu.SiluAndMul(x)
+        y_c = ref.silu_and_mul_cpu(x)
+        y_o = oracle.silu_and_mul(x)
+        assert torch.equal(y_t.view(torch.int16), y_o.view(torch.int16)), "silu_and_mul must be bit-exact"
+        dc = _ulp16(y_c, y_o)
+        print(f"silu T={T} d={d} {dtype}: oracle == torch ref bit-exact; compiled ref differs on "
+              f"{(dc > 0).float().mean().item():.2f} of elements by <= {int(dc.max())} ulp")
+        assert int(dc.max()) <= 2   # two roundings against one
+        tol = 1e-2 if dtype == "bf16" else 1e-3   # the reference's own bound (test/srt/cpu/utils.py:6-10)
+        torch.testing.assert_close(y_c, y_o, atol=tol, rtol=tol)
+        out[f"x{i}"], out[f"y{i}"], out[f"y_cpu{i}"] = u16(x), u16(y_t), u16(y_c)
+        out[f"dtype{i}"] = np.bytes_(dtype)
+    out["n"] = np.int64(len(cases))
+    return out
+
+
+def run_rope_cases(ref, t_rope):
+    """Neox RoPE: RotaryEmbedding.forward_native of sgl-kernel/tests/test_rotary_embedding.py:38-117 (q/k in
+    fp32, fp32 cos/sin cache, one rounding to the dtype: the arithmetic of apply_rope_with_cos_sin_cache_inplace)
+    -- the oracle is bit-exact with it -- and the compiled rotary_embedding_cpu (rope.cpp:241-344), which takes
+    a 16-bit cos/sin cache and therefore agrees only to its test's tolerance (test/srt/cpu/test_rope.py)."""
+    out = {}
+    # head_size, rotary_dim, max_pos, base, dtype, T, Hq, Hkv   (rows 1-3 of the reference's own parametrisation
+    # at reduced token counts, then the model geometries)
+    cases = [(64, 64, 32, 8000, "bf16", 32, 1, 1), (256, 128, 1024, 10000, "bf16", 40, 4, 2),
+             (512, 128, 311, 10000, "bf16", 39, 4, 2), (128, 128, 2048, 500000, "bf16", 16, 32, 8),
+             (64, 64, 1024, 1000000, "fp16", 33, 14, 2), (128, 128, 512, 10000, "fp16", 9, 32, 32)]
+    for i, (hs, rd, max_pos, base, dtype, T, Hq, Hkv) in enumerate(cases):
+        g = torch.Generator().manual_seed(600 + i)
+        dt = torch.bfloat16 if dtype == "bf16" else torch.float16
+        rope = t_rope.RotaryEmbedding(hs, rd, max_pos, base, True, dt)
+        pos = torch.randint(0, max_pos, (T,), generator=g)
+        q = torch.randn(T, Hq * hs, generator=g).to(dt)
+        k = torch.randn(T, Hkv * hs, generator=g).to(dt)
+        q_t, k_t = rope.forward_native(pos, q.clone(), k.clone())
+        cache = rope.cos_sin_cache.float().contiguous()
+        q_o, k_o = q.clone().view(T, Hq, hs), k.clone().view(T, Hkv, hs)
+        oracle.rope_neox(q_o, pos, cache, rot_dim=rd)
+        oracle.rope_neox(k_o, pos, cache, rot_dim=rd)
+        assert torch.equal(q_t.view(torch.int16), q_o.reshape(T, -1).view(torch.int16)), "rope q must be bit-exact"
+        assert torch.equal(k_t.view(torch.int16), k_o.reshape(T, -1).view(torch.int16)), "rope k must be bit-exact"
+        q_c, k_c = ref.rotary_embedding_cpu(pos, q.clone(), k.clone(), hs, cache.to(dt), True)
+        dq = (q_c.float() - q_t.float()).abs().max().item()
+        print(f"rope hs={hs} rot={rd} T={T} {Hq}/{Hkv} {dtype}: oracle == torch ref bit-exact; "
+              f"compiled ref (16-bit cache) max|d|={dq:.2e}")
+        torch.testing.assert_close(q_c.float(), q_t.float(), atol=3e-2, rtol=3e-2)
+        torch.testing.assert_close(k_c.float(), k_t.float(), atol=3e-2, rtol=3e-2)
+        out[f"q{i}"], out[f"k{i}"], out[f"pos{i}"], out[f"cache{i}"] = u16(q), u16(k), pos.numpy(), cache.numpy()
+        out[f"q_out{i}"], out[f"k_out{i}"] = u16(q_t), u16(k_t)
+        out[f"meta{i}"] = np.array([hs, rd, T, Hq, Hkv], dtype=np.int64)
+        out[f"dtype{i}"] = np.bytes_(dtype)
+    out["n"] = np.int64(len(cases))
+    return out
+
+
+def run_merge_state_cases(t_ms):
+    """merge_state: merge_state_torch of sgl-kernel/tests/test_merge_state_v2.py:100-133 (fp32 scales applied to
+    the 16-bit outputs; the kernel's +inf -> -inf rule).  Expected output is kept in fp32 (the torch
+    reference promotes) plus its one rounding to the dtype."""
+    out = {}
+    cases = [(37, 8, 32, "fp16"), (16, 32, 128, "bf16"), (13, 16, 48, "bf16"), (5, 14, 64, "fp16"), (9, 8, 256, "f32")]
+    for i, (N, H, D, dtype) in enumerate(cases):
+        g = torch.Generator().manual_seed(700 + i)
+        dt = {"bf16": torch.bfloat16, "fp16": torch.float16, "f32": torch.float32}[dtype]
+        po = torch.randn(N, H, D, generator=g).to(dt)
+        so = torch.randn(N, H, D, generator=g).to(dt)
+        pl = torch.randn(N, H, generator=g) * 3
+        sl = torch.randn(N, H, generator=g) * 3
+        # the reference test's special values (test_merge_state_v2.py:216-222): +inf marks an empty part
+        pl[0, 0], sl[1, 1] = float("inf"), float("inf")
+        pl[2, 2] = float("-inf")
+        o_t, lse_t = t_ms.merge_state_torch(po, pl.clone(), so, sl.clone(), None, torch.empty_like(pl))
+        o_o, lse_o = oracle.merge_state(po, pl.clone(), so, sl.clone())
+        torch.testing.assert_close(lse_o, lse_t, rtol=1e-6, atol=1e-6)
+        exp16 = o_t.to(dt)
+        if dt == torch.float32:
+            torch.testing.assert_close(o_o, o_t, rtol=1e-6, atol=1e-6)
+            mism = 0.0
+        else:
+            du = _ulp16(exp16, o_o)
+            assert int(du.max()) <= 1, "merge_state: more than one ulp"
+            mism = (du > 0).float().mean().item()
+            assert mism < 5e-3
+        print(f"merge_state N={N} H={H} D={D} {dtype}: lse equal to 1e-6; output differs from the torch ref on "
+              f"{mism:.1e} of elements (<= 1 ulp)")
+        enc = (lambda t: t.numpy()) if dt == torch.float32 else u16
+        out[f"po{i}"], out[f"so{i}"], out[f"pl{i}"], out[f"sl{i}"] = enc(po), enc(so), pl.numpy(), sl.numpy()
+        out[f"o_f32_{i}"], out[f"o{i}"], out[f"lse{i}"] = o_t.float().numpy(), enc(exp16), lse_t.numpy()
+        out[f"dtype{i}"] = np.bytes_(dtype)
+    out["n"] = np.int64(len(cases))
+    return out
+
+
+def write_elementwise(ref):
+    t_norm, t_rope, t_ms, t_cpu = _ref_elementwise_helpers()
+    np.savez_compressed(os.path.join(HERE, "rmsnorm.npz"), **run_norm_cases(ref, t_norm))
+    np.savez_compressed(os.path.join(HERE, "silu_and_mul.npz"), **run_silu_cases(ref, t_cpu))
+    np.savez_compressed(os.path.join(HERE, "rope_neox.npz"), **run_rope_cases(ref, t_rope))
+    np.savez_compressed(os.path.join(HERE, "merge_state.npz"), **run_merge_state_cases(t_ms))
+
+
 def main():
     torch.set_num_threads(8)
     ref = _load_ref_lib()
+    if "--elementwise-only" in sys.argv:
+        write_elementwise(ref)
+        return
     awq_dequantize_torch, torch_scaled_mm, torch_per_token_quant_fp8 = _ref_helpers()
     for i, case in enumerate(DECODE_CASES):
         name, data = run_decode_case(ref, case, seed=1000 + i)
@@ -432,6 +607,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "fp8_scaled_mm.npz"), **run_gemm_cases(torch_scaled_mm))
     np.savez_compressed(os.path.join(HERE, "awq.npz"), **run_awq_cases(awq_dequantize_torch))
     np.savez_compressed(os.path.join(HERE, "kv_indices.npz"), **run_kvindices_cases())
+    write_elementwise(ref)
     print("golden vectors written to", HERE)
 
 

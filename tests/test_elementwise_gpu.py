@@ -107,3 +107,64 @@ def test_argmax_equals_torch_argmax(dtype, rows, cols):
     wide = torch.randn(rows, cols + 24, device=DEV, generator=g).to(dtype)
     for _ in range(3):
         assert torch.equal(ops.argmax(wide[:, 8:8 + cols]), torch.argmax(wide[:, 8:8 + cols], dim=-1))
+
+
+# ----------------------------------------------------------------------------- reference-generated fixtures
+# tests/golden/{rmsnorm,silu_and_mul,rope_neox}.npz hold inputs and the outputs of the reference's own torch
+# references (sgl-kernel/tests/test_norm.py, test_rotary_embedding.py; test/srt/cpu/utils.py) and compiled CPU ops
+# (norm.cpp / activation.cpp / rope.cpp), written by tests/golden/make_golden.py in the build container.
+import numpy as np  # noqa: E402
+
+
+def _z16(z, key, dtype):
+    t = torch.from_numpy(z[key].view(np.int16).copy())
+    return t.view(torch.bfloat16 if dtype == "bf16" else torch.float16)
+
+
+def _ulp16(a, b):
+    return (a.cpu().contiguous().view(torch.int16).int() - b.contiguous().view(torch.int16).int()).abs()
+
+
+def _one_ulp_rare(got, exp, what, frac=5e-3):
+    d = _ulp16(got, exp)
+    assert int(d.max()) <= 1, f"{what}: {int(d.max())} ulp"
+    assert (d > 0).float().mean().item() < frac, f"{what}: {(d > 0).float().mean().item():.2e} of elements differ"
+
+
+def test_rmsnorm_vs_reference_fixture():
+    """At most one 16-bit ulp from the reference's torch result on < 0.5 % of the elements (fp32 summation order); the
+    residual update round(x + residual) is exact."""
+    z = np.load("tests/golden/rmsnorm.npz")
+    eps = float(z["eps"])
+    for i in range(int(z["n"])):
+        dtype = z[f"dtype{i}"].item().decode()
+        x, w, r = (_z16(z, f"{k}{i}", dtype).to(DEV) for k in "xwr")
+        _one_ulp_rare(ops.rmsnorm(x, w, eps), _z16(z, f"y{i}", dtype), f"rmsnorm case {i}")
+        xd, rd = x.clone(), r.clone()
+        ops.fused_add_rmsnorm(xd, rd, w, eps)
+        assert torch.equal(rd.cpu().view(torch.int16), _z16(z, f"r_out{i}", dtype).view(torch.int16))
+        _one_ulp_rare(xd, _z16(z, f"y_add{i}", dtype), f"fused_add_rmsnorm case {i}")
+        _one_ulp_rare(xd, _z16(z, f"y_add_cpu{i}", dtype), f"fused_add_rmsnorm vs compiled CPU op, case {i}")
+
+
+def test_silu_and_mul_vs_reference_fixture():
+    """SiluAndMul.forward_native rounds silu(x) to the 16-bit dtype before the product; the kernel does the same, so only
+    the last bit of expf can move a result: at most one ulp, rarely."""
+    z = np.load("tests/golden/silu_and_mul.npz")
+    for i in range(int(z["n"])):
+        dtype = z[f"dtype{i}"].item().decode()
+        y = ops.silu_and_mul(_z16(z, f"x{i}", dtype).to(DEV))
+        _one_ulp_rare(y, _z16(z, f"y{i}", dtype), f"silu_and_mul case {i}")
+        assert int(_ulp16(y, _z16(z, f"y_cpu{i}", dtype)).max()) <= 2
+
+
+def test_rope_neox_bit_exact_vs_reference_fixture():
+    z = np.load("tests/golden/rope_neox.npz")
+    for i in range(int(z["n"])):
+        dtype = z[f"dtype{i}"].item().decode()
+        hs, rd, T, Hq, Hkv = [int(v) for v in z[f"meta{i}"]]
+        q, k = _z16(z, f"q{i}", dtype).to(DEV), _z16(z, f"k{i}", dtype).to(DEV)
+        pos, cache = torch.from_numpy(z[f"pos{i}"]).to(DEV), torch.from_numpy(z[f"cache{i}"]).to(DEV)
+        ops.apply_rope_with_cos_sin_cache_inplace(pos, q, k, hs, cache, True)
+        assert torch.equal(q.cpu().view(torch.int16), _z16(z, f"q_out{i}", dtype).view(torch.int16)), f"q case {i}"
+        assert torch.equal(k.cpu().view(torch.int16), _z16(z, f"k_out{i}", dtype).view(torch.int16)), f"k case {i}"

@@ -48,3 +48,25 @@ def test_merge_state_of_two_halves_equals_attention_over_the_union():
     o2, l2 = torch.empty(oa.shape, device=DEV), torch.empty(la.shape, device=DEV)
     r = ops.merge_state(oa.contiguous(), la.contiguous(), ob.contiguous(), lb.contiguous(), o2, l2)
     assert r[0] is o2 and r[1] is l2 and torch.equal(o2, out)
+
+
+def test_merge_state_vs_reference_fixture():
+    """tests/golden/merge_state.npz: merge_state_torch of the reference's sgl-kernel/tests/test_merge_state_v2.py."""
+    import numpy as np
+    z = np.load("tests/golden/merge_state.npz")
+    for i in range(int(z["n"])):
+        dtype = z[f"dtype{i}"].item().decode()
+        dt = {"bf16": torch.bfloat16, "fp16": torch.float16, "f32": torch.float32}[dtype]
+
+        def t(key):
+            a = z[key]
+            return torch.from_numpy(a.copy()) if dtype == "f32" else torch.from_numpy(a.view(np.int16).copy()).view(dt)
+
+        out, lse = ops.merge_state(t(f"po{i}").to(DEV), torch.from_numpy(z[f"pl{i}"].copy()).to(DEV),
+                                   t(f"so{i}").to(DEV), torch.from_numpy(z[f"sl{i}"].copy()).to(DEV))
+        torch.testing.assert_close(lse.cpu(), torch.from_numpy(z[f"lse{i}"]), rtol=1e-5, atol=1e-5)
+        if dtype == "f32":
+            torch.testing.assert_close(out.cpu(), torch.from_numpy(z[f"o_f32_{i}"]), rtol=1e-5, atol=1e-5)
+        else:
+            d = (out.cpu().view(torch.int16).int() - t(f"o{i}").view(torch.int16).int()).abs()
+            assert int(d.max()) <= 1 and (d > 0).float().mean().item() < 5e-3

@@ -197,3 +197,67 @@ def test_extend_fp8kv_oracle_reduces_to_the_16bit_oracle():
     d_q = float((outs[(True, False)] - outs[(False, False)]).abs().max())
     d_p = float((outs[(True, True)] - outs[(True, False)]).abs().max())
     assert 0 < d_q < 0.25 * scale and 0 < d_p < 0.1 * scale
+
+
+# ----------------------------------------------------------------------------- "next" rows: pinned oracles
+def _z16(z, key, dtype):
+    a = z[key]
+    if dtype == "f32":
+        return torch.from_numpy(a.copy())
+    return _h(torch.from_numpy(a.view(np.int16).copy()), dtype)
+
+
+def _ulp16(a, b):
+    return (a.contiguous().view(torch.int16).int() - b.contiguous().view(torch.int16).int()).abs()
+
+
+def test_rmsnorm_oracle_vs_reference_fixture():
+    """Expected = llama_rms_norm / fused_add_rms_norm of the reference's sgl-kernel/tests/test_norm.py (and the compiled
+    rmsnorm_cpu / fused_add_rmsnorm_cpu): at most one 16-bit ulp apart on < 0.5 % of elements (fp32 summation order);
+    the residual update is exact."""
+    z = np.load("tests/golden/rmsnorm.npz")
+    eps = float(z["eps"])
+    for i in range(int(z["n"])):
+        dtype = z[f"dtype{i}"].item().decode()
+        x, w, r = (_z16(z, f"{k}{i}", dtype) for k in "xwr")
+        for exp_key, res in ((f"y{i}", None), (f"y_cpu{i}", None), (f"y_add{i}", r.clone()), (f"y_add_cpu{i}", r.clone())):
+            y = oracle.rmsnorm(x, w, eps, residual=res)
+            d = _ulp16(y, _z16(z, exp_key, dtype))
+            assert int(d.max()) <= 1 and (d > 0).float().mean().item() < 5e-3, exp_key
+            if res is not None:
+                assert torch.equal(res.view(torch.int16), _z16(z, f"r_out{i}", dtype).view(torch.int16))
+
+
+def test_silu_and_mul_oracle_bit_exact_vs_reference_fixture():
+    z = np.load("tests/golden/silu_and_mul.npz")
+    for i in range(int(z["n"])):
+        dtype = z[f"dtype{i}"].item().decode()
+        y = oracle.silu_and_mul(_z16(z, f"x{i}", dtype))
+        assert torch.equal(y.view(torch.int16), _z16(z, f"y{i}", dtype).view(torch.int16))
+        assert int(_ulp16(y, _z16(z, f"y_cpu{i}", dtype)).max()) <= 2  # the compiled CPU op rounds once, torch twice
+
+
+def test_rope_neox_oracle_bit_exact_vs_reference_fixture():
+    z = np.load("tests/golden/rope_neox.npz")
+    for i in range(int(z["n"])):
+        dtype = z[f"dtype{i}"].item().decode()
+        hs, rd, T, Hq, Hkv = [int(v) for v in z[f"meta{i}"]]
+        pos, cache = torch.from_numpy(z[f"pos{i}"]), torch.from_numpy(z[f"cache{i}"])
+        for name, H in (("q", Hq), ("k", Hkv)):
+            x = _z16(z, f"{name}{i}", dtype).clone().view(T, H, hs)
+            oracle.rope_neox(x, pos, cache, rot_dim=rd)
+            assert torch.equal(x.reshape(T, -1).view(torch.int16), _z16(z, f"{name}_out{i}", dtype).view(torch.int16))
+
+
+def test_merge_state_oracle_vs_reference_fixture():
+    z = np.load("tests/golden/merge_state.npz")
+    for i in range(int(z["n"])):
+        dtype = z[f"dtype{i}"].item().decode()
+        po, so = _z16(z, f"po{i}", dtype), _z16(z, f"so{i}", dtype)
+        out, lse = oracle.merge_state(po, torch.from_numpy(z[f"pl{i}"].copy()), so, torch.from_numpy(z[f"sl{i}"].copy()))
+        torch.testing.assert_close(lse, torch.from_numpy(z[f"lse{i}"]), rtol=1e-6, atol=1e-6)
+        if dtype == "f32":
+            torch.testing.assert_close(out, torch.from_numpy(z[f"o_f32_{i}"]), rtol=1e-6, atol=1e-6)
+        else:
+            d = _ulp16(out, _z16(z, f"o{i}", dtype))
+            assert int(d.max()) <= 1 and (d > 0).float().mean().item() < 5e-3
