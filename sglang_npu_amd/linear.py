@@ -5,6 +5,11 @@ Interface mirrored: python/sglang/srt/layers/linear.py
   MergedColumnParallelLinear (:416-), QKVParallelLinear (:728-), RowParallelLinear.forward (:1285-1309)
 ``quant_method = quant_config.get_quant_method(layer, prefix)``; ``out = quant_method.apply(layer, x, bias)``;
 row-parallel: bias only on rank 0 (:1298), then all-reduce (:1302-1303).
+
+Checkpoint loading follows the reference too: each layer hands ``weight_loader=self.weight_loader`` to
+``create_weights`` (:306-319), the parameters keep it, and a model loader calls
+``param.weight_loader(param, full_tensor[, shard_id])`` (models/llama.py:600-625); the layer then works out this
+rank's slice (``weight_loader_v2`` of :383-400, 674-726, 877-913, 1264-1283) and lets the parameter copy it.
 """
 from __future__ import annotations
 
@@ -22,6 +27,7 @@ class LinearBase(torch.nn.Module):
                  quant_config: Optional[QuantizationConfig] = None, prefix: str = ""):
         super().__init__()
         self.input_size, self.output_size, self.params_dtype = input_size, output_size, params_dtype
+        self.tp_rank, self.tp_size = get_tensor_model_parallel_rank(), get_tensor_model_parallel_world_size()
         self.quant_method = UnquantizedLinearMethod() if quant_config is None else \
             quant_config.get_quant_method(self, prefix=prefix)
 
@@ -35,10 +41,34 @@ class ColumnParallelLinear(LinearBase):
             assert s % tp == 0, f"output size {s} is not divisible by tp={tp}"
         self.output_partition_sizes = [s // tp for s in output_sizes]
         self.output_size_per_partition = sum(self.output_partition_sizes)
+        self.output_sizes = list(output_sizes)
         self.quant_method.create_weights(self, input_size, self.output_partition_sizes, input_size, self.output_size,
-                                         params_dtype)
+                                         params_dtype, weight_loader=self.weight_loader)
         self.bias = torch.nn.Parameter(torch.zeros(self.output_size_per_partition, dtype=params_dtype),
                                        requires_grad=False) if bias else None
+
+    def weight_loader(self, param, loaded_weight: torch.Tensor, loaded_shard_id=None):
+        """linear.py:383-400 / 674-726: one full (unsharded) checkpoint tensor -> this rank's rows.  With a shard id
+        (an index into ``output_sizes``) the tensor is that sub-matrix alone; without one it is the whole fused
+        matrix and is split here."""
+        if loaded_weight.dim() == 0:
+            loaded_weight = loaded_weight.reshape(1)
+        if len(self.output_sizes) == 1:
+            param.load_column_parallel_weight(loaded_weight, tp_rank=self.tp_rank)
+            return
+        if loaded_shard_id is None:  # fused on disk: walk the logical sub-matrices (:638-672)
+            off = 0
+            for i, size in enumerate(self.output_sizes):
+                lo, n = off, size
+                if getattr(param, "packed_dim", None) == param.output_dim:
+                    n, lo = param.adjust_shard_indexes_for_packing(shard_size=n, shard_offset=lo)
+                self.weight_loader(param, loaded_weight.narrow(param.output_dim, lo, n), i)
+                off += size
+            return
+        param.load_merged_column_weight(loaded_weight, shard_id=loaded_shard_id,
+                                        shard_offset=sum(self.output_sizes[:loaded_shard_id]) // self.tp_size,
+                                        shard_size=self.output_sizes[loaded_shard_id] // self.tp_size,
+                                        tp_rank=self.tp_rank, tp_size=self.tp_size)
 
     def forward(self, x):
         return self.quant_method.apply(self, x, self.bias), None
@@ -67,8 +97,30 @@ class QKVParallelLinear(ColumnParallelLinear):
             self.num_kv_heads, rep = 1, tp // total_num_kv_heads
         else:
             self.num_kv_heads, rep = total_num_kv_heads // tp, 1
+        self.head_size, self.total_num_heads, self.total_num_kv_heads = head_size, total_num_heads, total_num_kv_heads
+        self.num_kv_head_replicas = rep
         sizes = [total_num_heads * head_size, total_num_kv_heads * rep * head_size, total_num_kv_heads * rep * head_size]
         super().__init__(hidden_size, sizes, bias, params_dtype, quant_config, prefix)
+
+    def weight_loader(self, param, loaded_weight: torch.Tensor, loaded_shard_id=None):
+        """linear.py:877-913: shard ids "q" / "k" / "v"; the checkpoint's k / v hold ``total_num_kv_heads`` heads and
+        rank r takes head ``r // num_kv_head_replicas``."""
+        if loaded_shard_id is None:  # fused qkv on disk (:832-875)
+            hs, off = self.head_size, 0
+            for sid, n in (("q", self.total_num_heads * hs), ("k", self.total_num_kv_heads * hs),
+                           ("v", self.total_num_kv_heads * hs)):
+                lo, m = off, n
+                if getattr(param, "packed_dim", None) == param.output_dim:
+                    m, lo = param.adjust_shard_indexes_for_packing(shard_size=m, shard_offset=lo)
+                self.weight_loader(param, loaded_weight.narrow(param.output_dim, lo, m), sid)
+                off += n
+            return
+        assert loaded_shard_id in ("q", "k", "v")
+        q_size, kv_size = self.num_heads * self.head_size, self.num_kv_heads * self.head_size
+        offset = {"q": 0, "k": q_size, "v": q_size + kv_size}[loaded_shard_id]
+        param.load_qkv_weight(loaded_weight, num_heads=self.num_kv_head_replicas, shard_id=loaded_shard_id,
+                              shard_offset=offset, shard_size=q_size if loaded_shard_id == "q" else kv_size,
+                              tp_rank=self.tp_rank)
 
 
 class RowParallelLinear(LinearBase):
@@ -80,8 +132,18 @@ class RowParallelLinear(LinearBase):
         self.input_size_per_partition = input_size // tp
         self.reduce_results = reduce_results
         self.quant_method.create_weights(self, self.input_size_per_partition, [output_size], input_size, output_size,
-                                         params_dtype)
+                                         params_dtype, weight_loader=self.weight_loader)
         self.bias = torch.nn.Parameter(torch.zeros(output_size, dtype=params_dtype), requires_grad=False) if bias else None
+
+    def weight_loader(self, param, loaded_weight: torch.Tensor):
+        """linear.py:1264-1283: this rank's slice along the parameter's input dimension; per-output-channel scales
+        have none and are copied whole."""
+        if loaded_weight.dim() == 0:
+            loaded_weight = loaded_weight.reshape(1)
+        if hasattr(param, "input_dim"):
+            param.load_row_parallel_weight(loaded_weight, tp_rank=self.tp_rank)
+        else:
+            param.load_row_parallel_weight(loaded_weight)
 
     def forward(self, x):
         bias_ = None if (get_tensor_model_parallel_rank() > 0) else self.bias

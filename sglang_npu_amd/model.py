@@ -216,47 +216,23 @@ class LlamaForCausalLM(torch.nn.Module):
     @torch.no_grad()
     def load_dummy_weights(self):
         dev, dt, cfg = self.device_str, self.dtype, self.cfg
-        tp, rank = get_tensor_model_parallel_world_size(), get_tensor_model_parallel_rank()
-
-        def shard_rows(full, sizes_full):
-            # column-parallel: each logical sub-matrix is sliced by rows (output features)
-            outs, off = [], 0
-            for s in sizes_full:
-                per = s // tp
-                outs.append(full[off + rank * per: off + (rank + 1) * per])
-                off += s
-            return torch.cat(outs, 0)
-
+        rank = get_tensor_model_parallel_rank()
         for layer in self.layers:
             at, mlp = layer.self_attn, layer.mlp
-            kv_rep = max(1, tp // cfg.num_key_value_heads)
-            qkv_sizes = [cfg.num_attention_heads * cfg.head_dim, cfg.num_key_value_heads * cfg.head_dim,
-                         cfg.num_key_value_heads * cfg.head_dim]
+            qkv_n = (cfg.num_attention_heads + 2 * cfg.num_key_value_heads) * cfg.head_dim
             specs = [
-                (at.qkv_proj, sum(qkv_sizes), cfg.hidden_size, "col", qkv_sizes),
-                (at.o_proj, cfg.hidden_size, cfg.num_attention_heads * cfg.head_dim, "row", None),
-                (mlp.gate_up_proj, 2 * cfg.intermediate_size, cfg.hidden_size, "col", [cfg.intermediate_size] * 2),
-                (mlp.down_proj, cfg.hidden_size, cfg.intermediate_size, "row", None),
+                (at.qkv_proj, qkv_n, cfg.hidden_size),
+                (at.o_proj, cfg.hidden_size, cfg.num_attention_heads * cfg.head_dim),
+                (mlp.gate_up_proj, 2 * cfg.intermediate_size, cfg.hidden_size),
+                (mlp.down_proj, cfg.hidden_size, cfg.intermediate_size),
             ]
-            for lin, n_full, k_full, kind, sizes in specs:
+            for lin, n_full, k_full in specs:
                 if isinstance(self.quant_config, AWQConfig):
                     self._fill_awq(lin)
                     continue
-                w = _dummy((n_full, k_full), dt, dev)
-                if kind == "col":
-                    if lin is at.qkv_proj and kv_rep > 1:
-                        # replicate KV heads when tp > num_kv_heads (linear.py QKVParallelLinear)
-                        q, k, v = w.split(sizes, 0)
-                        hd = cfg.head_dim
-                        q = q[rank * at.q_size:(rank + 1) * at.q_size]
-                        kvh = rank // kv_rep
-                        w = torch.cat([q, k[kvh * hd:(kvh + 1) * hd], v[kvh * hd:(kvh + 1) * hd]], 0)
-                    else:
-                        w = shard_rows(w, sizes)
-                else:
-                    per = k_full // tp
-                    w = w[:, rank * per:(rank + 1) * per]
-                lin.weight.data = w.contiguous().to(lin.weight.dtype)
+                # the FULL (unsharded, fused-on-disk) matrix goes through the layer's checkpoint loader, which takes
+                # this rank's rows / columns (and replicates KV heads when tp > num_kv_heads) -- linear.py weight_loader
+                lin.weight.weight_loader(lin.weight, _dummy((n_full, k_full), dt, dev))
                 lin.quant_method.process_weights_after_loading(lin)
             layer.input_layernorm.weight.data = _dummy((cfg.hidden_size,), dt, dev, 0.5, 1.5)
             layer.post_attention_layernorm.weight.data = _dummy((cfg.hidden_size,), dt, dev, 0.5, 1.5, seed=4321)

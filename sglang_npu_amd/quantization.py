@@ -8,8 +8,14 @@ Interface mirrored (same method names / argument meaning):
   QUANTIZATION_METHODS registry             python/sglang/srt/layers/quantization/__init__.py:74-121
 
 ``create_weights`` registers the same attributes on the layer (``weight``, ``weight_scale`` /
-``qweight``, ``qzeros``, ``scales``) with the same shapes and dtypes, so a checkpoint loader written
-for the reference fills them unchanged; ``process_weights_after_loading`` stores ``weight.t()``
+``qweight``, ``qzeros``, ``scales``) with the same shapes, dtypes AND loader metadata: they are
+``ModelWeightParameter`` / ``ChannelQuantScaleParameter`` / ``PackedvLLMParameter`` /
+``GroupQuantScaleParameter`` instances (SGLang's own classes when SGLang is importable, same-named local
+ones otherwise -- ``parameter.classes()``) carrying the ``weight_loader`` the layer passes in
+``extra_weight_attrs`` (w8a8_fp8.py:153-173, awq.py:354-394), so SGLang's checkpoint loaders shard and fill
+them unchanged.  The method classes keep the reference's names because ``layers/linear.py:44-61,315``
+picks ``weight_loader_v2`` by ``quant_method.__class__.__name__``.
+``process_weights_after_loading`` stores ``weight.t()``
 (K-major [K,N] view) exactly like w8a8_fp8.py:115,132; ``apply`` runs the HIP kernels.  gfx950 uses
 OCP e4m3fn (is_fp8_fnuz() is False there), so no fnuz normalisation step exists here.
 """
@@ -22,6 +28,7 @@ import os
 import torch
 
 from . import ops
+from .parameter import classes as _param_classes, is_linear_layer
 
 
 class QuantizeMethodBase:
@@ -77,9 +84,9 @@ class UnquantizedLinearMethod(LinearMethodBase):
 
     def create_weights(self, layer, input_size_per_partition, output_partition_sizes, input_size, output_size,
                        params_dtype, **extra_weight_attrs):
-        w = torch.nn.Parameter(torch.empty(sum(output_partition_sizes), input_size_per_partition, dtype=params_dtype),
-                               requires_grad=False)
-        layer.register_parameter("weight", w)
+        layer.register_parameter("weight", _param_classes().ModelWeightParameter(
+            data=torch.empty(sum(output_partition_sizes), input_size_per_partition, dtype=params_dtype), input_dim=1,
+            output_dim=0, weight_loader=extra_weight_attrs.get("weight_loader")))
 
     def apply(self, layer, x, bias=None):
         return torch.nn.functional.linear(x, layer.weight, bias)
@@ -135,8 +142,8 @@ class W8A8Fp8Config(QuantizationConfig):
         return cls(is_checkpoint_fp8_serialized="compressed-tensors" in quant_method or "w8a8_fp8" in quant_method)
 
     def get_quant_method(self, layer, prefix: str):
-        from .linear import LinearBase
-        if isinstance(layer, LinearBase):
+        # w8a8_fp8.py:80-92: `isinstance(layer, LinearBase)` -- SGLang's LinearBase or the harness one
+        if is_linear_layer(layer):
             return W8A8Fp8LinearMethod(self)
         return None
 
@@ -149,13 +156,20 @@ class W8A8Fp8LinearMethod(LinearMethodBase):
                        params_dtype, **extra_weight_attrs):
         # w8a8_fp8.py:136-173: weight [N_part, K] (fp8 if the checkpoint is serialised in fp8, else
         # params_dtype and quantised after loading), weight_scale [N_part, 1] fp32
-        weight_dtype = torch.float8_e4m3fn if self.quantization_config.is_checkpoint_fp8_serialized else params_dtype
+        P = _param_classes()
+        serialized = self.quantization_config.is_checkpoint_fp8_serialized
+        weight_dtype = torch.float8_e4m3fn if serialized else params_dtype
+        weight_loader = extra_weight_attrs.get("weight_loader")
         n = sum(output_partition_sizes)
-        layer.register_parameter("weight", torch.nn.Parameter(
-            torch.empty(n, input_size_per_partition, dtype=weight_dtype), requires_grad=False))
-        layer.register_parameter("weight_scale", torch.nn.Parameter(
-            torch.empty((n, 1), dtype=torch.float32), requires_grad=False))
-        layer.logical_widths = output_partition_sizes
+        self.logical_widths = output_partition_sizes
+        layer.register_parameter("weight", P.ModelWeightParameter(
+            data=torch.empty(n, input_size_per_partition, dtype=weight_dtype), input_dim=1, output_dim=0,
+            weight_loader=weight_loader))
+        if serialized:
+            layer.register_parameter("weight_scale", P.ChannelQuantScaleParameter(
+                data=torch.empty((n, 1), dtype=torch.float32), output_dim=0, weight_loader=weight_loader))
+        else:
+            layer.weight_scale = None  # made by process_weights_after_loading from the 16-bit weight (:119-133)
         layer.input_scale = None
 
     def process_weights_after_loading(self, layer) -> None:
@@ -226,8 +240,7 @@ class AWQConfig(QuantizationConfig):
         return cls(get(["w_bit", "bits"]), get(["q_group_size", "group_size"]), get(["zero_point"], True))
 
     def get_quant_method(self, layer, prefix: str):
-        from .linear import LinearBase
-        if isinstance(layer, LinearBase):
+        if is_linear_layer(layer):  # awq.py:127-136
             return AWQLinearMethod(self)
         return None
 
@@ -251,12 +264,18 @@ class AWQLinearMethod(LinearMethodBase):
             raise ValueError("The output size is not aligned with the quantized weight shape. "
                              "This can be caused by too large tensor parallel size.")
         pf = self.quant_config.pack_factor
-        layer.register_parameter("qweight", torch.nn.Parameter(
-            torch.empty(input_size_per_partition, n // pf, dtype=torch.int32), requires_grad=False))
-        layer.register_parameter("qzeros", torch.nn.Parameter(
-            torch.empty(input_size_per_partition // g, n // pf, dtype=torch.int32), requires_grad=False))
-        layer.register_parameter("scales", torch.nn.Parameter(
-            torch.empty(input_size_per_partition // g, n, dtype=params_dtype), requires_grad=False))
+        P = _param_classes()
+        weight_loader = extra_weight_attrs.get("weight_loader")
+        # awq.py:354-394: K is the slow dimension (input_dim 0), eight output columns per int32 (packed_dim 1)
+        layer.register_parameter("qweight", P.PackedvLLMParameter(
+            data=torch.empty(input_size_per_partition, n // pf, dtype=torch.int32), input_dim=0, output_dim=1,
+            packed_dim=1, packed_factor=pf, weight_loader=weight_loader))
+        layer.register_parameter("qzeros", P.PackedvLLMParameter(
+            data=torch.empty(input_size_per_partition // g, n // pf, dtype=torch.int32), input_dim=0, output_dim=1,
+            packed_dim=1, packed_factor=pf, weight_loader=weight_loader))
+        layer.register_parameter("scales", P.GroupQuantScaleParameter(
+            data=torch.empty(input_size_per_partition // g, n, dtype=params_dtype), input_dim=0, output_dim=1,
+            weight_loader=weight_loader))
 
     def process_weights_after_loading(self, layer) -> None:
         layer.qweight = torch.nn.Parameter(layer.qweight.data, requires_grad=False)
@@ -266,6 +285,9 @@ class AWQLinearMethod(LinearMethodBase):
         # repack freely" (base_config.py process_weights_after_loading).  Costs K*N/2 + K*N/32 extra bytes per
         # layer; SGL_MI355_AWQ_NO_REPACK=1 keeps only the checkpoint layout.
         layer.awq_packed = None
+        # a reload (update_weights / RL sync) must not leave a prefill weight from the previous checkpoint behind
+        layer.awq_dequant_cache = None
+        layer._awq_cache_refused = False
         K, N = layer.qweight.shape[0], layer.qweight.shape[1] * self.quant_config.pack_factor
         G = K // layer.scales.shape[0]
         if layer.qweight.is_cuda and not os.environ.get("SGL_MI355_AWQ_NO_REPACK") and \

@@ -41,13 +41,18 @@ def _worker(rank, world, port, q):
         w1, w2 = torch.randn(N, K, generator=gen), torch.randn(K, N, generator=gen)
         x = torch.randn(5, K, generator=gen)
         col = MergedColumnParallelLinear(K, [N // 2, N // 2], params_dtype=torch.float32)
+        # the full checkpoint matrices go through the layers' weight loaders, which take this rank's slice
+        col.weight.weight_loader(col.weight, w1[:N // 2], 0)
+        col.weight.weight_loader(col.weight, w1[N // 2:], 1)
         half = N // 2 // world
-        col.weight.data = torch.cat([w1[rank * half:(rank + 1) * half], w1[N // 2 + rank * half: N // 2 + (rank + 1) * half]])
+        assert torch.equal(col.weight.data, torch.cat([w1[rank * half:(rank + 1) * half],
+                                                       w1[N // 2 + rank * half: N // 2 + (rank + 1) * half]]))
+        # the row-parallel layer consumes the column-parallel output: its K index runs over [gate shard | up shard] of
+        # every rank in turn, so the "checkpoint" is w2 with its columns in that order
+        perm = torch.cat([torch.cat([torch.arange(r * half, (r + 1) * half), N // 2 + torch.arange(r * half, (r + 1) * half)])
+                          for r in range(world)])
         row = RowParallelLinear(N, K, params_dtype=torch.float32)
-        perm = torch.cat([torch.arange(r * half, (r + 1) * half) for r in range(world)] +
-                         [N // 2 + torch.arange(r * half, (r + 1) * half) for r in range(world)])
-        cols_mine = torch.cat([torch.arange(rank * half, (rank + 1) * half), N // 2 + torch.arange(rank * half, (rank + 1) * half)])
-        row.weight.data = w2[:, cols_mine].contiguous()
+        row.weight.weight_loader(row.weight, w2[:, perm].contiguous())
         y, _ = col(x)
         z, _ = row(y)
         ref = (x @ w1.t()) @ w2.t()
