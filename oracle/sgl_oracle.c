@@ -156,7 +156,18 @@ static inline uint8_t f32_to_e4m3(float f) {
   return (uint8_t)(sign | bits);
 }
 
+/* torch's own float -> float8_e4m3fn cast (c10/util/Float8_e4m3fn.h, what `cache_k.to(torch.float8_e4m3fn)` of
+ * memory_pool.py:385-394 runs): RNE, NOT saturating -- NaN and everything that would round past 448 (|x| > 464;
+ * 464 itself ties to the even 448) become NaN, the sign kept: 0x7f / 0xff. */
+static inline uint8_t f32_to_e4m3_torch(float f) {
+  if (!(fabsf(f) <= 464.0f)) return (uint8_t)((signbit(f) ? 0x80u : 0u) | 0x7fu);
+  return f32_to_e4m3(f);
+}
+
 /* exposed so the tests can pin the scalar converters against torch's */
+void orc_cvt_f32_to_e4m3_torch(const float* x, uint8_t* y, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) y[i] = f32_to_e4m3_torch(x[i]);
+}
 void orc_cvt_f32_to_e4m3(const float* x, uint8_t* y, int64_t n) {
   for (int64_t i = 0; i < n; ++i) y[i] = f32_to_e4m3(x[i]);
 }
@@ -700,7 +711,7 @@ void orc_merge_state(const void* p_out, const float* p_lse, const void* s_out, c
  * set_kv_buffer with a pool dtype of float8_e4m3fn, python/sglang/srt/mem_cache/memory_pool.py:369-407:
  *   if cache_k.dtype != self.dtype: (optional) cache_k.div_(k_scale) -- IN the 16-bit dtype --, then .to(fp8)
  *   (:385-391); stored through a uint8 view (:114-118, :392-394).  The Triton backend passes no scale
- *   (triton_backend.py:647-650, 706-709).  Values beyond +-448 saturate here (torch's cast gives NaN there). */
+ *   (triton_backend.py:647-650, 706-709).  The cast is torch's: NaN and |x| > 464 are stored as NaN. */
 void orc_set_kv_buffer_fp8(uint8_t* k_buffer, uint8_t* v_buffer, const uint16_t* key, const uint16_t* value,
                            const int64_t* loc, int64_t T, int64_t Hkv, int64_t D, int64_t Dv, int64_t k_strideN,
                            int64_t k_strideH, int64_t v_strideN, int64_t v_strideH, int64_t nk_strideN,
@@ -711,12 +722,12 @@ void orc_set_kv_buffer_fp8(uint8_t* k_buffer, uint8_t* v_buffer, const uint16_t*
       for (int64_t d = 0; d < D; ++d) {
         float x = h_to_f32(key[t * nk_strideN + h * nk_strideH + d], dtype);
         if (k_scale > 0.f) x = h_to_f32(f32_to_h(x / k_scale, dtype), dtype);
-        k_buffer[loc[t] * k_strideN + h * k_strideH + d] = f32_to_e4m3(x);
+        k_buffer[loc[t] * k_strideN + h * k_strideH + d] = f32_to_e4m3_torch(x);
       }
       for (int64_t d = 0; d < Dv; ++d) {
         float x = h_to_f32(value[t * nv_strideN + h * nv_strideH + d], dtype);
         if (v_scale > 0.f) x = h_to_f32(f32_to_h(x / v_scale, dtype), dtype);
-        v_buffer[loc[t] * v_strideN + h * v_strideH + d] = f32_to_e4m3(x);
+        v_buffer[loc[t] * v_strideN + h * v_strideH + d] = f32_to_e4m3_torch(x);
       }
     }
 }

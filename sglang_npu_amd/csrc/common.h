@@ -104,6 +104,18 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
 
 __device__ __forceinline__ int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// float -> float8_e4m3fn exactly as torch's `.to(torch.float8_e4m3fn)` (c10/util/Float8_e4m3fn.h), which is what the
+// reference's FP8 KV-pool write runs (memory_pool.py:385-394): round to nearest even, NO saturation -- NaN and every
+// value that would round past 448 (|x| > 464) become NaN with the sign kept (0x7f / 0xff), so a numerical fault
+// upstream stays visible in the cache instead of being stored as a finite +-448.  Two values -> two bytes.
+__device__ __forceinline__ uint32_t e4m3_byte_fix(float x, uint32_t byte) {
+  return (fabsf(x) <= 464.0f) ? byte : (0x7fu | ((__float_as_uint(x) >> 24) & 0x80u));
+}
+__device__ __forceinline__ uint32_t cvt_pk_e4m3_torch(float a, float b) {
+  const int pk = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(a, -448.0f), 448.0f), fminf(fmaxf(b, -448.0f), 448.0f), 0, false);
+  return e4m3_byte_fix(a, (uint32_t)pk & 0xffu) | (e4m3_byte_fix(b, ((uint32_t)pk >> 8) & 0xffu) << 8);
+}
+
 }  // namespace sglm
 
 #define SGLM_CHECK_ARG(cond, ...)            \

@@ -301,12 +301,11 @@ __global__ __launch_bounds__(256) void rope_kernel(
   }
 }
 
-// One element into a KV-pool row: 16-bit as is, or (KV8) cast to e4m3 as set_kv_buffer_fp8 does (saturating RNE).
+// One element into a KV-pool row: 16-bit as is, or (KV8) cast to e4m3 as set_kv_buffer_fp8 does (torch's cast).
 template <int DTYPE, bool KV8>
 __device__ __forceinline__ void pool_store(char* row, int i, typename Half16<DTYPE>::T v) {
   if constexpr (KV8) {
-    const float a = fminf(fmaxf(Half16<DTYPE>::to_f32(v), -448.f), 448.f);
-    reinterpret_cast<uint8_t*>(row)[i] = (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32(a, 0.f, 0, false) & 0xFF);
+    reinterpret_cast<uint8_t*>(row)[i] = (uint8_t)(cvt_pk_e4m3_torch(Half16<DTYPE>::to_f32(v), 0.f) & 0xFF);
   } else {
     reinterpret_cast<typename Half16<DTYPE>::T*>(row)[i] = v;
   }
@@ -534,14 +533,10 @@ __global__ __launch_bounds__(256) void rope_kv_neox_kernel(
     const T16* vs = v + t * v_st + (int64_t)(h - Hq) * D;
     const t16x2 v0 = *reinterpret_cast<const t16x2*>(vs + 4 * l), v1 = *reinterpret_cast<const t16x2*>(vs + 4 * l + 2);
     if constexpr (KV8) {
-      auto sat = [](float x) { return fminf(fmaxf(x, -448.f), 448.f); };
-      const int p1 = __builtin_amdgcn_cvt_pk_fp8_f32(sat(Hh::to_f32(o1[0])), sat(Hh::to_f32(o1[1])), 0, false);
-      const int p2 = __builtin_amdgcn_cvt_pk_fp8_f32(sat(Hh::to_f32(o2[0])), sat(Hh::to_f32(o2[1])), 0, false);
-      *reinterpret_cast<uint16_t*>(kdst + 2 * l) = (uint16_t)(p1 & 0xFFFF);
-      *reinterpret_cast<uint16_t*>(kdst + half + 2 * l) = (uint16_t)(p2 & 0xFFFF);
-      int pv = __builtin_amdgcn_cvt_pk_fp8_f32(sat(Hh::to_f32(v0[0])), sat(Hh::to_f32(v0[1])), 0, false);
-      pv = __builtin_amdgcn_cvt_pk_fp8_f32(sat(Hh::to_f32(v1[0])), sat(Hh::to_f32(v1[1])), pv, true);
-      *reinterpret_cast<uint32_t*>(vdst + 4 * l) = (uint32_t)pv;
+      *reinterpret_cast<uint16_t*>(kdst + 2 * l) = (uint16_t)cvt_pk_e4m3_torch(Hh::to_f32(o1[0]), Hh::to_f32(o1[1]));
+      *reinterpret_cast<uint16_t*>(kdst + half + 2 * l) = (uint16_t)cvt_pk_e4m3_torch(Hh::to_f32(o2[0]), Hh::to_f32(o2[1]));
+      *reinterpret_cast<uint32_t*>(vdst + 4 * l) = cvt_pk_e4m3_torch(Hh::to_f32(v0[0]), Hh::to_f32(v0[1])) |
+                                                   (cvt_pk_e4m3_torch(Hh::to_f32(v1[0]), Hh::to_f32(v1[1])) << 16);
     } else {
       *reinterpret_cast<t16x2*>(kdst + 2 * (2 * l)) = o1;
       *reinterpret_cast<t16x2*>(kdst + 2 * (half + 2 * l)) = o2;
@@ -553,6 +548,44 @@ __global__ __launch_bounds__(256) void rope_kv_neox_kernel(
 
 // few long rows (decode batches, H >= 4096, at most 2048 vectors of 8): 512 / 1024 threads per row
 inline bool rms_wide(int64_t T, int nv) { return T <= 2048 && nv >= 512 && nv <= 2048; }
+
+// Any row length (the reference's own tests use 111 and 500, sgl-kernel/tests/test_norm.py:53): scalar accesses, two
+// passes over the row (sum of squares; then normalise -- recomputing x + residual from the inputs so that the norm is
+// taken on the unrounded fp32 sum exactly as in the vector kernel).  Every element is read and written by the same
+// thread in both passes, so `out` may alias `x` (fused_add_rmsnorm's in-place form).
+template <int DTYPE>
+__global__ __launch_bounds__(256) void rmsnorm_any_kernel(
+    const typename Half16<DTYPE>::T* x, typename Half16<DTYPE>::T* residual,
+    const typename Half16<DTYPE>::T* __restrict__ weight, typename Half16<DTYPE>::T* out, int H, float eps) {
+  using Hh = Half16<DTYPE>;
+  __shared__ float red[4];
+  const int64_t base = (int64_t)blockIdx.x * H;
+  float ss = 0.f;
+  for (int i = threadIdx.x; i < H; i += 256) {
+    float v = Hh::to_f32(x[base + i]);
+    if (residual) v += Hh::to_f32(residual[base + i]);
+    ss += v * v;
+  }
+  ss = block_reduce_sum(ss, red);
+  const float inv = 1.0f / sqrtf(ss / (float)H + eps);
+  for (int i = threadIdx.x; i < H; i += 256) {
+    float v = Hh::to_f32(x[base + i]);
+    if (residual) {
+      v += Hh::to_f32(residual[base + i]);
+      residual[base + i] = Hh::from_f32(v);
+    }
+    out[base + i] = Hh::from_f32(v * inv * Hh::to_f32(weight[i]));
+  }
+}
+
+template <int DTYPE>
+int launch_rmsnorm_any(const void* x, void* residual, const void* weight, void* out, int64_t T, int64_t H, float eps,
+                       hipStream_t s) {
+  using T16 = typename Half16<DTYPE>::T;
+  hipLaunchKernelGGL((rmsnorm_any_kernel<DTYPE>), dim3((unsigned)T), dim3(256), 0, s, (const T16*)x, (T16*)residual,
+                     (const T16*)weight, (T16*)out, (int)H, eps);
+  return check_hip(hipGetLastError(), "rmsnorm (generic row length) launch");
+}
 
 template <int DTYPE>
 int launch_rmsnorm(const void* x, void* residual, const void* weight, void* out, void* out_q, float* out_s, int64_t T,
@@ -668,10 +701,16 @@ using namespace sglm;
 extern "C" int sgl_mi355_rmsnorm(
     void* out, const void* x, const void* weight, int64_t num_tokens, int64_t hidden, float eps, int dtype,
     void* stream) {
-  int rc = check_rows("rmsnorm", num_tokens, hidden, 16384, dtype);
+  const bool vec = hidden % 8 == 0 && hidden <= 16384;  // otherwise the generic-row-length kernel
+  int rc = check_rows("rmsnorm", num_tokens, vec ? hidden : 8, 16384, dtype);
   if (rc) return rc;
+  SGLM_CHECK_ARG(hidden > 0 && hidden < (1ll << 31), "rmsnorm: bad row length %ld", (long)hidden);
   if (num_tokens == 0) return 0;
   SGLM_CHECK_ARG(out && x && weight, "rmsnorm: null tensor pointer");
+  if (!vec)
+    return dtype == SGL_MI355_BF16
+               ? launch_rmsnorm_any<SGL_MI355_BF16>(x, nullptr, weight, out, num_tokens, hidden, eps, as_stream(stream))
+               : launch_rmsnorm_any<SGL_MI355_FP16>(x, nullptr, weight, out, num_tokens, hidden, eps, as_stream(stream));
   return dtype == SGL_MI355_BF16
              ? launch_rmsnorm<SGL_MI355_BF16>(x, nullptr, weight, out, nullptr, nullptr, num_tokens, hidden, eps, as_stream(stream))
              : launch_rmsnorm<SGL_MI355_FP16>(x, nullptr, weight, out, nullptr, nullptr, num_tokens, hidden, eps, as_stream(stream));
@@ -680,10 +719,16 @@ extern "C" int sgl_mi355_rmsnorm(
 extern "C" int sgl_mi355_fused_add_rmsnorm(
     void* x, void* residual, const void* weight, int64_t num_tokens, int64_t hidden, float eps, int dtype,
     void* stream) {
-  int rc = check_rows("fused_add_rmsnorm", num_tokens, hidden, 16384, dtype);
+  const bool vec = hidden % 8 == 0 && hidden <= 16384;
+  int rc = check_rows("fused_add_rmsnorm", num_tokens, vec ? hidden : 8, 16384, dtype);
   if (rc) return rc;
+  SGLM_CHECK_ARG(hidden > 0 && hidden < (1ll << 31), "fused_add_rmsnorm: bad row length %ld", (long)hidden);
   if (num_tokens == 0) return 0;
   SGLM_CHECK_ARG(x && residual && weight, "fused_add_rmsnorm: null tensor pointer");
+  if (!vec)
+    return dtype == SGL_MI355_BF16
+               ? launch_rmsnorm_any<SGL_MI355_BF16>(x, residual, weight, x, num_tokens, hidden, eps, as_stream(stream))
+               : launch_rmsnorm_any<SGL_MI355_FP16>(x, residual, weight, x, num_tokens, hidden, eps, as_stream(stream));
   return dtype == SGL_MI355_BF16
              ? launch_rmsnorm<SGL_MI355_BF16>(x, residual, weight, x, nullptr, nullptr, num_tokens, hidden, eps, as_stream(stream))
              : launch_rmsnorm<SGL_MI355_FP16>(x, residual, weight, x, nullptr, nullptr, num_tokens, hidden, eps, as_stream(stream));

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void set_kv_kernel_u16(
 }
 
 // FP8 (e4m3fn) pool: cast of the 16-bit new entries (memory_pool.py:385-394: optional x.div_(scale) in the 16-bit
-// dtype, then .to(fp8), stored through a uint8 view).  Saturating RNE cast (v_cvt_pk_fp8_f32); one wave per row.
+// dtype, then .to(fp8), stored through a uint8 view).  torch's RNE cast (NaN and |x| > 464 stored as NaN, common.h cvt_pk_e4m3_torch); one wave per row.
 template <int DTYPE, typename LocT>
 __global__ __launch_bounds__(256) void set_kv_fp8_kernel(
     uint8_t* __restrict__ kb, uint8_t* __restrict__ vb, const typename Half16<DTYPE>::T* __restrict__ key,
@@ -75,10 +75,7 @@ __global__ __launch_bounds__(256) void set_kv_fp8_kernel(
         a = Hh::to_f32(Hh::from_f32(a / scale));
         b = Hh::to_f32(Hh::from_f32(b / scale));
       }
-      a = fminf(fmaxf(a, -448.f), 448.f);
-      b = fminf(fmaxf(b, -448.f), 448.f);
-      const int pk = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
-      *reinterpret_cast<uint16_t*>(dst + i) = (uint16_t)(pk & 0xFFFF);
+      *reinterpret_cast<uint16_t*>(dst + i) = (uint16_t)cvt_pk_e4m3_torch(a, b);  // torch's cast: NaN / overflow -> NaN
     }
   };
   cast_row(key + t * nk_sn + h * nk_sh, kb + slot * k_sn + h * k_sh, D, k_scale);

@@ -150,7 +150,7 @@ def _is_fp8_pool(k_buffer, v_buffer, q) -> bool:
 
 def set_kv_buffer_fp8(k_buffer, v_buffer, loc, cache_k, cache_v, k_scale=None, v_scale=None):
     """MHATokenToKVPool.set_kv_buffer for a float8_e4m3fn pool (memory_pool.py:385-394): optional x.div_(scale) in the
-    16-bit dtype, cast to e4m3 (saturating), store."""
+    16-bit dtype, then torch's own e4m3 cast (round to nearest even; NaN and |x| > 464 become NaN, nothing saturates), store."""
     _need_gpu(k_buffer, v_buffer, loc, cache_k, cache_v)
     if k_buffer.dtype not in _FP8_KV or v_buffer.dtype not in _FP8_KV:
         raise RuntimeError("set_kv_buffer_fp8: the pool must be float8_e4m3fn (or its uint8 view)")
@@ -367,7 +367,43 @@ def sgl_per_token_quant_fp8(input: torch.Tensor, output_q: torch.Tensor, output_
         _I(_dtype_code(input)), _stream(input)))
 
 
-_fp8_workspace = {}
+class _ScratchPool:
+    """fp32 scratch for split-K partials, one buffer per (device, stream).
+
+    * per stream, because the C entry points take the buffer as an argument and a second stream on the same device
+      (the all-reduce side stream, a draft model, a second model instance) must not share partial sums with the first;
+    * never shrunk or freed: a captured HIP graph holds the raw pointer of the buffer it was captured with, so a buffer
+      that has to grow is replaced by a larger one while every earlier one stays alive (``_retired``);
+    * growing an existing buffer while its stream is being captured raises instead: the graph would keep writing into
+      the old buffer while eager calls move on to the new one.  ``reserve_gemm_workspace()`` on the capture stream
+      before capturing avoids it (the default size already covers every Llama-3-8B / 70B / Llama-2-7B decode GEMM)."""
+
+    def __init__(self, floor_floats: int):
+        self.floor, self._cur, self._retired = floor_floats, {}, []
+
+    def get(self, device: torch.device, need_floats: int) -> torch.Tensor:
+        key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+        cur = self._cur.get(key)
+        if cur is None or cur.numel() < need_floats:
+            if cur is not None:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError(
+                        f"split-K workspace of {cur.numel()} floats would have to grow to {need_floats} during graph "
+                        "capture; call sglang_npu_amd.ops.reserve_gemm_workspace(device, rows, cols) before capturing")
+                self._retired.append(cur)
+            cur = torch.empty(max(need_floats, self.floor), dtype=torch.float32, device=device)
+            self._cur[key] = cur
+        return cur
+
+
+_fp8_workspace = _ScratchPool(7 * 64 * 28672)
+
+
+def reserve_gemm_workspace(device, rows: int = 64, cols: int = 28672) -> None:
+    """Size this stream's split-K scratch (FP8 and AWQ decode GEMMs) for GEMMs of up to ``rows`` x ``cols`` outputs."""
+    device = torch.device(device)
+    _fp8_workspace.get(device, 32 * min(rows, 64) * cols)
+    _awq_workspace.get(device, 16 * min(rows, 64) * cols)
 
 
 def fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None) -> torch.Tensor:
@@ -402,10 +438,7 @@ def fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None) -> tor
     ws = None
     if 0 < M <= 64:  # split-K partials of the decode-time weight streamer
         need = max(-(-K // 2048), min(K // 512, -(-2048 // max(1, N // 16)))) * M * N + M * N
-        ws = _fp8_workspace.get(mat_a.device)
-        if ws is None or ws.numel() < need:
-            ws = torch.empty(max(need, 7 * 64 * 28672), dtype=torch.float32, device=mat_a.device)
-            _fp8_workspace[mat_a.device] = ws
+        ws = _fp8_workspace.get(mat_a.device, need)
     _lib.check(_lib.lib().sgl_mi355_fp8_scaled_mm(
         _ptr(mat_a), _ptr(mat_b), _ptr(scales_a), _ptr(scales_b), _ptr(bias), _ptr(out),
         _ptr(ws), _I64(ws.numel() if ws is not None else 0),
@@ -417,7 +450,7 @@ def fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None) -> tor
 class GemmPartials:
     """An fp8_scaled_mm whose epilogue has not run yet: raw fp32 split-K partial sums in the shared workspace
     (sgl_mi355_fp8_scaled_mm_partials).  Must be consumed -- finalize() or one of the *_from_partials ops -- before the
-    next decode GEMM on this device, which reuses the workspace."""
+    next decode GEMM on this device AND stream, which reuses the workspace (other streams have their own)."""
     __slots__ = ("ws", "num_slices", "x_scale", "w_scale", "bias", "M", "N", "out_dtype")
 
     def __init__(self, ws, num_slices, x_scale, w_scale, bias, M, N, out_dtype):
@@ -439,11 +472,7 @@ def fp8_scaled_mm_partials(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=Non
     N = mat_b.size(1)
     if not (0 < M <= 64) or mat_a.stride(1) != 1 or mat_b.stride(0) != 1 or mat_b.size(0) != K:
         return None
-    need = 32 * M * N
-    ws = _fp8_workspace.get(mat_a.device)
-    if ws is None or ws.numel() < need:
-        ws = torch.empty(max(need, 7 * 64 * 28672), dtype=torch.float32, device=mat_a.device)
-        _fp8_workspace[mat_a.device] = ws
+    ws = _fp8_workspace.get(mat_a.device, 32 * M * N)
     sk = ctypes.c_int32(0)
     rc = _lib.lib().sgl_mi355_fp8_scaled_mm_partials(
         _ptr(mat_a), _ptr(mat_b), _ptr(ws), _I64(ws.numel()), _I64(M), _I64(N), _I64(K),
@@ -525,7 +554,7 @@ def awq_dequantize(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Te
     return out
 
 
-_awq_workspace = {}
+_awq_workspace = _ScratchPool(16 * 64 * 4096)
 
 
 def awq_gemm(x: torch.Tensor, qweight, scales, qzeros, bias=None) -> torch.Tensor:
@@ -545,11 +574,7 @@ def awq_gemm(x: torch.Tensor, qweight, scales, qzeros, bias=None) -> torch.Tenso
             out.add_(bias)
         return out
     out = torch.empty((M, N), dtype=x.dtype, device=x.device)
-    need = 16 * M * N
-    ws = _awq_workspace.get(x.device)
-    if ws is None or ws.numel() < need:
-        ws = torch.empty(max(need, 16 * 64 * 4096), dtype=torch.float32, device=x.device)
-        _awq_workspace[x.device] = ws
+    ws = _awq_workspace.get(x.device, 16 * M * N)
     _lib.check(_lib.lib().sgl_mi355_awq_gemm(_ptr(x), _ptr(qweight), _ptr(scales), _ptr(qzeros), _ptr(bias), _ptr(out),
                                              _ptr(ws), _I64(ws.numel()), _I64(M), _I64(N), _I64(K), _I64(G),
                                              _I(_dtype_code(x)), _stream(x)))
@@ -593,11 +618,7 @@ def awq_gemm_packed(x: torch.Tensor, wp: torch.Tensor, sz: torch.Tensor, group_s
     if wp.size(1) * 8 != _awq_kp(K) or sz.size(0) != N:
         raise RuntimeError("awq_gemm_packed: x and the packed weight shapes cannot be multiplied")
     out = torch.empty((M, N), dtype=x.dtype, device=x.device)
-    need = 16 * M * N
-    ws = _awq_workspace.get(x.device)
-    if ws is None or ws.numel() < need:
-        ws = torch.empty(max(need, 16 * 64 * 4096), dtype=torch.float32, device=x.device)
-        _awq_workspace[x.device] = ws
+    ws = _awq_workspace.get(x.device, 16 * M * N)
     _lib.check(_lib.lib().sgl_mi355_awq_gemm_packed(
         _ptr(x), _ptr(wp), _ptr(sz), _ptr(bias), _ptr(out), _ptr(ws), _I64(ws.numel()), _I64(M), _I64(N), _I64(K),
         _I64(group_size), _I64(x.stride(0) if M > 1 else K), _I(_dtype_code(x)), _stream(x)))

@@ -165,3 +165,39 @@ def test_k_steps_not_multiple_of_eight(M, K, N):
     part = ops.fp8_scaled_mm_partials(a, w.t(), sa, sb, torch.bfloat16, bias)
     if part is not None:
         assert torch.allclose(part.finalize().float(), ref, rtol=2 ** -7, atol=2 ** -7 * float(ref.abs().max()))
+
+
+def test_split_k_workspace_is_per_stream_and_never_replaced_under_a_graph():
+    """The split-K scratch is keyed by (device, stream); a buffer that must grow is replaced while the old one stays
+    alive (captured graphs hold its pointer); growing one during capture raises."""
+    dev = torch.device(DEV)
+    pool = ops._ScratchPool(1024)
+    a = pool.get(dev, 100)
+    assert pool.get(dev, 1000) is a
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        b = pool.get(dev, 100)
+    assert b.data_ptr() != a.data_ptr()
+    c = pool.get(dev, 5000)
+    assert c.numel() >= 5000 and c is not a and any(t is a for t in pool._retired)
+    g = torch.cuda.CUDAGraph()
+    cap = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(cap):
+        pool.get(dev, 10)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=cap):
+            torch.zeros(8, device=dev)
+            pool.get(dev, 10)               # fits: fine
+            with pytest.raises(RuntimeError, match="during graph capture"):
+                pool.get(dev, 1 << 20)
+    # a GEMM captured on one stream and eager GEMMs on another do not share partial sums
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    x = ((torch.rand(64, 4096, device=DEV, generator=gen) - 0.5) * 8).to(torch.float8_e4m3fn)
+    w = ((torch.rand(4096, 4096, device=DEV, generator=gen) - 0.5) * 8).to(torch.float8_e4m3fn)
+    sa, sb = torch.rand(64, device=DEV, generator=gen) + 0.5, torch.rand(4096, device=DEV, generator=gen) + 0.5
+    ref = ops.fp8_scaled_mm(x, w.t(), sa, sb, torch.bfloat16)
+    with torch.cuda.stream(side):
+        side.wait_stream(torch.cuda.current_stream())
+        other = ops.fp8_scaled_mm(x, w.t(), sa, sb, torch.bfloat16)
+    torch.cuda.synchronize()
+    assert torch.equal(ref, other)

@@ -21,7 +21,11 @@ def test_set_kv_buffer_fp8_bit_exact(dtype, scales):
     T, Hkv, D = 37, 4, 128
     k = (torch.randn(T, Hkv, D, generator=g) * 4).to(dtype)
     v = (torch.randn(T, Hkv, D, generator=g) * 4).to(dtype)
-    k[0, 0, :4] = torch.tensor([500.0, -1000.0, 448.0, 1e-4]).to(dtype)  # saturation and a subnormal
+    # torch's cast does not saturate: NaN, infinities and everything that rounds past 448 (|x| > 464) are stored as NaN
+    special = torch.tensor([500.0, -1000.0, 448.0, 1e-4, float("nan"), float("inf"), -float("inf"), 449.0, 464.0, -464.0,
+                            466.0, -470.0, 479.0, 480.0])
+    k[0, 0, :special.numel()] = special.to(dtype)
+    v[1, 1, :special.numel()] = special.to(dtype)
     loc = (torch.randperm(99, generator=g)[:T] + 1)
     kb, vb = torch.zeros(100, Hkv, D, dtype=torch.uint8), torch.zeros(100, Hkv, D, dtype=torch.uint8)
     ks, vs = scales if scales else (None, None)
@@ -29,9 +33,12 @@ def test_set_kv_buffer_fp8_bit_exact(dtype, scales):
     kb_d, vb_d = torch.zeros_like(kb, device=DEV), torch.zeros_like(vb, device=DEV)
     ops.set_kv_buffer_fp8(kb_d, vb_d, loc.to(DEV), k.to(DEV), v.to(DEV), ks, vs)
     assert torch.equal(kb_d.cpu(), kb) and torch.equal(vb_d.cpu(), vb)
-    # in range it is torch's own cast (memory_pool.py:389-391)
-    ref = (v / vs if vs else v).to(torch.float8_e4m3fn).view(torch.uint8)
-    assert torch.equal(vb[loc], ref)
+    # it is torch's own cast (memory_pool.py:389-391), out-of-range values and NaN included (NaN's sign bit aside)
+    for pool, src, sc in ((kb, k, ks), (vb, v, vs)):
+        ref = (src / sc if sc else src).to(torch.float8_e4m3fn).view(torch.uint8)
+        got = pool[loc]
+        nan = (ref & 0x7f) == 0x7f
+        assert torch.equal(got[~nan], ref[~nan]) and bool(((got[nan] & 0x7f) == 0x7f).all()) and int(nan.sum()) >= 3
 
 
 @pytest.mark.parametrize("Hq,Hkv,D", [(32, 8, 128), (8, 1, 128), (14, 2, 64), (32, 32, 128)])

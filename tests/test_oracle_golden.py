@@ -112,6 +112,15 @@ def test_scalar_converters_match_torch():
     y = torch.empty(x.numel(), dtype=torch.uint8)
     lib.orc_cvt_f32_to_e4m3(ctypes.c_void_p(xc.data_ptr()), ctypes.c_void_p(y.data_ptr()), ctypes.c_int64(x.numel()))
     assert torch.equal(y, xc.to(torch.float8_e4m3fn).view(torch.uint8))
+    # the KV-pool cast is torch's UNclamped one (memory_pool.py:385-394): NaN, infinities and |x| > 464 give NaN
+    xe = torch.cat([x, torch.tensor([float("nan"), -float("nan"), float("inf"), -float("inf"), 449.0, 463.9, 464.0,
+                                     -464.0, 464.1, -465.0, 479.9, 480.0, 1e6, -1e30])])
+    ye = torch.empty(xe.numel(), dtype=torch.uint8)
+    lib.orc_cvt_f32_to_e4m3_torch(ctypes.c_void_p(xe.data_ptr()), ctypes.c_void_p(ye.data_ptr()), ctypes.c_int64(xe.numel()))
+    ref_e = xe.to(torch.float8_e4m3fn).view(torch.uint8)
+    assert torch.equal(ye & 0x7f, ref_e & 0x7f)                       # magnitudes incl. the NaN code 0x7f
+    fin = ~torch.isnan(xe)
+    assert torch.equal(ye[fin], ref_e[fin])                           # the sign too wherever the input is a number
     back = torch.empty(256, dtype=torch.float32)
     allb = torch.arange(256, dtype=torch.uint8)
     lib.orc_cvt_e4m3_to_f32(ctypes.c_void_p(allb.data_ptr()), ctypes.c_void_p(back.data_ptr()), ctypes.c_int64(256))
