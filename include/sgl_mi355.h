@@ -34,7 +34,7 @@ extern "C" {
 #define SGL_MI355_ERR_RUNTIME 3          /* a HIP runtime call failed                */
 
 /* ABI version of this header; bumped on any signature change. */
-#define SGL_MI355_ABI_VERSION 3
+#define SGL_MI355_ABI_VERSION 4
 int sgl_mi355_abi_version(void);
 
 /* Copies the calling thread's last error message (NUL-terminated) into buf. Returns its length. */
@@ -402,10 +402,18 @@ int sgl_mi355_rotary_embedding_set_kv_fp8kv(const int64_t* positions, void* quer
  *   ar_create allocates this rank's uncached comm buffer (signals + double-buffered payload of max_bytes);
  *   ar_get_ipc_handle returns its 64-byte hipIpcMemHandle_t; the host all-gathers the handles and passes
  *   the world_size x 64 bytes to ar_open_peers; ar_all_reduce(inp -> out, SUM) is then a single kernel on
- *   `stream` (graph-capturable, out-of-place).  dtype: 0 bf16, 1 fp16, 2 fp32; nbytes % 16 == 0. */
+ *   `stream` (graph-capturable, out-of-place).  dtype: 0 bf16, 1 fp16, 2 fp32; nbytes % 16 == 0.
+ *   Failure (the role of the std::runtime_error of custom_all_reduce_hip.cuh:512-519): every in-kernel wait is
+ *   bounded; a wait that runs out sets a sticky status word in host-mapped memory, the output of that call and of
+ *   every later call is filled with NaN (all-ones bytes) instead of a sum of unsynchronised buffers, and
+ *   ar_timed_out reads the word without synchronising the device -- the caller checks it before each launch.
+ *   ar_set_peers_local wires `world` communicators created in ONE process (ranks that share a device or reach
+ *   each other by peer access: no IPC handles needed); ar_set_spin_limit shortens the bound (tests). */
 int sgl_mi355_ar_create(int rank, int world_size, int64_t max_bytes, void** comm_out);
 int sgl_mi355_ar_get_ipc_handle(void* comm, void* handle_out);
 int sgl_mi355_ar_open_peers(void* comm, const void* all_handles);
+int sgl_mi355_ar_set_peers_local(void* comm, void* const* comms);
+int sgl_mi355_ar_set_spin_limit(int64_t spins);
 int sgl_mi355_ar_all_reduce(void* comm, const void* inp, void* out, int64_t nbytes, int dtype, void* stream);
 int sgl_mi355_ar_timed_out(void* comm, int* flag_out);
 int sgl_mi355_ar_destroy(void* comm);

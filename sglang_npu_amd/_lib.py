@@ -11,7 +11,7 @@ import threading
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "lib", "libsgl_mi355.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 _lock = threading.Lock()

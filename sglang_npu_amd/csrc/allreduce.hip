@@ -15,7 +15,11 @@
 // The sum order is rank 0..W-1 on every rank, so all ranks produce bit-identical results (and integer-
 // valued payloads are exact, the property test_custom_allreduce.py:118-146 relies on).
 // The call counter lives in device memory (kernel arguments are frozen under HIP-graph replay).
-// Every spin is bounded; a timeout sets a flag word that the host can read.
+// Every spin is bounded and a timeout FAILS CLOSED: the block that gave up raises a sticky status word in
+// host-mapped pinned memory (so the host polls it without a device sync), every block that sees it fills
+// its part of the output with all-ones bytes (NaN in bf16 / fp16 / fp32) instead of summing buffers that
+// were never synchronised, and every later call on that communicator does the same without spinning.
+// GroupCoordinator.all_reduce checks the word before each launch and raises (distributed.py).
 #include <string.h>
 
 #include "common.h"
@@ -35,12 +39,17 @@ struct ArComm {
   size_t data_off, half_bytes;
   char* peer[kMaxRanks]; // mapped bases of every rank (own entry = base)
   bool opened[kMaxRanks];
+  uint32_t* status_host; // pinned, device-mapped: 0 = healthy, 1 = a barrier timed out (sticky)
+  uint32_t* status_dev;
 };
 
 struct ArArgs {
   char* peer[kMaxRanks];
   size_t data_off, half_bytes;
   int rank, world;
+  uint32_t* status;      // sticky failure word in this rank's own device buffer (read on every call: must be cheap)
+  uint32_t* status_host; // its mirror in host-mapped pinned memory (written once, when a wait gives up)
+  unsigned spin_limit;
 };
 
 // signals: uint32 [2 slots][world][kMaxBlocks] at offset 0; counter uint32[kMaxBlocks] after them; then timeout
@@ -49,10 +58,13 @@ __device__ __forceinline__ uint32_t* sig_ptr(char* base, int slot, int from, int
 }
 constexpr size_t kSigBytes = 2 * kMaxRanks * kMaxBlocks * 4;
 constexpr size_t kCounterOff = kSigBytes;
-constexpr size_t kTimeoutOff = kCounterOff + kMaxBlocks * 4;
+constexpr size_t kStatusOff = kCounterOff + kMaxBlocks * 4;
 constexpr size_t kHeaderBytes = 8192;
 
-__device__ __forceinline__ void block_barrier(const ArArgs& a, int slot, uint32_t val) {
+// Returns false when this rank's communicator is (or has just become) failed: the caller must not read peer data.
+__device__ __forceinline__ bool block_barrier(const ArArgs& a, int slot, uint32_t val) {
+  __shared__ int failed;
+  if (threadIdx.x == 0) failed = 0;
   __syncthreads();
   if (threadIdx.x < a.world) {
     const int t = threadIdx.x;
@@ -61,14 +73,25 @@ __device__ __forceinline__ void block_barrier(const ArArgs& a, int slot, uint32_
     uint32_t* mine = sig_ptr(a.peer[a.rank], slot, t, blockIdx.x);
     unsigned spins = 0;
     while (__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < val) {
-      if (++spins > kSpinLimit) {
-        *reinterpret_cast<uint32_t*>(a.peer[a.rank] + kTimeoutOff) = 1;
+      // another block of this rank (or an earlier call) already gave up: do not wait out the full limit again
+      if (++spins > a.spin_limit ||
+          ((spins & 1023u) == 0 && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)) {
+        __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(a.status_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        failed = 1;
         break;
       }
       __builtin_amdgcn_s_sleep(1);
     }
   }
   __syncthreads();
+  return failed == 0;
+}
+
+// all-ones bytes: NaN in every supported dtype
+__device__ __forceinline__ void poison(uint4* out, int64_t n16, int64_t tid, int64_t nthr) {
+  const uint4 bad{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+  for (int64_t i = tid; i < n16; i += nthr) out[i] = bad;
 }
 
 template <int DTYPE>
@@ -108,9 +131,18 @@ __global__ __launch_bounds__(kThreads) void all_reduce_kernel(ArArgs a, const ui
   // result area of the two-shot variant sits behind the payload area of the same half
   const size_t res_off = a.half_bytes / 2;
 
-  // phase A: publish my input
-  for (int64_t i = tid; i < n16; i += nthr) reinterpret_cast<uint4*>(my_data)[i] = inp[i];
-  block_barrier(a, 0, call);
+  // a communicator that has timed out once stays failed: no spinning, poisoned output
+  bool ok = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0;
+  if (ok) {
+    // phase A: publish my input
+    for (int64_t i = tid; i < n16; i += nthr) reinterpret_cast<uint4*>(my_data)[i] = inp[i];
+    ok = block_barrier(a, 0, call);
+  }
+  if (!ok) {
+    poison(out, n16, tid, nthr);
+    if (threadIdx.x == 0) *counter = call;
+    return;
+  }
 
   if (!two_shot) {
     for (int64_t i = tid; i < n16; i += nthr) {
@@ -133,7 +165,11 @@ __global__ __launch_bounds__(kThreads) void all_reduce_kernel(ArArgs a, const ui
         A::add(f, reinterpret_cast<const uint4*>(a.peer[p] + a.data_off + half * a.half_bytes)[i]);
       reinterpret_cast<uint4*>(my_data + res_off)[i] = A::pack(f);
     }
-    block_barrier(a, 1, call);
+    if (!block_barrier(a, 1, call)) {
+      poison(out, n16, tid, nthr);
+      if (threadIdx.x == 0) *counter = call;
+      return;
+    }
     // phase C: gather every rank's reduced slice
     for (int64_t i = tid; i < n16; i += nthr) {
       const int owner = (int)(i / per);
@@ -173,6 +209,21 @@ extern "C" int sgl_mi355_ar_create(int rank, int world_size, int64_t max_bytes, 
     return check_hip(e, "hipMemset");
   }
   c->base = (char*)p;
+  void* st = nullptr;
+  e = hipHostMalloc(&st, 64, hipHostMallocMapped);
+  if (e == hipSuccess) {
+    *(volatile uint32_t*)st = 0;
+    void* st_dev = nullptr;
+    e = hipHostGetDevicePointer(&st_dev, st, 0);
+    c->status_host = (uint32_t*)st;
+    c->status_dev = (uint32_t*)st_dev;
+  }
+  if (e != hipSuccess) {
+    if (st) (void)hipHostFree(st);
+    (void)hipFree(p);
+    delete c;
+    return check_hip(e, "hipHostMalloc(mapped status word)");
+  }
   for (int i = 0; i < kMaxRanks; ++i) { c->peer[i] = nullptr; c->opened[i] = false; }
   c->peer[rank] = c->base;
   *comm_out = c;
@@ -201,6 +252,26 @@ extern "C" int sgl_mi355_ar_open_peers(void* comm, const void* all_handles /* wo
   return 0;
 }
 
+extern "C" int sgl_mi355_ar_set_peers_local(void* comm, void* const* comms /* world communicators of THIS process */) {
+  SGLM_CHECK_ARG(comm && comms, "ar_set_peers_local: null argument");
+  ArComm* c = (ArComm*)comm;
+  for (int r = 0; r < c->world; ++r) {
+    SGLM_CHECK_ARG(comms[r] != nullptr, "ar_set_peers_local: communicator %d is null", r);
+    const ArComm* o = (const ArComm*)comms[r];
+    SGLM_CHECK_ARG(o->rank == r && o->world == c->world && o->max_bytes == c->max_bytes,
+                   "ar_set_peers_local: communicator %d does not belong to this group", r);
+    c->peer[r] = o->base;
+  }
+  return 0;
+}
+
+static unsigned g_spin_limit = kSpinLimit;
+extern "C" int sgl_mi355_ar_set_spin_limit(int64_t spins) {
+  SGLM_CHECK_ARG(spins > 0 && spins <= (int64_t)kSpinLimit, "ar_set_spin_limit: 1 .. %u", kSpinLimit);
+  g_spin_limit = (unsigned)spins;
+  return 0;
+}
+
 extern "C" int sgl_mi355_ar_all_reduce(void* comm, const void* inp, void* out, int64_t nbytes, int dtype /* 0 bf16, 1 fp16, 2 fp32 */,
                                         void* stream) {
   SGLM_CHECK_ARG(comm, "ar_all_reduce: null communicator");
@@ -214,6 +285,7 @@ extern "C" int sgl_mi355_ar_all_reduce(void* comm, const void* inp, void* out, i
   ArArgs a{};
   for (int r = 0; r < c->world; ++r) a.peer[r] = c->peer[r];
   a.data_off = c->data_off; a.half_bytes = c->half_bytes; a.rank = c->rank; a.world = c->world;
+  a.status = reinterpret_cast<uint32_t*>(c->base + kStatusOff); a.status_host = c->status_dev; a.spin_limit = g_spin_limit;
   const int64_t n16 = nbytes / 16;
   const int two_shot = nbytes > 256 * 1024 && c->world > 1;
   int blocks = (int)((n16 + kThreads - 1) / kThreads);
@@ -231,9 +303,7 @@ extern "C" int sgl_mi355_ar_all_reduce(void* comm, const void* inp, void* out, i
 extern "C" int sgl_mi355_ar_timed_out(void* comm, int* flag_out) {
   SGLM_CHECK_ARG(comm && flag_out, "ar_timed_out: null argument");
   ArComm* c = (ArComm*)comm;
-  uint32_t v = 0;
-  SGLM_CHECK_HIP(hipMemcpy(&v, c->base + kTimeoutOff, 4, hipMemcpyDeviceToHost));
-  *flag_out = (int)v;
+  *flag_out = (int)*(volatile uint32_t*)c->status_host;  // pinned host memory: no device synchronisation
   return 0;
 }
 
@@ -243,6 +313,7 @@ extern "C" int sgl_mi355_ar_destroy(void* comm) {
   for (int r = 0; r < c->world; ++r)
     if (c->opened[r]) (void)hipIpcCloseMemHandle(c->peer[r]);
   (void)hipFree(c->base);
+  if (c->status_host) (void)hipHostFree(c->status_host);
   delete c;
   return 0;
 }

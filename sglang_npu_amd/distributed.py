@@ -43,7 +43,7 @@ class CustomAllreduce:
     _SUPPORTED_WORLD_SIZES = [2, 4, 6, 8]
 
     def __init__(self, group, device: torch.device, max_size: int = 16 * 1024 * 1024, rank: Optional[int] = None,
-                 world_size: Optional[int] = None):
+                 world_size: Optional[int] = None, exchange: bool = True):
         import ctypes
         from . import _lib
         self.disabled = True
@@ -58,6 +58,9 @@ class CustomAllreduce:
         comm = ctypes.c_void_p()
         _lib.check(lib.sgl_mi355_ar_create(ctypes.c_int(self.rank), ctypes.c_int(self.world_size),
                                            ctypes.c_int64(max_size), ctypes.byref(comm)))
+        self._comm, self._lib, self._ct = comm, lib, ctypes
+        if not exchange:  # the caller wires the peers itself (connect_local)
+            return
         handle = ctypes.create_string_buffer(64)
         _lib.check(lib.sgl_mi355_ar_get_ipc_handle(comm, handle))
         gathered = [None] * self.world_size
@@ -65,8 +68,21 @@ class CustomAllreduce:
         blob = b"".join(gathered)
         _lib.check(lib.sgl_mi355_ar_open_peers(comm, ctypes.c_char_p(blob)))
         dist.barrier(group=group)
-        self._comm, self._lib, self._ct = comm, lib, ctypes
         self.disabled = False
+
+    @classmethod
+    def connect_local(cls, world_size: int, device: torch.device, max_size: int = 16 * 1024 * 1024):
+        """All `world_size` ranks inside ONE process (they share a device or reach each other by peer access): the
+        peers are wired by pointer (sgl_mi355_ar_set_peers_local), no IPC handles and no process group.  Used to run
+        the 6- and 8-rank protocol on a one-GPU box, where one process per rank is not possible."""
+        import ctypes
+        from . import _lib
+        comms = [cls(None, device, max_size, rank=r, world_size=world_size, exchange=False) for r in range(world_size)]
+        arr = (ctypes.c_void_p * world_size)(*[c._comm for c in comms])
+        for c in comms:
+            _lib.check(c._lib.sgl_mi355_ar_set_peers_local(c._comm, arr))
+            c.disabled = False
+        return comms
 
     def should_custom_ar(self, inp: torch.Tensor) -> bool:
         if self.disabled or not inp.is_cuda or not inp.is_contiguous():
@@ -79,6 +95,12 @@ class CustomAllreduce:
         if not self.should_custom_ar(inp):
             return None
         from . import _lib
+        if self.timed_out():
+            # fail closed: a peer never arrived at a barrier (its output of that call is NaN-filled); the communicator
+            # stays unusable -- the role of the std::runtime_error of custom_all_reduce_hip.cuh:512-519
+            self.disabled = True
+            raise RuntimeError("custom all-reduce: a peer did not reach the barrier in time; the affected outputs were "
+                               "filled with NaN and this communicator is disabled")
         out = torch.empty_like(inp)
         code = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}[inp.dtype]
         ct = self._ct
@@ -136,22 +158,23 @@ class GroupCoordinator:
         return input_
 
     def all_reduce_async(self, input_: torch.Tensor) -> AllReduceHandle:
-        """Issue the all-reduce on the side stream; the caller's stream is only fenced at wait()."""
-        if self.world_size == 1:
+        """Issue the all-reduce on the side stream; the caller's stream is only fenced at wait().  Same dispatch as
+        all_reduce (stub / custom P2P / RCCL); the handle's tensor is the result (the P2P kernel is out of place)."""
+        if self.world_size == 1 or self.stub_all_reduce:
             return AllReduceHandle(input_)
         if not input_.is_cuda:
-            dist.all_reduce(input_, group=self.device_group)
-            return AllReduceHandle(input_)
+            return AllReduceHandle(self.all_reduce(input_))
         side = self.side_stream
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream())
         side.wait_event(ready)
         with torch.cuda.stream(side):
-            dist.all_reduce(input_, group=self.device_group)
+            out = self.all_reduce(input_)
             done = torch.cuda.Event()
             done.record(side)
         input_.record_stream(side)
-        return AllReduceHandle(input_, done, side)
+        out.record_stream(torch.cuda.current_stream())
+        return AllReduceHandle(out, done, side)
 
     def all_gather(self, input_: torch.Tensor, dim: int = -1) -> torch.Tensor:
         """parallel_state.py all_gather: concatenate the ranks' tensors along `dim`."""

@@ -17,7 +17,7 @@ from typing import List, Optional
 
 import torch
 
-from .distributed import (get_tensor_model_parallel_rank, get_tensor_model_parallel_world_size,
+from .distributed import (get_tensor_model_parallel_rank, get_tensor_model_parallel_world_size, get_tp_group,
                           tensor_model_parallel_all_reduce)
 from .quantization import QuantizationConfig, UnquantizedLinearMethod
 
@@ -145,12 +145,20 @@ class RowParallelLinear(LinearBase):
         else:
             param.load_row_parallel_weight(loaded_weight)
 
-    def forward(self, x):
+    def _reduce(self, out, async_reduce: bool):
+        """linear.py:1302-1303.  async_reduce: the collective goes to the TP group's side stream and an
+        AllReduceHandle comes back instead of the tensor; its consumer (the next norm) calls wait(), which fences the
+        main stream on the collective's event -- whatever the main stream launches in between overlaps it."""
+        if not (self.reduce_results and get_tensor_model_parallel_world_size() > 1):
+            return out
+        if async_reduce and out.is_cuda:
+            return get_tp_group().all_reduce_async(out)
+        return tensor_model_parallel_all_reduce(out)
+
+    def forward(self, x, async_reduce: bool = False):
         bias_ = None if (get_tensor_model_parallel_rank() > 0) else self.bias
         out = self.quant_method.apply(self, x, bias_)
-        if self.reduce_results and get_tensor_model_parallel_world_size() > 1:
-            out = tensor_model_parallel_all_reduce(out)
-        return out, None
+        return self._reduce(out, async_reduce), None
 
     def forward_prequantized_partials(self, qinput, x_scale, out_dtype):
         """Split-K partials for a fused consumer; only without tensor parallelism (the all-reduce needs the
@@ -160,9 +168,7 @@ class RowParallelLinear(LinearBase):
             return None
         return fn(self, qinput, x_scale, out_dtype, self.bias)
 
-    def forward_prequantized(self, qinput, x_scale, out_dtype):
+    def forward_prequantized(self, qinput, x_scale, out_dtype, async_reduce: bool = False):
         bias_ = None if (get_tensor_model_parallel_rank() > 0) else self.bias
         out = self.quant_method.apply_prequantized(self, qinput, x_scale, out_dtype, bias_)
-        if self.reduce_results and get_tensor_model_parallel_world_size() > 1:
-            out = tensor_model_parallel_all_reduce(out)
-        return out, None
+        return self._reduce(out, async_reduce), None

@@ -24,7 +24,8 @@ import os
 import torch
 
 from . import ops
-from .distributed import get_tensor_model_parallel_rank, get_tensor_model_parallel_world_size, get_tp_group
+from .distributed import (AllReduceHandle, get_tensor_model_parallel_rank, get_tensor_model_parallel_world_size,
+                          get_tp_group)
 from .harness import ForwardBatch, ModelConfig, RadixAttention
 from .layers import RMSNorm, RotaryEmbedding, SiluAndMul
 from .linear import MergedColumnParallelLinear, QKVParallelLinear, RowParallelLinear
@@ -39,6 +40,16 @@ def _dummy(shape, dtype, device, low=-1e-3, high=1e-3, seed=1234):
                     device=device)
     t.uniform_(low, high, generator=g)
     return t.to(dtype)
+
+
+# Row-parallel layers hand their all-reduce to the TP group's side stream and return an AllReduceHandle; the next
+# norm waits on it (north_star: "RCCL all-reduce overlapped on a side HIP stream").  SGL_MI355_SYNC_AR=1: in-stream.
+ASYNC_AR = not os.environ.get("SGL_MI355_SYNC_AR")
+
+
+def _arrived(h):
+    """The tensor behind a pending all-reduce (fences the current stream on it), or h itself."""
+    return h.wait() if isinstance(h, AllReduceHandle) else h
 
 
 # fewest decode rows for which GEMM epilogues are deferred into the consumer kernels (tuning: SGL_MI355_DEFER_MIN_ROWS)
@@ -58,7 +69,7 @@ class LlamaMLP(torch.nn.Module):
     def forward(self, x):
         gate_up, _ = self.gate_up_proj(x)
         x = self.act_fn(gate_up)
-        x, _ = self.down_proj(x)
+        x, _ = self.down_proj(x, async_reduce=ASYNC_AR)
         return x
 
     def forward_fp8(self, xq, xs, out_dtype, defer: bool = False):
@@ -77,7 +88,7 @@ class LlamaMLP(torch.nn.Module):
             part = self.down_proj.forward_prequantized_partials(aq, a_s, out_dtype)
             if part is not None:
                 return part
-        x, _ = self.down_proj.forward_prequantized(aq, a_s, out_dtype)
+        x, _ = self.down_proj.forward_prequantized(aq, a_s, out_dtype, async_reduce=ASYNC_AR)
         return x
 
 
@@ -104,7 +115,7 @@ class LlamaAttention(torch.nn.Module):
         q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
         q, k = self.rotary_emb(positions, q, k)
         attn_output = self.attn(q, k, v, forward_batch)
-        output, _ = self.o_proj(attn_output)
+        output, _ = self.o_proj(attn_output, async_reduce=ASYNC_AR)
         return output
 
     def forward_fp8(self, positions, xq, xs, forward_batch: ForwardBatch, out_dtype, defer: bool = False):
@@ -136,13 +147,13 @@ class LlamaAttention(torch.nn.Module):
             a_s = torch.empty((a2.shape[0], 1), dtype=torch.float32, device=a2.device)
             ops.sgl_per_token_quant_fp8(a2, aq, a_s)
         else:
-            output, _ = self.o_proj(attn_output)
+            output, _ = self.o_proj(attn_output, async_reduce=ASYNC_AR)
             return output
         if defer:  # leave the o_proj epilogue to post_attention_layernorm
             part = self.o_proj.forward_prequantized_partials(aq, a_s, out_dtype)
             if part is not None:
                 return part
-        output, _ = self.o_proj.forward_prequantized(aq, a_s, out_dtype)
+        output, _ = self.o_proj.forward_prequantized(aq, a_s, out_dtype, async_reduce=ASYNC_AR)
         return output
 
 
@@ -155,13 +166,14 @@ class LlamaDecoderLayer(torch.nn.Module):
         self.post_attention_layernorm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps, dtype)
 
     def forward(self, positions, hidden_states, forward_batch, residual):
+        hidden_states = _arrived(hidden_states)  # the previous layer's down_proj all-reduce
         if residual is None:
             residual = hidden_states
             hidden_states = self.input_layernorm(hidden_states)
         else:
             hidden_states, residual = self.input_layernorm(hidden_states, residual)
         hidden_states = self.self_attn(positions, hidden_states, forward_batch)
-        hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
+        hidden_states, residual = self.post_attention_layernorm(_arrived(hidden_states), residual)
         hidden_states = self.mlp(hidden_states)
         return hidden_states, residual
 
@@ -170,11 +182,13 @@ class LlamaDecoderLayer(torch.nn.Module):
         directly, so no standalone quant kernel runs before qkv / gate_up / down.  `hidden_states` may be an
         ops.GemmPartials left by the previous layer's down_proj (defer=True)."""
         def norm_quant(norm, h, res):
+            h = _arrived(h)  # a row-parallel GEMM's all-reduce still running on the side stream
             if isinstance(h, ops.GemmPartials):  # the producer GEMM left its epilogue to this kernel
                 return ops.rmsnorm_quant_fp8_from_partials(h, res, norm.weight.data, norm.variance_epsilon)
             q, s_, _ = ops.rmsnorm_quant_fp8(h, norm.weight.data, norm.variance_epsilon, residual=res)
             return q, s_
 
+        hidden_states = _arrived(hidden_states)
         dt = residual.dtype if residual is not None else hidden_states.dtype
         if residual is None:
             residual = hidden_states.clone()
@@ -269,6 +283,7 @@ class LlamaForCausalLM(torch.nn.Module):
                 hidden_states, residual = layer.forward_fp8(positions, hidden_states, forward_batch, residual, defer)
             else:
                 hidden_states, residual = layer(positions, hidden_states, forward_batch, residual)
+        hidden_states = _arrived(hidden_states)
         if isinstance(hidden_states, ops.GemmPartials):
             hidden_states = hidden_states.finalize()
         if forward_batch.forward_mode.is_extend() and forward_batch.extend_seq_lens is not None:

@@ -1,6 +1,9 @@
 """GPU: the P2P all-reduce kernel with 2 and 4 ranks sharing the ONE GPU of the box (IPC handles between
 processes, same protocol as across GPUs; RCCL itself refuses duplicate devices so gloo carries the handle
-exchange).  Integer-valued payloads: the result must be exact (test_custom_allreduce.py:118-146)."""
+exchange).  Integer-valued payloads: the result must be exact (test_custom_allreduce.py:118-146).
+The 6- and 8-rank protocol runs with all ranks inside this one process (the box admits at most six processes on its
+GPU): the ranks' communicators are wired by pointer (CustomAllreduce.connect_local) and their kernels run concurrently
+on one stream each.  A missing peer must fail closed: NaN output, sticky status, the next call raises."""
 import os
 import socket
 
@@ -64,6 +67,28 @@ def _worker(rank, world, port, q):
             graph.replay()
             torch.cuda.synchronize()
             assert torch.all(y == float(sum(r + 1 + k for r in range(world)))), k
+        # side-stream form (GroupCoordinator.all_reduce_async), eager and inside a captured graph: fork at the call,
+        # join at wait(); the result must be the same tensor values as the in-stream call
+        x2 = (torch.arange(1 << 14, device=dev, dtype=torch.float32) % 7 + rank).to(torch.bfloat16)
+        want = sum(((torch.arange(1 << 14, dtype=torch.float32) % 7 + r).to(torch.bfloat16)).float() for r in range(world))
+        h = tp.all_reduce_async(x2)
+        assert torch.equal(h.wait().float().cpu(), want)
+        y2 = torch.empty_like(x2)
+        dist.barrier()
+        graph2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph2):
+            hh = tp.all_reduce_async(x2)
+            z = x2 * 2           # main-stream work between the fork and the join
+            y2.copy_(hh.wait())
+            y2.add_(z)
+        for k in range(2):
+            dist.barrier()
+            graph2.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(y2.float().cpu(), (want + 2 * x2.float().cpu()).to(torch.bfloat16).float()), k
+        tp.stub_all_reduce = True   # measurement stub: identity, also for the async form
+        assert tp.all_reduce_async(x2).wait() is x2
+        tp.stub_all_reduce = False
         assert not ca.timed_out()
         dist.barrier()
         ca.close()
@@ -87,3 +112,78 @@ def test_p2p_all_reduce_shared_gpu(world):
         p.join(30)
     for rank, msg in res:
         assert msg == "ok", f"rank {rank}: {msg}"
+
+
+def _local_ranks_worker(world, q):
+    # one hardware queue per rank's stream: streams that share a queue would run their kernels one after the other
+    # and the ranks could never meet at the flag barriers (read by the HIP runtime when it initialises)
+    os.environ["GPU_MAX_HW_QUEUES"] = "16"
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        from sglang_npu_amd.distributed import CustomAllreduce
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        comms = CustomAllreduce.connect_local(world, dev, max_size=4 * 1024 * 1024)
+        streams = [torch.cuda.Stream(device=dev) for _ in range(world)]
+        for dt in (torch.bfloat16, torch.float32):
+            for nbytes in (512, 65536, 262144 + 16 * world, 1 << 20, (1 << 21) + 4096):   # one-shot and two-shot
+                n = nbytes // torch.tensor([], dtype=dt).element_size()
+                g = torch.Generator().manual_seed(n % 991)
+                parts = [torch.randint(-3, 4, (n,), generator=g).to(dt).to(dev) for _ in range(world)]
+                ref = sum(p.float() for p in parts).to(dt)
+                for rep in range(2):             # both halves of the double buffer
+                    torch.cuda.synchronize()
+                    outs = []
+                    for r in range(world):       # every rank's kernel on its own stream: they meet at the flag barriers
+                        with torch.cuda.stream(streams[r]):
+                            outs.append(comms[r].custom_all_reduce(parts[r]))
+                    torch.cuda.synchronize()
+                    for r in range(world):
+                        assert torch.equal(outs[r], ref), (dt, nbytes, r, rep)
+        assert not any(c.timed_out() for c in comms)
+        for c in comms:
+            c.close()
+        q.put("ok")
+    except Exception:
+        import traceback
+        q.put(traceback.format_exc())
+
+
+@pytest.mark.parametrize("world", [6, 8])
+@pytest.mark.timeout(300)
+def test_p2p_all_reduce_six_and_eight_ranks_in_one_process(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_local_ranks_worker, args=(world, q))
+    p.start()
+    msg = q.get(timeout=240)
+    p.join(30)
+    assert msg == "ok", msg
+
+
+def test_p2p_all_reduce_missing_peer_fails_closed():
+    """Rank 1 never launches: rank 0's bounded wait runs out, its output is NaN (not a sum of whatever the buffers
+    held), the status word is visible to the host without a device sync, and the next call raises."""
+    from sglang_npu_amd import _lib
+    from sglang_npu_amd.distributed import CustomAllreduce, GroupCoordinator
+    import ctypes
+    dev = torch.device("cuda", 0)
+    lib = _lib.lib()
+    comms = CustomAllreduce.connect_local(2, dev, max_size=1 << 20)
+    _lib.check(lib.sgl_mi355_ar_set_spin_limit(ctypes.c_int64(20000)))
+    try:
+        x = torch.ones(4096, device=dev, dtype=torch.bfloat16)
+        out = comms[0].custom_all_reduce(x)
+        torch.cuda.synchronize()
+        assert bool(torch.isnan(out.float()).all()), "a timed-out all-reduce must not return a partial sum"
+        assert comms[0].timed_out() and not comms[1].timed_out()
+        tp = GroupCoordinator(None, 0, 2, dev)
+        tp.ca_comm = comms[0]
+        with pytest.raises(RuntimeError, match="did not reach the barrier"):
+            tp.all_reduce(x)
+        assert comms[0].disabled
+    finally:
+        _lib.check(lib.sgl_mi355_ar_set_spin_limit(ctypes.c_int64(1 << 27)))
+        for c in comms:
+            c.close()

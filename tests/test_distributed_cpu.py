@@ -33,6 +33,12 @@ def _worker(rank, world, port, q):
                 assert torch.equal(out, ref), (n, dt)
                 h = tp.all_reduce_async(x.clone())
                 assert torch.equal(h.wait(), ref)
+        # the measurement stub turns both forms into identities; the row-parallel layer's async form on CPU tensors is
+        # the plain in-stream all-reduce (there is no side stream to fork to)
+        tp.stub_all_reduce = True
+        xs = torch.arange(4.0)
+        assert tp.all_reduce(xs) is xs and tp.all_reduce_async(xs).wait() is xs
+        tp.stub_all_reduce = False
         g = D.tensor_model_parallel_all_gather(torch.full((3, 2), float(rank)), dim=-1)
         assert g.shape == (3, 2 * world) and torch.equal(g[:, 2 * rank], torch.full((3,), float(rank)))
         # row-parallel (K split + all-reduce) o column-parallel (N split) == the unsharded product
@@ -55,6 +61,8 @@ def _worker(rank, world, port, q):
         row.weight.weight_loader(row.weight, w2[:, perm].contiguous())
         y, _ = col(x)
         z, _ = row(y)
+        z2, _ = row(y, async_reduce=True)
+        assert torch.equal(z2, z)
         ref = (x @ w1.t()) @ w2.t()
         torch.testing.assert_close(z, ref, rtol=1e-4, atol=1e-4)
         qkv = QKVParallelLinear(64, 16, 8, 1, params_dtype=torch.float32)  # fewer KV heads than ranks -> replicated
