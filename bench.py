@@ -18,8 +18,16 @@ random-permutation page table (worst case for HBM), context length CTX per reque
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (paged decode attention):
 achieved = algorithmic bytes per launch / its average launch duration, measured with HIP events
 around every launch of it in an instrumented (eager) pass over the same K steps.
+`roofline_gemm` = the four decode GEMMs at M = bs (HBM fraction) and at M = 4096 (MFMA fraction), event-timed
+in this run over the model's own per-layer weights.
+`value` is the fused call order (`--call-order fused`: norm+quant / RoPE+KV-write / SiLU+quant producers, GEMM
+epilogues inside their consumers); `dropin_ms_per_step` is the SAME model driven in the reference's call order
+(RMSNorm -> LinearMethodBase.apply [quant + GEMM] -> RoPE -> AttentionBackend.forward(save_kv_cache=True) -> ...,
+models/llama.py:94-98,186-191,245-268), i.e. what an untouched SGLang model file gets from the drop-in classes.
 `cpu_baseline` = the CPU oracle (a port of the reference's CPU algorithm, oracle/) timed on the
-host cores on a bounded sample (1 of the 32 layers' hot path), scaled to the full step.
+host cores on a bounded sample (1 of the 32 layers' hot path, 2 warm-ups + median of 7), scaled to the full step;
+`reference_cpu_container` quotes the compiled reference's own timing in the build container
+(tools/time_reference_cpu.py -> profiles/r02_reference_cpu_container.json).
 """
 from __future__ import annotations
 
@@ -34,6 +42,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PMC_SUMMARY = "r01_decode_pmc_summary.json"  # refreshed per round when the kernel changes
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 
 
@@ -52,6 +61,9 @@ def parse():
     ap.add_argument("--emulate-tp", type=int, default=0,
                     help="debug only: run ONE rank's share of a TP=N step on this GPU with the all-reduce stubbed to "
                          "identity (per-rank kernel rehearsal on a 1-GPU box; invalidates the number)")
+    ap.add_argument("--call-order", default="fused", choices=["fused", "reference"],
+                    help="which call order `value` reports: the backend's fused producers (default) or the reference's "
+                         "unfused operator order; the other one is reported beside it")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -234,24 +246,119 @@ def cpu_baseline(cfg, B, ctx, n_layers_full):
     o = torch.zeros(B, Hq, D, dtype=torch.bfloat16)
     logits = torch.zeros(B, Hq, 8, D + 1)
     rpi, seq = torch.arange(B), torch.full((B,), ctx)
-    t0 = time.perf_counter()
-    oracle.decode_attention(q, kb, vb, o, None, None, None, logits, r2t, rpi, seq, D ** -0.5, 0.0, lib=lib)
-    t_attn = time.perf_counter() - t0
-    t_lin = 0.0
+    budget_end = time.perf_counter() + 40.0
+
+    def med(fn, warm=2, reps=7):
+        """2 warm-ups, then the median of up to 7 runs (fewer if the 40 s budget of the whole baseline runs out)."""
+        for _ in range(warm):
+            fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+            if time.perf_counter() > budget_end and len(ts) >= 3:
+                break
+        ts.sort()
+        return ts[len(ts) // 2], len(ts)
+
+    t_attn, n_attn = med(lambda: oracle.decode_attention(q, kb, vb, o, None, None, None, logits, r2t, rpi, seq,
+                                                         D ** -0.5, 0.0, lib=lib))
+    t_lin, n_lin = 0.0, 7
     for (K, N) in [(H, (Hq + 2 * Hkv) * D), (Hq * D, H), (H, 2 * I), (I, H)]:
         x = torch.randn(B, K, generator=g).bfloat16()
         w = ((torch.rand(N, K, generator=g) - 0.5) * 8).to(torch.float8_e4m3fn)
         sb = torch.rand(N, generator=g) * 1e-2
-        t0 = time.perf_counter()
         xq = torch.empty(B, K, dtype=torch.uint8)
         xs = torch.empty(B)
-        oracle.per_token_quant_fp8(x, xq, xs, lib=lib)
-        oracle.fp8_scaled_mm(xq.view(torch.float8_e4m3fn), w.t(), xs, sb, torch.bfloat16, lib=lib)
-        t_lin += time.perf_counter() - t0
+
+        def lin():
+            oracle.per_token_quant_fp8(x, xq, xs, lib=lib)
+            oracle.fp8_scaled_mm(xq.view(torch.float8_e4m3fn), w.t(), xs, sb, torch.bfloat16, lib=lib)
+
+        t, n = med(lin)
+        t_lin += t
+        n_lin = min(n_lin, n)
     t_layer = t_attn + t_lin
     return {"value": round(B / (t_layer * n_layers_full), 3), "unit": "tokens/s", "cores": cores, "kind": "port",
-            "sample": f"1 of {n_layers_full} layers (decode attention {t_attn * 1e3:.0f} ms + 4 quant-GEMMs "
-                      f"{t_lin * 1e3:.0f} ms at bs={B}, ctx={ctx}), scaled x{n_layers_full}; norms/LM head not counted"}
+            "sample": f"1 of {n_layers_full} layers (decode attention {t_attn * 1e3:.1f} ms + 4 quant-GEMMs "
+                      f"{t_lin * 1e3:.1f} ms at bs={B}, ctx={ctx}; 2 warm-ups, median of {min(n_attn, n_lin)}), "
+                      f"scaled x{n_layers_full}; norms/LM head not counted"}
+
+
+def reference_cpu_container():
+    """The compiled reference's own CPU timing, taken in the build container (the reference cannot travel)."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r02_reference_cpu_container.json")))
+        p = [x for x in d["points"] if x["op"] == "decode_attention_cpu" and x["S"] == 2048][0]
+        return {"op": "decode_attention_cpu (sgl-kernel/csrc/cpu/decode.cpp, compiled from /root/reference)",
+                "shape": f"bs={p['B']} ctx={p['S']} {p['Hq']}/{p['Hkv']}/{p['D']} bf16", "ms": p["ms"],
+                "kv_GBps": p["kv_GBps"], "cores": d["cores"], "cpu": d["cpu"], "method": d["method"],
+                "source": "tools/time_reference_cpu.py -> profiles/r02_reference_cpu_container.json (build container)"}
+    except (OSError, KeyError, IndexError, ValueError):
+        return None
+
+
+def time_decode_gemms(net, cfg, B, device, tp):
+    """`roofline_gemm`: the four FP8 decode GEMMs of a layer, each as ONE captured HIP graph that runs it once per
+    layer on that layer's own weights (32 different weight matrices: nothing is served from L2 / Infinity Cache the
+    way a loop over one matrix would be), timed with HIP events over 5 replays; M = B rows for the HBM fraction
+    (bytes = M*K + K*N + 2*M*N + 4*(M+N)) and M = 4096 for the MFMA fraction (2*M*N*K flops
+    against the 5 PFLOP/s dense FP8 peak)."""
+    from sglang_npu_amd import ops
+    layers = list(net.layers)
+    if not hasattr(layers[0].mlp.gate_up_proj, "weight") or layers[0].mlp.gate_up_proj.weight.dtype != torch.float8_e4m3fn:
+        return None
+    names = [("qkv", lambda l: l.self_attn.qkv_proj), ("o", lambda l: l.self_attn.o_proj),
+             ("gate_up", lambda l: l.mlp.gate_up_proj), ("down", lambda l: l.mlp.down_proj)]
+    out = {"unit_hbm": "GB/s", "peak_hbm": HBM_PEAK_GBPS, "unit_mfma": "TFLOP/s", "peak_mfma": 5000.0, "shapes": []}
+    g = torch.Generator(device=device).manual_seed(7)
+    for name, pick in names:
+        lins = [pick(l) for l in layers]
+        K, N = lins[0].weight.shape  # stored K-major [K, N]
+        row = {"name": name, "K": int(K), "N": int(N)}
+        for M, key in ((B, "decode"), (4096, "prefill")):
+            a = ((torch.rand(M, K, device=device, generator=g) - 0.5) * 8).to(torch.float8_e4m3fn)
+            sa = torch.rand(M, 1, device=device, generator=g) * 1e-2 + 1e-3
+
+            def run():
+                for lin in lins:
+                    ops.fp8_scaled_mm(a, lin.weight, sa, lin.weight_scale, torch.bfloat16)
+
+            s = torch.cuda.Stream(device=device)
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                run()
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                run()
+            graph.replay()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(5):
+                st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                st.record()
+                graph.replay()
+                en.record()
+                torch.cuda.synchronize()
+                ts.append(st.elapsed_time(en) * 1e3 / len(lins))
+            ts.sort()
+            us = ts[len(ts) // 2]
+            nbytes = M * K + K * N + 2 * M * N + 4 * (M + N)
+            flops = 2.0 * M * N * K
+            row[key] = {"M": M, "us": round(us, 2), "GBps": round(nbytes / us / 1e3, 1),
+                        "frac_hbm": round(nbytes / us / 1e3 / HBM_PEAK_GBPS, 4),
+                        "TFLOPs": round(flops / us / 1e6, 1), "frac_mfma": round(flops / us / 1e6 / 5000.0, 4)}
+            del graph
+        out["shapes"].append(row)
+    dec_bytes = sum(r["decode"]["M"] * r["K"] + r["K"] * r["N"] + 2 * r["decode"]["M"] * r["N"] for r in out["shapes"])
+    dec_us = sum(r["decode"]["us"] for r in out["shapes"])
+    out["decode_all_four"] = {"us": round(dec_us, 2), "frac_hbm": round(dec_bytes / dec_us / 1e3 / HBM_PEAK_GBPS, 4)}
+    out["note"] = ("event-timed in this run: one HIP graph per shape with one call per layer on that layer's weights, "
+                   "median of 5 replays / layers; includes split-K finalize launches where the kernel uses them")
+    return out
 
 
 def main():
@@ -297,28 +404,65 @@ def main():
 
     net, cfg, runner, backend, max_len = build(args, device, tp)
     loop = DecodeLoop(net, runner, backend, args.batch, args.ctx, device)
-    if use_graph:
-        loop.capture()
+    can_fuse = net.fuse_quant          # only the FP8 config has fused producers
+    want_fused = can_fuse and args.call_order == "fused"
 
     def barrier():
         if dist_on:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        loop.step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loop.step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist_on:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    def max_over_ranks(x):
+        if not dist_on:
+            return x
+        t = torch.tensor([x], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+        return float(t.item())
+
+    def set_call_order(fused):
+        """Switch the model between the fused producers and the reference's operator order, rewind the requests to
+        ctx (the page table has room for ctx + steps + warmup + 8 positions only) and re-capture the step."""
+        net.fuse_quant = bool(fused and can_fuse)
+        loop.seq_lens.fill_(args.ctx)
+        loop._refresh()
+        if use_graph:
+            loop.capture()
+
+    def timed(n_warm, n_steps):
+        for _ in range(n_warm):
+            loop.step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            loop.step()
+        barrier()
+        return max_over_ranks(time.perf_counter() - t0)
+
+    # ---- the contract's timed region: W warm-up steps, then exactly K steps between barriers
+    set_call_order(want_fused)
+    elapsed = timed(args.warmup, args.steps)
     ms_per_step = elapsed / args.steps * 1e3
     value = args.batch * args.steps / elapsed
+
+    # ---- the other call order, and a device-synchronised per-step median (bench_one_batch.py:380-424 shape)
+    other = None
+    if can_fuse:
+        n_other = min(args.steps, 10)
+        set_call_order(not want_fused)
+        other = timed(2, n_other) / n_other * 1e3
+        set_call_order(want_fused)
+    fused_ms, dropin_ms = (ms_per_step, other) if want_fused else (other, ms_per_step)
+    sync_ts = []
+    for _ in range(min(args.steps, 10) + 2):
+        barrier()
+        t0 = time.perf_counter()
+        loop.step()
+        torch.cuda.synchronize()
+        sync_ts.append((time.perf_counter() - t0) * 1e3)
+    sync_ts = sorted(sync_ts[2:])
+    median_synced_ms = max_over_ranks(sync_ts[len(sync_ts) // 2])
+    loop.seq_lens.fill_(args.ctx + args.warmup + args.steps)   # where the instrumented passes below expect to start
+    loop._refresh()
 
     # ---- all-reduce overhead (N > 1): the same step with the TP all-reduce stubbed to identity, outside the timed
     # region above (SURVEY 8d config 5: (t_with - t_without) / t_with)
@@ -368,10 +512,10 @@ def main():
     traffic, traffic_src = None, None
     try:
         pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                                          "r01_decode_pmc_summary.json")))
+                                          PMC_SUMMARY)))
         if tp == 1 and args.batch == 64 and (hq, hkv, d) == (32, 8, 128) and kv_esz == 2:
             traffic = int(alg_bytes * pmc["traffic_over_algorithmic"])
-            traffic_src = ("profiles/r01_decode_pmc_summary.json: FETCH_SIZE x2 (gfx950) + WRITE_SIZE, separate --pmc "
+            traffic_src = (f"profiles/{PMC_SUMMARY}: FETCH_SIZE x2 (gfx950) + WRITE_SIZE, separate --pmc "
                            f"passes, ratio {pmc['traffic_over_algorithmic']} to algorithmic bytes at bs=64 ctx=2048")
     except (OSError, KeyError, ValueError):
         pass
@@ -387,6 +531,14 @@ def main():
                    "global_batch": args.batch, "seq_len": args.ctx, "layers": len(net.layers),
                    "parallelism": f"tp{tp}" + (" (ONE rank emulated on one GPU, collectives stubbed: not a job number)"
                                                if args.emulate_tp > 1 and not dist_on else "")},
+        "call_order": "fused" if want_fused else "reference",
+        "fused_ms_per_step": round(fused_ms, 4) if fused_ms is not None else None,
+        "dropin_ms_per_step": round(dropin_ms, 4) if dropin_ms is not None else None,
+        "dropin_tokens_per_s": round(args.batch / dropin_ms * 1e3, 1) if dropin_ms else None,
+        "dropin_note": "the same model in the reference's operator order (RMSNorm -> apply() [per-token quant + "
+                       "fp8_scaled_mm] -> RoPE -> attn_backend.forward(save_kv_cache=True) -> ... ), what SGLang's "
+                       "untouched models/llama.py gets from the drop-in classes; min(steps,10) steps after 2 warm-ups",
+        "median_step_ms_synced": round(median_synced_ms, 4),
         "roofline": {"bound": "hbm", "kernel": "decode_mfma_pair_kernel / decode_mfma_kernel (paged decode attention)",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
@@ -396,6 +548,10 @@ def main():
     }
     if ar_info is not None:
         out["allreduce"] = ar_info
+    try:
+        out["roofline_gemm"] = time_decode_gemms(net, cfg, args.batch, device, tp)
+    except Exception as e:  # a diagnostic: never take the headline down with it
+        out["roofline_gemm"] = {"error": f"{type(e).__name__}: {e}"}
     try:
         ttft_ms, ttft_len = time_ttft(net, runner, backend, device)
         if dist_on:
@@ -412,6 +568,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, args.batch, args.ctx, cfg.num_hidden_layers)
         except Exception as e:  # the baseline must never take the GPU number down with it
             out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        out["reference_cpu_container"] = reference_cpu_container()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist_on:

@@ -507,22 +507,31 @@ void orc_fp8_scaled_mm(
     int64_t a_strideM, int64_t b_strideN, int out_dtype, int bias_after_round) {
   float lut[256];
   for (int i = 0; i < 256; ++i) lut[i] = e4m3_to_f32((uint8_t)i);
+  /* Loop order: A is expanded to fp32 once, the work is split over the N weight rows (each expanded once and
+   * reused by all M activation rows), the inner dot runs 8 fp32 lanes over k that the compiler vectorises.  The
+   * summation order of every (m, n) element -- 8 strided partial sums, the fixed tree, the scalar tail -- does not
+   * depend on the loop order, so results are the same bits as a row-by-row evaluation. */
+  float* af = (float*)malloc(sizeof(float) * (size_t)M * (size_t)K);
+#pragma omp parallel for schedule(static)
+  for (int64_t m = 0; m < M; ++m)
+    for (int64_t k = 0; k < K; ++k) af[m * K + k] = lut[a[m * a_strideM + k]];
 #pragma omp parallel
   {
-    float* af = (float*)malloc(sizeof(float) * (size_t)K);
-#pragma omp for schedule(dynamic, 1)
-    for (int64_t m = 0; m < M; ++m) {
-      for (int64_t k = 0; k < K; ++k) af[k] = lut[a[m * a_strideM + k]];
-      for (int64_t n = 0; n < N; ++n) {
-        const uint8_t* bn = b + n * b_strideN;
+    float* bf = (float*)malloc(sizeof(float) * (size_t)K);
+#pragma omp for schedule(dynamic, 16)
+    for (int64_t n = 0; n < N; ++n) {
+      const uint8_t* bn = b + n * b_strideN;
+      for (int64_t k = 0; k < K; ++k) bf[k] = lut[bn[k]];
+      for (int64_t m = 0; m < M; ++m) {
+        const float* am = af + m * K;
         /* fp32 accumulation in 8 lanes then a tree: products of two e4m3 values are
          * exact in fp32, so only the summation order differs between implementations */
         float acc8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         int64_t k = 0;
         for (; k + 8 <= K; k += 8)
-          for (int j = 0; j < 8; ++j) acc8[j] += af[k + j] * lut[bn[k + j]];
+          for (int j = 0; j < 8; ++j) acc8[j] += am[k + j] * bf[k + j];
         float acc = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
-        for (; k < K; ++k) acc += af[k] * lut[bn[k]];
+        for (; k < K; ++k) acc += am[k] * bf[k];
         float v = acc * scale_b[n] * scale_a[m];
         if (bias) {
           if (bias_after_round) {
@@ -534,8 +543,9 @@ void orc_fp8_scaled_mm(
         out[m * N + n] = f32_to_h(v, out_dtype);
       }
     }
-    free(af);
+    free(bf);
   }
+  free(af);
 }
 
 /* ------------------------------------------------------------------ AWQ INT4

@@ -238,8 +238,10 @@ __global__ __launch_bounds__(NT) void silu_mul_kernel(
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float af = Hh::to_f32(a[j]);
-        const float s = af / (1.0f + __expf(-af));
-        o[j] = Hh::from_f32(s * Hh::to_f32(b[j]));  // fp32 math, one rounding (activation.cu)
+        // silu() returns the 16-bit type (activation.cu:56-60) and the product is taken in it (act_and_mul_kernel;
+        // SiluAndMul.forward_native, activation.py:59-62, rounds the same way): two roundings, like the reference
+        const float s = Hh::to_f32(Hh::from_f32(af / (1.0f + __expf(-af))));
+        o[j] = Hh::from_f32(s * Hh::to_f32(b[j]));
         v[i][j] = Hh::to_f32(o[j]);
         amax = fmaxf(amax, fabsf(v[i][j]));
       }

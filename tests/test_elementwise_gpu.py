@@ -125,9 +125,9 @@ def _ulp16(a, b):
     return (a.cpu().contiguous().view(torch.int16).int() - b.contiguous().view(torch.int16).int()).abs()
 
 
-def _one_ulp_rare(got, exp, what, frac=5e-3):
+def _one_ulp_rare(got, exp, what, frac=5e-3, max_ulp=1):
     d = _ulp16(got, exp)
-    assert int(d.max()) <= 1, f"{what}: {int(d.max())} ulp"
+    assert int(d.max()) <= max_ulp, f"{what}: {int(d.max())} ulp"
     assert (d > 0).float().mean().item() < frac, f"{what}: {(d > 0).float().mean().item():.2e} of elements differ"
 
 
@@ -148,13 +148,14 @@ def test_rmsnorm_vs_reference_fixture():
 
 
 def test_silu_and_mul_vs_reference_fixture():
-    """SiluAndMul.forward_native rounds silu(x) to the 16-bit dtype before the product; the kernel does the same, so only
-    the last bit of expf can move a result: at most one ulp, rarely."""
+    """SiluAndMul.forward_native (and the reference's CUDA kernel, activation.cu:56-60) round silu(x) to the 16-bit dtype
+    before the product; the kernel does the same, so only the last bit of expf can move silu(x) across a rounding
+    boundary -- rarely (< 0.5 % of elements), and a one-ulp step of silu(x) is at most two ulps of the product."""
     z = np.load("tests/golden/silu_and_mul.npz")
     for i in range(int(z["n"])):
         dtype = z[f"dtype{i}"].item().decode()
         y = ops.silu_and_mul(_z16(z, f"x{i}", dtype).to(DEV))
-        _one_ulp_rare(y, _z16(z, f"y{i}", dtype), f"silu_and_mul case {i}")
+        _one_ulp_rare(y, _z16(z, f"y{i}", dtype), f"silu_and_mul case {i}", max_ulp=2)
         assert int(_ulp16(y, _z16(z, f"y_cpu{i}", dtype)).max()) <= 2
 
 
