@@ -45,14 +45,18 @@ def _compile(src, obj, extra):
     return src, r.returncode, r.stdout + r.stderr
 
 
-def build(force: bool = False, jobs: int = 4, verbose: bool = True, extra=None) -> str:
-    os.makedirs(LIB_DIR, exist_ok=True)
-    os.makedirs(OBJ_DIR, exist_ok=True)
+def build(force: bool = False, jobs: int = 4, verbose: bool = True, extra=None, variant: str = "") -> str:
+    """variant: build a second copy of the library with `extra` compiler flags (e.g. -DSGLM_KV_DMA_POLICY=1) into
+    lib/variants/libsgl_mi355_<variant>.so for same-box A/B runs; the default build is untouched."""
+    lib_path = os.path.join(LIB_DIR, "variants", f"libsgl_mi355_{variant}.so") if variant else LIB
+    obj_dir = os.path.join(OBJ_DIR, "variant_" + variant) if variant else OBJ_DIR
+    os.makedirs(os.path.dirname(lib_path), exist_ok=True)
+    os.makedirs(obj_dir, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     deps = _deps()
     todo, objs = [], []
     for s in srcs:
-        o = os.path.join(OBJ_DIR, os.path.basename(s)[:-4] + ".o")
+        o = os.path.join(obj_dir, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
         if force or _stale(o, [s] + deps):
             todo.append((s, o))
@@ -65,19 +69,21 @@ def build(force: bool = False, jobs: int = 4, verbose: bool = True, extra=None) 
                     raise RuntimeError(f"hipcc failed on {src}:\n{out}")
                 if verbose:
                     print(f"[build_ext] compiled {os.path.basename(src)}")
-    if force or todo or _stale(LIB, objs):
-        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+    if force or todo or _stale(lib_path, objs):
+        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib_path] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
         if verbose:
-            print(f"[build_ext] linked {LIB}")
-    return LIB
+            print(f"[build_ext] linked {lib_path}")
+    return lib_path
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--jobs", type=int, default=4)
+    ap.add_argument("--variant", default="", help="name of an A/B variant build (lib/variants/)")
+    ap.add_argument("--flag", action="append", default=[], help="extra compiler flag of the variant, e.g. -DSGLM_X=1")
     a = ap.parse_args()
-    print(build(force=a.force, jobs=a.jobs))
+    print(build(force=a.force, jobs=a.jobs, extra=a.flag, variant=a.variant))

@@ -43,6 +43,21 @@ constexpr int kMaxIdx = 2048;    // page-table entries staged in LDS per pass (x
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 
+// K/V tile pieces go in with the NON-TEMPORAL cache policy: every K/V row is read once per step by one CU, and without
+// the hint the stream (537 MB per launch at bs=64, ctx 2048) churns L2 and the Infinity Cache.  Same-box A/B
+// (tools/ab_variants.py, bs=64 32/8/128, random page table, S = 512 / 2048 / 4096): 30.2 / 98.5 / 185 us default policy
+// vs 28.3 / 88.4 / 170 us nt -- 5.47 -> 6.09 TB/s at S = 2048.  -DSGLM_KV_DMA_NT=0 builds the default-policy variant.
+#ifndef SGLM_KV_DMA_NT
+#define SGLM_KV_DMA_NT 1
+#endif
+__device__ __forceinline__ void kv_dma16(const void* gsrc, uint32_t lds_addr) {
+#if SGLM_KV_DMA_NT
+  lds_dma16_nt(gsrc, lds_addr);
+#else
+  lds_dma16(gsrc, lds_addr);
+#endif
+}
+
 struct DecodeArgs {
   const void* q;
   int64_t q_sb, q_sh;
@@ -249,7 +264,7 @@ __global__ __launch_bounds__(kWaves * 64) void decode_mfma_kernel(DecodeArgs a) 
           src_off[i] = ((lane % CH8) ^ swz8<D>(row)) * 16;
         }
 #pragma unroll
-        for (int i = 0; i < NI8; ++i) lds_dma16(gb + (int64_t)tok8[i] * rb + src_off[i], dst8 + i * 1024);
+        for (int i = 0; i < NI8; ++i) kv_dma16(gb + (int64_t)tok8[i] * rb + src_off[i], dst8 + i * 1024);
         return;
       }
       const uint32_t dst = __builtin_amdgcn_readfirstlane(
@@ -264,7 +279,7 @@ __global__ __launch_bounds__(kWaves * 64) void decode_mfma_kernel(DecodeArgs a) 
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
         const int c = swz_chunk<D>(dma_pos, i * ROWS_PER_DMA + dma_row);
-        lds_dma16(gb + (int64_t)tok[i] * rb + c * 16, dst + i * 1024);
+        kv_dma16(gb + (int64_t)tok[i] * rb + c * 16, dst + i * 1024);
       }
     };
 
@@ -680,7 +695,7 @@ __global__ __launch_bounds__(256) void decode_mfma_pair_kernel(DecodeArgs a, int
           src_off[i] = ((lane % CH8) ^ swz8<D>(row)) * 16;
         }
 #pragma unroll
-        for (int i = 0; i < NI8; ++i) lds_dma16(gb + (int64_t)tok8[i] * rb + src_off[i], dst8 + i * 1024);
+        for (int i = 0; i < NI8; ++i) kv_dma16(gb + (int64_t)tok8[i] * rb + src_off[i], dst8 + i * 1024);
       };
       auto wait_units = [&](int units) __attribute__((always_inline)) {
         switch (units) {
@@ -807,7 +822,7 @@ __global__ __launch_bounds__(256) void decode_mfma_pair_kernel(DecodeArgs a, int
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
         const int c = swz_chunk<D>(dma_pos, i * ROWS_PER_DMA + dma_row);
-        lds_dma16(gb + (int64_t)tok[i] * rb + c * 16, dst + i * 1024);
+        kv_dma16(gb + (int64_t)tok[i] * rb + c * 16, dst + i * 1024);
       }
     };
     if (nvt > 0) {

@@ -98,6 +98,22 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, uint32_t lds_addr) {
       : "memory");
 }
 
+// The same piece with the non-temporal cache policy: for bytes that ONE CU reads once (the KV stream of a decode
+// step): they should not displace what other kernels of the step keep in L2 / Infinity Cache.
+__device__ __forceinline__ void lds_dma16_nt(const void* gsrc, uint32_t lds_addr) {
+  lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off nt\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_addr)
+      : "memory");
+}
+
 __device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
   return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
 }

@@ -74,18 +74,22 @@ __device__ __forceinline__ typename Half16<DTYPE>::x8 gemm_row8(const PartialSrc
   using Hh = Half16<DTYPE>;
   float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const float* src = ps.partials + row * ps.N + col;
-  // four slices' loads in flight at a time (a plain slice loop serialises one L2 round trip per slice); the sums
-  // still run in slice order, as in fp8_gemm_finalize_kernel
-  for (int s0 = 0; s0 < ps.num_slices; s0 += 4) {
-    f32x4 a[4], b[4];
+  // EIGHT slices' loads in flight at a time: the decode GEMMs leave 6-8 slices, so the whole reduction is one memory
+  // round trip (a plain slice loop serialises one per slice; four at a time made it two).  The sums still run in
+  // slice order, as in fp8_gemm_finalize_kernel.
+  constexpr int U = 8;
+  const float sa = ps.sa[row];
+  const f32x4 sb0 = *reinterpret_cast<const f32x4*>(ps.sb + col), sb1 = *reinterpret_cast<const f32x4*>(ps.sb + col + 4);
+  for (int s0 = 0; s0 < ps.num_slices; s0 += U) {
+    f32x4 a[U], b[U];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int si = s0 + u < ps.num_slices ? s0 + u : ps.num_slices - 1;
       a[u] = *reinterpret_cast<const f32x4*>(src + si * ps.slice_stride);
       b[u] = *reinterpret_cast<const f32x4*>(src + si * ps.slice_stride + 4);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < U; ++u)
       if (s0 + u < ps.num_slices) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -94,12 +98,11 @@ __device__ __forceinline__ typename Half16<DTYPE>::x8 gemm_row8(const PartialSrc
         }
       }
   }
-  const float sa = ps.sa[row];
   typename Hh::x8 o;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
 #pragma clang fp contract(off)  // explicit roundings (no fma contraction): must match fp8_gemm_finalize_kernel bit for bit
-    float r = (v[j] * ps.sb[col + j]) * sa;
+    float r = (v[j] * (j < 4 ? sb0[j] : sb1[j - 4])) * sa;
     if (ps.bias) r = r + Hh::to_f32(reinterpret_cast<const typename Hh::T*>(ps.bias)[col + j]);
     o[j] = Hh::from_f32(r);
   }
@@ -110,12 +113,12 @@ __device__ __forceinline__ typename Half16<DTYPE>::T gemm_elem(const PartialSrc&
   using Hh = Half16<DTYPE>;
   float v = 0.f;
   const float* src = ps.partials + row * ps.N + col;
-  for (int s0 = 0; s0 < ps.num_slices; s0 += 4) {
-    float a[4];
+  for (int s0 = 0; s0 < ps.num_slices; s0 += 8) {
+    float a[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) a[u] = src[(s0 + u < ps.num_slices ? s0 + u : ps.num_slices - 1) * ps.slice_stride];
+    for (int u = 0; u < 8; ++u) a[u] = src[(s0 + u < ps.num_slices ? s0 + u : ps.num_slices - 1) * ps.slice_stride];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < 8; ++u)
       if (s0 + u < ps.num_slices) v += a[u];
   }
   float r;
@@ -149,12 +152,14 @@ __global__ __launch_bounds__(NT) void rmsnorm_kernel(
   for (int i = 0; i < VPT; ++i) {
     const int vi = threadIdx.x + NT * i;
     if (vi < nv) {
+      // every load of the row is issued before the first use: weight, residual and (FROM_PARTIALS) all slices
+      wq[i] = reinterpret_cast<const x8*>(weight)[vi];
+      x8 rv;
+      if (residual) rv = reinterpret_cast<const x8*>(residual + row * H)[vi];
       x8 xv;
       if constexpr (FROM_PARTIALS) xv = gemm_row8<DTYPE>(ps, row, 8 * vi);
       else xv = reinterpret_cast<const x8*>(x + row * H)[vi];
-      wq[i] = reinterpret_cast<const x8*>(weight)[vi];
       if (residual) {
-        const x8 rv = reinterpret_cast<const x8*>(residual + row * H)[vi];
         x8 nr;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {

@@ -102,9 +102,17 @@ union Frag32 {  // 32 contiguous K bytes of one row = four MFMA operands
 // between only makes the count stricter, never wrong.  (With ordinary loads hipcc put a single vmcnt(0) at
 // the loop head and sank the refills to the loop end: no load/MFMA overlap inside a wave.)
 // Address = scalar base (saddr) + 32-bit per-lane offset: zero VALU per load.
+#ifndef SGLM_W_NT
+#define SGLM_W_NT 0
+#endif
 __device__ __forceinline__ void gload32_asm(Frag32& f, const uint8_t* sbase, uint32_t voff) {
+#if SGLM_W_NT
+  asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(f.x[0]) : "v"(voff), "s"(sbase) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:64 nt" : "=v"(f.x[1]) : "v"(voff), "s"(sbase) : "memory");
+#else
   asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(f.x[0]) : "v"(voff), "s"(sbase) : "memory");
   asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=v"(f.x[1]) : "v"(voff), "s"(sbase) : "memory");
+#endif
 }
 // (a non-temporal hint on these loads was measured: no difference on any decode shape, profiles/README.md)
 // End of a hand-scheduled loop: the tail refills are never consumed, so hipcc considers their destination

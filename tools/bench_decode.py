@@ -55,7 +55,13 @@ def run(B, Hq, Hkv, D, S, splits, layout, iters=20, dtype=torch.bfloat16, nlayer
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--headline", action="store_true", help="bs=64 32/8/128, S = 512 / 2048, random page table, one split")
     a = ap.parse_args()
+    if a.headline:
+        for S in (512, 2048, 4096):
+            ms, gbs = run(64, 32, 8, 128, S, 1, "random", iters=64, nlayers=8)
+            print(json.dumps(dict(S=S, us=round(ms * 1e3, 2), GBps=round(gbs, 1), frac=round(gbs / 8000, 4))), flush=True)
+        sys.exit(0)
     rows = []
     cfgs = [
         # B, Hq, Hkv, D, S
