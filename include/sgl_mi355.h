@@ -394,6 +394,28 @@ int sgl_mi355_rotary_embedding_set_kv_fp8kv(const int64_t* positions, void* quer
                                             void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Replaces: sgl_per_token_group_quant_fp8(Tensor input, Tensor output_q, Tensor output_s, int group_size, float eps,
+ *                                         float fp8_min, float fp8_max, bool scale_ue8m0) -> ()
+ *           -- sgl-kernel/csrc/common_extension.cc:116-119, csrc/gemm/per_token_group_quant_8bit.cu:15-215;
+ *           Python wrapper python/sgl_kernel/gemm.py:100-112; Triton twin fp8_kernel.py:115-155.
+ * input [num_tokens, hidden_dim] contiguous (dtype 0 bf16, 1 fp16, 2 fp32); output_q e4m3fn, same shape; output_s
+ * fp32, element (token, group) at token * s_stride_token + group * s_stride_group (row-major [T, K/G]: strides
+ * (K/G, 1); the reference's column-major form: (1, T_padded)).  Per group: absmax = max(eps, max|x|),
+ * scale = absmax / fp8_max, q = clamp(x / scale, fp8_min, fp8_max) rounded to nearest even.  scale_ue8m0 != 0
+ * (packed power-of-two scales) returns SGL_MI355_ERR_UNSUPPORTED. */
+int sgl_mi355_per_token_group_quant_fp8(const void* input, void* output_q, float* output_s, int64_t num_tokens,
+                                        int64_t hidden_dim, int64_t group_size, int64_t s_stride_token,
+                                        int64_t s_stride_group, float eps, float fp8_min, float fp8_max, int scale_ue8m0,
+                                        int dtype, void* stream);
+
+/* Replaces: sgl_per_tensor_quant_fp8(Tensor input, Tensor output_q, Tensor output_s, bool is_static) -> ()
+ *           -- common_extension.cc:126-127, csrc/gemm/per_tensor_quant_fp8.cu:9-120; wrapper gemm.py:129-137.
+ * is_static == 0: output_s[0] (zero-initialised by the caller, as the reference's callers do) receives
+ * max|x| / 448 by atomic max; then q = clamp(x * (1 / output_s[0]), -448, 448).  Any contiguous shape. */
+int sgl_mi355_per_tensor_quant_fp8(const void* input, void* output_q, float* output_s, int64_t num_elements,
+                                   int is_static, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * P2P all-reduce over IPC-mapped peer buffers (one process per GPU, <= 8 ranks of one node).
  * Replaces: the native half of CustomAllreduce -- init_custom_ar / allocate_meta_buffer /
  *           get_meta_buffer_ipc_handle / register_buffer / all_reduce_reg / dispose

@@ -193,6 +193,26 @@ def per_token_quant_fp8(input, output_q, output_s, lib=None):
     lib.orc_per_token_quant_fp8(_ptr(input), _ptr(output_q), _ptr(output_s), _I64(T), _I64(K), _I(_dt(input)))
 
 
+def _in_code(t):
+    return {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}[t.dtype]
+
+
+def per_token_group_quant_fp8(input, output_q, output_s, group_size, eps, fp8_min, fp8_max, lib=None):
+    """sgl_per_token_group_quant_fp8 with row-major scales (per_token_group_quant_8bit.cu:15-215)."""
+    lib = lib or load()
+    assert input.is_contiguous() and output_q.is_contiguous() and output_s.is_contiguous()
+    lib.orc_per_token_group_quant_fp8(_ptr(input), _ptr(output_q), _ptr(output_s), _I64(input.numel() // group_size),
+                                      _I64(group_size), _F(eps), _F(fp8_min), _F(fp8_max), _I(_in_code(input)))
+
+
+def per_tensor_quant_fp8(input, output_q, output_s, is_static, lib=None):
+    """sgl_per_tensor_quant_fp8 (per_tensor_quant_fp8.cu:90-120)."""
+    lib = lib or load()
+    assert input.is_contiguous() and output_q.is_contiguous() and output_s.numel() == 1
+    lib.orc_per_tensor_quant_fp8(_ptr(input), _ptr(output_q), _ptr(output_s), _I64(input.numel()),
+                                 _I(1 if is_static else 0), _I(_in_code(input)))
+
+
 def fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None, bias_after_round: bool = False, lib=None):
     """fp8_scaled_mm (fp8_gemm_kernel.cu:1071-1146).  mat_b is [K,N] with stride(0)==1."""
     lib = lib or load()

@@ -492,6 +492,48 @@ void orc_per_token_quant_fp8(const uint16_t* x, uint8_t* q, float* s, int64_t T,
   }
 }
 
+/* sgl_per_token_group_quant_fp8, sgl-kernel/csrc/gemm/per_token_group_quant_8bit.cu:15-137 (row-major scales):
+ *   absmax = max(eps, max|x|) per group; y_s = absmax / fp8_max; q = cast(clamp(x / y_s, fp8_min, fp8_max)).
+ * A true division, not a reciprocal multiply (:99).  x: dtype 0 bf16, 1 fp16, 2 fp32. */
+void orc_per_token_group_quant_fp8(const void* x, uint8_t* q, float* s, int64_t num_groups, int64_t group_size, float eps,
+                                   float fp8_min, float fp8_max, int dtype) {
+#pragma omp parallel for schedule(static)
+  for (int64_t g = 0; g < num_groups; ++g) {
+    float amax = eps;
+    for (int64_t i = 0; i < group_size; ++i) {
+      const int64_t e = g * group_size + i;
+      const float v = dtype == 2 ? ((const float*)x)[e] : h_to_f32(((const uint16_t*)x)[e], dtype);
+      amax = fmaxf(amax, fabsf(v));
+    }
+    const float y_s = amax / fp8_max;
+    s[g] = y_s;
+    for (int64_t i = 0; i < group_size; ++i) {
+      const int64_t e = g * group_size + i;
+      const float v = dtype == 2 ? ((const float*)x)[e] : h_to_f32(((const uint16_t*)x)[e], dtype);
+      q[e] = f32_to_e4m3(fminf(fmaxf(v / y_s, fp8_min), fp8_max));
+    }
+  }
+}
+
+/* sgl_per_tensor_quant_fp8, sgl-kernel/csrc/gemm/per_tensor_quant_fp8.cu:9-88: dynamic scale = max|x| / 448 (an
+ * atomic max into *s, which the caller zeroes), q = cast(clamp(x * (1 / scale), -448, 448)). */
+void orc_per_tensor_quant_fp8(const void* x, uint8_t* q, float* s, int64_t n, int is_static, int dtype) {
+  if (!is_static) {
+    float amax = 0.f;
+    for (int64_t e = 0; e < n; ++e) {
+      const float v = dtype == 2 ? ((const float*)x)[e] : h_to_f32(((const uint16_t*)x)[e], dtype);
+      amax = fmaxf(amax, fabsf(v));
+    }
+    *s = fmaxf(*s, amax / 448.0f);
+  }
+  const float inv = 1.0f / *s;
+#pragma omp parallel for schedule(static)
+  for (int64_t e = 0; e < n; ++e) {
+    const float v = dtype == 2 ? ((const float*)x)[e] : h_to_f32(((const uint16_t*)x)[e], dtype);
+    q[e] = f32_to_e4m3(fmaxf(fminf(v * inv, 448.0f), -448.0f));
+  }
+}
+
 /* ------------------------------------------------------------------ FP8 scaled GEMM
  * fp8_scaled_mm, sgl-kernel/csrc/gemm/fp8_gemm_kernel.cu:1071-1146; epilogue :498-546:
  *   D[m][n] = cast_out( (sum_k A[m][k] * B[k][n])_f32 * scale_b[n] * scale_a[m] (+ bias[n]) )

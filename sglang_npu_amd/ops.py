@@ -367,6 +367,50 @@ def sgl_per_token_quant_fp8(input: torch.Tensor, output_q: torch.Tensor, output_
         _I(_dtype_code(input)), _stream(input)))
 
 
+def _in_code(t: torch.Tensor) -> int:
+    code = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}.get(t.dtype)
+    if code is None:
+        raise RuntimeError(f"expected a bfloat16, float16 or float32 tensor, got {t.dtype}")
+    return code
+
+
+def sgl_per_token_group_quant_fp8(input: torch.Tensor, output_q: torch.Tensor, output_s: torch.Tensor, group_size: int,
+                                  eps: float, fp8_min: float, fp8_max: float, scale_ue8m0: bool = False) -> None:
+    """sgl_kernel.sgl_per_token_group_quant_fp8(input, output_q, output_s, group_size, eps, fp8_min, fp8_max,
+    scale_ue8m0) -- sgl-kernel/python/sgl_kernel/gemm.py:100-112, per_token_group_quant_8bit.cu:140-215.
+    output_s: fp32 [..., K / group_size], row-major or the reference's column-major (transposed-storage) form."""
+    _need_gpu(input, output_q, output_s)
+    if not input.is_contiguous() or not output_q.is_contiguous():
+        raise RuntimeError("sgl_per_token_group_quant_fp8: input and output_q must be contiguous")
+    if output_q.dtype not in (torch.float8_e4m3fn, torch.uint8) or output_q.shape != input.shape:
+        raise RuntimeError("sgl_per_token_group_quant_fp8: output_q must be float8_e4m3fn with input's shape")
+    K = input.size(-1)
+    T = input.numel() // K
+    if output_s.dim() != 2 or output_s.dtype != torch.float32:
+        raise RuntimeError("sgl_per_token_group_quant_fp8: output_s must be a 2-D float32 tensor")  # CHECK_EQ(output_s.dim(), 2)
+    if K % group_size != 0 or tuple(output_s.shape) != (T, K // group_size):
+        raise RuntimeError("sgl_per_token_group_quant_fp8: output_s must be [num_tokens, hidden_dim / group_size]")
+    _lib.check(_lib.lib().sgl_mi355_per_token_group_quant_fp8(
+        _ptr(input), _ptr(output_q), _ptr(output_s), _I64(T), _I64(K), _I64(group_size), _I64(output_s.stride(0)),
+        _I64(output_s.stride(1)), _F(eps), _F(fp8_min), _F(fp8_max), _I(1 if scale_ue8m0 else 0), _I(_in_code(input)),
+        _stream(input)))
+
+
+def sgl_per_tensor_quant_fp8(input: torch.Tensor, output_q: torch.Tensor, output_s: torch.Tensor, is_static: bool) -> None:
+    """sgl_kernel.sgl_per_tensor_quant_fp8(input, output_q, output_s, is_static) -- gemm.py:129-137,
+    per_tensor_quant_fp8.cu:90-120.  Dynamic form: output_s must come in zeroed (it is the target of an atomic max)."""
+    _need_gpu(input, output_q, output_s)
+    if not input.is_contiguous() or not output_q.is_contiguous() or not output_s.is_contiguous():
+        raise RuntimeError("sgl_per_tensor_quant_fp8: tensors must be contiguous")
+    if output_q.dtype not in (torch.float8_e4m3fn, torch.uint8) or output_q.numel() != input.numel():
+        raise RuntimeError("sgl_per_tensor_quant_fp8: output_q must be float8_e4m3fn with input's shape")
+    if output_s.dtype != torch.float32 or output_s.numel() != 1:
+        raise RuntimeError("sgl_per_tensor_quant_fp8: output_s must be a single float32")
+    _lib.check(_lib.lib().sgl_mi355_per_tensor_quant_fp8(
+        _ptr(input), _ptr(output_q), _ptr(output_s), _I64(input.numel()), _I(1 if is_static else 0), _I(_in_code(input)),
+        _stream(input)))
+
+
 class _ScratchPool:
     """fp32 scratch for split-K partials, one buffer per (device, stream).
 

@@ -53,8 +53,9 @@ def _load_by_path(name, path, placeholders):
     for modname, attrs in placeholders.items():
         saved[modname] = sys.modules.get(modname)
         m = types.ModuleType(modname)
-        for a in attrs:
-            setattr(m, a, lambda *args, **kw: False)
+        m.__path__ = []  # may be imported from as a package
+        for a in attrs:  # a list of names (dummy callables) or a {name: object} mapping
+            setattr(m, a, attrs[a] if isinstance(attrs, dict) else (lambda *args, **kw: False))
         sys.modules[modname] = m
     try:
         spec = importlib.util.spec_from_file_location(name, path)
@@ -582,12 +583,78 @@ def run_merge_state_cases(t_ms):
     return out
 
 
+def run_group_and_tensor_quant_cases():
+    """sgl_per_token_group_quant_fp8 / sgl_per_tensor_quant_fp8 against the torch references the reference's own tests
+    use: native_per_token_group_quant_fp8 (python/sglang/test/test_block_fp8.py:24-49: x / (absmax / 448), clamp,
+    cast) and torch_scaled_fp8_quant (sgl-kernel/tests/test_per_tensor_quant_fp8.py:30-38: x * (1 / scale), clamp,
+    cast), both loaded by file path."""
+    t_pt = _load_by_path("ref_test_ptq_tensor", f"{REF}/sgl-kernel/tests/test_per_tensor_quant_fp8.py",
+                         {"sgl_kernel": ["sgl_per_tensor_quant_fp8"], "sglang": [], "sglang.srt": [],
+                          "sglang.srt.utils": ["is_hip"]})
+    names = ["per_token_group_quant_fp8", "w8a8_block_fp8_matmul", "static_quant_fp8", "per_tensor_quant_mla_fp8",
+             "per_token_group_quant_mla_deep_gemm_masked_fp8"]
+    t_blk = _load_by_path("ref_test_block_fp8", f"{REF}/python/sglang/test/test_block_fp8.py",
+                          {"sglang": [], "sglang.srt": [], "sglang.srt.layers": [], "sglang.srt.layers.activation": ["SiluAndMul"],
+                           "sglang.srt.layers.moe": [], "sglang.srt.layers.moe.fused_moe_triton": [],
+                           "sglang.srt.layers.moe.fused_moe_triton.fused_moe": ["fused_moe"],
+                           "sglang.srt.layers.moe.topk": ["select_experts"],
+                           "sglang.srt.layers.quantization": [], "sglang.srt.layers.quantization.fp8_kernel": names,
+                           "sglang.srt.layers.quantization.fp8_utils": ["input_to_float8"],
+                           "sglang.test": [], "sglang.test.test_utils": {"CustomTestCase": __import__("unittest").TestCase}})
+    out = {}
+    cases = [(7, 512, 128, "bf16"), (83, 4096, 128, "fp16"), (5, 5120, 64, "bf16"), (3, 13824, 256, "f32"),
+             (16, 4096, 512, "bf16"), (2, 1024, 1024, "fp16")]
+    for i, (T, K, G, dtype) in enumerate(cases):
+        g = torch.Generator().manual_seed(800 + i)
+        dt = {"bf16": torch.bfloat16, "fp16": torch.float16, "f32": torch.float32}[dtype]
+        x = (torch.randn(T, K, generator=g) * (3.0 if i % 2 else 0.05)).to(dt)
+        if dt == torch.float32:
+            x[0, :G] = 0  # an all-zero group: absmax = eps.  (fp32 only: for 16-bit inputs the torch helper clamps
+                          # in the 16-bit dtype, i.e. to round16(1e-10), where the CUDA kernel uses the float eps)
+        q_t, s_t = t_blk.native_per_token_group_quant_fp8(x, G)
+        q_o = torch.empty(T, K, dtype=torch.uint8)
+        s_o = torch.empty(T, K // G)
+        oracle.per_token_group_quant_fp8(x, q_o, s_o, G, 1e-10, -448.0, 448.0)
+        assert torch.equal(s_o, s_t.float()), "group scales"
+        mism = (q_o != q_t.view(torch.uint8)).float().mean().item()
+        print(f"group quant T={T} K={K} G={G} {dtype}: scales equal, q bit mismatch vs the reference torch oracle = {mism:.1e}")
+        assert mism == 0.0
+        out[f"gx{i}"] = x.numpy() if dt == torch.float32 else u16(x)
+        out[f"gq{i}"], out[f"gs{i}"] = u8(q_t), s_t.float().numpy()
+        out[f"gmeta{i}"], out[f"gdtype{i}"] = np.array([T, K, G], dtype=np.int64), np.bytes_(dtype)
+    out["gn"] = np.int64(len(cases))
+    tcases = [(128, 512, "fp16"), (33, 2048, "bf16"), (7, 1001, "fp16")]
+    for i, (T, K, dtype) in enumerate(tcases):
+        g = torch.Generator().manual_seed(850 + i)
+        dt = torch.bfloat16 if dtype == "bf16" else torch.float16
+        x = torch.rand(T, K, generator=g).to(dt) * (2.0 if i else 1.0) - (0.5 if i else 0.0)
+        s_dyn = torch.zeros(1)
+        q_o = torch.empty(T, K, dtype=torch.uint8)
+        oracle.per_tensor_quant_fp8(x, q_o, s_dyn, False)
+        assert torch.equal(s_dyn, (x.float().abs().max() / 448.0).reshape(1))
+        q_t = t_pt.torch_scaled_fp8_quant(x, s_dyn)
+        mism = (q_o != q_t.view(torch.uint8)).float().mean().item()
+        s_static = torch.tensor([0.013 + 0.01 * i])
+        q_o2 = torch.empty(T, K, dtype=torch.uint8)
+        oracle.per_tensor_quant_fp8(x, q_o2, s_static.clone(), True)
+        q_t2 = t_pt.torch_scaled_fp8_quant(x, s_static)
+        mism2 = (q_o2 != q_t2.view(torch.uint8)).float().mean().item()
+        print(f"tensor quant T={T} K={K} {dtype}: q bit mismatch vs the reference torch oracle dynamic {mism:.1e} static {mism2:.1e}")
+        assert mism == 0.0 and mism2 == 0.0
+        out[f"tx{i}"], out[f"tq{i}"], out[f"ts{i}"] = u16(x), u8(q_t), s_dyn.numpy()
+        out[f"tq_static{i}"], out[f"ts_static{i}"] = u8(q_t2), s_static.numpy()
+        out[f"tdtype{i}"] = np.bytes_(dtype)
+    out["tn"] = np.int64(len(tcases))
+    return out
+
+
 def write_elementwise(ref):
     t_norm, t_rope, t_ms, t_cpu = _ref_elementwise_helpers()
     np.savez_compressed(os.path.join(HERE, "rmsnorm.npz"), **run_norm_cases(ref, t_norm))
     np.savez_compressed(os.path.join(HERE, "silu_and_mul.npz"), **run_silu_cases(ref, t_cpu))
     np.savez_compressed(os.path.join(HERE, "rope_neox.npz"), **run_rope_cases(ref, t_rope))
     np.savez_compressed(os.path.join(HERE, "merge_state.npz"), **run_merge_state_cases(t_ms))
+    np.savez_compressed(os.path.join(HERE, "group_tensor_quant_fp8.npz"), **run_group_and_tensor_quant_cases())
 
 
 def main():

@@ -201,3 +201,53 @@ def test_split_k_workspace_is_per_stream_and_never_replaced_under_a_graph():
         other = ops.fp8_scaled_mm(x, w.t(), sa, sb, torch.bfloat16)
     torch.cuda.synchronize()
     assert torch.equal(ref, other)
+
+
+def test_group_and_tensor_quant_bit_exact_vs_reference_fixture():
+    """sgl_per_token_group_quant_fp8 / sgl_per_tensor_quant_fp8 against the reference's own torch references
+    (tests/golden/group_tensor_quant_fp8.npz): scales and FP8 bytes must be identical."""
+    z = np.load("tests/golden/group_tensor_quant_fp8.npz")
+    for i in range(int(z["gn"])):
+        T, K, G = [int(v) for v in z[f"gmeta{i}"]]
+        dtype = z[f"gdtype{i}"].item().decode()
+        x = (torch.from_numpy(z[f"gx{i}"].copy()) if dtype == "f32" else _h(z[f"gx{i}"], dtype)).to(DEV)
+        q = torch.empty(T, K, dtype=torch.float8_e4m3fn, device=DEV)
+        s = torch.empty(T, K // G, device=DEV)
+        ops.sgl_per_token_group_quant_fp8(x, q, s, G, 1e-10, -448.0, 448.0)
+        assert torch.equal(s.cpu(), torch.from_numpy(z[f"gs{i}"])), f"group scales, case {i}"
+        assert torch.equal(q.cpu().view(torch.uint8), torch.from_numpy(z[f"gq{i}"])), f"group q, case {i}"
+        # the reference's column-major scale layout (create_per_token_group_quant_fp8_output_scale, fp8_kernel.py)
+        s_cm = torch.empty(K // G, T, device=DEV).t()
+        ops.sgl_per_token_group_quant_fp8(x, q, s_cm, G, 1e-10, -448.0, 448.0)
+        assert torch.equal(s_cm.contiguous().cpu(), torch.from_numpy(z[f"gs{i}"]))
+    for i in range(int(z["tn"])):
+        dtype = z[f"tdtype{i}"].item().decode()
+        x = _h(z[f"tx{i}"], dtype).to(DEV)
+        q = torch.empty(x.shape, dtype=torch.float8_e4m3fn, device=DEV)
+        s = torch.zeros(1, device=DEV)
+        ops.sgl_per_tensor_quant_fp8(x, q, s, False)
+        assert torch.equal(s.cpu(), torch.from_numpy(z[f"ts{i}"])), f"tensor scale, case {i}"
+        assert torch.equal(q.cpu().view(torch.uint8), torch.from_numpy(z[f"tq{i}"])), f"tensor q, case {i}"
+        ops.sgl_per_tensor_quant_fp8(x, q, torch.from_numpy(z[f"ts_static{i}"].copy()).to(DEV), True)
+        assert torch.equal(q.cpu().view(torch.uint8), torch.from_numpy(z[f"tq_static{i}"]))
+
+
+@pytest.mark.parametrize("T,K,G", [(64, 4096, 128), (7, 14336, 128), (2048, 512, 64), (1, 7168, 256)])
+def test_group_quant_vs_oracle_and_per_token_limit(T, K, G):
+    """Against the C oracle on other shapes; and group_size = K is the per-token HIP path of apply_fp8_linear
+    (fp8_utils.py:676-678): same scale as sgl_per_token_quant_fp8 whenever the row is not all zero."""
+    g = torch.Generator().manual_seed(T + K + G)
+    x = (torch.randn(T, K, generator=g) * 2).bfloat16()
+    q_ref, s_ref = torch.empty(T, K, dtype=torch.uint8), torch.empty(T, K // G)
+    oracle.per_token_group_quant_fp8(x, q_ref, s_ref, G, 1e-10, -448.0, 448.0)
+    q = torch.empty(T, K, dtype=torch.float8_e4m3fn, device=DEV)
+    s = torch.empty(T, K // G, device=DEV)
+    ops.sgl_per_token_group_quant_fp8(x.to(DEV), q, s, G, 1e-10, -448.0, 448.0)
+    assert torch.equal(s.cpu(), s_ref) and torch.equal(q.cpu().view(torch.uint8), q_ref)
+    if K <= 1024:
+        s1, s2 = torch.empty(T, 1, device=DEV), torch.empty(T, 1, device=DEV)
+        ops.sgl_per_token_group_quant_fp8(x.to(DEV), q, s1, K, 1e-10, -448.0, 448.0)
+        ops.sgl_per_token_quant_fp8(x.to(DEV), torch.empty_like(q), s2)
+        assert torch.equal(s1, s2)
+    with pytest.raises(NotImplementedError, match="UE8M0"):
+        ops.sgl_per_token_group_quant_fp8(x.to(DEV), q, s, G, 1e-10, -448.0, 448.0, True)

@@ -270,3 +270,30 @@ def test_merge_state_oracle_vs_reference_fixture():
         else:
             d = _ulp16(out, _z16(z, f"o{i}", dtype))
             assert int(d.max()) <= 1 and (d > 0).float().mean().item() < 5e-3
+
+
+def _gq_input(z, i):
+    dtype = z[f"gdtype{i}"].item().decode()
+    if dtype == "f32":
+        return torch.from_numpy(z[f"gx{i}"].copy()), dtype
+    return _h(torch.from_numpy(z[f"gx{i}"].view(np.int16).copy()), dtype), dtype
+
+
+def test_group_and_tensor_quant_oracle_bit_exact_vs_reference_fixture():
+    """tests/golden/group_tensor_quant_fp8.npz: native_per_token_group_quant_fp8 (python/sglang/test/test_block_fp8.py)
+    and torch_scaled_fp8_quant (sgl-kernel/tests/test_per_tensor_quant_fp8.py) of the reference."""
+    z = np.load("tests/golden/group_tensor_quant_fp8.npz")
+    for i in range(int(z["gn"])):
+        T, K, G = [int(v) for v in z[f"gmeta{i}"]]
+        x, _ = _gq_input(z, i)
+        q, s = torch.empty(T, K, dtype=torch.uint8), torch.empty(T, K // G)
+        oracle.per_token_group_quant_fp8(x, q, s, G, 1e-10, -448.0, 448.0)
+        assert torch.equal(s, torch.from_numpy(z[f"gs{i}"])) and torch.equal(q, torch.from_numpy(z[f"gq{i}"]))
+    for i in range(int(z["tn"])):
+        dtype = z[f"tdtype{i}"].item().decode()
+        x = _h(torch.from_numpy(z[f"tx{i}"].view(np.int16).copy()), dtype)
+        q, s = torch.empty(x.shape, dtype=torch.uint8), torch.zeros(1)
+        oracle.per_tensor_quant_fp8(x, q, s, False)
+        assert torch.equal(s, torch.from_numpy(z[f"ts{i}"])) and torch.equal(q, torch.from_numpy(z[f"tq{i}"]))
+        oracle.per_tensor_quant_fp8(x, q, torch.from_numpy(z[f"ts_static{i}"].copy()), True)
+        assert torch.equal(q, torch.from_numpy(z[f"tq_static{i}"]))
