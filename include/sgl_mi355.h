@@ -338,6 +338,13 @@ int sgl_mi355_awq_gemm_packed(const void* x, const uint32_t* wp, const uint32_t*
                               float* workspace, int64_t workspace_floats, int64_t M, int64_t N, int64_t K,
                               int64_t group_size, int64_t x_stride_m, int dtype, void* stream);
 
+/* The same product for M > 64 (prefill): 128 x 128 x 64 tiles on the fp16 MFMA with the INT4 weights unpacked in
+ * registers (csrc/awq_tiled.hip) -- the fused form of awq.py:413-417 / awq_gemm_triton (awq_triton.py:110-229).  No
+ * workspace, any M; same packed operands as sgl_mi355_awq_gemm_packed. */
+int sgl_mi355_awq_gemm_packed_tiled(const void* x, const uint32_t* wp, const uint32_t* sz, const void* bias, void* out,
+                                    int64_t M, int64_t N, int64_t K, int64_t group_size, int64_t x_stride_m, int dtype,
+                                    void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Elementwise ops around the hot path.
  * Replace: sgl_kernel.rmsnorm / fused_add_rmsnorm / silu_and_mul /

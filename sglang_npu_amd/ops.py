@@ -669,6 +669,23 @@ def awq_gemm_packed(x: torch.Tensor, wp: torch.Tensor, sz: torch.Tensor, group_s
     return out
 
 
+def awq_gemm_packed_tiled(x: torch.Tensor, wp: torch.Tensor, sz: torch.Tensor, group_size: int, bias=None) -> torch.Tensor:
+    """x [M, K] fp16 @ dequant(W) (+ bias) for prefill-sized M on the repacked weights of awq_repack: INT4 stays in HBM,
+    the unpacking happens in registers in front of the fp16 MFMA (csrc/awq_tiled.hip)."""
+    _need_gpu(x, wp, sz, bias)
+    if x.dim() != 2 or x.stride(1) != 1 or x.dtype != torch.float16:
+        raise RuntimeError("awq_gemm_packed_tiled: x must be a row-major fp16 [M,K] tensor")
+    M, K = x.shape
+    N = wp.size(0)
+    if wp.size(1) * 8 != _awq_kp(K) or sz.size(0) != N:
+        raise RuntimeError("awq_gemm_packed_tiled: x and the packed weight shapes cannot be multiplied")
+    out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.lib().sgl_mi355_awq_gemm_packed_tiled(
+        _ptr(x), _ptr(wp), _ptr(sz), _ptr(bias), _ptr(out), _I64(M), _I64(N), _I64(K), _I64(group_size),
+        _I64(x.stride(0) if M > 1 else K), _I(_dtype_code(x)), _stream(x)))
+    return out
+
+
 # --------------------------------------------------------------------------- elementwise ("next" rows)
 def _rows(x):
     if x.dim() < 1 or not x.is_contiguous():

@@ -285,9 +285,6 @@ class AWQLinearMethod(LinearMethodBase):
         # repack freely" (base_config.py process_weights_after_loading).  Costs K*N/2 + K*N/32 extra bytes per
         # layer; SGL_MI355_AWQ_NO_REPACK=1 keeps only the checkpoint layout.
         layer.awq_packed = None
-        # a reload (update_weights / RL sync) must not leave a prefill weight from the previous checkpoint behind
-        layer.awq_dequant_cache = None
-        layer._awq_cache_refused = False
         K, N = layer.qweight.shape[0], layer.qweight.shape[1] * self.quant_config.pack_factor
         G = K // layer.scales.shape[0]
         if layer.qweight.is_cuda and not os.environ.get("SGL_MI355_AWQ_NO_REPACK") and \
@@ -301,33 +298,14 @@ class AWQLinearMethod(LinearMethodBase):
         out_shape = x.shape[:-1] + (qweight.shape[-1] * pack_factor,)
         reshaped_x = x.reshape(-1, x.shape[-1])
         packed = getattr(layer, "awq_packed", None)
-        if packed is not None and reshaped_x.shape[0] <= 64 and reshaped_x.dtype == torch.float16:
-            out = ops.awq_gemm_packed(reshaped_x, packed[0], packed[1], packed[2], bias)
-        elif reshaped_x.shape[0] > 64 and reshaped_x.is_cuda and reshaped_x.dtype == scales.dtype and \
-                self._prefill_weight(layer) is not None:
-            # prefill: x @ awq_dequantize(...) exactly as awq.py:413-417, with the dequantised weight kept from the first
-            # call on (288 GB of HBM: K * N * 2 bytes per layer buys back the dequant pass of every prefill)
-            out = torch.matmul(reshaped_x, layer.awq_dequant_cache)
-            if bias is not None:
-                out.add_(bias)
+        if packed is not None and reshaped_x.dtype == torch.float16:
+            if reshaped_x.shape[0] <= 64:  # decode: weight-streaming kernel on the k-packed copy
+                out = ops.awq_gemm_packed(reshaped_x, packed[0], packed[1], packed[2], bias)
+            else:  # prefill: 128 x 128 tiles on the fp16 MFMA, INT4 unpacked in registers -- no fp16 weight copy anywhere
+                out = ops.awq_gemm_packed_tiled(reshaped_x, packed[0], packed[1], packed[2], bias)
         else:
             out = ops.awq_gemm(reshaped_x, qweight, scales, qzeros, bias)
         return out.reshape(out_shape)
-
-    @staticmethod
-    def _prefill_weight(layer):
-        """The dequantised [K, N] weight for prefill GEMMs, built on first use; None when disabled
-        (SGL_MI355_AWQ_PREFILL_CACHE=0) or when less than 32 GB of device memory would remain."""
-        cache = getattr(layer, "awq_dequant_cache", None)
-        if cache is not None or getattr(layer, "_awq_cache_refused", False):
-            return cache
-        K, N = layer.qweight.shape[0], layer.qweight.shape[1] * 8
-        free, _ = torch.cuda.mem_get_info(layer.qweight.device)
-        if os.environ.get("SGL_MI355_AWQ_PREFILL_CACHE") == "0" or free - K * N * 2 < (32 << 30):
-            layer._awq_cache_refused = True
-            return None
-        layer.awq_dequant_cache = ops.awq_dequantize(layer.qweight.data, layer.scales.data, layer.qzeros.data)
-        return layer.awq_dequant_cache
 
 
 QUANTIZATION_METHODS = {

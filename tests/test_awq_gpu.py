@@ -144,26 +144,54 @@ def test_awq_linear_method_repacks_and_matches_unpacked(monkeypatch):
     torch.testing.assert_close(outs[0].float(), outs[1].float(), rtol=2.0 ** -9, atol=1e-2)
 
 
-def test_awq_prefill_weight_cache_is_the_reference_computation(monkeypatch):
-    """M > 64: x @ awq_dequantize(...) (awq.py:413-417).  The linear method keeps the dequantised weight after the first
-    prefill; with and without the cache the output is the same tensor bit for bit."""
+@pytest.mark.parametrize("M", [65, 128, 200, 512, 1000])
+@pytest.mark.parametrize("K,N", [(4096, 4096), (4096, 12288), (11008, 4096), (512, 128), (2176, 1000), (4096, 22016)])
+def test_awq_gemm_packed_tiled_vs_reference_computation(M, K, N):
+    """Prefill (M > 64): 128 x 128 x 64 tiles with the INT4 weights unpacked in registers.  Reference computation =
+    x @ awq_dequantize(...) (awq.py:413-417) with the bit-exact-pinned dequant and an fp64 product (order-free), or the C
+    oracle where it finishes in seconds.  Ragged M and N tiles, K padded to 512 inside the packed copy, bias on odd M."""
+    g = torch.Generator().manual_seed(M * 5 + K + N)
+    G = 128
+    qw, qz, sc = _awq_case(K, N, G, g)
+    x = torch.randn(M, K, generator=g).half()
+    bias = torch.randn(N, generator=g).half() if M % 2 else None
+    ref = _awq_reference(x, qw, sc, qz, bias)
+    wp, sz = ops.awq_repack(qw.to(DEV), sc.to(DEV), qz.to(DEV))
+    out = ops.awq_gemm_packed_tiled(x.to(DEV), wp, sz, G, bias.to(DEV) if bias is not None else None)
+    torch.testing.assert_close(out.float().cpu(), ref.float(), rtol=2.0 ** -10, atol=2e-3 * float(ref.float().abs().max()))
+
+
+@pytest.mark.parametrize("K,N,G", [(512, 128, 128), (4096, 1000, 128), (11008, 256, 256)])
+def test_awq_tiled_dequant_is_bit_exact(K, N, G):
+    """One-hot activation rows: output row m is W[k_m, :] exactly -- the in-register unpacking of the tiled kernel is the
+    reference's dequantisation bit for bit (same argument as test_awq_packed_dequant_is_bit_exact)."""
+    g = torch.Generator().manual_seed(K + N + 1)
+    qw, qz, sc = _awq_case(K, N, G, g)
+    w_ref = oracle.awq_dequantize(qw, sc, qz)
+    wp, sz = ops.awq_repack(qw.to(DEV), sc.to(DEV), qz.to(DEV))
+    ks = torch.randperm(K, generator=g)[:160]
+    x = torch.zeros(160, K, dtype=torch.float16)
+    x[torch.arange(160), ks] = 1.0
+    out = ops.awq_gemm_packed_tiled(x.to(DEV), wp, sz, G)
+    assert torch.equal((out.cpu() + 0.0).view(torch.int16), (w_ref[ks] + 0.0).view(torch.int16))
+
+
+def test_awq_linear_method_prefill_keeps_int4_only():
+    """M > 64 through AWQLinearMethod.apply: the fused tiled kernel, no dequantised copy of the weight on the layer, and
+    a reload (process_weights_after_loading again) is picked up by both the decode and the prefill path."""
     from sglang_npu_amd.quantization import AWQConfig
     from sglang_npu_amd.linear import ColumnParallelLinear
     K, N, M = 1024, 512, 200
-    outs = []
-    for cache in ("1", "0"):
-        monkeypatch.setenv("SGL_MI355_AWQ_PREFILL_CACHE", cache)
-        layer = ColumnParallelLinear(K, [N], bias=False, params_dtype=torch.float16,
-                                     quant_config=AWQConfig(4, 128, True)).to(DEV)
-        qw, qz, sc = _awq_case(K, N, 128, torch.Generator().manual_seed(10))
+    layer = ColumnParallelLinear(K, [N], bias=False, params_dtype=torch.float16, quant_config=AWQConfig(4, 128, True)).to(DEV)
+    x = torch.randn(M, K, generator=torch.Generator().manual_seed(9)).half().to(DEV)
+    for seed in (10, 11):  # second round = a weight reload
+        qw, qz, sc = _awq_case(K, N, 128, torch.Generator().manual_seed(seed))
         layer.qweight.data.copy_(qw), layer.qzeros.data.copy_(qz), layer.scales.data.copy_(sc)
         layer.quant_method.process_weights_after_loading(layer)
-        x = torch.randn(M, K, generator=torch.Generator().manual_seed(9)).half().to(DEV)
-        ys = [layer(x), layer(x)]  # second call: served from the cache (or dequantised again)
-        ys = [y[0] if isinstance(y, tuple) else y for y in ys]
-        assert torch.equal(ys[0], ys[1])
-        assert (getattr(layer, "awq_dequant_cache", None) is not None) == (cache == "1")
-        outs.append(ys[0])
-    assert torch.equal(outs[0], outs[1])
-    ref = x @ ops.awq_dequantize(qw.to(DEV), sc.to(DEV), qz.to(DEV))
-    assert torch.equal(outs[0], ref)
+        y = layer(x)[0]
+        ref = (x.double() @ ops.awq_dequantize(qw.to(DEV), sc.to(DEV), qz.to(DEV)).double())
+        torch.testing.assert_close(y.double(), ref, rtol=2.0 ** -10, atol=2e-3 * float(ref.abs().max()))
+        y_dec = layer(x[:7])[0]
+        torch.testing.assert_close(y_dec.double(), ref[:7], rtol=2.0 ** -10, atol=2e-3 * float(ref.abs().max()))
+    assert not hasattr(layer, "awq_dequant_cache")
+    assert not any(t.dtype == torch.float16 and t.numel() >= K * N for t in vars(layer).values() if isinstance(t, torch.Tensor))
