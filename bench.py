@@ -122,6 +122,7 @@ class DecodeLoop:
                                req_to_token_pool=runner.req_to_token_pool, token_to_kv_pool=runner.token_to_kv_pool,
                                attn_backend=backend)
         self.next_ids = torch.zeros(B, dtype=torch.int64, device=device)
+        self.cur_len, self.max_len = ctx, self.r2t.size(1)  # host copy of the (uniform) sequence length: bounds check
         self.graph = None
         self.use_graph = use_graph
         self._refresh()
@@ -147,11 +148,20 @@ class DecodeLoop:
                 self._forward()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        # capture on the stream the warm-up passes ran on (cuda_graph_runner.py:526-534 does the same): per-stream state
+        # such as the split-K scratch then already has its final size
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, stream=s):
             self._forward()
 
+    def rewind(self, ctx):
+        self.seq_lens.fill_(ctx)
+        self.cur_len = ctx
+        self._refresh()
+
     def step(self):
+        if self.cur_len + 1 > self.max_len:  # the gather in _refresh would read past the request's page-table row
+            raise RuntimeError(f"decode loop ran past the page table ({self.cur_len + 1} > {self.max_len}): rewind() first")
         if self.graph is not None:
             self.backend.init_forward_metadata_replay_cuda_graph(self.B, self.req_pool_indices, self.seq_lens,
                                                                  0, None, self.fb.forward_mode, None, None)
@@ -162,6 +172,7 @@ class DecodeLoop:
         # feed the sampled token back and advance every request by one position
         self.input_ids.copy_(self.next_ids % 10000)
         self.seq_lens += 1
+        self.cur_len += 1
         self._refresh()
 
 
@@ -332,7 +343,7 @@ def time_decode_gemms(net, cfg, B, device, tp):
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, stream=s):
                 run()
             graph.replay()
             torch.cuda.synchronize()
@@ -423,8 +434,7 @@ def main():
         """Switch the model between the fused producers and the reference's operator order, rewind the requests to
         ctx (the page table has room for ctx + steps + warmup + 8 positions only) and re-capture the step."""
         net.fuse_quant = bool(fused and can_fuse)
-        loop.seq_lens.fill_(args.ctx)
-        loop._refresh()
+        loop.rewind(args.ctx)
         if use_graph:
             loop.capture()
 
@@ -453,6 +463,7 @@ def main():
         set_call_order(want_fused)
     fused_ms, dropin_ms = (ms_per_step, other) if want_fused else (other, ms_per_step)
     sync_ts = []
+    loop.rewind(args.ctx)  # the page table has room for ctx + steps + warmup + 8 positions only
     for _ in range(min(args.steps, 10) + 2):
         barrier()
         t0 = time.perf_counter()
@@ -461,8 +472,7 @@ def main():
         sync_ts.append((time.perf_counter() - t0) * 1e3)
     sync_ts = sorted(sync_ts[2:])
     median_synced_ms = max_over_ranks(sync_ts[len(sync_ts) // 2])
-    loop.seq_lens.fill_(args.ctx + args.warmup + args.steps)   # where the instrumented passes below expect to start
-    loop._refresh()
+    loop.rewind(args.ctx + args.warmup + args.steps)   # where the instrumented passes below expect to start
 
     # ---- all-reduce overhead (N > 1): the same step with the TP all-reduce stubbed to identity, outside the timed
     # region above ((t_with - t_without) / t_with)
@@ -470,9 +480,8 @@ def main():
     if dist_on:
         try:
             tp_group.stub_all_reduce = True
-            seq_after = loop.seq_lens.clone()
-            loop.seq_lens.fill_(args.ctx)  # the page table has room for ctx + steps + warmup + 8 positions only
-            loop._refresh()
+            len_after = loop.cur_len
+            loop.rewind(args.ctx)  # the page table has room for ctx + steps + warmup + 8 positions only
             if loop.graph is not None:
                 loop.capture()
             n_stub = min(args.steps, 6)
@@ -494,8 +503,7 @@ def main():
                        "message_bytes": args.batch * cfg.hidden_size * 2}
         finally:
             tp_group.stub_all_reduce = False
-            loop.seq_lens.copy_(seq_after)
-            loop._refresh()
+            loop.rewind(len_after)
         if loop.graph is not None:
             loop.capture()  # the instrumented passes below run the real step again
 

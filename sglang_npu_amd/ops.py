@@ -662,7 +662,9 @@ def awq_gemm_packed(x: torch.Tensor, wp: torch.Tensor, sz: torch.Tensor, group_s
     if wp.size(1) * 8 != _awq_kp(K) or sz.size(0) != N:
         raise RuntimeError("awq_gemm_packed: x and the packed weight shapes cannot be multiplied")
     out = torch.empty((M, N), dtype=x.dtype, device=x.device)
-    ws = _awq_workspace.get(x.device, 16 * M * N)
+    # split-K slabs: the kernel splits K only while (N / 16 / consumer waves) x slices <= 256 workgroups
+    # (awq_packed.hip launch): at most 256 // ceil(N / 128) slices of M x N floats
+    ws = _awq_workspace.get(x.device, max(1, min(16, 256 // max(1, -(-N // 128)))) * M * N)
     _lib.check(_lib.lib().sgl_mi355_awq_gemm_packed(
         _ptr(x), _ptr(wp), _ptr(sz), _ptr(bias), _ptr(out), _ptr(ws), _I64(ws.numel()), _I64(M), _I64(N), _I64(K),
         _I64(group_size), _I64(x.stride(0) if M > 1 else K), _I(_dtype_code(x)), _stream(x)))
