@@ -21,6 +21,9 @@
 // Per k-step a lane (column r16 of a block, k-group kg) reads ONE ds_read_b64 of W per column block = its 16 k-values
 // (k = 16 kg + 8 ks + t for MFMA ks), so the matching activation chunk of row r is chunk 2 kg + ks of the 128-B row.
 // 64.5 KiB of LDS per workgroup: two workgroups per CU hide each other's barriers.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace sglm {
@@ -69,14 +72,18 @@ __device__ __forceinline__ f16x8 unpack8(uint32_t w, h2 zb2, h2 sc2) {
   return r;
 }
 
-constexpr int kTM = 128, kTN = 128, kBK = 64, kStagesT = 3;
-constexpr int kOpA = kTM * 128;           // 16 KiB
+constexpr int kTN = 128, kBK = 64;
 constexpr int kOpW = kTN * 32;            // 4 KiB
 constexpr int kOpS = 4 * 256;             // 1 KiB: 64 dwords per wave
-constexpr int kStageT = kOpA + kOpW + kOpS;
-constexpr int kOpsPerStage = 4 + 1 + 1;   // DMA instructions per wave and stage
 
+// RI = 16-row blocks per tile: 8 (128 rows) or 4 (64 rows, for shapes whose 128-row tiles would not fill the chip)
+template <int kStagesT, int RI>
 __global__ __launch_bounds__(256, 2) void awq_tiled_kernel(AwqTArgs p) {
+  constexpr int kTM = 16 * RI;
+  constexpr int kOpA = kTM * 128;           // 16 / 8 KiB
+  constexpr int kStageT = kOpA + kOpW + kOpS;
+  constexpr int UA = RI / 2;                // 1-KiB A pieces per wave and stage
+  constexpr int kOpsPerStage = UA + 1 + 1;  // DMA instructions per wave and stage
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -96,10 +103,10 @@ __global__ __launch_bounds__(256, 2) void awq_tiled_kernel(AwqTArgs p) {
   const int m0 = tm * kTM, n0 = tn * kTN;
 
   // ---- DMA sources of this lane
-  const uint8_t* a_src[4];
+  const uint8_t* a_src[UA];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int row = (4 * wave + u) * 8 + (lane >> 3);
+  for (int u = 0; u < UA; ++u) {
+    const int row = (UA * wave + u) * 8 + (lane >> 3);
     const int j = (lane & 7) ^ ((row >> 1) & 7);
     int m = m0 + row;
     m = m < p.M ? m : p.M - 1;  // rows past the edge re-read a valid row; never stored
@@ -117,14 +124,14 @@ __global__ __launch_bounds__(256, 2) void awq_tiled_kernel(AwqTArgs p) {
     const uint32_t dst = smem_base + stage * kStageT;
     const int akt = kt < p.real_steps ? kt : p.real_steps - 1;  // padded steps: finite activations x zero weights
 #pragma unroll
-    for (int u = 0; u < 4; ++u) lds_dma16(a_src[u] + (int64_t)akt * 128, dst + (4 * wave + u) * 1024);
+    for (int u = 0; u < UA; ++u) lds_dma16(a_src[u] + (int64_t)akt * 128, dst + (UA * wave + u) * 1024);
     lds_dma16(w_src + (int64_t)kt * 32, dst + kOpA + wave * 1024);
     lds_dma4(s_src + (kt >> p.gshift), dst + kOpA + kOpW + wave * 256);
   };
 
-  f32x4 acc[8][2];
+  f32x4 acc[RI][2];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < RI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -140,7 +147,15 @@ __global__ __launch_bounds__(256, 2) void awq_tiled_kernel(AwqTArgs p) {
     if (st < nk) dma_stage(st, st);
   for (int kt = 0; kt < nk; ++kt) {
     // this wave's pieces of stage kt have landed once at most the younger stage's are outstanding
-    if (kt + 1 < nk) wait_vmcnt<kOpsPerStage>(); else wait_vmcnt<0>();
+    // (kStagesT - 2 younger stages stay in flight; the tail drains)
+    const int younger = (nk - 1 - kt) < (kStagesT - 2) ? (nk - 1 - kt) : (kStagesT - 2);
+    switch (younger) {
+      case 0: wait_vmcnt<0>(); break;
+      case 1: wait_vmcnt<kOpsPerStage>(); break;
+      case 2: wait_vmcnt<2 * kOpsPerStage>(); break;
+      case 3: wait_vmcnt<3 * kOpsPerStage>(); break;
+      default: wait_vmcnt<4 * kOpsPerStage>(); break;
+    }
     __syncthreads();  // everyone's pieces landed; everyone is done reading the stage refilled next
     if (kt + kStagesT - 1 < nk) dma_stage((kt + kStagesT - 1) % kStagesT, kt + kStagesT - 1);
     const char* st_ = smem + (kt % kStagesT) * kStageT;
@@ -156,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void awq_tiled_kernel(AwqTArgs p) {
       bf[cb][1] = unpack8(w2.y, zb2, sc2);
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < RI; ++i) {
       const f16x8 a0 = *reinterpret_cast<const f16x8*>(st_ + i * 2048 + ca0);
       const f16x8 a1 = *reinterpret_cast<const f16x8*>(st_ + i * 2048 + ca1);
 #pragma unroll
@@ -168,8 +183,8 @@ __global__ __launch_bounds__(256, 2) void awq_tiled_kernel(AwqTArgs p) {
   }
   __syncthreads();  // all stages dead: the epilogue reuses the memory
 
-  // ---- epilogue through a wave-private [128][32] (+8 pad) fp16 patch: 16-B row segments to global
-  _Float16* ep = reinterpret_cast<_Float16*>(smem) + wave * (128 * 40);
+  // ---- epilogue through a wave-private [rows][32] (+8 pad) fp16 patch: 16-B row segments to global
+  _Float16* ep = reinterpret_cast<_Float16*>(smem) + wave * (kTM * 40);
   float bv[2] = {0.f, 0.f};
   if (p.bias) {
 #pragma unroll
@@ -179,15 +194,15 @@ __global__ __launch_bounds__(256, 2) void awq_tiled_kernel(AwqTArgs p) {
     }
   }
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < RI; ++i)
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) ep[(16 * i + 4 * kg + r) * 40 + 16 * cb + r16] = (_Float16)(acc[i][cb][r] + bv[cb]);
   wait_lgkmcnt0();  // wave-private patch
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int c = lane + 64 * it;  // 512 segments: row c >> 2, 8-column piece c & 3
+  for (int it = 0; it < RI; ++it) {
+    const int c = lane + 64 * it;  // 4 segments per row: row c >> 2, 8-column piece c & 3
     const int ml = c >> 2, nl = (c & 3) * 8;
     const int m = m0 + ml, n = n0 + 32 * wave + nl;
     if (m < p.M && n < p.N)  // N % 8 == 0: a piece is all in or all out
@@ -220,13 +235,30 @@ extern "C" int sgl_mi355_awq_gemm_packed_tiled(const void* x, const uint32_t* wp
   AwqTArgs p{(const uint8_t*)x, x_stride_m * 2, (const uint8_t*)wp, sz, bias, out, (int)M, (int)N, (int)Kp, (int)(K / 64),
              0, (int)ngp};
   for (int64_t g = group_size / 64; g > 1; g >>= 1) ++p.gshift;
-  constexpr int lds = kStagesT * kStageT;
-  static int attr_rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(awq_tiled_kernel),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds),
-                                 "hipFuncSetAttribute");
-  if (attr_rc) return attr_rc;
-  const int64_t tiles = ((M + kTM - 1) / kTM) * ((N + kTN - 1) / kTN);
+  // Tile height and pipeline depth by tile count (same-box A/B, Llama-2-7B shapes, M = 512 / 1024 / 4096): 128-row tiles with
+  // 2 stages (43 KiB: three workgroups per CU) where they fill the chip three times over, 3 stages (64.5 KiB, two per CU)
+  // otherwise; 64-row tiles when even that leaves CUs idle.  SGL_MI355_AWQ_TILED="stages,rows" overrides (tuning aid).
+  const int64_t tn_ = (N + kTN - 1) / kTN;
+  const int64_t tiles128 = ((M + 127) / 128) * tn_;
+  int nst = tiles128 > 512 ? 2 : 3, rows = tiles128 >= 256 ? 128 : 64;
+  {
+    static const char* force = getenv("SGL_MI355_AWQ_TILED");
+    int fs = 0, fr = 0;
+    if (force && sscanf(force, "%d,%d", &fs, &fr) == 2 && (fs == 2 || fs == 3) && (fr == 64 || fr == 128)) nst = fs, rows = fr;
+  }
+  const int64_t tiles = ((M + rows - 1) / rows) * tn_;
   SGLM_CHECK_ARG(tiles < (1ll << 31), "awq_gemm_packed_tiled: too many tiles");
-  hipLaunchKernelGGL(awq_tiled_kernel, dim3((unsigned)tiles), dim3(256), lds, as_stream(stream), p);
+#define AWQ_T(NST, RI_)                                                                                                 \
+  do {                                                                                                                  \
+    constexpr int lds = NST * (16 * RI_ * 128 + kOpW + kOpS);                                                           \
+    static int attr_rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(awq_tiled_kernel<NST, RI_>),       \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds),                \
+                                   "hipFuncSetAttribute");                                                              \
+    if (attr_rc) return attr_rc;                                                                                        \
+    hipLaunchKernelGGL((awq_tiled_kernel<NST, RI_>), dim3((unsigned)tiles), dim3(256), lds, as_stream(stream), p);      \
+  } while (0)
+  if (rows == 128) { if (nst == 2) AWQ_T(2, 8); else AWQ_T(3, 8); }
+  else { if (nst == 2) AWQ_T(2, 4); else AWQ_T(3, 4); }
+#undef AWQ_T
   return check_hip(hipGetLastError(), "awq_tiled launch");
 }
