@@ -401,6 +401,15 @@ int sgl_mi355_rotary_embedding_set_kv_fp8kv(const int64_t* positions, void* quer
                                             void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Replaces: the LM-head product of LogitsProcessor._get_logits, `torch.matmul(hidden_states, lm_head.weight.T)`
+ *           (python/sglang/srt/layers/logits_processor.py:430-505), and any unquantised decode linear
+ *           (layers/quantization/unquant.py: F.linear): out[M, N] = x[M, K] @ weight[N, K]^T (+ bias).
+ * 16-bit operands (dtype 0 bf16, 1 fp16), fp32 accumulation, M <= 64 (decode batches; the weight-streaming kernel of
+ * csrc/gemm_bf16.hip), N % 8 == 0, K % 256 == 0; strides in elements; out contiguous [M, N]. */
+int sgl_mi355_gemm16_nt(const void* x, const void* weight, const void* bias, void* out, int64_t M, int64_t N, int64_t K,
+                        int64_t x_stride_m, int64_t w_stride_n, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Replaces: sgl_per_token_group_quant_fp8(Tensor input, Tensor output_q, Tensor output_s, int group_size, float eps,
  *                                         float fp8_min, float fp8_max, bool scale_ue8m0) -> ()
  *           -- sgl-kernel/csrc/common_extension.cc:116-119, csrc/gemm/per_token_group_quant_8bit.cu:15-215;

@@ -1,0 +1,305 @@
+// 16-bit weight-streaming GEMM for decode-sized batches: out[M, N] = x[M, K] @ W[N, K]^T (+ bias), M <= 64.
+//
+// Replaces: the LM-head matmul of LogitsProcessor._get_logits -- `torch.matmul(hidden_states, lm_head.weight.T)`
+//   (python/sglang/srt/layers/logits_processor.py:430-505) -- which at Llama-3-8B is a 4096 x 128256 bf16 matrix:
+//   1.05 GB read per decode step, as much as five decoder layers' weights.  (Also any unquantised decode linear.)
+//
+// HBM-bound (AI = 2 M / 2 B = 64 flop/B at M = 64): the structure is the FP8 weight streamer's (gemm_fp8.hip
+// fp8_gemm_wstream_kernel) with 16-bit operands:
+//   * a consumer wave owns 16 output columns over all of K; its weights go HBM -> registers, two 128-B row segments
+//     (64 k) ahead, hand-counted vmcnt (the loads are inline asm: hipcc would drain the queue at every use);
+//   * the activations of a phase (PH k-steps of 64, <= 64 KiB) are put into LDS by a producer wave with LDS-DMA into an
+//     XOR-swizzled [step][row][128 B] image, double-buffered, one workgroup barrier per phase;
+//   * v_mfma_f32_16x16x32_{bf16,f16}: lane group g takes 16-B chunks g and 4 + g of a 128-B segment for both operands
+//     (whole 64-B sectors per load instruction); fp32 accumulation, one rounding at the end (+ bias in fp32).
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace sglm {
+namespace {
+
+struct G16Args {
+  const uint8_t* a;  // activations [M][K] 16-bit
+  int64_t a_sm;      // bytes between rows
+  const uint8_t* b;  // weights [N][K] 16-bit (K contiguous)
+  int64_t b_sn;      // bytes between weight rows
+  const void* bias;  // [N] 16-bit or null
+  void* out;         // [M][N] 16-bit
+  int M, N, KB;      // KB = K * 2: contraction length in BYTES (128 per k-step)
+  int throttle;      // producer: k-steps of activation DMA allowed in flight (0 = the whole phase at once)
+};
+
+union Seg32 {  // this lane's 2 x 16 B of a 128-B row segment = two MFMA operands
+  uint4 v[2];
+  i32x4 x[2];
+};
+
+__device__ __forceinline__ void wload(Seg32& f, const uint8_t* sbase, uint32_t voff) {
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(f.x[0]) : "v"(voff), "s"(sbase) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=v"(f.x[1]) : "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void wload_nt(Seg32& f, const uint8_t* sbase, uint32_t voff) {
+  asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(f.x[0]) : "v"(voff), "s"(sbase) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:64 nt" : "=v"(f.x[1]) : "v"(voff), "s"(sbase) : "memory");
+}
+template <int N, int NB>
+__device__ __forceinline__ void wait_segs(Seg32 (&f)[NB]) {
+  static_assert(NB == 1 || NB == 2, "NB");
+  if constexpr (NB == 1)
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(f[0].x[0]), "+v"(f[0].x[1]) : "n"(N) : "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(f[0].x[0]), "+v"(f[0].x[1]), "+v"(f[1].x[0]), "+v"(f[1].x[1]) : "n"(N) : "memory");
+}
+// the never-consumed tail refills: wait, THEN keep every queue register alive across the wait (gemm_fp8.hip 4.3.1 g)
+template <int PB, int NB>
+__device__ __forceinline__ void drain_segs(Seg32 (&q)[PB][NB]) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < PB; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) asm volatile("" ::"v"(q[i][j].x[0]), "v"(q[i][j].x[1]));
+}
+
+template <int DTYPE, int MB, int PH, bool NT, int NB, int PB = 2>
+__global__ __launch_bounds__(576) void gemm16_wstream_kernel(G16Args p) {
+  static_assert(PH * MB <= 32, "one A buffer is at most 64 KiB");
+  using H = Half16<DTYPE>;
+  using T = typename H::T;
+  using x8 = typename H::x8;
+  constexpr int ROWS = 16 * MB;
+  constexpr int STEP_BYTES = ROWS * 128;
+  constexpr int BUF_BYTES = PH * STEP_BYTES;
+  // PB: weight k-steps in flight per wave (2: gemm_fp8.hip 4.3.1 l found deeper queues slower there)
+  constexpr int UPS = 2 * MB;     // 1-KiB DMA pieces (8 rows x 128 B) per k-step
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int NC = (int)(blockDim.x >> 6) - 1;  // consumer waves; wave NC is the DMA producer
+  const int r16 = lane & 15, g = lane >> 4;
+  const int nph = (p.KB >> 7) / PH;
+  // NB 16-column blocks per consumer wave (NB = 2 at 64 rows: the activation image, re-read from L2 by every workgroup,
+  // is then amortised over twice the weight bytes -- at M = 64 it is half as many bytes per k-step as 8 waves' weights)
+  const int nb0 = (blockIdx.x * NC + wave) * NB;
+  const uint32_t smem_base = lds_addr_of(smem);
+
+  f32x4 acc[NB][MB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[j][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (wave == NC) {
+    // producer: lane i of a piece lands at chunk i & 7 of row i >> 3 and fetches source chunk (i & 7) ^ ((row >> 1) & 7)
+    const uint8_t* a_lane[UPS];
+#pragma unroll
+    for (int rg = 0; rg < UPS; ++rg) {
+      const int drow = rg * 8 + (lane >> 3);
+      const int dj = (lane & 7) ^ ((drow >> 1) & 7);
+      a_lane[rg] = p.a + (int64_t)(drow < p.M ? drow : p.M - 1) * p.a_sm + 16 * dj;  // rows past M: never stored
+    }
+    auto dma_phase = [&](int ph, int buf) __attribute__((always_inline)) {
+      for (int sl = 0; sl < PH; ++sl) {
+#pragma unroll
+        for (int rg = 0; rg < UPS; ++rg)
+          lds_dma16(a_lane[rg] + ((ph * PH + sl) << 7), smem_base + buf * BUF_BYTES + sl * STEP_BYTES + rg * 1024);
+        // pace the image: a whole phase (64 KiB) issued at once crowds the consumers' weight loads out of the CU's
+        // memory pipe for microseconds; it is not needed before the NEXT phase barrier
+        if (p.throttle == 1) wait_vmcnt<UPS>();
+        else if (p.throttle == 2) wait_vmcnt<2 * UPS>();
+        else if (p.throttle == 4) wait_vmcnt<4 * UPS>();
+      }
+    };
+    dma_phase(0, 0);
+    for (int lp = 0; lp < nph; ++lp) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // phase lp has landed
+      __syncthreads();                                   // barrier #lp
+      if (lp + 1 < nph) dma_phase(lp + 1, (lp + 1) & 1);
+    }
+    __syncthreads();  // the consumers' final barrier
+    return;
+  }
+
+  // consumers
+  uint32_t lane_off[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int n = (nb0 + j) * 16 + r16;
+    lane_off[j] = (uint32_t)((int64_t)(n < p.N ? n : 0) * p.b_sn + 16 * g);
+  }
+  const int rot = (nb0 * 3) & (PH - 1);  // per-wave rotation of the sweep inside a phase
+  const int last = nph * PH - 1;
+  const int sw = (r16 >> 1) & 7;
+  const uint32_t o0 = r16 * 128 + 16 * (g ^ sw);
+  const uint32_t o1 = r16 * 128 + 16 * ((4 + g) ^ sw);
+
+  int f_pf = 0;
+  auto refill = [&](Seg32 (&fr)[NB]) __attribute__((always_inline)) {
+    const int f = f_pf < last ? f_pf : last;  // tail refills re-read the last step, never consumed
+    const int ks = (f & ~(PH - 1)) + ((f + rot) & (PH - 1));
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      if constexpr (NT) wload_nt(fr[j], p.b + ((int64_t)ks << 7), lane_off[j]);
+      else wload(fr[j], p.b + ((int64_t)ks << 7), lane_off[j]);
+    }
+    ++f_pf;
+  };
+  Seg32 bq[PB][NB];
+#pragma unroll
+  for (int i = 0; i < PB; ++i) refill(bq[i]);
+
+#pragma clang loop unroll(disable)  // exactly one copy of the step body (gemm_fp8.hip 4.3.1 f)
+  for (int lp = 0; lp < nph; ++lp) {
+    __syncthreads();  // barrier #lp: phase lp is in LDS
+    const uint32_t abuf = (lp & 1) * BUF_BYTES;
+    for (int s0 = 0; s0 < PH; s0 += PB) {
+#pragma unroll
+      for (int i = 0; i < PB; ++i) {
+        const int t = (s0 + i + rot) & (PH - 1);
+        // the slot's 2 NB loads are the oldest in the queue: 2 NB (PB - 1) younger ones may stay in flight
+        wait_segs<2 * NB * (PB - 1), NB>(bq[i]);
+        const char* a0 = smem + abuf + t * STEP_BYTES + o0;
+        const char* a1 = smem + abuf + t * STEP_BYTES + o1;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          const x8 f0 = *reinterpret_cast<const x8*>(a0 + mb * 2048);
+          const x8 f1 = *reinterpret_cast<const x8*>(a1 + mb * 2048);
+#pragma unroll
+          for (int j = 0; j < NB; ++j) {
+            acc[j][mb] = H::mfma16(f0, __builtin_bit_cast(x8, bq[i][j].v[0]), acc[j][mb]);
+            acc[j][mb] = H::mfma16(f1, __builtin_bit_cast(x8, bq[i][j].v[1]), acc[j][mb]);
+          }
+        }
+        refill(bq[i]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+
+  drain_segs(bq);
+  __syncthreads();  // the A buffers are dead: reuse their memory
+  T* ep = reinterpret_cast<T*>(smem) + wave * (ROWS * 24);  // [ROWS][16] (+8 pad), one column block at a time
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int nb = nb0 + j;
+    const int n = nb * 16 + r16;
+    const float bv = p.bias ? H::to_f32(reinterpret_cast<const T*>(p.bias)[n < p.N ? n : p.N - 1]) : 0.f;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ep[(16 * mb + 4 * g + r) * 24 + r16] = H::from_f32(acc[j][mb][r] + bv);
+    wait_lgkmcnt0();
+    for (int c = lane; c < ROWS * 2; c += 64) {
+      const int m = c >> 1, half = c & 1;
+      const int nn = nb * 16 + half * 8;
+      if (m < p.M && nn < p.N)
+        *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.out) + (int64_t)m * p.N + nn) =
+            *reinterpret_cast<const uint4*>(ep + m * 24 + half * 8);
+    }
+    wait_lgkmcnt0();  // the patch is rewritten by the next column block
+  }
+}
+
+template <int DTYPE, int MB, int PH, bool NT, int NB>
+int launch16_ph(const G16Args& p, int nc, int groups, hipStream_t s) {
+  static const int pb_env = [] { const char* e = getenv("SGL_MI355_GEMM16_PB"); return e ? atoi(e) : 2; }();  // A/B aid
+  if constexpr (PH >= 4 && NB == 1 && !NT) {
+    if (pb_env == 4) {
+      auto k4 = gemm16_wstream_kernel<DTYPE, MB, PH, NT, NB, 4>;
+      constexpr int lds4 = 2 * PH * 16 * MB * 128;
+      static int rc4 = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(k4), hipFuncAttributeMaxDynamicSharedMemorySize, lds4), "hipFuncSetAttribute");
+      if (rc4) return rc4;
+      hipLaunchKernelGGL(k4, dim3((unsigned)groups), dim3(64 * (nc + 1)), lds4, s, p);
+      return check_hip(hipGetLastError(), "gemm16_wstream launch");
+    }
+  }
+  auto kern = gemm16_wstream_kernel<DTYPE, MB, PH, NT, NB>;
+  constexpr int lds = 2 * PH * 16 * MB * 128;
+  static int attr_rc = check_hip(
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
+      "hipFuncSetAttribute");
+  if (attr_rc) return attr_rc;
+  hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(64 * (nc + 1)), lds, s, p);
+  return check_hip(hipGetLastError(), "gemm16_wstream launch");
+}
+
+template <int DTYPE, int MB>
+int launch16(const G16Args& p, hipStream_t s) {
+  const int steps = p.KB >> 7;
+  // two column blocks per wave at 64 rows and wide N (SGL_MI355_GEMM16_NB=1|2: A/B aid)
+  static const int nb_env = [] { const char* e = getenv("SGL_MI355_GEMM16_NB"); return e ? atoi(e) : 0; }();
+  constexpr bool kCanNB2 = MB == 4;
+  const bool nb2 = kCanNB2 && nb_env == 2;  // measured (LM head, M = 64): 243 us vs 218 with one block per wave -- off by default
+  const int nblocks = ((p.N + 15) / 16 + (nb2 ? 1 : 0)) / (nb2 ? 2 : 1);  // units of NB column blocks
+  // Phase length.  At 64 rows FOUR k-steps (2 x 32 KiB of LDS: two workgroups per CU) beat eight (one workgroup per CU)
+  // and two: LM head 4096 x 128256, same box, M = 64: PH 8 / 4 / 2 = 234 / 218 / 245 us (hipBLASLt 210).  Fewer rows take
+  // the longest phase that divides K (M = 16: 180 us, hipBLASLt 181).  SGL_MI355_GEMM16_PH caps it (A/B aid).
+  static const int ph_cap = [] { const char* e = getenv("SGL_MI355_GEMM16_PH"); return e ? atoi(e) : 32; }();
+  int PH = 0;
+  for (int ph = (MB == 4 ? 4 : 32 / MB); ph >= 2; ph >>= 1)
+    if (steps % ph == 0 && ph <= ph_cap) { PH = ph; break; }
+  if (PH == 0) {
+    set_error("gemm16: K (%d elements) must be a multiple of 256", p.KB / 2);
+    return SGL_MI355_ERR_INVALID_ARGUMENT;
+  }
+  // consumer waves: the count that leaves the fewest k-steps on the busiest CU (one workgroup per CU)
+  int nc = 8, best = 1 << 30;
+  for (int c = 8; c >= 4; --c) {
+    const int groups_c = (nblocks + c - 1) / c;
+    const int cost = ((groups_c + 255) / 256) * c;
+    if (cost < best) { best = cost; nc = c; }
+  }
+  const int groups = (nblocks + nc - 1) / nc;
+  // weight-load cache policy (SGL_MI355_GEMM16_NT=0|1: A/B aid)
+  // (measured, LM head 4096 x 128256, M = 1 / 16 / 64: nt 188 / 196 / 249 us, default policy 175 / 180 / 231 us: unlike
+  //  the LDS-DMA K/V stream of the decode kernel, register loads do not gain from the hint)
+  static const int nt = [] { const char* e = getenv("SGL_MI355_GEMM16_NT"); return e ? atoi(e) : 0; }();
+#define G16_GO(PH_)                                                                                   \
+  do {                                                                                                \
+    if constexpr (kCanNB2) {                                                                          \
+      if (nb2) return nt ? launch16_ph<DTYPE, MB, PH_, true, 2>(p, nc, groups, s)                     \
+                         : launch16_ph<DTYPE, MB, PH_, false, 2>(p, nc, groups, s);                   \
+    }                                                                                                 \
+    return nt ? launch16_ph<DTYPE, MB, PH_, true, 1>(p, nc, groups, s)                                \
+              : launch16_ph<DTYPE, MB, PH_, false, 1>(p, nc, groups, s);                              \
+  } while (0)
+  if constexpr (MB == 1) { if (PH == 32) G16_GO(32); }
+  if constexpr (MB <= 2) { if (PH == 16) G16_GO(16); }
+  if (PH == 4) G16_GO(4);
+  if (PH == 2) G16_GO(2);
+  G16_GO(8);
+#undef G16_GO
+}
+
+}  // namespace
+}  // namespace sglm
+
+using namespace sglm;
+
+extern "C" int sgl_mi355_gemm16_nt(const void* x, const void* weight, const void* bias, void* out, int64_t M, int64_t N,
+                                   int64_t K, int64_t x_stride_m, int64_t w_stride_n, int dtype, void* stream) {
+  SGLM_CHECK_ARG(dtype == SGL_MI355_BF16 || dtype == SGL_MI355_FP16, "gemm16_nt: dtype must be bfloat16 or float16");
+  SGLM_CHECK_ARG(M >= 0 && M <= 64, "gemm16_nt: the weight-streaming kernel takes M <= 64 rows (got %ld)", (long)M);
+  SGLM_CHECK_ARG(N > 0 && N % 8 == 0 && K > 0 && K % 256 == 0 && N < (1ll << 31) && K < (1ll << 30),
+                 "gemm16_nt: N %% 8 == 0 and K %% 256 == 0 required (N=%ld K=%ld)", (long)N, (long)K);
+  SGLM_CHECK_ARG(x_stride_m >= K && w_stride_n >= K && x_stride_m % 8 == 0 && w_stride_n % 8 == 0,
+                 "gemm16_nt: row strides must be >= K and multiples of 8 elements");
+  SGLM_CHECK_ARG(N * w_stride_n * 2 < (1ll << 32), "gemm16_nt: weight larger than 4 GiB (32-bit lane offsets)");
+  if (M == 0) return 0;
+  SGLM_CHECK_ARG(x && weight && out, "gemm16_nt: null tensor pointer");
+  SGLM_CHECK_ARG(reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(weight) % 16 == 0 &&
+                     reinterpret_cast<uintptr_t>(out) % 16 == 0, "gemm16_nt: operands must be 16-byte aligned");
+  static const int throttle = [] { const char* e = getenv("SGL_MI355_GEMM16_THROTTLE"); return e ? atoi(e) : 0; }();  // A/B aid
+  G16Args p{(const uint8_t*)x, x_stride_m * 2, (const uint8_t*)weight, w_stride_n * 2, bias, out, (int)M, (int)N, (int)(K * 2), throttle};
+  hipStream_t s = as_stream(stream);
+#define G16_D(D)                                   \
+  do {                                             \
+    if (M <= 16) return launch16<D, 1>(p, s);      \
+    if (M <= 32) return launch16<D, 2>(p, s);      \
+    return launch16<D, 4>(p, s);                   \
+  } while (0)
+  if (dtype == SGL_MI355_BF16) G16_D(SGL_MI355_BF16);
+  G16_D(SGL_MI355_FP16);
+#undef G16_D
+}

@@ -294,7 +294,11 @@ class LlamaForCausalLM(torch.nn.Module):
         hidden_states, _ = self.norm(hidden_states, residual)
         if not self.with_lm_head:
             return hidden_states
-        logits = torch.matmul(hidden_states, self.lm_head.t())  # plain library GEMM (LM head)
+        # LM head (logits_processor.py:430-505): the 16-bit weight streamer at decode sizes, the library GEMM beyond 64 rows
+        if ops.linear16_supported(hidden_states.shape[0], self.lm_head.shape[0], self.lm_head.shape[1]):
+            logits = ops.linear16(hidden_states, self.lm_head)
+        else:
+            logits = torch.matmul(hidden_states, self.lm_head.t())
         if get_tensor_model_parallel_world_size() > 1:
             logits = get_tp_group().all_gather(logits, dim=-1)
         return logits

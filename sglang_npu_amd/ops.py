@@ -579,6 +579,28 @@ def rope_set_kv_from_partials(part: GemmPartials, positions, num_q_heads, num_k_
     return q
 
 
+def linear16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """F.linear(x, weight, bias) = x @ weight.T for decode-sized batches of 16-bit operands: the LM head of
+    LogitsProcessor._get_logits (logits_processor.py:430-505) and unquantised decode linears.  x [M <= 64, K],
+    weight [N, K] (K contiguous), both bf16 or both fp16."""
+    _need_gpu(x, weight, bias)
+    if x.dim() != 2 or weight.dim() != 2 or x.stride(1) != 1 or weight.stride(1) != 1:
+        raise RuntimeError("linear16: x [M,K] and weight [N,K] must be 2-D with a contiguous last dimension")
+    if x.dtype != weight.dtype or x.size(1) != weight.size(1):
+        raise RuntimeError("linear16: x and weight must share dtype and K")
+    M, K = x.shape
+    N = weight.size(0)
+    out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.lib().sgl_mi355_gemm16_nt(
+        _ptr(x), _ptr(weight), _ptr(bias), _ptr(out), _I64(M), _I64(N), _I64(K), _I64(x.stride(0) if M > 1 else K),
+        _I64(weight.stride(0) if N > 1 else K), _I(_dtype_code(x)), _stream(x)))
+    return out
+
+
+def linear16_supported(M: int, N: int, K: int) -> bool:
+    return 0 < M <= 64 and N % 8 == 0 and K % 256 == 0 and N * K * 2 < (1 << 32)
+
+
 # --------------------------------------------------------------------------- AWQ INT4
 def awq_dequantize(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tensor) -> torch.Tensor:
     """sgl_kernel.awq_dequantize(qweight, scales, qzeros) -- sgl-kernel/python/sgl_kernel/gemm.py:7-12,

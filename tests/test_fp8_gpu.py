@@ -251,3 +251,27 @@ def test_group_quant_vs_oracle_and_per_token_limit(T, K, G):
         assert torch.equal(s1, s2)
     with pytest.raises(NotImplementedError, match="UE8M0"):
         ops.sgl_per_token_group_quant_fp8(x.to(DEV), q, s, G, 1e-10, -448.0, 448.0, True)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M", [1, 7, 16, 33, 64])
+@pytest.mark.parametrize("N,K", [(128256, 4096), (32000, 4096), (1000, 512), (4096, 1024), (151936, 896 + 128)])
+def test_linear16_lm_head_vs_fp64(M, N, K, dtype):
+    """LM head / unquantised decode linear (logits_processor.py:430-505): x @ W^T in 16 bit with fp32 accumulation.
+    Reference: an fp64 product of the same 16-bit values (order-free) rounded once -- one output ulp."""
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    x = torch.randn(M, K, device=DEV, generator=g).to(dtype)
+    w = (torch.randn(N, K, device=DEV, generator=g) * 0.05).to(dtype)
+    bias = torch.randn(N, device=DEV, generator=g).to(dtype) if M % 2 == 0 else None
+    out = ops.linear16(x, w, bias)
+    ref = x.double() @ w.double().t()
+    if bias is not None:
+        ref = ref + bias.double()
+    ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    torch.testing.assert_close(out.double(), ref, rtol=ulp, atol=ulp * float(ref.abs().max()) * 0.05)
+    # rows of a wider activation matrix (strided view) give the same result
+    wide = torch.zeros(M, K + 64, device=DEV, dtype=dtype)
+    wide[:, :K] = x
+    assert torch.equal(ops.linear16(wide[:, :K], w, bias), out)
+    with pytest.raises(RuntimeError, match="M <= 64"):
+        ops.linear16(torch.zeros(65, K, device=DEV, dtype=dtype), w)
