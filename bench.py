@@ -499,6 +499,9 @@ def main():
             stub_ms = float(t.item()) / n_stub * 1e3
             ar_info = {"ms_per_step_allreduce_stubbed": round(stub_ms, 4),
                        "overhead_frac": round(max(0.0, (ms_per_step - stub_ms) / ms_per_step), 4),
+                       "backend": ("p2p kernel over IPC buffers (verified against the process group at start-up), fused "
+                                   "with the next add+RMSNorm" if tp_group.ca_comm is not None and not tp_group.ca_comm.disabled
+                                   else "rccl (torch.distributed)"),
                        "collectives_per_step": 2 * len(net.layers) + 1,
                        "message_bytes": args.batch * cfg.hidden_size * 2}
         finally:

@@ -453,6 +453,16 @@ int sgl_mi355_ar_open_peers(void* comm, const void* all_handles);
 int sgl_mi355_ar_set_peers_local(void* comm, void* const* comms);
 int sgl_mi355_ar_set_spin_limit(int64_t spins);
 int sgl_mi355_ar_all_reduce(void* comm, const void* inp, void* out, int64_t nbytes, int dtype, void* stream);
+/* All-reduce (SUM over the ranks) of `inp` [num_tokens, hidden] + residual add + RMSNorm (+ optional per-token FP8
+ * quant) in one kernel: what RMSNorm.forward_with_allreduce_fusion (layers/layernorm.py:191-216; seam
+ * layers/communicator.py:190-199,425-441 with RowParallelLinear.forward(can_fuse_mlp_allreduce=True),
+ * layers/linear.py:1285-1303) asks of a backend.  residual [num_tokens, hidden] is updated in place with
+ * round(all_reduce(inp) + residual); out (nullable) receives the normalised rows; out_q / out_s (nullable) their
+ * per-token e4m3 quantisation.  Bit-identical on every rank to ar_all_reduce followed by sgl_mi355_fused_add_rmsnorm /
+ * sgl_mi355_rmsnorm_quant_fp8.  hidden % (8 * world) == 0, hidden <= 16384, num_tokens * hidden * 2 <= max_bytes. */
+int sgl_mi355_ar_fused_add_rmsnorm(void* comm, const void* inp, void* residual, const void* weight, void* out,
+                                   void* out_q, float* out_s, int64_t num_tokens, int64_t hidden, float eps, int dtype,
+                                   void* stream);
 int sgl_mi355_ar_timed_out(void* comm, int* flag_out);
 int sgl_mi355_ar_destroy(void* comm);
 

@@ -180,6 +180,178 @@ __global__ __launch_bounds__(kThreads) void all_reduce_kernel(ArArgs a, const ui
   if (threadIdx.x == 0) *counter = call;
 }
 
+// ------------------------------------------------------------------------------------------
+// All-reduce + residual add + RMSNorm (+ per-token FP8 quant) in ONE kernel: the consumer of a row-parallel GEMM under
+// tensor parallelism (o_proj / down_proj -> the next norm).  Upstream seam: RowParallelLinear.forward(...,
+// can_fuse_mlp_allreduce=True) skips its collective (layers/linear.py:1285-1303) and
+// RMSNorm.forward_with_allreduce_fusion (layers/layernorm.py:191-216, called from layers/communicator.py:190-199,425-441)
+// performs it -- today only through flashinfer on sm100.  At Llama-3-70B TP = 8 a decode step has 160 such pairs on
+// [64, 8192] bf16 (1 MiB): a separate collective launch plus a norm launch each would be ~10 us of pure latency.
+//
+// Protocol = the two-shot all-reduce above with the reduce-scatter cut by COLUMNS and the all-gather fused into the
+// norm: block b owns row b (rows b + gridDim.x, ... for longer inputs) in every phase, on every rank:
+//   A  copy my row into my IPC buffer;                                     flag barrier 0
+//   B  rank r sums columns [r H/W, (r+1) H/W) of the row over all peers (rank order, fp32), rounds to the 16-bit
+//      dtype -- exactly the all-reduce's output value -- into its result area; flag barrier 1
+//   C  gather the W reduced column slices of the row, add the residual (fp32 sum, residual updated with its rounding),
+//      RMSNorm on the unrounded sum, optional per-token FP8 quant -- the arithmetic of rmsnorm_kernel (elementwise.hip).
+// Small inputs (one-shot: T H 2 B <= 256 KiB) skip phase B: phase C sums the peers' full rows itself.
+// Bit-identical to custom_all_reduce followed by fused_add_rmsnorm / rmsnorm_quant_fp8 on every rank.
+__device__ __forceinline__ float ar_block_sum(float v, float* red) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  const int nw = blockDim.x >> 6;
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = 0.f;
+  for (int i = 0; i < nw; ++i) r += red[i];
+  __syncthreads();
+  return r;
+}
+__device__ __forceinline__ float ar_block_max(float v, float* red) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+  const int nw = blockDim.x >> 6;
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = 0.f;
+  for (int i = 0; i < nw; ++i) r = fmaxf(r, red[i]);
+  __syncthreads();
+  return r;
+}
+
+// kNormThreads threads x kNormVPT 8-element vectors per row: the launcher picks the SAME pair as launch_rmsnorm
+// (elementwise.hip) would for the shape, so that the sum of squares is reduced in the same order and the result is
+// bit-identical to the unfused norm.
+template <int DTYPE, int kNormVPT, int kNormThreads>
+__global__ __launch_bounds__(kNormThreads) void ar_add_rmsnorm_kernel(
+    ArArgs a, const typename Half16<DTYPE>::T* inp /* may alias out */, typename Half16<DTYPE>::T* __restrict__ residual,
+    const typename Half16<DTYPE>::T* __restrict__ weight, typename Half16<DTYPE>::T* out,
+    uint8_t* __restrict__ out_q, float* __restrict__ out_s, int T, int H, float eps, int one_shot) {
+  using Hh = Half16<DTYPE>;
+  using x8 = typename Hh::x8;
+  __shared__ float red[kNormThreads / 64];
+  uint32_t* counter = reinterpret_cast<uint32_t*>(a.peer[a.rank] + kCounterOff) + blockIdx.x;
+  const uint32_t call = *counter + 1;
+  const int half = call & 1;
+  char* my_data = a.peer[a.rank] + a.data_off + half * a.half_bytes;
+  const size_t res_off = a.half_bytes / 2;
+  const int nv = H >> 3;            // vectors per row
+  const int nvs = nv / a.world;     // vectors per column slice
+  const int tid = threadIdx.x;
+
+  auto fail = [&]() {  // a peer never arrived: NaN rows instead of a norm over unsynchronised buffers
+    for (int row = blockIdx.x; row < T; row += gridDim.x)
+      for (int vi = tid; vi < nv; vi += kNormThreads) {
+        const uint4 bad{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+        if (out) reinterpret_cast<uint4*>(out + (int64_t)row * H)[vi] = bad;
+        if (out_q) reinterpret_cast<uint2*>(out_q + (int64_t)row * H)[vi] = uint2{0x7f7f7f7fu, 0x7f7f7f7fu};  // e4m3 NaN
+        if (out_s && vi == 0) out_s[row] = __builtin_nanf("");
+      }
+    if (tid == 0) *counter = call;
+  };
+
+  bool ok = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0;
+  if (ok) {
+    // phase A
+    for (int row = blockIdx.x; row < T; row += gridDim.x)
+      for (int vi = tid; vi < nv; vi += kNormThreads)
+        reinterpret_cast<uint4*>(my_data + (int64_t)row * H * 2)[vi] = reinterpret_cast<const uint4*>(inp + (int64_t)row * H)[vi];
+    ok = block_barrier(a, 0, call);
+  }
+  if (!ok) {
+    fail();
+    return;
+  }
+  if (!one_shot) {
+    // phase B: my column slice of my rows, summed in rank order, rounded like the all-reduce's output
+    for (int row = blockIdx.x; row < T; row += gridDim.x)
+      for (int vs = tid; vs < nvs; vs += kNormThreads) {
+        const int vi = a.rank * nvs + vs;
+        float f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int p = 0; p < a.world; ++p)
+          Acc8<DTYPE>::add(f, reinterpret_cast<const uint4*>(a.peer[p] + a.data_off + half * a.half_bytes + (int64_t)row * H * 2)[vi]);
+        reinterpret_cast<uint4*>(my_data + res_off + (int64_t)row * H * 2)[vi] = Acc8<DTYPE>::pack(f);
+      }
+    if (!block_barrier(a, 1, call)) {
+      fail();
+      return;
+    }
+  }
+  // phase C: gather + add + norm (+ quant), one row at a time
+  for (int row = blockIdx.x; row < T; row += gridDim.x) {
+    float v[kNormVPT][8];
+    x8 wq[kNormVPT];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < kNormVPT; ++i) {
+      const int vi = tid + kNormThreads * i;
+      if (vi < nv) {
+        wq[i] = reinterpret_cast<const x8*>(weight)[vi];
+        const x8 rv = reinterpret_cast<const x8*>(residual + (int64_t)row * H)[vi];
+        x8 xv;
+        if (one_shot) {
+          float f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+          for (int p = 0; p < a.world; ++p)
+            Acc8<DTYPE>::add(f, reinterpret_cast<const uint4*>(a.peer[p] + a.data_off + half * a.half_bytes + (int64_t)row * H * 2)[vi]);
+          xv = __builtin_bit_cast(x8, Acc8<DTYPE>::pack(f));
+        } else {
+          const int owner = vi / nvs;
+          xv = __builtin_bit_cast(x8, reinterpret_cast<const uint4*>(a.peer[owner] + a.data_off + half * a.half_bytes + res_off +
+                                                                    (int64_t)row * H * 2)[vi]);
+        }
+        x8 nr;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          v[i][j] = Hh::to_f32(xv[j]) + Hh::to_f32(rv[j]);  // the norm continues on the unrounded fp32 sum
+          nr[j] = Hh::from_f32(v[i][j]);
+          ss += v[i][j] * v[i][j];
+        }
+        reinterpret_cast<x8*>(residual + (int64_t)row * H)[vi] = nr;
+      }
+    }
+    ss = ar_block_sum(ss, red);
+    const float inv = 1.0f / sqrtf(ss / (float)H + eps);
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < kNormVPT; ++i) {
+      const int vi = tid + kNormThreads * i;
+      if (vi < nv) {
+        x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          o[j] = Hh::from_f32(v[i][j] * inv * Hh::to_f32(wq[i][j]));
+          v[i][j] = Hh::to_f32(o[j]);
+          amax = fmaxf(amax, fabsf(v[i][j]));
+        }
+        if (out) reinterpret_cast<x8*>(out + (int64_t)row * H)[vi] = o;
+      }
+    }
+    if (out_q) {
+      amax = ar_block_max(amax, red);
+      const float scale = amax / 448.0f;
+      if (tid == 0) out_s[row] = scale;
+      const float sinv = scale == 0.f ? 0.f : 1.0f / scale;
+#pragma unroll
+      for (int i = 0; i < kNormVPT; ++i) {
+        const int vi = tid + kNormThreads * i;
+        if (vi < nv) {
+          float f[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f[j] = fminf(fmaxf(v[i][j] * sinv, -448.0f), 448.0f);
+          int lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false);
+          lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+          int hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0, false);
+          hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+          reinterpret_cast<uint2*>(out_q + (int64_t)row * H)[vi] = uint2{(unsigned)lo, (unsigned)hi};
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) *counter = call;
+}
+
 }  // namespace
 }  // namespace sglm
 
@@ -298,6 +470,55 @@ extern "C" int sgl_mi355_ar_all_reduce(void* comm, const void* inp, void* out, i
   else
     hipLaunchKernelGGL((all_reduce_kernel<AccF32>), dim3(blocks), dim3(kThreads), 0, s, a, (const uint4*)inp, (uint4*)out, n16, two_shot);
   return check_hip(hipGetLastError(), "all_reduce_kernel launch");
+}
+
+extern "C" int sgl_mi355_ar_fused_add_rmsnorm(void* comm, const void* inp, void* residual, const void* weight, void* out,
+                                              void* out_q, float* out_s, int64_t num_tokens, int64_t hidden, float eps,
+                                              int dtype, void* stream) {
+  SGLM_CHECK_ARG(comm, "ar_fused_add_rmsnorm: null communicator");
+  ArComm* c = (ArComm*)comm;
+  SGLM_CHECK_ARG(dtype == SGL_MI355_BF16 || dtype == SGL_MI355_FP16, "ar_fused_add_rmsnorm: dtype must be bfloat16 or float16");
+  SGLM_CHECK_ARG(num_tokens >= 0 && hidden > 0 && hidden % (8 * c->world) == 0 && hidden <= 16384,
+                 "ar_fused_add_rmsnorm: hidden (%ld) must be a multiple of 8 x world (%d) and at most 16384", (long)hidden,
+                 c->world);
+  const int64_t nbytes = num_tokens * hidden * 2;
+  SGLM_CHECK_ARG((size_t)nbytes <= c->max_bytes, "ar_fused_add_rmsnorm: %ld B exceeds the registered capacity %ld B", (long)nbytes,
+                 (long)c->max_bytes);
+  if (num_tokens == 0) return 0;
+  SGLM_CHECK_ARG(inp && residual && weight && (out || out_q), "ar_fused_add_rmsnorm: null tensor pointer");
+  SGLM_CHECK_ARG(!out_q || out_s, "ar_fused_add_rmsnorm: out_q needs out_s");
+  for (int r = 0; r < c->world; ++r) SGLM_CHECK_ARG(c->peer[r] != nullptr, "ar_fused_add_rmsnorm: peer %d not opened", r);
+  ArArgs a{};
+  for (int r = 0; r < c->world; ++r) a.peer[r] = c->peer[r];
+  a.data_off = c->data_off; a.half_bytes = c->half_bytes; a.rank = c->rank; a.world = c->world;
+  a.status = reinterpret_cast<uint32_t*>(c->base + kStatusOff); a.status_host = c->status_dev; a.spin_limit = g_spin_limit;
+  const int one_shot = nbytes <= 256 * 1024 || c->world == 1;
+  const int blocks = (int)(num_tokens < kMaxBlocks ? num_tokens : kMaxBlocks);
+  hipStream_t s = as_stream(stream);
+  // threads / vectors per thread exactly as launch_rmsnorm (elementwise.hip): few long rows take 512 / 1024 threads
+  const int nv = (int)(hidden >> 3);
+  const bool wide = num_tokens <= 2048 && nv >= 512 && nv <= 2048;
+  const int vpt256 = (nv + 255) / 256;
+#define ARN(D, V, NT_)                                                                                                    \
+  hipLaunchKernelGGL((ar_add_rmsnorm_kernel<D, V, NT_>), dim3(blocks), dim3(NT_), 0, s, a, (const Half16<D>::T*)inp,     \
+                     (Half16<D>::T*)residual, (const Half16<D>::T*)weight, (Half16<D>::T*)out, (uint8_t*)out_q, out_s, \
+                     (int)num_tokens, (int)hidden, eps, one_shot)
+#define ARN_D(D)                                   \
+  do {                                             \
+    if (wide) {                                    \
+      if (nv <= 512) ARN(D, 1, 512);               \
+      else if (nv <= 1024) ARN(D, 1, 1024);        \
+      else ARN(D, 2, 1024);                        \
+    } else if (vpt256 <= 1) ARN(D, 1, 256);        \
+    else if (vpt256 <= 2) ARN(D, 2, 256);          \
+    else if (vpt256 <= 4) ARN(D, 4, 256);          \
+    else ARN(D, 8, 256);                           \
+  } while (0)
+  if (dtype == SGL_MI355_BF16) ARN_D(SGL_MI355_BF16);
+  else ARN_D(SGL_MI355_FP16);
+#undef ARN_D
+#undef ARN
+  return check_hip(hipGetLastError(), "ar_add_rmsnorm_kernel launch");
 }
 
 extern "C" int sgl_mi355_ar_timed_out(void* comm, int* flag_out) {

@@ -110,6 +110,41 @@ class CustomAllreduce:
             ct.c_void_p(torch.cuda.current_stream(inp.device).cuda_stream)))
         return out
 
+    def should_fuse_norm(self, inp: torch.Tensor) -> bool:
+        """Shapes the fused all-reduce + add + RMSNorm kernel takes (sgl_mi355_ar_fused_add_rmsnorm)."""
+        if self.disabled or not inp.is_cuda or inp.dim() != 2 or not inp.is_contiguous():
+            return False
+        H = inp.size(1)
+        return inp.dtype in (torch.bfloat16, torch.float16) and H % (8 * self.world_size) == 0 and H <= 16384 and \
+            0 < inp.numel() * 2 <= self.max_size
+
+    def fused_add_rmsnorm(self, inp: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float,
+                          quant_fp8: bool = False):
+        """all_reduce(inp) + residual -> residual (in place); RMSNorm of the sum -> a new tensor, or with quant_fp8 its
+        per-token e4m3 quantisation (q, scale).  One kernel; bit-identical to custom_all_reduce + fused_add_rmsnorm
+        (+ sgl_per_token_quant_fp8).  The role of flashinfer_allreduce_residual_rmsnorm behind
+        RMSNorm.forward_with_allreduce_fusion (layers/layernorm.py:191-216)."""
+        from . import _lib
+        if self.timed_out():
+            self.disabled = True
+            raise RuntimeError("custom all-reduce: a peer did not reach the barrier in time; the affected outputs were "
+                               "filled with NaN and this communicator is disabled")
+        T, H = inp.shape
+        ct = self._ct
+        out = q = s = None
+        if quant_fp8:
+            q = torch.empty((T, H), dtype=torch.float8_e4m3fn, device=inp.device)
+            s = torch.empty((T, 1), dtype=torch.float32, device=inp.device)
+        else:
+            out = torch.empty_like(inp)
+        _lib.check(self._lib.sgl_mi355_ar_fused_add_rmsnorm(
+            self._comm, ct.c_void_p(inp.data_ptr()), ct.c_void_p(residual.data_ptr()), ct.c_void_p(weight.data_ptr()),
+            ct.c_void_p(out.data_ptr()) if out is not None else None, ct.c_void_p(q.data_ptr()) if q is not None else None,
+            ct.c_void_p(s.data_ptr()) if s is not None else None, ct.c_int64(T), ct.c_int64(H), ct.c_float(eps),
+            ct.c_int(0 if inp.dtype == torch.bfloat16 else 1),
+            ct.c_void_p(torch.cuda.current_stream(inp.device).cuda_stream)))
+        return (q, s) if quant_fp8 else out
+
     @contextlib.contextmanager
     def capture(self):
         """Reference surface (custom_all_reduce.py:248-262 registers graph buffers when the capture ends).  Inputs are
@@ -218,9 +253,59 @@ def init_distributed_environment(backend: Optional[str] = None, device: Optional
             kwargs["device_id"] = device
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
     _TP = GroupCoordinator(dist.group.WORLD, rank, world, device)
-    if os.environ.get("SGL_MI355_CUSTOM_AR") == "1" and device is not None and device.type == "cuda":
-        _TP.ca_comm = CustomAllreduce(dist.group.WORLD, device)
+    # P2P all-reduce: SGL_MI355_CUSTOM_AR=1 on, =0 off, unset = "verify": build it, check it against the process
+    # group's own all-reduce on this very node (integer payloads: exact), and keep it only if EVERY rank agrees --
+    # otherwise RCCL stays the data plane.  (The kernel has been exercised with ranks sharing one GPU and with all ranks
+    # in one process; this start-up check is what covers the first run across xGMI.)
+    mode = os.environ.get("SGL_MI355_CUSTOM_AR", "verify")
+    if mode != "0" and device is not None and device.type == "cuda" and world in CustomAllreduce._SUPPORTED_WORLD_SIZES:
+        try:
+            ca = CustomAllreduce(dist.group.WORLD, device)
+            ok = (not ca.disabled) and (mode == "1" or _verify_custom_ar(ca, _TP))
+        except Exception as e:  # IPC mapping refused, library missing an entry point, ...
+            ca, ok = None, False
+            if rank == 0:
+                print(f"[sglang_npu_amd] P2P all-reduce unavailable ({type(e).__name__}: {e}); using RCCL", flush=True)
+        flag = torch.tensor([1 if ok else 0], device=device, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            _TP.ca_comm = ca
+        elif ca is not None:
+            ca.close()
     return _TP
+
+
+def _verify_custom_ar(ca: "CustomAllreduce", tp: "GroupCoordinator") -> bool:
+    """One-shot and two-shot all-reduce and the fused all-reduce + add + RMSNorm against the process group's
+    all-reduce + the plain ops, on integer-valued payloads (sums exact in bf16): True only if everything matches."""
+    from . import ops
+    dev, rank, world = tp.device, tp.rank_in_group, tp.world_size
+    try:
+        for n in (4096, 1 << 19):  # 8 KiB (one-shot) and 1 MiB (two-shot) of bf16
+            g = torch.Generator(device=dev).manual_seed(100 + rank)
+            x = torch.randint(-3, 4, (n,), device=dev, generator=g).to(torch.bfloat16)
+            ref = x.clone()
+            dist.all_reduce(ref, group=tp.device_group)
+            for _ in range(2):  # both halves of the double buffer
+                out = ca.custom_all_reduce(x)
+                torch.cuda.synchronize(dev)
+                if out is None or ca.timed_out() or not torch.equal(out, ref):
+                    return False
+        T, H = 64, 1024 * world
+        g = torch.Generator(device=dev).manual_seed(7)
+        part = torch.randint(-2, 3, (T, H), device=dev, generator=g).to(torch.bfloat16) * (rank + 1)
+        res = torch.randint(-2, 3, (T, H), device=dev, generator=g).to(torch.bfloat16)
+        w = torch.ones(H, device=dev, dtype=torch.bfloat16)
+        red = part.clone()
+        dist.all_reduce(red, group=tp.device_group)
+        res_ref = res.clone()
+        ops.fused_add_rmsnorm(red, res_ref, w, 1e-5)
+        res2 = res.clone()
+        got = ca.fused_add_rmsnorm(part, res2, w, 1e-5)
+        torch.cuda.synchronize(dev)
+        return (not ca.timed_out()) and torch.equal(got, red) and torch.equal(res2, res_ref)
+    except RuntimeError:
+        return False
 
 
 def get_tp_group() -> GroupCoordinator:

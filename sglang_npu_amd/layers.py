@@ -28,6 +28,22 @@ class RMSNorm(torch.nn.Module):
             return x, residual
         return ops.rmsnorm(x, self.weight.data, self.variance_epsilon)
 
+    def forward_with_allreduce_fusion(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None, quant_fp8: bool = False):
+        """layers/layernorm.py:191-216: `x` is a row-parallel GEMM's output whose all-reduce was skipped
+        (RowParallelLinear.forward(..., can_fuse_mlp_allreduce=True), linear.py:1285-1303); do the collective, the
+        residual add and the norm here -- in one kernel when the P2P communicator takes the shape, else the plain
+        sequence.  quant_fp8: return ((q, scale), residual) for the FP8 linear that follows."""
+        from .distributed import get_tp_group, tensor_model_parallel_all_reduce
+        tp = get_tp_group()
+        ca = tp.ca_comm
+        if residual is not None and tp.world_size > 1 and not tp.stub_all_reduce and ca is not None and ca.should_fuse_norm(x):
+            r = ca.fused_add_rmsnorm(x, residual, self.weight.data, self.variance_epsilon, quant_fp8)
+            return r, residual
+        x = tensor_model_parallel_all_reduce(x)
+        if quant_fp8:
+            return self.forward_quant_fp8(x, residual)
+        return self.forward(x, residual)
+
     def forward_quant_fp8(self, x, residual=None):
         """Fused (add +) norm + per-token FP8 quant; returns ((q, scale), residual)."""
         q, s, _ = ops.rmsnorm_quant_fp8(x, self.weight.data, self.variance_epsilon, residual=residual)

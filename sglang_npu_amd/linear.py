@@ -145,7 +145,20 @@ class RowParallelLinear(LinearBase):
         else:
             param.load_row_parallel_weight(loaded_weight)
 
-    def _reduce(self, out, async_reduce: bool):
+    def _can_fuse(self, out) -> bool:
+        ca = get_tp_group().ca_comm
+        return (self.reduce_results and get_tensor_model_parallel_world_size() > 1 and not get_tp_group().stub_all_reduce
+                and ca is not None and out.dim() == 2 and ca.should_fuse_norm(out))
+
+    def _reduce(self, out, async_reduce: bool, can_fuse_mlp_allreduce: bool = False):
+        if can_fuse_mlp_allreduce and self._can_fuse(out):
+            # linear.py:1302: the collective is left to the next norm (RMSNorm.forward_with_allreduce_fusion); the
+            # partial sum travels tagged the way upstream tags it (communicator.py:190-199, deepseek_v2.py:1924)
+            out._sglang_needs_allreduce_fusion = True
+            return out
+        return self._reduce_now(out, async_reduce)
+
+    def _reduce_now(self, out, async_reduce: bool):
         """linear.py:1302-1303.  async_reduce: the collective goes to the TP group's side stream and an
         AllReduceHandle comes back instead of the tensor; its consumer (the next norm) calls wait(), which fences the
         main stream on the collective's event -- whatever the main stream launches in between overlaps it."""
@@ -155,10 +168,10 @@ class RowParallelLinear(LinearBase):
             return get_tp_group().all_reduce_async(out)
         return tensor_model_parallel_all_reduce(out)
 
-    def forward(self, x, async_reduce: bool = False):
+    def forward(self, x, async_reduce: bool = False, can_fuse_mlp_allreduce: bool = False):
         bias_ = None if (get_tensor_model_parallel_rank() > 0) else self.bias
         out = self.quant_method.apply(self, x, bias_)
-        return self._reduce(out, async_reduce), None
+        return self._reduce(out, async_reduce, can_fuse_mlp_allreduce), None
 
     def forward_prequantized_partials(self, qinput, x_scale, out_dtype):
         """Split-K partials for a fused consumer; only without tensor parallelism (the all-reduce needs the
@@ -168,7 +181,8 @@ class RowParallelLinear(LinearBase):
             return None
         return fn(self, qinput, x_scale, out_dtype, self.bias)
 
-    def forward_prequantized(self, qinput, x_scale, out_dtype, async_reduce: bool = False):
+    def forward_prequantized(self, qinput, x_scale, out_dtype, async_reduce: bool = False,
+                             can_fuse_mlp_allreduce: bool = False):
         bias_ = None if (get_tensor_model_parallel_rank() > 0) else self.bias
         out = self.quant_method.apply_prequantized(self, qinput, x_scale, out_dtype, bias_)
-        return self._reduce(out, async_reduce), None
+        return self._reduce(out, async_reduce, can_fuse_mlp_allreduce), None

@@ -52,6 +52,16 @@ def _arrived(h):
     return h.wait() if isinstance(h, AllReduceHandle) else h
 
 
+# With the P2P communicator on (SGL_MI355_CUSTOM_AR=1) row-parallel layers skip their collective and the next norm runs
+# all-reduce + residual add + RMSNorm (+ FP8 quant) as ONE kernel (upstream seam: can_fuse_mlp_allreduce /
+# RMSNorm.forward_with_allreduce_fusion).  SGL_MI355_NO_AR_FUSION=1 keeps them apart.
+FUSE_AR_NORM = not os.environ.get("SGL_MI355_NO_AR_FUSION")
+
+
+def _unreduced(h) -> bool:
+    return isinstance(h, torch.Tensor) and getattr(h, "_sglang_needs_allreduce_fusion", False)
+
+
 # fewest decode rows for which GEMM epilogues are deferred into the consumer kernels (tuning: SGL_MI355_DEFER_MIN_ROWS)
 DEFER_MIN_ROWS = int(os.environ.get("SGL_MI355_DEFER_MIN_ROWS", "32"))
 # widest per-rank gate_up (2 * intermediate / tp) that goes through split-K partials + fused SiLU (tuning: SGL_MI355_GATE_UP_PARTIALS_MAX_N)
@@ -69,7 +79,7 @@ class LlamaMLP(torch.nn.Module):
     def forward(self, x):
         gate_up, _ = self.gate_up_proj(x)
         x = self.act_fn(gate_up)
-        x, _ = self.down_proj(x, async_reduce=ASYNC_AR)
+        x, _ = self.down_proj(x, async_reduce=ASYNC_AR, can_fuse_mlp_allreduce=FUSE_AR_NORM)
         return x
 
     def forward_fp8(self, xq, xs, out_dtype, defer: bool = False):
@@ -88,7 +98,8 @@ class LlamaMLP(torch.nn.Module):
             part = self.down_proj.forward_prequantized_partials(aq, a_s, out_dtype)
             if part is not None:
                 return part
-        x, _ = self.down_proj.forward_prequantized(aq, a_s, out_dtype, async_reduce=ASYNC_AR)
+        x, _ = self.down_proj.forward_prequantized(aq, a_s, out_dtype, async_reduce=ASYNC_AR,
+                                                  can_fuse_mlp_allreduce=FUSE_AR_NORM)
         return x
 
 
@@ -115,7 +126,7 @@ class LlamaAttention(torch.nn.Module):
         q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
         q, k = self.rotary_emb(positions, q, k)
         attn_output = self.attn(q, k, v, forward_batch)
-        output, _ = self.o_proj(attn_output, async_reduce=ASYNC_AR)
+        output, _ = self.o_proj(attn_output, async_reduce=ASYNC_AR, can_fuse_mlp_allreduce=FUSE_AR_NORM)
         return output
 
     def forward_fp8(self, positions, xq, xs, forward_batch: ForwardBatch, out_dtype, defer: bool = False):
@@ -147,13 +158,14 @@ class LlamaAttention(torch.nn.Module):
             a_s = torch.empty((a2.shape[0], 1), dtype=torch.float32, device=a2.device)
             ops.sgl_per_token_quant_fp8(a2, aq, a_s)
         else:
-            output, _ = self.o_proj(attn_output, async_reduce=ASYNC_AR)
+            output, _ = self.o_proj(attn_output, async_reduce=ASYNC_AR, can_fuse_mlp_allreduce=FUSE_AR_NORM)
             return output
         if defer:  # leave the o_proj epilogue to post_attention_layernorm
             part = self.o_proj.forward_prequantized_partials(aq, a_s, out_dtype)
             if part is not None:
                 return part
-        output, _ = self.o_proj.forward_prequantized(aq, a_s, out_dtype, async_reduce=ASYNC_AR)
+        output, _ = self.o_proj.forward_prequantized(aq, a_s, out_dtype, async_reduce=ASYNC_AR,
+                                                      can_fuse_mlp_allreduce=FUSE_AR_NORM)
         return output
 
 
@@ -170,10 +182,15 @@ class LlamaDecoderLayer(torch.nn.Module):
         if residual is None:
             residual = hidden_states
             hidden_states = self.input_layernorm(hidden_states)
+        elif _unreduced(hidden_states):  # communicator.py:190-199
+            hidden_states, residual = self.input_layernorm.forward_with_allreduce_fusion(hidden_states, residual)
         else:
             hidden_states, residual = self.input_layernorm(hidden_states, residual)
-        hidden_states = self.self_attn(positions, hidden_states, forward_batch)
-        hidden_states, residual = self.post_attention_layernorm(_arrived(hidden_states), residual)
+        hidden_states = _arrived(self.self_attn(positions, hidden_states, forward_batch))
+        if _unreduced(hidden_states):
+            hidden_states, residual = self.post_attention_layernorm.forward_with_allreduce_fusion(hidden_states, residual)
+        else:
+            hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
         hidden_states = self.mlp(hidden_states)
         return hidden_states, residual
 
@@ -183,6 +200,8 @@ class LlamaDecoderLayer(torch.nn.Module):
         ops.GemmPartials left by the previous layer's down_proj (defer=True)."""
         def norm_quant(norm, h, res):
             h = _arrived(h)  # a row-parallel GEMM's all-reduce still running on the side stream
+            if _unreduced(h) and res is not None:  # all-reduce + add + norm + quant in one kernel
+                return norm.forward_with_allreduce_fusion(h, res, quant_fp8=True)[0]
             if isinstance(h, ops.GemmPartials):  # the producer GEMM left its epilogue to this kernel
                 return ops.rmsnorm_quant_fp8_from_partials(h, res, norm.weight.data, norm.variance_epsilon)
             q, s_, _ = ops.rmsnorm_quant_fp8(h, norm.weight.data, norm.variance_epsilon, residual=res)
@@ -286,12 +305,19 @@ class LlamaForCausalLM(torch.nn.Module):
         hidden_states = _arrived(hidden_states)
         if isinstance(hidden_states, ops.GemmPartials):
             hidden_states = hidden_states.finalize()
+        pending_ar = _unreduced(hidden_states)  # the last layer's down_proj left its all-reduce to the final norm
         if forward_batch.forward_mode.is_extend() and forward_batch.extend_seq_lens is not None:
             # LogitsProcessor (logits_processor.py:430-470): prefill only needs the last position of every request
             last = torch.cumsum(forward_batch.extend_seq_lens, dim=0) - 1
-            hidden_states = hidden_states[last]
+            hidden_states = hidden_states[last]  # (a new tensor: the tag does not travel with it)
             residual = residual[last] if residual is not None else None
-        hidden_states, _ = self.norm(hidden_states, residual)
+        if pending_ar:
+            if residual is not None and residual.is_contiguous() and hidden_states.is_contiguous():
+                hidden_states, _ = self.norm.forward_with_allreduce_fusion(hidden_states, residual)
+            else:
+                hidden_states, _ = self.norm(get_tp_group().all_reduce(hidden_states.contiguous()), residual)
+        else:
+            hidden_states, _ = self.norm(hidden_states, residual)
         if not self.with_lm_head:
             return hidden_states
         # LM head (logits_processor.py:430-505): the 16-bit weight streamer at decode sizes, the library GEMM beyond 64 rows

@@ -141,6 +141,44 @@ def _local_ranks_worker(world, q):
                     torch.cuda.synchronize()
                     for r in range(world):
                         assert torch.equal(outs[r], ref), (dt, nbytes, r, rep)
+        # all-reduce + residual add + RMSNorm (+ FP8 quant) in one kernel == the three separate ops, bit for bit, on
+        # every rank; one-shot (small) and two-shot (column-sliced) forms, several calls in a row (double buffering)
+        from sglang_npu_amd import ops
+        for dt in (torch.bfloat16, torch.float16):
+            for (T, H) in [(4, 1024), (64, 8192), (7, 4096), (130, 2048)]:
+                if H % (8 * world):
+                    continue
+                g = torch.Generator().manual_seed(T * H + world)
+                parts = [(torch.randn(T, H, generator=g) * 0.5).to(dt).to(dev) for _ in range(world)]
+                res0 = torch.randn(T, H, generator=g).to(dt).to(dev)
+                w = (torch.rand(H, generator=g) + 0.5).to(dt).to(dev)
+                for quant in (False, True):
+                    torch.cuda.synchronize()
+                    ars = []
+                    for r in range(world):
+                        with torch.cuda.stream(streams[r]):
+                            ars.append(comms[r].custom_all_reduce(parts[r].view(-1)).view(T, H))
+                    torch.cuda.synchronize()
+                    assert all(torch.equal(ars[0], a) for a in ars)
+                    res_ref = res0.clone()
+                    if quant:
+                        q_ref, s_ref, _ = ops.rmsnorm_quant_fp8(ars[0], w, 1e-5, residual=res_ref)
+                    else:
+                        x_ref = ars[0].clone()
+                        ops.fused_add_rmsnorm(x_ref, res_ref, w, 1e-5)
+                    torch.cuda.synchronize()
+                    outs, ress = [], [res0.clone() for _ in range(world)]
+                    for r in range(world):
+                        assert comms[r].should_fuse_norm(parts[r])
+                        with torch.cuda.stream(streams[r]):
+                            outs.append(comms[r].fused_add_rmsnorm(parts[r], ress[r], w, 1e-5, quant_fp8=quant))
+                    torch.cuda.synchronize()
+                    for r in range(world):
+                        assert torch.equal(ress[r], res_ref), ("residual", dt, T, H, quant, r)
+                        if quant:
+                            assert torch.equal(outs[r][1], s_ref) and torch.equal(outs[r][0].view(torch.uint8), q_ref.view(torch.uint8))
+                        else:
+                            assert torch.equal(outs[r], x_ref), ("norm", dt, T, H, r)
         assert not any(c.timed_out() for c in comms)
         for c in comms:
             c.close()
@@ -150,7 +188,7 @@ def _local_ranks_worker(world, q):
         q.put(traceback.format_exc())
 
 
-@pytest.mark.parametrize("world", [6, 8])
+@pytest.mark.parametrize("world", [2, 6, 8])
 @pytest.mark.timeout(300)
 def test_p2p_all_reduce_six_and_eight_ranks_in_one_process(world):
     ctx = mp.get_context("spawn")

@@ -1,0 +1,117 @@
+"""GPU: the tensor-parallel decoder stack with TWO ranks sharing the one GPU of the box (gloo carries the IPC handle
+exchange; the P2P all-reduce kernel carries the data, as it would over xGMI).  Checks, on a 2-layer Llama-3-8B-shaped FP8
+stack at bs = 64:
+  * the three ways a row-parallel layer's collective can run give the SAME bits: in-stream all-reduce + norm, side-stream
+    all-reduce (AllReduceHandle) + norm, and the fused all-reduce + residual add + RMSNorm + FP8 quant kernel;
+  * both ranks hold identical hidden states afterwards;
+  * the TP = 2 result agrees with the TP = 1 stack to bf16 accumulation noise (different summation split).
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_stack(tp_rank, tp_world, device, fuse, async_ar):
+    """One prefill-free decode step of a 2-layer stack (with_lm_head=False: the output is the final hidden state)."""
+    from sglang_npu_amd import model as M
+    from sglang_npu_amd.harness import (ForwardBatch, ForwardMode, MHATokenToKVPool, ModelRunnerLike, ReqToTokenPool,
+                                        ServerArgs, install_attention_backend)
+    M.FUSE_AR_NORM, M.ASYNC_AR = fuse, async_ar
+    cfg = M.LLAMA3_8B
+    B, ctx = 64, 96
+    net = M.LlamaForCausalLM(cfg, "w8a8_fp8", torch.bfloat16, str(device), num_layers=2, with_lm_head=False).load_dummy_weights()
+    max_len = ctx + 4
+    n_tok = B * max_len + 1
+    r2t_pool = ReqToTokenPool(B, max_len, str(device))
+    kv_pool = MHATokenToKVPool(n_tok, 1, torch.bfloat16, cfg.get_num_kv_heads(tp_world), cfg.head_dim, 2, str(device))
+    g = torch.Generator(device=device).manual_seed(1234 + 7 * tp_rank * 0)
+    # every rank fills ITS kv heads from the same full-head tensor so that TP = 1 and TP = 2 see the same cache
+    hkv_full = cfg.num_key_value_heads
+    per = hkv_full // tp_world
+    for l in range(2):
+        rows = kv_pool.k_buffer[l].shape[0]  # size + page_size (memory_pool.py:222-241)
+        kf = torch.randn(rows, hkv_full, cfg.head_dim, device=device, generator=g, dtype=torch.float32).bfloat16()
+        vf = torch.randn(rows, hkv_full, cfg.head_dim, device=device, generator=g, dtype=torch.float32).bfloat16()
+        kv_pool.k_buffer[l].copy_(kf[:, tp_rank * per:(tp_rank + 1) * per])
+        kv_pool.v_buffer[l].copy_(vf[:, tp_rank * per:(tp_rank + 1) * per])
+    perm = (torch.randperm(n_tok - 1, device=device, generator=g) + 1).to(torch.int32)
+    r2t_pool.req_to_token.copy_(perm[: B * max_len].view(B, max_len))
+    runner = ModelRunnerLike(cfg, r2t_pool, kv_pool, str(device), 0, tp_world, ServerArgs())
+    backend = install_attention_backend(runner)
+    ids = torch.randint(0, 10000, (B,), device=device, generator=g)
+    seq = torch.full((B,), ctx, dtype=torch.int64, device=device)
+    pos = seq - 1
+    rpi = torch.arange(B, dtype=torch.int64, device=device)
+    loc = r2t_pool.req_to_token[rpi, pos].to(torch.int64)
+    fb = ForwardBatch(ForwardMode.DECODE, B, ids, rpi, seq, loc, B * ctx, None, pos, req_to_token_pool=r2t_pool,
+                      token_to_kv_pool=kv_pool, attn_backend=backend)
+    backend.init_forward_metadata(fb)
+    out = net(ids, pos, fb)
+    torch.cuda.synchronize()
+    return out.float().cpu()
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        import torch.distributed as dist
+        from sglang_npu_amd import distributed as D
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        tp = D.GroupCoordinator(dist.group.WORLD, rank, world, dev)
+        tp.ca_comm = D.CustomAllreduce(dist.group.WORLD, dev, max_size=8 * 1024 * 1024)
+        D.set_tp_group(tp)
+        outs = {}
+        for name, fuse, asy in (("sync", False, False), ("async", False, True), ("fused", True, False)):
+            dist.barrier()
+            outs[name] = _run_stack(rank, world, dev, fuse, asy)
+        assert torch.equal(outs["sync"], outs["async"]), "side-stream all-reduce changed the result"
+        assert torch.equal(outs["sync"], outs["fused"]), "fused all-reduce + norm kernel changed the result"
+        gathered = [None] * world
+        dist.all_gather_object(gathered, outs["fused"])
+        assert all(torch.equal(gathered[0], t) for t in gathered), "ranks disagree"
+        assert not tp.ca_comm.timed_out()
+        dist.barrier()
+        tp.ca_comm.close()
+        q.put((rank, "ok", outs["fused"].numpy() if rank == 0 else None))  # numpy: plain pickling, no shared-memory fds
+    except Exception:
+        import traceback
+        q.put((rank, traceback.format_exc(), None))
+
+
+@pytest.mark.timeout(600)
+def test_tp2_stack_three_collective_forms_agree_and_match_tp1():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=500) for _ in procs]
+    for p in procs:
+        p.join(30)
+    tp2 = None
+    for rank, msg, out in res:
+        assert msg == "ok", f"rank {rank}: {msg}"
+        tp2 = torch.from_numpy(out) if out is not None else tp2
+    from sglang_npu_amd import distributed as D
+    D.set_tp_group(D.GroupCoordinator(None, 0, 1, torch.device("cuda", 0)))
+    tp1 = _run_stack(0, 1, torch.device("cuda", 0), False, False)
+    err, scale = float((tp1 - tp2).abs().max()), float(tp1.abs().max())
+    assert err <= 2.0 ** -5 * scale, f"TP=2 vs TP=1 hidden states: {err:.3e} (max {scale:.3e})"
