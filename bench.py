@@ -42,7 +42,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PMC_SUMMARY = "r01_decode_pmc_summary.json"  # refreshed per round when the kernel changes
+PMC_SUMMARY = "r02_decode_pmc_summary.json"  # refreshed per round when the kernel changes
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 
 

@@ -105,6 +105,9 @@ union Frag32 {  // 32 contiguous K bytes of one row = four MFMA operands
 #ifndef SGLM_W_NT
 #define SGLM_W_NT 0
 #endif
+#ifndef SGLM_SLAB_SC1
+#define SGLM_SLAB_SC1 0
+#endif
 __device__ __forceinline__ void gload32_asm(Frag32& f, const uint8_t* sbase, uint32_t voff) {
 #if SGLM_W_NT
   asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(f.x[0]) : "v"(voff), "s"(sbase) : "memory");
@@ -912,8 +915,16 @@ __global__ __launch_bounds__(576) void fp8_gemm_wstream_kernel(GemmArgs p, float
     for (int c = lane; c < ROWS * 4; c += 64) {
       const int m = c >> 2, q = c & 3;
       const int nn = nb * 16 + q * 4;
-      if (m < p.M && nn < p.N)
+      if (m < p.M && nn < p.N) {
+#if SGLM_SLAB_SC1
+        // write-through: the slab leaves L2 while the kernel is still streaming instead of at its end
+        const f32x4 val = *reinterpret_cast<const f32x4*>(ep + m * 20 + q * 4);
+        float* gp = dst + (int64_t)m * p.N + nn;
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(gp), "v"(val) : "memory");
+#else
         *reinterpret_cast<f32x4*>(dst + (int64_t)m * p.N + nn) = *reinterpret_cast<const f32x4*>(ep + m * 20 + q * 4);
+#endif
+      }
     }
   } else {
     // ---- epilogue through a wave-private LDS patch (transposes to 16-B row segments)

@@ -1,7 +1,8 @@
-for f in none 4,7 4,8 8,7; do
+# same-box A/B of the unsplit FP8 weight streamer's (phase length, consumer waves): SGL_MI355_WSTREAM_FORCE="PH,nc"
+for f in none 4,4 4,5 4,6 8,4; do
   if [ $f = none ]; then unset SGL_MI355_WSTREAM_FORCE; else export SGL_MI355_WSTREAM_FORCE=$f; fi
   python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>&1 | tail -1 | python -c "
 import sys,json
 d=json.loads(sys.stdin.read()); g=d['roofline_gemm']
-print('$f', d['ms_per_step'], d['dropin_ms_per_step'], [(s['name'], s['decode']['us']) for s in g['shapes']])"
+print('$f', d['ms_per_step'], [(s['name'], s['decode']['us']) for s in g['shapes']])"
 done
