@@ -66,6 +66,9 @@ def parse():
                          "unfused operator order; the other one is reported beside it")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short runs of BASELINE configs 2, 4 and 5 (one rank emulated) that the default N=1 "
+                         "invocation reports beside the headline")
     return ap.parse_args()
 
 
@@ -372,11 +375,40 @@ def time_decode_gemms(net, cfg, B, device, tp):
     return out
 
 
+def other_configs():
+    """BASELINE configs 2 (bf16), 4 (Llama-2-7B AWQ) and 5 (Llama-3-70B FP8, ONE rank of TP = 8 with the collectives
+    stubbed) as short child runs of this script, started BEFORE this process touches the GPU; each contributes its
+    whole-step time, TTFT and attention roofline fraction to the headline's JSON line (`other_configs`)."""
+    import subprocess
+    runs = [("config 2: llama3-8b bf16 TP=1", ["--quant", "none"]),
+            ("config 4: llama2-7b AWQ INT4 g128 TP=1", ["--model", "llama2-7b", "--quant", "awq"]),
+            ("config 5 (ONE rank of TP=8 on one GPU, collectives stubbed -- not a job number): llama3-70b w8a8_fp8",
+             ["--model", "llama3-70b", "--emulate-tp", "8"])]
+    out = []
+    for name, extra in runs:
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "10", "--warmup", "3", "--no-cpu-baseline",
+               "--no-other-configs"] + extra
+        try:
+            r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=240)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+            d = json.loads(line)
+            out.append({"config": name, "ms_per_step": d["ms_per_step"], "tokens_per_s": d["value"],
+                        "ttft_ms_p50": d.get("ttft_ms_p50"), "decode_attention_frac_hbm": d["roofline"]["frac"],
+                        "workload": d["config"]["workload"]})
+        except Exception as e:  # a side measurement: never take the headline down with it
+            out.append({"config": name, "error": f"{type(e).__name__}: {str(e)[:200]}"})
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    others = None
+    if (world == 1 and args.gpus == 1 and not args.no_other_configs and args.model == "llama3-8b" and
+            args.quant == "w8a8_fp8" and args.emulate_tp == 0 and args.layers is None and args.kv_dtype == "auto"):
+        others = other_configs()
     if world != args.gpus:
         if args.gpus > 1 and world == 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
@@ -580,6 +612,8 @@ def main():
         except Exception as e:  # the baseline must never take the GPU number down with it
             out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         out["reference_cpu_container"] = reference_cpu_container()
+    if others is not None:
+        out["other_configs"] = others
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist_on:

@@ -79,8 +79,8 @@ class QuantizationConfig:
 
 # ----------------------------------------------------------------------------- unquantised
 class UnquantizedLinearMethod(LinearMethodBase):
-    """layers/quantization/unquant.py: F.linear.  Decode batches (<= 64 rows) run the 16-bit weight-streaming kernel
-    (csrc/gemm_bf16.hip); prefill sizes the library GEMM (hipBLASLt through torch) -- the bf16 plumbing config."""
+    """layers/quantization/unquant.py: F.linear.  Plain library GEMM (hipBLASLt through torch) -- the
+    bf16 plumbing config only; not part of the hand-written hot path."""
 
     def create_weights(self, layer, input_size_per_partition, output_partition_sizes, input_size, output_size,
                        params_dtype, **extra_weight_attrs):
@@ -89,12 +89,10 @@ class UnquantizedLinearMethod(LinearMethodBase):
             output_dim=0, weight_loader=extra_weight_attrs.get("weight_loader")))
 
     def apply(self, layer, x, bias=None):
-        x2 = x.reshape(-1, x.shape[-1])
-        w = layer.weight
-        if x2.is_cuda and x2.dtype == w.dtype and x2.dtype in (torch.bfloat16, torch.float16) and x2.stride(-1) == 1 and \
-                ops.linear16_supported(x2.shape[0], w.shape[0], w.shape[1]):
-            return ops.linear16(x2, w, bias).reshape(*x.shape[:-1], w.shape[0])  # decode: 16-bit weight streamer
-        return torch.nn.functional.linear(x, w, bias)
+        # (the 16-bit weight streamer ops.linear16 serves the LM head; for the four per-layer GEMMs of the bf16 plumbing
+        #  config it has no split-K form yet -- N = 4096 would run on 32 workgroups -- and the whole step measured
+        #  10.2 ms against 8.1 ms with the library GEMM, so the layers stay on F.linear)
+        return torch.nn.functional.linear(x, layer.weight, bias)
 
 
 # ----------------------------------------------------------------------------- FP8 w8a8
