@@ -34,7 +34,7 @@ extern "C" {
 #define SGL_MI355_ERR_RUNTIME 3          /* a HIP runtime call failed                */
 
 /* ABI version of this header; bumped on any signature change. */
-#define SGL_MI355_ABI_VERSION 4
+#define SGL_MI355_ABI_VERSION 5
 int sgl_mi355_abi_version(void);
 
 /* Copies the calling thread's last error message (NUL-terminated) into buf. Returns its length. */
@@ -314,6 +314,21 @@ int sgl_mi355_rotary_embedding_set_kv_from_partials(
     const void* bias, int64_t num_tokens, int64_t num_q_heads, int64_t num_k_heads, int64_t head_size, int64_t rot_dim,
     int64_t q_out_stride_t, int64_t kb_stride_n, int64_t kb_stride_h, int64_t vb_stride_n, int64_t vb_stride_h,
     int is_neox, int dtype, void* stream);
+/* The qkv epilogue + RoPE + KV write folded into the decode attention itself (one launch instead of two).
+ * Replaces: the same reference sequence as sgl_mi355_rotary_embedding_set_kv_from_partials followed by
+ *           sgl_mi355_decode_attention (rotary_embedding.py:79-260, memory_pool.py:369-407, decode.cpp:1521-1668), bit for
+ *           bit.  partials [num_slices][num_seqs][(num_heads + 2 num_kv_heads) head_size]; loc[b] is the pool row of
+ *           request b's new token, seq_lens[b] counts it.  Only the pairs-of-items kernel has this prologue: one split,
+ *           num_seqs * num_kv_heads > 256, 16-bit pool, head_size in {64, 128} == rot_dim, neox, group <= 16.  Any other
+ *           shape returns SGL_MI355_ERR_UNSUPPORTED without launching anything; the caller then makes the two calls. */
+int sgl_mi355_decode_attention_qkv_partials(
+    const float* partials, int64_t num_slices, const float* scales_a, const float* scales_b, const void* bias,
+    const int64_t* positions, const float* cos_sin_cache, int64_t rot_dim, int is_neox, const void* loc, int loc_is64,
+    void* k_cache, void* v_cache, void* output, const void* req_to_token, int req_to_token_is64,
+    const int64_t* req_pool_indices, const int64_t* seq_lens, int64_t num_seqs, int64_t max_context_len,
+    int64_t num_heads, int64_t num_kv_heads, int64_t head_size, int64_t k_stride_n, int64_t k_stride_h,
+    int64_t v_stride_n, int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h, float sm_scale, float logit_cap,
+    int dtype, void* stream);
 /* same, k_buffer / v_buffer an e4m3 pool (cast as sgl_mi355_set_kv_buffer_fp8 without scales; strides in elements) */
 int sgl_mi355_rotary_embedding_set_kv_from_partials_fp8kv(
     void* q_out, void* k_buffer, void* v_buffer, const int64_t* positions, const void* loc, int loc_is64,

@@ -319,6 +319,27 @@ class MI355AttnBackend(AttentionBackend):
                                        layer.logit_cap)
         return o
 
+    def forward_decode_qkv_partials(self, part, positions, cos_sin_cache, is_neox, layer, forward_batch: ForwardBatch):
+        """MI355X extension: decode attention taking the layer's qkv projection while it is still split-K partial sums
+        (ops.GemmPartials) -- the kernel's prologue applies the GEMM epilogue, RoPE and the KV-pool write
+        (RotaryEmbedding.forward_cuda + MHATokenToKVPool.set_kv_buffer + forward_decode in one launch).  Returns the
+        [T, Hq * D] output, or None when this batch is outside the fused kernel's form (the caller then runs the
+        separate ops); nothing has been written in that case."""
+        md = self.forward_metadata
+        sw = getattr(layer, "sliding_window_size", None)
+        if (self.flat_kv_indices or md.kv_indices is not None or md.num_kv_splits != 1
+                or not isinstance(md.num_kv_splits, int) or layer.qk_head_dim != layer.v_head_dim
+                or (sw is not None and sw > -1) or positions.dtype != torch.int64):
+            return None
+        kb = forward_batch.token_to_kv_pool.get_key_buffer(layer.layer_id)
+        vb = forward_batch.token_to_kv_pool.get_value_buffer(layer.layer_id)
+        o = torch.empty((part.M, layer.tp_q_head_num * layer.v_head_dim), dtype=part.out_dtype, device=kb.device)
+        done = ops.decode_attention_qkv_partials(
+            part, positions, cos_sin_cache, is_neox, forward_batch.out_cache_loc, kb, vb,
+            o.view(-1, layer.tp_q_head_num, layer.v_head_dim), self.req_to_token, forward_batch.req_pool_indices,
+            forward_batch.seq_lens, layer.tp_q_head_num, layer.scaling, layer.logit_cap)
+        return o if done else None
+
     def forward_extend(self, q, k, v, layer, forward_batch: ForwardBatch, save_kv_cache=True, **kwargs):
         if layer.qk_head_dim != layer.v_head_dim:
             o = q.new_empty((q.shape[0], layer.tp_q_head_num * layer.v_head_dim))

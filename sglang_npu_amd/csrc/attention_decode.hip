@@ -33,6 +33,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "partials.h"
 
 namespace sglm {
 namespace {
@@ -83,6 +84,17 @@ struct DecodeArgs {
   float sm_scale, logit_cap;
   int mode;
   int kv8;  // 1: the pool is e4m3fn bytes (strides in elements = bytes); K is upcast, P is rounded to FP8 before PV
+};
+
+// The qkv GEMM of the SAME decode step, still split-K partial sums (sgl_mi355_decode_attention_qkv_partials): the pair
+// kernel finishes it in its prologue -- epilogue, RoPE on q and k, k/v rows into the pool at loc[b] -- instead of a
+// separate RoPE/KV-write launch in front of the attention.
+struct FusedQkv {
+  PartialSrc ps;             // [slices][B][(Hq + 2 Hk) D]
+  const int64_t* positions;  // [B]
+  const void* loc;           // [B] pool rows of the new tokens (int32 / int64)
+  int loc_is64;
+  const float* cos_sin;      // [max_pos][D] = cos | sin (rot_dim == D, neox pairs (d, d + D/2))
 };
 
 __device__ __forceinline__ void split_range(const DecodeArgs& a, int b, int split, int64_t& base, int& s0, int& s1) {
@@ -552,8 +564,8 @@ __global__ __launch_bounds__(kWaves * 64) void decode_mfma_kernel(DecodeArgs a) 
 // tables and both Q blocks are fetched in the one prologue, every wave walks its tiles of the first item and continues
 // straight into its tiles of the second (the two-stage ring keeps prefetching across the boundary), and both merges run
 // at the end.  16-bit pools, one split, 4 waves; items longer than the staged window fall back to one item at a time.
-template <int DTYPE, int D, typename IdxT, bool KV8 = false>
-__global__ __launch_bounds__(256) void decode_mfma_pair_kernel(DecodeArgs a, int num_items) {
+template <int DTYPE, int D, typename IdxT, bool KV8 = false, bool FUSED = false>
+__global__ __launch_bounds__(256) void decode_mfma_pair_kernel(DecodeArgs a, int num_items, FusedQkv fq) {
   using H = Half16<DTYPE>;
   using T = typename H::T;
   using x8 = typename H::x8;
@@ -595,6 +607,9 @@ __global__ __launch_bounds__(256) void decode_mfma_pair_kernel(DecodeArgs a, int
     const char *kbase, *vbase;
   } it[2];
   x8 qfs[2][KS];
+  bool newtok[2];       // FUSED: the item has a new token (always, unless seq_lens[b] == 0)
+  float s_new[2];       // FUSED: its score for head hl, log2 domain (what the streamed tiles call sv)
+  float v_new[2];       // FUSED: its value at dv = tid % D (the merge loop's dv of this thread)
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int item = 2 * (int)blockIdx.x + i;
@@ -608,17 +623,21 @@ __global__ __launch_bounds__(256) void decode_mfma_pair_kernel(DecodeArgs a, int
     it[i].nh = (a.group - hb * 16) < 16 ? (a.group - hb * 16) : 16;
     int s0, s1;
     split_range(a, b, 0, it[i].base, s0, s1);
-    it[i].len = ok ? s1 : -1;  // -1: no such item
+    // -1: no such item.  FUSED: the new token (position s1 - 1) is not streamed from the pool -- it joins at the merge
+    it[i].len = ok ? (FUSED ? (s1 > 0 ? s1 - 1 : 0) : s1) : -1;
+    newtok[i] = FUSED && ok && s1 > 0;
     it[i].kbase = reinterpret_cast<const char*>(a.k) + (int64_t)kvh * a.k_sh * KVB;
     it[i].vbase = reinterpret_cast<const char*>(a.v) + (int64_t)kvh * a.v_sh * KVB;
-    const T* qp = reinterpret_cast<const T*>(a.q) + (int64_t)b * a.q_sb + (int64_t)(it[i].h0 + hl) * a.q_sh;
+    if constexpr (!FUSED) {
+      const T* qp = reinterpret_cast<const T*>(a.q) + (int64_t)b * a.q_sb + (int64_t)(it[i].h0 + hl) * a.q_sh;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      if (hl < it[i].nh) {
-        qfs[i][ks] = *reinterpret_cast<const x8*>(qp + 32 * ks + 8 * g);
-      } else {
+      for (int ks = 0; ks < KS; ++ks) {
+        if (hl < it[i].nh) {
+          qfs[i][ks] = *reinterpret_cast<const x8*>(qp + 32 * ks + 8 * g);
+        } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) qfs[i][ks][j] = (T)0.f;
+          for (int j = 0; j < 8; ++j) qfs[i][ks][j] = (T)0.f;
+        }
       }
     }
   }
@@ -628,6 +647,86 @@ __global__ __launch_bounds__(256) void decode_mfma_pair_kernel(DecodeArgs a, int
     const int n = it[i].len < CAP ? it[i].len : CAP;
     const IdxT* src = reinterpret_cast<const IdxT*>(a.indices) + it[i].base;
     for (int e = tid; e < n; e += 256) idx_lds[i * CAP + e] = (int32_t)src[e];
+  }
+  if constexpr (FUSED) {
+    // q/k/v of this step come out of the qkv GEMM's partial sums.  Tasks of 8 columns (and their RoPE partners D/2 columns
+    // on) are dealt over the 256 threads: per item nh q heads x HC chunk pairs, HC k chunk pairs, 2 HC v chunks.  Rotated
+    // q, k and v are staged in LDS (wave 0's ring, before any DMA lands there): [item][16 heads | k | v][D].  k and v also
+    // go to the pool row loc[b] for the steps to come; THIS launch does not read them back -- the stream covers the
+    // len - 1 older tokens and the new one joins at the merge as one more partial state (m = its score, l = 1, o = v).
+    static_assert(!KV8 && 256 % D == 0, "fused qkv prologue: 16-bit pools, head size dividing 256");
+    constexpr int HC = D / 16;  // 8-column chunks in half a head
+    T* q_lds = reinterpret_cast<T*>(smem);
+    int64_t pos[2], row[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {  // loads that depend on b alone go out with the page-table loads above
+      pos[i] = fq.positions[it[i].b];
+      row[i] = fq.loc_is64 ? reinterpret_cast<const int64_t*>(fq.loc)[it[i].b]
+                           : (int64_t) reinterpret_cast<const int32_t*>(fq.loc)[it[i].b];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (!newtok[i]) continue;
+      const int b = it[i].b, kvh = it[i].h0 / a.group;
+      const int ntask = (it[i].nh + 3) * HC;
+      const float* cs = fq.cos_sin + pos[i] * D;
+      T* stage = q_lds + i * 18 * D;
+      for (int task = tid; task < ntask; task += 256) {
+        const int hq = task / HC, c = task - hq * HC;
+        if (hq <= it[i].nh) {  // a q head (hq < nh) or the k head (hq == nh): rotate the pair of chunks (8c, 8c + D/2)
+          const bool is_k = hq == it[i].nh;
+          const int col = (is_k ? (a.num_heads + kvh) : (it[i].h0 + hq)) * D + 8 * c;
+          const x8 x1 = gemm_row8<DTYPE>(fq.ps, b, col), x2 = gemm_row8<DTYPE>(fq.ps, b, col + D / 2);
+          const f32x4 c0 = *reinterpret_cast<const f32x4*>(cs + 8 * c), c1 = *reinterpret_cast<const f32x4*>(cs + 8 * c + 4);
+          const f32x4 s0 = *reinterpret_cast<const f32x4*>(cs + D / 2 + 8 * c),
+                      s1 = *reinterpret_cast<const f32x4*>(cs + D / 2 + 8 * c + 4);
+          x8 o1, o2;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float r1, r2;
+            rope_pair(H::to_f32(x1[j]), H::to_f32(x2[j]), j < 4 ? c0[j] : c1[j - 4], j < 4 ? s0[j] : s1[j - 4], r1, r2);
+            o1[j] = H::from_f32(r1);
+            o2[j] = H::from_f32(r2);
+          }
+          T* dst = stage + (is_k ? 16 : hq) * D;
+          *reinterpret_cast<x8*>(dst + 8 * c) = o1;
+          *reinterpret_cast<x8*>(dst + D / 2 + 8 * c) = o2;
+          if (is_k) {
+            T* kp = reinterpret_cast<T*>(const_cast<void*>(a.k)) + row[i] * a.k_sn + (int64_t)kvh * a.k_sh;
+            *reinterpret_cast<x8*>(kp + 8 * c) = o1;
+            *reinterpret_cast<x8*>(kp + D / 2 + 8 * c) = o2;
+          }
+        } else {  // v chunk
+          const int vc = task - (it[i].nh + 1) * HC;
+          const x8 x = gemm_row8<DTYPE>(fq.ps, b, (a.num_heads + a.num_kv_heads + kvh) * D + 8 * vc);
+          *reinterpret_cast<x8*>(stage + 17 * D + 8 * vc) = x;
+          *reinterpret_cast<x8*>(reinterpret_cast<T*>(const_cast<void*>(a.v)) + row[i] * a.v_sn + (int64_t)kvh * a.v_sh +
+                                 8 * vc) = x;
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const T* stage = q_lds + i * 18 * D;
+      float dot = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (hl < it[i].nh && newtok[i]) {
+          qfs[i][ks] = *reinterpret_cast<const x8*>(stage + hl * D + 32 * ks + 8 * g);
+          const x8 kn = *reinterpret_cast<const x8*>(stage + 16 * D + 32 * ks + 8 * g);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) dot += H::to_f32(qfs[i][ks][j]) * H::to_f32(kn[j]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) qfs[i][ks][j] = (T)0.f;
+        }
+      }
+      dot += __shfl_xor(dot, 16);
+      dot += __shfl_xor(dot, 32);
+      s_new[i] = has_cap ? a.logit_cap * tanhf(dot * a.sm_scale / a.logit_cap) * kLog2e : dot * scale_log2;
+      v_new[i] = newtok[i] ? H::to_f32(stage[17 * D + (tid % D)]) : 0.f;
+    }
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -954,15 +1053,16 @@ __global__ __launch_bounds__(256) void decode_mfma_pair_kernel(DecodeArgs a, int
   l_first += __shfl_xor(l_first, 32);
   // both items' partials go to LDS behind ONE barrier (the dead rings hold 2 x [wave][16][D] floats + m, l), then every
   // thread finishes output elements of both
-  constexpr int MRG = kWaves * 16 * D + 2 * kWaves * 16;  // floats per item
+  constexpr int MRG = kWaves * 16 * D + 2 * kWaves * 16 + 16;  // floats per item (+ the new token's scores, FUSED)
   float* mrg = reinterpret_cast<float*>(smem);
   __syncthreads();  // every wave is done with its ring
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    if (it[i].len <= 0) continue;
+    if (it[i].len < 0 || (it[i].len == 0 && !newtok[i])) continue;
     float* mrg_o = mrg + i * MRG;
     float* mrg_m = mrg_o + kWaves * 16 * D;
     float* mrg_l = mrg_m + kWaves * 16;
+    if (FUSED && wave == 0 && g == 0) mrg_l[kWaves * 16 + hl] = s_new[i];
     if (hl < it[i].nh) {
       float* dst = mrg_o + (wave * 16 + hl) * D;
 #pragma unroll
@@ -980,7 +1080,7 @@ __global__ __launch_bounds__(256) void decode_mfma_pair_kernel(DecodeArgs a, int
     const int len = it[i].len;
     if (len < 0) break;  // no such item (workgroup-uniform)
     const int nh = it[i].nh;
-    if (len == 0) {  // empty sequence: zero rows
+    if (len == 0 && !newtok[i]) {  // empty sequence: zero rows
       if (tid < nh) {
         T* o = reinterpret_cast<T*>(a.out) + (int64_t)it[i].b * a.o_sb + (int64_t)(it[i].h0 + tid) * a.o_sh;
         for (int d = 0; d < D; ++d) o[d] = H::from_f32(0.f);
@@ -996,12 +1096,22 @@ __global__ __launch_bounds__(256) void decode_mfma_pair_kernel(DecodeArgs a, int
       float M = -INFINITY;
 #pragma unroll
       for (int w = 0; w < kWaves; ++w) M = fmaxf(M, mrg_m[w * 16 + h]);
+      float mn = -INFINITY;
+      if constexpr (FUSED) {
+        mn = newtok[i] ? mrg_l[kWaves * 16 + h] : -INFINITY;
+        M = fmaxf(M, mn);
+      }
       float L = 0.f, val = 0.f;
 #pragma unroll
       for (int w = 0; w < kWaves; ++w) {
         const float f = exp2f(mrg_m[w * 16 + h] - M);
         L += mrg_l[w * 16 + h] * f;
         val += mrg_o[(w * 16 + h) * D + dv] * f;
+      }
+      if constexpr (FUSED) {  // the new token: one more partial state, (m, l, o) = (score, 1, v); dv == tid % D here
+        const float f = exp2f(mn - M);
+        L += f;
+        val += v_new[i] * f;
       }
       reinterpret_cast<T*>(a.out)[(int64_t)it[i].b * a.o_sb + (int64_t)(it[i].h0 + h) * a.o_sh + dv] = H::from_f32(val / L);
     }
@@ -1233,6 +1343,17 @@ int launch_mfma_w(const DecodeArgs& a, int64_t grid, hipStream_t stream) {
   return check_hip(hipGetLastError(), "decode_mfma_kernel launch");
 }
 
+// More items than CUs and one split: pairs of items per workgroup (decode_mfma_pair_kernel).
+// SGL_MI355_DECODE_PAIR=0|1 overrides (tuning aid).
+inline bool pair_eligible(const DecodeArgs& a, int64_t grid) {
+  static const int pair_env = [] { const char* e = getenv("SGL_MI355_DECODE_PAIR"); return e ? atoi(e) : -1; }();
+  return a.num_splits == 1 && a.num_kv_splits == nullptr && (pair_env >= 0 ? pair_env != 0 : grid > 256);
+}
+
+// set by sgl_mi355_decode_attention_qkv_partials around its call of the regular entry point
+thread_local const FusedQkv* tl_fq = nullptr;
+thread_local bool tl_fq_used = false;
+
 template <int DTYPE, int D, typename IdxT, bool DIRECT>
 int launch_mfma(const DecodeArgs& a, int64_t batch, hipStream_t stream) {
   const int nhb = (a.group + 15) / 16;
@@ -1242,15 +1363,22 @@ int launch_mfma(const DecodeArgs& a, int64_t batch, hipStream_t stream) {
     // decode_mfma_pair_kernel).  Measured, bs=64 x 8 kv heads, S = 256 / 1024 / 2048 / 8192: 20.2 / 53.4 / 99.0 / 352 us
     // vs 25.6 / 57.5 / 103.0 / 375 one item per workgroup; 2048 items (MHA, 32 kv heads): 363 vs 375 us with the 2-wave
     // workgroups.  SGL_MI355_DECODE_PAIR=0|1 overrides (tuning aid).
-    static const int pair_env = [] { const char* e = getenv("SGL_MI355_DECODE_PAIR"); return e ? atoi(e) : -1; }();
-    const bool pair = a.num_splits == 1 && a.num_kv_splits == nullptr &&
-                      (pair_env >= 0 ? pair_env != 0 : grid > 256);
+    const bool pair = pair_eligible(a, grid);
+    if (pair && !a.kv8 && tl_fq != nullptr) {  // + the qkv GEMM epilogue, RoPE and the KV write in the prologue
+      auto kern = decode_mfma_pair_kernel<DTYPE, D, IdxT, false, true>;
+      constexpr int lds = mfma_lds_bytes<D, 4, 0>();
+      static int attr_rc = set_max_lds(kern, lds);
+      if (attr_rc != 0) return attr_rc;
+      hipLaunchKernelGGL(kern, dim3((unsigned)((grid + 1) / 2)), dim3(256), lds, stream, a, (int)grid, *tl_fq);
+      tl_fq_used = true;
+      return check_hip(hipGetLastError(), "decode_mfma_pair_kernel (qkv partials) launch");
+    }
     if (pair && !a.kv8) {
       auto kern = decode_mfma_pair_kernel<DTYPE, D, IdxT>;
       constexpr int lds = mfma_lds_bytes<D, 4, 0>();
       static int attr_rc = set_max_lds(kern, lds);
       if (attr_rc != 0) return attr_rc;
-      hipLaunchKernelGGL(kern, dim3((unsigned)((grid + 1) / 2)), dim3(256), lds, stream, a, (int)grid);
+      hipLaunchKernelGGL(kern, dim3((unsigned)((grid + 1) / 2)), dim3(256), lds, stream, a, (int)grid, FusedQkv{});
       return check_hip(hipGetLastError(), "decode_mfma_pair_kernel launch");
     }
     static const int pair8_env = [] { const char* e = getenv("SGL_MI355_DECODE_PAIR_KV8"); return e ? atoi(e) : 0; }();
@@ -1262,7 +1390,7 @@ int launch_mfma(const DecodeArgs& a, int64_t batch, hipStream_t stream) {
       constexpr int lds = mfma_lds_bytes<D, 4, 1>();
       static int attr_rc = set_max_lds(kern, lds);
       if (attr_rc != 0) return attr_rc;
-      hipLaunchKernelGGL(kern, dim3((unsigned)((grid + 1) / 2)), dim3(256), lds, stream, a, (int)grid);
+      hipLaunchKernelGGL(kern, dim3((unsigned)((grid + 1) / 2)), dim3(256), lds, stream, a, (int)grid, FusedQkv{});
       return check_hip(hipGetLastError(), "decode_mfma_pair_kernel (e4m3 pool) launch");
     }
   }
@@ -1434,6 +1562,58 @@ extern "C" int sgl_mi355_decode_attention_fp8kv(
                                             v_stride_h, 0, 0, 0, 0, o_stride_b, o_stride_h, sm_scale, logit_cap, dtype,
                                             stream);
   tl_kv8 = 0;
+  return rc;
+}
+
+// Decode attention straight off the qkv GEMM's split-K partial sums: one launch does the GEMM epilogue, RoPE on q/k,
+// the k/v pool write at loc[b] and the attention over [0, seq_lens[b]) (which includes the new token).  Same result, bit
+// for bit, as sgl_mi355_rotary_embedding_set_kv_from_partials followed by sgl_mi355_decode_attention.  Only the
+// pairs-of-items form takes it (one split, more than 256 (request, kv head) items, 16-bit pool, head size 64/128 = rot_dim,
+// neox pairs, group <= 16): anything else returns SGL_MI355_ERR_UNSUPPORTED WITHOUT launching, and the caller runs the two
+// calls instead.
+extern "C" int sgl_mi355_decode_attention_qkv_partials(
+    const float* partials, int64_t num_slices, const float* scales_a, const float* scales_b, const void* bias,
+    const int64_t* positions, const float* cos_sin_cache, int64_t rot_dim, int is_neox, const void* loc, int loc_is64,
+    void* k_cache, void* v_cache, void* output, const void* req_to_token, int req_to_token_is64,
+    const int64_t* req_pool_indices, const int64_t* seq_lens, int64_t num_seqs, int64_t max_context_len,
+    int64_t num_heads, int64_t num_kv_heads, int64_t head_size, int64_t k_stride_n, int64_t k_stride_h,
+    int64_t v_stride_n, int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h, float sm_scale, float logit_cap,
+    int dtype, void* stream) {
+  int rc = check_common(num_seqs, num_heads, num_kv_heads, head_size, head_size, 1, dtype);
+  if (rc) return rc;
+  if (num_seqs == 0) return 0;
+  SGLM_CHECK_ARG(partials && scales_a && scales_b && positions && cos_sin_cache && loc && k_cache && v_cache && output &&
+                     req_to_token && req_pool_indices && seq_lens && num_slices >= 1,
+                 "decode_attention_qkv_partials: null tensor pointer");
+  DecodeArgs probe{};
+  probe.num_splits = 1;
+  const bool ok = pair_eligible(probe, num_seqs * num_kv_heads) && (head_size == 128 || head_size == 64) &&
+                  rot_dim == head_size && is_neox && num_heads / num_kv_heads <= 16 && k_stride_n % 8 == 0 &&
+                  k_stride_h % 8 == 0 && v_stride_n % 8 == 0 && v_stride_h % 8 == 0 &&
+                  reinterpret_cast<uintptr_t>(k_cache) % 16 == 0 && reinterpret_cast<uintptr_t>(v_cache) % 16 == 0 &&
+                  reinterpret_cast<uintptr_t>(partials) % 16 == 0 && reinterpret_cast<uintptr_t>(scales_b) % 16 == 0 &&
+                  reinterpret_cast<uintptr_t>(cos_sin_cache) % 16 == 0;
+  if (!ok) {
+    set_error("decode_attention_qkv_partials: shape outside the fused form (needs > 256 (request, kv head) items, head "
+              "size 64/128 == rot_dim, neox, group <= 16, 16-byte aligned rows)");
+    return SGL_MI355_ERR_UNSUPPORTED;
+  }
+  const int64_t N = (num_heads + 2 * num_kv_heads) * head_size;
+  const FusedQkv fq{PartialSrc{partials, (int)num_slices, num_seqs * N, scales_a, scales_b, bias, (int)N}, positions, loc,
+                    loc_is64, cos_sin_cache};
+  tl_fq = &fq;
+  tl_fq_used = false;
+  // the query pointer is not read in this form (q comes from the partials); strides as a [B, Hq, D] tensor would have
+  rc = sgl_mi355_decode_attention(partials, k_cache, v_cache, output, nullptr, nullptr, nullptr, nullptr, req_to_token,
+                                  req_to_token_is64, req_pool_indices, seq_lens, num_seqs, max_context_len, num_heads,
+                                  num_kv_heads, head_size, head_size, 1, num_heads * head_size, head_size, k_stride_n,
+                                  k_stride_h, v_stride_n, v_stride_h, 0, 0, 0, 0, o_stride_b, o_stride_h, sm_scale,
+                                  logit_cap, dtype, stream);
+  tl_fq = nullptr;
+  if (rc == 0 && !tl_fq_used) {
+    set_error("decode_attention_qkv_partials: internal error, the dispatcher did not take the fused kernel");
+    return SGL_MI355_ERR_RUNTIME;
+  }
   return rc;
 }
 

@@ -105,6 +105,17 @@ union Frag32 {  // 32 contiguous K bytes of one row = four MFMA operands
 #ifndef SGLM_W_NT
 #define SGLM_W_NT 0
 #endif
+// timing ablations of fp8_gemm_wstream_kernel (WRONG RESULTS; tools/ab_variants.py only): no phase barriers / no LDS
+// reads + MFMA / another weight-queue depth
+#ifndef SGLM_WS_ABL_NOBAR
+#define SGLM_WS_ABL_NOBAR 0
+#endif
+#ifndef SGLM_WS_ABL_NOMFMA
+#define SGLM_WS_ABL_NOMFMA 0
+#endif
+#ifndef SGLM_WS_PB
+#define SGLM_WS_PB 2
+#endif
 #ifndef SGLM_SLAB_SC1
 #define SGLM_SLAB_SC1 0
 #endif
@@ -798,7 +809,7 @@ __global__ __launch_bounds__(576) void fp8_gemm_wstream_kernel(GemmArgs p, float
   // 37.8 us, down 24.6 / 23.4 / 22.6 / 26.5, qkv 16.6 / 15.7 / 15.0 / 16.6; M = 16: gate_up 26.3 / 25.5 / 25.0 / 30.4, down
   // 21.9 / 20.9 / 19.5 / 22.5) -- with 7-8 consumer waves per CU a deeper per-wave queue only lets the waves drift apart
   // (more to wait out at every phase barrier) and oversubscribes the CU's ~10 B/clk HBM path.
-  constexpr int PB = 2;
+  constexpr int PB = SGLM_WS_PB;
   constexpr int UPS = 2 * MB;                 // 1-KiB DMA units per k-step
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -845,7 +856,9 @@ __global__ __launch_bounds__(576) void fp8_gemm_wstream_kernel(GemmArgs p, float
     dma_phase(ph0, 0);
     for (int lp = 0; lp < nph; ++lp) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // phase lp has landed
+#if !SGLM_WS_ABL_NOBAR
       __syncthreads();                                   // barrier #lp: consumers may read it; the other buffer is free
+#endif
       if (lp + 1 < nph) dma_phase(ph0 + lp + 1, (lp + 1) & 1);
     }
     __syncthreads();  // the consumers' final barrier
@@ -877,7 +890,9 @@ __global__ __launch_bounds__(576) void fp8_gemm_wstream_kernel(GemmArgs p, float
   // of registers whose loads have not landed).
 #pragma clang loop unroll(disable)  // no peeled copies either: see above
   for (int lp = 0; lp < nph; ++lp) {
+#if !SGLM_WS_ABL_NOBAR
     __syncthreads();  // barrier #lp: phase lp is in LDS
+#endif
     const uint32_t abuf = (lp & 1) * BUF_BYTES;
     for (int s0 = 0; s0 < PH; s0 += PB) {
 #pragma unroll
@@ -886,6 +901,10 @@ __global__ __launch_bounds__(576) void fp8_gemm_wstream_kernel(GemmArgs p, float
         wait_frag<2 * (PB - 1)>(bq[i]);
         const char* a0 = smem + abuf + t * STEP_BYTES + o0;
         const char* a1 = smem + abuf + t * STEP_BYTES + o1;
+#if SGLM_WS_ABL_NOMFMA
+        (void)a0; (void)a1;
+        acc[0][0] += __builtin_bit_cast(float, (int)bq[i].l[0]);
+#else
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
           Frag32 af;
@@ -895,6 +914,7 @@ __global__ __launch_bounds__(576) void fp8_gemm_wstream_kernel(GemmArgs p, float
           for (int kk = 0; kk < 4; ++kk)
             acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(af.l[kk], bq[i].l[kk], acc[mb], 0, 0, 0);
         }
+#endif
         refill(bq[i]);
         __builtin_amdgcn_sched_barrier(0);
       }

@@ -58,6 +58,13 @@ def _arrived(h):
 FUSE_AR_NORM = not os.environ.get("SGL_MI355_NO_AR_FUSION")
 
 
+# SGL_MI355_QKV_ATTN_FUSION=1: the qkv GEMM's epilogue + RoPE + KV write run in the decode attention kernel's prologue when
+# the batch allows (MI355AttnBackend.forward_decode_qkv_partials).  OFF by default: measured slower than the separate
+# RoPE/KV-write launch (96.0 vs 91.3 us for the pair at bs=64 ctx=2048, profiles/README.md round 2) -- the prologue's
+# dependent round trips sit in front of every workgroup's K/V stream, the separate kernel runs wide and costs < 1 us.
+FUSE_QKV_ATTN = bool(os.environ.get("SGL_MI355_QKV_ATTN_FUSION"))
+
+
 def _unreduced(h) -> bool:
     return isinstance(h, torch.Tensor) and getattr(h, "_sglang_needs_allreduce_fusion", False)
 
@@ -137,7 +144,16 @@ class LlamaAttention(torch.nn.Module):
         pool = forward_batch.token_to_kv_pool
         kb, vb = pool.get_key_buffer(self.attn.layer_id), pool.get_value_buffer(self.attn.layer_id)
         part = self.qkv_proj.forward_prequantized_partials(xq, xs, out_dtype) if defer else None
-        if part is not None:  # qkv epilogue + RoPE + KV write in one kernel
+        attn_output = None
+        if part is not None and FUSE_QKV_ATTN and forward_batch.forward_mode.is_decode():
+            # ... and all of that inside the decode attention kernel's prologue, when the batch has the shape for it
+            fused = getattr(forward_batch.attn_backend, "forward_decode_qkv_partials", None)
+            if fused is not None:
+                attn_output = fused(part, positions, self.rotary_emb.cos_sin_cache, self.rotary_emb.is_neox_style,
+                                    self.attn, forward_batch)
+        if attn_output is not None:
+            pass
+        elif part is not None:  # qkv epilogue + RoPE + KV write in one kernel
             q = ops.rope_set_kv_from_partials(part, positions, self.num_heads, self.num_kv_heads, self.head_dim,
                                               self.rotary_emb.cos_sin_cache, kb, vb, forward_batch.out_cache_loc,
                                               self.rotary_emb.is_neox_style)
@@ -148,8 +164,9 @@ class LlamaAttention(torch.nn.Module):
             ops.apply_rope_and_set_kv_buffer(positions, q, k, v, self.head_dim, self.rotary_emb.cos_sin_cache, kb, vb,
                                              forward_batch.out_cache_loc, self.rotary_emb.is_neox_style)
         # fp8_out: when the backend merges kv-splits anyway, the merge kernel also does o_proj's input quant
-        attn_output = self.attn(q, k, v, forward_batch, save_kv_cache=False,
-                                fp8_out=forward_batch.forward_mode.is_decode())
+        if attn_output is None:
+            attn_output = self.attn(q, k, v, forward_batch, save_kv_cache=False,
+                                    fp8_out=forward_batch.forward_mode.is_decode())
         if isinstance(attn_output, tuple):
             aq, a_s = attn_output
         elif defer:

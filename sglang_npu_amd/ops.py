@@ -579,6 +579,42 @@ def rope_set_kv_from_partials(part: GemmPartials, positions, num_q_heads, num_k_
     return q
 
 
+def decode_attention_qkv_partials(part: GemmPartials, positions, cos_sin_cache, is_neox, loc, k_buffer, v_buffer, o,
+                                  req_to_token, req_pool_indices, seq_lens, num_q_heads, sm_scale,
+                                  logit_cap=0.0) -> bool:
+    """rope_set_kv_from_partials + decode_attention_paged in ONE launch: the attention kernel's prologue finishes the
+    qkv GEMM (epilogue, RoPE, k/v rows into the pool at loc) and attends over seq_lens (which count the new token).
+    Bit-identical to the two calls.  Returns False -- nothing launched, nothing written -- when the shape is outside
+    the fused kernel's form (sgl_mi355.h: > 256 (request, kv head) items, one split, 16-bit pool, head 64/128 ==
+    rot_dim, neox); the caller then makes the two calls.  o: [B, Hq, D]."""
+    _need_gpu(positions, cos_sin_cache, k_buffer, v_buffer, loc, o, req_to_token, req_pool_indices, seq_lens)
+    if cos_sin_cache.dtype != torch.float32 or not cos_sin_cache.is_contiguous():
+        raise RuntimeError("cos_sin_cache should be float32")
+    if req_pool_indices.dtype != torch.int64 or seq_lens.dtype != torch.int64 or positions.dtype != torch.int64:
+        raise RuntimeError("decode_attention_qkv_partials: positions, req_pool_indices and seq_lens must be int64")
+    B, Hq, D = o.shape
+    Hk = k_buffer.size(1)
+    if Hq != num_q_heads or part.M != B or part.N != (Hq + 2 * Hk) * D or loc.numel() != B:
+        raise RuntimeError("decode_attention_qkv_partials: the GEMM is not this batch's [B, (Hq + 2 Hk) D] qkv projection")
+    if o.dtype != part.out_dtype or o.stride(-1) != 1 or k_buffer.stride(-1) != 1 or v_buffer.stride(-1) != 1:
+        raise RuntimeError("decode_attention_qkv_partials: bad output / pool layout")
+    if req_to_token.dim() != 2 or req_to_token.stride(1) != 1 or req_to_token.stride(0) != req_to_token.size(1):
+        raise RuntimeError("decode_attention_qkv_partials: req_to_token must be a contiguous 2-D tensor")
+    if _is_fp8_pool(k_buffer, v_buffer, o) or v_buffer.size(2) != D or k_buffer.size(2) != D:
+        return False
+    rc = _lib.lib().sgl_mi355_decode_attention_qkv_partials(
+        _ptr(part.ws), _I64(part.num_slices), _ptr(part.x_scale), _ptr(part.w_scale), _ptr(part.bias), _ptr(positions),
+        _ptr(cos_sin_cache), _I64(cos_sin_cache.size(1)), _I(1 if is_neox else 0), _ptr(loc), _I(_is64(loc, "loc")),
+        _ptr(k_buffer), _ptr(v_buffer), _ptr(o), _ptr(req_to_token), _I(_is64(req_to_token, "req_to_token")),
+        _ptr(req_pool_indices), _ptr(seq_lens), _I64(B), _I64(req_to_token.size(1)), _I64(Hq), _I64(Hk), _I64(D),
+        _I64(k_buffer.stride(0)), _I64(k_buffer.stride(1)), _I64(v_buffer.stride(0)), _I64(v_buffer.stride(1)),
+        _I64(o.stride(0)), _I64(o.stride(1)), _F(sm_scale), _F(logit_cap), _I(_dtype_code(o)), _stream(o))
+    if rc == 2:  # SGL_MI355_ERR_UNSUPPORTED: not launched
+        return False
+    _lib.check(rc)
+    return True
+
+
 def linear16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """F.linear(x, weight, bias) = x @ weight.T for decode-sized batches of 16-bit operands: the LM head of
     LogitsProcessor._get_logits (logits_processor.py:430-505) and unquantised decode linears.  x [M <= 64, K],
