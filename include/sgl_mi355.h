@@ -283,6 +283,28 @@ int sgl_mi355_awq_gemm(const void* x, const int32_t* qweight, const void* scales
                        const void* bias, void* out, float* workspace, int64_t workspace_floats,
                        int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, void* stream);
 
+/* Pre-shuffled ("fragment-major") FP8 weights for the decode GEMMs -- MI355X extension.
+ * Replaces: nothing in the dense w8a8 path of the reference (it keeps the checkpoint's row-major [N, K] weight and only
+ *           transposes the view, w8a8_fp8.py:104-134); the same idea as the aiter `shuffle_weight(w, (16, 16))` repack the
+ *           reference applies to its ROCm MoE weights in process_weights_after_loading (fp8.py:99, 780-783, 913-918).
+ *   Why: a decode wave's MFMA operand is 16 weight rows x 16 bytes per lane group, so a load instruction on a row-major
+ *   weight touches 16 rows x 64 B (half cache lines, rows K bytes apart).  In the shuffled layout the two load
+ *   instructions of a (16-column block, 128-byte k-step) are 1 KiB contiguous each:
+ *       piece index  = ((n / 16) * (K / 128) + k / 128) * 2 + (k % 128) / 64          (1 KiB each)
+ *       inside piece = ((k % 64) / 16) * 256 + (n % 16) * 16 + k % 16                 (bytes)
+ *   Measured (M = 64, gate_up 4096 -> 28672): 31.5 -> 25.9 us; the whole decode step 6.34 -> 6.16 ms.
+ *   sgl_mi355_fp8_shuffle_weight re-lays a row-major weight (inverse != 0: back).  N % 16 == 0, K % 512 == 0.
+ *   sgl_mi355_fp8_scaled_mm_wshuffled / _partials_wshuffled: sgl_mi355_fp8_scaled_mm / _partials with mat_b in that layout
+ *   (no b_stride_n); results bit-identical to the row-major calls. */
+int sgl_mi355_fp8_shuffle_weight(const void* src, void* dst, int64_t N, int64_t K, int64_t row_stride, int inverse,
+                                 void* stream);
+int sgl_mi355_fp8_scaled_mm_wshuffled(const void* mat_a, const void* mat_b, const float* scales_a, const float* scales_b,
+                                      const void* bias, void* out, float* workspace, int64_t workspace_floats, int64_t M,
+                                      int64_t N, int64_t K, int64_t a_stride_m, int out_dtype, void* stream);
+int sgl_mi355_fp8_scaled_mm_partials_wshuffled(const void* mat_a, const void* mat_b, float* workspace,
+                                               int64_t workspace_floats, int64_t M, int64_t N, int64_t K,
+                                               int64_t a_stride_m, int32_t* num_slices, void* stream);
+
 /* Split-K form of fp8_scaled_mm for fused consumers (decode, M <= 64).
  *   fp8_scaled_mm_partials leaves raw fp32 partial sums workspace[slice][M][N] and reports the slice count
  *   (SGL_MI355_ERR_UNSUPPORTED when the shape is not on the split-K weight-streaming path: the caller then uses

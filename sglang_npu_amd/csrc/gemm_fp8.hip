@@ -88,7 +88,36 @@ struct GemmArgs {
   const void* bias;
   void* out;
   int M, N, K;
+  // 1: W is stored fragment-major ("pre-shuffled", sgl_mi355_fp8_shuffle_weight / include/sgl_mi355.h): for column block
+  // nb = n / 16 and k-step ks = k / 128 one 2-KiB piece [half][g][r16][16 B] holding bytes 64 half + 16 g .. + 16 of row
+  // 16 nb + r16 -- exactly the two 1-KiB load instructions of a decode wave, contiguous.  b_sn is unused then.
+  int b_shuf = 0;
 };
+
+// Where a decode wave finds its weight fragments: scalar base of (column block, k-step 0), bytes between k-steps, and
+// the two per-lane offsets of the step's load instructions (lane = 16 g + r16 holds row 16 nb + r16, bytes 16 g.. and
+// 64 + 16 g.. of the step).  Row-major: 16 rows x 64 B per instruction; pre-shuffled: 1 KiB contiguous.
+struct WFrag {
+  int64_t base;
+  int step;
+  uint32_t v0, v1;
+};
+__device__ __forceinline__ WFrag wfrag_addr(const GemmArgs& p, int nb, int lane) {
+  WFrag w;
+  if (p.b_shuf) {
+    w.base = (int64_t)nb * 16 * p.K;
+    w.step = 2048;
+    w.v0 = (uint32_t)lane * 16;
+    w.v1 = w.v0 + 1024;
+  } else {
+    const int n = nb * 16 + (lane & 15);
+    w.base = 0;
+    w.step = 128;
+    w.v0 = (uint32_t)((int64_t)(n < p.N ? n : p.N - 1) * p.b_sn + 16 * (lane >> 4));
+    w.v1 = w.v0 + 64;
+  }
+  return w;
+}
 
 union Frag32 {  // 32 contiguous K bytes of one row = four MFMA operands
   uint4 v[2];
@@ -126,6 +155,16 @@ __device__ __forceinline__ void gload32_asm(Frag32& f, const uint8_t* sbase, uin
 #else
   asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(f.x[0]) : "v"(voff), "s"(sbase) : "memory");
   asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=v"(f.x[1]) : "v"(voff), "s"(sbase) : "memory");
+#endif
+}
+// the same with the second instruction's offset in a register (row-major weights: + 64; pre-shuffled: + 1024)
+__device__ __forceinline__ void gload32_asm2(Frag32& f, const uint8_t* sbase, uint32_t voff0, uint32_t voff1) {
+#if SGLM_W_NT
+  asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(f.x[0]) : "v"(voff0), "s"(sbase) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(f.x[1]) : "v"(voff1), "s"(sbase) : "memory");
+#else
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(f.x[0]) : "v"(voff0), "s"(sbase) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(f.x[1]) : "v"(voff1), "s"(sbase) : "memory");
 #endif
 }
 // (a non-temporal hint on these loads was measured: no difference on any decode shape, profiles/README.md)
@@ -384,7 +423,7 @@ __global__ __launch_bounds__(512) void fp8_gemm_oneshot_kernel(GemmArgs p) {
   const int r16 = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.x * 16;
   const int n = n0 + r16;
-  const uint32_t boff = (uint32_t)((int64_t)(n < p.N ? n : p.N - 1) * p.b_sn + 16 * g);
+  const WFrag wf = wfrag_addr(p, blockIdx.x, lane);
   uint32_t aoff[MB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
@@ -396,7 +435,7 @@ __global__ __launch_bounds__(512) void fp8_gemm_oneshot_kernel(GemmArgs p) {
   Frag32 bq[S];
   Frag32 aq[S][MB];
 #pragma unroll
-  for (int s = 0; s < S; ++s) gload32_asm(bq[s], p.b + k0 + (s << 7), boff);
+  for (int s = 0; s < S; ++s) gload32_asm2(bq[s], p.b + wf.base + (int64_t)(wk * S + s) * wf.step, wf.v0, wf.v1);
 #pragma unroll
   for (int s = 0; s < S; ++s)
 #pragma unroll
@@ -467,7 +506,7 @@ template <int OUT_DTYPE, int MB>
 int launch_oneshot(const GemmArgs& p, hipStream_t s, bool& used) {
   used = false;
   if ((p.K & 127) != 0 || (p.N & 7) != 0) return 0;
-  if ((int64_t)p.N * p.b_sn >= ((int64_t)1 << 32) || (int64_t)p.M * p.a_sm >= ((int64_t)1 << 32)) return 0;
+  if ((!p.b_shuf && (int64_t)p.N * p.b_sn >= ((int64_t)1 << 32)) || (int64_t)p.M * p.a_sm >= ((int64_t)1 << 32)) return 0;
   const int steps = p.K >> 7;
   int S = 0;
   for (int c = 1; c <= 4; ++c)
@@ -866,7 +905,8 @@ __global__ __launch_bounds__(576) void fp8_gemm_wstream_kernel(GemmArgs p, float
   }
 
   // ---------------- consumers: one column block each, weights through registers, A fragments from LDS
-  const uint32_t lane_off = (uint32_t)((int64_t)(n_ok ? n : 0) * p.b_sn + 16 * g);
+  const WFrag wf = wfrag_addr(p, (nb * 16 < p.N) ? nb : 0, lane);
+  const uint8_t* wbase = p.b + wf.base;
   const int rot = (nb * 3) & (PH - 1);   // per-column-block rotation of the sweep inside a phase
   const int last = ph1 * PH - 1;
   // A fragment offsets inside a k-step: row r16 (+16 mb), chunks g and 4 + g, swizzled
@@ -878,7 +918,7 @@ __global__ __launch_bounds__(576) void fp8_gemm_wstream_kernel(GemmArgs p, float
   auto refill = [&](Frag32& fr) __attribute__((always_inline)) {
     const int f = f_pf < last ? f_pf : last;  // tail refills re-read the last step, never consumed
     const int ks = (f & ~(PH - 1)) + ((f + rot) & (PH - 1));
-    gload32_asm(fr, p.b + (ks << 7), lane_off);
+    gload32_asm2(fr, wbase + (int64_t)ks * wf.step, wf.v0, wf.v1);
     ++f_pf;
   };
   Frag32 bq[PB];
@@ -1013,7 +1053,7 @@ int launch_wstream(const GemmArgs& p, float* slabs, int64_t slab_floats, hipStre
   // count; the epilogue runs inside the consumer kernel (sgl_mi355_*_from_partials).
   used = false;
   if ((p.K & 127) != 0 || (p.N & 7) != 0 || (p.a_sm & 15) != 0) return 0;
-  if ((int64_t)p.N * p.b_sn >= ((int64_t)1 << 32)) return 0;  // per-lane weight offsets are 32-bit
+  if (!p.b_shuf && (int64_t)p.N * p.b_sn >= ((int64_t)1 << 32)) return 0;  // per-lane weight offsets are 32-bit
   const int steps = p.K >> 7;
   static const int ph_cap = [] { const char* e = getenv("SGL_MI355_WSTREAM_PH"); return e ? atoi(e) : 32; }();  // tuning aid
   const int nblocks = (p.N + 15) / 16;
@@ -1419,19 +1459,30 @@ __global__ __launch_bounds__(64 * WM * WN) void fp8_gemm_tiled2_kernel(GemmArgs 
   }
 #pragma unroll
   for (int u = 0; u < UB; ++u) {
-    const int row = (UB * wave + u) * 8 + (lane >> 3);
-    const int j = (lane & 7) ^ ((row >> 1) & 7);
-    int n = n0 + row;
-    n = n < p.N ? n : p.N - 1;
-    b_src[u] = p.b + (int64_t)n * p.b_sn + 16 * j;
+    if (p.b_shuf) {
+      // pre-shuffled W: the 2-KiB piece of (16-column block, k-step) is copied VERBATIM, one contiguous KiB per DMA
+      // instruction; the B image of a stage is then [block][half][g][r16][16 B] and a fragment read of 16 rows x 16 B is
+      // 256 contiguous bytes (no swizzle needed)
+      const int q = UB * wave + u;  // tile-local KiB: block q >> 1, half q & 1
+      int nb = (n0 >> 4) + (q >> 1);
+      nb = nb < (p.N >> 4) ? nb : (p.N >> 4) - 1;
+      b_src[u] = p.b + (int64_t)nb * 16 * p.K + (q & 1) * 1024 + lane * 16;
+    } else {
+      const int row = (UB * wave + u) * 8 + (lane >> 3);
+      const int j = (lane & 7) ^ ((row >> 1) & 7);
+      int n = n0 + row;
+      n = n < p.N ? n : p.N - 1;
+      b_src[u] = p.b + (int64_t)n * p.b_sn + 16 * j;
+    }
   }
+  const int b_step = p.b_shuf ? 2048 : 128;
   const uint32_t smem_base = lds_addr_of(smem);
   auto dma_stage = [&](int stage, int kt) __attribute__((always_inline)) {
     const uint32_t dst = smem_base + stage * STAGE;
 #pragma unroll
     for (int u = 0; u < UA; ++u) lds_dma16(a_src[u] + (int64_t)kt * 128, dst + (UA * wave + u) * 1024);
 #pragma unroll
-    for (int u = 0; u < UB; ++u) lds_dma16(b_src[u] + (int64_t)kt * 128, dst + OPA + (UB * wave + u) * 1024);
+    for (int u = 0; u < UB; ++u) lds_dma16(b_src[u] + (int64_t)kt * b_step, dst + OPA + (UB * wave + u) * 1024);
   };
 
   f32x4 acc[RI][4];
@@ -1443,7 +1494,12 @@ __global__ __launch_bounds__(64 * WM * WN) void fp8_gemm_tiled2_kernel(GemmArgs 
   // fragment byte offsets inside an operand tile: row (.. + 16 i + r16), chunks 2g and 2g+1
   const int sw = (r16 >> 1) & 7;  // (row >> 1) & 7 with row = 16 x + r16
   const uint32_t c0 = 16 * ((2 * g) ^ sw), c1 = 16 * ((2 * g + 1) ^ sw);
-  const uint32_t a_row = (wm * 16 * RI + r16) * 128, b_row = (wn * 64 + r16) * 128;
+  const uint32_t a_row = (wm * 16 * RI + r16) * 128;
+  // B fragment i (16 columns): row-major image as A; verbatim pre-shuffled image: block wn * 4 + i, chunks 2g / 2g + 1
+  // = (half g >> 1, lane group (2g) & 3 and the next one), row r16
+  const uint32_t b_row = p.b_shuf ? wn * 4 * 2048 + r16 * 16 : (wn * 64 + r16) * 128;
+  const uint32_t bc0 = p.b_shuf ? (g >> 1) * 1024 + ((2 * g) & 3) * 256 : c0;
+  const uint32_t bc1 = p.b_shuf ? bc0 + 256 : c1;
 
   const int nk = p.K >> 7;
 #pragma unroll
@@ -1467,8 +1523,8 @@ __global__ __launch_bounds__(64 * WM * WN) void fp8_gemm_tiled2_kernel(GemmArgs 
     af[0].v[1] = *reinterpret_cast<const uint4*>(sa_ + a_row + c1);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      bf[i].v[0] = *reinterpret_cast<const uint4*>(sb_ + b_row + i * 2048 + c0);
-      bf[i].v[1] = *reinterpret_cast<const uint4*>(sb_ + b_row + i * 2048 + c1);
+      bf[i].v[0] = *reinterpret_cast<const uint4*>(sb_ + b_row + i * 2048 + bc0);
+      bf[i].v[1] = *reinterpret_cast<const uint4*>(sb_ + b_row + i * 2048 + bc1);
     }
 #pragma unroll
     for (int i = 1; i < RI; ++i) {
@@ -1591,7 +1647,7 @@ int run_gemm(const GemmArgs& p, float* workspace, int64_t workspace_floats, hipS
                            : launch_wstream<OUT_DTYPE, 4>(p, nullptr, 0, s, used);
       if (rc || used) return rc;
     }
-    if (!no_astat && p.N >= 16 * 8 * 160) {  // same shapes, K tails / odd step counts: phase-filled A image
+    if (!no_astat && !p.b_shuf && p.N >= 16 * 8 * 160) {  // same shapes, K tails / odd step counts: phase-filled A image
       bool used = false;
       int rc = p.M <= 16   ? launch_astat_direct<OUT_DTYPE, 1>(p, s, used)
                : p.M <= 32 ? launch_astat_direct<OUT_DTYPE, 2>(p, s, used)
@@ -1613,7 +1669,7 @@ int run_gemm(const GemmArgs& p, float* workspace, int64_t workspace_floats, hipS
       if (rc || used) return rc;
     }
     static const int astat_min = [] { const char* e = getenv("SGL_MI355_ASTAT_MIN_MI"); return e ? atoi(e) : 40; }();  // tuning aid
-    if (!no_astat && workspace != nullptr && (int64_t)p.N * p.K >= ((int64_t)astat_min << 20)) {
+    if (!no_astat && !p.b_shuf && workspace != nullptr && (int64_t)p.N * p.K >= ((int64_t)astat_min << 20)) {
       bool used = false;
       int rc = p.M <= 16   ? launch_astat<OUT_DTYPE, 1>(p, workspace, workspace_floats, s, used)
                : p.M <= 32 ? launch_astat<OUT_DTYPE, 2>(p, workspace, workspace_floats, s, used)
@@ -1628,9 +1684,22 @@ int run_gemm(const GemmArgs& p, float* workspace, int64_t workspace_floats, hipS
                            : launch_oneshot<OUT_DTYPE, 4>(p, s, used);
       if (rc || used) return rc;
     }
+    if (p.b_shuf) {  // a pre-shuffled weight is only read by the weight-streaming, one-shot and tiled-v2 kernels
+      bool used = false;
+      int rc = p.M <= 16   ? launch_wstream<OUT_DTYPE, 1>(p, nullptr, 0, s, used)
+               : p.M <= 32 ? launch_wstream<OUT_DTYPE, 2>(p, nullptr, 0, s, used)
+                           : launch_wstream<OUT_DTYPE, 4>(p, nullptr, 0, s, used);
+      if (rc || used) return rc;
+      set_error("fp8_scaled_mm (pre-shuffled weight): no kernel for M=%d N=%d K=%d", p.M, p.N, p.K);
+      return SGL_MI355_ERR_UNSUPPORTED;
+    }
     if (p.M <= 16) return dispatch_skinny<OUT_DTYPE, 1>(p, s);
     if (p.M <= 32) return dispatch_skinny<OUT_DTYPE, 2>(p, s);
     return dispatch_skinny<OUT_DTYPE, 4>(p, s);
+  }
+  if (p.b_shuf && (p.K & 127) != 0) {
+    set_error("fp8_scaled_mm (pre-shuffled weight): K must be a multiple of 128");
+    return SGL_MI355_ERR_UNSUPPORTED;
   }
   // v2 (LDS-DMA + block-scaled MFMA) whenever K has no tail; variant by tile count (see the kernel's comment).
   static const int v2_env = [] { const char* e = getenv("SGL_MI355_TILED_V2"); return e ? atoi(e) : -1; }();  // 0 off; 2, 3, 8, 48, 84 force a variant
@@ -1642,7 +1711,8 @@ int run_gemm(const GemmArgs& p, float* workspace, int64_t workspace_floats, hipS
   // (A 4-wave 256x256 with 128x128 wave tiles -- MFMA-bound on paper -- reached only 1.47-2.12: with one wave per SIMD
   //  every barrier and first-fragment latency is exposed.)
   const unsigned grid_b = (unsigned)(((p.M + 255) / 256) * ((p.N + 255) / 256));
-  const int v2 = v2_env >= 0 ? v2_env : (grid_b >= 192 ? 84 : (grid_s <= 256 ? 22 : 2));
+  int v2 = v2_env >= 0 ? v2_env : (grid_b >= 192 ? 84 : (grid_s <= 256 ? 22 : 2));
+  if (p.b_shuf && v2 == 0) v2 = 2;  // the register-staged predecessor below does not read the pre-shuffled layout
   if (v2 && (p.K & 127) == 0) {
 #define TILED2_GO(NST, RI_, WM_, WN_)                                                                             \
   {                                                                                                               \
@@ -1680,6 +1750,23 @@ int run_gemm(const GemmArgs& p, float* workspace, int64_t workspace_floats, hipS
   return check_hip(hipGetLastError(), "fp8_gemm_tiled launch");
 }
 
+// Row-major [N][K] FP8 weight <-> the fragment-major layout the decode kernels stream (GemmArgs::b_shuf).  One thread
+// per 16-byte piece: piece (nb, ks, half, lane = 16 g + r16) <-> bytes 128 ks + 64 half + 16 g .. + 16 of row 16 nb + r16.
+__global__ __launch_bounds__(256) void fp8_shuffle_weight_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                                 int64_t row_stride, int N, int K, int inverse) {
+  const int64_t piece = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (piece >= (int64_t)N * K / 16) return;
+  const int lane = (int)(piece & 63);
+  const int half = (int)((piece >> 6) & 1);
+  const int64_t blk = piece >> 7;  // nb * (K / 128) + ks
+  const int ksteps = K >> 7;
+  const int ks = (int)(blk % ksteps);
+  const int64_t nb = blk / ksteps;
+  const int64_t rm = (nb * 16 + (lane & 15)) * row_stride + ks * 128 + half * 64 + (lane >> 4) * 16;
+  if (inverse) *reinterpret_cast<uint4*>(dst + rm) = *reinterpret_cast<const uint4*>(src + piece * 16);
+  else *reinterpret_cast<uint4*>(dst + piece * 16) = *reinterpret_cast<const uint4*>(src + rm);
+}
+
 }  // namespace
 }  // namespace sglm
 
@@ -1712,8 +1799,12 @@ extern "C" int sgl_mi355_per_token_quant_fp8(
   return check_hip(hipGetLastError(), "per_token_quant_fp8 launch");
 }
 
-extern "C" int sgl_mi355_fp8_scaled_mm(
-    const void* mat_a, const void* mat_b, const float* scales_a, const float* scales_b, const void* bias, void* out,
+// K % 512 == 0 (whole phases of four 128-byte k-steps) and N % 16 == 0: what every kernel that reads the pre-shuffled
+// layout can take at any M
+static bool shuffle_shape_ok(int64_t N, int64_t K) { return N > 0 && K > 0 && N % 16 == 0 && K % 512 == 0; }
+
+static int fp8_scaled_mm_impl(
+    int b_shuf, const void* mat_a, const void* mat_b, const float* scales_a, const float* scales_b, const void* bias, void* out,
     float* workspace, int64_t workspace_floats, int64_t M, int64_t N, int64_t K, int64_t a_stride_m,
     int64_t b_stride_n, int out_dtype, void* stream) {
   // preconditions of fp8_gemm_kernel.cu:1078-1108
@@ -1728,21 +1819,44 @@ extern "C" int sgl_mi355_fp8_scaled_mm(
   SGLM_CHECK_ARG(reinterpret_cast<uintptr_t>(mat_a) % 16 == 0 && reinterpret_cast<uintptr_t>(mat_b) % 16 == 0 &&
                      reinterpret_cast<uintptr_t>(out) % 16 == 0,
                  "fp8_scaled_mm: operands must be 16-byte aligned");
+  SGLM_CHECK_ARG(!b_shuf || shuffle_shape_ok(N, K), "fp8_scaled_mm_wshuffled: N %% 16 == 0 and K %% 512 == 0 required (N=%ld K=%ld)",
+                 (long)N, (long)K);
   GemmArgs p{(const uint8_t*)mat_a, a_stride_m, (const uint8_t*)mat_b, b_stride_n, scales_a, scales_b, bias, out,
              (int)M, (int)N, (int)K};
+  p.b_shuf = b_shuf;
+  // timing ablation (WRONG RESULTS): read a row-major weight as if it were pre-shuffled -- same bytes, contiguous loads
+  static const bool abl_shuf = getenv("SGL_MI355_ABL_SHUF") != nullptr;
+  if (abl_shuf && shuffle_shape_ok(N, K)) p.b_shuf = 1;
   hipStream_t s = as_stream(stream);
   return out_dtype == SGL_MI355_BF16 ? run_gemm<SGL_MI355_BF16>(p, workspace, workspace_floats, s)
                                      : run_gemm<SGL_MI355_FP16>(p, workspace, workspace_floats, s);
+}
+
+extern "C" int sgl_mi355_fp8_scaled_mm(
+    const void* mat_a, const void* mat_b, const float* scales_a, const float* scales_b, const void* bias, void* out,
+    float* workspace, int64_t workspace_floats, int64_t M, int64_t N, int64_t K, int64_t a_stride_m,
+    int64_t b_stride_n, int out_dtype, void* stream) {
+  return fp8_scaled_mm_impl(0, mat_a, mat_b, scales_a, scales_b, bias, out, workspace, workspace_floats, M, N, K, a_stride_m,
+                            b_stride_n, out_dtype, stream);
+}
+
+// mat_b in the pre-shuffled layout of sgl_mi355_fp8_shuffle_weight (N % 16 == 0, K % 512 == 0); otherwise as above
+extern "C" int sgl_mi355_fp8_scaled_mm_wshuffled(
+    const void* mat_a, const void* mat_b, const float* scales_a, const float* scales_b, const void* bias, void* out,
+    float* workspace, int64_t workspace_floats, int64_t M, int64_t N, int64_t K, int64_t a_stride_m, int out_dtype,
+    void* stream) {
+  return fp8_scaled_mm_impl(1, mat_a, mat_b, scales_a, scales_b, bias, out, workspace, workspace_floats, M, N, K, a_stride_m,
+                            K, out_dtype, stream);
 }
 
 // Split-K partial sums only: workspace[slice][m][n] = sum over the slice's k of a[m][k] * b[n][k] (raw fp32, no
 // scales).  The epilogue (x w_scale, x x_scale, + bias, round) is applied by the consumer: sgl_mi355_fp8_scaled_mm_finalize
 // or one of the fused *_from_partials kernels, which sum the slices in the same order -- bit-identical to
 // sgl_mi355_fp8_scaled_mm on the split-K path.  UNSUPPORTED when the shape has no split-K path (caller falls back).
-extern "C" int sgl_mi355_fp8_scaled_mm_partials(const void* mat_a, const void* mat_b, float* workspace,
-                                                int64_t workspace_floats, int64_t M, int64_t N, int64_t K,
-                                                int64_t a_stride_m, int64_t b_stride_n, int32_t* num_slices,
-                                                void* stream) {
+static int fp8_scaled_mm_partials_impl(int b_shuf, const void* mat_a, const void* mat_b, float* workspace,
+                                       int64_t workspace_floats, int64_t M, int64_t N, int64_t K,
+                                       int64_t a_stride_m, int64_t b_stride_n, int32_t* num_slices,
+                                       void* stream) {
   SGLM_CHECK_ARG(num_slices != nullptr && workspace != nullptr, "fp8_scaled_mm_partials: null workspace / num_slices");
   SGLM_CHECK_ARG(M > 0 && N > 0 && K > 0 && N < (1ll << 31) && K < (1ll << 31), "fp8_scaled_mm_partials: bad shape");
   SGLM_CHECK_ARG(a_stride_m % 16 == 0 && b_stride_n % 16 == 0 && a_stride_m >= K && b_stride_n >= K,
@@ -1754,8 +1868,12 @@ extern "C" int sgl_mi355_fp8_scaled_mm_partials(const void* mat_a, const void* m
     set_error("fp8_scaled_mm_partials: only the decode kernels (M <= 64) have a split-K form");
     return SGL_MI355_ERR_UNSUPPORTED;
   }
+  SGLM_CHECK_ARG(!b_shuf || shuffle_shape_ok(N, K), "fp8_scaled_mm_partials_wshuffled: N %% 16 == 0 and K %% 512 == 0 required");
   GemmArgs p{(const uint8_t*)mat_a, a_stride_m, (const uint8_t*)mat_b, b_stride_n, nullptr, nullptr, nullptr, nullptr,
              (int)M, (int)N, (int)K};
+  p.b_shuf = b_shuf;
+  static const bool abl_shuf = getenv("SGL_MI355_ABL_SHUF") != nullptr;  // timing ablation, see fp8_scaled_mm_impl
+  if (abl_shuf && shuffle_shape_ok(N, K)) p.b_shuf = 1;
   hipStream_t s = as_stream(stream);
   bool used = false;
   int sk = 0;
@@ -1770,6 +1888,20 @@ extern "C" int sgl_mi355_fp8_scaled_mm_partials(const void* mat_a, const void* m
   }
   *num_slices = sk;
   return 0;
+}
+
+extern "C" int sgl_mi355_fp8_scaled_mm_partials(const void* mat_a, const void* mat_b, float* workspace,
+                                                int64_t workspace_floats, int64_t M, int64_t N, int64_t K,
+                                                int64_t a_stride_m, int64_t b_stride_n, int32_t* num_slices,
+                                                void* stream) {
+  return fp8_scaled_mm_partials_impl(0, mat_a, mat_b, workspace, workspace_floats, M, N, K, a_stride_m, b_stride_n, num_slices,
+                                     stream);
+}
+
+extern "C" int sgl_mi355_fp8_scaled_mm_partials_wshuffled(const void* mat_a, const void* mat_b, float* workspace,
+                                                          int64_t workspace_floats, int64_t M, int64_t N, int64_t K,
+                                                          int64_t a_stride_m, int32_t* num_slices, void* stream) {
+  return fp8_scaled_mm_partials_impl(1, mat_a, mat_b, workspace, workspace_floats, M, N, K, a_stride_m, K, num_slices, stream);
 }
 
 extern "C" int sgl_mi355_fp8_scaled_mm_finalize(const float* partials, int64_t num_slices, const float* scales_a,
@@ -1788,4 +1920,20 @@ extern "C" int sgl_mi355_fp8_scaled_mm_finalize(const float* partials, int64_t n
     hipLaunchKernelGGL((fp8_gemm_finalize_kernel<SGL_MI355_FP16>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p,
                        partials, (int)num_slices);
   return check_hip(hipGetLastError(), "fp8_gemm_finalize launch");
+}
+
+// Re-lay a row-major FP8 weight [N][K] (row stride in bytes) into the layout sgl_mi355_fp8_scaled_mm_wshuffled reads
+// (inverse != 0: back to row-major; row_stride then describes dst).  N % 16 == 0, K % 512 == 0; src and dst must not
+// overlap.  A one-time cost in process_weights_after_loading (w8a8_fp8.py:104-134 is the reference's hook for repacking).
+extern "C" int sgl_mi355_fp8_shuffle_weight(const void* src, void* dst, int64_t N, int64_t K, int64_t row_stride, int inverse,
+                                            void* stream) {
+  SGLM_CHECK_ARG(shuffle_shape_ok(N, K) && N < (1ll << 31) && K < (1ll << 31),
+                 "fp8_shuffle_weight: N %% 16 == 0 and K %% 512 == 0 required (N=%ld K=%ld)", (long)N, (long)K);
+  SGLM_CHECK_ARG(src && dst && src != dst && row_stride >= K && row_stride % 16 == 0 &&
+                     reinterpret_cast<uintptr_t>(src) % 16 == 0 && reinterpret_cast<uintptr_t>(dst) % 16 == 0,
+                 "fp8_shuffle_weight: 16-byte aligned, distinct buffers; row stride >= K, multiple of 16");
+  const int64_t pieces = N * K / 16;
+  hipLaunchKernelGGL(fp8_shuffle_weight_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, as_stream(stream),
+                     (const uint8_t*)src, (uint8_t*)dst, row_stride, (int)N, (int)K, inverse);
+  return check_hip(hipGetLastError(), "fp8_shuffle_weight launch");
 }

@@ -450,6 +450,44 @@ def reserve_gemm_workspace(device, rows: int = 64, cols: int = 28672) -> None:
     _awq_workspace.get(device, 16 * min(rows, 64) * cols)
 
 
+_WSHUF_ATTR = "_sgl_mi355_wshuffled"
+
+
+def is_wshuffled(w: torch.Tensor) -> bool:
+    """True for a weight whose BYTES are in the fragment-major layout of fp8_shuffle_weight (the tensor keeps the
+    [K, N] shape and strides of the row-major view it replaced; only this backend's GEMMs may read it)."""
+    return bool(getattr(w, _WSHUF_ATTR, False))
+
+
+def fp8_shuffle_supported(N: int, K: int) -> bool:
+    return N > 0 and K > 0 and N % 16 == 0 and K % 512 == 0
+
+
+def fp8_shuffle_weight(weight_nk: torch.Tensor, inverse: bool = False) -> torch.Tensor:
+    """Row-major FP8 weight [N, K] -> the same-shape tensor whose bytes are laid out for the decode GEMMs' contiguous
+    1-KiB loads (include/sgl_mi355.h "Pre-shuffled FP8 weights"); inverse=True undoes it.  The result of the forward
+    direction is tagged (is_wshuffled) -- and so is its .t() made by mark_wshuffled."""
+    _need_gpu(weight_nk)
+    if weight_nk.dim() != 2 or weight_nk.element_size() != 1 or weight_nk.stride(1) != 1:
+        raise RuntimeError("fp8_shuffle_weight: a 2-D one-byte weight [N, K] with contiguous rows is required")
+    N, K = weight_nk.shape
+    if not fp8_shuffle_supported(N, K):
+        raise RuntimeError(f"fp8_shuffle_weight: N % 16 == 0 and K % 512 == 0 required, got N={N} K={K}")
+    if inverse and weight_nk.stride(0) != K:
+        raise RuntimeError("fp8_shuffle_weight(inverse): the shuffled tensor must be contiguous")
+    out = torch.empty((N, K), dtype=weight_nk.dtype, device=weight_nk.device)
+    # forward: src is the row-major tensor (its row stride counts); inverse: dst is
+    _lib.check(_lib.lib().sgl_mi355_fp8_shuffle_weight(
+        _ptr(weight_nk), _ptr(out), _I64(N), _I64(K), _I64(K if inverse else weight_nk.stride(0)),
+        _I(1 if inverse else 0), _stream(weight_nk)))
+    return out if inverse else mark_wshuffled(out)
+
+
+def mark_wshuffled(w: torch.Tensor) -> torch.Tensor:
+    setattr(w, _WSHUF_ATTR, True)
+    return w
+
+
 def fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None) -> torch.Tensor:
     """sgl_kernel.fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None)
     -- sgl-kernel/python/sgl_kernel/gemm.py:34-42, fp8_gemm_kernel.cu:1071-1146 (same checks)."""
@@ -483,6 +521,15 @@ def fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None) -> tor
     if 0 < M <= 64:  # split-K partials of the decode-time weight streamer
         need = max(-(-K // 2048), min(K // 512, -(-2048 // max(1, N // 16)))) * M * N + M * N
         ws = _fp8_workspace.get(mat_a.device, need)
+    if is_wshuffled(mat_b):  # bytes in the fragment-major layout (fp8_shuffle_weight); shape/strides still say [K, N]
+        if b_stride_n != K:
+            raise RuntimeError("fp8_scaled_mm: a pre-shuffled weight must be the whole [K, N] view of its [N, K] storage")
+        _lib.check(_lib.lib().sgl_mi355_fp8_scaled_mm_wshuffled(
+            _ptr(mat_a), _ptr(mat_b), _ptr(scales_a), _ptr(scales_b), _ptr(bias), _ptr(out),
+            _ptr(ws), _I64(ws.numel() if ws is not None else 0),
+            _I64(M), _I64(N), _I64(K), _I64(mat_a.stride(0) if M > 1 else K),
+            _I(0 if out_dtype == torch.bfloat16 else 1), _stream(mat_a)))
+        return out
     _lib.check(_lib.lib().sgl_mi355_fp8_scaled_mm(
         _ptr(mat_a), _ptr(mat_b), _ptr(scales_a), _ptr(scales_b), _ptr(bias), _ptr(out),
         _ptr(ws), _I64(ws.numel() if ws is not None else 0),
@@ -518,9 +565,16 @@ def fp8_scaled_mm_partials(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=Non
         return None
     ws = _fp8_workspace.get(mat_a.device, 32 * M * N)
     sk = ctypes.c_int32(0)
-    rc = _lib.lib().sgl_mi355_fp8_scaled_mm_partials(
-        _ptr(mat_a), _ptr(mat_b), _ptr(ws), _I64(ws.numel()), _I64(M), _I64(N), _I64(K),
-        _I64(mat_a.stride(0) if M > 1 else K), _I64(mat_b.stride(1) if N > 1 else K), ctypes.byref(sk), _stream(mat_a))
+    if is_wshuffled(mat_b):
+        if N > 1 and mat_b.stride(1) != K:
+            raise RuntimeError("fp8_scaled_mm_partials: a pre-shuffled weight must be the whole [K, N] view of its storage")
+        rc = _lib.lib().sgl_mi355_fp8_scaled_mm_partials_wshuffled(
+            _ptr(mat_a), _ptr(mat_b), _ptr(ws), _I64(ws.numel()), _I64(M), _I64(N), _I64(K),
+            _I64(mat_a.stride(0) if M > 1 else K), ctypes.byref(sk), _stream(mat_a))
+    else:
+        rc = _lib.lib().sgl_mi355_fp8_scaled_mm_partials(
+            _ptr(mat_a), _ptr(mat_b), _ptr(ws), _I64(ws.numel()), _I64(M), _I64(N), _I64(K),
+            _I64(mat_a.stride(0) if M > 1 else K), _I64(mat_b.stride(1) if N > 1 else K), ctypes.byref(sk), _stream(mat_a))
     if rc == 2:  # SGL_MI355_ERR_UNSUPPORTED
         return None
     _lib.check(rc)

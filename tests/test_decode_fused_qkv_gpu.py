@@ -148,3 +148,47 @@ def test_fused_qkv_decode_rejects_mismatched_gemm():
     with pytest.raises(RuntimeError, match="qkv projection"):
         ops.decode_attention_qkv_partials(s["partials"](), s["pos"], s["cache"], True, s["loc"], s["kb"], s["vb"], o,
                                           s["r2t"], s["rpi"], s["lens"], Hq + 1, D ** -0.5)
+
+
+def test_model_step_with_the_fused_prologue_matches_the_two_launch_step(monkeypatch):
+    """SGL_MI355_QKV_ATTN_FUSION wiring: LlamaAttention.forward_fp8 -> MI355AttnBackend.forward_decode_qkv_partials.
+    Layer 0 sees identical inputs, so its pool rows are bit-identical; logits agree within 16-bit rounding noise."""
+    from sglang_npu_amd import model as M, ops
+    from sglang_npu_amd.harness import (ForwardBatch, ForwardMode, MHATokenToKVPool, ModelConfig, ModelRunnerLike,
+                                        ReqToTokenPool, ServerArgs, install_attention_backend)
+    cfg = ModelConfig(8, 8, 128, 1024, 2048, 3, 512, 256)
+    B = 40  # 40 requests x 8 kv heads = 320 items: the pairs-of-items kernel
+    outs, taken = [], []
+    real = ops.decode_attention_qkv_partials
+
+    def counted(*a, **kw):
+        done = real(*a, **kw)
+        taken.append(done)
+        return done
+
+    monkeypatch.setattr(ops, "decode_attention_qkv_partials", counted)
+    for fuse in (False, True):
+        monkeypatch.setattr(M, "FUSE_QKV_ATTN", fuse)
+        net = M.LlamaForCausalLM(cfg, "w8a8_fp8", torch.bfloat16, DEV).load_dummy_weights()
+        net.defer_epilogues = True
+        r2t = ReqToTokenPool(B, 256, DEV)
+        pool = MHATokenToKVPool(B * 256 + 1, 1, torch.bfloat16, 8, 128, 3, DEV)
+        g = torch.Generator(device=DEV).manual_seed(0)
+        for l in range(3):
+            pool.k_buffer[l].normal_(generator=g)
+            pool.v_buffer[l].normal_(generator=g)
+        r2t.req_to_token.copy_((torch.randperm(B * 256, device=DEV, generator=g) + 1).view(B, 256).to(torch.int32))
+        runner = ModelRunnerLike(cfg, r2t, pool, DEV, 0, 1, ServerArgs())
+        backend = install_attention_backend(runner)
+        seq = (torch.arange(B, device=DEV) * 6 + 1).clamp(max=255)
+        ids = torch.arange(B, device=DEV) + 1
+        rows = torch.arange(B, device=DEV)
+        fb = ForwardBatch(ForwardMode.DECODE, B, ids, rows, seq, r2t.req_to_token[rows, seq - 1].long(), int(seq.sum()),
+                          seq.cpu(), seq - 1, req_to_token_pool=r2t, token_to_kv_pool=pool, attn_backend=backend)
+        backend.init_forward_metadata(fb)
+        outs.append((net(ids, seq - 1, fb).float(), pool.k_buffer[0].clone(), pool.v_buffer[0].clone()))
+    assert taken == [True] * 3, f"the fused kernel must have run in all three layers, got {taken}"
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2]), "layer-0 pool rows differ"
+    assert torch.isfinite(outs[1][0]).all()
+    scale = outs[0][0].abs().max().item()
+    assert (outs[0][0] - outs[1][0]).abs().max().item() <= 0.02 * scale

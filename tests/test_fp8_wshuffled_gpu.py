@@ -1,0 +1,118 @@
+"""GPU: the pre-shuffled (fragment-major) FP8 weight layout of the decode GEMMs.
+* the re-layout kernel against the index formula in include/sgl_mi355.h, and its inverse;
+* fp8_scaled_mm / fp8_scaled_mm_partials on a shuffled weight against the same call on the row-major weight:
+  bit-identical wherever both run the same kernel (same products, same fp32 summation order -- only the addresses of the
+  loads differ), within one output ulp where the shuffled weight forces another kernel, and against an fp64 product;
+* W8A8Fp8LinearMethod.process_weights_after_loading tags and shuffles eligible weights, leaves others row-major, and a
+  model step with shuffled weights equals the step with SGL_MI355_NO_WSHUFFLE semantics."""
+import pytest
+import torch
+
+from sglang_npu_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rand_fp8(shape, g):
+    return ((torch.rand(shape, generator=g, device=DEV) - 0.5) * 2 * 448).clamp(-448, 448).to(torch.float8_e4m3fn)
+
+
+def _shuffle_by_formula(w):
+    """piece = ((n/16) * (K/128) + k/128) * 2 + (k%128)/64 ; inside = ((k%64)/16)*256 + (n%16)*16 + k%16."""
+    N, K = w.shape
+    b = w.view(torch.uint8).view(N // 16, 16, K // 128, 2, 4, 16)  # [nb, r16, ks, half, g, byte]
+    return b.permute(0, 2, 3, 4, 1, 5).contiguous().view(N, K)     # [nb, ks, half, g, r16, byte]
+
+
+@pytest.mark.parametrize("N,K", [(16, 512), (48, 1024), (4096, 4096), (1280, 3584), (28672, 4096)])
+def test_shuffle_weight_layout_and_inverse(N, K):
+    g = torch.Generator(device=DEV).manual_seed(N + K)
+    w = torch.randint(0, 256, (N, K), dtype=torch.uint8, device=DEV, generator=g).view(torch.float8_e4m3fn)
+    sh = ops.fp8_shuffle_weight(w)
+    assert ops.is_wshuffled(sh) and sh.shape == w.shape
+    assert torch.equal(sh.view(torch.uint8), _shuffle_by_formula(w))
+    back = ops.fp8_shuffle_weight(sh, inverse=True)
+    assert not ops.is_wshuffled(back) and torch.equal(back.view(torch.uint8), w.view(torch.uint8))
+    # a strided source (rows of a wider buffer) is re-laid the same
+    wide = torch.zeros(N, K + 256, dtype=torch.uint8, device=DEV).view(torch.float8_e4m3fn)
+    wide[:, :K] = w
+    assert torch.equal(ops.fp8_shuffle_weight(wide[:, :K]).view(torch.uint8), sh.view(torch.uint8))
+
+
+def test_shuffle_weight_rejects_other_shapes():
+    w = torch.zeros(24, 512, dtype=torch.uint8, device=DEV).view(torch.float8_e4m3fn)
+    with pytest.raises(RuntimeError, match="N % 16 == 0 and K % 512 == 0"):
+        ops.fp8_shuffle_weight(w)
+    w = torch.zeros(32, 640, dtype=torch.uint8, device=DEV).view(torch.float8_e4m3fn)
+    with pytest.raises(RuntimeError, match="N % 16 == 0 and K % 512 == 0"):
+        ops.fp8_shuffle_weight(w)
+    assert not ops.fp8_shuffle_supported(24, 512) and ops.fp8_shuffle_supported(1280, 3584)
+
+
+SHAPES = [(6144, 4096), (4096, 4096), (28672, 4096), (4096, 14336), (1024, 512), (48, 1024), (1280, 3584), (20480, 1024),
+          (512, 7168)]
+
+
+@pytest.mark.parametrize("M", [1, 7, 16, 17, 32, 33, 64, 65, 200, 1000])
+@pytest.mark.parametrize("N,K", SHAPES)
+def test_fp8_scaled_mm_on_shuffled_weight(M, N, K):
+    g = torch.Generator(device=DEV).manual_seed(M * 1000 + N + K)
+    dt = torch.bfloat16 if (M + N // 16) % 2 == 0 else torch.float16
+    a, w = _rand_fp8((M, K), g), _rand_fp8((N, K), g)
+    sa = torch.rand(M, 1, generator=g, device=DEV) * 1e-3 + 1e-4
+    sb = torch.rand(N, 1, generator=g, device=DEV) * 1e-3 + 1e-4
+    bias = torch.randn(N, generator=g, device=DEV).to(dt) if M % 2 else None
+    plain = ops.fp8_scaled_mm(a, w.t(), sa, sb, dt, bias)
+    wsh = ops.mark_wshuffled(ops.fp8_shuffle_weight(w).t())
+    out = ops.fp8_scaled_mm(a, wsh, sa, sb, dt, bias)
+    ref = (a.double() @ w.double().t()) * sb.double().view(1, -1) * sa.double()
+    if bias is not None:
+        ref = ref + bias.double()
+    ulp = 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10
+    torch.testing.assert_close(out.float(), ref.float(), rtol=ulp, atol=1e-3 * float(ref.abs().max()))
+    torch.testing.assert_close(out.float(), plain.float(), rtol=2 * ulp, atol=1e-3 * float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("M", [16, 64])
+@pytest.mark.parametrize("N,K", [(6144, 4096), (4096, 4096), (28672, 4096), (4096, 14336)])
+def test_headline_decode_shapes_are_bit_identical_to_row_major(M, N, K):
+    """Both layouts run fp8_gemm_wstream_kernel with the same (phase, consumer, slice) choice here: same bits."""
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    a, w = _rand_fp8((M, K), g), _rand_fp8((N, K), g)
+    sa = torch.rand(M, 1, generator=g, device=DEV) * 1e-3 + 1e-4
+    sb = torch.rand(N, 1, generator=g, device=DEV) * 1e-3 + 1e-4
+    wsh = ops.mark_wshuffled(ops.fp8_shuffle_weight(w).t())
+    assert torch.equal(ops.fp8_scaled_mm(a, wsh, sa, sb, torch.bfloat16), ops.fp8_scaled_mm(a, w.t(), sa, sb, torch.bfloat16))
+    p0 = ops.fp8_scaled_mm_partials(a, w.t(), sa, sb, torch.bfloat16)
+    if p0 is not None:
+        f0, n0 = p0.finalize(), p0.num_slices
+        p1 = ops.fp8_scaled_mm_partials(a, wsh, sa, sb, torch.bfloat16)
+        assert p1 is not None and p1.num_slices == n0
+        assert torch.equal(p1.finalize(), f0)
+
+
+def test_linear_method_shuffles_eligible_weights_only(monkeypatch):
+    from sglang_npu_amd import quantization as Q
+    from sglang_npu_amd.linear import RowParallelLinear
+
+    def make(n, k, shuffle):
+        monkeypatch.setattr(Q, "PRESHUFFLE_FP8_WEIGHTS", shuffle)
+        lin = RowParallelLinear(k, n, bias=False, quant_config=Q.W8A8Fp8Config(is_checkpoint_fp8_serialized=False),
+                                params_dtype=torch.bfloat16).to(DEV)
+        g = torch.Generator(device=DEV).manual_seed(n + k)
+        lin.weight.data.copy_(torch.randn(n, k, device=DEV, generator=g) * 0.05)
+        lin.quant_method.process_weights_after_loading(lin)
+        return lin
+
+    x = torch.randn(40, 1024, device=DEV, dtype=torch.bfloat16)
+    a, b = make(512, 1024, True), make(512, 1024, False)
+    assert ops.is_wshuffled(a.weight) and not ops.is_wshuffled(b.weight)
+    assert a.weight.shape == b.weight.shape == (1024, 512)
+    assert torch.equal(ops.fp8_shuffle_weight(a.weight.t(), inverse=True).view(torch.uint8), b.weight.t().contiguous().view(torch.uint8))
+    ya, yb = a(x)[0], b(x)[0]
+    torch.testing.assert_close(ya.float(), yb.float(), rtol=2.0 ** -6, atol=1e-3 * float(yb.float().abs().max()))
+    c = make(520, 1024, True)  # N % 16 != 0: stays row-major
+    assert not ops.is_wshuffled(c.weight)
+    d = make(512, 640, True)   # K % 512 != 0
+    assert not ops.is_wshuffled(d.weight)

@@ -17,10 +17,16 @@ for tp in [int(x) for x in os.environ.get("TP_LIST", "1,2,4,8").split(",")]:
         nw = max(2, int(600e6 // (K * N)))
         nw = min(nw, 64)
         ws = [((torch.rand(N, K, device=dev, generator=g) - 0.5) * 8).to(torch.float8_e4m3fn) for _ in range(nw)]
+        if os.environ.get("WSHUF") and ops.fp8_shuffle_supported(N, K):  # the pre-shuffled layout (what the linear method stores)
+            ws = [ops.fp8_shuffle_weight(w) for w in ws]
+            tag = lambda w: ops.mark_wshuffled(w.t())
+        else:
+            tag = lambda w: w.t()
+        wt = [tag(w) for w in ws]
         sb = torch.rand(N, 1, device=dev, generator=g) * 1e-2
         a = ((torch.rand(M, K, device=dev, generator=g) - 0.5) * 8).to(torch.float8_e4m3fn)
         sa = torch.rand(M, 1, device=dev, generator=g) * 1e-2
-        run = lambda i: ops.fp8_scaled_mm(a, ws[i % nw].t(), sa, sb, torch.bfloat16)
+        run = lambda i: ops.fp8_scaled_mm(a, wt[i % nw], sa, sb, torch.bfloat16)
         for i in range(3): run(i)
         torch.cuda.synchronize()
         gr = torch.cuda.CUDAGraph()
@@ -36,4 +42,4 @@ for tp in [int(x) for x in os.environ.get("TP_LIST", "1,2,4,8").split(",")]:
         nbytes = K * N + M * K + 2 * M * N
         print(json.dumps(dict(tp=tp, op=name, K=K, N=N, M=M, us=round(us, 2), GBps=round(nbytes / us / 1e3),
                               floor_us=round(nbytes / 6.0e6, 2))), flush=True)
-        del ws
+        del ws, wt
