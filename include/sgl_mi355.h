@@ -365,7 +365,11 @@ int sgl_mi355_rotary_embedding_set_kv_from_partials_fp8kv(
  *   wp uint32 [N][K/8]: the 8 nibbles of column n for k = 8kk..8kk+7 per dword; sz uint32 [N][K/G]: {fp16 scale,
  *   fp16 (1024 + zero)}.  Values are bit-identical to awq_dequantize (same (w - z) * s in fp16).
  *   K is padded to sgl_mi355_awq_packed_k(K) (next multiple of 512) with weights that dequantise to exactly 0, so
- *   wp is [N][Kp/8] and sz [N][ceil(Kp/G)].
+ *   wp is [N][Kp/8] and sz [N][ceil(Kp/G)] LOGICALLY.  Both are stored fragment-major (round 2; a decode lane's loads are
+ *   then 1 KiB contiguous per wave instead of 16 rows x 64 B): dword (n, kk) of wp at
+ *   ((n/16) (Kp/128) + kk/16) 256 + ((kk/4) % 4) 64 + (n % 16) 4 + kk % 4, dword (n, g) of sz at ((n/16) ngroups + g) 16 + n % 16.
+ *   The buffers must hold ceil(N/16) 16 columns (zero the tail when N % 16 != 0); they are opaque to everything but the
+ *   two GEMMs below.
  * awq_gemm_packed: x fp16 [M<=64][K] (row stride x_stride_m elements), out fp16 [M][N]; K % 128 == 0, N % 8 == 0,
  *   group_size a power of two >= 128; workspace as for awq_gemm (nullable: disables split-K). */
 int64_t sgl_mi355_awq_packed_k(int64_t K);

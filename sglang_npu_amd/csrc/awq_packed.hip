@@ -46,6 +46,18 @@ struct AwqPArgs {
 
 constexpr int ORDER[8] = {0, 4, 1, 5, 2, 6, 3, 7};  // awq_triton.py:56-69: column 8c+j lives in nibble ORDER[j]
 
+// Round 2: both buffers are FRAGMENT-MAJOR (as the FP8 weights, gemm_fp8.hip GemmArgs::b_shuf).  A decode lane
+// (column r16 of block nb, k-group kg) loads the 16 bytes = dwords 16 ks + 4 kg .. + 3 of its column for k-step ks; row-major
+// wp made that 16 rows x 64 B per instruction, rows Kp/2 bytes apart.  Stored instead as one contiguous KiB per
+// (block, step), [kg][r16][16 B]; sz as 64 contiguous bytes per (block, group), [r16].  Logical shapes (wp [N][Kp/8],
+// sz [N][Kp/G]) are unchanged; the buffers hold ceil(N / 16) * 16 columns.
+__host__ __device__ __forceinline__ int64_t wp_index(int n, int kk, int Kp) {  // dword index of (column n, dword kk)
+  return ((int64_t)(n >> 4) * (Kp >> 7) + (kk >> 4)) * 256 + (((kk >> 2) & 3) * 16 + (n & 15)) * 4 + (kk & 3);
+}
+__host__ __device__ __forceinline__ int64_t sz_index(int n, int gp, int ngp) {
+  return ((int64_t)(n >> 4) * ngp + gp) * 16 + (n & 15);
+}
+
 // ---------------------------------------------------------------- repack (once per layer)
 __global__ __launch_bounds__(256) void awq_repack_kernel(const uint32_t* __restrict__ qweight,
                                                          const _Float16* __restrict__ scales,
@@ -70,7 +82,7 @@ __global__ __launch_bounds__(256) void awq_repack_kernel(const uint32_t* __restr
       for (int r = 0; r < 8; ++r) v[r] = (w[r] >> (4 * ORDER[j])) & 0xFu;
       const uint32_t d = v[0] | (v[2] << 4) | (v[4] << 8) | (v[6] << 12) | (v[1] << 16) | (v[3] << 20) | (v[5] << 24) |
                          (v[7] << 28);
-      wp[(int64_t)(8 * c + j) * (Kp / 8) + kk] = d;
+      wp[wp_index(8 * c + j, kk, Kp)] = d;
     }
   }
   const int64_t total2 = (int64_t)ngp * N;
@@ -80,7 +92,7 @@ __global__ __launch_bounds__(256) void awq_repack_kernel(const uint32_t* __restr
     const uint32_t z = (qzeros[(int64_t)g * N8 + n / 8] >> (4 * ORDER[n % 8])) & 0xFu;
     const _Float16 zb = (_Float16)(float)(1024 + (int)z);
     const _Float16 sc = scales[(int64_t)g * N + n];
-    sz[(int64_t)n * ngp + gp] = (uint32_t)__builtin_bit_cast(uint16_t, sc) | ((uint32_t)__builtin_bit_cast(uint16_t, zb) << 16);
+    sz[sz_index(n, gp, ngp)] = (uint32_t)__builtin_bit_cast(uint16_t, sc) | ((uint32_t)__builtin_bit_cast(uint16_t, zb) << 16);
   }
 }
 
@@ -179,16 +191,18 @@ __global__ __launch_bounds__(576) void awq_wstream_kernel(AwqPArgs p, float* sla
   }
 
   // ---------------- consumers
-  const int ncl = n_ok ? n : 0;
-  const uint32_t w_off = (uint32_t)((int64_t)ncl * (p.K / 2) + 16 * kg);  // bytes: row n, this lane's 32 k of a step
-  const uint32_t s_off = (uint32_t)((int64_t)ncl * p.ngroups * 4);
+  const int nbc = nb * 16 < p.N ? nb : 0;  // a wave past the last block streams block 0 (never stored)
+  const uint8_t* w_blk = p.wp + (int64_t)nbc * (p.K >> 7) * 1024;  // fragment-major: one KiB per (block, step)
+  const uint32_t* s_blk = p.sz + (int64_t)nbc * p.ngroups * 16;
+  const uint32_t w_off = (uint32_t)lane * 16;
+  const uint32_t s_off = (uint32_t)r16 * 4;
   const int rot = (nb * 3) & (PH - 1);
   const int last = ph1 * PH - 1;
   int f_pf = ph0 * PH;
   auto refill = [&](WFrag& fr) __attribute__((always_inline)) {
     const int f = f_pf < last ? f_pf : last;
     const int ks = (f & ~(PH - 1)) + ((f + rot) & (PH - 1));
-    wload_asm(fr, p.wp + (int64_t)ks * 64, w_off, p.sz + (ks >> p.gshift), s_off);
+    wload_asm(fr, w_blk + (int64_t)ks * 1024, w_off, s_blk + (ks >> p.gshift) * 16, s_off);
     ++f_pf;
   };
   WFrag wq[PB];

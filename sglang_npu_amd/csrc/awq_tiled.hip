@@ -112,12 +112,16 @@ __global__ __launch_bounds__(256, 2) void awq_tiled_kernel(AwqTArgs p) {
     m = m < p.M ? m : p.M - 1;  // rows past the edge re-read a valid row; never stored
     a_src[u] = p.x + (int64_t)m * p.x_sm + 16 * j;
   }
-  int ncol = n0 + 32 * wave + (lane >> 1);        // W: two lanes (16 B each) per column
-  ncol = ncol < p.N ? ncol : p.N - 1;
-  const uint8_t* w_src = p.wp + (int64_t)ncol * (p.Kp >> 1) + 16 * (lane & 1);
-  int scol = n0 + 32 * wave + (lane & 31);        // sz: lanes 32..63 repeat lanes 0..31
-  scol = scol < p.N ? scol : p.N - 1;
-  const uint32_t* s_src = p.sz + (int64_t)scol * p.ngroups;
+  // W (fragment-major, awq_packed.hip wp_index): the wave's 32 columns are two 16-column blocks; of a block's KiB per
+  // 128-k step this 64-k stage takes k-groups 2 half, 2 half + 1 = 512 contiguous bytes.  Lane = (block lane >> 5,
+  // k-group (lane >> 4) & 1, column lane & 15); the LDS image is that order verbatim.
+  const int nblocks = (p.N + 15) >> 4;
+  int wnb = (n0 >> 4) + 2 * wave + (lane >> 5);
+  wnb = wnb < nblocks ? wnb : nblocks - 1;
+  const uint8_t* w_src = p.wp + (int64_t)wnb * (p.Kp >> 7) * 1024 + ((lane >> 4) & 1) * 256 + (lane & 15) * 16;
+  int snb = (n0 >> 4) + 2 * wave + ((lane & 31) >> 4);  // sz: lanes 32..63 repeat lanes 0..31
+  snb = snb < nblocks ? snb : nblocks - 1;
+  const uint32_t* s_src = p.sz + (int64_t)snb * p.ngroups * 16 + (lane & 15);
 
   const uint32_t smem_base = lds_addr_of(smem);
   auto dma_stage = [&](int stage, int kt) __attribute__((always_inline)) {
@@ -125,8 +129,8 @@ __global__ __launch_bounds__(256, 2) void awq_tiled_kernel(AwqTArgs p) {
     const int akt = kt < p.real_steps ? kt : p.real_steps - 1;  // padded steps: finite activations x zero weights
 #pragma unroll
     for (int u = 0; u < UA; ++u) lds_dma16(a_src[u] + (int64_t)akt * 128, dst + (UA * wave + u) * 1024);
-    lds_dma16(w_src + (int64_t)kt * 32, dst + kOpA + wave * 1024);
-    lds_dma4(s_src + (kt >> p.gshift), dst + kOpA + kOpW + wave * 256);
+    lds_dma16(w_src + (int64_t)(kt >> 1) * 1024 + (kt & 1) * 512, dst + kOpA + wave * 1024);
+    lds_dma4(s_src + (kt >> p.gshift) * 16, dst + kOpA + kOpW + wave * 256);
   };
 
   f32x4 acc[RI][2];
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void awq_tiled_kernel(AwqTArgs p) {
   // fragment offsets: activation row (16 i + r16), chunk 2 kg + ks, swizzled; weight column 16 cb + r16 of the wave
   const int sw = (r16 >> 1) & 7;
   const uint32_t ca0 = r16 * 128 + 16 * ((2 * kg) ^ sw), ca1 = r16 * 128 + 16 * ((2 * kg + 1) ^ sw);
-  const uint32_t wo = kOpA + wave * 1024 + r16 * 32 + 8 * kg;
+  const uint32_t wo = kOpA + wave * 1024 + (kg >> 1) * 256 + r16 * 16 + 8 * (kg & 1);  // image [block][k-group pair][column][16 B]
   const uint32_t so = kOpA + kOpW + wave * 256 + r16 * 4;
 
   const int nk = p.Kp >> 6;

@@ -749,7 +749,8 @@ def _awq_kp(K: int) -> int:
 
 def awq_repack(qweight, scales, qzeros):
     """One-off repack for the decode GEMM (what AWQLinearMethod.process_weights_after_loading may do):
-    returns (wp uint32 [N, K/8], sz uint32 [N, K/G]) -- k-packed nibbles and {scale, 1024+zero} pairs."""
+    returns (wp uint32 [N, K/8], sz uint32 [N, K/G]) -- k-packed nibbles and {scale, 1024+zero} pairs, stored
+    fragment-major (awq_packed.hip wp_index / sz_index): opaque to anything but awq_gemm_packed(_tiled)."""
     _need_gpu(qweight, scales, qzeros)
     K, N = qweight.size(0), qweight.size(1) * 8
     G = K // scales.size(0)
@@ -757,8 +758,11 @@ def awq_repack(qweight, scales, qzeros):
                                                                          qzeros.is_contiguous() and scales.is_contiguous()):
         raise RuntimeError("awq_repack: qweight/qzeros must be contiguous int32, scales contiguous")
     Kp = _awq_kp(K)
-    wp = torch.empty((N, Kp // 8), dtype=torch.int32, device=qweight.device)
-    sz = torch.empty((N, -(-Kp // G)), dtype=torch.int32, device=qweight.device)
+    # fragment-major buffers hold whole 16-column blocks: allocate ceil(N / 16) * 16 rows, hand out the [:N] views
+    Np = -(-N // 16) * 16
+    alloc = torch.empty if Np == N else torch.zeros
+    wp = alloc((Np, Kp // 8), dtype=torch.int32, device=qweight.device)[:N]
+    sz = alloc((Np, -(-Kp // G)), dtype=torch.int32, device=qweight.device)[:N]
     _lib.check(_lib.lib().sgl_mi355_awq_repack(_ptr(qweight), _ptr(scales), _ptr(qzeros), _ptr(wp), _ptr(sz), _I64(K),
                                                _I64(N), _I64(G), _I(_dtype_code(scales)), _stream(qweight)))
     return wp, sz
