@@ -1062,6 +1062,8 @@ int launch_wstream(const GemmArgs& p, float* slabs, int64_t slab_floats, hipStre
   // Without slabs: all of K per workgroup, longest phase (N = 28672: 7 consumers -> exactly 256 workgroups).
   int PH = 0, nc = 8, SK = 1, pps = 0, best = 1 << 30;
   // K / 128 not a multiple of 8 (e.g. 3584 = 28 steps): phases of 4 steps, four weight steps in flight
+  // (phases of 2 steps for the split-K form -- 192 workgroups instead of 48 on the TP = 8 qkv shape 4096 x 768 -- were
+  //  tried: one rank's TP = 4 / 8 step 3.07 -> 3.04 / 2.42 -> 2.45 ms, i.e. nothing; those shapes are launch-bound)
   const int ph_min = (steps % 8 == 0) ? 8 : 4;
   for (int ph = 32 / MB; ph >= ph_min; ph >>= 1) {
     if (ph > ph_cap && ph > 8) continue;

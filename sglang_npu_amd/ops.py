@@ -443,6 +443,14 @@ class _ScratchPool:
 _fp8_workspace = _ScratchPool(7 * 64 * 28672)
 
 
+def _fp8_slab_floats(M: int, N: int, K: int) -> int:
+    """Upper bound of the fp32 split-K scratch launch_wstream (gemm_fp8.hip) may ask for: K slices of at least two
+    128-byte steps, at most 256 workgroups of >= 4 column blocks each (+ one slice of slack)."""
+    groups = max(1, -(-(-(-N // 16)) // 8))
+    slices = max(1, min(K // 256, max(1, 256 // groups)))
+    return (slices + 1) * M * N
+
+
 def reserve_gemm_workspace(device, rows: int = 64, cols: int = 28672) -> None:
     """Size this stream's split-K scratch (FP8 and AWQ decode GEMMs) for GEMMs of up to ``rows`` x ``cols`` outputs."""
     device = torch.device(device)
@@ -519,8 +527,7 @@ def fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None) -> tor
     b_stride_n = mat_b.stride(1) if N > 1 else K
     ws = None
     if 0 < M <= 64:  # split-K partials of the decode-time weight streamer
-        need = max(-(-K // 2048), min(K // 512, -(-2048 // max(1, N // 16)))) * M * N + M * N
-        ws = _fp8_workspace.get(mat_a.device, need)
+        ws = _fp8_workspace.get(mat_a.device, _fp8_slab_floats(M, N, K))
     if is_wshuffled(mat_b):  # bytes in the fragment-major layout (fp8_shuffle_weight); shape/strides still say [K, N]
         if b_stride_n != K:
             raise RuntimeError("fp8_scaled_mm: a pre-shuffled weight must be the whole [K, N] view of its [N, K] storage")
@@ -563,7 +570,7 @@ def fp8_scaled_mm_partials(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=Non
     N = mat_b.size(1)
     if not (0 < M <= 64) or mat_a.stride(1) != 1 or mat_b.stride(0) != 1 or mat_b.size(0) != K:
         return None
-    ws = _fp8_workspace.get(mat_a.device, 32 * M * N)
+    ws = _fp8_workspace.get(mat_a.device, max(32 * M * N, _fp8_slab_floats(M, N, K)))
     sk = ctypes.c_int32(0)
     if is_wshuffled(mat_b):
         if N > 1 and mat_b.stride(1) != K:

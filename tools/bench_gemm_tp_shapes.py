@@ -6,6 +6,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sglang_npu_amd import ops
 dev = "cuda:0"
+ops.reserve_gemm_workspace(dev, 64, 2 * 28672)  # the split-K scratch may not grow under graph capture
 g = torch.Generator(device=dev).manual_seed(0)
 M = int(os.environ.get("M", "64"))
 H, I, Hq, Hkv, D = 4096, 14336, 32, 8, 128
@@ -26,7 +27,12 @@ for tp in [int(x) for x in os.environ.get("TP_LIST", "1,2,4,8").split(",")]:
         sb = torch.rand(N, 1, device=dev, generator=g) * 1e-2
         a = ((torch.rand(M, K, device=dev, generator=g) - 0.5) * 8).to(torch.float8_e4m3fn)
         sa = torch.rand(M, 1, device=dev, generator=g) * 1e-2
-        run = lambda i: ops.fp8_scaled_mm(a, wt[i % nw], sa, sb, torch.bfloat16)
+        if os.environ.get("PARTIALS"):  # the split-K form the model's deferred-epilogue path calls, completed by finalize
+            def run(i):
+                part = ops.fp8_scaled_mm_partials(a, wt[i % nw], sa, sb, torch.bfloat16)
+                return part.finalize() if part is not None else ops.fp8_scaled_mm(a, wt[i % nw], sa, sb, torch.bfloat16)
+        else:
+            run = lambda i: ops.fp8_scaled_mm(a, wt[i % nw], sa, sb, torch.bfloat16)
         for i in range(3): run(i)
         torch.cuda.synchronize()
         gr = torch.cuda.CUDAGraph()
