@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--model", default="llama3-8b", choices=["llama3-8b", "llama3-70b", "llama2-7b", "qwen2-0.5b"])
     ap.add_argument("--quant", default="w8a8_fp8", choices=["w8a8_fp8", "awq", "none"])
     ap.add_argument("--layers", type=int, default=None, help="override the layer count (debug only; invalidates the number)")
-    ap.add_argument("--kv-dtype", default="auto", choices=["auto", "fp8_e4m3"],
+    ap.add_argument("--kv-dtype", default="auto", choices=["auto", "fp8_e4m3", "fp8_e5m2"],
                     help="KV pool dtype (server_args.py --kv-cache-dtype); the headline number is 'auto' = the model dtype")
     ap.add_argument("--emulate-tp", type=int, default=0,
                     help="debug only: run ONE rank's share of a TP=N step on this GPU with the all-reduce stubbed to "
@@ -87,17 +87,17 @@ def build(args, device, tp):
     n_tok = B * max_len + 1
     hkv = cfg.get_num_kv_heads(tp)
     r2t_pool = ReqToTokenPool(B, max_len, str(device))
-    kv_dtype = torch.float8_e4m3fn if args.kv_dtype == "fp8_e4m3" else dtype
+    kv_dtype = {"fp8_e4m3": torch.float8_e4m3fn, "fp8_e5m2": torch.float8_e5m2}.get(args.kv_dtype, dtype)
     kv_pool = MHATokenToKVPool(n_tok, 1, kv_dtype, hkv, cfg.head_dim, n_layers, str(device))
     g = torch.Generator(device=device).manual_seed(1234)
     for l in range(n_layers):  # KV of the already-decoded context: N(0,1) like the reference's kernel tests
         if kv_dtype == dtype:
             kv_pool.k_buffer[l].normal_(generator=g)
             kv_pool.v_buffer[l].normal_(generator=g)
-        else:  # uint8 storage of e4m3 values
+        else:  # uint8 storage of e4m3 / e5m2 values
             for buf in (kv_pool.k_buffer[l], kv_pool.v_buffer[l]):
                 buf.copy_(torch.randn(buf.shape, device=device, generator=g, dtype=torch.bfloat16)
-                          .to(torch.float8_e4m3fn).view(torch.uint8))
+                          .to(kv_dtype).view(torch.uint8))
     # token-level page table = one random permutation of the pool (slot 0 stays the padding slot)
     perm = (torch.randperm(n_tok - 1, device=device, generator=g) + 1).to(torch.int32)
     r2t_pool.req_to_token.copy_(perm[: B * max_len].view(B, max_len))
@@ -560,7 +560,7 @@ def main():
     hq, hkv, d = cfg.num_attention_heads // tp, cfg.get_num_kv_heads(tp), cfg.head_dim
     attn_ms, n_launch = time_attention_kernel(loop, min(args.steps, 8))
     ctx_mid = args.ctx + args.warmup + args.steps + min(args.steps, 8) / 2
-    kv_esz = 1 if args.kv_dtype == "fp8_e4m3" else 2
+    kv_esz = 1 if args.kv_dtype in ("fp8_e4m3", "fp8_e5m2") else 2
     alg_bytes = args.batch * ctx_mid * hkv * 2 * d * kv_esz + 4 * args.batch * ctx_mid + 2 * args.batch * hq * 2 * d
     achieved = alg_bytes / (attn_ms * 1e-3) / 1e9
     # HBM traffic of that kernel from the committed rocprofv3 --pmc passes (bench.py cannot run the profiler on
@@ -579,7 +579,7 @@ def main():
         "metric": "output tokens/s (decode, whole model step) + p50 TTFT", "value": round(value, 1), "unit": "tokens/s",
         "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": ("fp8_e4m3 (GEMM) / bf16 (attention" + (", KV)" if kv_esz == 2 else "), fp8_e4m3 KV"))
+        "dtype": ("fp8_e4m3 (GEMM) / bf16 (attention" + (", KV)" if kv_esz == 2 else "), " + args.kv_dtype + " KV"))
         if args.quant == "w8a8_fp8" else args.quant,
         "data": "synthetic (dummy-loader random weights, N(0,1) KV, random-permutation page table)",
         "config": {"workload": f"{args.model} {args.quant} decode bs={args.batch} ctx={args.ctx} TP={tp} "

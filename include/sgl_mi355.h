@@ -194,6 +194,59 @@ int sgl_mi355_extend_attention_fwd_fp8kv(
     const uint8_t* custom_mask, const int64_t* mask_indptr, int skip_prefix_custom_mask, int64_t sliding_window_size,
     int dtype, void* stream);
 
+
+/* ------------------------------------------------------------------------------------------
+ * float8_e5m2 KV cache, `--kv-cache-dtype fp8_e5m2` (server_args.py:829-833) -- round 2.
+ * Replaces: the same call sites as the e4m3 entry points above with dtype float8_e5m2 (memory_pool.py:114-118, 385-394;
+ *           decode_attention.py:336,373; extend_attention.py:149,200).  Argument lists are identical; only the byte format
+ *           differs: the write is torch's `.to(torch.float8_e5m2)` (round to nearest even on the half-precision bits,
+ *           overflow -> +-inf, NaN -> 0x7f | sign), K is upcast exactly, P (and Q in the extend prefix stage) is rounded
+ *           to e5m2 before the products. */
+int sgl_mi355_set_kv_buffer_fp8_e5m2(void* k_buffer, void* v_buffer, const void* loc, int loc_is64, const void* key,
+                                const void* value, int64_t num_tokens, int64_t num_kv_heads, int64_t head_size,
+                                int64_t head_size_v, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n,
+                                int64_t v_stride_h, int64_t key_stride_n, int64_t key_stride_h, int64_t value_stride_n,
+                                int64_t value_stride_h, float k_scale, float v_scale, int dtype, void* stream);
+int sgl_mi355_decode_attention_fp8kv_e5m2(
+    const void* query, void* k_cache, void* v_cache, void* output, float* attn_logits, const void* req_to_token,
+    int req_to_token_is64, const int64_t* req_pool_indices, const int64_t* seq_lens, int64_t num_seqs,
+    int64_t max_context_len, int64_t num_heads, int64_t num_kv_heads, int64_t head_size, int64_t head_size_v,
+    int64_t num_kv_splits, int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h,
+    int64_t v_stride_n, int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h, float sm_scale, float logit_cap,
+    int dtype, void* stream);
+int sgl_mi355_decode_attention_fwd_fp8kv_e5m2(
+    const void* q, const void* k_buffer, const void* v_buffer, void* o, const int32_t* kv_indptr,
+    const int32_t* kv_indices, float* attn_logits, float* attn_lse, const int32_t* num_kv_splits,
+    int64_t max_kv_splits, int64_t batch, int64_t num_heads, int64_t num_kv_heads, int64_t head_size,
+    int64_t head_size_v, int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h,
+    int64_t v_stride_n, int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h, float sm_scale, float logit_cap,
+    int dtype, void* stream);
+int sgl_mi355_extend_attention_fwd_fp8kv_e5m2(
+    const void* q_extend, const void* k_extend, const void* v_extend, void* o_extend,
+    const void* k_buffer, const void* v_buffer,
+    const int32_t* qo_indptr, const int32_t* kv_indptr, const int32_t* kv_indices, int is_causal,
+    int64_t max_len_extend, int64_t batch, int64_t num_heads, int64_t num_kv_heads,
+    int64_t head_size, int64_t head_size_v,
+    int64_t q_stride_t, int64_t q_stride_h, int64_t ke_stride_t, int64_t ke_stride_h,
+    int64_t ve_stride_t, int64_t ve_stride_h, int64_t o_stride_t, int64_t o_stride_h,
+    int64_t kb_stride_n, int64_t kb_stride_h, int64_t vb_stride_n, int64_t vb_stride_h,
+    float sm_scale, float logit_cap,
+    const uint8_t* custom_mask, const int64_t* mask_indptr, int skip_prefix_custom_mask, int64_t sliding_window_size,
+    int dtype, void* stream);
+int sgl_mi355_rotary_embedding_set_kv_fp8kv_e5m2(const int64_t* positions, void* query, void* key, const void* value,
+                                            const float* cos_sin_cache, void* k_buffer, void* v_buffer, const void* loc,
+                                            int loc_is64, int64_t num_tokens, int64_t num_q_heads, int64_t num_k_heads,
+                                            int64_t head_size, int64_t rot_dim, int64_t q_stride_t, int64_t k_stride_t,
+                                            int64_t v_stride_t, int64_t kb_stride_n, int64_t kb_stride_h,
+                                            int64_t vb_stride_n, int64_t vb_stride_h, int is_neox, int dtype,
+                                            void* stream);
+int sgl_mi355_rotary_embedding_set_kv_from_partials_fp8kv_e5m2(
+    void* q_out, void* k_buffer, void* v_buffer, const int64_t* positions, const void* loc, int loc_is64,
+    const float* cos_sin_cache, const float* partials, int64_t num_slices, const float* scales_a, const float* scales_b,
+    const void* bias, int64_t num_tokens, int64_t num_q_heads, int64_t num_k_heads, int64_t head_size, int64_t rot_dim,
+    int64_t q_out_stride_t, int64_t kb_stride_n, int64_t kb_stride_h, int64_t vb_stride_n, int64_t vb_stride_h,
+    int is_neox, int dtype, void* stream);
+
 /* Split merge fused with the per-token FP8 quant of the attention output (the input of o_proj in the w8a8 model).
  * Replaces: stage 2 of the decode (decode.cpp:812-860 / decode_attention.py:491-548) followed by sgl_per_token_quant_fp8
  *           (per_token_quant_fp8.cu:15-87) on the [num_seqs, num_heads * head_size_v] result -- bit-identical to the pair.

@@ -298,12 +298,42 @@ def merge_state(prefix_output, prefix_lse, suffix_output, suffix_lse, lib=None):
     return out, out_lse
 
 
-# ----------------------------------------------------------------------------- FP8 (e4m3) KV cache
-def set_kv_buffer_fp8(k_buffer, v_buffer, key, value, loc, k_scale=None, v_scale=None, lib=None):
-    """MHATokenToKVPool.set_kv_buffer with dtype float8_e4m3fn (memory_pool.py:369-407): pools are uint8/e4m3
-    [N,Hkv,D], key/value the 16-bit new entries [T,Hkv,D]."""
+# ----------------------------------------------------------------------------- FP8 (e4m3 / e5m2) KV cache
+class _kv_format:
+    """`with _kv_format(lib, kv_dtype):` -- the pool format the *_fp8kv C functions read for the duration of one call
+    (float8_e5m2, or the default float8_e4m3fn; a uint8 view needs the explicit kv_dtype)."""
+
+    def __init__(self, lib, kv_dtype, *pools):
+        if kv_dtype is None and any(p.dtype == torch.float8_e5m2 for p in pools):
+            kv_dtype = torch.float8_e5m2
+        self.lib, self.fmt = lib, 2 if kv_dtype == torch.float8_e5m2 else 1
+
+    def __enter__(self):
+        self.lib.orc_set_kv_format(_I(self.fmt))
+
+    def __exit__(self, *exc):
+        self.lib.orc_set_kv_format(_I(1))
+
+
+def cvt_f32_to_e5m2(x: torch.Tensor, lib=None) -> torch.Tensor:
+    """torch's fp32 -> float8_e5m2 cast as the oracle restates it (uint8 bytes)."""
+    lib = lib or load()
+    x = x.float().contiguous()
+    y = torch.empty(x.shape, dtype=torch.uint8)
+    lib.orc_cvt_f32_to_e5m2(_ptr(x), _ptr(y), _I64(x.numel()))
+    return y
+
+
+def set_kv_buffer_fp8(k_buffer, v_buffer, key, value, loc, k_scale=None, v_scale=None, kv_dtype=None, lib=None):
+    """MHATokenToKVPool.set_kv_buffer with dtype float8_e4m3fn / float8_e5m2 (memory_pool.py:369-407): pools are
+    uint8 / fp8 [N,Hkv,D], key/value the 16-bit new entries [T,Hkv,D]."""
     lib = lib or load()
     T, Hkv, D = key.shape
+    with _kv_format(lib, kv_dtype, k_buffer, v_buffer):
+        _set_kv_buffer_fp8(lib, k_buffer, v_buffer, key, value, loc, k_scale, v_scale, T, Hkv, D)
+
+
+def _set_kv_buffer_fp8(lib, k_buffer, v_buffer, key, value, loc, k_scale, v_scale, T, Hkv, D):
     lib.orc_set_kv_buffer_fp8(
         _ptr(k_buffer), _ptr(v_buffer), _ptr(key), _ptr(value), _ptr(_i64(loc).contiguous()), _I64(T), _I64(Hkv), _I64(D),
         _I64(value.size(2)), _I64(k_buffer.stride(0)), _I64(k_buffer.stride(1)), _I64(v_buffer.stride(0)),
@@ -312,10 +342,18 @@ def set_kv_buffer_fp8(k_buffer, v_buffer, key, value, loc, k_scale=None, v_scale
 
 
 def decode_attention_fp8kv(query, k_buffer, v_buffer, output, attn_logits, req_to_token, req_pool_indices, seq_lens,
-                           sm_scale, logit_cap=0.0, p_fp8: bool = True, lib=None):
-    """Triton decode over an e4m3 KV pool (decode_attention.py:240-488): K upcast, P rounded to FP8 per 32-token block.
-    attn_logits [B,Hq,splits,Dv+1] fp32 scratch; p_fp8=False keeps P in fp32 (the truth for noise measurements)."""
+                           sm_scale, logit_cap=0.0, p_fp8: bool = True, kv_dtype=None, lib=None):
+    """Triton decode over an FP8 KV pool (decode_attention.py:240-488): K upcast, P rounded to the pool format per
+    32-token block.  attn_logits [B,Hq,splits,Dv+1] fp32 scratch; p_fp8=False keeps P in fp32 (the truth for noise
+    measurements)."""
     lib = lib or load()
+    with _kv_format(lib, kv_dtype, k_buffer, v_buffer):
+        return _decode_attention_fp8kv(lib, query, k_buffer, v_buffer, output, attn_logits, req_to_token, req_pool_indices,
+                                       seq_lens, sm_scale, logit_cap, p_fp8)
+
+
+def _decode_attention_fp8kv(lib, query, k_buffer, v_buffer, output, attn_logits, req_to_token, req_pool_indices, seq_lens,
+                            sm_scale, logit_cap, p_fp8):
     B = seq_lens.numel()
     lib.orc_decode_attention_fp8kv(
         _ptr(query), _ptr(k_buffer), _ptr(v_buffer), _ptr(output), _ptr(attn_logits), _ptr(req_to_token),
@@ -330,10 +368,21 @@ def decode_attention_fp8kv(query, k_buffer, v_buffer, output, attn_logits, req_t
 def extend_attention_fp8kv(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, req_to_token, req_pool_indices,
                            seq_lens, extend_seq_lens, extend_start_loc, sm_scale, logit_cap=0.0, p_round: bool = True,
                            causal: bool = True, custom_mask=None, mask_indptr=None, skip_prefix_custom_mask: bool = True,
-                           sliding_window_size: int = -1, q_fp8: bool = True, p_fp8: bool = True, lib=None):
-    """Extend attention over an e4m3 pool (uint8 / float8_e4m3fn k_buffer, v_buffer), Triton-kernel semantics
-    (extend_attention.py:124-303: Q and P rounded to FP8 in the prefix stage, blocks of 64 keys)."""
+                           sliding_window_size: int = -1, q_fp8: bool = True, p_fp8: bool = True, kv_dtype=None,
+                           lib=None):
+    """Extend attention over an FP8 pool (uint8 / float8_e4m3fn / float8_e5m2 k_buffer, v_buffer), Triton-kernel
+    semantics (extend_attention.py:124-303: Q and P rounded to the pool format in the prefix stage, blocks of 64 keys)."""
     lib = lib or load()
+    with _kv_format(lib, kv_dtype, k_buffer, v_buffer):
+        return _extend_attention_fp8kv(lib, q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, req_to_token,
+                                       req_pool_indices, seq_lens, extend_seq_lens, extend_start_loc, sm_scale, logit_cap,
+                                       p_round, causal, custom_mask, mask_indptr, skip_prefix_custom_mask,
+                                       sliding_window_size, q_fp8, p_fp8)
+
+
+def _extend_attention_fp8kv(lib, q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, req_to_token, req_pool_indices,
+                            seq_lens, extend_seq_lens, extend_start_loc, sm_scale, logit_cap, p_round, causal, custom_mask,
+                            mask_indptr, skip_prefix_custom_mask, sliding_window_size, q_fp8, p_fp8):
     assert k_buffer.element_size() == 1 and v_buffer.element_size() == 1
     cm = mi = None
     if custom_mask is not None:

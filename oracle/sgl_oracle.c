@@ -164,6 +164,55 @@ static inline uint8_t f32_to_e4m3_torch(float f) {
   return f32_to_e4m3(f);
 }
 
+/* OCP e5m2 (torch.float8_e5m2, `--kv-cache-dtype fp8_e5m2`, server_args.py:829-833): 1-5-2, bias 15, IEEE-like
+ * (inf = S.11111.00, NaN = S.11111.xx), i.e. the upper byte of a half.  torch's cast (c10/util/Float8_e5m2.h): round to
+ * nearest even straight from fp32, overflow -> inf, NaN -> 0x7f | sign. */
+static inline float e5m2_to_f32(uint8_t v) { return fp16_to_f32((uint16_t)((uint16_t)v << 8)); }
+static inline uint8_t f32_to_e5m2(float f) {
+  uint32_t x;
+  memcpy(&x, &f, 4);
+  uint8_t sign = (uint8_t)((x >> 24) & 0x80u);
+  uint32_t ax = x & 0x7fffffffu;
+  if (ax > 0x7f800000u) return (uint8_t)(sign | 0x7fu);
+  float a = fabsf(f);
+  if (a >= 61440.0f) return (uint8_t)(sign | 0x7cu); /* 57344 + half an ulp (ties to the even "65536" = inf) and beyond */
+  if (a == 0.0f) return sign;
+  int e;
+  (void)frexpf(a, &e);
+  int E = e - 1;
+  if (E < -14) E = -14;          /* subnormals share the 2^-14 exponent; quantum 2^(E-2) */
+  float q = ldexpf(a, 2 - E);    /* exact */
+  uint32_t ri = (uint32_t)nearbyintf(q); /* RNE */
+  uint32_t bits;
+  if (E == -14 && ri < 4) {
+    bits = ri;
+  } else {
+    if (ri == 8) {
+      ri = 4;
+      E += 1;
+    }
+    bits = ((uint32_t)(E + 15) << 2) | (ri - 4);
+  }
+  return (uint8_t)(sign | bits);
+}
+
+/* Format of the FP8 KV pool the *_fp8kv functions below work on: 1 = e4m3fn (default), 2 = e5m2.  Test infrastructure:
+ * a process-wide switch set by the Python wrapper around each call (oracle/__init__.py), read-only inside the call. */
+static int g_kv_fmt = 1;
+void orc_set_kv_format(int fmt) { g_kv_fmt = fmt == 2 ? 2 : 1; }
+static inline float kv_to_f32(uint8_t v) { return g_kv_fmt == 2 ? e5m2_to_f32(v) : e4m3_to_f32(v); }
+/* the pool write: torch's cast of the format */
+static inline uint8_t f32_to_kv_torch(float f) { return g_kv_fmt == 2 ? f32_to_e5m2(f) : f32_to_e4m3_torch(f); }
+/* `x.to(k.dtype)` / `p.to(v.dtype)` inside the Triton kernels (in-range values: both forms agree with the hardware cast) */
+static inline uint8_t f32_to_kv(float f) { return g_kv_fmt == 2 ? f32_to_e5m2(f) : f32_to_e4m3(f); }
+
+void orc_cvt_f32_to_e5m2(const float* x, uint8_t* y, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) y[i] = f32_to_e5m2(x[i]);
+}
+void orc_cvt_e5m2_to_f32(const uint8_t* x, float* y, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) y[i] = e5m2_to_f32(x[i]);
+}
+
 /* exposed so the tests can pin the scalar converters against torch's */
 void orc_cvt_f32_to_e4m3_torch(const float* x, uint8_t* y, int64_t n) {
   for (int64_t i = 0; i < n; ++i) y[i] = f32_to_e4m3_torch(x[i]);
@@ -774,12 +823,12 @@ void orc_set_kv_buffer_fp8(uint8_t* k_buffer, uint8_t* v_buffer, const uint16_t*
       for (int64_t d = 0; d < D; ++d) {
         float x = h_to_f32(key[t * nk_strideN + h * nk_strideH + d], dtype);
         if (k_scale > 0.f) x = h_to_f32(f32_to_h(x / k_scale, dtype), dtype);
-        k_buffer[loc[t] * k_strideN + h * k_strideH + d] = f32_to_e4m3_torch(x);
+        k_buffer[loc[t] * k_strideN + h * k_strideH + d] = f32_to_kv_torch(x);
       }
       for (int64_t d = 0; d < Dv; ++d) {
         float x = h_to_f32(value[t * nv_strideN + h * nv_strideH + d], dtype);
         if (v_scale > 0.f) x = h_to_f32(f32_to_h(x / v_scale, dtype), dtype);
-        v_buffer[loc[t] * v_strideN + h * v_strideH + d] = f32_to_e4m3_torch(x);
+        v_buffer[loc[t] * v_strideN + h * v_strideH + d] = f32_to_kv_torch(x);
       }
     }
 }
@@ -799,7 +848,7 @@ void orc_decode_attention_fp8kv(
     int64_t v_strideN, int64_t v_strideH, int64_t o_strideM, int64_t o_strideH, float sm_scale, float logit_cap,
     int dtype, int p_fp8) {
   float lut[256];
-  for (int i = 0; i < 256; ++i) lut[i] = e4m3_to_f32((uint8_t)i);
+  for (int i = 0; i < 256; ++i) lut[i] = kv_to_f32((uint8_t)i);
   const int64_t group = num_heads / num_heads_kv;
   const int64_t ls2 = head_size_v + 1, ls1 = num_kv_splits * ls2, ls0 = num_heads * ls1;
 #pragma omp parallel for schedule(dynamic, 1) collapse(2)
@@ -841,7 +890,7 @@ void orc_decode_attention_fp8kv(
           for (int64_t j = 0; j < nb; ++j) {
             p[j] = expf(qk[j] - n_e_max);
             psum += p[j];
-            if (p_fp8) p[j] = lut[f32_to_e4m3(p[j])];
+            if (p_fp8) p[j] = lut[f32_to_kv(p[j])];
           }
           for (int64_t j = 0; j < nb; ++j) {
             const int64_t tok = load_index(req_to_token, req * max_context_len + n0 + j, idx64);
@@ -896,7 +945,7 @@ void orc_extend_attention_fp8kv(
     const uint8_t* custom_mask, const int64_t* mask_indptr, int skip_prefix_mask, int64_t window,
     int q_fp8, int p_fp8) {
   float lut[256];
-  for (int i = 0; i < 256; ++i) lut[i] = e4m3_to_f32((uint8_t)i);
+  for (int i = 0; i < 256; ++i) lut[i] = kv_to_f32((uint8_t)i);
   const int64_t group = num_heads / num_heads_kv;
 #pragma omp parallel for schedule(dynamic, 1) collapse(2)
   for (int64_t b = 0; b < num_seqs; ++b)
@@ -911,7 +960,7 @@ void orc_extend_attention_fp8kv(
         const uint16_t* q = q_extend + (start + r) * q_strideM + h * q_strideH;
         for (int64_t d = 0; d < head_size; ++d) {
           qf[d] = h_to_f32(q[d], dtype);
-          q8[d] = q_fp8 ? lut[f32_to_e4m3(qf[d])] : qf[d];
+          q8[d] = q_fp8 ? lut[f32_to_kv(qf[d])] : qf[d];
         }
         for (int64_t d = 0; d < head_size_v; ++d) acc[d] = 0.f;
         float e_max = -INFINITY, deno = 0.f;
@@ -943,7 +992,7 @@ void orc_extend_attention_fp8kv(
           for (int64_t j = 0; j < nb; ++j) {
             p[j] = expf(qk[j] - n_e_max);
             psum += p[j];
-            if (p_fp8) p[j] = lut[f32_to_e4m3(p[j])];
+            if (p_fp8) p[j] = lut[f32_to_kv(p[j])];
           }
           for (int64_t j = 0; j < nb; ++j) {
             if (p[j] == 0.f) continue;

@@ -83,7 +83,7 @@ struct DecodeArgs {
   int num_heads, num_kv_heads, group;
   float sm_scale, logit_cap;
   int mode;
-  int kv8;  // 1: the pool is e4m3fn bytes (strides in elements = bytes); K is upcast, P is rounded to FP8 before PV
+  int kv8;  // 1 / 2: the pool is e4m3fn / e5m2 bytes (strides in elements = bytes); K is upcast, P is rounded to that format before PV
 };
 
 // The qkv GEMM of the SAME decode step, still split-K partial sums (sgl_mi355_decode_attention_qkv_partials): the pair
@@ -134,7 +134,8 @@ __device__ __forceinline__ int swz8(int row) {
 // KV8 = 1: the pool holds e4m3 bytes.  Tiles are DMA'd as bytes (four stages per wave); K fragments are upcast in
 // registers on their way into the 16-bit QK^T MFMA, P is packed to e4m3 and P.V runs on the FP8 MFMA with V^T taken by
 // ds_read_b64_tr_b8 (profiles/r01_tr_b8_probe.txt) -- no 16-bit copy of the tile, no LDS writes.  HBM traffic halves.
-template <int DTYPE, int D, typename IdxT, bool DIRECT_OUT, int kWaves, int KV8 = 0>
+// E5: the pool bytes are e5m2 instead of e4m3fn (only the conversions and the byte MFMA differ)
+template <int DTYPE, int D, typename IdxT, bool DIRECT_OUT, int kWaves, int KV8 = 0, bool E5 = false>
 __global__ __launch_bounds__(kWaves * 64) void decode_mfma_kernel(DecodeArgs a) {
   using H = Half16<DTYPE>;
   using T = typename H::T;
@@ -340,8 +341,8 @@ __global__ __launch_bounds__(kWaves * 64) void decode_mfma_kernel(DecodeArgs a) 
             const int c = (2 * ks + (g >> 1)) ^ swz8<D>(row);
             const uint2 raw = *reinterpret_cast<const uint2*>(kst + row * D + c * 16 + 8 * (g & 1));
             x8 kf;
-            const f32x2_t a0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)raw.x, false), a1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)raw.x, true);
-            const f32x2_t b0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)raw.y, false), b1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)raw.y, true);
+            const f32x2_t a0 = cvt_pk_f32_kv<E5, false>((int)raw.x), a1 = cvt_pk_f32_kv<E5, true>((int)raw.x);
+            const f32x2_t b0 = cvt_pk_f32_kv<E5, false>((int)raw.y), b1 = cvt_pk_f32_kv<E5, true>((int)raw.y);
             kf[0] = H::from_f32(a0[0]); kf[1] = H::from_f32(a0[1]); kf[2] = H::from_f32(a1[0]); kf[3] = H::from_f32(a1[1]);
             kf[4] = H::from_f32(b0[0]); kf[5] = H::from_f32(b0[1]); kf[6] = H::from_f32(b1[0]); kf[7] = H::from_f32(b1[1]);
             s_acc[th] = H::mfma16(kf, qf[ks], s_acc[th]);
@@ -379,10 +380,10 @@ __global__ __launch_bounds__(kWaves * 64) void decode_mfma_kernel(DecodeArgs a) 
         l_run = l_run * alpha + psum;
         m_run = m_new;
         // P^T as e4m3 bytes, k-slot order j = 0..7 (decode_attention.py:373: p.to(v.dtype))
-        int p_lo = __builtin_amdgcn_cvt_pk_fp8_f32(pv[0], pv[1], 0, false);
-        p_lo = __builtin_amdgcn_cvt_pk_fp8_f32(pv[2], pv[3], p_lo, true);
-        int p_hi = __builtin_amdgcn_cvt_pk_fp8_f32(pv[4], pv[5], 0, false);
-        p_hi = __builtin_amdgcn_cvt_pk_fp8_f32(pv[6], pv[7], p_hi, true);
+        int p_lo = cvt_pk_kv_f32<E5, false>(pv[0], pv[1], 0);
+        p_lo = cvt_pk_kv_f32<E5, true>(pv[2], pv[3], p_lo);
+        int p_hi = cvt_pk_kv_f32<E5, false>(pv[4], pv[5], 0);
+        p_hi = cvt_pk_kv_f32<E5, true>(pv[6], pv[7], p_hi);
         const long pf8 = (long)(((unsigned long)(unsigned)p_hi << 32) | (unsigned long)(unsigned)p_lo);
         if (__ballot(alpha != 1.f) != 0) {  // the running max of some head moved: rescale (exact no-op otherwise)
 #pragma unroll
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(kWaves * 64) void decode_mfma_kernel(DecodeArgs a) 
             const v2i_t vr = __builtin_amdgcn_ds_read_tr8_b64_v2i32(
                 (__attribute__((address_space(3))) v2i_t*)(vrp + ((dvb ^ vsw) * 16)));
             const long vf8 = (long)(((unsigned long)(unsigned)vr[1] << 32) | (unsigned long)(unsigned)vr[0]);
-            o_acc[dvb] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(vf8, pf8, o_acc[dvb], 0, 0, 0);
+            o_acc[dvb] = mfma_kv8<E5>(vf8, pf8, o_acc[dvb]);
           }
         }
         wait_lgkmcnt0();  // the V bytes are in registers: refill the slot
@@ -1333,9 +1334,9 @@ int set_max_lds(K kernel, int bytes) {
       "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
 }
 
-template <int DTYPE, int D, typename IdxT, bool DIRECT, int kWaves, int KV8 = 0>
+template <int DTYPE, int D, typename IdxT, bool DIRECT, int kWaves, int KV8 = 0, bool E5 = false>
 int launch_mfma_w(const DecodeArgs& a, int64_t grid, hipStream_t stream) {
-  auto kern = decode_mfma_kernel<DTYPE, D, IdxT, DIRECT, kWaves, KV8>;
+  auto kern = decode_mfma_kernel<DTYPE, D, IdxT, DIRECT, kWaves, KV8, E5>;
   constexpr int lds = mfma_lds_bytes<D, kWaves, KV8>();
   static int attr_rc = set_max_lds(kern, lds);
   if (attr_rc != 0) return attr_rc;
@@ -1385,7 +1386,7 @@ int launch_mfma(const DecodeArgs& a, int64_t batch, hipStream_t stream) {
     // e4m3 pool: opt-in (SGL_MI355_DECODE_PAIR_KV8=1).  Measured against the two-workgroups-per-CU layout at bs=64 x 8 kv
     // heads, S = 512 / 1024 / 2048 / 4096: 28.0 / 38.2 / 63.2 / 112.4 us vs 22.5 / 35.7 / 65.1 / 122.6 -- better only
     // from ~2k tokens, and the launcher cannot see the lengths.
-    if (pair && a.kv8 && pair8_env) {
+    if (pair && a.kv8 == 1 && pair8_env) {
       auto kern = decode_mfma_pair_kernel<DTYPE, D, IdxT, true>;
       constexpr int lds = mfma_lds_bytes<D, 4, 1>();
       static int attr_rc = set_max_lds(kern, lds);
@@ -1394,6 +1395,8 @@ int launch_mfma(const DecodeArgs& a, int64_t batch, hipStream_t stream) {
       return check_hip(hipGetLastError(), "decode_mfma_pair_kernel (e4m3 pool) launch");
     }
   }
+  if (a.kv8 == 2)  // e5m2 pool: the two-workgroups-per-CU layout only (one set of instantiations; same structure)
+    return launch_mfma_w<DTYPE, D, IdxT, DIRECT, 4, 2, true>(a, grid, stream);
   if (a.kv8) {
     // measured at bs=64 x 8 kv heads (512 workgroups), S = 512 / 2048 / 8192: two per CU 22 / 64 / 224 us, one per CU
     // with four stages 30 / 70 / 205 us.  SGL_MI355_DECODE_KV8_STAGES=2|4 overrides (tuning aid).
@@ -1625,6 +1628,41 @@ extern "C" int sgl_mi355_decode_attention_fwd_fp8kv(
     int64_t v_stride_n, int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h, float sm_scale, float logit_cap,
     int dtype, void* stream) {
   tl_kv8 = 1;
+  const int rc = sgl_mi355_decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_logits, attn_lse,
+                                                num_kv_splits, max_kv_splits, batch, num_heads, num_kv_heads, head_size,
+                                                head_size_v, q_stride_b, q_stride_h, k_stride_n, k_stride_h, v_stride_n,
+                                                v_stride_h, o_stride_b, o_stride_h, sm_scale, logit_cap, dtype, stream);
+  tl_kv8 = 0;
+  return rc;
+}
+
+// float8_e5m2 pools (`--kv-cache-dtype fp8_e5m2`): same argument lists and kernels, the byte format aside
+extern "C" int sgl_mi355_decode_attention_fp8kv_e5m2(
+    const void* query, void* k_cache, void* v_cache, void* output, float* attn_logits, const void* req_to_token,
+    int req_to_token_is64, const int64_t* req_pool_indices, const int64_t* seq_lens, int64_t num_seqs,
+    int64_t max_context_len, int64_t num_heads, int64_t num_kv_heads, int64_t head_size, int64_t head_size_v,
+    int64_t num_kv_splits, int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h,
+    int64_t v_stride_n, int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h, float sm_scale, float logit_cap,
+    int dtype, void* stream) {
+  tl_kv8 = 2;
+  const int rc = sgl_mi355_decode_attention(query, k_cache, v_cache, output, nullptr, nullptr, nullptr, attn_logits,
+                                            req_to_token, req_to_token_is64, req_pool_indices, seq_lens, num_seqs,
+                                            max_context_len, num_heads, num_kv_heads, head_size, head_size_v,
+                                            num_kv_splits, q_stride_b, q_stride_h, k_stride_n, k_stride_h, v_stride_n,
+                                            v_stride_h, 0, 0, 0, 0, o_stride_b, o_stride_h, sm_scale, logit_cap, dtype,
+                                            stream);
+  tl_kv8 = 0;
+  return rc;
+}
+
+extern "C" int sgl_mi355_decode_attention_fwd_fp8kv_e5m2(
+    const void* q, const void* k_buffer, const void* v_buffer, void* o, const int32_t* kv_indptr,
+    const int32_t* kv_indices, float* attn_logits, float* attn_lse, const int32_t* num_kv_splits,
+    int64_t max_kv_splits, int64_t batch, int64_t num_heads, int64_t num_kv_heads, int64_t head_size,
+    int64_t head_size_v, int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h,
+    int64_t v_stride_n, int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h, float sm_scale, float logit_cap,
+    int dtype, void* stream) {
+  tl_kv8 = 2;
   const int rc = sgl_mi355_decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_logits, attn_lse,
                                                 num_kv_splits, max_kv_splits, batch, num_heads, num_kv_heads, head_size,
                                                 head_size_v, q_stride_b, q_stride_h, k_stride_n, k_stride_h, v_stride_n,

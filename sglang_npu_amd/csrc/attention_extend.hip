@@ -61,7 +61,7 @@ struct ExtendArgs {
   const int64_t* mask_indptr;  // [B+1]
   int skip_prefix_mask;        // SKIP_PREFIX_CUSTOM_MASK
   int window;                  // SLIDING_WINDOW_SIZE (prefix stage only: q <= n + window)
-  int kv8;                     // pool rows are e4m3 bytes (strides in elements = bytes)
+  int kv8;                     // 1 / 2: pool rows are e4m3fn / e5m2 bytes (strides in elements = bytes)
 };
 
 __device__ __forceinline__ void seq_info(const ExtendArgs& a, int b, int64_t& idx_base, int& prefix, int& ext,
@@ -90,16 +90,17 @@ __device__ __forceinline__ int swz_v(int c, int row) {  // ds_read_b64_tr_b16: k
 }
 
 // 8 e4m3 bytes -> 8 values of the 16-bit dtype (exact)
+// (e5: the bytes are e5m2 -- a workgroup-uniform flag, not a template parameter: this path is not the hot one)
 template <int DTYPE>
-__device__ __forceinline__ typename Half16<DTYPE>::x8 cvt8_fp8(const uint2& raw) {
+__device__ __forceinline__ typename Half16<DTYPE>::x8 cvt8_fp8(const uint2& raw, bool e5) {
   using Hh = Half16<DTYPE>;
   typedef float f32x2_t __attribute__((ext_vector_type(2)));
   typename Hh::x8 out;
   const uint32_t w[2] = {raw.x, raw.y};
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const f32x2_t lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[i], false);
-    const f32x2_t hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[i], true);
+    const f32x2_t lo = e5 ? __builtin_amdgcn_cvt_pk_f32_bf8((int)w[i], false) : __builtin_amdgcn_cvt_pk_f32_fp8((int)w[i], false);
+    const f32x2_t hi = e5 ? __builtin_amdgcn_cvt_pk_f32_bf8((int)w[i], true) : __builtin_amdgcn_cvt_pk_f32_fp8((int)w[i], true);
     out[4 * i + 0] = Hh::from_f32(lo[0]);
     out[4 * i + 1] = Hh::from_f32(lo[1]);
     out[4 * i + 2] = Hh::from_f32(hi[0]);
@@ -108,8 +109,13 @@ __device__ __forceinline__ typename Half16<DTYPE>::x8 cvt8_fp8(const uint2& raw)
   return out;
 }
 // fp32 rounded to e4m3 (saturating) and back: `x.to(fp8)` of the Triton kernel for Q (extend_attention.py:149) and P (:200)
-__device__ __forceinline__ float round_fp8(float x) {
+__device__ __forceinline__ float round_fp8(float x, bool e5) {
   typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  if (e5) {
+    const int pk = __builtin_amdgcn_cvt_pk_bf8_f32(x, 0.f, 0, false);
+    const f32x2_t r = __builtin_amdgcn_cvt_pk_f32_bf8(pk, false);
+    return r[0];
+  }
   const int pk = __builtin_amdgcn_cvt_pk_fp8_f32(x, 0.f, 0, false);
   const f32x2_t r = __builtin_amdgcn_cvt_pk_f32_fp8(pk, false);
   return r[0];
@@ -130,6 +136,7 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
   using T = typename H::T;
   using x8 = typename H::x8;
   using x4 = typename H::x4;
+  const bool e5 = a.kv8 == 2;  // the pool bytes are e5m2 (KV8 kernels only)
   constexpr int ROWB = D * 2;
   constexpr int CH = ROWB / 16;
   constexpr int ROWS_PER_DMA = 1024 / ROWB;
@@ -192,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
 #pragma unroll
       for (int s = 0; s < KS; ++s)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) qf[s][j] = H::from_f32(round_fp8(H::to_f32(qf[s][j])));
+        for (int j = 0; j < 8; ++j) qf[s][j] = H::from_f32(round_fp8(H::to_f32(qf[s][j]), e5));
     }
 #pragma unroll
     for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(qf[s]));  // keep hipcc's wait for these loads out of the loop
@@ -320,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
       for (int r = 0; r < 16; ++r) {
         const float p = __builtin_amdgcn_exp2f(s_acc[ti][r] - m_safe);
         psum += p;
-        pf[ti][r >> 3][r & 7] = H::from_f32((KV8 && phase == 0) ? round_fp8(p) : p);
+        pf[ti][r >> 3][r & 7] = H::from_f32((KV8 && phase == 0) ? round_fp8(p, e5) : p);
       }
     l_run = l_run * alpha + psum;
     m_run = m_new;
@@ -413,8 +420,8 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
       const int c = tid + 256 * i, row = c / CPR, ch = c % CPR;
       const uint2 kr = *reinterpret_cast<const uint2*>(ks8 + row * D + ch * 8);
       const uint2 vr = *reinterpret_cast<const uint2*>(vs8 + row * D + ch * 8);
-      *reinterpret_cast<x8*>(kst + row * ROWB + swz_k<D>(ch, row) * 16) = cvt8_fp8<DTYPE>(kr);
-      *reinterpret_cast<x8*>(vst + row * ROWB + swz_v<D>(ch, row) * 16) = cvt8_fp8<DTYPE>(vr);
+      *reinterpret_cast<x8*>(kst + row * ROWB + swz_k<D>(ch, row) * 16) = cvt8_fp8<DTYPE>(kr, e5);
+      *reinterpret_cast<x8*>(vst + row * ROWB + swz_v<D>(ch, row) * 16) = cvt8_fp8<DTYPE>(vr, e5);
     }
   };
   auto run_phase8 = [&](int t_begin, int t_end, int idx_off, int n_keys) __attribute__((always_inline)) {
@@ -755,6 +762,23 @@ extern "C" int sgl_mi355_extend_attention_fwd_fp8kv(
     const uint8_t* custom_mask, const int64_t* mask_indptr, int skip_prefix_custom_mask, int64_t sliding_window_size,
     int dtype, void* stream) {
   return extend_fwd_impl(1, q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices,
+                         is_causal, max_len_extend, batch, num_heads, num_kv_heads, head_size, head_size_v, q_stride_t,
+                         q_stride_h, ke_stride_t, ke_stride_h, ve_stride_t, ve_stride_h, o_stride_t, o_stride_h,
+                         kb_stride_n, kb_stride_h, vb_stride_n, vb_stride_h, sm_scale, logit_cap, custom_mask, mask_indptr,
+                         skip_prefix_custom_mask, sliding_window_size, dtype, stream);
+}
+
+// float8_e5m2 pool: Q and P of the prefix stage are rounded to e5m2 instead
+extern "C" int sgl_mi355_extend_attention_fwd_fp8kv_e5m2(
+    const void* q_extend, const void* k_extend, const void* v_extend, void* o_extend, const void* k_buffer,
+    const void* v_buffer, const int32_t* qo_indptr, const int32_t* kv_indptr, const int32_t* kv_indices, int is_causal,
+    int64_t max_len_extend, int64_t batch, int64_t num_heads, int64_t num_kv_heads, int64_t head_size,
+    int64_t head_size_v, int64_t q_stride_t, int64_t q_stride_h, int64_t ke_stride_t, int64_t ke_stride_h,
+    int64_t ve_stride_t, int64_t ve_stride_h, int64_t o_stride_t, int64_t o_stride_h, int64_t kb_stride_n,
+    int64_t kb_stride_h, int64_t vb_stride_n, int64_t vb_stride_h, float sm_scale, float logit_cap,
+    const uint8_t* custom_mask, const int64_t* mask_indptr, int skip_prefix_custom_mask, int64_t sliding_window_size,
+    int dtype, void* stream) {
+  return extend_fwd_impl(2, q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices,
                          is_causal, max_len_extend, batch, num_heads, num_kv_heads, head_size, head_size_v, q_stride_t,
                          q_stride_h, ke_stride_t, ke_stride_h, ve_stride_t, ve_stride_h, o_stride_t, o_stride_h,
                          kb_stride_n, kb_stride_h, vb_stride_n, vb_stride_h, sm_scale, logit_cap, custom_mask, mask_indptr,

@@ -132,6 +132,42 @@ __device__ __forceinline__ uint32_t cvt_pk_e4m3_torch(float a, float b) {
   return e4m3_byte_fix(a, (uint32_t)pk & 0xffu) | (e4m3_byte_fix(b, ((uint32_t)pk >> 8) & 0xffu) << 8);
 }
 
+// The same for `--kv-cache-dtype fp8_e5m2` (server_args.py:829-833): torch's .to(torch.float8_e5m2) of a 16-bit value.
+// e5m2 is the upper byte of an IEEE half: round to nearest even on the half's bits, overflow goes to +-inf (0x7c / 0xfc,
+// no saturation), NaN -> 0x7f | sign.  Exact for every fp16 and every bf16 input (the bf16 -> half step never rounds
+// in a way that changes the e5m2 result; checked exhaustively against torch in tests/test_fp8kv_gpu.py).
+__device__ __forceinline__ uint32_t cvt_e5m2_torch(float x) {
+  const uint32_t h = __builtin_bit_cast(uint16_t, (_Float16)x);
+  const uint32_t r = (h + 0x7Fu + ((h >> 8) & 1u)) >> 8;
+  return ((h & 0x7FFFu) > 0x7C00u) ? (0x7Fu | ((h >> 8) & 0x80u)) : (r & 0xFFu);
+}
+__device__ __forceinline__ uint32_t cvt_pk_e5m2_torch(float a, float b) { return cvt_e5m2_torch(a) | (cvt_e5m2_torch(b) << 8); }
+
+// KV-pool byte formats: 1 = e4m3fn, 2 = e5m2 ("bf8" in the ISA).  Two 16-bit-representable values -> two pool bytes.
+template <int FMT>
+__device__ __forceinline__ uint32_t cvt_pk_kv_torch(float a, float b) {
+  if constexpr (FMT == 2) return cvt_pk_e5m2_torch(a, b);
+  else return cvt_pk_e4m3_torch(a, b);
+}
+typedef float sglm_f32x2 __attribute__((ext_vector_type(2)));
+// pool bytes -> fp32 (exact), fp32 -> pool bytes in hardware rounding (RNE; callers pass values inside the finite range:
+// softmax weights in [0, 1]), and the byte x byte MFMA
+template <bool E5, bool HI>
+__device__ __forceinline__ sglm_f32x2 cvt_pk_f32_kv(int v) {
+  if constexpr (E5) return __builtin_amdgcn_cvt_pk_f32_bf8(v, HI);
+  else return __builtin_amdgcn_cvt_pk_f32_fp8(v, HI);
+}
+template <bool E5, bool HI>
+__device__ __forceinline__ int cvt_pk_kv_f32(float a, float b, int old) {
+  if constexpr (E5) return __builtin_amdgcn_cvt_pk_bf8_f32(a, b, old, HI);
+  else return __builtin_amdgcn_cvt_pk_fp8_f32(a, b, old, HI);
+}
+template <bool E5>
+__device__ __forceinline__ f32x4 mfma_kv8(long a, long b, f32x4 c) {
+  if constexpr (E5) return __builtin_amdgcn_mfma_f32_16x16x32_bf8_bf8(a, b, c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a, b, c, 0, 0, 0);
+}
+
 }  // namespace sglm
 
 #define SGLM_CHECK_ARG(cond, ...)            \

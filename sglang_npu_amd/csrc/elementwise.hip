@@ -226,10 +226,10 @@ __global__ __launch_bounds__(256) void rope_kernel(
 }
 
 // One element into a KV-pool row: 16-bit as is, or (KV8) cast to e4m3 as set_kv_buffer_fp8 does (torch's cast).
-template <int DTYPE, bool KV8>
+template <int DTYPE, int KV8>  // 0: 16-bit pool, 1: e4m3fn bytes, 2: e5m2 bytes
 __device__ __forceinline__ void pool_store(char* row, int i, typename Half16<DTYPE>::T v) {
   if constexpr (KV8) {
-    reinterpret_cast<uint8_t*>(row)[i] = (uint8_t)(cvt_pk_e4m3_torch(Half16<DTYPE>::to_f32(v), 0.f) & 0xFF);
+    reinterpret_cast<uint8_t*>(row)[i] = (uint8_t)(cvt_pk_kv_torch<KV8>(Half16<DTYPE>::to_f32(v), 0.f) & 0xFF);
   } else {
     reinterpret_cast<typename Half16<DTYPE>::T*>(row)[i] = v;
   }
@@ -240,7 +240,7 @@ __device__ __forceinline__ void pool_store(char* row, int i, typename Half16<DTY
 // One 64-thread wave per (token, head) over q heads, then k heads (which also carry v).
 // RoPE + KV write straight from the split-K partials of the qkv GEMM: column c of the [T, (Hq + 2 Hk) D] qkv row is
 // produced on the fly (gemm_elem), q goes (rotated) to q_out [T, Hq D], k (rotated) and v to the pool.
-template <int DTYPE, typename LocT, bool KV8>
+template <int DTYPE, typename LocT, int KV8>
 __global__ __launch_bounds__(256) void rope_kv_from_partials_kernel(
     typename Half16<DTYPE>::T* __restrict__ q_out, char* __restrict__ kb,
     char* __restrict__ vb, const int64_t* __restrict__ positions, const LocT* __restrict__ loc,
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void rope_kv_from_partials_kernel(
   }
 }
 
-template <int DTYPE, typename LocT, bool KV8>
+template <int DTYPE, typename LocT, int KV8>
 __global__ __launch_bounds__(256) void rope_kv_kernel(
     typename Half16<DTYPE>::T* __restrict__ q, typename Half16<DTYPE>::T* __restrict__ k,
     const typename Half16<DTYPE>::T* __restrict__ v, char* __restrict__ kb,
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void argmax_kernel(const typename ArgElem<DTYP
 // (token, head) -- each lane rotates two adjacent pairs with 4-byte accesses and copies four value elements -- so a wave
 // covers 2 or 4 heads.  At 1024 prefill tokens the one-pair-per-lane kernel was bound by its 2-byte accesses (14 us
 // for 25 MB).  Same arithmetic, same roundings.
-template <int DTYPE, typename LocT, bool KV8, int D>
+template <int DTYPE, typename LocT, int KV8, int D>
 __global__ __launch_bounds__(256) void rope_kv_neox_kernel(
     typename Half16<DTYPE>::T* __restrict__ q, typename Half16<DTYPE>::T* __restrict__ k,
     const typename Half16<DTYPE>::T* __restrict__ v, char* __restrict__ kb, char* __restrict__ vb,
@@ -457,10 +457,10 @@ __global__ __launch_bounds__(256) void rope_kv_neox_kernel(
     const T16* vs = v + t * v_st + (int64_t)(h - Hq) * D;
     const t16x2 v0 = *reinterpret_cast<const t16x2*>(vs + 4 * l), v1 = *reinterpret_cast<const t16x2*>(vs + 4 * l + 2);
     if constexpr (KV8) {
-      *reinterpret_cast<uint16_t*>(kdst + 2 * l) = (uint16_t)cvt_pk_e4m3_torch(Hh::to_f32(o1[0]), Hh::to_f32(o1[1]));
-      *reinterpret_cast<uint16_t*>(kdst + half + 2 * l) = (uint16_t)cvt_pk_e4m3_torch(Hh::to_f32(o2[0]), Hh::to_f32(o2[1]));
-      *reinterpret_cast<uint32_t*>(vdst + 4 * l) = cvt_pk_e4m3_torch(Hh::to_f32(v0[0]), Hh::to_f32(v0[1])) |
-                                                   (cvt_pk_e4m3_torch(Hh::to_f32(v1[0]), Hh::to_f32(v1[1])) << 16);
+      *reinterpret_cast<uint16_t*>(kdst + 2 * l) = (uint16_t)cvt_pk_kv_torch<KV8>(Hh::to_f32(o1[0]), Hh::to_f32(o1[1]));
+      *reinterpret_cast<uint16_t*>(kdst + half + 2 * l) = (uint16_t)cvt_pk_kv_torch<KV8>(Hh::to_f32(o2[0]), Hh::to_f32(o2[1]));
+      *reinterpret_cast<uint32_t*>(vdst + 4 * l) = cvt_pk_kv_torch<KV8>(Hh::to_f32(v0[0]), Hh::to_f32(v0[1])) |
+                                                   (cvt_pk_kv_torch<KV8>(Hh::to_f32(v1[0]), Hh::to_f32(v1[1])) << 16);
     } else {
       *reinterpret_cast<t16x2*>(kdst + 2 * (2 * l)) = o1;
       *reinterpret_cast<t16x2*>(kdst + 2 * (half + 2 * l)) = o2;
@@ -713,7 +713,7 @@ extern "C" int sgl_mi355_rotary_embedding(
   return check_hip(hipGetLastError(), "rotary_embedding launch");
 }
 
-static int rope_set_kv_impl(bool kv8,
+static int rope_set_kv_impl(int kv8,
     
     const int64_t* positions, void* query, void* key, const void* value, const float* cos_sin_cache,
     void* k_buffer, void* v_buffer, const void* loc, int loc_is64, int64_t num_tokens, int64_t num_q_heads,
@@ -753,7 +753,8 @@ static int rope_set_kv_impl(bool kv8,
   } while (0)
 #define ROPEF_K(DT, TT, LT)                  \
   do {                                       \
-    if (kv8) ROPEF_D(DT, TT, LT, true);      \
+    if (kv8 == 2) ROPEF_D(DT, TT, LT, 2);    \
+    else if (kv8) ROPEF_D(DT, TT, LT, 1);    \
     else ROPEF_D(DT, TT, LT, false);         \
   } while (0)
     if (dtype == SGL_MI355_BF16) {
@@ -773,7 +774,8 @@ static int rope_set_kv_impl(bool kv8,
                      v_stride_t, kb_stride_n, kb_stride_h, vb_stride_n, vb_stride_h, is_neox)
 #define ROPEKV(DT, TT, LT)                  \
   do {                                      \
-    if (kv8) ROPEKV_(DT, TT, LT, true);     \
+    if (kv8 == 2) ROPEKV_(DT, TT, LT, 2);   \
+    else if (kv8) ROPEKV_(DT, TT, LT, 1);   \
     else ROPEKV_(DT, TT, LT, false);        \
   } while (0)
   if (dtype == SGL_MI355_BF16) {
@@ -792,7 +794,7 @@ extern "C" int sgl_mi355_rotary_embedding_set_kv(
     int64_t num_k_heads, int64_t head_size, int64_t rot_dim, int64_t q_stride_t, int64_t k_stride_t,
     int64_t v_stride_t, int64_t kb_stride_n, int64_t kb_stride_h, int64_t vb_stride_n, int64_t vb_stride_h,
     int is_neox, int dtype, void* stream) {
-  return rope_set_kv_impl(false, positions, query, key, value, cos_sin_cache, k_buffer, v_buffer, loc, loc_is64, num_tokens, num_q_heads,
+  return rope_set_kv_impl(0, positions, query, key, value, cos_sin_cache, k_buffer, v_buffer, loc, loc_is64, num_tokens, num_q_heads,
                           num_k_heads, head_size, rot_dim, q_stride_t, k_stride_t, v_stride_t, kb_stride_n, kb_stride_h,
                           vb_stride_n, vb_stride_h, is_neox, dtype, stream);
 }
@@ -804,7 +806,7 @@ extern "C" int sgl_mi355_rotary_embedding_set_kv_fp8kv(
     int64_t num_k_heads, int64_t head_size, int64_t rot_dim, int64_t q_stride_t, int64_t k_stride_t,
     int64_t v_stride_t, int64_t kb_stride_n, int64_t kb_stride_h, int64_t vb_stride_n, int64_t vb_stride_h,
     int is_neox, int dtype, void* stream) {
-  return rope_set_kv_impl(true, positions, query, key, value, cos_sin_cache, k_buffer, v_buffer, loc, loc_is64, num_tokens, num_q_heads,
+  return rope_set_kv_impl(1, positions, query, key, value, cos_sin_cache, k_buffer, v_buffer, loc, loc_is64, num_tokens, num_q_heads,
                           num_k_heads, head_size, rot_dim, q_stride_t, k_stride_t, v_stride_t, kb_stride_n, kb_stride_h,
                           vb_stride_n, vb_stride_h, is_neox, dtype, stream);
 }
@@ -824,7 +826,7 @@ extern "C" int sgl_mi355_rmsnorm_quant_fp8_from_partials(
              : launch_rmsnorm_partials<SGL_MI355_FP16>(ps, residual, weight, out_q, out_s, num_tokens, hidden, eps, as_stream(stream));
 }
 
-static int rope_set_kv_partials_impl(bool kv8,
+static int rope_set_kv_partials_impl(int kv8,
     
     void* q_out, void* k_buffer, void* v_buffer, const int64_t* positions, const void* loc, int loc_is64,
     const float* cos_sin_cache, const float* partials, int64_t num_slices, const float* scales_a, const float* scales_b,
@@ -851,7 +853,8 @@ static int rope_set_kv_partials_impl(bool kv8,
                      vb_stride_n, vb_stride_h, is_neox, ps)
 #define ROPEKVP(DT, TT, LT)                 \
   do {                                      \
-    if (kv8) ROPEKVP_(DT, TT, LT, true);    \
+    if (kv8 == 2) ROPEKVP_(DT, TT, LT, 2);  \
+    else if (kv8) ROPEKVP_(DT, TT, LT, 1);  \
     else ROPEKVP_(DT, TT, LT, false);       \
   } while (0)
   if (dtype == SGL_MI355_BF16) {
@@ -864,13 +867,25 @@ static int rope_set_kv_partials_impl(bool kv8,
   return check_hip(hipGetLastError(), "rotary_embedding_set_kv_from_partials launch");
 }
 
+// ... and with a float8_e5m2 pool
+extern "C" int sgl_mi355_rotary_embedding_set_kv_fp8kv_e5m2(
+    const int64_t* positions, void* query, void* key, const void* value, const float* cos_sin_cache,
+    void* k_buffer, void* v_buffer, const void* loc, int loc_is64, int64_t num_tokens, int64_t num_q_heads,
+    int64_t num_k_heads, int64_t head_size, int64_t rot_dim, int64_t q_stride_t, int64_t k_stride_t,
+    int64_t v_stride_t, int64_t kb_stride_n, int64_t kb_stride_h, int64_t vb_stride_n, int64_t vb_stride_h,
+    int is_neox, int dtype, void* stream) {
+  return rope_set_kv_impl(2, positions, query, key, value, cos_sin_cache, k_buffer, v_buffer, loc, loc_is64, num_tokens, num_q_heads,
+                          num_k_heads, head_size, rot_dim, q_stride_t, k_stride_t, v_stride_t, kb_stride_n, kb_stride_h,
+                          vb_stride_n, vb_stride_h, is_neox, dtype, stream);
+}
+
 extern "C" int sgl_mi355_rotary_embedding_set_kv_from_partials(
     void* q_out, void* k_buffer, void* v_buffer, const int64_t* positions, const void* loc, int loc_is64,
     const float* cos_sin_cache, const float* partials, int64_t num_slices, const float* scales_a, const float* scales_b,
     const void* bias /* nullable */, int64_t num_tokens, int64_t num_q_heads, int64_t num_k_heads, int64_t head_size,
     int64_t rot_dim, int64_t q_out_stride_t, int64_t kb_stride_n, int64_t kb_stride_h, int64_t vb_stride_n,
     int64_t vb_stride_h, int is_neox, int dtype, void* stream) {
-  return rope_set_kv_partials_impl(false, q_out, k_buffer, v_buffer, positions, loc, loc_is64, cos_sin_cache, partials, num_slices, scales_a,
+  return rope_set_kv_partials_impl(0, q_out, k_buffer, v_buffer, positions, loc, loc_is64, cos_sin_cache, partials, num_slices, scales_a,
                                     scales_b, bias, num_tokens, num_q_heads, num_k_heads, head_size, rot_dim, q_out_stride_t,
                                     kb_stride_n, kb_stride_h, vb_stride_n, vb_stride_h, is_neox, dtype, stream);
 }
@@ -881,7 +896,18 @@ extern "C" int sgl_mi355_rotary_embedding_set_kv_from_partials_fp8kv(
     const void* bias /* nullable */, int64_t num_tokens, int64_t num_q_heads, int64_t num_k_heads, int64_t head_size,
     int64_t rot_dim, int64_t q_out_stride_t, int64_t kb_stride_n, int64_t kb_stride_h, int64_t vb_stride_n,
     int64_t vb_stride_h, int is_neox, int dtype, void* stream) {
-  return rope_set_kv_partials_impl(true, q_out, k_buffer, v_buffer, positions, loc, loc_is64, cos_sin_cache, partials, num_slices, scales_a,
+  return rope_set_kv_partials_impl(1, q_out, k_buffer, v_buffer, positions, loc, loc_is64, cos_sin_cache, partials, num_slices, scales_a,
+                                    scales_b, bias, num_tokens, num_q_heads, num_k_heads, head_size, rot_dim, q_out_stride_t,
+                                    kb_stride_n, kb_stride_h, vb_stride_n, vb_stride_h, is_neox, dtype, stream);
+}
+
+extern "C" int sgl_mi355_rotary_embedding_set_kv_from_partials_fp8kv_e5m2(
+    void* q_out, void* k_buffer, void* v_buffer, const int64_t* positions, const void* loc, int loc_is64,
+    const float* cos_sin_cache, const float* partials, int64_t num_slices, const float* scales_a, const float* scales_b,
+    const void* bias /* nullable */, int64_t num_tokens, int64_t num_q_heads, int64_t num_k_heads, int64_t head_size,
+    int64_t rot_dim, int64_t q_out_stride_t, int64_t kb_stride_n, int64_t kb_stride_h, int64_t vb_stride_n,
+    int64_t vb_stride_h, int is_neox, int dtype, void* stream) {
+  return rope_set_kv_partials_impl(2, q_out, k_buffer, v_buffer, positions, loc, loc_is64, cos_sin_cache, partials, num_slices, scales_a,
                                     scales_b, bias, num_tokens, num_q_heads, num_k_heads, head_size, rot_dim, q_out_stride_t,
                                     kb_stride_n, kb_stride_h, vb_stride_n, vb_stride_h, is_neox, dtype, stream);
 }

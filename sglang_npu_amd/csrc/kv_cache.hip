@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void set_kv_kernel_u16(
 
 // FP8 (e4m3fn) pool: cast of the 16-bit new entries (memory_pool.py:385-394: optional x.div_(scale) in the 16-bit
 // dtype, then .to(fp8), stored through a uint8 view).  torch's RNE cast (NaN and |x| > 464 stored as NaN, common.h cvt_pk_e4m3_torch); one wave per row.
-template <int DTYPE, typename LocT>
+template <int DTYPE, typename LocT, int FMT>
 __global__ __launch_bounds__(256) void set_kv_fp8_kernel(
     uint8_t* __restrict__ kb, uint8_t* __restrict__ vb, const typename Half16<DTYPE>::T* __restrict__ key,
     const typename Half16<DTYPE>::T* __restrict__ val, const LocT* __restrict__ loc, int64_t rows, int num_kv_heads,
@@ -75,7 +75,8 @@ __global__ __launch_bounds__(256) void set_kv_fp8_kernel(
         a = Hh::to_f32(Hh::from_f32(a / scale));
         b = Hh::to_f32(Hh::from_f32(b / scale));
       }
-      *reinterpret_cast<uint16_t*>(dst + i) = (uint16_t)cvt_pk_e4m3_torch(a, b);  // torch's cast: NaN / overflow -> NaN
+      // torch's cast (common.h): e4m3fn NaN / overflow -> NaN; e5m2 overflow -> inf
+      *reinterpret_cast<uint16_t*>(dst + i) = (uint16_t)cvt_pk_kv_torch<FMT>(a, b);
     }
   };
   cast_row(key + t * nk_sn + h * nk_sh, kb + slot * k_sn + h * k_sh, D, k_scale);
@@ -172,8 +173,8 @@ extern "C" int sgl_mi355_create_kv_indices(
   return check_hip(hipGetLastError(), "create_kv_indices launch");
 }
 
-extern "C" int sgl_mi355_set_kv_buffer_fp8(
-    void* k_buffer, void* v_buffer, const void* loc, int loc_is64, const void* key, const void* value,
+static int set_kv_buffer_fp8_impl(
+    int fmt, void* k_buffer, void* v_buffer, const void* loc, int loc_is64, const void* key, const void* value,
     int64_t num_tokens, int64_t num_kv_heads, int64_t head_size, int64_t head_size_v, int64_t k_stride_n,
     int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h, int64_t key_stride_n, int64_t key_stride_h,
     int64_t value_stride_n, int64_t value_stride_h, float k_scale, float v_scale, int dtype, void* stream) {
@@ -190,10 +191,18 @@ extern "C" int sgl_mi355_set_kv_buffer_fp8(
   const unsigned grid = (unsigned)((rows + 3) / 4);
   hipStream_t s = as_stream(stream);
 #define SETKV8(DT, TT, LT)                                                                                            \
-  hipLaunchKernelGGL((set_kv_fp8_kernel<DT, LT>), dim3(grid), dim3(256), 0, s, (uint8_t*)k_buffer, (uint8_t*)v_buffer, \
-                     (const TT*)key, (const TT*)value, (const LT*)loc, rows, (int)num_kv_heads, (int)head_size,        \
-                     (int)head_size_v, k_stride_n, k_stride_h, v_stride_n, v_stride_h, key_stride_n, key_stride_h,    \
-                     value_stride_n, value_stride_h, k_scale, v_scale)
+  do {                                                                                                                \
+    if (fmt == 2)                                                                                                     \
+      hipLaunchKernelGGL((set_kv_fp8_kernel<DT, LT, 2>), dim3(grid), dim3(256), 0, s, (uint8_t*)k_buffer,              \
+                         (uint8_t*)v_buffer, (const TT*)key, (const TT*)value, (const LT*)loc, rows, (int)num_kv_heads, \
+                         (int)head_size, (int)head_size_v, k_stride_n, k_stride_h, v_stride_n, v_stride_h, key_stride_n, \
+                         key_stride_h, value_stride_n, value_stride_h, k_scale, v_scale);                              \
+    else                                                                                                              \
+      hipLaunchKernelGGL((set_kv_fp8_kernel<DT, LT, 1>), dim3(grid), dim3(256), 0, s, (uint8_t*)k_buffer,              \
+                         (uint8_t*)v_buffer, (const TT*)key, (const TT*)value, (const LT*)loc, rows, (int)num_kv_heads, \
+                         (int)head_size, (int)head_size_v, k_stride_n, k_stride_h, v_stride_n, v_stride_h, key_stride_n, \
+                         key_stride_h, value_stride_n, value_stride_h, k_scale, v_scale);                              \
+  } while (0)
   if (dtype == SGL_MI355_BF16) {
     if (loc_is64) SETKV8(SGL_MI355_BF16, __bf16, int64_t); else SETKV8(SGL_MI355_BF16, __bf16, int32_t);
   } else {
@@ -201,4 +210,25 @@ extern "C" int sgl_mi355_set_kv_buffer_fp8(
   }
 #undef SETKV8
   return check_hip(hipGetLastError(), "set_kv_buffer_fp8 launch");
+}
+
+extern "C" int sgl_mi355_set_kv_buffer_fp8(
+    void* k_buffer, void* v_buffer, const void* loc, int loc_is64, const void* key, const void* value,
+    int64_t num_tokens, int64_t num_kv_heads, int64_t head_size, int64_t head_size_v, int64_t k_stride_n,
+    int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h, int64_t key_stride_n, int64_t key_stride_h,
+    int64_t value_stride_n, int64_t value_stride_h, float k_scale, float v_scale, int dtype, void* stream) {
+  return set_kv_buffer_fp8_impl(1, k_buffer, v_buffer, loc, loc_is64, key, value, num_tokens, num_kv_heads, head_size,
+                                head_size_v, k_stride_n, k_stride_h, v_stride_n, v_stride_h, key_stride_n, key_stride_h,
+                                value_stride_n, value_stride_h, k_scale, v_scale, dtype, stream);
+}
+
+// the same into a float8_e5m2 pool (`--kv-cache-dtype fp8_e5m2`)
+extern "C" int sgl_mi355_set_kv_buffer_fp8_e5m2(
+    void* k_buffer, void* v_buffer, const void* loc, int loc_is64, const void* key, const void* value,
+    int64_t num_tokens, int64_t num_kv_heads, int64_t head_size, int64_t head_size_v, int64_t k_stride_n,
+    int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h, int64_t key_stride_n, int64_t key_stride_h,
+    int64_t value_stride_n, int64_t value_stride_h, float k_scale, float v_scale, int dtype, void* stream) {
+  return set_kv_buffer_fp8_impl(2, k_buffer, v_buffer, loc, loc_is64, key, value, num_tokens, num_kv_heads, head_size,
+                                head_size_v, k_stride_n, k_stride_h, v_stride_n, v_stride_h, key_stride_n, key_stride_h,
+                                value_stride_n, value_stride_h, k_scale, v_scale, dtype, stream);
 }

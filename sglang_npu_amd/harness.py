@@ -81,8 +81,6 @@ class MHATokenToKVPool:
         self.v_head_dim = v_head_dim or head_dim
         # an FP8 pool is stored as uint8 because index_put is not implemented for float8 (memory_pool.py:114-118)
         self.store_dtype = torch.uint8 if dtype in (torch.float8_e5m2, torch.float8_e4m3fn) else dtype
-        if dtype == torch.float8_e5m2:
-            raise NotImplementedError("kv_cache_dtype fp8_e5m2 is not supported by this backend (fp8_e4m3 is)")
         self.k_buffer = [torch.zeros((size + page_size, head_num, head_dim), dtype=self.store_dtype, device=device)
                          for _ in range(layer_num)]
         self.v_buffer = [torch.zeros((size + page_size, head_num, self.v_head_dim), dtype=self.store_dtype, device=device)
@@ -108,7 +106,7 @@ class MHATokenToKVPool:
         if self.store_dtype != self.dtype:  # memory_pool.py:385-394: (scale,) cast, uint8 view
             ops.set_kv_buffer_fp8(self.k_buffer[lid], self.v_buffer[lid], loc,
                                   cache_k.view(-1, self.head_num, self.head_dim),
-                                  cache_v.view(-1, self.head_num, self.v_head_dim), k_scale, v_scale)
+                                  cache_v.view(-1, self.head_num, self.v_head_dim), k_scale, v_scale, fp8_dtype=self.dtype)
             return
         ops.set_kv_buffer(self.k_buffer[lid], self.v_buffer[lid], loc,
                           cache_k.view(-1, self.head_num, self.head_dim),

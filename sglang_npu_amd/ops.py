@@ -138,29 +138,45 @@ def decode_attention(query, k_cache, v_cache, output, key, value, loc, attn_logi
 _FP8_KV = (torch.float8_e4m3fn, torch.uint8)  # an e4m3 pool is stored through a uint8 view (memory_pool.py:114-118)
 
 
-def _is_fp8_pool(k_buffer, v_buffer, q) -> bool:
-    """FP8 (e4m3fn) KV pool next to 16-bit queries; float8_e5m2 pools are not supported."""
+def _kv_format(k_buffer, v_buffer, q) -> int:
+    """0: 16-bit pool (the queries' dtype); 1: float8_e4m3fn (or a uint8 view, read as e4m3fn); 2: float8_e5m2."""
     if k_buffer.dtype == q.dtype and v_buffer.dtype == q.dtype:
-        return False
+        return 0
+    if k_buffer.dtype == torch.float8_e5m2 and v_buffer.dtype == torch.float8_e5m2:
+        return 2
     if k_buffer.dtype in _FP8_KV and v_buffer.dtype in _FP8_KV:
-        return True
+        return 1
     raise NotImplementedError(f"KV pool dtype {k_buffer.dtype}/{v_buffer.dtype} with {q.dtype} queries is not "
-                              "supported (16-bit pools, or float8_e4m3fn / its uint8 view)")
+                              "supported (16-bit pools, float8_e4m3fn / its uint8 view, float8_e5m2)")
 
 
-def set_kv_buffer_fp8(k_buffer, v_buffer, loc, cache_k, cache_v, k_scale=None, v_scale=None):
-    """MHATokenToKVPool.set_kv_buffer for a float8_e4m3fn pool (memory_pool.py:385-394): optional x.div_(scale) in the
-    16-bit dtype, then torch's own e4m3 cast (round to nearest even; NaN and |x| > 464 become NaN, nothing saturates), store."""
+def _is_fp8_pool(k_buffer, v_buffer, q) -> bool:
+    return _kv_format(k_buffer, v_buffer, q) != 0
+
+
+def _kv_fn(base: str, fmt: int):
+    """C entry point of an op for the pool format: base, base + "_fp8kv", base + "_fp8kv_e5m2"."""
+    return getattr(_lib.lib(), base + ("", "_fp8kv", "_fp8kv_e5m2")[fmt])
+
+
+def set_kv_buffer_fp8(k_buffer, v_buffer, loc, cache_k, cache_v, k_scale=None, v_scale=None, fp8_dtype=None):
+    """MHATokenToKVPool.set_kv_buffer for an FP8 pool (memory_pool.py:385-394): optional x.div_(scale) in the 16-bit dtype,
+    then torch's own cast, store.  float8_e4m3fn: round to nearest even; NaN and |x| > 464 become NaN, nothing saturates.
+    float8_e5m2: round to nearest even, overflow -> inf.  The pool is usually passed as its uint8 storage
+    (memory_pool.py:114-118); `fp8_dtype` then says which format it holds (default: the buffer's own dtype, uint8 = e4m3fn)."""
     _need_gpu(k_buffer, v_buffer, loc, cache_k, cache_v)
-    if k_buffer.dtype not in _FP8_KV or v_buffer.dtype not in _FP8_KV:
-        raise RuntimeError("set_kv_buffer_fp8: the pool must be float8_e4m3fn (or its uint8 view)")
+    fmt_dtype = fp8_dtype if fp8_dtype is not None else k_buffer.dtype
+    if k_buffer.dtype not in _FP8_KV + (torch.float8_e5m2,) or v_buffer.dtype != k_buffer.dtype or \
+            fmt_dtype not in _FP8_KV + (torch.float8_e5m2,):
+        raise RuntimeError("set_kv_buffer_fp8: the pool must be float8_e4m3fn / float8_e5m2 (or the uint8 view)")
     for t in (k_buffer, v_buffer, cache_k, cache_v):
         if t.dim() != 3 or t.stride(-1) != 1:
             raise RuntimeError("set_kv_buffer_fp8: expected [N,H,D] pool and [T,H,D] new entries, last dim contiguous")
     T, Hkv, D = cache_k.shape
     if loc.dim() != 1 or loc.numel() != T or cache_v.size(0) != T:
         raise RuntimeError("set_kv_buffer_fp8: loc must hold one slot per new token")
-    _lib.check(_lib.lib().sgl_mi355_set_kv_buffer_fp8(
+    fn = _lib.lib().sgl_mi355_set_kv_buffer_fp8_e5m2 if fmt_dtype == torch.float8_e5m2 else _lib.lib().sgl_mi355_set_kv_buffer_fp8
+    _lib.check(fn(
         _ptr(k_buffer), _ptr(v_buffer), _ptr(loc), _I(_is64(loc, "loc")), _ptr(cache_k), _ptr(cache_v), _I64(T),
         _I64(Hkv), _I64(D), _I64(cache_v.size(2)), _I64(k_buffer.stride(0)), _I64(k_buffer.stride(1)),
         _I64(v_buffer.stride(0)), _I64(v_buffer.stride(1)), _I64(cache_k.stride(0)), _I64(cache_k.stride(1)),
@@ -190,8 +206,9 @@ def decode_attention_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_indi
                                "[B, Hq, num_kv_splits, Dv+1]")
     if req_to_token.dim() != 2 or req_to_token.stride(1) != 1 or req_to_token.stride(0) != req_to_token.size(1):
         raise RuntimeError("decode_attention_paged: req_to_token must be a contiguous 2-D tensor")
-    if _is_fp8_pool(k_buffer, v_buffer, q):
-        _lib.check(_lib.lib().sgl_mi355_decode_attention_fp8kv(
+    fmt = _kv_format(k_buffer, v_buffer, q)
+    if fmt:
+        _lib.check(_kv_fn("sgl_mi355_decode_attention", fmt)(
             _ptr(q), _ptr(k_buffer), _ptr(v_buffer), _ptr(o), _ptr(attn_logits), _ptr(req_to_token),
             _I(_is64(req_to_token, "req_to_token")), _ptr(req_pool_indices), _ptr(seq_lens), _I64(B),
             _I64(req_to_token.size(1)), _I64(Hq), _I64(k_buffer.size(1)), _I64(D), _I64(Dv), _I64(num_kv_splits),
@@ -247,8 +264,7 @@ def decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_l
     for name, t in (("q", q), ("k_buffer", k_buffer), ("v_buffer", v_buffer), ("o", o)):
         if t.dim() != 3 or t.stride(-1) != 1:
             raise RuntimeError(f"decode_attention_fwd: {name} must be 3-D, contiguous at the last dimension")
-    fn = _lib.lib().sgl_mi355_decode_attention_fwd_fp8kv if _is_fp8_pool(k_buffer, v_buffer, q) \
-        else _lib.lib().sgl_mi355_decode_attention_fwd
+    fn = _kv_fn("sgl_mi355_decode_attention_fwd", _kv_format(k_buffer, v_buffer, q))
     _lib.check(fn(
         _ptr(q), _ptr(k_buffer), _ptr(v_buffer), _ptr(o), _ptr(kv_indptr), _ptr(kv_indices),
         _ptr(attn_logits), _ptr(attn_lse), _ptr(num_kv_splits), _I64(max_kv_splits),
@@ -290,8 +306,7 @@ def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buf
     D = q_extend.size(2)
     sm_scale = sm_scale if sm_scale is not None else 1.0 / (D ** 0.5)
     # FP8 (e4m3) KV pool: the prefix stage reads FP8 rows with q and p rounded to FP8 (extend_attention.py:149, :200)
-    fn = _lib.lib().sgl_mi355_extend_attention_fwd_fp8kv if _is_fp8_pool(k_buffer, v_buffer, q_extend) \
-        else _lib.lib().sgl_mi355_extend_attention_fwd
+    fn = _kv_fn("sgl_mi355_extend_attention_fwd", _kv_format(k_buffer, v_buffer, q_extend))
     _lib.check(fn(
         _ptr(q_extend), _ptr(k_extend), _ptr(v_extend), _ptr(o_extend), _ptr(k_buffer), _ptr(v_buffer),
         _ptr(qo_indptr), _ptr(kv_indptr), _ptr(kv_indices), _I(1 if is_causal else 0), _I64(max_len_extend),
@@ -629,8 +644,7 @@ def rope_set_kv_from_partials(part: GemmPartials, positions, num_q_heads, num_k_
     q = torch.empty((part.M, num_q_heads * head_size), dtype=part.out_dtype, device=k_buffer.device)
     if loc.numel() != part.M:
         raise RuntimeError("rope_set_kv_from_partials: loc must hold one pool slot per token")
-    fn = _lib.lib().sgl_mi355_rotary_embedding_set_kv_from_partials_fp8kv if _is_fp8_pool(k_buffer, v_buffer, q) \
-        else _lib.lib().sgl_mi355_rotary_embedding_set_kv_from_partials
+    fn = _kv_fn("sgl_mi355_rotary_embedding_set_kv_from_partials", _kv_format(k_buffer, v_buffer, q))
     _lib.check(fn(
         _ptr(q), _ptr(k_buffer), _ptr(v_buffer), _ptr(positions), _ptr(loc), _I(_is64(loc, "loc")), _ptr(cos_sin_cache),
         _ptr(part.ws), _I64(part.num_slices), _ptr(part.x_scale), _ptr(part.w_scale), _ptr(part.bias), _I64(part.M),
@@ -935,8 +949,7 @@ def apply_rope_and_set_kv_buffer(positions, query, key, value, head_size, cos_si
         raise RuntimeError("apply_rope_and_set_kv_buffer: pool head size must equal head_size")
     if loc.numel() != positions.numel():
         raise RuntimeError("apply_rope_and_set_kv_buffer: loc must hold one pool slot per token")
-    fn = _lib.lib().sgl_mi355_rotary_embedding_set_kv_fp8kv if _is_fp8_pool(k_buffer, v_buffer, query) \
-        else _lib.lib().sgl_mi355_rotary_embedding_set_kv
+    fn = _kv_fn("sgl_mi355_rotary_embedding_set_kv", _kv_format(k_buffer, v_buffer, query))
     _lib.check(fn(
         _ptr(positions), _ptr(query), _ptr(key), _ptr(value), _ptr(cos_sin_cache), _ptr(k_buffer), _ptr(v_buffer),
         _ptr(loc), _I(_is64(loc, "loc")), _I64(positions.numel()), _I64(query.size(-1) // head_size),

@@ -88,17 +88,23 @@ def test_fp8_pool_unsupported_shapes_raise():
         ops.decode_attention_paged(q, kb, kb, torch.zeros_like(q), torch.zeros(1, 4, dtype=torch.int32, device=DEV),
                                    torch.zeros(1, dtype=torch.int64, device=DEV), torch.ones(1, dtype=torch.int64, device=DEV),
                                    None, 1, 1.0, 0.0)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(NotImplementedError):  # mixed pool formats
         ops.decode_attention_paged(torch.zeros(1, 2, 128, dtype=torch.bfloat16, device=DEV),
                                    torch.zeros(9, 2, 128, dtype=torch.float8_e5m2, device=DEV),
-                                   torch.zeros(9, 2, 128, dtype=torch.float8_e5m2, device=DEV),
+                                   torch.zeros(9, 2, 128, dtype=torch.float8_e4m3fn, device=DEV),
                                    torch.zeros(1, 2, 128, dtype=torch.bfloat16, device=DEV),
                                    torch.zeros(1, 4, dtype=torch.int32, device=DEV), torch.zeros(1, dtype=torch.int64, device=DEV),
                                    torch.ones(1, dtype=torch.int64, device=DEV), None, 1, 1.0, 0.0)
+    with pytest.raises(NotImplementedError):  # head size 80 on an e5m2 pool
+        kb5 = torch.zeros(9, 2, 80, dtype=torch.float8_e5m2, device=DEV)
+        ops.decode_attention_paged(q, kb5, kb5, torch.zeros_like(q), torch.zeros(1, 4, dtype=torch.int32, device=DEV),
+                                   torch.zeros(1, dtype=torch.int64, device=DEV), torch.ones(1, dtype=torch.int64, device=DEV),
+                                   None, 1, 1.0, 0.0)
 
 
-def test_backend_prefill_then_decode_with_fp8_pool():
-    """MI355AttnBackend on an FP8 pool: EXTEND without a cached prefix (16-bit kernel on the new tokens, K/V cast into
+@pytest.mark.parametrize("kv_dtype", [torch.float8_e4m3fn, torch.float8_e5m2])
+def test_backend_prefill_then_decode_with_fp8_pool(kv_dtype):
+    """MI355AttnBackend on an FP8 pool (e4m3fn, e5m2): EXTEND without a cached prefix (16-bit kernel on the new tokens, K/V cast into
     the pool), DECODE steps reading the byte rows, then an EXTEND over a cached prefix in the pool."""
     from sglang_npu_amd.attention_backend import MI355AttnBackend
     from sglang_npu_amd.harness import (ForwardBatch, ForwardMode, MHATokenToKVPool, ModelConfig, ModelRunnerLike,
@@ -107,8 +113,8 @@ def test_backend_prefill_then_decode_with_fp8_pool():
     cfg = ModelConfig(Hq, Hkv, D, Hq * D, 4 * Hq * D, 1, 1000, max_len)
     r2t = ReqToTokenPool(B, max_len, DEV)
     n_tok = B * max_len + 1
-    pool = MHATokenToKVPool(n_tok, 1, torch.float8_e4m3fn, Hkv, D, 1, DEV)
-    assert pool.k_buffer[0].dtype == torch.uint8 and pool.get_key_buffer(0).dtype == torch.float8_e4m3fn
+    pool = MHATokenToKVPool(n_tok, 1, kv_dtype, Hkv, D, 1, DEV)
+    assert pool.k_buffer[0].dtype == torch.uint8 and pool.get_key_buffer(0).dtype == kv_dtype
     g = torch.Generator(device=DEV).manual_seed(0)
     r2t.req_to_token.copy_((torch.randperm(n_tok - 1, device=DEV, generator=g) + 1)[: B * max_len].view(B, max_len).int())
     backend = MI355AttnBackend(ModelRunnerLike(cfg, r2t, pool, DEV, 0, 1, ServerArgs()))
@@ -131,7 +137,7 @@ def test_backend_prefill_then_decode_with_fp8_pool():
     assert torch.isfinite(o.float()).all()
     kb_ref = torch.zeros(n_tok + 1, Hkv, D, dtype=torch.uint8)
     vb_ref = torch.zeros_like(kb_ref)
-    oracle.set_kv_buffer_fp8(kb_ref, vb_ref, k.cpu().view(T, Hkv, D), v.cpu().view(T, Hkv, D), loc.cpu())
+    oracle.set_kv_buffer_fp8(kb_ref, vb_ref, k.cpu().view(T, Hkv, D), v.cpu().view(T, Hkv, D), loc.cpu(), kv_dtype=kv_dtype)
     assert torch.equal(pool.k_buffer[0].cpu(), kb_ref) and torch.equal(pool.v_buffer[0].cpu(), vb_ref)
     # decode
     seq = seq + 1
@@ -143,14 +149,14 @@ def test_backend_prefill_then_decode_with_fp8_pool():
                       req_to_token_pool=r2t, token_to_kv_pool=pool, attn_backend=backend)
     backend.init_forward_metadata(fb)
     od = layer(qd, kd, vd, fb)
-    oracle.set_kv_buffer_fp8(kb_ref, vb_ref, kd.cpu().view(B, Hkv, D), vd.cpu().view(B, Hkv, D), locd.cpu())
+    oracle.set_kv_buffer_fp8(kb_ref, vb_ref, kd.cpu().view(B, Hkv, D), vd.cpu().view(B, Hkv, D), locd.cpu(), kv_dtype=kv_dtype)
     assert torch.equal(pool.k_buffer[0].cpu(), kb_ref)
     truth, ref = torch.zeros(B, Hq, D, dtype=torch.bfloat16), torch.zeros(B, Hq, D, dtype=torch.bfloat16)
     args = (qd.cpu().view(B, Hq, D), kb_ref, vb_ref)
     oracle.decode_attention_fp8kv(*args, truth, torch.zeros(B, Hq, 1, D + 1), r2t.req_to_token.cpu(), rpi.cpu(), seq.cpu(),
-                                  D ** -0.5, p_fp8=False)
+                                  D ** -0.5, p_fp8=False, kv_dtype=kv_dtype)
     oracle.decode_attention_fp8kv(*args, ref, torch.zeros(B, Hq, 1, D + 1), r2t.req_to_token.cpu(), rpi.cpu(), seq.cpu(),
-                                  D ** -0.5, p_fp8=True)
+                                  D ** -0.5, p_fp8=True, kv_dtype=kv_dtype)
     err = float((od.float().cpu().view(B, Hq, D) - truth.float()).abs().max())
     assert err <= 1.5 * float((ref.float() - truth.float()).abs().max()) + 2.0 ** -8 * float(truth.float().abs().max())
     # a cached prefix in the FP8 pool: the prefix stage reads the byte rows (q and p rounded to FP8)
@@ -162,14 +168,14 @@ def test_backend_prefill_then_decode_with_fp8_pool():
                       attn_backend=backend)
     backend.init_forward_metadata(fb)
     oe = layer(q[:4], k[:4], v[:4], fb)
-    oracle.set_kv_buffer_fp8(kb_ref, vb_ref, k[:4].cpu().view(4, Hkv, D), v[:4].cpu().view(4, Hkv, D), loc4.cpu())
+    oracle.set_kv_buffer_fp8(kb_ref, vb_ref, k[:4].cpu().view(4, Hkv, D), v[:4].cpu().view(4, Hkv, D), loc4.cpu(), kv_dtype=kv_dtype)
     assert torch.equal(pool.k_buffer[0].cpu(), kb_ref)
     outs = []
     for p_fp8 in (False, True):
         o_ref = torch.zeros(4, Hq, D, dtype=torch.bfloat16)
         oracle.extend_attention_fp8kv(q[:4].cpu().view(4, Hq, D), k[:4].cpu().view(4, Hkv, D), v[:4].cpu().view(4, Hkv, D),
                                       o_ref, kb_ref, vb_ref, r2t.req_to_token.cpu(), torch.tensor([0]), torch.tensor([95]),
-                                      torch.tensor([4]), torch.tensor([0]), D ** -0.5, p_fp8=p_fp8)
+                                      torch.tensor([4]), torch.tensor([0]), D ** -0.5, p_fp8=p_fp8, kv_dtype=kv_dtype)
         outs.append(o_ref.float())
     err = float((oe.float().cpu().view(4, Hq, D) - outs[0]).abs().max())
     assert err <= 1.5 * float((outs[1] - outs[0]).abs().max()) + 2.0 ** -8 * float(outs[0].abs().max())
