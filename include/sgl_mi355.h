@@ -547,6 +547,14 @@ int sgl_mi355_ar_open_peers(void* comm, const void* all_handles);
 int sgl_mi355_ar_set_peers_local(void* comm, void* const* comms);
 int sgl_mi355_ar_set_spin_limit(int64_t spins);
 int sgl_mi355_ar_all_reduce(void* comm, const void* inp, void* out, int64_t nbytes, int dtype, void* stream);
+/* QuickReduce-class all-reduce for prefill-size messages (MI355X counterpart of qr_all_reduce, quick_all_reduce.cu:60-110,
+ * driven by device_communicators/quick_all_reduce.py:216-260): two-shot over the same IPC staging area, the message cut
+ * into chunks (one launch each), with block-scaled integer transport -- blocks of 32 values share a half scale,
+ * regime 1 / 2 / 3 = INT8 / INT6 / INT4 (QuickReduceRegime, quick_all_reduce.py:47-52), regime 0 = exact fp32-accumulated
+ * two-shot.  nbytes % 64 == 0; dtype 0 bf16, 1 fp16.  Every rank returns bit-identical results; with an integer regime
+ * they differ from the exact sum by at most two quantisation steps per element. */
+int sgl_mi355_ar_quick_all_reduce(void* comm, const void* inp, void* out, int64_t nbytes, int dtype, int regime,
+                                  void* stream);
 /* All-reduce (SUM over the ranks) of `inp` [num_tokens, hidden] + residual add + RMSNorm (+ optional per-token FP8
  * quant) in one kernel: what RMSNorm.forward_with_allreduce_fusion (layers/layernorm.py:191-216; seam
  * layers/communicator.py:190-199,425-441 with RowParallelLinear.forward(can_fuse_mlp_allreduce=True),

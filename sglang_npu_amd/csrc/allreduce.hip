@@ -181,6 +181,155 @@ __global__ __launch_bounds__(kThreads) void all_reduce_kernel(ArArgs a, const ui
 }
 
 // ------------------------------------------------------------------------------------------
+// QuickReduce-class all-reduce: two-shot with BLOCK-SCALED INTEGER TRANSPORT for prefill-size messages.
+//
+// Role in the reference: sgl-kernel/csrc/allreduce/quick_all_reduce.cuh (AllReduceTwoshot over CodecQ8 / CodecQ6 /
+// CodecQ4, :50-480) behind device_communicators/quick_all_reduce.py:56-260 -- ROCm only, opt-in through
+// ROCM_QUICK_REDUCE_QUANTIZATION, for messages the custom all-reduce does not take (its 16 MiB cap) or is slower on.
+// Codec semantics restated from there (quick_all_reduce.cuh:71-135 Q4, :210-290 Q6, :346-440 Q8): blocks of 32
+// consecutive values share one half-precision scale; with R = 2^(bits-1),
+//     dec = half(-absmax / R)            (the NEGATIVE scale of the reference: +absmax maps to -R, exactly representable)
+//     enc = 1 / (dec + eps)              (eps = the smallest positive half, 2^-24)
+//     q   = clamp(rint(x * enc), -R, R - 1) + R      (unsigned, `bits` wide)
+//     x'  = (q - R) * dec
+// The reference does this arithmetic in packed half / bfloat16; here it is fp32 with the scale rounded to half (what is
+// transported), which only makes the rounding decisions more faithful.  The wire layout is this file's own (all ranks
+// run this code): per transmitted region the packed integers of unit u (8 values, `bits` bytes) at u * bits, then the
+// scales, one half per 4 units.
+//
+// Protocol = the two-shot all-reduce above on the QUANTISED image, chunked by the host so that any message size runs
+// through the fixed IPC staging area (the reference's tiles, quick_all_reduce.cuh kTileSize):
+//   A  quantise my chunk into my IPC buffer;                                              flag barrier 0
+//   B  owner r: dequantise slice r of every rank (rank order, fp32 sum), re-quantise, store in its result area;   barrier 1
+//   C  everyone: dequantise the W reduced slices into `out`.
+// All ranks decode the same bytes in phase C, so every rank returns bit-identical results; the result differs from the
+// exact sum by at most two quantisation steps per element (test_quick_allreduce.py:162-163 allows atol 1.25 W, rtol 0.5 W).
+template <int BITS>
+struct QPack {  // 8 unsigned `BITS`-wide values <-> BITS bytes
+  static __device__ __forceinline__ void store(char* p, const uint32_t* q) {
+    if constexpr (BITS == 8) {
+      *reinterpret_cast<uint2*>(p) = uint2{q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24), q[4] | (q[5] << 8) | (q[6] << 16) | (q[7] << 24)};
+    } else if constexpr (BITS == 4) {
+      uint32_t w = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w |= q[j] << (4 * j);
+      *reinterpret_cast<uint32_t*>(p) = w;
+    } else {
+      uint64_t w = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w |= (uint64_t)q[j] << (6 * j);
+      uint16_t* d = reinterpret_cast<uint16_t*>(p);
+      d[0] = (uint16_t)w; d[1] = (uint16_t)(w >> 16); d[2] = (uint16_t)(w >> 32);
+    }
+  }
+  static __device__ __forceinline__ void load(const char* p, uint32_t* q) {
+    if constexpr (BITS == 8) {
+      const uint2 w = *reinterpret_cast<const uint2*>(p);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { q[j] = (w.x >> (8 * j)) & 0xffu; q[4 + j] = (w.y >> (8 * j)) & 0xffu; }
+    } else if constexpr (BITS == 4) {
+      const uint32_t w = *reinterpret_cast<const uint32_t*>(p);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) q[j] = (w >> (4 * j)) & 0xfu;
+    } else {
+      const uint16_t* d = reinterpret_cast<const uint16_t*>(p);
+      const uint64_t w = (uint64_t)d[0] | ((uint64_t)d[1] << 16) | ((uint64_t)d[2] << 32);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) q[j] = (uint32_t)(w >> (6 * j)) & 0x3fu;
+    }
+  }
+};
+
+// quantise the 8 values of this thread; the 4 threads of a 32-value block are 4 consecutive lanes (aligned)
+template <int BITS>
+__device__ __forceinline__ void q_encode(const float* f, char* qdst, _Float16* sdst, bool leader) {
+  constexpr float R = (float)(1 << (BITS - 1));
+  float am = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) am = fmaxf(am, fabsf(f[j]));
+  am = fmaxf(am, __shfl_xor(am, 1));
+  am = fmaxf(am, __shfl_xor(am, 2));
+  const _Float16 dech = (_Float16)(am * (-1.0f / R));
+  const float dec = (float)dech;
+  const float enc = 1.0f / (dec + 5.9604644775390625e-8f);
+  uint32_t q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) q[j] = (uint32_t)(int)(fminf(fmaxf(rintf(f[j] * enc), -R), R - 1.0f) + R);
+  QPack<BITS>::store(qdst, q);
+  if (leader) *sdst = dech;
+}
+template <int BITS>
+__device__ __forceinline__ void q_decode_add(float* f, const char* qsrc, const _Float16* ssrc) {
+  constexpr int R = 1 << (BITS - 1);
+  uint32_t q[8];
+  QPack<BITS>::load(qsrc, q);
+  const float dec = (float)*ssrc;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] += (float)((int)q[j] - R) * dec;
+}
+
+template <int DTYPE, int BITS>
+__global__ __launch_bounds__(kThreads) void quick_reduce_kernel(ArArgs a, const uint4* __restrict__ inp, uint4* __restrict__ out,
+                                                                int64_t n_units) {
+  using A = Acc8<DTYPE>;
+  uint32_t* counter = reinterpret_cast<uint32_t*>(a.peer[a.rank] + kCounterOff) + blockIdx.x;
+  const uint32_t call = *counter + 1;
+  const int half = call & 1;
+  const int64_t tid = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  const int64_t nthr = (int64_t)gridDim.x * kThreads;
+  const size_t area = a.data_off + half * a.half_bytes;  // this call's quantised-input area (per rank)
+  const size_t res_off = a.half_bytes / 2;               // the owner's re-quantised slice, same indexing
+  const size_t sc_off = ((size_t)n_units * BITS + 15) & ~(size_t)15;
+  char* mine = a.peer[a.rank] + area;
+
+  bool ok = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0;
+  if (ok) {
+    // phase A: my chunk, quantised (n_units % 4 == 0 and nthr % 4 == 0: a block's 4 threads move together)
+    for (int64_t u = tid; u < n_units; u += nthr) {
+      float f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      A::add(f, inp[u]);
+      q_encode<BITS>(f, mine + u * BITS, reinterpret_cast<_Float16*>(mine + sc_off) + (u >> 2), (u & 3) == 0);
+    }
+    ok = block_barrier(a, 0, call);
+  }
+  if (!ok) {
+    poison(out, n_units, tid, nthr);
+    if (threadIdx.x == 0) *counter = call;
+    return;
+  }
+  // phase B: my slice of every rank -> fp32 sum in rank order -> quantised again into my result area.  As in the
+  // exact kernel, unit u is always handled by global thread u % nthr (the flag barriers pair equal block indices).
+  int64_t per = (n_units + a.world - 1) / a.world;
+  per = (per + 3) & ~(int64_t)3;
+  const int64_t lo = (int64_t)a.rank * per < n_units ? (int64_t)a.rank * per : n_units;
+  const int64_t hi = (lo + per) < n_units ? (lo + per) : n_units;
+  const int64_t first = lo + (((tid - lo) % nthr) + nthr) % nthr;
+  for (int64_t u = first; u < hi; u += nthr) {
+    float f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int p = 0; p < a.world; ++p) {
+      const char* src = a.peer[p] + area;
+      q_decode_add<BITS>(f, src + u * BITS, reinterpret_cast<const _Float16*>(src + sc_off) + (u >> 2));
+    }
+    q_encode<BITS>(f, mine + res_off + u * BITS, reinterpret_cast<_Float16*>(mine + res_off + sc_off) + (u >> 2), (u & 3) == 0);
+  }
+  if (!block_barrier(a, 1, call)) {
+    poison(out, n_units, tid, nthr);
+    if (threadIdx.x == 0) *counter = call;
+    return;
+  }
+  // phase C: all reduced slices
+  for (int64_t u = tid; u < n_units; u += nthr) {
+    const int owner = (int)(u / per);
+    const char* src = a.peer[owner] + area + res_off;
+    float f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    q_decode_add<BITS>(f, src + u * BITS, reinterpret_cast<const _Float16*>(src + sc_off) + (u >> 2));
+    out[u] = A::pack(f);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) *counter = call;
+}
+
+// ------------------------------------------------------------------------------------------
 // All-reduce + residual add + RMSNorm (+ per-token FP8 quant) in ONE kernel: the consumer of a row-parallel GEMM under
 // tensor parallelism (o_proj / down_proj -> the next norm).  Upstream seam: RowParallelLinear.forward(...,
 // can_fuse_mlp_allreduce=True) skips its collective (layers/linear.py:1285-1303) and
@@ -470,6 +619,52 @@ extern "C" int sgl_mi355_ar_all_reduce(void* comm, const void* inp, void* out, i
   else
     hipLaunchKernelGGL((all_reduce_kernel<AccF32>), dim3(blocks), dim3(kThreads), 0, s, a, (const uint4*)inp, (uint4*)out, n16, two_shot);
   return check_hip(hipGetLastError(), "all_reduce_kernel launch");
+}
+
+// QuickReduce entry point (qr_all_reduce of the reference, _custom_ops.py / quick_all_reduce.cu:60-110): any size that is
+// a multiple of 64 bytes (whole 32-value blocks), fp16 / bf16; regime = QuickReduceRegime (quick_all_reduce.py:47-52):
+// 0 FP (exact two-shot, chunked), 1 INT8, 2 INT6, 3 INT4.  The message runs through the communicator's staging area in
+// chunks, one kernel launch per chunk on `stream`.
+extern "C" int sgl_mi355_ar_quick_all_reduce(void* comm, const void* inp, void* out, int64_t nbytes, int dtype /* 0 bf16, 1 fp16 */,
+                                              int regime, void* stream) {
+  SGLM_CHECK_ARG(comm, "ar_quick_all_reduce: null communicator");
+  ArComm* c = (ArComm*)comm;
+  SGLM_CHECK_ARG(nbytes >= 0 && nbytes % 64 == 0, "ar_quick_all_reduce: size (%ld B) must be a multiple of 64 bytes", (long)nbytes);
+  SGLM_CHECK_ARG(dtype == 0 || dtype == 1, "ar_quick_all_reduce: dtype must be bf16 (0) or fp16 (1), got %d", dtype);
+  SGLM_CHECK_ARG(regime >= 0 && regime <= 3, "ar_quick_all_reduce: regime must be 0 (FP), 1 (INT8), 2 (INT6) or 3 (INT4), got %d", regime);
+  if (nbytes == 0) return 0;
+  SGLM_CHECK_ARG(inp && out, "ar_quick_all_reduce: null tensor pointer");
+  for (int r = 0; r < c->world; ++r) SGLM_CHECK_ARG(c->peer[r] != nullptr, "ar_quick_all_reduce: peer %d not opened", r);
+  ArArgs a{};
+  for (int r = 0; r < c->world; ++r) a.peer[r] = c->peer[r];
+  a.data_off = c->data_off; a.half_bytes = c->half_bytes; a.rank = c->rank; a.world = c->world;
+  a.status = reinterpret_cast<uint32_t*>(c->base + kStatusOff); a.status_host = c->status_dev; a.spin_limit = g_spin_limit;
+  hipStream_t s = as_stream(stream);
+  const int bits = regime == 0 ? 16 : regime == 1 ? 8 : regime == 2 ? 6 : 4;
+  // units of 8 values (16 B of input) per chunk: packed integers + one half per 4 units must fit the area of max_bytes
+  int64_t cap_units = regime == 0 ? (int64_t)(c->max_bytes / 16) : (int64_t)((c->max_bytes - 64) * 2 / (2 * bits + 1));
+  cap_units &= ~(int64_t)(4 * kMaxRanks - 1);  // whole 32-value blocks, and slices that are whole blocks
+  SGLM_CHECK_ARG(cap_units > 0, "ar_quick_all_reduce: the staging area (%ld B) is too small", (long)c->max_bytes);
+  const int64_t total_units = nbytes / 16;
+  for (int64_t u0 = 0; u0 < total_units; u0 += cap_units) {
+    const int64_t n = (total_units - u0) < cap_units ? (total_units - u0) : cap_units;
+    const uint4* ip = (const uint4*)inp + u0;
+    uint4* op = (uint4*)out + u0;
+    int blocks = (int)((n + kThreads - 1) / kThreads);
+    blocks = blocks < 1 ? 1 : (blocks > kMaxBlocks ? kMaxBlocks : blocks);
+#define QR_GO(DT)                                                                                                    \
+    do {                                                                                                             \
+      if (regime == 0) hipLaunchKernelGGL((all_reduce_kernel<Acc8<DT>>), dim3(blocks), dim3(kThreads), 0, s, a, ip, op, n, c->world > 1 ? 1 : 0); \
+      else if (regime == 1) hipLaunchKernelGGL((quick_reduce_kernel<DT, 8>), dim3(blocks), dim3(kThreads), 0, s, a, ip, op, n);  \
+      else if (regime == 2) hipLaunchKernelGGL((quick_reduce_kernel<DT, 6>), dim3(blocks), dim3(kThreads), 0, s, a, ip, op, n);  \
+      else hipLaunchKernelGGL((quick_reduce_kernel<DT, 4>), dim3(blocks), dim3(kThreads), 0, s, a, ip, op, n);                   \
+    } while (0)
+    if (dtype == 0) QR_GO(SGL_MI355_BF16); else QR_GO(SGL_MI355_FP16);
+#undef QR_GO
+    int rc = check_hip(hipGetLastError(), "quick_reduce_kernel launch");
+    if (rc) return rc;
+  }
+  return 0;
 }
 
 extern "C" int sgl_mi355_ar_fused_add_rmsnorm(void* comm, const void* inp, void* residual, const void* weight, void* out,

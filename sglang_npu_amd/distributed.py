@@ -19,8 +19,12 @@ import contextlib
 import os
 from typing import Optional
 
+import logging
+
 import torch
 import torch.distributed as dist
+
+logger = logging.getLogger(__name__)
 
 
 class AllReduceHandle:
@@ -163,6 +167,84 @@ class CustomAllreduce:
             self.disabled = True
 
 
+class QuickReduceRegime:
+    """device_communicators/quick_all_reduce.py:47-52."""
+    FP, INT8, INT6, INT4, NONE = 0, 1, 2, 3, 4
+    _NAMES = {"FP": 0, "INT8": 1, "INT6": 2, "INT4": 3, "NONE": 4}
+
+
+class QuickAllReduce:
+    """QuickReduce for prefill-size messages -- same role, switches and method names as
+    python/sglang/srt/distributed/device_communicators/quick_all_reduce.py:56-273 (``disabled``,
+    ``should_quick_allreduce(inp)``, ``quick_all_reduce(inp, out=None)``, ``close()``):
+    * opt-in through ``ROCM_QUICK_REDUCE_QUANTIZATION`` = FP | INT8 | INT6 | INT4 (default NONE = disabled, :183-199);
+    * ``ROCM_QUICK_REDUCE_MAX_SIZE_BYTES_MB`` caps the message size (default 2 GiB as ``ops.qr_max_size()``, :205-215);
+    * the per-(dtype, world size, regime) minimum sizes of ``_QR_MIN_SIZE`` (:62-71): below them the custom all-reduce
+      or RCCL is faster and ``should_quick_allreduce`` says no;
+    * ``ROCM_QUICK_REDUCE_CAST_BF16_TO_FP16`` (:177-181) is read for the threshold table only: the kernels here do the
+      codec arithmetic in fp32 whatever the input dtype, so there is nothing to cast.
+    It runs on the P2P communicator's IPC staging area (``CustomAllreduce``; the reference allocates a second one), in
+    chunks, by ``sgl_mi355_ar_quick_all_reduce``.  World sizes 2 / 4 / 8 as upstream (6 works too)."""
+
+    _SUPPORTED_WORLD_SIZES = [2, 4, 6, 8]
+    _SUPPORTED_DTYPES = [torch.float16, torch.bfloat16]
+    _MB = 1024 * 1024
+    # quick_all_reduce.py:62-71, [FP, INT8, INT6, INT4]; world size 6 takes the row of 8
+    _QR_MIN_SIZE = {
+        (torch.float16, 2): [1, 2, 2, 1], (torch.float16, 4): [1, 16, 4, 2], (torch.float16, 8): [16, 4, 4, 2],
+        (torch.bfloat16, 2): [2, 8, 8, 8], (torch.bfloat16, 4): [8, 64, 64, 16], (torch.bfloat16, 8): [16, 2048, 2048, 2048],
+    }
+
+    def __init__(self, ca_comm: Optional[CustomAllreduce], regime: Optional[str] = None, max_size_mb: Optional[int] = None):
+        self.disabled = True
+        self.ca_comm = ca_comm
+        if ca_comm is None or ca_comm._comm is None or ca_comm.world_size not in self._SUPPORTED_WORLD_SIZES:
+            return
+        regime = regime if regime is not None else os.environ.get("ROCM_QUICK_REDUCE_QUANTIZATION", "NONE")
+        if regime not in QuickReduceRegime._NAMES:
+            logger.warning("quick all-reduce: invalid quantization level %r (supported: %s)", regime,
+                           list(QuickReduceRegime._NAMES))
+            return
+        if regime == "NONE":
+            return
+        self.qr_quant_level = QuickReduceRegime._NAMES[regime]
+        self.use_fp16_kernels = int(os.environ.get("ROCM_QUICK_REDUCE_CAST_BF16_TO_FP16", 1))
+        mb = max_size_mb if max_size_mb is not None else int(os.environ.get("ROCM_QUICK_REDUCE_MAX_SIZE_BYTES_MB", 0))
+        self.qr_max_size = mb * self._MB if mb > 0 else 2048 * self._MB
+        self.world_size, self.rank = ca_comm.world_size, ca_comm.rank
+        self.disabled = False
+
+    def should_quick_allreduce(self, inp: torch.Tensor) -> bool:
+        if self.disabled or self.ca_comm.disabled or inp.dtype not in self._SUPPORTED_DTYPES or not inp.is_cuda:
+            return False
+        nbytes = inp.numel() * inp.element_size()
+        if nbytes % 64 != 0 or not inp.is_contiguous():  # whole 32-value blocks (upstream: multiples of 16 bytes)
+            return False
+        dtype = torch.float16 if self.use_fp16_kernels else inp.dtype
+        ws = 8 if self.world_size == 6 else self.world_size
+        return self._QR_MIN_SIZE[(dtype, ws)][self.qr_quant_level] * self._MB <= nbytes <= self.qr_max_size
+
+    def quick_all_reduce(self, inp: torch.Tensor, *, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Out of place; graph-capturable (static IPC staging area, as upstream :240-243)."""
+        from . import _lib
+        ca = self.ca_comm
+        if ca.timed_out():
+            ca.disabled = True
+            raise RuntimeError("quick all-reduce: a peer did not reach the barrier in time; the affected outputs were "
+                               "filled with NaN and this communicator is disabled")
+        if out is None:
+            out = torch.empty_like(inp)
+        ct = ca._ct
+        _lib.check(ca._lib.sgl_mi355_ar_quick_all_reduce(
+            ca._comm, ct.c_void_p(inp.data_ptr()), ct.c_void_p(out.data_ptr()),
+            ct.c_int64(inp.numel() * inp.element_size()), ct.c_int(0 if inp.dtype == torch.bfloat16 else 1),
+            ct.c_int(self.qr_quant_level), ct.c_void_p(torch.cuda.current_stream(inp.device).cuda_stream)))
+        return out
+
+    def close(self):
+        self.disabled = True
+
+
 class GroupCoordinator:
     def __init__(self, group: Optional[dist.ProcessGroup], rank: int, world_size: int, device: Optional[torch.device]):
         self.device_group = group
@@ -171,6 +253,7 @@ class GroupCoordinator:
         self.device = device
         self._side_stream = None
         self.ca_comm: Optional[CustomAllreduce] = None
+        self.qr_comm: Optional["QuickAllReduce"] = None
         # measurement aid (overhead = (step with AR - step with AR stubbed to identity) / step)
         self.stub_all_reduce = False
 
@@ -184,7 +267,11 @@ class GroupCoordinator:
         """SUM over the TP ranks (in place, like the pynccl path parallel_state.py:563-568)."""
         if self.world_size == 1 or self.stub_all_reduce:
             return input_
-        # dispatch order of parallel_state.py:519-542: custom P2P all-reduce if it accepts the tensor, else RCCL
+        # dispatch order of parallel_state.py:519-542: QuickReduce, then the custom P2P all-reduce, if they accept the
+        # tensor, else RCCL
+        qr = getattr(self, "qr_comm", None)
+        if qr is not None and not qr.disabled and qr.should_quick_allreduce(input_):
+            return qr.quick_all_reduce(input_)
         if self.ca_comm is not None and not self.ca_comm.disabled:
             out = self.ca_comm.custom_all_reduce(input_)
             if out is not None:
@@ -270,6 +357,7 @@ def init_distributed_environment(backend: Optional[str] = None, device: Optional
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 1:
             _TP.ca_comm = ca
+            _TP.qr_comm = QuickAllReduce(ca)  # disabled unless ROCM_QUICK_REDUCE_QUANTIZATION asks for a regime
         elif ca is not None:
             ca.close()
     return _TP

@@ -225,3 +225,90 @@ def test_p2p_all_reduce_missing_peer_fails_closed():
         _lib.check(lib.sgl_mi355_ar_set_spin_limit(ctypes.c_int64(1 << 27)))
         for c in comms:
             c.close()
+
+
+def _quick_reduce_worker(world, q):
+    """QuickReduce (sgl_mi355_ar_quick_all_reduce) with all ranks in one process: every regime against the numpy oracle
+    (oracle/quick_reduce.py), bit for bit, on every rank; message sizes below and far above the staging area."""
+    os.environ["GPU_MAX_HW_QUEUES"] = "16"
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        import numpy as np
+        from oracle import quick_reduce as qro
+        from sglang_npu_amd.distributed import CustomAllreduce, QuickAllReduce
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        max_size = 1 << 20
+        comms = CustomAllreduce.connect_local(world, dev, max_size=max_size)
+        streams = [torch.cuda.Stream(device=dev) for _ in range(world)]
+        for dt in (torch.float16, torch.bfloat16):
+            rnd = (lambda x: x.astype(np.float16).astype(np.float32)) if dt == torch.float16 else \
+                (lambda x: torch.from_numpy(x).to(torch.bfloat16).float().numpy())
+            for regime, name in ((1, "INT8"), (2, "INT6"), (3, "INT4"), (0, "FP")):
+                qrs = [QuickAllReduce(c, name, max_size_mb=64) for c in comms]
+                assert not any(x.disabled for x in qrs)
+                for n in (32, 32 * 1000, (1 << 20) + 32 * 7, 3 * (1 << 20) + 64):   # values; the last two: several chunks
+                    g = torch.Generator().manual_seed(n % 977 + regime)
+                    parts = [(torch.randn(n, generator=g) * (1 + r)).to(dt) for r in range(world)]
+                    parts[0][:64] = 0                                  # all-zero blocks
+                    parts_d = [p.to(dev) for p in parts]
+                    if regime == 0:
+                        # exact two-shot: fp32 accumulation in rank order, one rounding
+                        acc = torch.zeros(n)
+                        for p in parts:
+                            acc = acc + p.float()
+                        ref = acc.to(dt)
+                    else:
+                        ref = torch.from_numpy(qro.quick_all_reduce([p.float().numpy() for p in parts], regime, rnd,
+                                                                    max_bytes=max_size)).to(dt)
+                    for rep in range(2):
+                        torch.cuda.synchronize()
+                        outs = []
+                        for r in range(world):
+                            with torch.cuda.stream(streams[r]):
+                                outs.append(qrs[r].quick_all_reduce(parts_d[r]))
+                        torch.cuda.synchronize()
+                        for r in range(world):
+                            same = torch.equal(outs[r].cpu().view(torch.int16), ref.view(torch.int16))
+                            assert same, (str(dt), name, n, r, rep, float((outs[r].cpu().float() - ref.float()).abs().max()))
+                # the reference test's own payload and bound (test_quick_allreduce.py:131-165)
+                n = 32 * 4096
+                g = torch.Generator().manual_seed(regime)
+                parts = [torch.randint(1, 24, (n,), generator=g).to(dt).to(dev) for _ in range(world)]
+                exact = sum(p.float() for p in parts)
+                outs = []
+                for r in range(world):
+                    with torch.cuda.stream(streams[r]):
+                        outs.append(qrs[r].quick_all_reduce(parts[r]))
+                torch.cuda.synchronize()
+                torch.testing.assert_close(outs[0].float(), exact, atol=1.25 * world, rtol=0.5 * world)
+                if regime == 0:
+                    assert torch.equal(outs[0].float(), exact)
+        # the exact P2P all-reduce still works on the same communicators afterwards (shared call counters)
+        x = [torch.full((4096,), float(r + 1), dtype=torch.bfloat16, device=dev) for r in range(world)]
+        outs = []
+        for r in range(world):
+            with torch.cuda.stream(streams[r]):
+                outs.append(comms[r].custom_all_reduce(x[r]))
+        torch.cuda.synchronize()
+        assert all(float(o[0]) == world * (world + 1) / 2 for o in outs)
+        assert not any(c.timed_out() for c in comms)
+        for c in comms:
+            c.close()
+        q.put("ok")
+    except Exception:
+        import traceback
+        q.put(traceback.format_exc())
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.timeout(600)
+def test_quick_reduce_all_regimes_vs_oracle(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_quick_reduce_worker, args=(world, q))
+    p.start()
+    msg = q.get(timeout=500)
+    p.join(30)
+    assert msg == "ok", msg
