@@ -142,8 +142,8 @@ union Frag32 {  // 32 contiguous K bytes of one row = four MFMA operands
 #ifndef SGLM_WS_ABL_NOMFMA
 #define SGLM_WS_ABL_NOMFMA 0
 #endif
-#ifndef SGLM_WS_PB
-#define SGLM_WS_PB 2
+#ifdef SGLM_WS_PB
+#define SGLM_WS_PB_SET 1
 #endif
 #ifndef SGLM_SLAB_SC1
 #define SGLM_SLAB_SC1 0
@@ -158,14 +158,18 @@ __device__ __forceinline__ void gload32_asm(Frag32& f, const uint8_t* sbase, uin
 #endif
 }
 // the same with the second instruction's offset in a register (row-major weights: + 64; pre-shuffled: + 1024)
-__device__ __forceinline__ void gload32_asm2(Frag32& f, const uint8_t* sbase, uint32_t voff0, uint32_t voff1) {
-#if SGLM_W_NT
-  asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(f.x[0]) : "v"(voff0), "s"(sbase) : "memory");
-  asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(f.x[1]) : "v"(voff1), "s"(sbase) : "memory");
-#else
-  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(f.x[0]) : "v"(voff0), "s"(sbase) : "memory");
-  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(f.x[1]) : "v"(voff1), "s"(sbase) : "memory");
+#ifndef SGLM_W_NT_UNSPLIT
+#define SGLM_W_NT_UNSPLIT 1  // the unsplit weight-streaming kernel reads its weights with the nt hint (see PB below)
 #endif
+template <bool NT = false>
+__device__ __forceinline__ void gload32_asm2(Frag32& f, const uint8_t* sbase, uint32_t voff0, uint32_t voff1) {
+  if constexpr (NT || SGLM_W_NT) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(f.x[0]) : "v"(voff0), "s"(sbase) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(f.x[1]) : "v"(voff1), "s"(sbase) : "memory");
+  } else {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(f.x[0]) : "v"(voff0), "s"(sbase) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(f.x[1]) : "v"(voff1), "s"(sbase) : "memory");
+  }
 }
 // (a non-temporal hint on these loads was measured: no difference on any decode shape, profiles/README.md)
 // End of a hand-scheduled loop: the tail refills are never consumed, so hipcc considers their destination
@@ -844,11 +848,16 @@ __global__ __launch_bounds__(576) void fp8_gemm_wstream_kernel(GemmArgs p, float
   constexpr int ROWS = 16 * MB;
   constexpr int STEP_BYTES = ROWS * 128;
   constexpr int BUF_BYTES = PH * STEP_BYTES;  // <= 64 KiB
-  // Weight k-steps in flight per wave.  TWO, not more: same-box A/B of 8 / 4 / 2 / 1 (M = 64: gate_up 33.1 / 32.4 / 30.8 /
-  // 37.8 us, down 24.6 / 23.4 / 22.6 / 26.5, qkv 16.6 / 15.7 / 15.0 / 16.6; M = 16: gate_up 26.3 / 25.5 / 25.0 / 30.4, down
-  // 21.9 / 20.9 / 19.5 / 22.5) -- with 7-8 consumer waves per CU a deeper per-wave queue only lets the waves drift apart
-  // (more to wait out at every phase barrier) and oversubscribes the CU's ~10 B/clk HBM path.
+  // Weight k-steps in flight per wave.  Round 1 (row-major weights, 16 rows x 64 B per load): same-box A/B of 8 / 4 / 2 / 1
+  // gave gate_up 33.1 / 32.4 / 30.8 / 37.8 us, down 24.6 / 23.4 / 22.6 / 26.5, qkv 16.6 / 15.7 / 15.0 / 16.6 at M = 64 --
+  // two it was.  Round 2 (contiguous 1-KiB loads on pre-shuffled weights): the unsplit kernel (gate_up) does better with
+  // FOUR steps and a non-temporal hint on the weight stream (25.4 -> 23.8 us; whole step 6.16 -> 6.10 ms), the split-K
+  // kernels stay at two without the hint (down 20.5 vs 20.75 with four; the hint costs them ~0.5 us each).
+#ifdef SGLM_WS_PB_SET
   constexpr int PB = SGLM_WS_PB;
+#else
+  constexpr int PB = SLAB ? 2 : 4;
+#endif
   constexpr int UPS = 2 * MB;                 // 1-KiB DMA units per k-step
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -918,7 +927,7 @@ __global__ __launch_bounds__(576) void fp8_gemm_wstream_kernel(GemmArgs p, float
   auto refill = [&](Frag32& fr) __attribute__((always_inline)) {
     const int f = f_pf < last ? f_pf : last;  // tail refills re-read the last step, never consumed
     const int ks = (f & ~(PH - 1)) + ((f + rot) & (PH - 1));
-    gload32_asm2(fr, wbase + (int64_t)ks * wf.step, wf.v0, wf.v1);
+    gload32_asm2<(SGLM_W_NT_UNSPLIT != 0) && !SLAB>(fr, wbase + (int64_t)ks * wf.step, wf.v0, wf.v1);
     ++f_pf;
   };
   Frag32 bq[PB];
