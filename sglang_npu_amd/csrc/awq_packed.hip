@@ -101,8 +101,11 @@ struct WFrag {
   i32x4 w;      // 32 nibbles: this lane's 32 k-values of the step
   uint32_t sz;  // {scale, 1024 + zero} of the step's group
 };
+// NT: non-temporal hint on the weight stream (read once per step); the scale/zero words stay cacheable
+template <bool NT>
 __device__ __forceinline__ void wload_asm(WFrag& f, const uint8_t* wbase, uint32_t woff, const uint32_t* sbase, uint32_t soff) {
-  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(f.w) : "v"(woff), "s"(wbase) : "memory");
+  if constexpr (NT) asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(f.w) : "v"(woff), "s"(wbase) : "memory");
+  else asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(f.w) : "v"(woff), "s"(wbase) : "memory");
   asm volatile("global_load_dword %0, %1, %2" : "=v"(f.sz) : "v"(soff), "s"(sbase) : "memory");
 }
 template <int N>
@@ -139,7 +142,12 @@ __global__ __launch_bounds__(576) void awq_wstream_kernel(AwqPArgs p, float* sla
   // weight k-steps in flight per wave: shallow, as in gemm_fp8.hip (deeper queues only let the waves drift apart).
   // Same-box A/B of 8 / 4 / 2: M = 64 qkv 22.0 / 22.0 / 21.3, gate_up 30.7 / 30.3 / 29.3, down 24.2 / 24.0 / 22.8 us;
   // M = 1 qkv 15.8 / 14.7 / 14.9, down 15.7 / 14.0 / 16.1 us.
-  constexpr int PB = MB == 4 ? 2 : (PH >= 4 ? 4 : PH);
+  // (round 2, fragment-major weights: the unsplit kernel takes four steps and the nt hint, as in gemm_fp8.hip)
+#ifndef SGLM_AWQ_UNSPLIT_DEEP
+#define SGLM_AWQ_UNSPLIT_DEEP 1
+#endif
+  constexpr bool kDeep = SGLM_AWQ_UNSPLIT_DEEP && !SLAB;
+  constexpr int PB = (MB == 4 && !kDeep) ? 2 : (PH >= 4 ? 4 : PH);
   constexpr int UPS = 4 * MB;                 // 1-KiB DMA units (4 rows x 256 B) per k-step
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -202,7 +210,7 @@ __global__ __launch_bounds__(576) void awq_wstream_kernel(AwqPArgs p, float* sla
   auto refill = [&](WFrag& fr) __attribute__((always_inline)) {
     const int f = f_pf < last ? f_pf : last;
     const int ks = (f & ~(PH - 1)) + ((f + rot) & (PH - 1));
-    wload_asm(fr, w_blk + (int64_t)ks * 1024, w_off, s_blk + (ks >> p.gshift) * 16, s_off);
+    wload_asm<kDeep>(fr, w_blk + (int64_t)ks * 1024, w_off, s_blk + (ks >> p.gshift) * 16, s_off);
     ++f_pf;
   };
   WFrag wq[PB];
