@@ -24,15 +24,17 @@ def _free_port():
     return p
 
 
-def _run_stack(tp_rank, tp_world, device, fuse, async_ar):
-    """One prefill-free decode step of a 2-layer stack (with_lm_head=False: the output is the final hidden state)."""
+def _run_stack(tp_rank, tp_world, device, fuse, async_ar, with_lm_head=False):
+    """One prefill-free decode step of a 2-layer stack (with_lm_head=False: the output is the final hidden state;
+    True: the vocab-parallel LM head's logits after the all-gather over the ranks, logits_processor.py:430-505)."""
     from sglang_npu_amd import model as M
     from sglang_npu_amd.harness import (ForwardBatch, ForwardMode, MHATokenToKVPool, ModelRunnerLike, ReqToTokenPool,
                                         ServerArgs, install_attention_backend)
     M.FUSE_AR_NORM, M.ASYNC_AR = fuse, async_ar
     cfg = M.LLAMA3_8B
     B, ctx = 64, 96
-    net = M.LlamaForCausalLM(cfg, "w8a8_fp8", torch.bfloat16, str(device), num_layers=2, with_lm_head=False).load_dummy_weights()
+    net = M.LlamaForCausalLM(cfg, "w8a8_fp8", torch.bfloat16, str(device), num_layers=2,
+                             with_lm_head=with_lm_head).load_dummy_weights()
     max_len = ctx + 4
     n_tok = B * max_len + 1
     r2t_pool = ReqToTokenPool(B, max_len, str(device))
@@ -86,10 +88,18 @@ def _worker(rank, world, port, q):
         gathered = [None] * world
         dist.all_gather_object(gathered, outs["fused"])
         assert all(torch.equal(gathered[0], t) for t in gathered), "ranks disagree"
+        # vocab-parallel LM head: every rank computes its slice of the logits, the all-gather puts them together
+        dist.barrier()
+        logits = _run_stack(rank, world, dev, True, False, with_lm_head=True)
+        assert logits.shape == (64, 128256), logits.shape
+        gathered = [None] * world
+        dist.all_gather_object(gathered, logits)
+        assert all(torch.equal(gathered[0], t) for t in gathered), "ranks disagree on the logits"
         assert not tp.ca_comm.timed_out()
         dist.barrier()
         tp.ca_comm.close()
-        q.put((rank, "ok", outs["fused"].numpy() if rank == 0 else None))  # numpy: plain pickling, no shared-memory fds
+        # numpy: plain pickling, no shared-memory fds
+        q.put((rank, "ok", (outs["fused"].numpy(), logits.numpy()) if rank == 0 else None))
     except Exception:
         import traceback
         q.put((rank, traceback.format_exc(), None))
@@ -109,9 +119,17 @@ def test_tp2_stack_three_collective_forms_agree_and_match_tp1():
     tp2 = None
     for rank, msg, out in res:
         assert msg == "ok", f"rank {rank}: {msg}"
-        tp2 = torch.from_numpy(out) if out is not None else tp2
+        if out is not None:
+            tp2, tp2_logits = torch.from_numpy(out[0]), torch.from_numpy(out[1])
     from sglang_npu_amd import distributed as D
     D.set_tp_group(D.GroupCoordinator(None, 0, 1, torch.device("cuda", 0)))
     tp1 = _run_stack(0, 1, torch.device("cuda", 0), False, False)
     err, scale = float((tp1 - tp2).abs().max()), float(tp1.abs().max())
     assert err <= 2.0 ** -5 * scale, f"TP=2 vs TP=1 hidden states: {err:.3e} (max {scale:.3e})"
+    tp1_logits = _run_stack(0, 1, torch.device("cuda", 0), False, False, with_lm_head=True)
+    err, scale = float((tp1_logits - tp2_logits).abs().max()), float(tp1_logits.abs().max())
+    assert err <= 2.0 ** -4 * scale, f"TP=2 vs TP=1 logits: {err:.3e} (max {scale:.3e})"
+    # greedy tokens agree wherever the TP=1 top-2 margin exceeds that noise
+    top2 = tp1_logits.topk(2, dim=-1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 2 * err
+    assert torch.equal(tp1_logits.argmax(-1)[clear], tp2_logits.argmax(-1)[clear])
