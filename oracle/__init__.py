@@ -14,7 +14,14 @@ its HIP library is missing instead of falling back to anything here.
 Parity pin: see ``tests/golden/make_golden.py`` -- this oracle was checked in the build
 container against the reference's own compiled CPU kernels (``oracle/_ref``) and the
 pure-torch references embedded in the reference's tests; the vectors are committed
-under ``tests/golden/``.
+under ``tests/golden/``.  Round-2 additions and what pins them:
+* float8_e5m2 conversions (``f32_to_e5m2`` / ``e5m2_to_f32``, ``kv_dtype=`` on the ``*_fp8kv`` functions): torch's own
+  cast, checked here against ``x.to(torch.float8_e5m2)`` on every fp16 and bf16 bit pattern and on fp32 samples
+  (tests/test_fp8kv_e5m2_gpu.py::test_e5m2_cast_every_16_bit_value_matches_torch);
+* ``oracle/quick_reduce.py`` (numpy): the QuickReduce codec formulas of quick_all_reduce.cuh and the bound of the
+  reference's test_quick_allreduce.py; the reference's device code cannot run in the build container, so it is pinned
+  to the codec definition and that bound only ("parity unpinned" against the reference kernel's own output -- said so in
+  its header).
 """
 from __future__ import annotations
 
