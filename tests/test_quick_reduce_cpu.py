@@ -99,3 +99,44 @@ def test_quick_all_reduce_host_logic(monkeypatch):
     monkeypatch.setenv("ROCM_QUICK_REDUCE_CAST_BF16_TO_FP16", "0")
     q2 = QuickAllReduce(FakeCA(), "INT8")
     assert not q2.should_quick_allreduce(T(4 * mb, torch.bfloat16))  # bf16 ws 8 INT8: 2048 MiB
+
+
+def test_group_coordinator_dispatch_order():
+    """parallel_state.py:519-542: QuickReduce first, then the custom all-reduce, then the process group."""
+    from sglang_npu_amd.distributed import GroupCoordinator
+    calls = []
+
+    class QR:
+        disabled = False
+
+        def __init__(self, accept):
+            self.accept = accept
+
+        def should_quick_allreduce(self, x):
+            return self.accept
+
+        def quick_all_reduce(self, x):
+            calls.append("qr")
+            return x + 1
+
+    class CA:
+        disabled = False
+
+        def __init__(self, accept):
+            self.accept = accept
+
+        def custom_all_reduce(self, x):
+            calls.append("ca")
+            return x + 2 if self.accept else None
+
+    tp = GroupCoordinator(None, 0, 2, torch.device("cpu"))
+    x = torch.zeros(4)
+    tp.qr_comm, tp.ca_comm = QR(True), CA(True)
+    assert float(tp.all_reduce(x)[0]) == 1 and calls == ["qr"]
+    calls.clear()
+    tp.qr_comm = QR(False)
+    assert float(tp.all_reduce(x)[0]) == 2 and calls == ["ca"]
+    calls.clear()
+    tp.qr_comm.disabled = True
+    tp.qr_comm.accept = True
+    assert float(tp.all_reduce(x)[0]) == 2 and calls == ["ca"]
