@@ -184,8 +184,17 @@ def time_attention_kernel(loop, steps):
     of it on the launching stream, over `steps` eager steps of the same loop."""
     from sglang_npu_amd import ops
     durations = []
-    real, real_fused = ops.decode_attention_paged, ops.decode_attention_qkv_partials
+    real, real_fused, real_absmax = ops.decode_attention_paged, ops.decode_attention_qkv_partials, ops.decode_attention_paged_absmax
     pairs = []
+
+    def timed_absmax(*a, **kw):  # the same kernel with the row-absmax epilogue (model.py FUSE_ATTN_QUANT)
+        st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        st.record()
+        done = real_absmax(*a, **kw)
+        en.record()
+        if done:
+            pairs.append((st, en))
+        return done
 
     def timed(*a, **kw):
         st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -207,6 +216,7 @@ def time_attention_kernel(loop, steps):
 
     ops.decode_attention_paged = timed
     ops.decode_attention_qkv_partials = timed_fused
+    ops.decode_attention_paged_absmax = timed_absmax
     g = loop.graph
     loop.graph = None
     try:
@@ -216,6 +226,7 @@ def time_attention_kernel(loop, steps):
     finally:
         ops.decode_attention_paged = real
         ops.decode_attention_qkv_partials = real_fused
+        ops.decode_attention_paged_absmax = real_absmax
         loop.graph = g
     durations = [s.elapsed_time(e) for s, e in pairs]
     durations.sort()

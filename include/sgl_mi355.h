@@ -34,7 +34,7 @@ extern "C" {
 #define SGL_MI355_ERR_RUNTIME 3          /* a HIP runtime call failed                */
 
 /* ABI version of this header; bumped on any signature change. */
-#define SGL_MI355_ABI_VERSION 6
+#define SGL_MI355_ABI_VERSION 7
 int sgl_mi355_abi_version(void);
 
 /* Copies the calling thread's last error message (NUL-terminated) into buf. Returns its length. */
@@ -246,6 +246,28 @@ int sgl_mi355_rotary_embedding_set_kv_from_partials_fp8kv_e5m2(
     const void* bias, int64_t num_tokens, int64_t num_q_heads, int64_t num_k_heads, int64_t head_size, int64_t rot_dim,
     int64_t q_out_stride_t, int64_t kb_stride_n, int64_t kb_stride_h, int64_t vb_stride_n, int64_t vb_stride_h,
     int is_neox, int dtype, void* stream);
+
+/* The per-token quant of the attention output folded into its producer and its consumer (round 2) -- instead of a
+ * sgl_per_token_quant_fp8 launch between the decode attention and the w8a8 o_proj:
+ *   sgl_mi355_decode_attention_absmax     = sgl_mi355_decode_attention (page-table form, one split, 16-bit pool, no KV
+ *     write) that also leaves row_absmax[b] = max |output[b]| (the stored 16-bit values, all heads) by atomic max into a
+ *     buffer the caller zeroed.  Pairs-of-items kernel only (num_seqs * num_kv_heads > 256, head size 64 / 128,
+ *     group <= 16); otherwise SGL_MI355_ERR_UNSUPPORTED, nothing launched.
+ *   sgl_mi355_fp8_scaled_mm_partials_a16  = sgl_mi355_fp8_scaled_mm_partials on those 16-bit activations: each workgroup
+ *     quantises its K slice while staging it (scale = absmax / 448, x * (1 / scale) clamped to +-448, e4m3fn -- the
+ *     arithmetic of per_token_quant_fp8.cu:15-87) and scales_a_out[m] is written for the consumer's epilogue.
+ * Replaces: decode (decode_attention.py:491-596) -> sgl_per_token_quant_fp8 -> fp8_scaled_mm; partial sums and scales are
+ * bit-identical to that sequence.  UNSUPPORTED unless M <= 64 and the split-K slices are single-phase (K / slices <= 1024). */
+int sgl_mi355_decode_attention_absmax(
+    const void* query, void* k_cache, void* v_cache, void* output, float* row_absmax, const void* req_to_token,
+    int req_to_token_is64, const int64_t* req_pool_indices, const int64_t* seq_lens, int64_t num_seqs,
+    int64_t max_context_len, int64_t num_heads, int64_t num_kv_heads, int64_t head_size, int64_t q_stride_b,
+    int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h, int64_t o_stride_b,
+    int64_t o_stride_h, float sm_scale, float logit_cap, int dtype, void* stream);
+int sgl_mi355_fp8_scaled_mm_partials_a16(const void* mat_a16, int64_t a_stride_m, const float* row_absmax,
+                                         float* scales_a_out, const void* mat_b, int b_shuffled, int64_t b_stride_n,
+                                         float* workspace, int64_t workspace_floats, int64_t M, int64_t N, int64_t K,
+                                         int a_dtype, int32_t* num_slices, void* stream);
 
 /* Split merge fused with the per-token FP8 quant of the attention output (the input of o_proj in the w8a8 model).
  * Replaces: stage 2 of the decode (decode.cpp:812-860 / decode_attention.py:491-548) followed by sgl_per_token_quant_fp8

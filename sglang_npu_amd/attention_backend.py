@@ -319,6 +319,27 @@ class MI355AttnBackend(AttentionBackend):
                                        layer.logit_cap)
         return o
 
+    def forward_decode_absmax(self, q, layer, forward_batch: ForwardBatch, row_absmax: torch.Tensor):
+        """MI355X extension: forward_decode (KV already in the pool) that also leaves row_absmax[t] = max |output[t]| over
+        all heads (float32 [T], zeroed by the caller) -- the absmax pass of the w8a8 o_proj's per-token input quant, taken
+        in the attention kernel's epilogue (ops.decode_attention_paged_absmax).  Returns the [T, Hq * D] output, or None
+        (nothing launched) when the batch is outside that kernel's form."""
+        md = self.forward_metadata
+        sw = getattr(layer, "sliding_window_size", None)
+        if (self.flat_kv_indices or md.kv_indices is not None or md.num_kv_splits != 1
+                or not isinstance(md.num_kv_splits, int) or layer.qk_head_dim != layer.v_head_dim
+                or (sw is not None and sw > -1)):
+            return None
+        q = q.reshape(-1, layer.tp_q_head_num * layer.qk_head_dim)
+        kb = forward_batch.token_to_kv_pool.get_key_buffer(layer.layer_id)
+        vb = forward_batch.token_to_kv_pool.get_value_buffer(layer.layer_id)
+        o = torch.empty_like(q)
+        done = ops.decode_attention_paged_absmax(
+            q.view(-1, layer.tp_q_head_num, layer.qk_head_dim), kb, vb, o.view(-1, layer.tp_q_head_num, layer.v_head_dim),
+            row_absmax, self.req_to_token, forward_batch.req_pool_indices, forward_batch.seq_lens, layer.scaling,
+            layer.logit_cap)
+        return o if done else None
+
     def forward_decode_qkv_partials(self, part, positions, cos_sin_cache, is_neox, layer, forward_batch: ForwardBatch):
         """MI355X extension: decode attention taking the layer's qkv projection while it is still split-K partial sums
         (ops.GemmPartials) -- the kernel's prologue applies the GEMM epilogue, RoPE and the KV-pool write

@@ -83,6 +83,10 @@ struct DecodeArgs {
   int num_heads, num_kv_heads, group;
   float sm_scale, logit_cap;
   int mode;
+  // non-null (pairs-of-items kernel only): row_absmax[b] = max |output| over all heads of request b, as the 16-bit values
+  // that are stored (atomic max; the caller zeroes it) -- the per-token scale of the w8a8 o_proj input without a pass
+  // over the output (sgl_mi355_decode_attention_absmax)
+  float* row_absmax;
   int kv8;  // 1 / 2: the pool is e4m3fn / e5m2 bytes (strides in elements = bytes); K is upcast, P is rounded to that format before PV
 };
 
@@ -1091,6 +1095,7 @@ __global__ __launch_bounds__(256) void decode_mfma_pair_kernel(DecodeArgs a, int
     const float* mrg_o = mrg + i * MRG;
     const float* mrg_m = mrg_o + kWaves * 16 * D;
     const float* mrg_l = mrg_m + kWaves * 16;
+    float amx = 0.f;  // max |stored output| of this thread's elements (row_absmax)
     for (int e = tid; e < nh * D; e += kWaves * 64) {
       const int h = e / D;
       const int dv = e - h * D;
@@ -1114,7 +1119,14 @@ __global__ __launch_bounds__(256) void decode_mfma_pair_kernel(DecodeArgs a, int
         L += f;
         val += v_new[i] * f;
       }
-      reinterpret_cast<T*>(a.out)[(int64_t)it[i].b * a.o_sb + (int64_t)(it[i].h0 + h) * a.o_sh + dv] = H::from_f32(val / L);
+      const T ov = H::from_f32(val / L);
+      reinterpret_cast<T*>(a.out)[(int64_t)it[i].b * a.o_sb + (int64_t)(it[i].h0 + h) * a.o_sh + dv] = ov;
+      amx = fmaxf(amx, fabsf(H::to_f32(ov)));
+    }
+    if (a.row_absmax != nullptr) {  // non-negative floats order like their bit patterns: an integer atomic max is exact
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) amx = fmaxf(amx, __shfl_xor(amx, off));
+      if (lane == 0) atomicMax(reinterpret_cast<unsigned int*>(a.row_absmax) + it[i].b, __float_as_uint(amx));
     }
   }
 }
@@ -1354,6 +1366,8 @@ inline bool pair_eligible(const DecodeArgs& a, int64_t grid) {
 // set by sgl_mi355_decode_attention_qkv_partials around its call of the regular entry point
 thread_local const FusedQkv* tl_fq = nullptr;
 thread_local bool tl_fq_used = false;
+// set by sgl_mi355_decode_attention_absmax around its call of the regular entry point
+thread_local float* tl_row_absmax = nullptr;
 
 template <int DTYPE, int D, typename IdxT, bool DIRECT>
 int launch_mfma(const DecodeArgs& a, int64_t batch, hipStream_t stream) {
@@ -1512,6 +1526,7 @@ extern "C" int sgl_mi355_decode_attention(
   a.split_align = 1;  // SPLIT_SIZE = div_up(seq_len, num_kv_splits) (decode.cpp:916)
   a.num_heads = (int)num_heads; a.num_kv_heads = (int)num_kv_heads; a.group = (int)(num_heads / num_kv_heads);
   a.sm_scale = sm_scale; a.logit_cap = logit_cap; a.kv8 = tl_kv8;
+  a.row_absmax = tl_row_absmax;
   hipStream_t s = as_stream(stream);
   return dtype == SGL_MI355_BF16
              ? run_decode<SGL_MI355_BF16>(a, num_seqs, (int)head_size, (int)head_size_v, req_to_token_is64 != 0, s)
@@ -1565,6 +1580,41 @@ extern "C" int sgl_mi355_decode_attention_fp8kv(
                                             v_stride_h, 0, 0, 0, 0, o_stride_b, o_stride_h, sm_scale, logit_cap, dtype,
                                             stream);
   tl_kv8 = 0;
+  return rc;
+}
+
+// sgl_mi355_decode_attention (page-table form, no KV write, one split, 16-bit pool) that ALSO leaves
+// row_absmax[b] = max over all heads and dims of |output[b]| (the stored 16-bit values) by atomic max into a buffer the
+// caller zeroed: the absmax pass of sgl_per_token_quant_fp8 on the attention output (per_token_quant_fp8.cu:15-60, the
+// w8a8 o_proj input) comes for free, and sgl_mi355_fp8_scaled_mm_partials_a16 quantises while it stages the activations.
+// Only the pairs-of-items kernel has the epilogue (num_seqs * num_kv_heads > 256, head size 64 / 128, group <= 16): any
+// other shape returns SGL_MI355_ERR_UNSUPPORTED without launching.
+extern "C" int sgl_mi355_decode_attention_absmax(
+    const void* query, void* k_cache, void* v_cache, void* output, float* row_absmax, const void* req_to_token,
+    int req_to_token_is64, const int64_t* req_pool_indices, const int64_t* seq_lens, int64_t num_seqs,
+    int64_t max_context_len, int64_t num_heads, int64_t num_kv_heads, int64_t head_size, int64_t q_stride_b,
+    int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h, int64_t o_stride_b,
+    int64_t o_stride_h, float sm_scale, float logit_cap, int dtype, void* stream) {
+  SGLM_CHECK_ARG(row_absmax != nullptr && output != nullptr, "decode_attention_absmax: null output / row_absmax");
+  SGLM_CHECK_ARG(num_heads > 0 && num_kv_heads > 0 && num_heads % num_kv_heads == 0, "decode_attention_absmax: bad head counts");
+  DecodeArgs probe{};
+  probe.num_splits = 1;
+  const bool aligned = q_stride_b % 8 == 0 && q_stride_h % 8 == 0 && k_stride_n % 8 == 0 && k_stride_h % 8 == 0 &&
+                       v_stride_n % 8 == 0 && v_stride_h % 8 == 0 && reinterpret_cast<uintptr_t>(query) % 16 == 0 &&
+                       reinterpret_cast<uintptr_t>(k_cache) % 16 == 0 && reinterpret_cast<uintptr_t>(v_cache) % 16 == 0;
+  if (!(pair_eligible(probe, num_seqs * num_kv_heads) && (head_size == 128 || head_size == 64) &&
+        num_heads / num_kv_heads <= 16 && aligned)) {
+    set_error("decode_attention_absmax: shape outside the pairs-of-items kernel (needs > 256 (request, kv head) items, head "
+              "size 64 / 128, group <= 16, aligned rows)");
+    return SGL_MI355_ERR_UNSUPPORTED;
+  }
+  tl_row_absmax = row_absmax;
+  const int rc = sgl_mi355_decode_attention(query, k_cache, v_cache, output, nullptr, nullptr, nullptr, nullptr, req_to_token,
+                                            req_to_token_is64, req_pool_indices, seq_lens, num_seqs, max_context_len,
+                                            num_heads, num_kv_heads, head_size, head_size, 1, q_stride_b, q_stride_h,
+                                            k_stride_n, k_stride_h, v_stride_n, v_stride_h, 0, 0, 0, 0, o_stride_b,
+                                            o_stride_h, sm_scale, logit_cap, dtype, stream);
+  tl_row_absmax = nullptr;
   return rc;
 }
 

@@ -92,6 +92,13 @@ struct GemmArgs {
   // nb = n / 16 and k-step ks = k / 128 one 2-KiB piece [half][g][r16][16 B] holding bytes 64 half + 16 g .. + 16 of row
   // 16 nb + r16 -- exactly the two 1-KiB load instructions of a decode wave, contiguous.  b_sn is unused then.
   int b_shuf = 0;
+  // 16-bit activations quantised while they are staged (sgl_mi355_fp8_scaled_mm_partials_a16; `a` is unused then):
+  // row m of a16 (a16_sm elements apart) is multiplied by 448 / a_absmax[m] and cast to e4m3 exactly as
+  // sgl_per_token_quant_fp8 does; a_scale_out[m] = a_absmax[m] / 448 is written for the consumer's epilogue
+  const void* a16 = nullptr;
+  int64_t a16_sm = 0;
+  const float* a_absmax = nullptr;
+  float* a_scale_out = nullptr;
 };
 
 // Where a decode wave finds its weight fragments: scalar base of (column block, k-step 0), bytes between k-steps, and
@@ -879,6 +886,58 @@ __global__ __launch_bounds__(576) void fp8_gemm_wstream_kernel(GemmArgs p, float
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // a16 form (single-phase slices only): every wave of the workgroup converts its share of the slice's 16-bit
+  // activations to e4m3 straight into the phase image -- 32 source bytes -> one 16-byte chunk at its swizzled position
+  auto fill_a16 = [&]() __attribute__((always_inline)) {
+    const T* src = reinterpret_cast<const T*>(p.a16);
+    const int per_row = PH * 8;  // 16-byte chunks of one row in the phase
+    const int total = ROWS * per_row;
+    constexpr int UB = 8;        // units whose loads are in flight together (one memory round trip per batch)
+    for (int u0 = tid; u0 < total; u0 += UB * (int)blockDim.x) {
+      typename H::x8 v0[UB], v1[UB];
+      float amax[UB];
+#pragma unroll
+      for (int i = 0; i < UB; ++i) {  // unconditional loads from clamped addresses (gemm_fp8.hip 4.3.1 c)
+        int u = u0 + i * (int)blockDim.x;
+        u = u < total ? u : total - 1;
+        const int row = u / per_row, kpos = u - row * per_row;
+        const int mrow = row < p.M ? row : p.M - 1;  // rows past M: never stored
+        const typename H::x8* sp =
+            reinterpret_cast<const typename H::x8*>(src + (int64_t)mrow * p.a16_sm + ((int64_t)ph0 * PH << 7) + kpos * 16);
+        v0[i] = sp[0];
+        v1[i] = sp[1];
+        amax[i] = p.a_absmax[mrow];
+      }
+#pragma unroll
+      for (int i = 0; i < UB; ++i) {
+        const int u = u0 + i * (int)blockDim.x;
+        if (u < total) {
+          const int row = u / per_row, kpos = u - row * per_row;
+          const float scale = amax[i] / 448.0f;
+          const float inv = scale == 0.f ? 0.f : 1.0f / scale;
+          uint32_t w[4];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const typename H::x8 v = h ? v1[i] : v0[i];
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = fminf(fmaxf(H::to_f32(v[j]) * inv, -448.0f), 448.0f);
+            int lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false);
+            lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+            int hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0, false);
+            hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+            w[2 * h] = (uint32_t)lo;
+            w[2 * h + 1] = (uint32_t)hi;
+          }
+          const int step = kpos >> 3, j = kpos & 7;
+          *reinterpret_cast<uint4*>(smem + step * STEP_BYTES + row * 128 + 16 * (j ^ ((row >> 1) & 7))) =
+              uint4{w[0], w[1], w[2], w[3]};
+        }
+      }
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && p.a_scale_out != nullptr && tid < p.M) p.a_scale_out[tid] = p.a_absmax[tid] / 448.0f;
+  };
+
   if (wave == NC) {
     // ---------------- producer: the A image of every phase, one 1-KiB unit (8 rows x 128 B) per instruction.
     // Lane i of a unit lands at LDS chunk i & 7 of row i >> 3 and therefore fetches source chunk
@@ -901,7 +960,7 @@ __global__ __launch_bounds__(576) void fp8_gemm_wstream_kernel(GemmArgs p, float
     // drift apart -- and are NOT valid: LDS-DMA data is ordered for another wave's ds_read only by the issuing
     // wave's vmcnt followed by a barrier the reader has passed; with a ds_write flag the M = 7 down_proj case
     // read stale rows.  They were not faster either.)
-    dma_phase(ph0, 0);
+    if (p.a16 != nullptr) fill_a16(); else dma_phase(ph0, 0);
     for (int lp = 0; lp < nph; ++lp) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // phase lp has landed
 #if !SGLM_WS_ABL_NOBAR
@@ -933,6 +992,7 @@ __global__ __launch_bounds__(576) void fp8_gemm_wstream_kernel(GemmArgs p, float
   Frag32 bq[PB];
 #pragma unroll
   for (int i = 0; i < PB; ++i) refill(bq[i]);
+  if (p.a16 != nullptr) fill_a16();  // the weight prefetch is in flight meanwhile
 
   // ONE copy of the 8-step body (a second copy -- e.g. a variant with another wait count -- makes hipcc merge
   // the in-flight weight registers of the two paths with v_mov copies placed in front of the wait, i.e. reads
@@ -1106,6 +1166,7 @@ int launch_wstream(const GemmArgs& p, float* slabs, int64_t slab_floats, hipStre
     }
   }
   if (PH == 0) return 0;
+  if (p.a16 != nullptr && (slabs == nullptr || pps != 1)) return 0;  // the a16 fill covers single-phase slices only
   const int groups = (nblocks + nc - 1) / nc;
   if (slabs != nullptr && ((SK < 2 && partial_slices == nullptr) || slab_floats < (int64_t)SK * p.M * p.N)) return 0;
   if (partial_slices != nullptr) *partial_slices = SK;
@@ -1913,6 +1974,56 @@ extern "C" int sgl_mi355_fp8_scaled_mm_partials_wshuffled(const void* mat_a, con
                                                           int64_t workspace_floats, int64_t M, int64_t N, int64_t K,
                                                           int64_t a_stride_m, int32_t* num_slices, void* stream) {
   return fp8_scaled_mm_partials_impl(1, mat_a, mat_b, workspace, workspace_floats, M, N, K, a_stride_m, K, num_slices, stream);
+}
+
+// sgl_mi355_fp8_scaled_mm_partials on 16-bit activations whose per-token absmax is already known (left by
+// sgl_mi355_decode_attention_absmax): the kernel applies sgl_per_token_quant_fp8's arithmetic (scale = absmax / 448,
+// x * (1 / scale) clamped to +-448, cast to e4m3fn) while it stages its K slice into LDS, and writes scales_a_out[m] for
+// the consumer's epilogue.  Partial sums and scales are bit-identical to sgl_per_token_quant_fp8 followed by
+// sgl_mi355_fp8_scaled_mm_partials.  b_shuffled != 0: mat_b in the pre-shuffled layout (b_stride_n unused).
+// UNSUPPORTED (nothing launched) unless M <= 64 and the split-K choice gives single-phase slices (K / slices <= 1024,
+// e.g. o_proj 4096 -> 4096).
+extern "C" int sgl_mi355_fp8_scaled_mm_partials_a16(const void* mat_a16, int64_t a_stride_m, const float* row_absmax,
+                                                    float* scales_a_out, const void* mat_b, int b_shuffled,
+                                                    int64_t b_stride_n, float* workspace, int64_t workspace_floats,
+                                                    int64_t M, int64_t N, int64_t K, int a_dtype, int32_t* num_slices,
+                                                    void* stream) {
+  SGLM_CHECK_ARG(num_slices != nullptr && workspace != nullptr, "fp8_scaled_mm_partials_a16: null workspace / num_slices");
+  SGLM_CHECK_ARG(a_dtype == SGL_MI355_BF16 || a_dtype == SGL_MI355_FP16, "fp8_scaled_mm_partials_a16: activations must be bf16 / fp16");
+  SGLM_CHECK_ARG(M > 0 && N > 0 && K > 0 && N < (1ll << 31) && K < (1ll << 31) && K % 16 == 0, "fp8_scaled_mm_partials_a16: bad shape");
+  SGLM_CHECK_ARG(a_stride_m % 8 == 0 && a_stride_m >= K, "fp8_scaled_mm_partials_a16: activation rows must be 16-byte aligned");
+  SGLM_CHECK_ARG(mat_a16 && mat_b && row_absmax && scales_a_out && reinterpret_cast<uintptr_t>(mat_a16) % 16 == 0 &&
+                     reinterpret_cast<uintptr_t>(mat_b) % 16 == 0,
+                 "fp8_scaled_mm_partials_a16: null or misaligned tensor pointer");
+  SGLM_CHECK_ARG(!b_shuffled || shuffle_shape_ok(N, K), "fp8_scaled_mm_partials_a16: N %% 16 == 0 and K %% 512 == 0 required for a pre-shuffled weight");
+  SGLM_CHECK_ARG(b_shuffled || (b_stride_n % 16 == 0 && b_stride_n >= K), "fp8_scaled_mm_partials_a16: bad weight row stride");
+  *num_slices = 0;
+  if (M > 64) {
+    set_error("fp8_scaled_mm_partials_a16: only the decode kernels (M <= 64) have this form");
+    return SGL_MI355_ERR_UNSUPPORTED;
+  }
+  GemmArgs p{nullptr, K, (const uint8_t*)mat_b, b_shuffled ? K : b_stride_n, nullptr, nullptr, nullptr, nullptr, (int)M, (int)N, (int)K};
+  p.b_shuf = b_shuffled ? 1 : 0;
+  p.a16 = mat_a16; p.a16_sm = a_stride_m; p.a_absmax = row_absmax; p.a_scale_out = scales_a_out;
+  hipStream_t s = as_stream(stream);
+  bool used = false;
+  int sk = 0;
+  int rc;
+  if (a_dtype == SGL_MI355_BF16)
+    rc = M <= 16   ? launch_wstream<SGL_MI355_BF16, 1>(p, workspace, workspace_floats, s, used, &sk)
+         : M <= 32 ? launch_wstream<SGL_MI355_BF16, 2>(p, workspace, workspace_floats, s, used, &sk)
+                   : launch_wstream<SGL_MI355_BF16, 4>(p, workspace, workspace_floats, s, used, &sk);
+  else
+    rc = M <= 16   ? launch_wstream<SGL_MI355_FP16, 1>(p, workspace, workspace_floats, s, used, &sk)
+         : M <= 32 ? launch_wstream<SGL_MI355_FP16, 2>(p, workspace, workspace_floats, s, used, &sk)
+                   : launch_wstream<SGL_MI355_FP16, 4>(p, workspace, workspace_floats, s, used, &sk);
+  if (rc) return rc;
+  if (!used) {
+    set_error("fp8_scaled_mm_partials_a16: shape (M=%ld N=%ld K=%ld) has no single-phase split-K form", (long)M, (long)N, (long)K);
+    return SGL_MI355_ERR_UNSUPPORTED;
+  }
+  *num_slices = sk;
+  return 0;
 }
 
 extern "C" int sgl_mi355_fp8_scaled_mm_finalize(const float* partials, int64_t num_slices, const float* scales_a,

@@ -181,6 +181,14 @@ class RowParallelLinear(LinearBase):
             return None
         return fn(self, qinput, x_scale, out_dtype, self.bias)
 
+    def forward_a16_partials(self, x16, row_absmax, out_dtype):
+        """forward_prequantized_partials on 16-bit activations whose per-token absmax is known: the GEMM quantises while
+        staging (ops.fp8_scaled_mm_partials_a16).  None when the method or the shape has no such form, or under TP."""
+        fn = getattr(self.quant_method, "apply_a16_partials", None)
+        if fn is None or get_tensor_model_parallel_world_size() > 1:
+            return None
+        return fn(self, x16, row_absmax, out_dtype, self.bias)
+
     def forward_prequantized(self, qinput, x_scale, out_dtype, async_reduce: bool = False,
                              can_fuse_mlp_allreduce: bool = False):
         bias_ = None if (get_tensor_model_parallel_rank() > 0) else self.bias

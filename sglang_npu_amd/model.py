@@ -67,6 +67,13 @@ FUSE_QKV_ATTN = bool(os.environ.get("SGL_MI355_QKV_ATTN_FUSION"))
 
 LM_HEAD_STREAMER_MAX_ROWS = 32
 
+# SGL_MI355_ATTN_QUANT_FUSION=1: the per-token FP8 quant between the decode attention and o_proj folded into the two
+# (attention epilogue: row absmax by atomic max; o_proj GEMM: quantise while staging; bit-identical results).  OFF by
+# default: it removes a launch but every one of the 256 GEMM workgroups then converts its whole 64 x 1024 activation slice
+# (64-fold redundant VALU work on 5 waves per CU): o_proj + neighbours 17.5 -> 20.3 us per layer, the step 6.09 -> 6.22 ms
+# (tools/bench_attn_quant_fusion.py).
+FUSE_ATTN_QUANT = bool(os.environ.get("SGL_MI355_ATTN_QUANT_FUSION"))
+
 
 def _unreduced(h) -> bool:
     return isinstance(h, torch.Tensor) and getattr(h, "_sglang_needs_allreduce_fusion", False)
@@ -166,6 +173,19 @@ class LlamaAttention(torch.nn.Module):
             q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
             ops.apply_rope_and_set_kv_buffer(positions, q, k, v, self.head_dim, self.rotary_emb.cos_sin_cache, kb, vb,
                                              forward_batch.out_cache_loc, self.rotary_emb.is_neox_style)
+        # o_proj's per-token input quant without a launch of its own: the attention epilogue takes the row absmax, the
+        # o_proj GEMM quantises while it stages its activations (bit-identical to the quant kernel in between)
+        absmax = getattr(forward_batch, "attn_row_absmax", None)
+        if (attn_output is None and defer and FUSE_ATTN_QUANT and absmax is not None and k is None
+                and forward_batch.forward_mode.is_decode() and get_tensor_model_parallel_world_size() == 1):
+            fn = getattr(forward_batch.attn_backend, "forward_decode_absmax", None)
+            row = absmax[self.attn.layer_id, :q.shape[0]]
+            o16 = fn(q, self.attn, forward_batch, row) if fn is not None else None
+            if o16 is not None:
+                part = self.o_proj.forward_a16_partials(o16, row, out_dtype)
+                if part is not None:
+                    return part
+                attn_output = o16  # the attention ran; quantise its output the ordinary way
         # fp8_out: when the backend merges kv-splits anyway, the merge kernel also does o_proj's input quant
         if attn_output is None:
             attn_output = self.attn(q, k, v, forward_batch, save_kv_cache=False,
@@ -247,6 +267,7 @@ class LlamaForCausalLM(torch.nn.Module):
         self.cfg, self.dtype, self.device_str = cfg, dtype, device
         self.fuse_quant = fuse_quant and quantization == "w8a8_fp8"
         self.defer_epilogues = not os.environ.get("SGL_MI355_NO_DEFER")  # GEMM epilogues inside the consumer kernels
+        self._attn_absmax = None  # [layers, 64] float32, see FUSE_ATTN_QUANT
         self.quant_config = None
         if quantization == "w8a8_fp8":
             self.quant_config = W8A8Fp8Config(is_checkpoint_fp8_serialized=False)
@@ -317,6 +338,13 @@ class LlamaForCausalLM(torch.nn.Module):
         # bs=32 5.24 vs 5.23, bs=48 6.58 vs 6.44, bs=64 7.17 vs 7.06)
         defer = (fused and self.defer_epilogues and forward_batch.forward_mode.is_decode()
                  and input_ids.shape[0] > DEFER_MIN_ROWS)
+        if defer and FUSE_ATTN_QUANT:  # one zeroed row-absmax vector per layer (the attention kernels max into it)
+            if self._attn_absmax is None:
+                self._attn_absmax = torch.zeros((len(self.layers), 64), dtype=torch.float32, device=hidden_states.device)
+            self._attn_absmax.zero_()
+            forward_batch.attn_row_absmax = self._attn_absmax
+        else:
+            forward_batch.attn_row_absmax = None
         for layer in self.layers:
             if fused:
                 hidden_states, residual = layer.forward_fp8(positions, hidden_states, forward_batch, residual, defer)

@@ -184,6 +184,37 @@ def set_kv_buffer_fp8(k_buffer, v_buffer, loc, cache_k, cache_v, k_scale=None, v
         _F(float(v_scale) if v_scale else 0.0), _I(_dtype_code(cache_k)), _stream(cache_k)))
 
 
+def decode_attention_paged_absmax(q, k_buffer, v_buffer, o, row_absmax, req_to_token, req_pool_indices, seq_lens, sm_scale,
+                                  logit_cap=0.0) -> bool:
+    """decode_attention_paged (one split, 16-bit pool) that also leaves row_absmax[b] = max |o[b]| over all heads by atomic
+    max into `row_absmax` (float32 [B], zeroed by the caller): the absmax pass of the per-token FP8 quant that
+    fp8_scaled_mm_partials_a16 then applies while staging.  Returns False -- nothing launched -- when the batch is outside
+    the pairs-of-items kernel (sgl_mi355.h); the caller then runs decode_attention_paged and sgl_per_token_quant_fp8."""
+    _need_gpu(q, k_buffer, v_buffer, o, row_absmax, req_to_token, req_pool_indices, seq_lens)
+    if req_pool_indices.dtype != torch.int64 or seq_lens.dtype != torch.int64:
+        raise RuntimeError("decode_attention_paged_absmax: req_pool_indices and seq_lens must be int64")
+    for name, t in (("q", q), ("k_buffer", k_buffer), ("v_buffer", v_buffer), ("o", o)):
+        if t.dim() != 3 or t.stride(-1) != 1:
+            raise RuntimeError(f"decode_attention_paged_absmax: {name} must be 3-D, contiguous at the last dimension")
+    B, Hq, D = q.shape
+    if row_absmax.dtype != torch.float32 or row_absmax.numel() < B or not row_absmax.is_contiguous():
+        raise RuntimeError("decode_attention_paged_absmax: row_absmax must be contiguous float32 [B]")
+    if req_to_token.dim() != 2 or req_to_token.stride(1) != 1 or req_to_token.stride(0) != req_to_token.size(1):
+        raise RuntimeError("decode_attention_paged_absmax: req_to_token must be a contiguous 2-D tensor")
+    if _kv_format(k_buffer, v_buffer, q) != 0 or v_buffer.size(2) != D:
+        return False
+    rc = _lib.lib().sgl_mi355_decode_attention_absmax(
+        _ptr(q), _ptr(k_buffer), _ptr(v_buffer), _ptr(o), _ptr(row_absmax), _ptr(req_to_token),
+        _I(_is64(req_to_token, "req_to_token")), _ptr(req_pool_indices), _ptr(seq_lens), _I64(B), _I64(req_to_token.size(1)),
+        _I64(Hq), _I64(k_buffer.size(1)), _I64(D), _I64(q.stride(0)), _I64(q.stride(1)), _I64(k_buffer.stride(0)),
+        _I64(k_buffer.stride(1)), _I64(v_buffer.stride(0)), _I64(v_buffer.stride(1)), _I64(o.stride(0)), _I64(o.stride(1)),
+        _F(sm_scale), _F(logit_cap), _I(_dtype_code(q)), _stream(q))
+    if rc == 2:
+        return False
+    _lib.check(rc)
+    return True
+
+
 def decode_attention_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens, attn_logits,
                            num_kv_splits, sm_scale, logit_cap=0.0):
     """Decode straight from the request page table (no flattened kv_indices, no KV write): the form
@@ -601,6 +632,35 @@ def fp8_scaled_mm_partials(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=Non
         return None
     _lib.check(rc)
     return GemmPartials(ws, sk.value, scales_a.reshape(-1), scales_b.reshape(-1), bias, M, N, out_dtype)
+
+
+def fp8_scaled_mm_partials_a16(mat_a16, row_absmax, mat_b, scales_b, out_dtype, bias=None) -> Optional[GemmPartials]:
+    """fp8_scaled_mm_partials on 16-bit activations [M, K] whose per-token absmax (float32 [M]) is known: the GEMM
+    quantises while staging (sgl_per_token_quant_fp8's arithmetic) and produces the per-token scales itself.  Partial
+    sums and scales bit-identical to sgl_per_token_quant_fp8 + fp8_scaled_mm_partials.  None (nothing launched) when the
+    shape has no such form."""
+    _need_gpu(mat_a16, row_absmax, mat_b, scales_b, bias)
+    M, K = mat_a16.shape
+    N = mat_b.size(1)
+    if not (0 < M <= 64) or mat_a16.stride(1) != 1 or mat_b.stride(0) != 1 or mat_b.size(0) != K or \
+            mat_a16.dtype not in (torch.bfloat16, torch.float16) or mat_b.dtype != torch.float8_e4m3fn:
+        return None
+    if row_absmax.dtype != torch.float32 or row_absmax.numel() < M or not row_absmax.is_contiguous():
+        raise RuntimeError("fp8_scaled_mm_partials_a16: row_absmax must be contiguous float32 [M]")
+    shuf = is_wshuffled(mat_b)
+    if shuf and N > 1 and mat_b.stride(1) != K:
+        raise RuntimeError("fp8_scaled_mm_partials_a16: a pre-shuffled weight must be the whole [K, N] view of its storage")
+    ws = _fp8_workspace.get(mat_a16.device, max(32 * M * N, _fp8_slab_floats(M, N, K)))
+    x_scale = torch.empty((M, 1), dtype=torch.float32, device=mat_a16.device)
+    sk = ctypes.c_int32(0)
+    rc = _lib.lib().sgl_mi355_fp8_scaled_mm_partials_a16(
+        _ptr(mat_a16), _I64(mat_a16.stride(0) if M > 1 else K), _ptr(row_absmax), _ptr(x_scale), _ptr(mat_b),
+        _I(1 if shuf else 0), _I64(mat_b.stride(1) if N > 1 else K), _ptr(ws), _I64(ws.numel()), _I64(M), _I64(N), _I64(K),
+        _I(0 if mat_a16.dtype == torch.bfloat16 else 1), ctypes.byref(sk), _stream(mat_a16))
+    if rc == 2:
+        return None
+    _lib.check(rc)
+    return GemmPartials(ws, sk.value, x_scale.reshape(-1), scales_b.reshape(-1), bias, M, N, out_dtype)
 
 
 def rmsnorm_quant_fp8_from_partials(part: GemmPartials, residual: torch.Tensor, weight: torch.Tensor, eps: float):

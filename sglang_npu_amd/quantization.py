@@ -219,6 +219,14 @@ class W8A8Fp8LinearMethod(LinearMethodBase):
         return ops.fp8_scaled_mm_partials(q2, layer.weight, x_scale, layer.weight_scale, out_dtype, bias)
 
 
+    def apply_a16_partials(self, layer, x16: torch.Tensor, row_absmax: torch.Tensor, out_dtype: torch.dtype,
+                           bias: Optional[torch.Tensor] = None):
+        """apply_prequantized_partials with the per-token quant done inside the GEMM (the absmax comes from the producer
+        of x16, e.g. the decode attention's epilogue); ops.GemmPartials or None."""
+        return ops.fp8_scaled_mm_partials_a16(x16.view(-1, x16.shape[-1]), row_absmax, layer.weight, layer.weight_scale,
+                                              out_dtype, bias)
+
+
 # ----------------------------------------------------------------------------- AWQ INT4
 class AWQConfig(QuantizationConfig):
     """awq.py:75-150."""
