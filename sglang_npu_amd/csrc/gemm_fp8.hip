@@ -99,6 +99,7 @@ struct GemmArgs {
   int64_t a16_sm = 0;
   const float* a_absmax = nullptr;
   float* a_scale_out = nullptr;
+  int raster_gn = 1;  // tiled v3: column tiles per rasterisation group (see the kernel)
 };
 
 // Where a decode wave finds its weight fragments: scalar base of (column block, k-step 0), bytes between k-steps, and
@@ -1475,6 +1476,57 @@ __global__ __launch_bounds__(256) void fp8_gemm_tiled_kernel(GemmArgs p) {
   }
 }
 
+// Epilogue of the tiled kernels: each wave scales its (16 RI) x 64 accumulator tile, adds the bias and stores it in passes
+// of 64 rows through a wave-private [64][64] (+8 pad) LDS patch (9216 B) that turns the MFMA layout into 16-B row segments.
+template <int OUT_DTYPE, int RI>
+__device__ __forceinline__ void tiled_epilogue(const GemmArgs& p, char* smem, f32x4 (&acc)[RI][4], int m0, int n0, int wm,
+                                               int wn, int wave, int lane) {
+  using H = Half16<OUT_DTYPE>;
+  using T = typename H::T;
+  const int r16 = lane & 15, g = lane >> 4;
+  T* ep = reinterpret_cast<T*>(smem) + wave * (64 * 72);
+  float sbv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + wn * 64 + 16 * j + r16;
+    sbv[j] = p.sb[n < p.N ? n : p.N - 1];
+  }
+  constexpr int RP = RI < 4 ? RI : 4;  // 16-row fragments per epilogue pass
+#pragma unroll
+  for (int pass = 0; pass < RI / RP; ++pass) {
+    const int mw0 = m0 + wm * 16 * RI + 16 * RP * pass;
+#pragma unroll
+    for (int i = 0; i < RP; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ml = 16 * i + 4 * g + r;
+        const int m = mw0 + ml;
+        const float sa = p.sa[m < p.M ? m : p.M - 1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int nl = 16 * j + r16;
+          float v = acc[RP * pass + i][j][r] * sbv[j] * sa;
+          if (p.bias) {
+            const int n = n0 + wn * 64 + nl;
+            v += H::to_f32(reinterpret_cast<const T*>(p.bias)[n < p.N ? n : p.N - 1]);
+          }
+          ep[ml * 72 + nl] = H::from_f32(v);
+        }
+      }
+    wait_lgkmcnt0();  // wave-private patch: a wave-level LDS wait is enough
+#pragma unroll
+    for (int it = 0; it < 2 * RP; ++it) {
+      const int c = lane + 64 * it;
+      const int ml = c >> 3, nl = (c & 7) * 8;
+      const int m = mw0 + ml, n = n0 + wn * 64 + nl;
+      if (m < p.M && n < p.N)
+        *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.out) + (int64_t)m * p.N + n) =
+            *reinterpret_cast<const uint4*>(ep + ml * 72 + nl);
+    }
+    wait_lgkmcnt0();  // the patch is rewritten by the next pass
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // tiled v2 (K % 128 == 0): the same 128x128x128 tile and 2x2 waves, but
 //   * operands go global -> LDS by LDS-DMA (no VGPR staging, no ds_write), NSTAGE stages, prefetch distance NSTAGE-1;
@@ -1625,48 +1677,189 @@ __global__ __launch_bounds__(64 * WM * WN) void fp8_gemm_tiled2_kernel(GemmArgs 
   }
   __syncthreads();  // all stages dead: the epilogue reuses the memory
 
-  // ---- epilogue in passes of 64 rows per wave through a wave-private [64][64] (+8 pad) patch (9216 B)
-  T* ep = reinterpret_cast<T*>(smem) + wave * (64 * 72);
-  float sbv[4];
+  tiled_epilogue<OUT_DTYPE, RI>(p, smem, acc, m0, n0, wm, wn, wave, lane);
+}
+
+// Tiled v3 (pre-shuffled weights only): the B operand never touches LDS.  In the fragment-major layout the 32 bytes a lane
+// feeds to one block-scaled MFMA are two 16-B pieces 1 KiB apart, and a wave's load instruction covers one contiguous KiB,
+// so every wave streams the weight fragments of its own 64 columns global -> VGPR (each fragment refilled one k-step ahead
+// right after its last MFMA, hand-counted vmcnt as in the weight-streaming decode kernel) while only A goes global -> LDS.  Per k-step of a
+// 256 x 256 tile that leaves 128 KiB of LDS fragment reads + 32 KiB of DMA writes (v2: 192 + 64), i.e. the LDS pipe is
+// busy for less than half of the step's MFMA time, at the price of each weight byte crossing L2 -> CU once per wave row
+// (WM times).  k permutation inside a step: lane group g holds bytes [16g, +16) and [64 + 16g, +16) -- on both operands.
+// Shapes: 256 x 256 with 8 waves (2 x 4), or 128 x 256 with 4 waves (1 x 4: no weight byte is loaded twice) and TWO
+// workgroups per CU, whose barriers and first-fragment latencies then overlap each other's MFMAs.
+template <int OUT_DTYPE, int NSTAGE, int RI, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, 2) void fp8_gemm_tiled3_kernel(GemmArgs p) {
+  static_assert(NSTAGE >= 3, "the wait count below assumes A(kt) was issued before B(kt)");
+  constexpr int NW = WM * WN;
+  constexpr int TMB = 16 * RI * WM;     // block rows
+  constexpr int TNB = 64 * WN;          // block columns
+  constexpr int STAGE = TMB * 128;      // A tile: TMB rows x 128 B
+  constexpr int UA = TMB / 8 / NW;      // 1-KiB DMA units (8 rows x 128 B) per wave and stage
+  static_assert((TMB / 8) % NW == 0, "DMA units must divide over the waves");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int r16 = lane & 15, g = lane >> 4;
+
+  const int tiles_m = (p.M + TMB - 1) / TMB, tiles_n = (p.N + TNB - 1) / TNB;
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  // Rasterisation: tiles go in groups of raster_gn column tiles, row tile fastest across the group's columns, so the
+  // workgroups resident on an XCD at any time (a contiguous run of `bid`) form a compact block of tiles and both operands
+  // are shared through that XCD's L2 (with one column per group every resident workgroup streams its own rows of A).
+  int tm, tn;
+  {
+    const int gsz = p.raster_gn * tiles_m;
+    const int grp = bid / gsz, r = bid - grp * gsz;
+    const int left = tiles_n - grp * p.raster_gn;
+    const int gn = left < p.raster_gn ? left : p.raster_gn;
+    tm = r / gn;
+    tn = grp * p.raster_gn + (r - tm * gn);
+  }
+  const int m0 = tm * TMB, n0 = tn * TNB;
+
+  const uint8_t* a_src[UA];
+#pragma unroll
+  for (int u = 0; u < UA; ++u) {
+    const int row = (UA * wave + u) * 8 + (lane >> 3);  // tile-local row
+    const int j = (lane & 7) ^ ((row >> 1) & 7);
+    int m = m0 + row;
+    m = m < p.M ? m : p.M - 1;  // rows past the edge re-read a valid row; never stored
+    a_src[u] = p.a + (int64_t)m * p.a_sm + 16 * j;
+  }
+  const uint32_t smem_base = lds_addr_of(smem);
+  auto dma_stage = [&](int stage, int kt) __attribute__((always_inline)) {
+    const uint32_t dst = smem_base + stage * STAGE;
+#pragma unroll
+    for (int u = 0; u < UA; ++u) lds_dma16(a_src[u] + (int64_t)kt * 128, dst + (UA * wave + u) * 1024);
+  };
+  // weight fragments: column block (n0 / 16 + 4 wn + j), k-step kt = 2 KiB at block * 16 K + 2048 kt; lane i takes bytes
+  // 16 i.. of each KiB.  Blocks past N re-read the last one (their columns are never stored).
+  const uint8_t* b_blk[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int n = n0 + wn * 64 + 16 * j + r16;
-    sbv[j] = p.sb[n < p.N ? n : p.N - 1];
+    int nb = (n0 >> 4) + wn * 4 + j;
+    nb = nb < (p.N >> 4) ? nb : (p.N >> 4) - 1;
+    b_blk[j] = p.b + (int64_t)nb * 16 * p.K;
   }
-  constexpr int RP = RI < 4 ? RI : 4;  // 16-row fragments per epilogue pass
+  const int nk = p.K >> 7;
+  auto load_b = [&](Frag32 (&q)[4], int kt) __attribute__((always_inline)) {
+    const uint32_t voff = (uint32_t)lane * 16 + (uint32_t)kt * 2048;
 #pragma unroll
-  for (int pass = 0; pass < RI / RP; ++pass) {
-    const int mw0 = m0 + wm * 16 * RI + 16 * RP * pass;
-#pragma unroll
-    for (int i = 0; i < RP; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ml = 16 * i + 4 * g + r;
-        const int m = mw0 + ml;
-        const float sa = p.sa[m < p.M ? m : p.M - 1];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int nl = 16 * j + r16;
-          float v = acc[RP * pass + i][j][r] * sbv[j] * sa;
-          if (p.bias) {
-            const int n = n0 + wn * 64 + nl;
-            v += H::to_f32(reinterpret_cast<const T*>(p.bias)[n < p.N ? n : p.N - 1]);
-          }
-          ep[ml * 72 + nl] = H::from_f32(v);
-        }
-      }
-    wait_lgkmcnt0();  // wave-private patch: a wave-level LDS wait is enough
-#pragma unroll
-    for (int it = 0; it < 2 * RP; ++it) {
-      const int c = lane + 64 * it;
-      const int ml = c >> 3, nl = (c & 7) * 8;
-      const int m = mw0 + ml, n = n0 + wn * 64 + nl;
-      if (m < p.M && n < p.N)
-        *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.out) + (int64_t)m * p.N + n) =
-            *reinterpret_cast<const uint4*>(ep + ml * 72 + nl);
+    for (int j = 0; j < 4; ++j) {
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(q[j].x[0]) : "v"(voff), "s"(b_blk[j]) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(q[j].x[1]) : "v"(voff), "s"(b_blk[j]) : "memory");
     }
-    wait_lgkmcnt0();  // the patch is rewritten by the next pass
+  };
+
+  f32x4 acc[RI][4];
+#pragma unroll
+  for (int i = 0; i < RI; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // A fragment offsets inside the stage: row (16 (RI wm + i) + r16), chunks g and 4 + g, swizzled as the DMA wrote them
+  const int sw = (r16 >> 1) & 7;
+  const uint32_t a_row = (wm * 16 * RI + r16) * 128;
+  const uint32_t c0 = 16 * (g ^ sw), c1 = 16 * ((4 + g) ^ sw);
+
+  // Register budget (two waves per SIMD = 256 per lane): 128 accumulators + 64 for the step's RI A fragments + 32 for ONE
+  // set of weight fragments.  The MFMAs therefore go column by column: once the RI MFMAs of column block j are issued,
+  // its fragment registers are refilled with the NEXT step's bytes, which have a whole step to arrive.
+  // VMEM issue order per step: A DMAs of step kt + 2 (UA per wave), then refills R0..R3 (two loads each).  Loads retire in
+  // order, so in front of column j "R_j of the previous step has landed" is vmcnt(6 + UA): R_j+1.. of the previous step,
+  // this step's DMAs, this step's R_0..j-1.  The same wait, at column 3, also proves this wave's DMAs of step kt + 1 (older
+  // than the previous step's R_3), which is what the next barrier publishes.  Tail steps re-issue the last step's DMAs into
+  // the dead stage and re-read the last weights, so the counts never change.
+  Frag32 bq[4];
+#pragma unroll
+  for (int st = 0; st < NSTAGE - 1; ++st) dma_stage(st, st < nk ? st : nk - 1);
+  load_b(bq, 0);
+  wait_vmcnt<(NSTAGE - 2) * UA + 8>();  // stage 0 landed (this wave's part)
+#ifndef SGLM_T3_ABL
+#define SGLM_T3_ABL 0  // timing ablations (WRONG RESULTS): 1 no barrier, 2 A fragments read once, 3 no weight refills, 4 no DMA, 5 DMA always of k-step 0 (L2-resident)
+#endif
+#if SGLM_T3_ABL == 2
+  Frag32 af[RI];
+#pragma unroll
+  for (int i = 0; i < RI; ++i) {
+    af[i].v[0] = *reinterpret_cast<const uint4*>(smem + a_row + i * 2048 + c0);
+    af[i].v[1] = *reinterpret_cast<const uint4*>(smem + a_row + i * 2048 + c1);
   }
+#endif
+#pragma clang loop unroll(disable)
+  for (int kt = 0; kt < nk; ++kt) {
+#if SGLM_T3_ABL != 1
+    __syncthreads();  // everyone's DMAs of stage kt landed; everyone finished reading the stage refilled below
+#endif
+#ifndef SGLM_T3_DMA_LATE
+#define SGLM_T3_DMA_LATE 1  // the step's A DMAs issue behind the first column's MFMAs (1-2 % over issuing them at the barrier)
+#endif
+    auto issue_dma = [&]() __attribute__((always_inline)) {
+#if SGLM_T3_ABL != 4
+      const int kn = kt + NSTAGE - 1;
+#if SGLM_T3_ABL == 5
+      dma_stage(kn % NSTAGE, 0);
+#else
+      dma_stage(kn % NSTAGE, kn < nk ? kn : nk - 1);
+#endif
+#endif
+    };
+#if !SGLM_T3_DMA_LATE
+    issue_dma();
+#endif
+#if SGLM_T3_ABL == 2
+#pragma unroll
+    for (int i = 0; i < RI; ++i) asm volatile("" : "+v"(af[i].x[0]), "+v"(af[i].x[1]));
+#else
+    const char* sa_ = smem + (kt % NSTAGE) * STAGE + a_row;
+    Frag32 af[RI];
+#pragma unroll
+    for (int i = 0; i < RI; ++i) {
+      af[i].v[0] = *reinterpret_cast<const uint4*>(sa_ + i * 2048 + c0);
+      af[i].v[1] = *reinterpret_cast<const uint4*>(sa_ + i * 2048 + c1);
+    }
+#endif
+    const uint32_t voff = (uint32_t)lane * 16 + (uint32_t)(kt + 1 < nk ? kt + 1 : nk - 1) * 2048;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#if SGLM_T3_ABL == 4
+      wait_frag<6>(bq[j]);
+#elif SGLM_T3_ABL == 3
+      wait_frag<0>(bq[j]);
+#elif SGLM_T3_DMA_LATE
+      if (j == 0) wait_frag<6>(bq[j]);
+      else wait_frag<6 + UA>(bq[j]);
+#else
+      wait_frag<6 + UA>(bq[j]);
+#endif
+#pragma unroll
+      for (int i = 0; i < RI; ++i)
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+            __builtin_bit_cast(v8i32_t, af[i]), __builtin_bit_cast(v8i32_t, bq[j]), acc[i][j], 0, 0, 0, 0x7F7F7F7F, 0,
+            0x7F7F7F7F);
+#if SGLM_T3_DMA_LATE
+      if (j == 0) issue_dma();  // behind the first column's MFMAs: the matrix pipe is busy while the DMAs issue
+#endif
+#if SGLM_T3_ABL != 3
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(bq[j].x[0]) : "v"(voff), "s"(b_blk[j]) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(bq[j].x[1]) : "v"(voff), "s"(b_blk[j]) : "memory");
+#else
+      (void)voff;
+#endif
+    }
+  }
+  drain_frags(bq);  // the never-consumed tail refills (and the tail DMAs)
+  __syncthreads();  // all stages dead: the epilogue reuses the memory
+  tiled_epilogue<OUT_DTYPE, RI>(p, smem, acc, m0, n0, wm, wn, wave, lane);
 }
 
 template <int OUT_DTYPE, int MB, int NB, int WK>
@@ -1785,6 +1978,33 @@ int run_gemm(const GemmArgs& p, float* workspace, int64_t workspace_floats, hipS
   const unsigned grid_b = (unsigned)(((p.M + 255) / 256) * ((p.N + 255) / 256));
   int v2 = v2_env >= 0 ? v2_env : (grid_b >= 192 ? 84 : (grid_s <= 256 ? 22 : 2));
   if (p.b_shuf && v2 == 0) v2 = 2;  // the register-staged predecessor below does not read the pre-shuffled layout
+  // v3 (weights global -> VGPR, pre-shuffled weights only) from 192 tiles of 128 x 256 (same box, us, v2 -> v3: M = 1024 qkv
+  // 38.4 -> 36.5, gate_up 116.4 -> 111.6; M = 2048 o 40.6 -> 37.6, down 122.0 -> 100.4; M = 4096 qkv 123.9 -> 93.5, gate_up
+  // 436 -> 396; M = 8192 gate_up 920 -> 774, down 397 -> 358; below that the 128 x 128 v2 tiles fill the chip better).
+  // Column tiles per rasterisation group: 4 (1 / 2 / 4 / 8 / 16 at M = 4096 gate_up: 437 / 418 / 408 / 403 / 435 us).
+  static const int v3_env = [] { const char* e = getenv("SGL_MI355_TILED_V3"); return e ? atoi(e) : -1; }();  // 0 off; 1 / 2 force 256x256x8 waves / 128x256x4 waves (A/B aid)
+  static const int gn_env = [] { const char* e = getenv("SGL_MI355_T3_GN"); return e ? atoi(e) : 0; }();       // tuning aid
+  const unsigned grid_3 = (unsigned)(((p.M + 127) / 128) * ((p.N + 255) / 256));
+  if (p.b_shuf && (p.K & 511) == 0 && (v3_env > 0 || (v3_env != 0 && grid_3 >= 192))) {
+#define TILED3_GO(WM_)                                                                                             \
+  {                                                                                                               \
+    GemmArgs p3 = p;                                                                                              \
+    p3.raster_gn = gn_env > 0 ? gn_env : 4;                                                                       \
+    auto k3 = fp8_gemm_tiled3_kernel<OUT_DTYPE, 3, 8, WM_, 4>;                                                    \
+    constexpr int tmb = 128 * WM_;                                                                                \
+    constexpr int lds_st = 3 * tmb * 128, lds_ep = WM_ * 4 * 64 * 72 * 2;                                         \
+    constexpr int lds3 = lds_st > lds_ep ? lds_st : lds_ep;                                                       \
+    static int a3 = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(k3),                              \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds3), "hipFuncSetAttribute"); \
+    if (a3) return a3;                                                                                            \
+    const unsigned g3 = (unsigned)(((p.M + tmb - 1) / tmb) * ((p.N + 255) / 256));                                \
+    hipLaunchKernelGGL(k3, dim3(g3), dim3(256 * WM_), lds3, s, p3);                                               \
+    return check_hip(hipGetLastError(), "fp8_gemm_tiled3 launch");                                                \
+  }
+    if (v3_env == 1) TILED3_GO(2)
+    TILED3_GO(1)
+#undef TILED3_GO
+  }
   if (v2 && (p.K & 127) == 0) {
 #define TILED2_GO(NST, RI_, WM_, WN_)                                                                             \
   {                                                                                                               \

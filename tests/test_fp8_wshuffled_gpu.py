@@ -74,6 +74,29 @@ def test_fp8_scaled_mm_on_shuffled_weight(M, N, K):
     torch.testing.assert_close(out.float(), plain.float(), rtol=2 * ulp, atol=1e-3 * float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("M,N,K", [(4000, 6160, 1024), (1537, 4112, 512), (3000, 4096, 14336), (2048, 4096, 4096),
+                                   (8192, 1280, 1536), (1025, 6144, 4096), (130, 28672, 512)])
+def test_prefill_shapes_on_shuffled_weight(M, N, K):
+    """>= 192 tiles of 128 x 256 on a pre-shuffled weight: fp8_gemm_tiled3_kernel (weights global -> VGPR).  Same products
+    and the same fp32 summation order over k as the row-major tiled kernel -> bit-identical; ragged M, N % 256 != 0."""
+    assert ((M + 127) // 128) * ((N + 255) // 256) >= 192
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    dt = torch.bfloat16 if M % 2 == 0 else torch.float16
+    a, w = _rand_fp8((M, K), g), _rand_fp8((N, K), g)
+    sa = torch.rand(M, 1, generator=g, device=DEV) * 1e-3 + 1e-4
+    sb = torch.rand(N, 1, generator=g, device=DEV) * 1e-3 + 1e-4
+    bias = torch.randn(N, generator=g, device=DEV).to(dt) if N % 32 else None
+    plain = ops.fp8_scaled_mm(a, w.t(), sa, sb, dt, bias)
+    out = ops.fp8_scaled_mm(a, ops.mark_wshuffled(ops.fp8_shuffle_weight(w).t()), sa, sb, dt, bias)
+    assert torch.equal(out, plain)
+    rows = torch.tensor([0, 1, 127, 128, M // 2, M - 2, M - 1], device=DEV)  # fp64 truth on a few rows (incl. the ragged edge)
+    ref = (a[rows].double() @ w.double().t()) * sb.double().view(1, -1) * sa[rows].double()
+    if bias is not None:
+        ref = ref + bias.double()
+    ulp = 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10
+    torch.testing.assert_close(out[rows].float(), ref.float(), rtol=ulp, atol=1e-3 * float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("M", [16, 64])
 @pytest.mark.parametrize("N,K", [(6144, 4096), (4096, 4096), (28672, 4096), (4096, 14336)])
 def test_headline_decode_shapes_are_bit_identical_to_row_major(M, N, K):
