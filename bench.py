@@ -185,7 +185,17 @@ def time_attention_kernel(loop, steps):
     from sglang_npu_amd import ops
     durations = []
     real, real_fused, real_absmax = ops.decode_attention_paged, ops.decode_attention_qkv_partials, ops.decode_attention_paged_absmax
+    real_merged = ops.decode_attention_paged_merged
     pairs = []
+
+    def timed_merged(*a, **kw):  # the split kernel with the merge (+ quant) in the same launch: all of it is timed
+        st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        st.record()
+        done = real_merged(*a, **kw)
+        en.record()
+        if done is not False:
+            pairs.append((st, en))
+        return done
 
     def timed_absmax(*a, **kw):  # the same kernel with the row-absmax epilogue (model.py FUSE_ATTN_QUANT)
         st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -217,6 +227,7 @@ def time_attention_kernel(loop, steps):
     ops.decode_attention_paged = timed
     ops.decode_attention_qkv_partials = timed_fused
     ops.decode_attention_paged_absmax = timed_absmax
+    ops.decode_attention_paged_merged = timed_merged
     g = loop.graph
     loop.graph = None
     try:
@@ -227,6 +238,7 @@ def time_attention_kernel(loop, steps):
         ops.decode_attention_paged = real
         ops.decode_attention_qkv_partials = real_fused
         ops.decode_attention_paged_absmax = real_absmax
+        ops.decode_attention_paged_merged = real_merged
         loop.graph = g
     durations = [s.elapsed_time(e) for s, e in pairs]
     durations.sort()

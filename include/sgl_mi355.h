@@ -34,7 +34,7 @@ extern "C" {
 #define SGL_MI355_ERR_RUNTIME 3          /* a HIP runtime call failed                */
 
 /* ABI version of this header; bumped on any signature change. */
-#define SGL_MI355_ABI_VERSION 7
+#define SGL_MI355_ABI_VERSION 8
 int sgl_mi355_abi_version(void);
 
 /* Copies the calling thread's last error message (NUL-terminated) into buf. Returns its length. */
@@ -278,6 +278,27 @@ int sgl_mi355_fp8_scaled_mm_partials_a16(const void* mat_a16, int64_t a_stride_m
 int sgl_mi355_decode_merge_quant_fp8(const float* attn_logits, int64_t num_seqs, int64_t num_heads, int64_t head_size_v,
                                      int64_t num_kv_splits, void* output, int64_t o_stride_b, int64_t o_stride_h,
                                      void* out_q, float* out_s, int dtype, void* stream);
+
+/* Paged decode with kv-splits whose merge -- and, if out_q / out_s are given, the per-token FP8 quant of the merged row --
+ * happens inside the SAME launch (no stage-2 kernel, no quant kernel).
+ * Replaces: decode_attention_fwd stage 1 + stage 2 (decode_attention.py:404-488, 491-596; decode.cpp:812-860) [+
+ *           sgl_per_token_quant_fp8 on the result]; bit-identical to sgl_mi355_decode_attention followed by
+ *           sgl_mi355_decode_merge_quant_fp8.
+ *   merge_counters int32 [num_seqs]: ZERO before the first call; every workgroup counts itself in after publishing its
+ *   partial (device-scope release), the one that completes request b's count merges b and zeroes the counter again --
+ *   so the buffer can be reused by the next call on the same stream (not by concurrent calls on other streams).
+ *   attn_logits fp32 [B][Hq][num_kv_splits][D+1] scratch as for sgl_mi355_decode_attention; output (nullable) 16-bit
+ *   [B, Hq, D] with the given strides; out_q (nullable) e4m3 [B, Hq * D] contiguous with out_s fp32 [B].
+ *   kv_format 0: 16-bit pool; 1: e4m3fn bytes; 2: e5m2 bytes (strides then count bytes).
+ *   SGL_MI355_ERR_UNSUPPORTED without a launch outside head size 64 / 128, 16-byte aligned rows. */
+int sgl_mi355_decode_attention_merged(const void* query, void* k_cache, void* v_cache, void* output, void* out_q, float* out_s,
+                                      float* attn_logits, int32_t* merge_counters, const void* req_to_token,
+                                      int req_to_token_is64, const int64_t* req_pool_indices, const int64_t* seq_lens,
+                                      int64_t num_seqs, int64_t max_context_len, int64_t num_heads, int64_t num_kv_heads,
+                                      int64_t head_size, int64_t num_kv_splits, int64_t q_stride_b, int64_t q_stride_h,
+                                      int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h,
+                                      int64_t o_stride_b, int64_t o_stride_h, float sm_scale, float logit_cap, int kv_format,
+                                      int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * merge_state: combine two partial attention results of the same queries by their log-sum-exp.

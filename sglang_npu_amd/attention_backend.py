@@ -24,12 +24,24 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Optional
 
+import os
+
 import torch
 
 from . import ops
 from .harness import AttentionType, ForwardBatch, ForwardMode
 
 NUM_CUS = 256
+
+
+# kv-split decode: merge (and per-token FP8 quant) inside the attention launch (sgl_mi355_decode_attention_merged) instead
+# of a stage-2 launch, while a request has at most FUSE_SPLIT_MERGE_MAX_WGS workgroups (kv heads x head blocks x splits).
+# Measured as HIP graphs at bs=64, ctx=2048 (tools/bench_decode_split_merge.py, us, two launches -> one): one rank of
+# Llama-3-70B TP=8 (8/1 heads, 4 splits) 23.7 -> 22.3, of Llama-3-8B TP=8 (4/1) 21.8 -> 20.5, TP=4 (8/2, 2 splits) 33.1 ->
+# 32.0; Llama-3-8B at bs=16 (32/8 heads, 2 splits = 16 workgroups and a 4096-wide row per request) 34.6 -> 37.1: the last
+# workgroup's serial merge outweighs the launch there.  SGL_MI355_NO_SPLIT_MERGE_FUSION=1 keeps the separate launches.
+FUSE_SPLIT_MERGE = os.environ.get("SGL_MI355_NO_SPLIT_MERGE_FUSION", "0") in ("", "0")
+FUSE_SPLIT_MERGE_MAX_WGS = 8
 
 
 @dataclass
@@ -111,8 +123,15 @@ class MI355AttnBackend(AttentionBackend):
             self.window_kv_indptr = torch.zeros_like(self.kv_indptr)
         if not skip_prefill:
             self.qo_indptr = torch.zeros((max_bs + 1,), dtype=torch.int32, device=self.device)
+        # arrival counters of the in-launch split merge (ops.decode_attention_paged_merged): zero here, left zero by every call
+        self._merge_counters = torch.zeros((max_bs,), dtype=torch.int32, device=self.device)
         self.forward_metadata: Optional[ForwardMetadata] = None
         self._graph = None  # static buffers once init_cuda_graph_state has run
+
+    def _fuse_split_merge(self, splits: int, bs: int) -> bool:
+        group = max(1, self.num_head // self.num_kv_head)
+        return (FUSE_SPLIT_MERGE and bs <= self._merge_counters.numel()
+                and self.num_kv_head * ((group + 15) // 16) * splits <= FUSE_SPLIT_MERGE_MAX_WGS)
 
     # ---------------------------------------------------------------- split policy (host only)
     def choose_num_kv_splits(self, bs: int, max_seq_len: Optional[int] = None) -> int:
@@ -291,6 +310,14 @@ class MI355AttnBackend(AttentionBackend):
             kb = forward_batch.token_to_kv_pool.get_key_buffer(layer.layer_id)
             vb = forward_batch.token_to_kv_pool.get_value_buffer(layer.layer_id)
             q3 = q.view(-1, layer.tp_q_head_num, layer.qk_head_dim)
+            if self._fuse_split_merge(md.num_kv_splits, q3.shape[0]):
+                # one launch: the workgroup that publishes a request's last partial merges and quantises its row
+                done = ops.decode_attention_paged_merged(q3, kb, vb, None, self.req_to_token, forward_batch.req_pool_indices,
+                                                         forward_batch.seq_lens, md.attn_logits[:q3.shape[0]],
+                                                         md.num_kv_splits, self._merge_counters, layer.scaling,
+                                                         layer.logit_cap, fp8_out=True)
+                if done is not False:
+                    return done
             ops.decode_attention_paged(q3, kb, vb, None, self.req_to_token, forward_batch.req_pool_indices,
                                        forward_batch.seq_lens, md.attn_logits[:q3.shape[0]], md.num_kv_splits,
                                        layer.scaling, layer.logit_cap)
@@ -314,6 +341,13 @@ class MI355AttnBackend(AttentionBackend):
             ops.decode_attention_fwd(q3, kb, vb, o3, md.kv_indptr, md.kv_indices, md.attn_logits, md.attn_lse, None,
                                      md.num_kv_splits, layer.scaling, layer.logit_cap)
         else:
+            if (isinstance(md.num_kv_splits, int) and md.num_kv_splits > 1 and md.attn_logits is not None
+                    and layer.qk_head_dim == layer.v_head_dim and self._fuse_split_merge(md.num_kv_splits, q3.shape[0])
+                    and ops.decode_attention_paged_merged(q3, kb, vb, o3, self.req_to_token, forward_batch.req_pool_indices,
+                                                          forward_batch.seq_lens, md.attn_logits[:q3.shape[0]],
+                                                          md.num_kv_splits, self._merge_counters, layer.scaling,
+                                                          layer.logit_cap) is not False):
+                return o
             ops.decode_attention_paged(q3, kb, vb, o3, self.req_to_token, forward_batch.req_pool_indices,
                                        forward_batch.seq_lens, md.attn_logits, md.num_kv_splits, layer.scaling,
                                        layer.logit_cap)

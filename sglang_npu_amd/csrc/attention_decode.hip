@@ -87,7 +87,12 @@ struct DecodeArgs {
   // that are stored (atomic max; the caller zeroes it) -- the per-token scale of the w8a8 o_proj input without a pass
   // over the output (sgl_mi355_decode_attention_absmax)
   float* row_absmax;
-  int kv8;  // 1 / 2: the pool is e4m3fn / e5m2 bytes (strides in elements = bytes); K is upcast, P is rounded to that format before PV
+  int kv8;  // 1 / 2: the pool is e4m3fn / e5m2 bytes (strides in elements = bytes); K is upcast, P is rounded to that format before PV  // non-null (split kernel with fp32 partials only): merge_counters[b] counts the workgroups of request b that have
+  // published their partial; the one that arrives last merges the request's kv-splits (and, if mq_out_q is given,
+  // quantises the row per token) in the same launch, then zeroes the counter again.  Caller: zero once.
+  int32_t* merge_counters;
+  uint8_t* mq_out_q;  // optional e4m3 [B][Hq * Dv] ...
+  float* mq_out_s;    // ... with its scale [B]
 };
 
 // The qkv GEMM of the SAME decode step, still split-K partial sums (sgl_mi355_decode_attention_qkv_partials): the pair
@@ -116,6 +121,43 @@ __device__ __forceinline__ void split_range(const DecodeArgs& a, int b, int spli
   s0 = per * split;
   s1 = s0 + per < len ? s0 + per : len;
   if (split >= splits) s1 = s0;  // no work
+}
+
+template <int DTYPE, bool COHERENT>
+__device__ void merge_quant_row(const DecodeArgs& a, int Dv, uint8_t* __restrict__ out_q, float* __restrict__ out_s, int b,
+                                int tid, int NT, char* smem, float* red);
+
+// Split kernels, fused merge (DecodeArgs::merge_counters): called by every thread of a workgroup after its partial (or
+// its "empty split" marker) is stored.  The other workgroups of the request may sit on another XCD (own L2), and a
+// device-scope fence (`__threadfence()` = L2 write-back + invalidate per workgroup) costs more than the launch it saves
+// (measured: 61.6 us against 24.9 for the two launches at 64 x 1 kv head x 4 splits).  So the partials themselves are
+// written and read as agent-scope relaxed atomics (`sc1`: written through to / read from the coherence point, no cache
+// maintenance): stores -> s_waitcnt vmcnt(0) (they are acknowledged) -> barrier -> one lane counts the workgroup in; the
+// workgroup that completes the request's count reads all partials with coherent loads and merges.
+// `tail`: 64 bytes at the end of the workgroup's dynamic LDS (flag + reduction scratch; no static LDS: the largest variants
+// of the kernel already ask for all 160 KB).
+__device__ __forceinline__ void store_coherent(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float load_coherent(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int DTYPE>
+__device__ __forceinline__ void arrive_and_merge(const DecodeArgs& a, int Dv, int b, int tid, int NT, char* smem, char* tail) {
+  int* s_last = reinterpret_cast<int*>(tail);
+  float* s_red = reinterpret_cast<float*>(tail + 16);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's partial stores are acknowledged
+  __syncthreads();                                  // ... and so are everyone's; every wave is done with the LDS
+  if (tid == 0) {
+    const int nhb = (a.group + 15) >> 4;
+    const int target = a.num_kv_heads * nhb * a.num_splits;
+    const int old = __hip_atomic_fetch_add(a.merge_counters + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *s_last = old == target - 1;
+    // the next launch starts from zero again (nobody else touches the counter before then)
+    if (old == target - 1) __hip_atomic_store(a.merge_counters + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (*s_last) merge_quant_row<DTYPE, true>(a, Dv, a.mq_out_q, a.mq_out_s, b, tid, NT, smem, s_red);
 }
 
 // 16-B chunk swizzle of a [token][D] 16-bit tile (see DESIGN.md "LDS image"):
@@ -200,9 +242,14 @@ __global__ __launch_bounds__(kWaves * 64) void decode_mfma_kernel(DecodeArgs a) 
         T* o = reinterpret_cast<T*>(a.out) + (int64_t)b * a.o_sb + (int64_t)(h0 + tid) * a.o_sh;
         for (int d = 0; d < D; ++d) o[d] = H::from_f32(0.f);
       } else {
-        a.mid_lse[(int64_t)b * a.ml_sb + (int64_t)(h0 + tid) * a.ml_sh + (int64_t)split * a.ml_ss] = -INFINITY;
+        float* lp = a.mid_lse + (int64_t)b * a.ml_sb + (int64_t)(h0 + tid) * a.ml_sh + (int64_t)split * a.ml_ss;
+        if (a.merge_counters != nullptr) store_coherent(lp, -INFINITY);
+        else *lp = -INFINITY;
       }
     }
+    if constexpr (!DIRECT_OUT)
+      if (a.merge_counters != nullptr)
+        arrive_and_merge<DTYPE>(a, D, b, tid, kWaves * 64, smem, smem + kWaves * WAVE_BYTES + kIdxCap * 4 - 64);
     return;
   }
 
@@ -552,12 +599,20 @@ __global__ __launch_bounds__(kWaves * 64) void decode_mfma_kernel(DecodeArgs a) 
     if (DIRECT_OUT) {
       reinterpret_cast<T*>(a.out)[(int64_t)b * a.o_sb + (int64_t)(h0 + h) * a.o_sh + dv] = H::from_f32(r);
     } else {
-      a.mid_o[(int64_t)b * a.mo_sb + (int64_t)(h0 + h) * a.mo_sh + (int64_t)split * a.mo_ss + dv] = r;
-      if (dv == 0)
-        a.mid_lse[(int64_t)b * a.ml_sb + (int64_t)(h0 + h) * a.ml_sh + (int64_t)split * a.ml_ss] =
-            (M + log2f(L)) * kLn2;
+      float* op = a.mid_o + (int64_t)b * a.mo_sb + (int64_t)(h0 + h) * a.mo_sh + (int64_t)split * a.mo_ss + dv;
+      float* lp = a.mid_lse + (int64_t)b * a.ml_sb + (int64_t)(h0 + h) * a.ml_sh + (int64_t)split * a.ml_ss;
+      if (a.merge_counters != nullptr) {  // read by another workgroup of this launch: see arrive_and_merge
+        store_coherent(op, r);
+        if (dv == 0) store_coherent(lp, (M + log2f(L)) * kLn2);
+      } else {
+        *op = r;
+        if (dv == 0) *lp = (M + log2f(L)) * kLn2;
+      }
     }
   }
+  if constexpr (!DIRECT_OUT)
+    if (a.merge_counters != nullptr)
+      arrive_and_merge<DTYPE>(a, D, b, tid, kWaves * 64, smem, smem + kWaves * WAVE_BYTES + kIdxCap * 4 - 64);
 }
 
 // --------------------------------------------------------------------------------------
@@ -1251,60 +1306,99 @@ __global__ __launch_bounds__(64) void decode_merge_kernel(DecodeArgs a, int Dv) 
 // dtype, takes the row absmax and writes e4m3 + scale exactly as sgl_per_token_quant_fp8 would on that 16-bit row
 // (per_token_quant_fp8.cu:15-87: scale = absmax / 448, q = clamp(x * (1 / scale))) -- bit-identical to the two
 // launches it replaces.  The 16-bit row itself is written only if `a.out` is given.
-template <int DTYPE, int NT>
-__global__ __launch_bounds__(NT) void decode_merge_quant_kernel(DecodeArgs a, int Dv, uint8_t* __restrict__ out_q,
-                                                                float* __restrict__ out_s) {
+template <int DTYPE, bool COHERENT>
+__device__ void merge_quant_row(const DecodeArgs& a, int Dv, uint8_t* __restrict__ out_q, float* __restrict__ out_s, int b,
+                                int tid, int NT, char* smem, float* red) {
   using H = Half16<DTYPE>;
   using T = typename H::T;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  auto ld = [](const float* p) __attribute__((always_inline)) { return COHERENT ? load_coherent(p) : *p; };
   const int Hq = a.num_heads, S = a.num_splits, R = Hq * Dv;
   T* row = reinterpret_cast<T*>(smem);                                   // [R] merged output, 16-bit
   float* ew = reinterpret_cast<float*>(smem + ((R * 2 + 15) & ~15));     // [Hq][S] exp(lse - M); then [Hq] 1 / L
   float* inv = ew + Hq * S;
-  __shared__ float red[NT / 64];
+  // all LSEs in one round trip (one (head, split) pair per thread), then the per-head weights from LDS
+  for (int i = tid; i < Hq * S; i += NT) {
+    const int h = i / S, sp = i - h * S;
+    ew[i] = ld(a.mid_lse + (int64_t)b * a.ml_sb + (int64_t)h * a.ml_sh + (int64_t)sp * a.ml_ss);
+  }
+  __syncthreads();
   for (int h = tid; h < Hq; h += NT) {
-    const float* lse = a.mid_lse + (int64_t)b * a.ml_sb + (int64_t)h * a.ml_sh;
+    float* lw = ew + h * S;  // in: lse; out: exp(lse - M)
     float M = -INFINITY;
-    for (int s = 0; s < S; ++s) M = fmaxf(M, lse[(int64_t)s * a.ml_ss]);
+    for (int s = 0; s < S; ++s) M = fmaxf(M, lw[s]);
     float L = 0.f;
     for (int s = 0; s < S; ++s) {
-      const float l = lse[(int64_t)s * a.ml_ss];
+      const float l = lw[s];
       const float e = (M == -INFINITY || l == -INFINITY) ? 0.f : expf(l - M);  // 0: an empty split, partial undefined
-      ew[h * S + s] = e;
+      lw[s] = e;
       if (M != -INFINITY) L += expf(l - M);
     }
     inv[h] = M == -INFINITY ? 0.f : 1.f / L;  // empty sequence: zero row
   }
   __syncthreads();
   float amax = 0.f;
-  for (int e = tid; e < R; e += NT) {
-    const int h = e / Dv, d = e - h * Dv;
-    const float* mo = a.mid_o + (int64_t)b * a.mo_sb + (int64_t)h * a.mo_sh + d;
-    const float* w = ew + h * S;
-    float acc = 0.f;
-    for (int s0 = 0; s0 < S; s0 += 8) {  // eight splits' loads in flight; the sum stays in split order
-      float m[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) m[u] = mo[(int64_t)(s0 + u < S ? s0 + u : S - 1) * a.mo_ss];
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (s0 + u < S) {
-          const float wu = w[s0 + u];
-          if (wu != 0.f) acc += wu * m[u];
-        }
-    }
+  auto finish = [&](int e, int h, int d, float acc) __attribute__((always_inline)) {
     const T o = H::from_f32(acc * inv[h]);
     row[e] = o;
     amax = fmaxf(amax, fabsf(H::to_f32(o)));
     if (a.out) reinterpret_cast<T*>(a.out)[(int64_t)b * a.o_sb + (int64_t)h * a.o_sh + d] = o;
+  };
+  if (S <= 8) {
+    // four elements x up to eight splits: all of a thread's loads of an iteration in flight together (this row is usually
+    // the whole job of the thread); the sum stays in split order
+    for (int e0 = tid; e0 < R; e0 += 4 * NT) {
+      float m[4][8];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * NT < R ? e0 + u * NT : R - 1;
+        const int h = e / Dv, d = e - h * Dv;
+        const float* mo = a.mid_o + (int64_t)b * a.mo_sb + (int64_t)h * a.mo_sh + d;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m[u][k] = ld(mo + (int64_t)(k < S ? k : S - 1) * a.mo_ss);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * NT;
+        if (e < R) {
+          const int h = e / Dv, d = e - h * Dv;
+          const float* w = ew + h * S;
+          float acc = 0.f;
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            if (k < S) {
+              const float wk = w[k];
+              if (wk != 0.f) acc += wk * m[u][k];
+            }
+          finish(e, h, d, acc);
+        }
+      }
+    }
+  } else {
+    for (int e = tid; e < R; e += NT) {
+      const int h = e / Dv, d = e - h * Dv;
+      const float* mo = a.mid_o + (int64_t)b * a.mo_sb + (int64_t)h * a.mo_sh + d;
+      const float* w = ew + h * S;
+      float acc = 0.f;
+      for (int s0 = 0; s0 < S; s0 += 8) {  // eight splits' loads in flight; the sum stays in split order
+        float m[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) m[u] = ld(mo + (int64_t)(s0 + u < S ? s0 + u : S - 1) * a.mo_ss);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (s0 + u < S) {
+            const float wu = w[s0 + u];
+            if (wu != 0.f) acc += wu * m[u];
+          }
+      }
+      finish(e, h, d, acc);
+    }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+  if (out_q == nullptr) return;  // merge only (the 16-bit row went to a.out)
   if ((tid & 63) == 0) red[tid >> 6] = amax;
   __syncthreads();
   amax = red[0];
-#pragma unroll
   for (int i = 1; i < NT / 64; ++i) amax = fmaxf(amax, red[i]);
   const float scale = amax / 448.0f;
   if (tid == 0) out_s[b] = scale;
@@ -1319,6 +1413,14 @@ __global__ __launch_bounds__(NT) void decode_merge_quant_kernel(DecodeArgs a, in
     hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
     reinterpret_cast<uint2*>(out_q + (int64_t)b * R)[v] = uint2{(unsigned)lo, (unsigned)hi};
   }
+}
+
+template <int DTYPE, int NT>
+__global__ __launch_bounds__(NT) void decode_merge_quant_kernel(DecodeArgs a, int Dv, uint8_t* __restrict__ out_q,
+                                                                float* __restrict__ out_s) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ float red[NT / 64];
+  merge_quant_row<DTYPE, false>(a, Dv, out_q, out_s, blockIdx.x, threadIdx.x, NT, smem, red);
 }
 
 template <int D, int kWaves, int KV8 = 0>
@@ -1368,6 +1470,9 @@ thread_local const FusedQkv* tl_fq = nullptr;
 thread_local bool tl_fq_used = false;
 // set by sgl_mi355_decode_attention_absmax around its call of the regular entry point
 thread_local float* tl_row_absmax = nullptr;
+// set by sgl_mi355_decode_attention_merged around its call of the regular entry point
+struct MergeFused { int32_t* counters; uint8_t* out_q; float* out_s; };
+thread_local MergeFused tl_merge{nullptr, nullptr, nullptr};
 
 template <int DTYPE, int D, typename IdxT, bool DIRECT>
 int launch_mfma(const DecodeArgs& a, int64_t batch, hipStream_t stream) {
@@ -1458,10 +1563,10 @@ int dispatch_stage1(const DecodeArgs& a, int64_t batch, int D, int Dv, bool dire
 template <int DTYPE>
 int run_decode(DecodeArgs a, int64_t batch, int D, int Dv, bool idx64, hipStream_t stream) {
   // a.out == nullptr: stage 1 only -- the caller merges (sgl_mi355_decode_merge_quant_fp8)
-  const bool direct = (a.num_splits == 1 && a.num_kv_splits == nullptr && a.out != nullptr);
+  const bool direct = (a.num_splits == 1 && a.num_kv_splits == nullptr && a.out != nullptr && a.merge_counters == nullptr);
   int rc = idx64 ? dispatch_stage1<DTYPE, int64_t>(a, batch, D, Dv, direct, stream)
                  : dispatch_stage1<DTYPE, int32_t>(a, batch, D, Dv, direct, stream);
-  if (rc != 0 || direct || a.out == nullptr) return rc;
+  if (rc != 0 || direct || a.merge_counters != nullptr || a.out == nullptr) return rc;  // (fused: the last workgroup of a request merged)
   hipLaunchKernelGGL((decode_merge_kernel<DTYPE>), dim3((unsigned)(batch * a.num_heads)), dim3(64), 0, stream, a, Dv);
   return check_hip(hipGetLastError(), "decode_merge_kernel launch");
 }
@@ -1527,6 +1632,7 @@ extern "C" int sgl_mi355_decode_attention(
   a.num_heads = (int)num_heads; a.num_kv_heads = (int)num_kv_heads; a.group = (int)(num_heads / num_kv_heads);
   a.sm_scale = sm_scale; a.logit_cap = logit_cap; a.kv8 = tl_kv8;
   a.row_absmax = tl_row_absmax;
+  a.merge_counters = tl_merge.counters; a.mq_out_q = tl_merge.out_q; a.mq_out_s = tl_merge.out_s;
   hipStream_t s = as_stream(stream);
   return dtype == SGL_MI355_BF16
              ? run_decode<SGL_MI355_BF16>(a, num_seqs, (int)head_size, (int)head_size_v, req_to_token_is64 != 0, s)
@@ -1580,6 +1686,51 @@ extern "C" int sgl_mi355_decode_attention_fp8kv(
                                             v_stride_h, 0, 0, 0, 0, o_stride_b, o_stride_h, sm_scale, logit_cap, dtype,
                                             stream);
   tl_kv8 = 0;
+  return rc;
+}
+
+// sgl_mi355_decode_attention (page-table form, no KV write) with kv-splits whose merge -- and, when out_q / out_s are
+// given, the per-token FP8 quant of the merged row (what sgl_mi355_decode_merge_quant_fp8 computes) -- happens in the SAME
+// launch: every workgroup counts itself in on merge_counters[b] (int32 [num_seqs], zero before the first call; left zero)
+// after publishing its partial, and the workgroup that completes request b's count merges it.  Same bits as the two (or
+// three) launches it replaces.  kv_format: 0 16-bit pool, 1 e4m3fn bytes, 2 e5m2 bytes.  `output` (16-bit row) and
+// out_q / out_s are each optional, at least one is required.  Shapes outside the MFMA split kernel (head size 64 / 128 =
+// v head size, 16-byte aligned rows) or rows that do not fit its LDS return SGL_MI355_ERR_UNSUPPORTED without launching.
+extern "C" int sgl_mi355_decode_attention_merged(
+    const void* query, void* k_cache, void* v_cache, void* output, void* out_q, float* out_s, float* attn_logits,
+    int32_t* merge_counters, const void* req_to_token, int req_to_token_is64, const int64_t* req_pool_indices,
+    const int64_t* seq_lens, int64_t num_seqs, int64_t max_context_len, int64_t num_heads, int64_t num_kv_heads,
+    int64_t head_size, int64_t num_kv_splits, int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_n,
+    int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h, float sm_scale,
+    float logit_cap, int kv_format, int dtype, void* stream) {
+  SGLM_CHECK_ARG(attn_logits != nullptr && merge_counters != nullptr, "decode_attention_merged: null attn_logits / merge_counters");
+  SGLM_CHECK_ARG(output != nullptr || (out_q != nullptr && out_s != nullptr), "decode_attention_merged: no output given");
+  SGLM_CHECK_ARG((out_q == nullptr) == (out_s == nullptr), "decode_attention_merged: out_q and out_s go together");
+  SGLM_CHECK_ARG(kv_format >= 0 && kv_format <= 2, "decode_attention_merged: kv_format must be 0, 1 or 2");
+  SGLM_CHECK_ARG(num_heads > 0 && num_kv_heads > 0 && num_heads % num_kv_heads == 0 && num_kv_splits >= 1,
+                 "decode_attention_merged: bad head counts / splits");
+  const int64_t esz = kv_format ? 16 : 8;  // 16-byte rows: elements per 16 bytes
+  const bool aligned = q_stride_b % 8 == 0 && q_stride_h % 8 == 0 && k_stride_n % esz == 0 && k_stride_h % esz == 0 &&
+                       v_stride_n % esz == 0 && v_stride_h % esz == 0 && reinterpret_cast<uintptr_t>(query) % 16 == 0 &&
+                       reinterpret_cast<uintptr_t>(k_cache) % 16 == 0 && reinterpret_cast<uintptr_t>(v_cache) % 16 == 0;
+  const int64_t R = num_heads * head_size;
+  const int64_t lds_need = ((R * 2 + 15) & ~15ll) + (num_heads * num_kv_splits + num_heads) * 4;
+  // the smallest dynamic LDS any variant of the split kernel is launched with (two waves, 16-bit tiles)
+  const int64_t lds_have = (head_size == 128 ? mfma_lds_bytes<128, 2, 0>() : mfma_lds_bytes<64, 2, 0>()) - 64;  // (its last 64 bytes: flag + scratch)
+  if (!((head_size == 128 || head_size == 64) && aligned && R % 8 == 0 && lds_need <= lds_have)) {
+    set_error("decode_attention_merged: shape outside the fused form (head size 64 / 128, 16-byte aligned rows, "
+              "num_heads * head_size * 2 + num_heads * (num_kv_splits + 1) * 4 bytes of LDS <= %ld)", (long)lds_have);
+    return SGL_MI355_ERR_UNSUPPORTED;
+  }
+  tl_merge = MergeFused{merge_counters, static_cast<uint8_t*>(out_q), out_s};
+  tl_kv8 = kv_format;
+  const int rc = sgl_mi355_decode_attention(query, k_cache, v_cache, output, nullptr, nullptr, nullptr, attn_logits,
+                                            req_to_token, req_to_token_is64, req_pool_indices, seq_lens, num_seqs,
+                                            max_context_len, num_heads, num_kv_heads, head_size, head_size, num_kv_splits,
+                                            q_stride_b, q_stride_h, k_stride_n, k_stride_h, v_stride_n, v_stride_h, 0, 0, 0,
+                                            0, o_stride_b, o_stride_h, sm_scale, logit_cap, dtype, stream);
+  tl_kv8 = 0;
+  tl_merge = MergeFused{nullptr, nullptr, nullptr};
   return rc;
 }
 

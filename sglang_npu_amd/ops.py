@@ -258,6 +258,48 @@ def decode_attention_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_indi
         _F(sm_scale), _F(logit_cap), _I(_dtype_code(q)), _stream(q)))
 
 
+def decode_attention_paged_merged(q, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens, attn_logits,
+                                 num_kv_splits, merge_counters, sm_scale, logit_cap=0.0, fp8_out=False):
+    """decode_attention_paged with kv-splits whose merge happens inside the same launch (the workgroup that publishes a
+    request's last partial merges it; `merge_counters`: int32 [>= B], zero before the first call, left zero).  With
+    fp8_out the merged row is also quantised per token in that launch and (q_fp8 [B, Hq*Dv], scale [B, 1]) is returned --
+    the bits of decode_attention_paged + decode_merge_quant_fp8; `o` (16-bit [B, Hq, Dv]) may then be None.
+    Returns False WITHOUT launching when the shape is outside the fused form (the caller runs the separate launches)."""
+    _need_gpu(q, k_buffer, v_buffer, req_to_token, req_pool_indices, seq_lens, attn_logits, merge_counters)
+    if req_pool_indices.dtype != torch.int64 or seq_lens.dtype != torch.int64:
+        raise RuntimeError("decode_attention_paged_merged: req_pool_indices and seq_lens must be int64")
+    for name, t in (("q", q), ("k_buffer", k_buffer), ("v_buffer", v_buffer), ("o", o)):
+        if t is not None and (t.dim() != 3 or t.stride(-1) != 1):
+            raise RuntimeError(f"decode_attention_paged_merged: {name} must be 3-D, contiguous at the last dimension")
+    B, Hq, D = q.shape
+    Dv = v_buffer.size(2)
+    if o is None and not fp8_out:
+        raise RuntimeError("decode_attention_paged_merged: no output requested")
+    if merge_counters.dtype != torch.int32 or not merge_counters.is_contiguous() or merge_counters.numel() < B:
+        raise RuntimeError("decode_attention_paged_merged: merge_counters must be contiguous int32 [>= B]")
+    if attn_logits.dtype != torch.float32 or not attn_logits.is_contiguous() or \
+            attn_logits.numel() < B * Hq * num_kv_splits * (Dv + 1):
+        raise RuntimeError("decode_attention_paged_merged: attn_logits must be contiguous float32 [B, Hq, num_kv_splits, Dv+1]")
+    if req_to_token.dim() != 2 or req_to_token.stride(1) != 1 or req_to_token.stride(0) != req_to_token.size(1):
+        raise RuntimeError("decode_attention_paged_merged: req_to_token must be a contiguous 2-D tensor")
+    if D != Dv:
+        return False
+    fmt = _kv_format(k_buffer, v_buffer, q)
+    out_q = torch.empty((B, Hq * Dv), dtype=torch.float8_e4m3fn, device=q.device) if fp8_out else None
+    out_s = torch.empty((B, 1), dtype=torch.float32, device=q.device) if fp8_out else None
+    o_sb, o_sh = (o.stride(0), o.stride(1)) if o is not None else (0, 0)
+    rc = _lib.lib().sgl_mi355_decode_attention_merged(
+        _ptr(q), _ptr(k_buffer), _ptr(v_buffer), _ptr(o), _ptr(out_q), _ptr(out_s), _ptr(attn_logits), _ptr(merge_counters),
+        _ptr(req_to_token), _I(_is64(req_to_token, "req_to_token")), _ptr(req_pool_indices), _ptr(seq_lens), _I64(B),
+        _I64(req_to_token.size(1)), _I64(Hq), _I64(k_buffer.size(1)), _I64(D), _I64(num_kv_splits), _I64(q.stride(0)),
+        _I64(q.stride(1)), _I64(k_buffer.stride(0)), _I64(k_buffer.stride(1)), _I64(v_buffer.stride(0)),
+        _I64(v_buffer.stride(1)), _I64(o_sb), _I64(o_sh), _F(sm_scale), _F(logit_cap), _I(fmt), _I(_dtype_code(q)), _stream(q))
+    if rc == 2:  # SGL_MI355_ERR_UNSUPPORTED: not launched
+        return False
+    _lib.check(rc)
+    return (out_q, out_s) if fp8_out else True
+
+
 def decode_merge_quant_fp8(attn_logits, num_kv_splits, out_dtype, o=None):
     """Merge the kv-split partials left by decode_attention_paged(..., o=None) and quantise the result per token to FP8
     in the same pass: (q [B, Hq*Dv] e4m3fn, scale [B,1] f32), bit-identical to the merge followed by
