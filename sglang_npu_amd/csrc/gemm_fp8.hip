@@ -1785,7 +1785,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void fp8_gemm_tiled3_kernel(GemmAr
   load_b(bq, 0);
   wait_vmcnt<(NSTAGE - 2) * UA + 8>();  // stage 0 landed (this wave's part)
 #ifndef SGLM_T3_ABL
-#define SGLM_T3_ABL 0  // timing ablations (WRONG RESULTS): 1 no barrier, 2 A fragments read once, 3 no weight refills, 4 no DMA, 5 DMA always of k-step 0 (L2-resident)
+#define SGLM_T3_ABL 0  // timing ablations (WRONG RESULTS): 1 no barrier, 2 A fragments read once, 3 no weight refills, 4 no DMA, 5 DMA always of k-step 0 (L2-resident), 6 the flops as 32x32x64 MFMAs
 #endif
 #if SGLM_T3_ABL == 2
   Frag32 af[RI];
@@ -1794,6 +1794,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void fp8_gemm_tiled3_kernel(GemmAr
     af[i].v[0] = *reinterpret_cast<const uint4*>(smem + a_row + i * 2048 + c0);
     af[i].v[1] = *reinterpret_cast<const uint4*>(smem + a_row + i * 2048 + c1);
   }
+#endif
+#if SGLM_T3_ABL == 6
+  f32x16 acc32[4][2];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc32[m][n][r] = 0.f;
 #endif
 #pragma clang loop unroll(disable)
   for (int kt = 0; kt < nk; ++kt) {
@@ -1841,11 +1850,21 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void fp8_gemm_tiled3_kernel(GemmAr
 #else
       wait_frag<6 + UA>(bq[j]);
 #endif
+#if SGLM_T3_ABL == 6
+      // the step's flops as 32x32x64 MFMAs on the same operand registers (garbage products): does the other shape hold a
+      // higher clock in this loop?  16 per step (4 x 2 tiles of 32 x 32, two k halves): 4 per column phase here
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        acc32[m][j >> 1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+            __builtin_bit_cast(v8i32_t, af[2 * m + (j & 1)]), __builtin_bit_cast(v8i32_t, bq[j]), acc32[m][j >> 1], 0, 0, 0,
+            0x7F7F7F7F, 0, 0x7F7F7F7F);
+#else
 #pragma unroll
       for (int i = 0; i < RI; ++i)
         acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
             __builtin_bit_cast(v8i32_t, af[i]), __builtin_bit_cast(v8i32_t, bq[j]), acc[i][j], 0, 0, 0, 0x7F7F7F7F, 0,
             0x7F7F7F7F);
+#endif
 #if SGLM_T3_DMA_LATE
       if (j == 0) issue_dma();  // behind the first column's MFMAs: the matrix pipe is busy while the DMAs issue
 #endif
@@ -1858,6 +1877,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void fp8_gemm_tiled3_kernel(GemmAr
     }
   }
   drain_frags(bq);  // the never-consumed tail refills (and the tail DMAs)
+#if SGLM_T3_ABL == 6
+#pragma unroll
+  for (int i = 0; i < RI; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = acc32[i >> 1][j >> 1][(i & 1) * 8 + (j & 1) * 4 + r];
+#endif
   __syncthreads();  // all stages dead: the epilogue reuses the memory
   tiled_epilogue<OUT_DTYPE, RI>(p, smem, acc, m0, n0, wm, wn, wave, lane);
 }
