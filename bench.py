@@ -184,6 +184,7 @@ def time_attention_kernel(loop, steps):
     of it on the launching stream, over `steps` eager steps of the same loop."""
     from sglang_npu_amd import ops
     durations = []
+    time_attention_kernel.merged_launches = False
     real, real_fused, real_absmax = ops.decode_attention_paged, ops.decode_attention_qkv_partials, ops.decode_attention_paged_absmax
     real_merged = ops.decode_attention_paged_merged
     pairs = []
@@ -195,6 +196,7 @@ def time_attention_kernel(loop, steps):
         en.record()
         if done is not False:
             pairs.append((st, en))
+            time_attention_kernel.merged_launches = True
         return done
 
     def timed_absmax(*a, **kw):  # the same kernel with the row-absmax epilogue (model.py FUSE_ATTN_QUANT)
@@ -431,6 +433,8 @@ def other_configs():
             out.append({"config": name, "ms_per_step": d["ms_per_step"], "tokens_per_s": d["value"],
                         "ttft_ms_p50": d.get("ttft_ms_p50"), "decode_attention_frac_hbm": d["roofline"]["frac"],
                         "workload": d["config"]["workload"]})
+            if "launch_includes" in d["roofline"]:
+                out[-1]["decode_attention_launch_includes"] = d["roofline"]["launch_includes"]
         except Exception as e:  # a side measurement: never take the headline down with it
             out.append({"config": name, "error": f"{type(e).__name__}: {str(e)[:200]}"})
     return out
@@ -625,6 +629,9 @@ def main():
                      "avg_launch_us": round(attn_ms * 1e3, 2), "launches_timed": n_launch,
                      "algorithmic_bytes_per_launch": int(alg_bytes)},
     }
+    if time_attention_kernel.merged_launches:
+        out["roofline"]["launch_includes"] = ("kv-split merge + per-token FP8 quant of the output (one launch: "
+                                              "sgl_mi355_decode_attention_merged); the bytes are the KV bytes alone")
     if ar_info is not None:
         out["allreduce"] = ar_info
     try:
