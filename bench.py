@@ -657,6 +657,52 @@ def main():
         out["reference_cpu_container"] = reference_cpu_container()
     if others is not None:
         out["other_configs"] = others
+    # ---- BASELINE config 5 on the real thing: when this IS an 8-GPU job (or a rehearsal asks for it), the same loop on the
+    # Llama-3-70B shape with TP = world, after everything above (the headline numbers are final by now).  Every rank
+    # takes the same decisions (environment + collectives only), so a failure anywhere skips it everywhere.
+    want_70b = (dist_on and args.model == "llama3-8b" and args.quant == "w8a8_fp8" and args.layers is None
+                and os.environ.get("SGL_MI355_BENCH_NO_70B", "0") in ("", "0")
+                and (world == 8 or os.environ.get("SGL_MI355_BENCH_EXTRA_70B", "0") not in ("", "0")))
+    if want_70b:
+        import copy
+        res = {"workload": f"llama3-70b w8a8_fp8 decode bs={args.batch} ctx={args.ctx} TP={tp}, random weights, the same loop"}
+        ok = 1.0
+        try:
+            del loop
+            net = runner = backend = None
+            torch.cuda.empty_cache()
+            a70 = copy.copy(args)
+            a70.model = "llama3-70b"
+            net, cfg70, runner, backend, _ = build(a70, device, tp)
+            loop = DecodeLoop(net, runner, backend, args.batch, args.ctx, device)
+            can_fuse = net.fuse_quant
+        except Exception as e:  # e.g. out of memory on one rank
+            ok = 0.0
+            res["error"] = f"{type(e).__name__}: {str(e)[:200]}"
+        t = torch.tensor([ok], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN)
+        if float(t.item()) == 1.0:
+            try:
+                n70 = min(args.steps, 16)
+                set_call_order(can_fuse)
+                ms70 = timed(3, n70) / n70 * 1e3
+                tp_group.stub_all_reduce = True
+                set_call_order(can_fuse)
+                stub70 = timed(2, min(n70, 6)) / min(n70, 6) * 1e3
+                tp_group.stub_all_reduce = False
+                res.update({"ms_per_step": round(ms70, 4), "tokens_per_s": round(args.batch / ms70 * 1e3, 1),
+                            "ms_per_step_allreduce_stubbed": round(stub70, 4),
+                            "allreduce_overhead_frac": round(max(0.0, (ms70 - stub70) / ms70), 4),
+                            "layers": len(net.layers), "collectives_per_step": 2 * len(net.layers) + 1,
+                            "message_bytes": args.batch * cfg70.hidden_size * 2,
+                            "graph": loop.graph is not None})
+            except Exception as e:
+                res["error"] = f"{type(e).__name__}: {str(e)[:200]}"
+            finally:
+                tp_group.stub_all_reduce = False
+        elif "error" not in res:
+            res["error"] = "another rank could not build the model"
+        out["config5_llama3_70b"] = res
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist_on:
