@@ -181,55 +181,34 @@ class DecodeLoop:
 
 def time_attention_kernel(loop, steps):
     """Average duration of the dominant kernel (paged decode attention), HIP events around each launch
-    of it on the launching stream, over `steps` eager steps of the same loop."""
+    of it on the launching stream, over `steps` eager steps of the same loop.  Every `ops.decode_attention*` entry is
+    wrapped: the plain launch, and the forms with extra work INSIDE the same launch (qkv epilogue + RoPE + KV write in the
+    prologue; row-absmax epilogue; kv-split merge + FP8 quant) -- that work is then part of the timed launch while the
+    algorithmic bytes stay the KV bytes alone (the fraction is, if anything, understated).  A form that declines a shape
+    (returns False / None without launching) is not counted."""
     from sglang_npu_amd import ops
-    durations = []
     time_attention_kernel.merged_launches = False
-    real, real_fused, real_absmax = ops.decode_attention_paged, ops.decode_attention_qkv_partials, ops.decode_attention_paged_absmax
-    real_merged = ops.decode_attention_paged_merged
+    names = [n for n in dir(ops) if n.startswith("decode_attention") and callable(getattr(ops, n))]
+    declines = {"decode_attention_qkv_partials": (False, None), "decode_attention_paged_absmax": (False, None),
+                "decode_attention_paged_merged": (False,)}
+    real = {n: getattr(ops, n) for n in names}
     pairs = []
 
-    def timed_merged(*a, **kw):  # the split kernel with the merge (+ quant) in the same launch: all of it is timed
-        st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        st.record()
-        done = real_merged(*a, **kw)
-        en.record()
-        if done is not False:
-            pairs.append((st, en))
-            time_attention_kernel.merged_launches = True
-        return done
+    def wrap(name, fn):
+        def timed(*a, **kw):
+            st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            st.record()
+            done = fn(*a, **kw)
+            en.record()
+            if not any(done is d for d in declines.get(name, ())):
+                pairs.append((st, en))
+                if name == "decode_attention_paged_merged":
+                    time_attention_kernel.merged_launches = True
+            return done
+        return timed
 
-    def timed_absmax(*a, **kw):  # the same kernel with the row-absmax epilogue (model.py FUSE_ATTN_QUANT)
-        st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        st.record()
-        done = real_absmax(*a, **kw)
-        en.record()
-        if done:
-            pairs.append((st, en))
-        return done
-
-    def timed(*a, **kw):
-        st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        st.record()
-        real(*a, **kw)
-        en.record()
-        pairs.append((st, en))
-
-    def timed_fused(*a, **kw):
-        # the same kernel with the qkv epilogue + RoPE + KV write in its prologue: that extra work is inside the timed
-        # launch, while the algorithmic bytes stay the KV bytes alone (the fraction is, if anything, understated)
-        st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        st.record()
-        done = real_fused(*a, **kw)
-        en.record()
-        if done:
-            pairs.append((st, en))
-        return done
-
-    ops.decode_attention_paged = timed
-    ops.decode_attention_qkv_partials = timed_fused
-    ops.decode_attention_paged_absmax = timed_absmax
-    ops.decode_attention_paged_merged = timed_merged
+    for n in names:
+        setattr(ops, n, wrap(n, real[n]))
     g = loop.graph
     loop.graph = None
     try:
@@ -237,13 +216,12 @@ def time_attention_kernel(loop, steps):
             loop.step()
         torch.cuda.synchronize()
     finally:
-        ops.decode_attention_paged = real
-        ops.decode_attention_qkv_partials = real_fused
-        ops.decode_attention_paged_absmax = real_absmax
-        ops.decode_attention_paged_merged = real_merged
+        for n in names:
+            setattr(ops, n, real[n])
         loop.graph = g
-    durations = [s.elapsed_time(e) for s, e in pairs]
-    durations.sort()
+    if not pairs:
+        raise RuntimeError("time_attention_kernel: no decode attention launch went through sglang_npu_amd.ops.decode_attention*")
+    durations = sorted(s.elapsed_time(e) for s, e in pairs)
     # drop the slowest 5 % (first-touch / clock ramp) but keep the mean honest otherwise
     keep = durations[: max(1, int(len(durations) * 0.95))]
     return sum(keep) / len(keep), len(durations)
