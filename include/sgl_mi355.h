@@ -34,7 +34,7 @@ extern "C" {
 #define SGL_MI355_ERR_RUNTIME 3          /* a HIP runtime call failed                */
 
 /* ABI version of this header; bumped on any signature change. */
-#define SGL_MI355_ABI_VERSION 8
+#define SGL_MI355_ABI_VERSION 9
 int sgl_mi355_abi_version(void);
 
 /* Copies the calling thread's last error message (NUL-terminated) into buf. Returns its length. */
@@ -608,6 +608,14 @@ int sgl_mi355_ar_quick_all_reduce(void* comm, const void* inp, void* out, int64_
 int sgl_mi355_ar_fused_add_rmsnorm(void* comm, const void* inp, void* residual, const void* weight, void* out,
                                    void* out_q, float* out_s, int64_t num_tokens, int64_t hidden, float eps, int dtype,
                                    void* stream);
+/* The same with this rank's addend still a split-K GEMM (sgl_mi355_fp8_scaled_mm_partials of the row-parallel layer,
+ * RowParallelLinear linear.py:1285-1303): the epilogue (slice sum in order, x w_scale, x x_scale, + bias on rank 0, ONE
+ * rounding to the 16-bit dtype) runs while the row is staged -- bit-identical to sgl_mi355_fp8_scaled_mm_finalize followed
+ * by sgl_mi355_ar_fused_add_rmsnorm.  partials fp32 [num_slices][num_tokens][hidden], 16-byte aligned. */
+int sgl_mi355_ar_fused_add_rmsnorm_partials(void* comm, const float* partials, int64_t num_slices, const float* scales_a,
+                                            const float* scales_b, const void* bias, void* residual, const void* weight,
+                                            void* out, void* out_q, float* out_s, int64_t num_tokens, int64_t hidden, float eps,
+                                            int dtype, void* stream);
 int sgl_mi355_ar_timed_out(void* comm, int* flag_out);
 int sgl_mi355_ar_destroy(void* comm);
 

@@ -23,6 +23,7 @@
 #include <string.h>
 
 #include "common.h"
+#include "partials.h"
 
 namespace sglm {
 namespace {
@@ -372,11 +373,13 @@ __device__ __forceinline__ float ar_block_max(float v, float* red) {
 // kNormThreads threads x kNormVPT 8-element vectors per row: the launcher picks the SAME pair as launch_rmsnorm
 // (elementwise.hip) would for the shape, so that the sum of squares is reduced in the same order and the result is
 // bit-identical to the unfused norm.
-template <int DTYPE, int kNormVPT, int kNormThreads>
+// PARTIALS: the rank's addend is a split-K GEMM in flight (PartialSrc); a separate instantiation so that the plain form
+// keeps its register footprint (the 8-ranks-on-one-GPU protocol test needs all 8 x 64 workgroups resident at once).
+template <int DTYPE, int kNormVPT, int kNormThreads, bool PARTIALS>
 __global__ __launch_bounds__(kNormThreads) void ar_add_rmsnorm_kernel(
     ArArgs a, const typename Half16<DTYPE>::T* inp /* may alias out */, typename Half16<DTYPE>::T* __restrict__ residual,
     const typename Half16<DTYPE>::T* __restrict__ weight, typename Half16<DTYPE>::T* out,
-    uint8_t* __restrict__ out_q, float* __restrict__ out_s, int T, int H, float eps, int one_shot) {
+    uint8_t* __restrict__ out_q, float* __restrict__ out_s, int T, int H, float eps, int one_shot, PartialSrc ps) {
   using Hh = Half16<DTYPE>;
   using x8 = typename Hh::x8;
   __shared__ float red[kNormThreads / 64];
@@ -402,10 +405,14 @@ __global__ __launch_bounds__(kNormThreads) void ar_add_rmsnorm_kernel(
 
   bool ok = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0;
   if (ok) {
-    // phase A
+    // phase A (ps.partials: my rows are still a split-K GEMM -- its epilogue runs here, rounded to the 16-bit dtype exactly as
+    // fp8_gemm_finalize_kernel would have, so the sum over ranks sees the same addends)
     for (int row = blockIdx.x; row < T; row += gridDim.x)
       for (int vi = tid; vi < nv; vi += kNormThreads)
-        reinterpret_cast<uint4*>(my_data + (int64_t)row * H * 2)[vi] = reinterpret_cast<const uint4*>(inp + (int64_t)row * H)[vi];
+        if constexpr (PARTIALS)
+          reinterpret_cast<uint4*>(my_data + (int64_t)row * H * 2)[vi] = __builtin_bit_cast(uint4, gemm_row8<DTYPE>(ps, row, 8 * vi));
+        else
+          reinterpret_cast<uint4*>(my_data + (int64_t)row * H * 2)[vi] = reinterpret_cast<const uint4*>(inp + (int64_t)row * H)[vi];
     ok = block_barrier(a, 0, call);
   }
   if (!ok) {
@@ -667,9 +674,9 @@ extern "C" int sgl_mi355_ar_quick_all_reduce(void* comm, const void* inp, void* 
   return 0;
 }
 
-extern "C" int sgl_mi355_ar_fused_add_rmsnorm(void* comm, const void* inp, void* residual, const void* weight, void* out,
-                                              void* out_q, float* out_s, int64_t num_tokens, int64_t hidden, float eps,
-                                              int dtype, void* stream) {
+static int ar_fused_add_rmsnorm_impl(void* comm, const void* inp, const PartialSrc& ps, void* residual, const void* weight,
+                                     void* out, void* out_q, float* out_s, int64_t num_tokens, int64_t hidden, float eps,
+                                     int dtype, void* stream) {
   SGLM_CHECK_ARG(comm, "ar_fused_add_rmsnorm: null communicator");
   ArComm* c = (ArComm*)comm;
   SGLM_CHECK_ARG(dtype == SGL_MI355_BF16 || dtype == SGL_MI355_FP16, "ar_fused_add_rmsnorm: dtype must be bfloat16 or float16");
@@ -680,7 +687,7 @@ extern "C" int sgl_mi355_ar_fused_add_rmsnorm(void* comm, const void* inp, void*
   SGLM_CHECK_ARG((size_t)nbytes <= c->max_bytes, "ar_fused_add_rmsnorm: %ld B exceeds the registered capacity %ld B", (long)nbytes,
                  (long)c->max_bytes);
   if (num_tokens == 0) return 0;
-  SGLM_CHECK_ARG(inp && residual && weight && (out || out_q), "ar_fused_add_rmsnorm: null tensor pointer");
+  SGLM_CHECK_ARG((inp || ps.partials) && residual && weight && (out || out_q), "ar_fused_add_rmsnorm: null tensor pointer");
   SGLM_CHECK_ARG(!out_q || out_s, "ar_fused_add_rmsnorm: out_q needs out_s");
   for (int r = 0; r < c->world; ++r) SGLM_CHECK_ARG(c->peer[r] != nullptr, "ar_fused_add_rmsnorm: peer %d not opened", r);
   ArArgs a{};
@@ -695,9 +702,16 @@ extern "C" int sgl_mi355_ar_fused_add_rmsnorm(void* comm, const void* inp, void*
   const bool wide = num_tokens <= 2048 && nv >= 512 && nv <= 2048;
   const int vpt256 = (nv + 255) / 256;
 #define ARN(D, V, NT_)                                                                                                    \
-  hipLaunchKernelGGL((ar_add_rmsnorm_kernel<D, V, NT_>), dim3(blocks), dim3(NT_), 0, s, a, (const Half16<D>::T*)inp,     \
-                     (Half16<D>::T*)residual, (const Half16<D>::T*)weight, (Half16<D>::T*)out, (uint8_t*)out_q, out_s, \
-                     (int)num_tokens, (int)hidden, eps, one_shot)
+  do {                                                                                                                    \
+    if (ps.partials != nullptr)                                                                                           \
+      hipLaunchKernelGGL((ar_add_rmsnorm_kernel<D, V, NT_, true>), dim3(blocks), dim3(NT_), 0, s, a, (const Half16<D>::T*)inp, \
+                         (Half16<D>::T*)residual, (const Half16<D>::T*)weight, (Half16<D>::T*)out, (uint8_t*)out_q, out_s, \
+                         (int)num_tokens, (int)hidden, eps, one_shot, ps);                                               \
+    else                                                                                                                  \
+      hipLaunchKernelGGL((ar_add_rmsnorm_kernel<D, V, NT_, false>), dim3(blocks), dim3(NT_), 0, s, a, (const Half16<D>::T*)inp, \
+                         (Half16<D>::T*)residual, (const Half16<D>::T*)weight, (Half16<D>::T*)out, (uint8_t*)out_q, out_s, \
+                         (int)num_tokens, (int)hidden, eps, one_shot, ps);                                               \
+  } while (0)
 #define ARN_D(D)                                   \
   do {                                             \
     if (wide) {                                    \
@@ -714,6 +728,30 @@ extern "C" int sgl_mi355_ar_fused_add_rmsnorm(void* comm, const void* inp, void*
 #undef ARN_D
 #undef ARN
   return check_hip(hipGetLastError(), "ar_add_rmsnorm_kernel launch");
+}
+
+extern "C" int sgl_mi355_ar_fused_add_rmsnorm(void* comm, const void* inp, void* residual, const void* weight, void* out,
+                                              void* out_q, float* out_s, int64_t num_tokens, int64_t hidden, float eps,
+                                              int dtype, void* stream) {
+  SGLM_CHECK_ARG(inp != nullptr || num_tokens == 0, "ar_fused_add_rmsnorm: null input");
+  return ar_fused_add_rmsnorm_impl(comm, inp, PartialSrc{}, residual, weight, out, out_q, out_s, num_tokens, hidden, eps, dtype,
+                                   stream);
+}
+
+// The same with this rank's addend still a split-K GEMM (sgl_mi355_fp8_scaled_mm_partials of the row-parallel layer): the
+// GEMM epilogue -- slices summed in order, x w_scale, x x_scale, + bias (rank 0 only, as RowParallelLinear), one rounding to
+// the 16-bit dtype -- runs while the row is staged into the IPC buffer.  Bit-identical to sgl_mi355_fp8_scaled_mm_finalize
+// followed by sgl_mi355_ar_fused_add_rmsnorm; one launch less per row-parallel layer.
+extern "C" int sgl_mi355_ar_fused_add_rmsnorm_partials(void* comm, const float* partials, int64_t num_slices,
+                                                       const float* scales_a, const float* scales_b, const void* bias,
+                                                       void* residual, const void* weight, void* out, void* out_q,
+                                                       float* out_s, int64_t num_tokens, int64_t hidden, float eps, int dtype,
+                                                       void* stream) {
+  SGLM_CHECK_ARG(partials && scales_a && scales_b && num_slices >= 1, "ar_fused_add_rmsnorm_partials: null partials / scales");
+  SGLM_CHECK_ARG(reinterpret_cast<uintptr_t>(partials) % 16 == 0 && reinterpret_cast<uintptr_t>(scales_b) % 16 == 0,
+                 "ar_fused_add_rmsnorm_partials: partials and scales_b must be 16-byte aligned");
+  const PartialSrc ps{partials, (int)num_slices, num_tokens * hidden, scales_a, scales_b, bias, (int)hidden};
+  return ar_fused_add_rmsnorm_impl(comm, nullptr, ps, residual, weight, out, out_q, out_s, num_tokens, hidden, eps, dtype, stream);
 }
 
 extern "C" int sgl_mi355_ar_timed_out(void* comm, int* flag_out) {

@@ -122,6 +122,38 @@ class CustomAllreduce:
         return inp.dtype in (torch.bfloat16, torch.float16) and H % (8 * self.world_size) == 0 and H <= 16384 and \
             0 < inp.numel() * 2 <= self.max_size
 
+    def should_fuse_norm_shape(self, T: int, H: int, dtype: torch.dtype) -> bool:
+        """should_fuse_norm for a [T, H] addend that does not exist as a tensor yet (split-K partials)."""
+        return (not self.disabled) and dtype in (torch.bfloat16, torch.float16) and H % (8 * self.world_size) == 0 and \
+            H <= 16384 and 0 < T * H * 2 <= self.max_size
+
+    def fused_add_rmsnorm_partials(self, part, residual: torch.Tensor, weight: torch.Tensor, eps: float,
+                                   quant_fp8: bool = False):
+        """fused_add_rmsnorm whose addend is still an ops.GemmPartials (the row-parallel GEMM's split-K sums): its epilogue
+        runs while the row is staged (sgl_mi355_ar_fused_add_rmsnorm_partials).  Bit-identical to part.finalize() followed
+        by fused_add_rmsnorm; the finalize launch is gone."""
+        from . import _lib
+        if self.timed_out():
+            self.disabled = True
+            raise RuntimeError("custom all-reduce: a peer did not reach the barrier in time; the affected outputs were "
+                               "filled with NaN and this communicator is disabled")
+        T, H = part.M, part.N
+        ct = self._ct
+        dev = residual.device
+        out = q = s = None
+        if quant_fp8:
+            q = torch.empty((T, H), dtype=torch.float8_e4m3fn, device=dev)
+            s = torch.empty((T, 1), dtype=torch.float32, device=dev)
+        else:
+            out = torch.empty((T, H), dtype=part.out_dtype, device=dev)
+        ptr = lambda t: ct.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+        _lib.check(self._lib.sgl_mi355_ar_fused_add_rmsnorm_partials(
+            self._comm, ptr(part.ws), ct.c_int64(part.num_slices), ptr(part.x_scale), ptr(part.w_scale), ptr(part.bias),
+            ptr(residual), ptr(weight), ptr(out), ptr(q), ptr(s), ct.c_int64(T), ct.c_int64(H), ct.c_float(eps),
+            ct.c_int(0 if part.out_dtype == torch.bfloat16 else 1),
+            ct.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        return (q, s) if quant_fp8 else out
+
     def fused_add_rmsnorm(self, inp: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float,
                           quant_fp8: bool = False):
         """all_reduce(inp) + residual -> residual (in place); RMSNorm of the sum -> a new tensor, or with quant_fp8 its

@@ -173,12 +173,31 @@ class RowParallelLinear(LinearBase):
         out = self.quant_method.apply(self, x, bias_)
         return self._reduce(out, async_reduce, can_fuse_mlp_allreduce), None
 
-    def forward_prequantized_partials(self, qinput, x_scale, out_dtype):
-        """Split-K partials for a fused consumer; only without tensor parallelism (the all-reduce needs the
-        completed output)."""
+    def forward_prequantized_partials(self, qinput, x_scale, out_dtype, can_fuse_mlp_allreduce: bool = False):
+        """Split-K partials for a fused consumer.  Under tensor parallelism the all-reduce needs the completed output --
+        unless the next norm runs it as all-reduce + add + RMSNorm in one kernel (can_fuse_mlp_allreduce and the P2P
+        communicator takes the shape): that kernel runs the GEMM epilogue itself while it stages this rank's rows
+        (CustomAllreduce.fused_add_rmsnorm_partials), and the partials travel tagged `needs_allreduce`."""
         fn = getattr(self.quant_method, "apply_prequantized_partials", None)
-        if fn is None or get_tensor_model_parallel_world_size() > 1:
+        if fn is None:
             return None
+        if get_tensor_model_parallel_world_size() > 1:
+            tp = get_tp_group()
+            ca = tp.ca_comm
+            if not (can_fuse_mlp_allreduce and self.reduce_results and not tp.stub_all_reduce and ca is not None
+                    and qinput.dim() == 2
+                    and ca.should_fuse_norm_shape(qinput.shape[0], self.output_size, out_dtype)):
+                return None
+            # only where the GEMM would run split-K + finalize anyway (gemm_fp8.hip run_gemm: from 20 Mi weights at more
+            # than 32 rows, 40 Mi below): elsewhere the single-pass kernels are faster than forcing the split-K form
+            # (Llama-3-8B TP = 2 o_proj, 2048 x 4096: 7.6 us single pass, 11.1 us split-K + finalize)
+            rows = qinput.shape[0]
+            if self.output_size * self.input_size_per_partition < ((20 if rows > 32 else 40) << 20):
+                return None
+            part = fn(self, qinput, x_scale, out_dtype, None if get_tensor_model_parallel_rank() > 0 else self.bias)
+            if part is not None:
+                part.needs_allreduce = True
+            return part
         return fn(self, qinput, x_scale, out_dtype, self.bias)
 
     def forward_a16_partials(self, x16, row_absmax, out_dtype):

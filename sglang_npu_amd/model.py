@@ -112,7 +112,7 @@ class LlamaMLP(torch.nn.Module):
             gate_up, _ = self.gate_up_proj.forward_prequantized(xq, xs, out_dtype)
             aq, a_s = ops.silu_and_mul_quant_fp8(gate_up)
         if defer:  # leave the down_proj epilogue to the next norm (ops.GemmPartials)
-            part = self.down_proj.forward_prequantized_partials(aq, a_s, out_dtype)
+            part = self.down_proj.forward_prequantized_partials(aq, a_s, out_dtype, can_fuse_mlp_allreduce=FUSE_AR_NORM)
             if part is not None:
                 return part
         x, _ = self.down_proj.forward_prequantized(aq, a_s, out_dtype, async_reduce=ASYNC_AR,
@@ -201,7 +201,7 @@ class LlamaAttention(torch.nn.Module):
             output, _ = self.o_proj(attn_output, async_reduce=ASYNC_AR, can_fuse_mlp_allreduce=FUSE_AR_NORM)
             return output
         if defer:  # leave the o_proj epilogue to post_attention_layernorm
-            part = self.o_proj.forward_prequantized_partials(aq, a_s, out_dtype)
+            part = self.o_proj.forward_prequantized_partials(aq, a_s, out_dtype, can_fuse_mlp_allreduce=FUSE_AR_NORM)
             if part is not None:
                 return part
         output, _ = self.o_proj.forward_prequantized(aq, a_s, out_dtype, async_reduce=ASYNC_AR,
@@ -241,6 +241,8 @@ class LlamaDecoderLayer(torch.nn.Module):
         def norm_quant(norm, h, res):
             h = _arrived(h)  # a row-parallel GEMM's all-reduce still running on the side stream
             if _unreduced(h) and res is not None:  # all-reduce + add + norm + quant in one kernel
+                return norm.forward_with_allreduce_fusion(h, res, quant_fp8=True)[0]
+            if isinstance(h, ops.GemmPartials) and h.needs_allreduce:  # ... and the collective: one kernel does it all
                 return norm.forward_with_allreduce_fusion(h, res, quant_fp8=True)[0]
             if isinstance(h, ops.GemmPartials):  # the producer GEMM left its epilogue to this kernel
                 return ops.rmsnorm_quant_fp8_from_partials(h, res, norm.weight.data, norm.variance_epsilon)
@@ -351,15 +353,26 @@ class LlamaForCausalLM(torch.nn.Module):
             else:
                 hidden_states, residual = layer(positions, hidden_states, forward_batch, residual)
         hidden_states = _arrived(hidden_states)
+        normed = False
         if isinstance(hidden_states, ops.GemmPartials):
-            hidden_states = hidden_states.finalize()
+            if hidden_states.needs_allreduce and residual is not None:
+                # the last down_proj left its epilogue AND its all-reduce to the final norm (decode only: no row selection)
+                hidden_states, _ = self.norm.forward_with_allreduce_fusion(hidden_states, residual)
+                normed = True
+            else:
+                tagged = hidden_states.needs_allreduce
+                hidden_states = hidden_states.finalize()
+                if tagged:
+                    hidden_states._sglang_needs_allreduce_fusion = True
         pending_ar = _unreduced(hidden_states)  # the last layer's down_proj left its all-reduce to the final norm
         if forward_batch.forward_mode.is_extend() and forward_batch.extend_seq_lens is not None:
             # LogitsProcessor (logits_processor.py:430-470): prefill only needs the last position of every request
             last = torch.cumsum(forward_batch.extend_seq_lens, dim=0) - 1
             hidden_states = hidden_states[last]  # (a new tensor: the tag does not travel with it)
             residual = residual[last] if residual is not None else None
-        if pending_ar:
+        if normed:
+            pass
+        elif pending_ar:
             if residual is not None and residual.is_contiguous() and hidden_states.is_contiguous():
                 hidden_states, _ = self.norm.forward_with_allreduce_fusion(hidden_states, residual)
             else:

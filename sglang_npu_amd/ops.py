@@ -637,11 +637,14 @@ class GemmPartials:
     """An fp8_scaled_mm whose epilogue has not run yet: raw fp32 split-K partial sums in the shared workspace
     (sgl_mi355_fp8_scaled_mm_partials).  Must be consumed -- finalize() or one of the *_from_partials ops -- before the
     next decode GEMM on this device AND stream, which reuses the workspace (other streams have their own)."""
-    __slots__ = ("ws", "num_slices", "x_scale", "w_scale", "bias", "M", "N", "out_dtype")
+    __slots__ = ("ws", "num_slices", "x_scale", "w_scale", "bias", "M", "N", "out_dtype", "needs_allreduce")
 
     def __init__(self, ws, num_slices, x_scale, w_scale, bias, M, N, out_dtype):
         self.ws, self.num_slices, self.x_scale, self.w_scale, self.bias = ws, num_slices, x_scale, w_scale, bias
         self.M, self.N, self.out_dtype = M, N, out_dtype
+        # a row-parallel layer's addend under tensor parallelism: the consumer must all-reduce it (the fused all-reduce +
+        # add + RMSNorm kernel takes it as it is; the counterpart of upstream's _sglang_needs_allreduce_fusion tag)
+        self.needs_allreduce = False
 
     def finalize(self) -> torch.Tensor:
         out = torch.empty((self.M, self.N), dtype=self.out_dtype, device=self.ws.device)

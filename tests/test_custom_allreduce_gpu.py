@@ -179,6 +179,46 @@ def _local_ranks_worker(world, q):
                             assert torch.equal(outs[r][1], s_ref) and torch.equal(outs[r][0].view(torch.uint8), q_ref.view(torch.uint8))
                         else:
                             assert torch.equal(outs[r], x_ref), ("norm", dt, T, H, r)
+        # the same with every rank's addend still a split-K GEMM (ops.GemmPartials): the fused kernel runs the GEMM epilogue
+        # while it stages the row -- bit-identical to finalize() + fused_add_rmsnorm; bias on rank 0 only (RowParallelLinear)
+        # (rows kept at <= 32: all ranks' workgroups -- one per row, 1024 threads, 89 VGPRs in this form -- must be resident
+        #  on the ONE GPU of this box at the same time for their flag barriers to meet)
+        for dt, cases in ((torch.bfloat16, [(32, 8192, 8), (7, 2048, 1), (16, 1024, 11), (16, 3072, 4)]),
+                          (torch.float16, [(24, 4096, 5)])):
+            for (T, H, SK) in cases:
+                if H % (8 * world):
+                    continue
+                g = torch.Generator().manual_seed(T + H + SK + world)
+                gps = []
+                for r in range(world):
+                    ws = torch.randn(SK, T, H, generator=g).to(dev)
+                    xs = (torch.rand(T, 1, generator=g) * 0.1 + 0.01).to(dev)
+                    wsc = (torch.rand(H, generator=g) * 0.1 + 0.01).to(dev)
+                    bias = (torch.randn(H, generator=g)).to(dt).to(dev) if r == 0 else None
+                    gps.append(ops.GemmPartials(ws, SK, xs, wsc, bias, T, H, dt))
+                res0 = torch.randn(T, H, generator=g).to(dt).to(dev)
+                w = (torch.rand(H, generator=g) + 0.5).to(dt).to(dev)
+                fins = [gp.finalize() for gp in gps]
+                for quant in (False, True):
+                    torch.cuda.synchronize()
+                    refs, ress_ref = [], [res0.clone() for _ in range(world)]
+                    for r in range(world):
+                        with torch.cuda.stream(streams[r]):
+                            refs.append(comms[r].fused_add_rmsnorm(fins[r], ress_ref[r], w, 1e-5, quant_fp8=quant))
+                    torch.cuda.synchronize()
+                    outs, ress = [], [res0.clone() for _ in range(world)]
+                    for r in range(world):
+                        assert comms[r].should_fuse_norm_shape(T, H, dt)
+                        with torch.cuda.stream(streams[r]):
+                            outs.append(comms[r].fused_add_rmsnorm_partials(gps[r], ress[r], w, 1e-5, quant_fp8=quant))
+                    torch.cuda.synchronize()
+                    for r in range(world):
+                        assert torch.equal(ress[r], ress_ref[r]), ("partials residual", dt, T, H, SK, quant, r)
+                        if quant:
+                            assert torch.equal(outs[r][1], refs[r][1]) and \
+                                torch.equal(outs[r][0].view(torch.uint8), refs[r][0].view(torch.uint8)), ("partials quant", dt, T, H, SK, r)
+                        else:
+                            assert torch.equal(outs[r], refs[r]), ("partials norm", dt, T, H, SK, r)
         assert not any(c.timed_out() for c in comms)
         for c in comms:
             c.close()
@@ -189,13 +229,13 @@ def _local_ranks_worker(world, q):
 
 
 @pytest.mark.parametrize("world", [2, 6, 8])
-@pytest.mark.timeout(300)
+@pytest.mark.timeout(600)
 def test_p2p_all_reduce_six_and_eight_ranks_in_one_process(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     p = ctx.Process(target=_local_ranks_worker, args=(world, q))
     p.start()
-    msg = q.get(timeout=240)
+    msg = q.get(timeout=540)
     p.join(30)
     assert msg == "ok", msg
 

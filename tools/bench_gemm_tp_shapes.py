@@ -6,7 +6,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sglang_npu_amd import ops
 dev = "cuda:0"
-ops.reserve_gemm_workspace(dev, 64, 2 * 28672)  # the split-K scratch may not grow under graph capture
+ops.reserve_gemm_workspace(dev, 64, 4 * 28672)  # the split-K scratch may not grow under graph capture
 g = torch.Generator(device=dev).manual_seed(0)
 M = int(os.environ.get("M", "64"))
 H, I, Hq, Hkv, D = 4096, 14336, 32, 8, 128
@@ -33,11 +33,15 @@ for tp in [int(x) for x in os.environ.get("TP_LIST", "1,2,4,8").split(",")]:
                 return part.finalize() if part is not None else ops.fp8_scaled_mm(a, wt[i % nw], sa, sb, torch.bfloat16)
         else:
             run = lambda i: ops.fp8_scaled_mm(a, wt[i % nw], sa, sb, torch.bfloat16)
-        for i in range(3): run(i)
+        cs = torch.cuda.Stream(device=dev)  # warm up ON the capture stream: the split-K scratch is per stream
+        cs.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cs):
+            for i in range(3): run(i)
+        torch.cuda.current_stream().wait_stream(cs)
         torch.cuda.synchronize()
         gr = torch.cuda.CUDAGraph()
         reps = 2 * nw
-        with torch.cuda.graph(gr):
+        with torch.cuda.graph(gr, stream=cs):
             for i in range(reps): out = run(i)
         gr.replay(); torch.cuda.synchronize()
         st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
