@@ -1776,8 +1776,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void fp8_gemm_tiled3_kernel(GemmAr
   // its fragment registers are refilled with the NEXT step's bytes, which have a whole step to arrive.
   // VMEM issue order per step: A DMAs of step kt + 2 (UA per wave), then refills R0..R3 (two loads each).  Loads retire in
   // order, so in front of column j "R_j of the previous step has landed" is vmcnt(6 + UA): R_j+1.. of the previous step,
-  // this step's DMAs, this step's R_0..j-1.  The same wait, at column 3, also proves this wave's DMAs of step kt + 1 (older
-  // than the previous step's R_3), which is what the next barrier publishes.  Tail steps re-issue the last step's DMAs into
+  // this step's DMAs, this step's R_0..j-1 (vmcnt(6) in front of column 0 when the DMAs are issued behind it,
+  // SGLM_T3_DMA_LATE -- a stricter count is never wrong).  The same wait, at column 3, also proves this wave's DMAs of
+  // step kt + 1 (older than the previous step's R_3), which is what the next barrier publishes.  Tail steps re-issue the last step's DMAs into
   // the dead stage and re-read the last weights, so the counts never change.
   Frag32 bq[4];
 #pragma unroll
@@ -1810,7 +1811,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void fp8_gemm_tiled3_kernel(GemmAr
     __syncthreads();  // everyone's DMAs of stage kt landed; everyone finished reading the stage refilled below
 #endif
 #ifndef SGLM_T3_DMA_LATE
-#define SGLM_T3_DMA_LATE 1  // the step's A DMAs issue behind the first column's MFMAs (1-2 % over issuing them at the barrier)
+#define SGLM_T3_DMA_LATE 1  // the step's A DMAs are written behind the first column: hipcc emits them after the step's fragment reads and the
+                            // first weight wait, still in front of that column's MFMAs (1-2 % over issuing them right at the barrier)
 #endif
     auto issue_dma = [&]() __attribute__((always_inline)) {
 #if SGLM_T3_ABL != 4
@@ -1866,7 +1868,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void fp8_gemm_tiled3_kernel(GemmAr
             0x7F7F7F7F);
 #endif
 #if SGLM_T3_DMA_LATE
-      if (j == 0) issue_dma();  // behind the first column's MFMAs: the matrix pipe is busy while the DMAs issue
+      if (j == 0) issue_dma();  // (see SGLM_T3_DMA_LATE for where hipcc puts them)
 #endif
 #if SGLM_T3_ABL != 3
       asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(bq[j].x[0]) : "v"(voff), "s"(b_blk[j]) : "memory");
