@@ -87,9 +87,12 @@ struct DecodeArgs {
   // that are stored (atomic max; the caller zeroes it) -- the per-token scale of the w8a8 o_proj input without a pass
   // over the output (sgl_mi355_decode_attention_absmax)
   float* row_absmax;
-  int kv8;  // 1 / 2: the pool is e4m3fn / e5m2 bytes (strides in elements = bytes); K is upcast, P is rounded to that format before PV  // non-null (split kernel with fp32 partials only): merge_counters[b] counts the workgroups of request b that have
+  int kv8;  // 1 / 2: the pool is e4m3fn / e5m2 bytes (strides in elements = bytes); K is upcast, P is rounded to that format before PV
+  // non-null (split kernel with fp32 partials only): merge_counters[b] counts the workgroups of request b that have
   // published their partial; the one that arrives last merges the request's kv-splits (and, if mq_out_q is given,
-  // quantises the row per token) in the same launch, then zeroes the counter again.  Caller: zero once.
+  // quantises the row per token) in the same launch, then zeroes the counter again.  Caller: zero once; the buffer
+  // belongs to ONE stream and ONE geometry at a time (a launch that found a counter non-zero -- another stream's launch in
+  // flight, or an earlier launch with another target -- would never complete the count and leave `out` unwritten).
   int32_t* merge_counters;
   uint8_t* mq_out_q;  // optional e4m3 [B][Hq * Dv] ...
   float* mq_out_s;    // ... with its scale [B]

@@ -133,6 +133,19 @@ __device__ __forceinline__ f16x8 dequant8(uint32_t w, f16x2 zb2, f16x2 sc2) {
   return r;
 }
 
+// Timing ablations (variant builds only, WRONG results): -DSGLM_AWQ_ABL_NODEQ=1 feeds the raw nibble words to the MFMA (no
+// dequant VALU work), -DSGLM_AWQ_ABL_NOMFMA=1 drops the A-fragment LDS reads and the MFMAs, -DSGLM_AWQ_ABL_NODMA=1 drops the
+// producer's activation DMA (the barriers stay).
+#ifndef SGLM_AWQ_ABL_NODEQ
+#define SGLM_AWQ_ABL_NODEQ 0
+#endif
+#ifndef SGLM_AWQ_ABL_NOMFMA
+#define SGLM_AWQ_ABL_NOMFMA 0
+#endif
+#ifndef SGLM_AWQ_ABL_NODMA
+#define SGLM_AWQ_ABL_NODMA 0
+#endif
+
 template <int MB, int PH, bool SLAB>
 __global__ __launch_bounds__(576) void awq_wstream_kernel(AwqPArgs p, float* slabs, int phases_per_slice) {
   static_assert(PH * MB <= 16, "one fp16 A buffer is at most 64 KiB");
@@ -180,6 +193,9 @@ __global__ __launch_bounds__(576) void awq_wstream_kernel(AwqPArgs p, float* sla
       a_lane[u] = p.x + (int64_t)(drow < p.M ? drow : p.M - 1) * p.x_sm + 16 * dj;  // rows past M: never stored
     }
     auto dma_phase = [&](int ph, int buf) __attribute__((always_inline)) {
+#if SGLM_AWQ_ABL_NODMA
+      return;
+#endif
       for (int sl = 0; sl < PH; ++sl) {
         int asl = ph * PH + sl;  // padded steps re-read the last real one (finite values x zero weights)
         asl = asl < p.real_steps ? asl : p.real_steps - 1;
@@ -231,9 +247,23 @@ __global__ __launch_bounds__(576) void awq_wstream_kernel(AwqPArgs p, float* sla
         const f16x2 sc2 = __builtin_bit_cast(f16x2, (szv & 0xFFFFu) | (szv << 16));
         const f16x2 zb2 = __builtin_bit_cast(f16x2, (szv >> 16) | (szv & 0xFFFF0000u));
         f16x8 bf[4];
+#if SGLM_AWQ_ABL_NODEQ
+        {
+          (void)zb2;
+          const i32x4 raw = {wq[i].w[0], wq[i].w[1], wq[i].w[2], wq[i].w[3] ^ (int)__builtin_bit_cast(uint32_t, sc2)};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bf[j] = __builtin_bit_cast(f16x8, raw);
+        }
+#else
 #pragma unroll
         for (int j = 0; j < 4; ++j) bf[j] = dequant8((uint32_t)wq[i].w[j], zb2, sc2);
+#endif
         const char* arow = smem + abuf + t * STEP_BYTES + r16 * 256;
+#if SGLM_AWQ_ABL_NOMFMA
+        (void)arow;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[0][j] += (float)bf[j][0];
+#else
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -241,6 +271,7 @@ __global__ __launch_bounds__(576) void awq_wstream_kernel(AwqPArgs p, float* sla
             const f16x8 af = *reinterpret_cast<const f16x8*>(arow + mb * 4096 + 16 * ((4 * kg + j) ^ r16));
             acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[j], acc[mb], 0, 0, 0);
           }
+#endif
         refill(wq[i]);
         __builtin_amdgcn_sched_barrier(0);
       }

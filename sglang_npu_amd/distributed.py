@@ -37,6 +37,55 @@ class AllReduceHandle:
         return self.tensor
 
 
+def _exchange_ipc_handles(group, world_size: int, create, open_peers) -> Optional[str]:
+    """The collective part of bringing up a P2P communicator, written so that EVERY rank issues the same two object
+    all-gathers whatever fails locally: `create()` -> this rank's IPC handle (bytes), `open_peers(blob)` maps the
+    others' buffers.  A local exception becomes a status the peers see; the second gather is both the barrier (nobody
+    launches a P2P kernel before every rank has mapped every peer) and the agreement.  Returns None when every rank
+    succeeded, else a message naming the first failing rank (identical on all ranks)."""
+    handle, err = b"", None
+    try:
+        handle = create()
+    except Exception as e:  # hipIpcGetMemHandle refused, out of memory, missing entry point, ...
+        err = f"create: {type(e).__name__}: {e}"
+    gathered = [None] * world_size
+    dist.all_gather_object(gathered, (err, handle), group=group)
+    failed = [(r, g[0]) for r, g in enumerate(gathered) if g[0] is not None]
+    if not failed:
+        try:
+            open_peers(b"".join(g[1] for g in gathered))
+        except Exception as e:  # a peer's buffer cannot be mapped from here (one-directional IPC / xGMI trouble)
+            err = f"open_peers: {type(e).__name__}: {e}"
+    second = [None] * world_size
+    dist.all_gather_object(second, err, group=group)
+    failed = failed or [(r, e) for r, e in enumerate(second) if e is not None]
+    return None if not failed else f"rank {failed[0][0]}: {failed[0][1]}"
+
+
+def _agree(tp: "GroupCoordinator", ok: bool) -> bool:
+    """True only if `ok` on every rank of the group (one MIN all-reduce of the same shape and dtype on all ranks)."""
+    dev = tp.device if tp.device is not None else torch.device("cpu")
+    flag = torch.tensor([1 if ok else 0], device=dev, dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=tp.device_group)
+    return int(flag.item()) == 1
+
+
+def _run_lockstep(tp: "GroupCoordinator", steps) -> bool:
+    """Run verification `steps` ((name, fn) pairs; fn() -> bool issues its group collectives FIRST, then the P2P kernel it
+    checks, then compares) so that no rank ever launches a P2P kernel its peers have given up on: the ranks agree
+    (all-reduce MIN) before every step and leave together at the first step after a failure anywhere.  A local exception
+    counts as a failed step.  The P2P kernels themselves are bounded (fail-closed timeout), so a step always returns."""
+    ok = True
+    for _name, fn in steps:
+        if not _agree(tp, ok):
+            return False
+        try:
+            ok = bool(fn())
+        except Exception:  # noqa: BLE001 -- any local error is a "no" the peers must hear about
+            ok = False
+    return _agree(tp, ok)
+
+
 class CustomAllreduce:
     """P2P all-reduce over IPC buffers -- same role and method names as
     python/sglang/srt/distributed/device_communicators/custom_all_reduce.py:35-421
@@ -52,27 +101,40 @@ class CustomAllreduce:
         from . import _lib
         self.disabled = True
         self._comm = None
+        self.init_error: Optional[str] = None
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world_size = dist.get_world_size(group) if world_size is None else world_size
         self.max_size = max_size
         self.device = device
         if self.world_size == 1 or self.world_size > 8:
             return
-        lib = _lib.lib()
-        comm = ctypes.c_void_p()
-        _lib.check(lib.sgl_mi355_ar_create(ctypes.c_int(self.rank), ctypes.c_int(self.world_size),
-                                           ctypes.c_int64(max_size), ctypes.byref(comm)))
-        self._comm, self._lib, self._ct = comm, lib, ctypes
+        self._lib, self._ct = _lib.lib(), ctypes
         if not exchange:  # the caller wires the peers itself (connect_local)
+            self._create()
             return
-        handle = ctypes.create_string_buffer(64)
-        _lib.check(lib.sgl_mi355_ar_get_ipc_handle(comm, handle))
-        gathered = [None] * self.world_size
-        dist.all_gather_object(gathered, bytes(handle.raw), group=group)
-        blob = b"".join(gathered)
-        _lib.check(lib.sgl_mi355_ar_open_peers(comm, ctypes.c_char_p(blob)))
-        dist.barrier(group=group)
+        # Every rank runs the SAME sequence of group collectives whatever happens locally (a one-directional IPC / xGMI
+        # problem must end in "all ranks fall back to RCCL", never in one rank waiting in a collective its peers skipped).
+        self.init_error = _exchange_ipc_handles(
+            group, self.world_size,
+            create=lambda: (self._create(), self._ipc_handle())[1],
+            open_peers=lambda blob: _lib.check(self._lib.sgl_mi355_ar_open_peers(self._comm, ctypes.c_char_p(blob))))
+        if self.init_error is not None:
+            self.close()
+            return
         self.disabled = False
+
+    def _create(self):
+        from . import _lib
+        comm = self._ct.c_void_p()
+        _lib.check(self._lib.sgl_mi355_ar_create(self._ct.c_int(self.rank), self._ct.c_int(self.world_size),
+                                                 self._ct.c_int64(self.max_size), self._ct.byref(comm)))
+        self._comm = comm
+
+    def _ipc_handle(self) -> bytes:
+        from . import _lib
+        handle = self._ct.create_string_buffer(64)
+        _lib.check(self._lib.sgl_mi355_ar_get_ipc_handle(self._comm, handle))
+        return bytes(handle.raw)
 
     @classmethod
     def connect_local(cls, world_size: int, device: torch.device, max_size: int = 16 * 1024 * 1024):
@@ -378,54 +440,119 @@ def init_distributed_environment(backend: Optional[str] = None, device: Optional
     # in one process; this start-up check is what covers the first run across xGMI.)
     mode = os.environ.get("SGL_MI355_CUSTOM_AR", "verify")
     if mode != "0" and device is not None and device.type == "cuda" and world in CustomAllreduce._SUPPORTED_WORLD_SIZES:
-        try:
-            ca = CustomAllreduce(dist.group.WORLD, device)
-            ok = (not ca.disabled) and (mode == "1" or _verify_custom_ar(ca, _TP))
-        except Exception as e:  # IPC mapping refused, library missing an entry point, ...
-            ca, ok = None, False
-            if rank == 0:
-                print(f"[sglang_npu_amd] P2P all-reduce unavailable ({type(e).__name__}: {e}); using RCCL", flush=True)
-        flag = torch.tensor([1 if ok else 0], device=device, dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 1:
-            _TP.ca_comm = ca
-            _TP.qr_comm = QuickAllReduce(ca)  # disabled unless ROCM_QUICK_REDUCE_QUANTIZATION asks for a regime
-        elif ca is not None:
-            ca.close()
+        _bring_up_custom_ar(_TP, lambda: CustomAllreduce(dist.group.WORLD, device), verify=(mode != "1"))
     return _TP
 
 
-def _verify_custom_ar(ca: "CustomAllreduce", tp: "GroupCoordinator") -> bool:
-    """One-shot and two-shot all-reduce and the fused all-reduce + add + RMSNorm against the process group's
-    all-reduce + the plain ops, on integer-valued payloads (sums exact in bf16): True only if everything matches."""
+def _bring_up_custom_ar(tp: "GroupCoordinator", make_comm, verify: bool = True, steps_of=None) -> bool:
+    """Build the P2P communicator (`make_comm()`), verify it against the process group and install it on `tp` only if
+    EVERY rank agrees; otherwise close it everywhere and leave RCCL as the data plane.  All ranks issue the same group
+    collectives in the same order whatever fails locally (a rank that bailed out early used to pair its
+    `flag` all-reduce with a peer's bf16 all-reduce and hang the job at init)."""
+    ca, err = None, None
+    try:
+        ca = make_comm()  # lockstep inside (_exchange_ipc_handles)
+        err = ca.init_error
+    except Exception as e:  # library missing, ctypes signature mismatch: before any collective of the constructor
+        err = f"{type(e).__name__}: {e}"
+    ok = _agree(tp, ca is not None and not ca.disabled)
+    if ok and verify:
+        qr = QuickAllReduce(ca)
+        steps = (steps_of or _verification_steps)(ca, qr, tp)
+        ok = _run_lockstep(tp, steps)
+    if ok:
+        tp.ca_comm = ca
+        tp.qr_comm = QuickAllReduce(ca)  # disabled unless ROCM_QUICK_REDUCE_QUANTIZATION asks for a regime
+        return True
+    if ca is not None:
+        ca.close()  # not leaked: the IPC staging area goes back
+    if tp.rank_in_group == 0:
+        print(f"[sglang_npu_amd] P2P all-reduce not used ({err or 'start-up verification failed on some rank'}); "
+              f"using RCCL", flush=True)
+    return False
+
+
+def _verification_steps(ca: "CustomAllreduce", qr: "QuickAllReduce", tp: "GroupCoordinator"):
+    """What the model is going to call, each against the process group's own all-reduce + the plain ops on integer-valued
+    payloads (sums exact in bf16): one-shot and two-shot all-reduce (both halves of the double buffer), the fused
+    all-reduce + add + RMSNorm on a finished addend AND on split-K partial sums (+ FP8 quant, the form the decode layers
+    use), and -- when ROCM_QUICK_REDUCE_QUANTIZATION enables it -- QuickReduce within the reference test's bound
+    (test_quick_allreduce.py:131-165) and identical on every rank."""
     from . import ops
     dev, rank, world = tp.device, tp.rank_in_group, tp.world_size
-    try:
-        for n in (4096, 1 << 19):  # 8 KiB (one-shot) and 1 MiB (two-shot) of bf16
+    grp = tp.device_group
+    steps = []
+
+    def plain(n):
+        def fn():
             g = torch.Generator(device=dev).manual_seed(100 + rank)
             x = torch.randint(-3, 4, (n,), device=dev, generator=g).to(torch.bfloat16)
             ref = x.clone()
-            dist.all_reduce(ref, group=tp.device_group)
+            dist.all_reduce(ref, group=grp)
+            good = True
             for _ in range(2):  # both halves of the double buffer
                 out = ca.custom_all_reduce(x)
                 torch.cuda.synchronize(dev)
-                if out is None or ca.timed_out() or not torch.equal(out, ref):
-                    return False
-        T, H = 64, 1024 * world
+                good = good and out is not None and not ca.timed_out() and torch.equal(out, ref)
+            return good
+        return fn
+    steps.append(("one-shot 8 KiB", plain(4096)))
+    steps.append(("two-shot 1 MiB", plain(1 << 19)))
+
+    T, H = 64, 1024 * world
+
+    def operands():
         g = torch.Generator(device=dev).manual_seed(7)
         part = torch.randint(-2, 3, (T, H), device=dev, generator=g).to(torch.bfloat16) * (rank + 1)
         res = torch.randint(-2, 3, (T, H), device=dev, generator=g).to(torch.bfloat16)
         w = torch.ones(H, device=dev, dtype=torch.bfloat16)
         red = part.clone()
-        dist.all_reduce(red, group=tp.device_group)
+        dist.all_reduce(red, group=grp)
+        return part, res, w, red
+
+    def fused_norm():
+        part, res, w, red = operands()
         res_ref = res.clone()
-        ops.fused_add_rmsnorm(red, res_ref, w, 1e-5)
+        ops.fused_add_rmsnorm(red, res_ref, w, 1e-5)  # in place: red <- norm, res_ref <- sum
         res2 = res.clone()
         got = ca.fused_add_rmsnorm(part, res2, w, 1e-5)
         torch.cuda.synchronize(dev)
         return (not ca.timed_out()) and torch.equal(got, red) and torch.equal(res2, res_ref)
-    except RuntimeError:
-        return False
+    steps.append(("fused all-reduce + add + RMSNorm", fused_norm))
+
+    def fused_norm_partials():
+        part, res, w, red = operands()
+        res_ref = res.clone()
+        q_ref, s_ref, _ = ops.rmsnorm_quant_fp8(red, w, 1e-5, residual=res_ref)
+        # the same addend as three split-K slices of integer-valued fp32 partial sums with unit scales
+        slabs = torch.stack([part.float() - 1.0, torch.ones_like(part, dtype=torch.float32),
+                             torch.zeros_like(part, dtype=torch.float32)]).contiguous()
+        gp = ops.GemmPartials(slabs, 3, torch.ones(T, device=dev), torch.ones(H, device=dev), None, T, H, torch.bfloat16)
+        res2 = res.clone()
+        q, s_ = ca.fused_add_rmsnorm_partials(gp, res2, w, 1e-5, quant_fp8=True)
+        torch.cuda.synchronize(dev)
+        return (not ca.timed_out()) and torch.equal(q.view(torch.uint8), q_ref.view(torch.uint8)) and \
+            torch.equal(s_.view(-1), s_ref.view(-1)) and torch.equal(res2, res_ref)
+    steps.append(("fused all-reduce + add + RMSNorm + FP8 quant on split-K partials", fused_norm_partials))
+
+    if not qr.disabled:
+        def quick():
+            n = 32 * 4096
+            g = torch.Generator(device=dev).manual_seed(1000 + rank)
+            x = torch.randint(1, 24, (n,), device=dev, generator=g).to(torch.bfloat16)
+            exact = x.float()
+            dist.all_reduce(exact, group=grp)
+            out = qr.quick_all_reduce(x)
+            torch.cuda.synchronize(dev)
+            lo, hi = out.float(), out.float()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=grp)  # (issued by every rank whatever `out` holds)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=grp)
+            same = torch.equal(lo, hi)  # every rank decoded the same bytes
+            close = bool(((out.float() - exact).abs() <= 1.25 * world + 0.5 * world * exact.abs()).all())
+            exact_fp = qr.qr_quant_level != QuickReduceRegime.FP or torch.equal(out.float(), exact)
+            return (not ca.timed_out()) and same and close and exact_fp
+        steps.append(("QuickReduce", quick))
+    return steps
 
 
 def get_tp_group() -> GroupCoordinator:

@@ -341,8 +341,11 @@ class LlamaForCausalLM(torch.nn.Module):
         defer = (fused and self.defer_epilogues and forward_batch.forward_mode.is_decode()
                  and input_ids.shape[0] > DEFER_MIN_ROWS)
         if defer and FUSE_ATTN_QUANT:  # one zeroed row-absmax vector per layer (the attention kernels max into it)
-            if self._attn_absmax is None:
-                self._attn_absmax = torch.zeros((len(self.layers), 64), dtype=torch.float32, device=hidden_states.device)
+            rows = input_ids.shape[0]
+            if self._attn_absmax is None or self._attn_absmax.shape[1] < rows:  # sized by the batch (never under capture: the
+                # first, eager, pass of a batch size allocates it)
+                self._attn_absmax = torch.zeros((len(self.layers), max(64, rows)), dtype=torch.float32,
+                                                device=hidden_states.device)
             self._attn_absmax.zero_()
             forward_batch.attn_row_absmax = self._attn_absmax
         else:

@@ -92,6 +92,108 @@ def test_tp2_gloo():
         assert msg == "ok", f"rank {rank}: {msg}"
 
 
+def _bringup_worker(rank, world, port, q):
+    """a P2P bring-up that fails on ONE rank only must end with every rank on the fallback, not in a hang."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    from sglang_npu_amd import distributed as D
+    try:
+        tp = D.init_distributed_environment(backend="gloo")
+        grp = tp.device_group
+        log = []
+
+        # --- handle exchange: (a) all fine, (b) create fails on rank 1, (c) open_peers fails on rank 1
+        def mk(create_fail=False, open_fail=False):
+            def create():
+                if create_fail and rank == 1:
+                    raise RuntimeError("hipIpcGetMemHandle: invalid argument")
+                return bytes([rank]) * 64
+            def open_peers(blob):
+                assert len(blob) == 64 * world and blob[64 * 1] == 1
+                log.append("open")
+                if open_fail and rank == 1:
+                    raise RuntimeError("hipIpcOpenMemHandle failed")
+            return create, open_peers
+        assert D._exchange_ipc_handles(grp, world, *mk()) is None
+        e = D._exchange_ipc_handles(grp, world, *mk(create_fail=True))
+        assert e is not None and e.startswith("rank 1: create") and log == ["open"]  # nobody opened peers after the failure
+        e = D._exchange_ipc_handles(grp, world, *mk(open_fail=True))
+        assert e is not None and e.startswith("rank 1: open_peers")
+
+        # --- verification in lockstep: step 2 fails on rank 1 (wrong result) / raises on rank 0; step 3 must not run anywhere
+        ran = []
+        def step(name, fail_rank=None, raises=False):
+            def fn():
+                t = torch.ones(8)
+                dist.all_reduce(t, group=grp)  # the reference collective: issued by every rank
+                ran.append(name)  # "the P2P kernel was launched"
+                if fail_rank == rank:
+                    if raises:
+                        raise RuntimeError("kernel launch failed")
+                    return False
+                return True
+            return (name, fn)
+        assert D._run_lockstep(tp, [step("a"), step("b")]) is True
+        ran.clear()
+        assert D._run_lockstep(tp, [step("a"), step("b", fail_rank=1), step("c")]) is False and ran == ["a", "b"]
+        ran.clear()
+        assert D._run_lockstep(tp, [step("a", fail_rank=0, raises=True), step("b")]) is False and ran == ["a"]
+
+        # --- the whole bring-up with a stand-in communicator: installed only when every rank agrees, closed otherwise
+        class FakeComm:
+            def __init__(self, disabled=False, init_error=None):
+                self.disabled, self.init_error, self.closed = disabled, init_error, False
+                self._comm, self.world_size, self.rank = None, world, rank
+            def close(self):
+                self.closed, self.disabled = True, True
+        made = []
+        def make(fail_rank=None, raises=False):
+            def f():
+                if raises and rank == fail_rank:
+                    raise OSError("libsgl_mi355.so: cannot open shared object file")
+                c = FakeComm(disabled=(rank == fail_rank), init_error="rank 1: create: boom" if fail_rank is not None else None)
+                made.append(c)
+                return c
+            return f
+        steps_ok = lambda ca, qr, tp_: [step("v1"), step("v2")]
+        steps_bad = lambda ca, qr, tp_: [step("v1"), step("v2", fail_rank=1)]
+        assert D._bring_up_custom_ar(tp, make(), steps_of=steps_ok) is True and tp.ca_comm is made[-1] and not made[-1].closed
+        tp.ca_comm = tp.qr_comm = None
+        assert D._bring_up_custom_ar(tp, make(), steps_of=steps_bad) is False and tp.ca_comm is None and made[-1].closed
+        assert D._bring_up_custom_ar(tp, make(fail_rank=1), steps_of=steps_ok) is False and tp.ca_comm is None and made[-1].closed
+        n = len(made)
+        assert D._bring_up_custom_ar(tp, make(fail_rank=0, raises=True), steps_of=steps_ok) is False and tp.ca_comm is None
+        assert len(made) == n + (1 if rank != 0 else 0) and (rank == 0 or made[-1].closed)
+        # the group is still usable afterwards (no collective left unpaired)
+        t = torch.full((4,), float(rank + 1))
+        dist.all_reduce(t, group=grp)
+        assert float(t[0]) == world * (world + 1) / 2
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        if torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_p2p_bring_up_fails_on_one_rank_without_hanging():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bringup_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=150) for _ in procs]
+    for p in procs:
+        p.join(30)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}: {msg}"
+
+
 def test_single_rank_all_reduce_is_identity():
     from sglang_npu_amd import distributed as D
     D.set_tp_group(D.GroupCoordinator(None, 0, 1, None))
