@@ -259,13 +259,36 @@ def time_ttft(net, runner, backend, device, input_len=1024, reps=7):
     return times[len(times) // 2], input_len
 
 
+def _effective_cpus() -> int:
+    """Cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (a one-GPU box shares a
+    128-core host: 128 OpenMP threads on a 16-core share would only measure oversubscription)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(cfg, B, ctx, n_layers_full):
-    """Time the CPU oracle on ONE layer's hot path (attention over ctx tokens + 4 quant-GEMMs), all host
-    cores, and scale to the full step.  Bounded to tens of seconds."""
+    """Time the CPU oracle on ONE layer's hot path (attention over ctx tokens + 4 quant-GEMMs) on the host cores this
+    process may use, and scale to the full step.  Decode attention runs the oracle's BLOCKED form (the structure of
+    decode.cpp:942-985, within 2x of the compiled reference per core; the token-at-a-time form is the checker).
+    3 warm-ups + median of 10 per op, bounded to about a minute."""
     import oracle
     lib_path = oracle.build(native=True, out=os.path.join("/tmp", f"libsgl_oracle_native_{os.getpid()}.so"), force=True)
     lib = oracle.load(lib_path)
-    cores = int(lib.orc_num_threads())
+    cores = min(int(lib.orc_num_threads()), _effective_cpus())
+    lib.orc_set_num_threads(cores)
     g = torch.Generator().manual_seed(0)
     Hq, Hkv, D, H, I = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cfg.hidden_size, cfg.intermediate_size
     n_tok = B * ctx + 1
@@ -276,10 +299,10 @@ def cpu_baseline(cfg, B, ctx, n_layers_full):
     o = torch.zeros(B, Hq, D, dtype=torch.bfloat16)
     logits = torch.zeros(B, Hq, 8, D + 1)
     rpi, seq = torch.arange(B), torch.full((B,), ctx)
-    budget_end = time.perf_counter() + 40.0
+    budget_end = time.perf_counter() + 60.0
 
-    def med(fn, warm=2, reps=7):
-        """2 warm-ups, then the median of up to 7 runs (fewer if the 40 s budget of the whole baseline runs out)."""
+    def med(fn, warm=3, reps=10):
+        """3 warm-ups, then the median of 10 runs (fewer, but never under 3, if the budget of the whole baseline runs out)."""
         for _ in range(warm):
             fn()
         ts = []
@@ -293,8 +316,8 @@ def cpu_baseline(cfg, B, ctx, n_layers_full):
         return ts[len(ts) // 2], len(ts)
 
     t_attn, n_attn = med(lambda: oracle.decode_attention(q, kb, vb, o, None, None, None, logits, r2t, rpi, seq,
-                                                         D ** -0.5, 0.0, lib=lib))
-    t_lin, n_lin = 0.0, 7
+                                                         D ** -0.5, 0.0, lib=lib, blocked=True))
+    t_lin, n_lin = 0.0, 10
     for (K, N) in [(H, (Hq + 2 * Hkv) * D), (Hq * D, H), (H, 2 * I), (I, H)]:
         x = torch.randn(B, K, generator=g).bfloat16()
         w = ((torch.rand(N, K, generator=g) - 0.5) * 8).to(torch.float8_e4m3fn)
@@ -311,9 +334,10 @@ def cpu_baseline(cfg, B, ctx, n_layers_full):
         n_lin = min(n_lin, n)
     t_layer = t_attn + t_lin
     return {"value": round(B / (t_layer * n_layers_full), 3), "unit": "tokens/s", "cores": cores, "kind": "port",
-            "sample": f"1 of {n_layers_full} layers (decode attention {t_attn * 1e3:.1f} ms + 4 quant-GEMMs "
-                      f"{t_lin * 1e3:.1f} ms at bs={B}, ctx={ctx}; 2 warm-ups, median of {min(n_attn, n_lin)}), "
-                      f"scaled x{n_layers_full}; norms/LM head not counted"}
+            "sample": f"1 of {n_layers_full} layers (decode attention {t_attn * 1e3:.1f} ms, blocked form of decode.cpp:942-985, "
+                      f"+ 4 quant-GEMMs {t_lin * 1e3:.1f} ms at bs={B}, ctx={ctx}; 3 warm-ups, median of "
+                      f"{min(n_attn, n_lin)}), scaled x{n_layers_full}; norms/LM head not counted; host threads = "
+                      f"min(OpenMP threads, affinity, cgroup quota)"}
 
 
 def reference_cpu_container():
@@ -389,6 +413,62 @@ def time_decode_gemms(net, cfg, B, device, tp):
     out["note"] = ("event-timed in this run: one HIP graph per shape with one call per layer on that layer's weights, "
                    "median of 5 replays / layers; includes split-K finalize launches where the kernel uses them")
     return out
+
+
+def allreduce_latency_vs_size(tp_group, device, world):
+    """All-reduce latency against message size, per data plane (the sizes of
+    /root/reference/test/srt/test_custom_allreduce.py:59-68 extended to 128 MiB): RCCL through torch.distributed, the P2P
+    kernel over IPC buffers while the message fits its staging area, QuickReduce when ROCM_QUICK_REDUCE_QUANTIZATION enables
+    it.  bf16, integer-valued payload (every backend must return the exact sum), 3 warm-ups + median of 20 event-timed
+    calls, max over ranks.  `bound_us` = 2 (n-1)/n x bytes over the 7 xGMI links x 153 GB/s a GPU has (each rank moves
+    that much in a reduce-scatter + all-gather).  Outside the timed region of the headline."""
+    import torch.distributed as dist
+    sizes = [512 << (2 * i) for i in range(10)]  # 512 B, 2 KiB, ... 128 MiB
+    planes = [("rccl", lambda x: (dist.all_reduce(x, group=tp_group.device_group), x)[1])]
+    ca, qr = tp_group.ca_comm, tp_group.qr_comm
+    if ca is not None and not ca.disabled:
+        planes.append(("p2p", lambda x: ca.custom_all_reduce(x)))
+    if qr is not None and not qr.disabled:
+        planes.append(("quickreduce", lambda x: qr.quick_all_reduce(x) if qr.should_quick_allreduce(x) else None))
+    link_bw = 7 * 153e9
+    rows = []
+    for nbytes in sizes:
+        n = nbytes // 2
+        g = torch.Generator(device=device).manual_seed(1 + tp_group.rank_in_group)
+        src = torch.randint(-3, 4, (n,), device=device, generator=g).to(torch.bfloat16)
+        ref = src.clone()
+        dist.all_reduce(ref, group=tp_group.device_group)
+        row = {"bytes": nbytes, "bound_us": round(2 * (world - 1) / world * nbytes / link_bw * 1e6, 3)}
+        for name, fn in planes:
+            try:
+                x = src.clone()
+                out = fn(x)
+                if out is None:  # this plane does not take the size (staging area / thresholds)
+                    continue
+                torch.cuda.synchronize(device)
+                exact = bool(torch.equal(out, ref)) if name != "quickreduce" else None
+                ts = []
+                for it in range(23):
+                    x.copy_(src)
+                    dist.barrier(group=tp_group.device_group) if it == 0 else None
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    fn(x)
+                    b.record()
+                    b.synchronize()
+                    if it >= 3:
+                        ts.append(a.elapsed_time(b) * 1e3)
+                ts.sort()
+                t = torch.tensor([ts[len(ts) // 2]], device=device, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=tp_group.device_group)
+                row[name + "_us"] = round(float(t.item()), 2)
+                if exact is not None:
+                    row[name + "_exact"] = exact
+            except Exception as e:  # a diagnostic: report and go on (every rank takes the same path: shapes only)
+                row[name + "_error"] = f"{type(e).__name__}: {str(e)[:120]}"
+        rows.append(row)
+    return {"dtype": "bf16", "world": world, "link_model": "7 xGMI links x 153 GB/s per GPU", "method": "3 warm-ups + median of 20 "
+            "event-timed calls per (size, data plane), max over ranks", "planes": [p[0] for p in planes], "points": rows}
 
 
 def other_configs():
@@ -553,12 +633,27 @@ def main():
                                    "with the next add+RMSNorm" if tp_group.ca_comm is not None and not tp_group.ca_comm.disabled
                                    else "rccl (torch.distributed)"),
                        "collectives_per_step": 2 * len(net.layers) + 1,
-                       "message_bytes": args.batch * cfg.hidden_size * 2}
+                       "message_bytes": args.batch * cfg.hidden_size * 2,
+                       "step_under_graph_replay": loop.graph is not None}
         finally:
             tp_group.stub_all_reduce = False
             loop.rewind(len_after)
+        # which data plane each collective of ONE step takes: counted where Python dispatches (one eager pass)
+        from sglang_npu_amd.distributed import DISPATCH_COUNTS
+        DISPATCH_COUNTS.clear()
         if loop.graph is not None:
-            loop.capture()  # the instrumented passes below run the real step again
+            loop.capture()  # (the instrumented passes below run the real step again) 2 warm-up passes + the captured one
+            passes = 3
+        else:
+            loop.backend.init_forward_metadata(loop.fb)
+            loop._forward()
+            passes = 1
+        torch.cuda.synchronize()
+        ar_info["dispatch_per_step"] = {k: v // passes for k, v in DISPATCH_COUNTS.items()}
+        try:
+            ar_info["latency_vs_size"] = allreduce_latency_vs_size(tp_group, device, world)
+        except Exception as e:
+            ar_info["latency_vs_size"] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
 
     # ---- roofline of the dominant kernel: paged decode attention (HBM-bound)
     ctx_mid = args.ctx + args.warmup + args.steps + args.steps // 2  # mean sequence length of the instrumented pass

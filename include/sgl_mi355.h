@@ -510,6 +510,17 @@ int sgl_mi355_rotary_embedding(const int64_t* positions, void* query, void* key,
                                int64_t rot_dim, int64_t q_stride_t, int64_t k_stride_t, int is_neox, int dtype,
                                void* stream);
 
+/* Vocab-parallel embedding lookup (SURVEY 2c "next", 8f row 4).
+ * Replaces: VocabParallelEmbedding.forward, python/sglang/srt/layers/vocab_parallel_embedding.py:462-486, with
+ *           get_masked_input_and_mask (:126-150), original vocabulary only (no added / LoRA vocabulary):
+ *   out[t] = table[ids[t] - vocab_start]  if vocab_start <= ids[t] < vocab_end  else 0
+ *   i.e. the masked gather followed by masked_fill_(mask, 0) in one pass; the caller then all-reduces `out` over the TP
+ *   group (vocab_parallel_embedding.py:483).  table [table_rows >= vocab_end - vocab_start][hidden] and out [T][hidden]
+ *   contiguous, elem_size 2 or 4 bytes (a byte copy: any 16- or 32-bit dtype), ids int32 / int64 [T]. */
+int sgl_mi355_vocab_parallel_embedding(const void* table, const void* ids, int ids_is64, void* out, int64_t num_tokens,
+                                       int64_t hidden, int64_t vocab_start, int64_t vocab_end, int64_t table_rows,
+                                       int elem_size, void* stream);
+
 /* Greedy sampling.
  * Replaces: torch.argmax(logits, -1) of Sampler.forward, python/sglang/srt/layers/sampler.py:72-75.
  *   logits [rows, cols] in `dtype` (0 bf16, 1 fp16, 2 fp32), rows `row_stride` elements apart; out int64 [rows].
@@ -545,6 +556,13 @@ int sgl_mi355_rotary_embedding_set_kv_fp8kv(const int64_t* positions, void* quer
  * csrc/gemm_bf16.hip), N % 8 == 0, K % 256 == 0; strides in elements; out contiguous [M, N]. */
 int sgl_mi355_gemm16_nt(const void* x, const void* weight, const void* bias, void* out, int64_t M, int64_t N, int64_t K,
                         int64_t x_stride_m, int64_t w_stride_n, int dtype, void* stream);
+/* The same product on a FRAGMENT-MAJOR weight (round 3): the bytes of weight [N][K] (16-bit) re-laid by
+ * sgl_mi355_fp8_shuffle_weight(src, dst, N, 2 * K bytes, row stride in bytes, ...) -- the layout is defined on 128-byte
+ * k-steps, i.e. 64 16-bit values here -- so that a decode wave's load instruction covers one contiguous KiB (what
+ * process_weights_after_loading of an untied ParallelLMHead may do once, logits_processor.py:430-505 reads it every
+ * step).  N % 16 == 0, K % 256 == 0.  Results are bit-identical to sgl_mi355_gemm16_nt on the row-major weight. */
+int sgl_mi355_gemm16_nt_wshuffled(const void* x, const void* weight_shuffled, const void* bias, void* out, int64_t M,
+                                  int64_t N, int64_t K, int64_t x_stride_m, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Replaces: sgl_per_token_group_quant_fp8(Tensor input, Tensor output_q, Tensor output_s, int group_size, float eps,
@@ -616,6 +634,12 @@ int sgl_mi355_ar_fused_add_rmsnorm_partials(void* comm, const float* partials, i
                                             const float* scales_b, const void* bias, void* residual, const void* weight,
                                             void* out, void* out_q, float* out_s, int64_t num_tokens, int64_t hidden, float eps,
                                             int dtype, void* stream);
+/* The fused all-reduce + norm kernels map row b to block b, and a byte of the staging area must always be handled by the
+ * same block index (allreduce.hip, file header): a communicator is bound to the first `hidden` it is used with and refuses
+ * others with SGL_MI355_ERR_UNSUPPORTED (the caller falls back to all_reduce + fused_add_rmsnorm).  This forgets the
+ * binding -- only while no call of the communicator is in flight on any rank (after a group barrier). */
+int sgl_mi355_ar_rebind_norm(void* comm);
+
 int sgl_mi355_ar_timed_out(void* comm, int* flag_out);
 int sgl_mi355_ar_destroy(void* comm);
 

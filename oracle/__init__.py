@@ -128,11 +128,13 @@ def set_kv_buffer(k_buffer, v_buffer, key, value, loc, lib=None):
 
 # ----------------------------------------------------------------------------- attention
 def decode_attention(query, k_buffer, v_buffer, output, key, value, loc, attn_logits, req_to_token,
-                     req_pool_indices, seq_lens, sm_scale, logit_cap, p_round: bool = False, lib=None):
+                     req_pool_indices, seq_lens, sm_scale, logit_cap, p_round: bool = False, lib=None,
+                     blocked: bool = False):
     """decode_attention_cpu (sgl-kernel/csrc/cpu/decode.cpp:1375-1575): same argument
     list and in-place behaviour (writes K/V at ``loc`` into the pool, fills
     ``attn_logits`` [B,Hq,splits,Dv+1] and ``output`` [B,Hq,Dv]).  ``loc=None`` skips the
-    KV write."""
+    KV write.  ``blocked=True`` runs the BLOCK_N-keys form of decode.cpp:942-985 (the one bench.py times as the CPU
+    baseline); the default token-at-a-time loop is the checker."""
     lib = lib or load()
     assert query.dim() == 3 and k_buffer.dim() == 3 and v_buffer.dim() == 3
     for t in (query, k_buffer, v_buffer):
@@ -149,7 +151,7 @@ def decode_attention(query, k_buffer, v_buffer, output, key, value, loc, attn_lo
         nk = (0, 0, 0, 0)
     else:
         nk = (key.stride(0), key.stride(1), value.stride(0), value.stride(1))
-    lib.orc_decode_attention(
+    (lib.orc_decode_attention_blocked if blocked else lib.orc_decode_attention)(
         _ptr(query), _ptr(k_buffer), _ptr(v_buffer), _ptr(output), _ptr(key), _ptr(value), _ptr(locc),
         _ptr(attn_logits), _ptr(req_to_token), _I(_is64(req_to_token)), _ptr(rpi), _ptr(sl),
         _I64(B), _I64(req_to_token.size(1)), _I64(query.size(1)), _I64(k_buffer.size(1)),
@@ -411,3 +413,15 @@ def _extend_attention_fp8kv(lib, q_extend, k_extend, v_extend, o_extend, k_buffe
         _ptr(cm), _ptr(mi), _I(1 if skip_prefix_custom_mask else 0), _I64(int(sliding_window_size)),
         _I(1 if q_fp8 else 0), _I(1 if p_fp8 else 0))
     return o_extend
+
+
+def vocab_parallel_embedding(ids, table, org_vocab_start, org_vocab_end, num_org_vocab_padding=0):
+    """One rank's VocabParallelEmbedding.forward before the all-reduce (vocab_parallel_embedding.py:462-482), the
+    original vocabulary only: get_masked_input_and_mask (:126-150) -> F.embedding on the rank's shard ->
+    masked_fill_(~vocab_mask, 0).  Plain torch on CPU tensors (index arithmetic and a byte copy: exact)."""
+    org_vocab_mask = (ids >= org_vocab_start) & (ids < org_vocab_end)
+    valid_offset = org_vocab_start * org_vocab_mask
+    masked = org_vocab_mask * (ids - valid_offset)
+    out = torch.nn.functional.embedding(masked.long(), table)
+    out.masked_fill_((~org_vocab_mask).unsqueeze(-1), 0)
+    return out

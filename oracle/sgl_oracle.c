@@ -237,6 +237,13 @@ int orc_num_threads(void) {
   return 1;
 #endif
 }
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
 
 static inline int64_t div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
@@ -413,6 +420,144 @@ void orc_decode_attention(
     uint16_t* o = output + b * o_strideM + h * o_strideH;
     float inv = s_prime > 0.f ? 1.f / s_prime : 0.f;
     for (int64_t d = 0; d < head_size_v; ++d) o[d] = f32_to_h(acc[d] * inv, dtype);
+    if (acc != accv) free(acc);
+  }
+}
+
+/* The same decode attention in the BLOCKED form the reference itself runs (decode.cpp:942-985: BLOCK_N keys x the
+ * heads of a GQA group per step: S = Q K^T, block max, P = exp(S - m), acc = acc * alpha + P V) -- the token-at-a-time
+ * loop above is the easiest form to check, this is the one timed as bench.py's cpu_baseline ("port"): fp32 tiles of
+ * ORC_BN keys that stay in L1/L2, reductions the compiler may vectorise (omp simd).  Same arithmetic up to the fp32
+ * summation order (tests/test_oracle_golden.py holds the two together).  Second stage = decode_accumulate_kv_splits. */
+#define ORC_BN 64
+void orc_decode_attention_blocked(
+    const uint16_t* query, uint16_t* k_buffer, uint16_t* v_buffer, uint16_t* output,
+    const uint16_t* key, const uint16_t* value, const int64_t* loc,
+    float* attn_logits, const void* req_to_token, int idx64,
+    const int64_t* req_pool_indices, const int64_t* seq_lens,
+    int64_t num_seqs, int64_t max_context_len, int64_t num_heads, int64_t num_heads_kv,
+    int64_t head_size, int64_t head_size_v, int64_t num_kv_splits,
+    int64_t q_strideM, int64_t q_strideH, int64_t k_strideN, int64_t k_strideH,
+    int64_t v_strideN, int64_t v_strideH, int64_t nk_strideN, int64_t nk_strideH,
+    int64_t nv_strideN, int64_t nv_strideH, int64_t o_strideM, int64_t o_strideH,
+    float sm_scale, float logit_cap, int dtype, int p_round) {
+  if (loc) {
+    orc_set_kv_buffer(k_buffer, v_buffer, key, value, loc, num_seqs, num_heads_kv, head_size, head_size_v,
+                      k_strideN, k_strideH, v_strideN, v_strideH, nk_strideN, nk_strideH, nv_strideN, nv_strideH);
+  }
+  const int64_t group = num_heads / num_heads_kv;
+  const int64_t l_stride2 = head_size_v + 1;
+  const int64_t l_stride1 = num_kv_splits * l_stride2;
+  const int64_t l_stride0 = num_heads * l_stride1;
+  const int64_t work = num_seqs * num_heads_kv * num_kv_splits;
+  const int64_t D = head_size, Dv = head_size_v;
+#pragma omp parallel
+  {
+    float* qf = (float*)malloc(sizeof(float) * (size_t)(group * D));
+    float* kf = (float*)malloc(sizeof(float) * (size_t)(ORC_BN * D));
+    float* vf = (float*)malloc(sizeof(float) * (size_t)(ORC_BN * Dv));
+    float* sc = (float*)malloc(sizeof(float) * (size_t)(group * ORC_BN));
+    float* acc = (float*)malloc(sizeof(float) * (size_t)(group * Dv));
+    float* m_prime = (float*)malloc(sizeof(float) * (size_t)group);
+    float* s_prime = (float*)malloc(sizeof(float) * (size_t)group);
+#pragma omp for schedule(dynamic, 1)
+    for (int64_t w = 0; w < work; ++w) {
+      const int64_t kv_id = w % num_kv_splits;
+      const int64_t hkv = (w / num_kv_splits) % num_heads_kv;
+      const int64_t b = w / (num_kv_splits * num_heads_kv);
+      const int64_t seq_len = seq_lens[b];
+      const int64_t req = req_pool_indices[b];
+      const int64_t split_size = div_up(seq_len, num_kv_splits);
+      const int64_t kv_start = kv_id * split_size;
+      const int64_t kv_end = kv_start + split_size < seq_len ? kv_start + split_size : seq_len;
+      for (int64_t g = 0; g < group; ++g) {
+        const uint16_t* q = query + b * q_strideM + (hkv * group + g) * q_strideH;
+        for (int64_t d = 0; d < D; ++d) qf[g * D + d] = h_to_f32(q[d], dtype) * sm_scale;
+        m_prime[g] = -INFINITY;
+        s_prime[g] = 0.f;
+        for (int64_t d = 0; d < Dv; ++d) acc[g * Dv + d] = 0.f;
+      }
+      for (int64_t n0 = kv_start; n0 < kv_end; n0 += ORC_BN) {
+        const int64_t nb = kv_end - n0 < ORC_BN ? kv_end - n0 : ORC_BN;
+        for (int64_t j = 0; j < nb; ++j) {  /* gather the block's rows through the page table, widen to fp32 */
+          const int64_t tok = load_index(req_to_token, req * max_context_len + n0 + j, idx64);
+          const uint16_t* kp = k_buffer + tok * k_strideN + hkv * k_strideH;
+          const uint16_t* vp = v_buffer + tok * v_strideN + hkv * v_strideH;
+          float* kr = kf + j * D;
+          float* vr = vf + j * Dv;
+          for (int64_t d = 0; d < D; ++d) kr[d] = h_to_f32(kp[d], dtype);
+          for (int64_t d = 0; d < Dv; ++d) vr[d] = h_to_f32(vp[d], dtype);
+        }
+        for (int64_t g = 0; g < group; ++g) {
+          const float* qg = qf + g * D;
+          float* sg = sc + g * ORC_BN;
+          float m_blk = -INFINITY;
+          for (int64_t j = 0; j < nb; ++j) {
+            const float* kr = kf + j * D;
+            float s = 0.f;
+#pragma omp simd reduction(+ : s)
+            for (int64_t d = 0; d < D; ++d) s += qg[d] * kr[d];
+            if (logit_cap > 0.f) s = logit_cap * tanhf(s / logit_cap);
+            sg[j] = s;
+            m_blk = s > m_blk ? s : m_blk;
+          }
+          const float m_i = m_blk > m_prime[g] ? m_blk : m_prime[g];
+          const float alpha = expf(m_prime[g] - m_i);
+          float l = 0.f;
+          for (int64_t j = 0; j < nb; ++j) {
+            const float pj = expf(sg[j] - m_i);
+            l += pj;
+            sg[j] = p_round ? h_to_f32(f32_to_h(pj, dtype), dtype) : pj;
+          }
+          s_prime[g] = s_prime[g] * alpha + l;
+          m_prime[g] = m_i;
+          float* a = acc + g * Dv;
+#pragma omp simd
+          for (int64_t d = 0; d < Dv; ++d) a[d] *= alpha;
+          for (int64_t j = 0; j < nb; ++j) {
+            const float pj = sg[j];
+            const float* vr = vf + j * Dv;
+#pragma omp simd
+            for (int64_t d = 0; d < Dv; ++d) a[d] += pj * vr[d];
+          }
+        }
+      }
+      for (int64_t g = 0; g < group; ++g) {
+        float* out = attn_logits + b * l_stride0 + (hkv * group + g) * l_stride1 + kv_id * l_stride2;
+        if (kv_end > kv_start) {
+          const float inv = 1.f / s_prime[g];
+          for (int64_t d = 0; d < Dv; ++d) out[d] = acc[g * Dv + d] * inv;
+          out[Dv] = m_prime[g] + logf(s_prime[g]);
+        } else {
+          for (int64_t d = 0; d < Dv; ++d) out[d] = 0.f;
+          out[Dv] = -INFINITY;
+        }
+      }
+    }
+    free(qf); free(kf); free(vf); free(sc); free(acc); free(m_prime); free(s_prime);
+  }
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < num_seqs * num_heads; ++i) {  /* decode_accumulate_kv_splits, decode.cpp:812-860 */
+    const int64_t b = i / num_heads, h = i % num_heads;
+    float* base = attn_logits + b * l_stride0 + h * l_stride1;
+    float m_prime = -INFINITY, s_prime = 0.f;
+    float accv[1024];
+    float* acc = Dv <= 1024 ? accv : (float*)malloc(sizeof(float) * (size_t)Dv);
+    for (int64_t d = 0; d < Dv; ++d) acc[d] = 0.f;
+    for (int64_t kv_id = 0; kv_id < num_kv_splits; ++kv_id) {
+      const float* tv = base + kv_id * l_stride2;
+      const float tlogic = tv[Dv];
+      if (tlogic == -INFINITY) continue;
+      const float m_i = tlogic > m_prime ? tlogic : m_prime;
+      const float m_delta = expf(m_prime - m_i);
+      const float e_logic = expf(tlogic - m_i);
+      for (int64_t d = 0; d < Dv; ++d) acc[d] = acc[d] * m_delta + tv[d] * e_logic;
+      s_prime = s_prime * m_delta + e_logic;
+      m_prime = m_i;
+    }
+    uint16_t* o = output + b * o_strideM + h * o_strideH;
+    const float inv = s_prime > 0.f ? 1.f / s_prime : 0.f;
+    for (int64_t d = 0; d < Dv; ++d) o[d] = f32_to_h(acc[d] * inv, dtype);
     if (acc != accv) free(acc);
   }
 }

@@ -11,7 +11,12 @@
 //   two-shot  (larger):     copy-in, barrier, rank r reduces slice r from all peers (reduce-scatter by
 //                           pull), barrier, every rank gathers the 8 reduced slices (all-gather by pull).
 // Buffers are double-buffered by call parity, so no trailing barrier is needed: a half is rewritten only
-// after the next call's first barrier proved that every peer left the previous call.
+// after the next call's first barrier proved that every peer left the previous call.  The parity is PER BLOCK (block b's
+// own call count) and a block's barrier only proves that the peers' blocks b left the previous call, so this holds as long
+// as a given byte of the staging area is always handled by the same block index.  Each kernel FAMILY therefore has its own
+// staging area, flags and counters (round 3): 0 = plain all-reduce (vector i <-> block (i / 256) % 64 whatever
+// the size), 1 = all-reduce fused with add + RMSNorm (row b <-> block b; the row length H is pinned per communicator by
+// the launcher), 2 = QuickReduce (one regime per communicator).
 // The sum order is rank 0..W-1 on every rank, so all ranks produce bit-identical results (and integer-
 // valued payloads are exact, the property test_custom_allreduce.py:118-146 relies on).
 // The call counter lives in device memory (kernel arguments are frozen under HIP-graph replay).
@@ -42,6 +47,7 @@ struct ArComm {
   bool opened[kMaxRanks];
   uint32_t* status_host; // pinned, device-mapped: 0 = healthy, 1 = a barrier timed out (sticky)
   uint32_t* status_dev;
+  int64_t norm_hidden;   // row length the fused all-reduce + norm family is bound to (0 = not yet used), see kFamNorm
 };
 
 struct ArArgs {
@@ -51,16 +57,24 @@ struct ArArgs {
   uint32_t* status;      // sticky failure word in this rank's own device buffer (read on every call: must be cheap)
   uint32_t* status_host; // its mirror in host-mapped pinned memory (written once, when a wait gives up)
   unsigned spin_limit;
+  int family;            // staging area / flags / counters of this kernel family (kFam*); data_off already points into it
 };
 
-// signals: uint32 [2 slots][world][kMaxBlocks] at offset 0; counter uint32[kMaxBlocks] after them; then timeout
-__device__ __forceinline__ uint32_t* sig_ptr(char* base, int slot, int from, int block) {
-  return reinterpret_cast<uint32_t*>(base) + (slot * kMaxRanks + from) * kMaxBlocks + block;
+// header: signals uint32 [kFamilies][2 slots][kMaxRanks][kMaxBlocks] at offset 0; counters uint32 [kFamilies][kMaxBlocks]
+// after them; then the sticky status word.  Data: [kFamilies][2 halves][half_bytes] from kHeaderBytes on.
+constexpr int kFamilies = 3;
+enum { kFamPlain = 0, kFamNorm = 1, kFamQuick = 2 };
+__device__ __forceinline__ uint32_t* sig_ptr(char* base, int family, int slot, int from, int block) {
+  return reinterpret_cast<uint32_t*>(base) + ((family * 2 + slot) * kMaxRanks + from) * kMaxBlocks + block;
 }
-constexpr size_t kSigBytes = 2 * kMaxRanks * kMaxBlocks * 4;
+constexpr size_t kSigBytes = (size_t)kFamilies * 2 * kMaxRanks * kMaxBlocks * 4;
 constexpr size_t kCounterOff = kSigBytes;
-constexpr size_t kStatusOff = kCounterOff + kMaxBlocks * 4;
-constexpr size_t kHeaderBytes = 8192;
+constexpr size_t kStatusOff = kCounterOff + (size_t)kFamilies * kMaxBlocks * 4;
+constexpr size_t kHeaderBytes = 16384;
+static_assert(kStatusOff + 64 <= kHeaderBytes, "header layout");
+__device__ __forceinline__ uint32_t* counter_ptr(const ArArgs& a) {
+  return reinterpret_cast<uint32_t*>(a.peer[a.rank] + kCounterOff) + a.family * kMaxBlocks + blockIdx.x;
+}
 
 // Returns false when this rank's communicator is (or has just become) failed: the caller must not read peer data.
 __device__ __forceinline__ bool block_barrier(const ArArgs& a, int slot, uint32_t val) {
@@ -70,8 +84,8 @@ __device__ __forceinline__ bool block_barrier(const ArArgs& a, int slot, uint32_
   if (threadIdx.x < a.world) {
     const int t = threadIdx.x;
     __threadfence_system();
-    __hip_atomic_store(sig_ptr(a.peer[t], slot, a.rank, blockIdx.x), val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    uint32_t* mine = sig_ptr(a.peer[a.rank], slot, t, blockIdx.x);
+    __hip_atomic_store(sig_ptr(a.peer[t], a.family, slot, a.rank, blockIdx.x), val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    uint32_t* mine = sig_ptr(a.peer[a.rank], a.family, slot, t, blockIdx.x);
     unsigned spins = 0;
     while (__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < val) {
       // another block of this rank (or an earlier call) already gave up: do not wait out the full limit again
@@ -123,7 +137,7 @@ struct AccF32 {
 template <typename A>
 __global__ __launch_bounds__(kThreads) void all_reduce_kernel(ArArgs a, const uint4* __restrict__ inp, uint4* __restrict__ out,
                                                               int64_t n16, int two_shot) {
-  uint32_t* counter = reinterpret_cast<uint32_t*>(a.peer[a.rank] + kCounterOff) + blockIdx.x;
+  uint32_t* counter = counter_ptr(a);
   const uint32_t call = *counter + 1;  // 1, 2, 3, ... ; every rank runs the same sequence of calls
   const int half = call & 1;
   const int64_t tid = (int64_t)blockIdx.x * kThreads + threadIdx.x;
@@ -273,7 +287,7 @@ template <int DTYPE, int BITS>
 __global__ __launch_bounds__(kThreads) void quick_reduce_kernel(ArArgs a, const uint4* __restrict__ inp, uint4* __restrict__ out,
                                                                 int64_t n_units) {
   using A = Acc8<DTYPE>;
-  uint32_t* counter = reinterpret_cast<uint32_t*>(a.peer[a.rank] + kCounterOff) + blockIdx.x;
+  uint32_t* counter = counter_ptr(a);
   const uint32_t call = *counter + 1;
   const int half = call & 1;
   const int64_t tid = (int64_t)blockIdx.x * kThreads + threadIdx.x;
@@ -383,7 +397,7 @@ __global__ __launch_bounds__(kNormThreads) void ar_add_rmsnorm_kernel(
   using Hh = Half16<DTYPE>;
   using x8 = typename Hh::x8;
   __shared__ float red[kNormThreads / 64];
-  uint32_t* counter = reinterpret_cast<uint32_t*>(a.peer[a.rank] + kCounterOff) + blockIdx.x;
+  uint32_t* counter = counter_ptr(a);
   const uint32_t call = *counter + 1;
   const int half = call & 1;
   char* my_data = a.peer[a.rank] + a.data_off + half * a.half_bytes;
@@ -519,10 +533,10 @@ extern "C" int sgl_mi355_ar_create(int rank, int world_size, int64_t max_bytes, 
                  "ar_create: bad rank/world (%d/%d), world must be <= %d", rank, world_size, kMaxRanks);
   SGLM_CHECK_ARG(max_bytes > 0 && max_bytes % 16 == 0 && max_bytes <= (1ll << 30), "ar_create: bad max_bytes");
   ArComm* c = new ArComm();
-  c->rank = rank; c->world = world_size; c->max_bytes = (size_t)max_bytes;
+  c->rank = rank; c->world = world_size; c->max_bytes = (size_t)max_bytes; c->norm_hidden = 0;
   c->half_bytes = 2 * (size_t)max_bytes;  // payload + two-shot result area
   c->data_off = kHeaderBytes;
-  const size_t total = kHeaderBytes + 2 * c->half_bytes;
+  const size_t total = kHeaderBytes + (size_t)kFamilies * 2 * c->half_bytes;
   void* p = nullptr;
   // uncached (fine-grained) memory: flags and payload are read by peer GPUs while kernels run
   hipError_t e = hipExtMallocWithFlags(&p, total, hipDeviceMallocUncached);
@@ -600,6 +614,15 @@ extern "C" int sgl_mi355_ar_set_spin_limit(int64_t spins) {
   return 0;
 }
 
+// Forget the row length the fused all-reduce + norm staging area is bound to (see kFamNorm).  Only while NO call of this
+// communicator is in flight on ANY rank (e.g. after a group barrier that follows a device synchronisation): the start-up
+// self-check uses a row length of its own before the model's first call.
+extern "C" int sgl_mi355_ar_rebind_norm(void* comm) {
+  SGLM_CHECK_ARG(comm, "ar_rebind_norm: null communicator");
+  ((ArComm*)comm)->norm_hidden = 0;
+  return 0;
+}
+
 extern "C" int sgl_mi355_ar_all_reduce(void* comm, const void* inp, void* out, int64_t nbytes, int dtype /* 0 bf16, 1 fp16, 2 fp32 */,
                                         void* stream) {
   SGLM_CHECK_ARG(comm, "ar_all_reduce: null communicator");
@@ -612,7 +635,8 @@ extern "C" int sgl_mi355_ar_all_reduce(void* comm, const void* inp, void* out, i
   for (int r = 0; r < c->world; ++r) SGLM_CHECK_ARG(c->peer[r] != nullptr, "ar_all_reduce: peer %d not opened", r);
   ArArgs a{};
   for (int r = 0; r < c->world; ++r) a.peer[r] = c->peer[r];
-  a.data_off = c->data_off; a.half_bytes = c->half_bytes; a.rank = c->rank; a.world = c->world;
+  a.family = kFamPlain;
+  a.data_off = c->data_off + (size_t)kFamPlain * 2 * c->half_bytes; a.half_bytes = c->half_bytes; a.rank = c->rank; a.world = c->world;
   a.status = reinterpret_cast<uint32_t*>(c->base + kStatusOff); a.status_host = c->status_dev; a.spin_limit = g_spin_limit;
   const int64_t n16 = nbytes / 16;
   const int two_shot = nbytes > 256 * 1024 && c->world > 1;
@@ -644,7 +668,8 @@ extern "C" int sgl_mi355_ar_quick_all_reduce(void* comm, const void* inp, void* 
   for (int r = 0; r < c->world; ++r) SGLM_CHECK_ARG(c->peer[r] != nullptr, "ar_quick_all_reduce: peer %d not opened", r);
   ArArgs a{};
   for (int r = 0; r < c->world; ++r) a.peer[r] = c->peer[r];
-  a.data_off = c->data_off; a.half_bytes = c->half_bytes; a.rank = c->rank; a.world = c->world;
+  a.family = kFamQuick;
+  a.data_off = c->data_off + (size_t)kFamQuick * 2 * c->half_bytes; a.half_bytes = c->half_bytes; a.rank = c->rank; a.world = c->world;
   a.status = reinterpret_cast<uint32_t*>(c->base + kStatusOff); a.status_host = c->status_dev; a.spin_limit = g_spin_limit;
   hipStream_t s = as_stream(stream);
   const int bits = regime == 0 ? 16 : regime == 1 ? 8 : regime == 2 ? 6 : 4;
@@ -687,12 +712,21 @@ static int ar_fused_add_rmsnorm_impl(void* comm, const void* inp, const PartialS
   SGLM_CHECK_ARG((size_t)nbytes <= c->max_bytes, "ar_fused_add_rmsnorm: %ld B exceeds the registered capacity %ld B", (long)nbytes,
                  (long)c->max_bytes);
   if (num_tokens == 0) return 0;
+  // row b <-> block b only holds for ONE row length: a byte of the staging area must always belong to the same block
+  // index (see the file header); a communicator is bound to the first H it is used with
+  if (c->norm_hidden == 0) c->norm_hidden = hidden;
+  if (c->norm_hidden != hidden) {
+    set_error("ar_fused_add_rmsnorm: this communicator's fused-norm staging area is bound to H=%ld (got %ld): use the plain "
+              "all-reduce followed by fused_add_rmsnorm for other row lengths", (long)c->norm_hidden, (long)hidden);
+    return SGL_MI355_ERR_UNSUPPORTED;
+  }
   SGLM_CHECK_ARG((inp || ps.partials) && residual && weight && (out || out_q), "ar_fused_add_rmsnorm: null tensor pointer");
   SGLM_CHECK_ARG(!out_q || out_s, "ar_fused_add_rmsnorm: out_q needs out_s");
   for (int r = 0; r < c->world; ++r) SGLM_CHECK_ARG(c->peer[r] != nullptr, "ar_fused_add_rmsnorm: peer %d not opened", r);
   ArArgs a{};
   for (int r = 0; r < c->world; ++r) a.peer[r] = c->peer[r];
-  a.data_off = c->data_off; a.half_bytes = c->half_bytes; a.rank = c->rank; a.world = c->world;
+  a.family = kFamNorm;
+  a.data_off = c->data_off + (size_t)kFamNorm * 2 * c->half_bytes; a.half_bytes = c->half_bytes; a.rank = c->rank; a.world = c->world;
   a.status = reinterpret_cast<uint32_t*>(c->base + kStatusOff); a.status_host = c->status_dev; a.spin_limit = g_spin_limit;
   const int one_shot = nbytes <= 256 * 1024 || c->world == 1;
   const int blocks = (int)(num_tokens < kMaxBlocks ? num_tokens : kMaxBlocks);

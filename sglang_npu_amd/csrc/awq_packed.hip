@@ -312,18 +312,253 @@ __global__ __launch_bounds__(576) void awq_wstream_kernel(AwqPArgs p, float* sla
   }
 }
 
-__global__ __launch_bounds__(256) void awq_packed_finalize_kernel(AwqPArgs p, const float* slabs, int SK) {
-  const int64_t total = (int64_t)p.M * p.N / 8;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int s = 0; s < SK; ++s) {
-      const float* src = slabs + (int64_t)s * p.M * p.N + i * 8;
-      const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+// ------------------------------------------------------------------------------------------
+// Round 3: TWO column blocks per consumer wave, deep weight queue, dequant pipelined under the MFMAs.
+//
+// Timing ablations of the kernel above (profiles/r03_awq_ablation.txt, M = 64, 4096 -> 22016): 27.6 us as built; 20.6
+// without the dequant VALU work; 17.1 without the LDS fragment reads + MFMAs; 15.7 with neither -- i.e. the bare
+// streaming skeleton already takes twice what the 45 MB need, and dequant and MFMA run one after the other on top.
+//   * skeleton: a wave kept 4 k-steps x 1 KiB in flight and a CU 6 such waves: 24 KiB per CU against ~2 us of loaded
+//     memory latency = 12 GB/s per CU (the FP8 streamer keeps 56 KiB).  Here a wave owns 32 columns (two 16-column
+//     blocks, each with its own queue) and keeps PB = 8 steps of both in flight: 16 KiB per wave, 48-64 KiB per CU.
+//   * LDS: the fp16 A fragments of a k-step (16 KiB at M = 64) are read ONCE per wave and feed both blocks -- half the
+//     LDS bytes per weight byte (the old kernel's 8 waves x 16 KiB per k-step round = 1024 clk of LDS per CU).
+//   * dequant: 13 VALU per dword instead of 19.  The odd nibbles are not shifted down: (w & 0x00F000F0) | 0x54005400 is
+//     the fp16 pair (64 + n) because the mantissa bit 4 of an fp16 in [64, 128) weighs 1, so one shift by 8 serves all four
+//     pairs of a dword; the second zero-point constant is 64 + z.  (64 + n) - (64 + z) = n - z exactly, times the scale
+//     rounds once: the reference's arithmetic, bit for bit.  v_and_or_b32 with the mask in an SGPR and the magic in a VGPR
+//     (a VOP3 instruction of this ISA takes neither a literal nor two scalar operands).
+//   * one wave per SIMD (<= 4 consumers + the DMA producer), so the in-order issue of a wave must itself overlap VALU and
+//     MFMA: the loop is rotated by half a step -- while the 16 MFMAs of block b run, the other block's next 32 k-values are
+//     dequantised; the raw registers of a slot are refilled right after its dequant, not after its MFMAs.
+__device__ __forceinline__ uint32_t and_or(uint32_t w, uint32_t mask_s, uint32_t magic_v) {
+  uint32_t r;
+  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(w), "s"(mask_s), "v"(magic_v));
+  return r;
+}
+struct DqConst {
+  uint32_t magic_lo, magic_hi;  // 0x64006400 / 0x54005400 in VGPRs
+};
+__device__ __forceinline__ f16x8 dequant8_v2(uint32_t w, f16x2 zlo, f16x2 zhi, f16x2 sc2, const DqConst& c) {
+  const uint32_t w8 = w >> 8;
+  const f16x2 h0 = (__builtin_bit_cast(f16x2, and_or(w, 0x000F000Fu, c.magic_lo)) - zlo) * sc2;
+  const f16x2 h1 = (__builtin_bit_cast(f16x2, and_or(w, 0x00F000F0u, c.magic_hi)) - zhi) * sc2;
+  const f16x2 h2 = (__builtin_bit_cast(f16x2, and_or(w8, 0x000F000Fu, c.magic_lo)) - zlo) * sc2;
+  const f16x2 h3 = (__builtin_bit_cast(f16x2, and_or(w8, 0x00F000F0u, c.magic_hi)) - zhi) * sc2;
+  return f16x8{h0[0], h0[1], h1[0], h1[1], h2[0], h2[1], h3[0], h3[1]};
+}
+
+template <int MB, int PH, int PB, bool SLAB>
+__global__ __launch_bounds__(320) void awq_wstream2_kernel(AwqPArgs p, float* slabs, int phases_per_slice) {
+  static_assert(PH * MB <= 16, "one fp16 A buffer is at most 64 KiB");
+  static_assert(PB % PH == 0 || PH % PB == 0, "PB and PH are powers of two");
+  constexpr int ROWS = 16 * MB;
+  constexpr int STEP_BYTES = ROWS * 256;
+  constexpr int BUF_BYTES = PH * STEP_BYTES;
+  constexpr int UPS = 4 * MB;
+  constexpr int NQ = 2 * PB;  // half-steps (block, k-step) in flight per wave
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int NC = (int)(blockDim.x >> 6) - 1;
+  const int r16 = lane & 15, kg = lane >> 4;
+  const int P_total = (p.K >> 7) / PH;
+  const int ph0 = SLAB ? (int)blockIdx.y * phases_per_slice : 0;
+  const int ph1 = SLAB ? (ph0 + phases_per_slice < P_total ? ph0 + phases_per_slice : P_total) : P_total;
+  const int nph = ph1 - ph0;
+  const uint32_t smem_base = lds_addr_of(smem);
+
+  if (wave == NC) {  // ---------------- producer (as in awq_wstream_kernel)
+    const int lrow = lane >> 4;
+    const uint8_t* a_lane[UPS];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        v[j] += a[j];
-        v[4 + j] += b[j];
+    for (int u = 0; u < UPS; ++u) {
+      const int drow = u * 4 + lrow;
+      const int dj = (lane & 15) ^ (drow & 15);
+      a_lane[u] = p.x + (int64_t)(drow < p.M ? drow : p.M - 1) * p.x_sm + 16 * dj;
+    }
+    auto dma_phase = [&](int ph, int buf) __attribute__((always_inline)) {
+      for (int sl = 0; sl < PH; ++sl) {
+        int asl = ph * PH + sl;
+        asl = asl < p.real_steps ? asl : p.real_steps - 1;
+#pragma unroll
+        for (int u = 0; u < UPS; ++u)
+          lds_dma16(a_lane[u] + (int64_t)asl * 256, smem_base + buf * BUF_BYTES + sl * STEP_BYTES + u * 1024);
       }
+    };
+    dma_phase(ph0, 0);
+    for (int lp = 0; lp < nph; ++lp) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (lp + 1 < nph) dma_phase(ph0 + lp + 1, (lp + 1) & 1);
+    }
+    __syncthreads();
+    return;
+  }
+
+  // ---------------- consumers: unit = column blocks 2u and 2u + 1
+  const int unit = blockIdx.x * NC + wave;
+  const int nblocks = (p.N + 15) >> 4;
+  const uint8_t* w_blk[2];
+  const uint32_t* s_blk[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int nb = 2 * unit + b;
+    const int nbc = nb < nblocks ? nb : 0;  // a block past the end streams block 0 (never stored)
+    w_blk[b] = p.wp + (int64_t)nbc * (p.K >> 7) * 1024;
+    s_blk[b] = p.sz + (int64_t)nbc * p.ngroups * 16;
+  }
+  const uint32_t w_off = (uint32_t)lane * 16;
+  const uint32_t s_off = (uint32_t)r16 * 4;
+  const int rot = (unit * 3) & (PH - 1);
+  const int first = ph0 * PH, last = ph1 * PH - 1;
+  DqConst dq;
+  asm volatile("v_mov_b32 %0, 0x64006400\n\tv_mov_b32 %1, 0x54005400" : "=v"(dq.magic_lo), "=v"(dq.magic_hi));
+
+  // half-step h (h even: block 0, odd: block 1) of flat step first + h / 2; loads past the end re-read the last step
+  int h_pf = 0;
+  auto refill = [&](WFrag& fr, int b) __attribute__((always_inline)) {
+    int f = first + (h_pf >> 1);
+    f = f < last ? f : last;
+    const int ks = (f & ~(PH - 1)) + ((f + rot) & (PH - 1));
+    wload_asm<!SLAB>(fr, w_blk[b] + (int64_t)ks * 1024, w_off, s_blk[b] + (ks >> p.gshift) * 16, s_off);
+    ++h_pf;
+  };
+  WFrag wq[NQ];
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) refill(wq[i], i & 1);
+
+  f32x4 acc[2][MB];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[b][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto dequant_slot = [&](WFrag& fr, f16x8 (&bf)[4]) __attribute__((always_inline)) {
+    const uint32_t szv = fr.sz;
+    const f16x2 sc2 = __builtin_bit_cast(f16x2, (szv & 0xFFFFu) | (szv << 16));
+    const f16x2 zlo = __builtin_bit_cast(f16x2, (szv >> 16) | (szv & 0xFFFF0000u));
+    const f16x2 zhi = zlo - f16x2{(_Float16)960.f, (_Float16)960.f};  // (1024 + z) - 960 = 64 + z, exact
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bf[j] = dequant8_v2((uint32_t)fr.w[j], zlo, zhi, sc2, dq);
+  };
+
+  f16x8 bf[2][4];  // [parity of the half-step]
+  wait_wfrag<2 * (NQ - 1)>(wq[0]);
+  dequant_slot(wq[0], bf[0]);
+  refill(wq[0], 0);
+
+  f16x8 af[MB][4];
+  const int nsteps = nph * PH;  // a multiple of PB (launcher)
+#pragma clang loop unroll(disable)  // exactly one copy of the body (gemm_fp8.hip 4.3.1 f)
+  for (int f0 = 0; f0 < nsteps; f0 += PB) {
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      const int fl = f0 + i;  // local flat step
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int cur = (2 * i + b) & 1, nxt = cur ^ 1;
+        const int slot_n = (2 * i + b + 1) % NQ;  // the next half-step's slot
+        if (b == 0) {
+          // a new phase starts here: wait until the producer's DMA of it is in LDS (static for PH <= PB)
+          if ((i % PH == 0) && (PH <= PB || (f0 & (PH - 1)) == 0)) __syncthreads();
+          const int t = (fl + rot) & (PH - 1);
+          const char* arow = smem + ((fl / PH) & 1) * BUF_BYTES + t * STEP_BYTES + r16 * 256;
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              af[mb][j] = *reinterpret_cast<const f16x8*>(arow + mb * 4096 + 16 * ((4 * kg + j) ^ r16));
+        }
+        wait_wfrag<2 * (NQ - 1)>(wq[slot_n]);
+        dequant_slot(wq[slot_n], bf[nxt]);  // next half-step's operands, under this half-step's MFMAs
+#pragma unroll
+        for (int j = 0; j < 4; ++j)  // j outside: consecutive MFMAs go to different accumulators (each still sums j = 0..3 in order)
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) acc[b][mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mb][j], bf[cur][j], acc[b][mb], 0, 0, 0);
+        // the dequantised operands are complete HERE (pure VALU ops would otherwise sink to their use in the next
+        // half-step, in front of its MFMAs instead of under these), interleaved 1 MFMA : 4 VALU by the groups below
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(bf[nxt][j]));
+        if (b == 0) __builtin_amdgcn_sched_group_barrier(0x100, 4 * MB, 0);  // the step's A fragments first
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);                    // ... and a first run of VALU under their latency
+#pragma unroll
+        for (int k = 0; k < 4 * MB; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, (56 + 4 * MB - 1) / (4 * MB), 0);
+        }
+        refill(wq[slot_n], (b + 1) & 1);    // its raw registers are free again
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+
+  drain_wfrags(wq);
+  __syncthreads();  // the A buffers are dead: reuse their memory
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int nb = 2 * unit + b;
+    const int n = nb * 16 + r16;
+    const bool n_ok = n < p.N;
+    if constexpr (SLAB) {
+      float* ep = reinterpret_cast<float*>(smem) + (wave * 2 + b) * (ROWS * 20);
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ep[(16 * mb + 4 * kg + r) * 20 + r16] = acc[b][mb][r];
+      wait_lgkmcnt0();
+      float* dst = slabs + (int64_t)blockIdx.y * p.M * p.N;
+      for (int c = lane; c < ROWS * 4; c += 64) {
+        const int m = c >> 2, q = c & 3;
+        const int nn = nb * 16 + q * 4;
+        if (m < p.M && nn < p.N)
+          *reinterpret_cast<f32x4*>(dst + (int64_t)m * p.N + nn) = *reinterpret_cast<const f32x4*>(ep + m * 20 + q * 4);
+      }
+    } else {
+      _Float16* ep = reinterpret_cast<_Float16*>(smem) + (wave * 2 + b) * (ROWS * 24);
+      const float bv = p.bias ? (float)reinterpret_cast<const _Float16*>(p.bias)[n_ok ? n : p.N - 1] : 0.f;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ep[(16 * mb + 4 * kg + r) * 24 + r16] = (_Float16)(acc[b][mb][r] + bv);
+      wait_lgkmcnt0();
+      for (int c = lane; c < ROWS * 2; c += 64) {
+        const int m = c >> 1, half = c & 1;
+        const int nn = nb * 16 + half * 8;
+        if (m < p.M && nn < p.N)
+          *reinterpret_cast<uint4*>(reinterpret_cast<_Float16*>(p.out) + (int64_t)m * p.N + nn) =
+              *reinterpret_cast<const uint4*>(ep + m * 24 + half * 8);
+      }
+    }
+  }
+}
+
+// Sum of the K slices (in slice order) + bias.  64-thread workgroups: the slabs (SK x M x N floats, several MB) come
+// from beyond this XCD's L2 and a CU draws only ~10 B/clk from there, so the read is spread over as many CUs as there
+// are 512-element pieces (round 3: 256-thread workgroups left half of the chip idle at N = 4096: 4.3-4.6 us per launch).
+__global__ __launch_bounds__(64) void awq_packed_finalize_kernel(AwqPArgs p, const float* slabs, int SK) {
+  const int64_t total = (int64_t)p.M * p.N / 8;
+  const int64_t sstride = (int64_t)p.M * p.N;
+  for (int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 64) {
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int s0 = 0; s0 < SK; s0 += 4) {  // four slices in flight; sums in slice order
+      f32x4 a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float* src = slabs + (int64_t)(s0 + u < SK ? s0 + u : SK - 1) * sstride + i * 8;
+        a[u] = *reinterpret_cast<const f32x4*>(src);
+        b[u] = *reinterpret_cast<const f32x4*>(src + 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (s0 + u < SK) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[j] += a[u][j];
+            v[4 + j] += b[u][j];
+          }
+        }
     }
     const int64_t e = i * 8;
     const int nn = (int)(e % p.N);
@@ -350,13 +585,86 @@ int launch_ph(const AwqPArgs& p, float* slabs, int SK, int pps, int nc, int grou
   int rc = check_hip(hipGetLastError(), "awq_wstream launch");
   if (rc || !SLAB) return rc;
   const int64_t total = (int64_t)p.M * p.N / 8;
-  hipLaunchKernelGGL(awq_packed_finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p,
+  hipLaunchKernelGGL(awq_packed_finalize_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, s, p,
                      (const float*)slabs, SK);
   return check_hip(hipGetLastError(), "awq_packed_finalize launch");
 }
 
+template <int MB, int PH, int PB, bool SLAB>
+int launch2_ph(const AwqPArgs& p, float* slabs, int SK, int pps, int nc, int groups, hipStream_t s) {
+  auto kern = awq_wstream2_kernel<MB, PH, PB, SLAB>;
+  constexpr int lds = 2 * PH * 16 * MB * 256;
+  static int attr_rc = check_hip(
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
+      "hipFuncSetAttribute");
+  if (attr_rc) return attr_rc;
+  hipLaunchKernelGGL(kern, dim3((unsigned)groups, (unsigned)SK), dim3(64 * (nc + 1)), lds, s, p, slabs, pps);
+  int rc = check_hip(hipGetLastError(), "awq_wstream2 launch");
+  if (rc || !SLAB) return rc;
+  const int64_t total = (int64_t)p.M * p.N / 8;
+  hipLaunchKernelGGL(awq_packed_finalize_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, s, p,
+                     (const float*)slabs, SK);
+  return check_hip(hipGetLastError(), "awq_packed_finalize launch");
+}
+
+// The two-blocks-per-wave kernel: (phase length, consumer waves <= 4, K slices) by the same reasoning as launch() below --
+// one workgroup per CU, fewest weight bytes on the busiest CU -- with the per-workgroup fixed cost weighing two "waves".
+template <int MB>
+int launch2(const AwqPArgs& p, float* slabs, int64_t slab_floats, hipStream_t s, bool& used) {
+  used = false;
+  const int steps = p.K >> 7;
+  const int units = ((p.N + 15) / 16 + 1) / 2;
+  constexpr int PH_BIG = 16 / MB;
+  const int ph = (steps % PH_BIG == 0) ? PH_BIG : 4;
+  if (steps % ph != 0) return 0;
+  const int P = steps / ph;
+  static const int force_nc = [] { const char* e = getenv("SGL_MI355_AWQ2_NC"); return e ? atoi(e) : 0; }();  // tuning aid
+  int nc = 0, SK = 1, pps = 0, best = 1 << 30;
+  for (int c = 4; c >= 2; --c) {
+    if (force_nc && c != force_nc) continue;
+    const int groups_c = (units + c - 1) / c;
+    int sk = 1, pp = P;
+    if (slabs != nullptr && groups_c < 200) {
+      int sk_max = 256 / groups_c;
+      if (sk_max > P) sk_max = P;
+      if (sk_max < 1) sk_max = 1;
+      pp = (P + sk_max - 1) / sk_max;
+      sk = (P + pp - 1) / pp;
+      if ((int64_t)sk * p.M * p.N > slab_floats) { sk = 1; pp = P; }
+    }
+    const int rounds = (groups_c * sk + 255) / 256;
+    const int cost = rounds * pp * ph * (c + 2) + (sk > 1 ? 40 : 0);  // + the finalize launch
+    if (cost < best) { best = cost; nc = c; SK = sk; pps = pp; }
+  }
+  if (nc == 0) return 0;
+  const int groups = (units + nc - 1) / nc;
+  const bool pb8 = (pps * ph) % 8 == 0;
+  used = true;
+#define AWQ2_GO(PH_, PB_)                                                                          \
+  return SK > 1 ? launch2_ph<MB, PH_, PB_, true>(p, slabs, SK, pps, nc, groups, s)                 \
+                : launch2_ph<MB, PH_, PB_, false>(p, nullptr, 1, pps, nc, groups, s)
+  if constexpr (PH_BIG > 4) { if (ph == PH_BIG) AWQ2_GO(PH_BIG, 8); }
+  if (pb8) AWQ2_GO(4, 8);
+  AWQ2_GO(4, 4);
+#undef AWQ2_GO
+}
+
 template <int MB>
 int launch(const AwqPArgs& p, float* slabs, int64_t slab_floats, hipStream_t s) {
+  // Which kernel (same box, M = 1 / 16 / 64, us, v2 vs v1, profiles/r03_awq_v2_points.txt): 4096 -> 22016 17.0 / 17.5 / 24.7 vs
+  // 17.2 / 17.6 / 25.5; 11008 -> 4096 12.6 / 14.4 / 19.2 vs 12.9 / 13.3 / 22.0; 4096 -> 12288 13.8 / 14.2 / 19.8 vs 13.2 / 13.6 /
+  // 19.7; 4096 -> 4096 11.6 / 12.5 / 15.5 vs 8.5 / 8.9 / 13.2.  The two-blocks-per-wave kernel wins where a workgroup has a
+  // long K walk (unsplit wide N, or long K at M > 32), the shallow one where a slice is a handful of steps.
+  // SGL_MI355_AWQ_V1=1 / SGL_MI355_AWQ_V2=1 force one of them (A/B aid).
+  static const bool v1 = getenv("SGL_MI355_AWQ_V1") != nullptr;
+  static const bool v2 = getenv("SGL_MI355_AWQ_V2") != nullptr;
+  const bool wide = (p.N + 15) / 16 >= 2 * 3 * 200;          // >= 200 workgroups of three 32-column units without splitting K
+  const bool long_k = (p.K >> 7) >= 64 && MB == 4;           // K >= 8192 at M > 32
+  if (!v1 && (v2 || wide || long_k)) {
+    bool used = false;
+    const int rc = launch2<MB>(p, slabs, slab_floats, s, used);
+    if (used || rc) return rc;
+  }
   const int steps = p.K >> 7;
   const int nblocks = (p.N + 15) / 16;
   // (PH, consumer waves, K slices) as in gemm_fp8.hip launch_wstream: fewest k-steps on the busiest CU.

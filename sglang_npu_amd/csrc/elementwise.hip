@@ -912,6 +912,49 @@ extern "C" int sgl_mi355_rotary_embedding_set_kv_from_partials_fp8kv_e5m2(
                                     kb_stride_n, kb_stride_h, vb_stride_n, vb_stride_h, is_neox, dtype, stream);
 }
 
+// Vocab-parallel embedding lookup (VocabParallelEmbedding.forward, vocab_parallel_embedding.py:462-486 with
+// get_masked_input_and_mask :126-150, original vocabulary only): out[t] = table[id - vocab_start] if vocab_start <= id <
+// vocab_end else 0 -- the masked gather + masked_fill_ of the reference in one pass; the caller all-reduces over the TP ranks.
+namespace sglm {
+namespace {
+template <typename IdT>
+__global__ __launch_bounds__(256) void vocab_embedding_kernel(const uint4* __restrict__ table, const IdT* __restrict__ ids,
+                                                              uint4* __restrict__ out, int64_t row_vec, int64_t vocab_start,
+                                                              int64_t vocab_end) {
+  const int64_t t = blockIdx.x;
+  const int64_t id = (int64_t)ids[t];
+  const bool mine = id >= vocab_start && id < vocab_end;
+  const uint4* src = table + (mine ? id - vocab_start : 0) * row_vec;
+  uint4* dst = out + t * row_vec;
+  for (int64_t i = threadIdx.x; i < row_vec; i += 256) dst[i] = mine ? src[i] : uint4{0u, 0u, 0u, 0u};
+}
+}  // namespace
+}  // namespace sglm
+
+extern "C" int sgl_mi355_vocab_parallel_embedding(const void* table, const void* ids, int ids_is64, void* out,
+                                                  int64_t num_tokens, int64_t hidden, int64_t vocab_start, int64_t vocab_end,
+                                                  int64_t table_rows, int elem_size, void* stream) {
+  SGLM_CHECK_ARG(num_tokens >= 0 && num_tokens < (1ll << 31) && hidden > 0 && (elem_size == 2 || elem_size == 4) &&
+                     (hidden * elem_size) % 16 == 0,
+                 "vocab_parallel_embedding: hidden * element size (%ld x %d) must be a multiple of 16 bytes", (long)hidden, elem_size);
+  SGLM_CHECK_ARG(vocab_start >= 0 && vocab_end >= vocab_start && vocab_end - vocab_start <= table_rows,
+                 "vocab_parallel_embedding: the shard [%ld, %ld) does not fit a table of %ld rows", (long)vocab_start,
+                 (long)vocab_end, (long)table_rows);
+  if (num_tokens == 0) return 0;
+  SGLM_CHECK_ARG(table && ids && out, "vocab_parallel_embedding: null tensor pointer");
+  SGLM_CHECK_ARG(reinterpret_cast<uintptr_t>(table) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0,
+                 "vocab_parallel_embedding: table and out must be 16-byte aligned");
+  const int64_t row_vec = hidden * elem_size / 16;
+  hipStream_t s = as_stream(stream);
+  if (ids_is64)
+    hipLaunchKernelGGL(vocab_embedding_kernel<int64_t>, dim3((unsigned)num_tokens), dim3(256), 0, s, (const uint4*)table,
+                       (const int64_t*)ids, (uint4*)out, row_vec, vocab_start, vocab_end);
+  else
+    hipLaunchKernelGGL(vocab_embedding_kernel<int32_t>, dim3((unsigned)num_tokens), dim3(256), 0, s, (const uint4*)table,
+                       (const int32_t*)ids, (uint4*)out, row_vec, vocab_start, vocab_end);
+  return check_hip(hipGetLastError(), "vocab_parallel_embedding launch");
+}
+
 extern "C" int sgl_mi355_argmax(const void* logits, int64_t* out, void* workspace, int64_t rows, int64_t cols,
                                 int64_t row_stride, int dtype, void* stream) {
   SGLM_CHECK_ARG(dtype == SGL_MI355_BF16 || dtype == SGL_MI355_FP16 || dtype == 2, "argmax: dtype must be bf16 (0), fp16 (1) or fp32 (2)");

@@ -28,6 +28,9 @@ struct G16Args {
   void* out;         // [M][N] 16-bit
   int M, N, KB;      // KB = K * 2: contraction length in BYTES (128 per k-step)
   int throttle;      // producer: k-steps of activation DMA allowed in flight (0 = the whole phase at once)
+  int b_shuf;        // weights are FRAGMENT-MAJOR (round 3): the 2 KiB of a (16-column block, 64-k step) stored as
+                     // [half][lane group g][row r16][16 B] -- the byte layout of the pre-shuffled FP8 weights
+                     // (include/sgl_mi355.h), so a wave's load instruction covers one contiguous KiB
 };
 
 union Seg32 {  // this lane's 2 x 16 B of a 128-B row segment = two MFMA operands
@@ -35,13 +38,17 @@ union Seg32 {  // this lane's 2 x 16 B of a 128-B row segment = two MFMA operand
   i32x4 x[2];
 };
 
+template <bool SHUF>
 __device__ __forceinline__ void wload(Seg32& f, const uint8_t* sbase, uint32_t voff) {
   asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(f.x[0]) : "v"(voff), "s"(sbase) : "memory");
-  asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=v"(f.x[1]) : "v"(voff), "s"(sbase) : "memory");
+  if constexpr (SHUF) asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(f.x[1]) : "v"(voff), "s"(sbase) : "memory");
+  else asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=v"(f.x[1]) : "v"(voff), "s"(sbase) : "memory");
 }
+template <bool SHUF>
 __device__ __forceinline__ void wload_nt(Seg32& f, const uint8_t* sbase, uint32_t voff) {
   asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(f.x[0]) : "v"(voff), "s"(sbase) : "memory");
-  asm volatile("global_load_dwordx4 %0, %1, %2 offset:64 nt" : "=v"(f.x[1]) : "v"(voff), "s"(sbase) : "memory");
+  if constexpr (SHUF) asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024 nt" : "=v"(f.x[1]) : "v"(voff), "s"(sbase) : "memory");
+  else asm volatile("global_load_dwordx4 %0, %1, %2 offset:64 nt" : "=v"(f.x[1]) : "v"(voff), "s"(sbase) : "memory");
 }
 template <int N, int NB>
 __device__ __forceinline__ void wait_segs(Seg32 (&f)[NB]) {
@@ -61,7 +68,7 @@ __device__ __forceinline__ void drain_segs(Seg32 (&q)[PB][NB]) {
     for (int j = 0; j < NB; ++j) asm volatile("" ::"v"(q[i][j].x[0]), "v"(q[i][j].x[1]));
 }
 
-template <int DTYPE, int MB, int PH, bool NT, int NB, int PB = 2>
+template <int DTYPE, int MB, int PH, bool NT, int NB, int PB = 2, bool SHUF = false>
 __global__ __launch_bounds__(576) void gemm16_wstream_kernel(G16Args p) {
   static_assert(PH * MB <= 32, "one A buffer is at most 64 KiB");
   using H = Half16<DTYPE>;
@@ -126,7 +133,10 @@ __global__ __launch_bounds__(576) void gemm16_wstream_kernel(G16Args p) {
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     const int n = (nb0 + j) * 16 + r16;
-    lane_off[j] = (uint32_t)((int64_t)(n < p.N ? n : 0) * p.b_sn + 16 * g);
+    if constexpr (SHUF)  // block nb starts at nb * (K / 64) * 2 KiB; the lane's 16 bytes of a KiB sit at lane * 16
+      lane_off[j] = (uint32_t)((int64_t)((nb0 + j) * 16 < p.N ? nb0 + j : 0) * (p.KB >> 7) * 2048 + lane * 16);
+    else
+      lane_off[j] = (uint32_t)((int64_t)(n < p.N ? n : 0) * p.b_sn + 16 * g);
   }
   const int rot = (nb0 * 3) & (PH - 1);  // per-wave rotation of the sweep inside a phase
   const int last = nph * PH - 1;
@@ -140,8 +150,9 @@ __global__ __launch_bounds__(576) void gemm16_wstream_kernel(G16Args p) {
     const int ks = (f & ~(PH - 1)) + ((f + rot) & (PH - 1));
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-      if constexpr (NT) wload_nt(fr[j], p.b + ((int64_t)ks << 7), lane_off[j]);
-      else wload(fr[j], p.b + ((int64_t)ks << 7), lane_off[j]);
+      const uint8_t* sb = p.b + ((int64_t)ks << (SHUF ? 11 : 7));
+      if constexpr (NT) wload_nt<SHUF>(fr[j], sb, lane_off[j]);
+      else wload<SHUF>(fr[j], sb, lane_off[j]);
     }
     ++f_pf;
   };
@@ -201,20 +212,9 @@ __global__ __launch_bounds__(576) void gemm16_wstream_kernel(G16Args p) {
   }
 }
 
-template <int DTYPE, int MB, int PH, bool NT, int NB>
-int launch16_ph(const G16Args& p, int nc, int groups, hipStream_t s) {
-  static const int pb_env = [] { const char* e = getenv("SGL_MI355_GEMM16_PB"); return e ? atoi(e) : 2; }();  // A/B aid
-  if constexpr (PH >= 4 && NB == 1 && !NT) {
-    if (pb_env == 4) {
-      auto k4 = gemm16_wstream_kernel<DTYPE, MB, PH, NT, NB, 4>;
-      constexpr int lds4 = 2 * PH * 16 * MB * 128;
-      static int rc4 = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(k4), hipFuncAttributeMaxDynamicSharedMemorySize, lds4), "hipFuncSetAttribute");
-      if (rc4) return rc4;
-      hipLaunchKernelGGL(k4, dim3((unsigned)groups), dim3(64 * (nc + 1)), lds4, s, p);
-      return check_hip(hipGetLastError(), "gemm16_wstream launch");
-    }
-  }
-  auto kern = gemm16_wstream_kernel<DTYPE, MB, PH, NT, NB>;
+template <int DTYPE, int MB, int PH, bool NT, int NB, int PB, bool SHUF>
+int launch16_k(const G16Args& p, int nc, int groups, hipStream_t s) {
+  auto kern = gemm16_wstream_kernel<DTYPE, MB, PH, NT, NB, PB, SHUF>;
   constexpr int lds = 2 * PH * 16 * MB * 128;
   static int attr_rc = check_hip(
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
@@ -224,13 +224,30 @@ int launch16_ph(const G16Args& p, int nc, int groups, hipStream_t s) {
   return check_hip(hipGetLastError(), "gemm16_wstream launch");
 }
 
+template <int DTYPE, int MB, int PH, bool NT, int NB>
+int launch16_ph(const G16Args& p, int nc, int groups, hipStream_t s) {
+  static const int pb_env = [] { const char* e = getenv("SGL_MI355_GEMM16_PB"); return e ? atoi(e) : 0; }();  // A/B aid
+  if constexpr (NB == 1) {
+    if (p.b_shuf) {  // fragment-major weights: contiguous 1-KiB loads
+      if constexpr (PH >= 4) {
+        if (pb_env == 4) return launch16_k<DTYPE, MB, PH, NT, 1, 4, true>(p, nc, groups, s);
+      }
+      return launch16_k<DTYPE, MB, PH, NT, 1, 2, true>(p, nc, groups, s);
+    }
+  }
+  if constexpr (PH >= 4 && NB == 1 && !NT) {
+    if (pb_env == 4) return launch16_k<DTYPE, MB, PH, NT, NB, 4, false>(p, nc, groups, s);
+  }
+  return launch16_k<DTYPE, MB, PH, NT, NB, 2, false>(p, nc, groups, s);
+}
+
 template <int DTYPE, int MB>
 int launch16(const G16Args& p, hipStream_t s) {
   const int steps = p.KB >> 7;
   // two column blocks per wave at 64 rows and wide N (SGL_MI355_GEMM16_NB=1|2: A/B aid)
   static const int nb_env = [] { const char* e = getenv("SGL_MI355_GEMM16_NB"); return e ? atoi(e) : 0; }();
   constexpr bool kCanNB2 = MB == 4;
-  const bool nb2 = kCanNB2 && nb_env == 2;  // measured (LM head, M = 64): 243 us vs 218 with one block per wave -- off by default
+  const bool nb2 = kCanNB2 && nb_env == 2 && !p.b_shuf;  // measured (LM head, M = 64): 243 us vs 218 with one block per wave -- off by default
   const int nblocks = ((p.N + 15) / 16 + (nb2 ? 1 : 0)) / (nb2 ? 2 : 1);  // units of NB column blocks
   // Phase length.  At 64 rows FOUR k-steps (2 x 32 KiB of LDS: two workgroups per CU) beat eight (one workgroup per CU)
   // and two: LM head 4096 x 128256, same box, M = 64: PH 8 / 4 / 2 = 234 / 218 / 245 us (hipBLASLt 210).  Fewer rows take
@@ -277,12 +294,13 @@ int launch16(const G16Args& p, hipStream_t s) {
 
 using namespace sglm;
 
-extern "C" int sgl_mi355_gemm16_nt(const void* x, const void* weight, const void* bias, void* out, int64_t M, int64_t N,
-                                   int64_t K, int64_t x_stride_m, int64_t w_stride_n, int dtype, void* stream) {
+static int gemm16_impl(const void* x, const void* weight, const void* bias, void* out, int64_t M, int64_t N, int64_t K,
+                       int64_t x_stride_m, int64_t w_stride_n, int b_shuf, int dtype, void* stream) {
   SGLM_CHECK_ARG(dtype == SGL_MI355_BF16 || dtype == SGL_MI355_FP16, "gemm16_nt: dtype must be bfloat16 or float16");
   SGLM_CHECK_ARG(M >= 0 && M <= 64, "gemm16_nt: the weight-streaming kernel takes M <= 64 rows (got %ld)", (long)M);
   SGLM_CHECK_ARG(N > 0 && N % 8 == 0 && K > 0 && K % 256 == 0 && N < (1ll << 31) && K < (1ll << 30),
                  "gemm16_nt: N %% 8 == 0 and K %% 256 == 0 required (N=%ld K=%ld)", (long)N, (long)K);
+  SGLM_CHECK_ARG(!b_shuf || N % 16 == 0, "gemm16_nt (pre-shuffled weight): N %% 16 == 0 required (N=%ld)", (long)N);
   SGLM_CHECK_ARG(x_stride_m >= K && w_stride_n >= K && x_stride_m % 8 == 0 && w_stride_n % 8 == 0,
                  "gemm16_nt: row strides must be >= K and multiples of 8 elements");
   SGLM_CHECK_ARG(N * w_stride_n * 2 < (1ll << 32), "gemm16_nt: weight larger than 4 GiB (32-bit lane offsets)");
@@ -291,7 +309,8 @@ extern "C" int sgl_mi355_gemm16_nt(const void* x, const void* weight, const void
   SGLM_CHECK_ARG(reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(weight) % 16 == 0 &&
                      reinterpret_cast<uintptr_t>(out) % 16 == 0, "gemm16_nt: operands must be 16-byte aligned");
   static const int throttle = [] { const char* e = getenv("SGL_MI355_GEMM16_THROTTLE"); return e ? atoi(e) : 0; }();  // A/B aid
-  G16Args p{(const uint8_t*)x, x_stride_m * 2, (const uint8_t*)weight, w_stride_n * 2, bias, out, (int)M, (int)N, (int)(K * 2), throttle};
+  G16Args p{(const uint8_t*)x, x_stride_m * 2, (const uint8_t*)weight, w_stride_n * 2, bias, out, (int)M, (int)N, (int)(K * 2),
+            throttle, b_shuf};
   hipStream_t s = as_stream(stream);
 #define G16_D(D)                                   \
   do {                                             \
@@ -302,4 +321,16 @@ extern "C" int sgl_mi355_gemm16_nt(const void* x, const void* weight, const void
   if (dtype == SGL_MI355_BF16) G16_D(SGL_MI355_BF16);
   G16_D(SGL_MI355_FP16);
 #undef G16_D
+}
+
+extern "C" int sgl_mi355_gemm16_nt(const void* x, const void* weight, const void* bias, void* out, int64_t M, int64_t N,
+                                   int64_t K, int64_t x_stride_m, int64_t w_stride_n, int dtype, void* stream) {
+  return gemm16_impl(x, weight, bias, out, M, N, K, x_stride_m, w_stride_n, 0, dtype, stream);
+}
+
+// The same product on a weight re-laid by sgl_mi355_fp8_shuffle_weight applied to its BYTES ([N][2 K] bytes: the
+// fragment-major layout is defined on 128-byte k-steps, i.e. 64 16-bit values): N % 16 == 0, K % 256 == 0.
+extern "C" int sgl_mi355_gemm16_nt_wshuffled(const void* x, const void* weight_shuffled, const void* bias, void* out, int64_t M,
+                                             int64_t N, int64_t K, int64_t x_stride_m, int dtype, void* stream) {
+  return gemm16_impl(x, weight_shuffled, bias, out, M, N, K, x_stride_m, K, 1, dtype, stream);
 }

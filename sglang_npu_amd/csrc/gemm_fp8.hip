@@ -144,6 +144,9 @@ union Frag32 {  // 32 contiguous K bytes of one row = four MFMA operands
 #endif
 // timing ablations of fp8_gemm_wstream_kernel (WRONG RESULTS; tools/ab_variants.py only): no phase barriers / no LDS
 // reads + MFMA / another weight-queue depth
+#ifndef SGLM_ABL_SHUF
+#define SGLM_ABL_SHUF 0
+#endif
 #ifndef SGLM_WS_ABL_NOBAR
 #define SGLM_WS_ABL_NOBAR 0
 #endif
@@ -2145,9 +2148,11 @@ static int fp8_scaled_mm_impl(
   GemmArgs p{(const uint8_t*)mat_a, a_stride_m, (const uint8_t*)mat_b, b_stride_n, scales_a, scales_b, bias, out,
              (int)M, (int)N, (int)K};
   p.b_shuf = b_shuf;
+#if SGLM_ABL_SHUF  // variant builds only (-DSGLM_ABL_SHUF=1), never in the default library
   // timing ablation (WRONG RESULTS): read a row-major weight as if it were pre-shuffled -- same bytes, contiguous loads
   static const bool abl_shuf = getenv("SGL_MI355_ABL_SHUF") != nullptr;
   if (abl_shuf && shuffle_shape_ok(N, K)) p.b_shuf = 1;
+#endif
   hipStream_t s = as_stream(stream);
   return out_dtype == SGL_MI355_BF16 ? run_gemm<SGL_MI355_BF16>(p, workspace, workspace_floats, s)
                                      : run_gemm<SGL_MI355_FP16>(p, workspace, workspace_floats, s);
@@ -2193,8 +2198,10 @@ static int fp8_scaled_mm_partials_impl(int b_shuf, const void* mat_a, const void
   GemmArgs p{(const uint8_t*)mat_a, a_stride_m, (const uint8_t*)mat_b, b_stride_n, nullptr, nullptr, nullptr, nullptr,
              (int)M, (int)N, (int)K};
   p.b_shuf = b_shuf;
-  static const bool abl_shuf = getenv("SGL_MI355_ABL_SHUF") != nullptr;  // timing ablation, see fp8_scaled_mm_impl
+#if SGLM_ABL_SHUF  // timing ablation, see fp8_scaled_mm_impl
+  static const bool abl_shuf = getenv("SGL_MI355_ABL_SHUF") != nullptr;
   if (abl_shuf && shuffle_shape_ok(N, K)) p.b_shuf = 1;
+#endif
   hipStream_t s = as_stream(stream);
   bool used = false;
   int sk = 0;

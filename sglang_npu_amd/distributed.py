@@ -26,6 +26,13 @@ import torch.distributed as dist
 
 logger = logging.getLogger(__name__)
 
+# How many collectives each data plane took since the last clear() -- bench.py reports it per step so that the first
+# multi-GPU run shows which backend every one of the 2 x layers + 1 all-reduces went through (keys: 'quickreduce',
+# 'p2p', 'p2p+norm', 'p2p+norm(partials)', 'rccl', 'stub').  Counted where Python dispatches, i.e. once per capture of a
+# graph, not per replay.
+import collections  # noqa: E402
+DISPATCH_COUNTS: "collections.Counter[str]" = collections.Counter()
+
 
 class AllReduceHandle:
     def __init__(self, tensor, event=None, stream=None):
@@ -102,6 +109,7 @@ class CustomAllreduce:
         self.disabled = True
         self._comm = None
         self.init_error: Optional[str] = None
+        self._norm_h: Optional[int] = None  # row length the fused all-reduce + norm staging area is bound to
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world_size = dist.get_world_size(group) if world_size is None else world_size
         self.max_size = max_size
@@ -167,6 +175,7 @@ class CustomAllreduce:
             self.disabled = True
             raise RuntimeError("custom all-reduce: a peer did not reach the barrier in time; the affected outputs were "
                                "filled with NaN and this communicator is disabled")
+        DISPATCH_COUNTS["p2p"] += 1
         out = torch.empty_like(inp)
         code = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}[inp.dtype]
         ct = self._ct
@@ -182,12 +191,20 @@ class CustomAllreduce:
             return False
         H = inp.size(1)
         return inp.dtype in (torch.bfloat16, torch.float16) and H % (8 * self.world_size) == 0 and H <= 16384 and \
-            0 < inp.numel() * 2 <= self.max_size
+            0 < inp.numel() * 2 <= self.max_size and self._norm_h in (None, H)
 
     def should_fuse_norm_shape(self, T: int, H: int, dtype: torch.dtype) -> bool:
         """should_fuse_norm for a [T, H] addend that does not exist as a tensor yet (split-K partials)."""
         return (not self.disabled) and dtype in (torch.bfloat16, torch.float16) and H % (8 * self.world_size) == 0 and \
-            H <= 16384 and 0 < T * H * 2 <= self.max_size
+            H <= 16384 and 0 < T * H * 2 <= self.max_size and self._norm_h in (None, H)
+
+    def rebind_fused_norm(self):
+        """Forget the row length the fused-norm staging area is bound to (sgl_mi355_ar_rebind_norm).  Collective in
+        spirit: only while no call of this communicator is in flight on any rank (after a group barrier)."""
+        from . import _lib
+        if self._comm is not None:
+            _lib.check(self._lib.sgl_mi355_ar_rebind_norm(self._comm))
+        self._norm_h = None
 
     def fused_add_rmsnorm_partials(self, part, residual: torch.Tensor, weight: torch.Tensor, eps: float,
                                    quant_fp8: bool = False):
@@ -199,7 +216,9 @@ class CustomAllreduce:
             self.disabled = True
             raise RuntimeError("custom all-reduce: a peer did not reach the barrier in time; the affected outputs were "
                                "filled with NaN and this communicator is disabled")
+        DISPATCH_COUNTS["p2p+norm(partials)"] += 1
         T, H = part.M, part.N
+        self._norm_h = H
         ct = self._ct
         dev = residual.device
         out = q = s = None
@@ -227,7 +246,9 @@ class CustomAllreduce:
             self.disabled = True
             raise RuntimeError("custom all-reduce: a peer did not reach the barrier in time; the affected outputs were "
                                "filled with NaN and this communicator is disabled")
+        DISPATCH_COUNTS["p2p+norm"] += 1
         T, H = inp.shape
+        self._norm_h = H
         ct = self._ct
         out = q = s = None
         if quant_fp8:
@@ -326,6 +347,7 @@ class QuickAllReduce:
             ca.disabled = True
             raise RuntimeError("quick all-reduce: a peer did not reach the barrier in time; the affected outputs were "
                                "filled with NaN and this communicator is disabled")
+        DISPATCH_COUNTS["quickreduce"] += 1
         if out is None:
             out = torch.empty_like(inp)
         ct = ca._ct
@@ -360,6 +382,8 @@ class GroupCoordinator:
     def all_reduce(self, input_: torch.Tensor) -> torch.Tensor:
         """SUM over the TP ranks (in place, like the pynccl path parallel_state.py:563-568)."""
         if self.world_size == 1 or self.stub_all_reduce:
+            if self.world_size > 1:
+                DISPATCH_COUNTS["stub"] += 1
             return input_
         # dispatch order of parallel_state.py:519-542: QuickReduce, then the custom P2P all-reduce, if they accept the
         # tensor, else RCCL
@@ -370,6 +394,7 @@ class GroupCoordinator:
             out = self.ca_comm.custom_all_reduce(input_)
             if out is not None:
                 return out
+        DISPATCH_COUNTS["rccl"] += 1
         dist.all_reduce(input_, group=self.device_group)
         return input_
 
@@ -459,7 +484,9 @@ def _bring_up_custom_ar(tp: "GroupCoordinator", make_comm, verify: bool = True, 
     if ok and verify:
         qr = QuickAllReduce(ca)
         steps = (steps_of or _verification_steps)(ca, qr, tp)
-        ok = _run_lockstep(tp, steps)
+        ok = _run_lockstep(tp, steps)  # (ends with a group agreement behind device synchronisations: nothing in flight)
+        if ok and hasattr(ca, "rebind_fused_norm"):
+            ca.rebind_fused_norm()     # the self-check used a row length of its own; the model binds its own H
     if ok:
         tp.ca_comm = ca
         tp.qr_comm = QuickAllReduce(ca)  # disabled unless ROCM_QUICK_REDUCE_QUANTIZATION asks for a regime

@@ -4,6 +4,7 @@
   SiluAndMul       python/sglang/srt/layers/activation.py:59-83
   RotaryEmbedding  python/sglang/srt/layers/rotary_embedding.py:79-260 (fp32 cos/sin cache, neox)
   Sampler (greedy) python/sglang/srt/layers/sampler.py:72-75       (ops.argmax: first maximal index, like torch.argmax)
+  VocabParallelEmbedding  python/sglang/srt/layers/vocab_parallel_embedding.py:153-486 (original vocabulary only)
 """
 from __future__ import annotations
 
@@ -81,3 +82,58 @@ class RotaryEmbedding(torch.nn.Module):
 def greedy_sample(logits: torch.Tensor) -> torch.Tensor:
     """Sampler.forward with temperature 0 (sampler.py:72-75): argmax over the vocabulary."""
     return ops.argmax(logits.view(-1, logits.shape[-1]))
+
+
+DEFAULT_VOCAB_PADDING_SIZE = 64  # vocab_parallel_embedding.py:36
+
+
+def pad_vocab_size(vocab_size: int, pad_to: int = DEFAULT_VOCAB_PADDING_SIZE) -> int:
+    """vocab_parallel_embedding.py:44-46."""
+    return ((vocab_size + pad_to - 1) // pad_to) * pad_to
+
+
+def vocab_shard_range(org_vocab_size: int, padded_vocab_size: int, rank: int, world: int):
+    """The original-vocabulary part of VocabParallelEmbedding._get_indices (vocab_parallel_embedding.py:49-62, 273-322):
+    the padded vocabulary is cut into `world` equal parts; a rank holds the real entries of its part.
+    Returns (org_vocab_start, org_vocab_end, rows_per_partition)."""
+    if padded_vocab_size % world != 0:
+        raise ValueError(f"padded vocabulary {padded_vocab_size} is not divisible by the TP size {world}")
+    per = padded_vocab_size // world
+    start = min(rank * per, org_vocab_size)
+    end = min((rank + 1) * per, org_vocab_size)
+    return start, end, per
+
+
+class VocabParallelEmbedding(torch.nn.Module):
+    """Embedding cut along the vocabulary over the TP ranks (vocab_parallel_embedding.py:153-486, original vocabulary
+    only -- no added / LoRA entries): `weight` [padded_vocab / tp, H] holds rows [org_vocab_start, org_vocab_end) of the
+    table (+ zero padding); forward = masked gather + masked fill (one kernel) + all-reduce over the TP group (:462-486)."""
+
+    def __init__(self, num_embeddings: int, embedding_dim: int, params_dtype=torch.bfloat16,
+                 padding_size: int = DEFAULT_VOCAB_PADDING_SIZE):
+        super().__init__()
+        from .distributed import get_tensor_model_parallel_rank, get_tensor_model_parallel_world_size
+        self.tp_size, self.tp_rank = get_tensor_model_parallel_world_size(), get_tensor_model_parallel_rank()
+        self.org_vocab_size, self.embedding_dim = num_embeddings, embedding_dim
+        # padded so that every rank gets whole blocks of `padding_size` rows (:203-216 pads to padding_size and asserts
+        # the divisibility; padding_size * tp makes it hold for any vocabulary)
+        self.num_embeddings_padded = pad_vocab_size(num_embeddings, padding_size * self.tp_size)
+        self.org_vocab_start_index, self.org_vocab_end_index, self.num_embeddings_per_partition = vocab_shard_range(
+            num_embeddings, self.num_embeddings_padded, self.tp_rank, self.tp_size)
+        self.weight = torch.nn.Parameter(torch.zeros(self.num_embeddings_per_partition, embedding_dim, dtype=params_dtype),
+                                         requires_grad=False)
+        self.weight.weight_loader = self.weight_loader
+
+    def weight_loader(self, param, loaded_weight: torch.Tensor):
+        """The FULL [org_vocab, H] table -> this rank's rows, zero padding behind them (:405-460)."""
+        assert loaded_weight.shape[0] == self.org_vocab_size, (loaded_weight.shape, self.org_vocab_size)
+        n = self.org_vocab_end_index - self.org_vocab_start_index
+        param.data[:n].copy_(loaded_weight[self.org_vocab_start_index:self.org_vocab_end_index])
+        param.data[n:].fill_(0)
+
+    def forward(self, input_: torch.Tensor) -> torch.Tensor:
+        from .distributed import tensor_model_parallel_all_reduce
+        out = ops.vocab_parallel_embedding(input_, self.weight.data, self.org_vocab_start_index, self.org_vocab_end_index)
+        if self.tp_size > 1:
+            out = tensor_model_parallel_all_reduce(out)
+        return out

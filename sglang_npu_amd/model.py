@@ -27,7 +27,7 @@ from . import ops
 from .distributed import (AllReduceHandle, get_tensor_model_parallel_rank, get_tensor_model_parallel_world_size,
                           get_tp_group)
 from .harness import ForwardBatch, ModelConfig, RadixAttention
-from .layers import RMSNorm, RotaryEmbedding, SiluAndMul
+from .layers import RMSNorm, RotaryEmbedding, SiluAndMul, VocabParallelEmbedding
 from .linear import MergedColumnParallelLinear, QKVParallelLinear, RowParallelLinear
 from .quantization import AWQConfig, W8A8Fp8Config
 
@@ -65,7 +65,13 @@ FUSE_AR_NORM = not os.environ.get("SGL_MI355_NO_AR_FUSION")
 FUSE_QKV_ATTN = bool(os.environ.get("SGL_MI355_QKV_ATTN_FUSION"))
 
 
+# LM head (logits_processor.py:430-505): rows up to which the 16-bit weight streamer runs instead of the library GEMM.
+# Round 3: on the fragment-major copy of an UNTIED head (ops.linear16_shuffle_weight, built once after loading; the
+# row-major tensor stays for batches above 64 rows) the streamer is ahead of the library at every M <= 64
+# (profiles/r03_lm_head_points.jsonl); on a row-major weight it loses above 32 rows (213 vs 201 us at M = 64).
 LM_HEAD_STREAMER_MAX_ROWS = 32
+LM_HEAD_SHUFFLED_MAX_ROWS = int(os.environ.get("SGL_MI355_LM_HEAD_SHUFFLED_MAX_ROWS", "64"))
+SHUFFLE_LM_HEAD = not os.environ.get("SGL_MI355_NO_LM_HEAD_SHUFFLE")
 
 # SGL_MI355_ATTN_QUANT_FUSION=1: the per-token FP8 quant between the decode attention and o_proj folded into the two
 # (attention epilogue: row absmax by atomic max; o_proj GEMM: quantise while staging; bit-identical results).  OFF by
@@ -284,8 +290,10 @@ class LlamaForCausalLM(torch.nn.Module):
             self.layers = torch.nn.ModuleList(
                 [LlamaDecoderLayer(cfg, i, self.quant_config, dtype, device) for i in range(n_layers)])
             self.norm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps, dtype)
-        self.embed_tokens = None
+        self.embed = None
+        self.embed_tokens = None  # (TP = 1 only) the table as a plain tensor, for tests that read it
         self.lm_head = None
+        self.lm_head_shuffled = None
         self.with_lm_head = with_lm_head
 
     # ------------------------------------------------------------------ synthetic weights
@@ -313,10 +321,19 @@ class LlamaForCausalLM(torch.nn.Module):
             layer.input_layernorm.weight.data = _dummy((cfg.hidden_size,), dt, dev, 0.5, 1.5)
             layer.post_attention_layernorm.weight.data = _dummy((cfg.hidden_size,), dt, dev, 0.5, 1.5, seed=4321)
         self.norm.weight.data = _dummy((cfg.hidden_size,), dt, dev, 0.5, 1.5)
-        self.embed_tokens = _dummy((cfg.vocab_size, cfg.hidden_size), dt, dev, -1.0, 1.0, seed=99)
+        # vocab-parallel table (vocab_parallel_embedding.py): the FULL dummy table goes through the layer's loader, which
+        # keeps this rank's rows; forward = masked gather + all-reduce
+        self.embed = VocabParallelEmbedding(cfg.vocab_size, cfg.hidden_size, params_dtype=dt).to(dev)
+        self.embed.weight.weight_loader(self.embed.weight, _dummy((cfg.vocab_size, cfg.hidden_size), dt, dev, -1.0, 1.0, seed=99))
+        self.embed_tokens = self.embed.weight.data if get_tensor_model_parallel_world_size() == 1 else None
+        if self.embed_tokens is not None:
+            self.embed_tokens = self.embed_tokens[:cfg.vocab_size]
         if self.with_lm_head:
             full = _dummy((cfg.vocab_size, cfg.hidden_size), dt, dev, -2e-2, 2e-2, seed=77)
             self.lm_head = full[rank * self.vocab_per_rank:(rank + 1) * self.vocab_per_rank].contiguous()
+            self.lm_head_shuffled = None
+            if SHUFFLE_LM_HEAD and ops.linear16_shuffle_supported(self.lm_head.shape[0], self.lm_head.shape[1]):
+                self.lm_head_shuffled = ops.linear16_shuffle_weight(self.lm_head)
         return self
 
     def _fill_awq(self, lin):
@@ -330,7 +347,7 @@ class LlamaForCausalLM(torch.nn.Module):
 
     # ------------------------------------------------------------------ forward
     def forward(self, input_ids, positions, forward_batch: ForwardBatch):
-        hidden_states = self.embed_tokens[input_ids]
+        hidden_states = self.embed(input_ids)
         residual = None
         fused = self.fuse_quant and (forward_batch.forward_mode.is_decode() or forward_batch.forward_mode.is_extend())
         # (under tensor parallelism the row-parallel GEMMs decline -- the all-reduce needs their finished output --
@@ -386,8 +403,12 @@ class LlamaForCausalLM(torch.nn.Module):
             return hidden_states
         # LM head (logits_processor.py:430-505): the 16-bit weight streamer up to 32 rows (176 / 183 us at M = 1 / 16 on the
         # 128256 x 4096 head, library 181-184), the library GEMM above (M = 64: 200.6 us vs 212.6)
-        if hidden_states.shape[0] <= LM_HEAD_STREAMER_MAX_ROWS and \
-                ops.linear16_supported(hidden_states.shape[0], self.lm_head.shape[0], self.lm_head.shape[1]):
+        rows = hidden_states.shape[0]
+        if getattr(self, "lm_head_shuffled", None) is not None and rows <= min(64, LM_HEAD_SHUFFLED_MAX_ROWS):
+            logits = ops.linear16(hidden_states if hidden_states.is_contiguous() else hidden_states.contiguous(),
+                                  self.lm_head_shuffled)
+        elif rows <= LM_HEAD_STREAMER_MAX_ROWS and \
+                ops.linear16_supported(rows, self.lm_head.shape[0], self.lm_head.shape[1]):
             logits = ops.linear16(hidden_states, self.lm_head)
         else:
             logits = torch.matmul(hidden_states, self.lm_head.t())

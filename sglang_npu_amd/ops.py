@@ -795,10 +795,20 @@ def decode_attention_qkv_partials(part: GemmPartials, positions, cos_sin_cache, 
     return True
 
 
-def linear16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+def linear16(x: torch.Tensor, weight, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """F.linear(x, weight, bias) = x @ weight.T for decode-sized batches of 16-bit operands: the LM head of
     LogitsProcessor._get_logits (logits_processor.py:430-505) and unquantised decode linears.  x [M <= 64, K],
     weight [N, K] (K contiguous), both bf16 or both fp16."""
+    if isinstance(weight, ShuffledWeight16):
+        _need_gpu(x, weight.data, bias)
+        if x.dim() != 2 or x.stride(1) != 1 or x.dtype != weight.dtype or x.size(1) != weight.K:
+            raise RuntimeError("linear16: x [M,K] must match the shuffled weight's dtype and K")
+        M = x.size(0)
+        out = torch.empty((M, weight.N), dtype=x.dtype, device=x.device)
+        _lib.check(_lib.lib().sgl_mi355_gemm16_nt_wshuffled(
+            _ptr(x), _ptr(weight.data), _ptr(bias), _ptr(out), _I64(M), _I64(weight.N), _I64(weight.K),
+            _I64(x.stride(0) if M > 1 else weight.K), _I(_dtype_code(x)), _stream(x)))
+        return out
     _need_gpu(x, weight, bias)
     if x.dim() != 2 or weight.dim() != 2 or x.stride(1) != 1 or weight.stride(1) != 1:
         raise RuntimeError("linear16: x [M,K] and weight [N,K] must be 2-D with a contiguous last dimension")
@@ -815,6 +825,58 @@ def linear16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]
 
 def linear16_supported(M: int, N: int, K: int) -> bool:
     return 0 < M <= 64 and N % 8 == 0 and K % 256 == 0 and N * K * 2 < (1 << 32)
+
+
+class ShuffledWeight16:
+    """A 16-bit weight [N, K] in the fragment-major byte layout of the decode GEMMs (linear16_shuffle_weight).  Its
+    storage is a uint8 tensor of shape [N / 16, 32 K] -- one row per 16-column block -- so that nothing that expects the
+    [N, K] matrix can take it by accident (a layout marked only by a Python attribute is lost by .data /
+    .detach() / deepcopy and every shape check still passes)."""
+    __slots__ = ("data", "N", "K", "dtype")
+
+    def __init__(self, data: torch.Tensor, N: int, K: int, dtype: torch.dtype):
+        assert data.dtype == torch.uint8 and data.shape == (N // 16, 32 * K) and data.is_contiguous()
+        self.data, self.N, self.K, self.dtype = data, N, K, dtype
+
+    def unshuffle(self) -> torch.Tensor:
+        out = torch.empty((self.N, 2 * self.K), dtype=torch.uint8, device=self.data.device)
+        _lib.check(_lib.lib().sgl_mi355_fp8_shuffle_weight(_ptr(self.data), _ptr(out), _I64(self.N), _I64(2 * self.K),
+                                                           _I64(2 * self.K), _I(1), _stream(self.data)))
+        return out.view(self.dtype)
+
+
+def linear16_shuffle_supported(N: int, K: int) -> bool:
+    return N % 16 == 0 and K % 256 == 0 and N * K * 2 < (1 << 32)
+
+
+def linear16_shuffle_weight(weight: torch.Tensor) -> ShuffledWeight16:
+    """Re-lay a row-major 16-bit weight [N, K] (e.g. an untied LM head) for linear16's contiguous 1-KiB loads."""
+    _need_gpu(weight)
+    if weight.dim() != 2 or weight.stride(1) != 1 or weight.dtype not in (torch.bfloat16, torch.float16):
+        raise RuntimeError("linear16_shuffle_weight: a 2-D bf16 / fp16 weight [N, K] with contiguous rows is required")
+    N, K = weight.shape
+    if not linear16_shuffle_supported(N, K):
+        raise RuntimeError(f"linear16_shuffle_weight: N % 16 == 0 and K % 256 == 0 required, got N={N} K={K}")
+    out = torch.empty((N // 16, 32 * K), dtype=torch.uint8, device=weight.device)
+    _lib.check(_lib.lib().sgl_mi355_fp8_shuffle_weight(_ptr(weight), _ptr(out), _I64(N), _I64(2 * K),
+                                                       _I64(2 * weight.stride(0)), _I(0), _stream(weight)))
+    return ShuffledWeight16(out, N, K, weight.dtype)
+
+
+def vocab_parallel_embedding(ids: torch.Tensor, table: torch.Tensor, vocab_start: int, vocab_end: int) -> torch.Tensor:
+    """This rank's part of VocabParallelEmbedding.forward (vocab_parallel_embedding.py:462-486): rows of `table`
+    ([>= vocab_end - vocab_start, H], the shard that holds vocabulary entries [vocab_start, vocab_end)) for the ids inside
+    the shard, zeros for the others; the caller all-reduces the result over the TP group."""
+    _need_gpu(ids, table)
+    if table.dim() != 2 or not table.is_contiguous() or ids.dtype not in (torch.int32, torch.int64):
+        raise RuntimeError("vocab_parallel_embedding: table must be a contiguous [rows, H] tensor and ids int32 / int64")
+    idsc = ids.reshape(-1).contiguous()
+    out = torch.empty((idsc.numel(), table.size(1)), dtype=table.dtype, device=table.device)
+    _lib.check(_lib.lib().sgl_mi355_vocab_parallel_embedding(
+        _ptr(table), _ptr(idsc), _I(1 if idsc.dtype == torch.int64 else 0), _ptr(out), _I64(idsc.numel()),
+        _I64(table.size(1)), _I64(vocab_start), _I64(vocab_end), _I64(table.size(0)), _I(table.element_size()),
+        _stream(table)))
+    return out.view(tuple(ids.shape) + (table.size(1),))
 
 
 # --------------------------------------------------------------------------- AWQ INT4

@@ -89,6 +89,19 @@ def test_decode_backend_form_vs_oracle(Hq, Hkv, D, splits):
     assert err <= bound, f"|hip - oracle| = {err:.3e} > {bound:.3e}"
 
 
+def test_kv_indices_vs_reference_fixture():
+    """The page-table flatten against tests/golden/kv_indices.npz -- outputs of the reference's own gather
+    (test/srt/test_create_kvindices.py:41-49), written by tests/golden/make_golden.py.  Integer work: bit-exact."""
+    g = load_golden("kv_indices")
+    for i in range(int(g["n"])):
+        max_batch, max_ctx = [int(x) for x in g[f"shape{i}"]]
+        r2t = torch.arange(max_batch * max_ctx, dtype=torch.int32, device=DEV).reshape(max_batch, max_ctx)
+        indptr = g[f"indptr{i}"].to(DEV)
+        out = torch.full((int(indptr[-1]),), -1, dtype=torch.int32, device=DEV)
+        ops.create_kv_indices(r2t, g[f"rpi{i}"].to(DEV), g[f"lens{i}"].to(DEV), indptr, None, out)
+        assert torch.equal(out.cpu(), g[f"kv_indices{i}"]), f"case {i}"
+
+
 def test_decode_fp16_int64_table_and_logit_cap():
     B, Hq, Hkv, D, S = 3, 32, 8, 128, 300
     q, kb, vb, r2t, rpi, seq = _random_case(B, Hq, Hkv, D, S, torch.float16, seed=5, idx_dtype=torch.int64)

@@ -169,3 +169,32 @@ def test_rope_neox_bit_exact_vs_reference_fixture():
         ops.apply_rope_with_cos_sin_cache_inplace(pos, q, k, hs, cache, True)
         assert torch.equal(q.cpu().view(torch.int16), _z16(z, f"q_out{i}", dtype).view(torch.int16)), f"q case {i}"
         assert torch.equal(k.cpu().view(torch.int16), _z16(z, f"k_out{i}", dtype).view(torch.int16)), f"k case {i}"
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("idt", [torch.int64, torch.int32])
+def test_vocab_parallel_embedding_vs_oracle(dtype, idt):
+    """ops.vocab_parallel_embedding (one rank's masked lookup of VocabParallelEmbedding.forward,
+    vocab_parallel_embedding.py:126-150, 462-482) against the oracle's restatement: a byte copy -- exact; the shards of
+    all ranks summed give the plain lookup (the all-reduce of :483)."""
+    import oracle
+    from sglang_npu_amd.layers import pad_vocab_size, vocab_shard_range
+    g = torch.Generator().manual_seed(3)
+    vocab, H, world = 1000, 896, 4
+    padded = pad_vocab_size(vocab, 64 * world)
+    table = torch.randn(vocab, H, generator=g).to(dtype)
+    ids = torch.randint(0, vocab, (2, 37), generator=g).to(idt)
+    ids[0, 0], ids[0, 1], ids[1, 0] = 0, vocab - 1, 250
+    total = torch.zeros(2, 37, H, dtype=torch.float64)
+    for rank in range(world):
+        start, end, per = vocab_shard_range(vocab, padded, rank, world)
+        shard = torch.zeros(per, H, dtype=dtype)
+        shard[:end - start] = table[start:end]
+        ref = oracle.vocab_parallel_embedding(ids.long(), shard, start, end)
+        got = ops.vocab_parallel_embedding(ids.to(DEV), shard.to(DEV), start, end)
+        assert got.shape == (2, 37, H) and torch.equal(got.cpu(), ref)
+        total += got.double().cpu()
+    assert torch.equal(total.to(dtype), table[ids.long()])
+    assert ops.vocab_parallel_embedding(ids[:0].to(DEV), table.to(DEV), 0, vocab).shape == (0, 37, H)
+    with pytest.raises(RuntimeError, match="does not fit"):
+        ops.vocab_parallel_embedding(ids.to(DEV), table[:10].contiguous().to(DEV), 0, vocab)

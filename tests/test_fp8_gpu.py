@@ -275,3 +275,35 @@ def test_linear16_lm_head_vs_fp64(M, N, K, dtype):
     assert torch.equal(ops.linear16(wide[:, :K], w, bias), out)
     with pytest.raises(RuntimeError, match="M <= 64"):
         ops.linear16(torch.zeros(65, K, device=DEV, dtype=dtype), w)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M", [1, 16, 17, 33, 64])
+@pytest.mark.parametrize("N,K", [(128256, 4096), (32000, 4096), (1008, 512), (4096, 1024), (151936, 1024)])
+def test_linear16_on_fragment_major_weight_is_bit_identical(M, N, K, dtype):
+    """The LM head on a weight re-laid once for contiguous 1-KiB loads (ops.linear16_shuffle_weight, round 3): the same
+    products in the same order -- only the addresses of the weight loads differ -- so the SAME BITS as the row-major call
+    (which test_linear16_lm_head_vs_fp64 holds to one output ulp of an fp64 product); the layout round-trips; the storage
+    has a shape of its own, so that it cannot be mistaken for the [N, K] matrix."""
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    x = torch.randn(M, K, device=DEV, generator=g).to(dtype)
+    w = (torch.randn(N, K, device=DEV, generator=g) * 0.05).to(dtype)
+    bias = torch.randn(N, device=DEV, generator=g).to(dtype) if M % 2 == 0 else None
+    wsh = ops.linear16_shuffle_weight(w)
+    assert wsh.data.dtype == torch.uint8 and wsh.data.shape == (N // 16, 32 * K)
+    assert torch.equal(wsh.unshuffle().view(torch.int16), w.view(torch.int16))
+    # the byte layout is the FP8 one applied to the [N][2K] byte image (include/sgl_mi355.h)
+    b = w.view(torch.uint8).view(N // 16, 16, (2 * K) // 128, 2, 4, 16).permute(0, 2, 3, 4, 1, 5).contiguous()
+    assert torch.equal(wsh.data.view(-1), b.view(-1))
+    assert torch.equal(ops.linear16(x, wsh, bias), ops.linear16(x, w, bias))
+    # a strided source (rows of a wider buffer) is re-laid the same
+    wide = torch.zeros(N, K + 256, device=DEV, dtype=dtype)
+    wide[:, :K] = w
+    assert torch.equal(ops.linear16_shuffle_weight(wide[:, :K]).data, wsh.data)
+
+
+def test_linear16_shuffle_rejects_other_shapes():
+    with pytest.raises(RuntimeError, match="N % 16 == 0"):
+        ops.linear16_shuffle_weight(torch.zeros(1000, 512, device=DEV, dtype=torch.bfloat16))
+    with pytest.raises(RuntimeError, match="K % 256 == 0"):
+        ops.linear16_shuffle_weight(torch.zeros(1024, 896, device=DEV, dtype=torch.bfloat16))

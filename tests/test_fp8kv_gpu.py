@@ -81,6 +81,66 @@ def test_decode_fp8_kv_vs_oracle(Hq, Hkv, D, splits):
     assert float((o2.float() - o.float()).abs().max()) <= 1.5 * float(err_ref.max()) + 2.0 ** -8 * scale
 
 
+@pytest.mark.parametrize("kv_dtype", [torch.float8_e4m3fn, torch.float8_e5m2])
+@pytest.mark.parametrize("Hq,Hkv", [(32, 8), (8, 1), (32, 32)])
+@pytest.mark.parametrize("splits", [1, 4])
+def test_decode_fp8_kv_exact_when_every_p_is_a_power_of_two(kv_dtype, Hq, Hkv, splits):
+    """A DETERMINISTIC case for the byte-MFMA path: q is one-hot and the keys carry small integers
+    on that dimension, sm_scale = ln 2, so every score is an integer n and every probability 2^(n - max) -- exact in e4m3
+    and in e5m2 whatever running max it is scaled by (tile order, split count).  The rounding of P to the pool format is
+    then the identity, fp8 x fp8 products are exact, and the kernel must agree with the oracle AND with the closed form
+    sum(2^n v) / sum(2^n) evaluated in float64 to one output ulp -- no statistical slack."""
+    import math
+    g = torch.Generator().manual_seed(Hq * 7 + splits)
+    B, D, max_len = 4, 128, 600
+    seq = torch.tensor([600, 1, 257, 96])
+    group = Hq // Hkv
+    n_tok = B * max_len + 1
+    kb = torch.randn(n_tok, Hkv, D, generator=g)
+    # integer scores in [-8, 0] on the first `group` dimensions (head h of a group looks at dimension h % group);
+    # -8 keeps 2^(n - max) >= 2^-8: representable in e4m3 (subnormal) and far from its 2^-10 rounding-to-zero tie
+    n = torch.randint(-8, 1, (n_tok, Hkv, group), generator=g)
+    kb[:, :, :group] = n.float()
+    vb = torch.randn(n_tok, Hkv, D, generator=g) * 2
+    kb8, vb8 = kb.to(kv_dtype), vb.to(kv_dtype)
+    assert torch.equal(kb8[:, :, :group].float(), n.float())  # small integers are exact in both formats
+    q = torch.zeros(B, Hq, D)
+    for h in range(Hq):
+        q[:, h, h % group] = 1.0
+    q = q.bfloat16()
+    r2t = (torch.randperm(n_tok - 1, generator=g) + 1).view(B, max_len).int()
+    rpi = torch.arange(B)
+    sm = math.log(2.0)
+    ref = torch.zeros(B, Hq, D, dtype=torch.bfloat16)
+    oracle.decode_attention_fp8kv(q, kb8, vb8, ref, torch.zeros(B, Hq, splits, D + 1), r2t, rpi, seq, sm, p_fp8=True)
+    # closed form in float64
+    truth = torch.zeros(B, Hq, D, dtype=torch.float64)
+    mag = torch.zeros(B, Hq, D, dtype=torch.float64)  # sum p |v| / sum p: what the fp32 summation noise scales with
+    for b in range(B):
+        rows = r2t[b, :int(seq[b])].long()
+        for h in range(Hq):
+            kvh = h // group
+            e = kb8[rows, kvh, h % group].double()
+            w = torch.exp2(e - e.max())
+            truth[b, h] = (w[:, None] * vb8[rows, kvh].double()).sum(0) / w.sum()
+            mag[b, h] = (w[:, None] * vb8[rows, kvh].double().abs()).sum(0) / w.sum()
+    o = torch.zeros(B, Hq, D, dtype=torch.bfloat16, device=DEV)
+    logits = torch.zeros(B, Hq, splits, D + 1, device=DEV) if splits > 1 else None
+    ops.decode_attention_paged(q.to(DEV), kb8.to(DEV), vb8.to(DEV), o, r2t.to(DEV), rpi.to(DEV), seq.to(DEV), logits, splits,
+                               sm, 0.0)
+    got = o.float().cpu()
+    t16 = truth.float().bfloat16().float()  # the correctly rounded answer
+    ulp = 2.0 ** -7  # one bf16 ulp relative to the element (8 significant bits)
+    # one output ulp, plus the fp32 accumulation noise of a sum whose terms (random signs) may cancel: 2^-18 of sum p|v| / sum p
+    # -- four orders of magnitude below what a wrongly rounded P would cause (2^-4 per probability)
+    slack = (2.0 ** -18 * mag).float()
+    for name, want in (("closed form", t16), ("oracle", ref.float())):
+        diff = (got - want).abs()
+        assert bool((diff <= ulp * want.abs() + slack).all()), (name, float(((diff - ulp * want.abs()) / mag.float()).max()))
+        # ... and nearly all elements are bit-equal (a 1-ulp step needs the fp32 value to sit on a rounding boundary)
+        assert float((diff == 0).float().mean()) > 0.98, (name, float((diff == 0).float().mean()))
+
+
 def test_fp8_pool_unsupported_shapes_raise():
     q = torch.zeros(1, 2, 80, dtype=torch.bfloat16, device=DEV)
     kb = torch.zeros(9, 2, 80, dtype=torch.float8_e4m3fn, device=DEV)

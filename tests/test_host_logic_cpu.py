@@ -62,3 +62,29 @@ def test_per_channel_weight_quant_matches_reference_formula():
     layer.weight.data = w
     meth.process_weights_after_loading(layer)
     assert layer.weight.shape == (64, 16) and layer.weight.stride(0) == 1, "stored as the K-major [K,N] view"
+
+
+def test_vocab_parallel_embedding_shards_cover_the_vocabulary_once():
+    """VocabParallelEmbedding (vocab_parallel_embedding.py:153-486, original vocabulary only): the shard ranges of all
+    ranks tile [0, vocab) exactly, and the masked per-rank lookups (oracle restatement of :126-150, :462-482) summed over
+    the ranks -- the all-reduce of :483 -- equal the plain lookup, bit for bit."""
+    import torch
+    import oracle
+    from sglang_npu_amd.layers import pad_vocab_size, vocab_shard_range
+    g = torch.Generator().manual_seed(0)
+    for vocab, world in ((128256, 8), (32000, 2), (151936, 4), (1000, 8), (100, 3)):
+        padded = pad_vocab_size(vocab, 64 * world)
+        table = torch.randn(vocab, 16, generator=g).bfloat16()
+        ids = torch.randint(0, vocab, (3, 7), generator=g)
+        ids[0, 0], ids[0, 1] = 0, vocab - 1
+        total = torch.zeros(3, 7, 16, dtype=torch.float32)
+        covered = torch.zeros(vocab, dtype=torch.int32)
+        for rank in range(world):
+            start, end, per = vocab_shard_range(vocab, padded, rank, world)
+            assert 0 <= start <= end <= vocab and end - start <= per and per * world == padded
+            covered[start:end] += 1
+            shard = torch.zeros(per, 16, dtype=torch.bfloat16)
+            shard[:end - start] = table[start:end]
+            total += oracle.vocab_parallel_embedding(ids, shard, start, end).float()
+        assert bool((covered == 1).all())
+        assert torch.equal(total.bfloat16(), table[ids])  # every id is in exactly one shard: the sum adds zeros

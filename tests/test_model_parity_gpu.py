@@ -111,15 +111,26 @@ def _check_step(cpu, tap, logits, positions, r2t_cpu, seq_len, loc, prefill, ste
     err, scale = float((logits - ref).abs().max()), float(ref.abs().max())
     # final norm + LM head from the HIP stack's own last hidden state: one bf16 ulp of the largest logit
     assert err <= 2.0 ** -7 * scale, f"step {step}: logits |hip - oracle| = {err:.3e}, max |logit| = {scale:.3e}"
+    # north_star: token ids bit-exact.  A greedy choice is DECIDED when the top-2 margin of the oracle's logits exceeds
+    # both 1e-3 of the largest logit (north_star's logit tolerance) and twice the error actually observed on this step
+    # (both sides round their logits to bf16: half an ulp = 2e-3 of a logit each, so a smaller margin can flip
+    # legitimately); every decided step must pick the same token -- no allowance.
     top2 = torch.topk(ref.flatten(), 2).values
-    if float(top2[0] - top2[1]) > 2 * err:  # a greedy choice the observed error cannot flip must be identical
-        assert int(logits.argmax()) == int(ref.argmax()), f"step {step}: greedy token differs"
+    margin = float(top2[0] - top2[1])
+    decided = margin > max(1e-3 * scale, 2 * err)
+    if decided:
+        assert int(logits.argmax()) == int(ref.argmax()), f"step {step}: greedy token differs (margin {margin:.3e}, err {err:.3e})"
+    _check_step.decided.append((step, decided, margin / scale, err / scale))
     return ref
+
+
+_check_step.decided = []
 
 
 def test_qwen2_05b_shaped_prefill_and_greedy_decode_match_cpu_oracle():
     cfg = M.QWEN2_05B
     input_len, new_tokens = 128, 6
+    _check_step.decided.clear()
     max_len = input_len + new_tokens + 2
     r2t = ReqToTokenPool(2, max_len, DEV)
     n_tok = 2 * max_len + 1
@@ -154,8 +165,12 @@ def test_qwen2_05b_shaped_prefill_and_greedy_decode_match_cpu_oracle():
     logits = net(ids, positions, fb)[-1:].float().cpu()
     _check_step(cpu, tap, logits, positions, r2t_cpu, input_len, loc, True, 0)
     e2e = cpu.forward(ids.cpu(), positions.cpu(), r2t_cpu, input_len, loc.cpu(), prefill=True).float()
+    def rel_margin(x):
+        t = torch.topk(x.flatten(), 2).values
+        return float((t[0] - t[1]) / x.abs().max())
     drift = [float((logits - e2e).abs().max() / e2e.abs().max())]
     same = [int(logits.argmax()) == int(e2e.argmax())]
+    margins = [rel_margin(e2e)]
     for step in range(1, new_tokens + 1):
         # ---- one greedy decode step (both sides continue from the oracle's token: same trajectory)
         nxt = torch.tensor([int(e2e.argmax())], device=DEV)
@@ -172,8 +187,17 @@ def test_qwen2_05b_shaped_prefill_and_greedy_decode_match_cpu_oracle():
         e2e = cpu.forward(nxt.cpu(), positions.cpu(), r2t_cpu, seq_len, loc.cpu(), prefill=False).float()
         drift.append(float((logits - e2e).abs().max() / e2e.abs().max()))
         same.append(int(logits.argmax()) == int(e2e.argmax()))
-    # 24 layers x ~10 independently rounded ops on each side: a few percent of the largest logit; the greedy tokens of
-    # the two free-running stacks agree wherever the top-2 margin exceeds that drift (checked per step above with the
-    # tight op-by-op error) -- here only a sanity bound that nothing systematic is wrong
+        margins.append(rel_margin(e2e))
+    # 24 layers x ~10 independently rounded ops on each side: a few percent of the largest logit is the drift of two
+    # free-running bf16 stacks -- a sanity bound that nothing systematic is wrong
     assert max(drift) <= 2.0 ** -3, f"end-to-end drift {drift}"
-    assert sum(same) >= len(same) - 2, f"greedy tokens of the free-running stacks: {same}, drift {drift}"
+    # free-running stacks: wherever the oracle's own top-2 margin exceeds twice the drift measured on that step the two
+    # greedy tokens MUST agree (no "k of n may differ" allowance); steps inside the drift are reported, not asserted
+    decided_free = [m > 2 * d for m, d in zip(margins, drift)]
+    for i, (dec, ok) in enumerate(zip(decided_free, same)):
+        assert ok or not dec, f"free-running step {i}: tokens differ although margin {margins[i]:.3e} > 2 x drift {drift[i]:.3e}"
+    n_tf = sum(1 for _, d, _, _ in _check_step.decided if d)
+    print(f"[model parity] teacher-forced steps decided (token ids asserted equal): {n_tf} of {len(_check_step.decided)}; "
+          f"free-running: {sum(decided_free)} of {len(same)} decided, {sum(same)} of {len(same)} equal; "
+          f"margins/max {[round(m, 4) for m in margins]}, drift {[round(d, 4) for d in drift]}")
+    assert n_tf >= 1, f"no step had a decided greedy choice: {_check_step.decided}"

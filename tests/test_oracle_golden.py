@@ -32,6 +32,31 @@ def test_decode_oracle_vs_reference(name):
         assert (o.float() - g["o_ref"].float()).abs().max().item() <= 2 * bound
 
 
+@pytest.mark.parametrize("name", golden_names("decode_"))
+def test_decode_blocked_port_vs_reference_and_token_loop(name):
+    """The BLOCKED form of the decode oracle (what bench.py times as cpu_baseline, structure of decode.cpp:942-985)
+    against the same reference fixtures, and against the token-at-a-time oracle (same arithmetic up to the fp32
+    summation order: a 16-bit output element may sit one rounding apart on a few elements, never more)."""
+    g = load_golden(name)
+    B, Hq, Hkv, D, Dv, S, splits = [int(x) for x in g["meta"]]
+    outs = []
+    for blocked in (False, True):
+        kb, vb = g["k_buffer"].clone(), g["v_buffer"].clone()
+        o = torch.zeros(B, Hq, Dv, dtype=g["q"].dtype)
+        oracle.decode_attention(g["q"], kb, vb, o, g["key"], g["value"], g["loc"], torch.zeros(B, Hq, splits, Dv + 1),
+                                g["req_to_token"], g["req_pool_indices"], g["seq_lens"], g["sm_scale"], g["logit_cap"],
+                                blocked=blocked)
+        outs.append(o.float())
+    bound = tol_for(g["dtype"], g["o_f32"])
+    assert (outs[1] - g["o_f32"]).abs().max().item() <= bound
+    if g["ref_valid"]:
+        assert (outs[1] - g["o_ref"].float()).abs().max().item() <= 2 * bound
+    ulp = 2.0 ** -7 if g["dtype"] == "bf16" else 2.0 ** -10
+    d = (outs[1] - outs[0]).abs()
+    assert bool((d <= ulp * outs[0].abs() + 1e-6).all()), float(d.max())
+    assert float((d == 0).float().mean()) > 0.97
+
+
 @pytest.mark.parametrize("name", golden_names("extend_"))
 def test_extend_oracle_vs_reference(name):
     g = load_golden(name)

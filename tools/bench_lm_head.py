@@ -10,6 +10,7 @@ dev = "cuda:0"
 g = torch.Generator(device=dev).manual_seed(0)
 N, K = 128256, 4096
 ws = [(torch.randn(N, K, device=dev, generator=g) * 0.02).bfloat16() for _ in range(2)]
+wsh = [ops.linear16_shuffle_weight(w) for w in ws]  # fragment-major copies (round 3)
 for M in (1, 16, 64):
     x = torch.randn(M, K, device=dev, generator=g).bfloat16()
 
@@ -27,7 +28,10 @@ for M in (1, 16, 64):
 
     us_k = t(lambda i: ops.linear16(x, ws[i & 1]))
     us_l = t(lambda i: torch.matmul(x, ws[i & 1].t()))
+    us_s = t(lambda i: ops.linear16(x, wsh[i & 1]))
+    assert torch.equal(ops.linear16(x, wsh[0]), ops.linear16(x, ws[0]))
     nbytes = N * K * 2 + M * K * 2 + M * N * 2
-    print(json.dumps(dict(M=M, linear16_us=round(us_k, 1), linear16_GBps=round(nbytes / us_k / 1e3, 1),
+    print(json.dumps(dict(M=M, linear16_shuffled_us=round(us_s, 1), linear16_shuffled_GBps=round(nbytes / us_s / 1e3, 1),
+                          pb=os.environ.get("SGL_MI355_GEMM16_PB", "2"), linear16_us=round(us_k, 1), linear16_GBps=round(nbytes / us_k / 1e3, 1),
                           hipblaslt_us=round(us_l, 1), hipblaslt_GBps=round(nbytes / us_l / 1e3, 1),
                           nt=os.environ.get("SGL_MI355_GEMM16_NT", "0"))), flush=True)
