@@ -42,7 +42,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PMC_SUMMARY = "r02_decode_pmc_summary.json"  # refreshed per round when the kernel changes
+PROFILED_ATTN_US = 94.17  # profiles/r03_bench_tp1_kernel_stats.csv: decode_mfma_pair_kernel, 1 792 launches of the profiled bench
+PMC_SUMMARY = "r03_decode_pmc_instep.json"  # in-step counters of the profiled bench command, refreshed per round
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 
 
@@ -660,8 +661,36 @@ def main():
     hq, hkv, d = cfg.num_attention_heads // tp, cfg.get_num_kv_heads(tp), cfg.head_dim
     attn_ms, n_launch = time_attention_kernel(loop, min(args.steps, 8))
     ctx_mid = args.ctx + args.warmup + args.steps + min(args.steps, 8) / 2
+    # ... and its cost INSIDE the graph-replayed step, as the difference of two event-timed runs of the same loop over the
+    # same sequence lengths: the step as it is, and the step with the decode attention launch left out
+    # (MI355AttnBackend.measure_skip_decode_kernel).  The eager launches timed above sit between idle gaps (the host
+    # cannot issue ten kernels per layer as fast as the GPU runs them) and read 4-12 % long, box by box; the profiler's
+    # average busy time of the kernel in the replayed step is what this difference tracks (it also carries the one kernel
+    # boundary that disappears with the launch, ~1.6 us).
+    attn_instep_ms = None
+    if loop.graph is not None and not dist_on and hasattr(backend, "measure_skip_decode_kernel"):
+        try:
+            n_d = min(args.steps, 16)
+            loop.rewind(args.ctx)
+            loop.capture()
+            t_full = timed(2, n_d) / n_d * 1e3
+            backend.measure_skip_decode_kernel = True
+            loop.rewind(args.ctx)
+            loop.capture()
+            t_skip = timed(2, n_d) / n_d * 1e3
+            attn_instep_ms = (t_full - t_skip) / len(net.layers)
+        finally:
+            backend.measure_skip_decode_kernel = False
+            loop.rewind(args.ctx)
+            loop.capture()
     kv_esz = 1 if args.kv_dtype in ("fp8_e4m3", "fp8_e5m2") else 2
     alg_bytes = args.batch * ctx_mid * hkv * 2 * d * kv_esz + 4 * args.batch * ctx_mid + 2 * args.batch * hq * 2 * d
+    eager_event_ms = attn_ms
+    if attn_instep_ms is not None and attn_instep_ms > 0:
+        # the lengths of the difference runs: ctx + 2 warm-ups + n_d steps, mean ctx + 2 + n_d / 2
+        ctx_d = args.ctx + 2 + min(args.steps, 16) / 2
+        alg_bytes = args.batch * ctx_d * hkv * 2 * d * kv_esz + 4 * args.batch * ctx_d + 2 * args.batch * hq * 2 * d
+        attn_ms = attn_instep_ms
     achieved = alg_bytes / (attn_ms * 1e-3) / 1e9
     # HBM traffic of that kernel from the committed rocprofv3 --pmc passes (bench.py cannot run the profiler on
     # itself): measured bytes / algorithmic bytes of the same kernel at the same geometry, applied to this launch.
@@ -671,8 +700,9 @@ def main():
                                           PMC_SUMMARY)))
         if tp == 1 and args.batch == 64 and (hq, hkv, d) == (32, 8, 128) and kv_esz == 2:
             traffic = int(alg_bytes * pmc["traffic_over_algorithmic"])
-            traffic_src = (f"profiles/{PMC_SUMMARY}: FETCH_SIZE x2 (gfx950) + WRITE_SIZE, separate --pmc "
-                           f"passes, ratio {pmc['traffic_over_algorithmic']} to algorithmic bytes at bs=64 ctx=2048")
+            traffic_src = (f"profiles/{PMC_SUMMARY}: FETCH_SIZE x2 (gfx950) + WRITE_SIZE of this kernel's launches INSIDE "
+                           f"the profiled `bench.py --steps 8 --warmup 2` step (tools/exp/prof_bench_pmc.sh, separate --pmc "
+                           f"passes), ratio {pmc['traffic_over_algorithmic']} to the algorithmic bytes of the lengths the run visits")
     except (OSError, KeyError, ValueError):
         pass
     out = {
@@ -700,7 +730,13 @@ def main():
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                      "traffic_source": traffic_src,
                      "avg_launch_us": round(attn_ms * 1e3, 2), "launches_timed": n_launch,
-                     "algorithmic_bytes_per_launch": int(alg_bytes)},
+                     "algorithmic_bytes_per_launch": int(alg_bytes),
+                     "method": ("in-step: (graph-replayed step - the same step without the decode attention launch) / layers, "
+                                "HIP events on the launch stream around min(steps,16) replays each"
+                                if attn_instep_ms is not None and attn_instep_ms > 0 else
+                                "HIP events around each eager launch of the kernel on the launch stream"),
+                     "eager_event_launch_us": round(eager_event_ms * 1e3, 2),
+                     "rocprofv3_avg_busy_us_same_command": PROFILED_ATTN_US},
     }
     if time_attention_kernel.merged_launches:
         out["roofline"]["launch_includes"] = ("kv-split merge + per-token FP8 quant of the output (one launch: "

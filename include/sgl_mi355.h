@@ -379,6 +379,10 @@ int sgl_mi355_awq_gemm(const void* x, const int32_t* qweight, const void* scales
                        const void* bias, void* out, float* workspace, int64_t workspace_floats,
                        int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, void* stream);
 
+/* Test aid: the kernel family the last sgl_mi355_fp8_scaled_mm* call of the calling thread launched ("skinny", "oneshot",
+ * "astat", "astat_direct", "wstream", "wstream_slab", "tiled", "tiled2", "tiled3"; "" before the first call). */
+const char* sgl_mi355_fp8_last_kernel(void);
+
 /* Pre-shuffled ("fragment-major") FP8 weights for the decode GEMMs -- MI355X extension.
  * Replaces: nothing in the dense w8a8 path of the reference (it keeps the checkpoint's row-major [N, K] weight and only
  *           transposes the view, w8a8_fp8.py:104-134); the same idea as the aiter `shuffle_weight(w, (16, 16))` repack the
@@ -572,8 +576,11 @@ int sgl_mi355_gemm16_nt_wshuffled(const void* x, const void* weight_shuffled, co
  * input [num_tokens, hidden_dim] contiguous (dtype 0 bf16, 1 fp16, 2 fp32); output_q e4m3fn, same shape; output_s
  * fp32, element (token, group) at token * s_stride_token + group * s_stride_group (row-major [T, K/G]: strides
  * (K/G, 1); the reference's column-major form: (1, T_padded)).  Per group: absmax = max(eps, max|x|),
- * scale = absmax / fp8_max, q = clamp(x / scale, fp8_min, fp8_max) rounded to nearest even.  scale_ue8m0 != 0
- * (packed power-of-two scales) returns SGL_MI355_ERR_UNSUPPORTED. */
+ * scale = absmax / fp8_max, q = clamp(x / scale, fp8_min, fp8_max) rounded to nearest even.
+ * scale_ue8m0 != 0 (round 3; per_token_group_quant_8bit.cu:24-137 SCALE_UE8M0): the scale is rounded UP to a power of two,
+ * exp2(ceil(log2(max(scale, 1e-10)))), and output_s is the int32 tensor of create_per_token_group_quant_fp8_output_scale
+ * (fp8_kernel.py:308-319) -- exponent bytes (log2 + 127) packed four to an int32, column-major: byte
+ * (group / 4) * s_stride_group * 4 + token * 4 + group % 4, s_stride_token == 1, s_stride_group in int32 elements. */
 int sgl_mi355_per_token_group_quant_fp8(const void* input, void* output_q, float* output_s, int64_t num_tokens,
                                         int64_t hidden_dim, int64_t group_size, int64_t s_stride_token,
                                         int64_t s_stride_group, float eps, float fp8_min, float fp8_max, int scale_ue8m0,

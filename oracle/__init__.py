@@ -214,6 +214,18 @@ def per_token_group_quant_fp8(input, output_q, output_s, group_size, eps, fp8_mi
                                       _I64(group_size), _F(eps), _F(fp8_min), _F(fp8_max), _I(_in_code(input)))
 
 
+def per_token_group_quant_fp8_ue8m0(input, output_q, output_s, group_size, eps, fp8_min, fp8_max, lib=None):
+    """sgl_per_token_group_quant_fp8(..., scale_ue8m0=True): power-of-two scales as exponent bytes packed four to an int32,
+    column-major (per_token_group_quant_8bit.cu:24-137).  output_s: int32 [T, ceil(K / G / 4)] with stride(0) == 1, as
+    create_per_token_group_quant_fp8_output_scale (fp8_kernel.py:308-319) makes it."""
+    lib = lib or load()
+    assert input.is_contiguous() and output_q.is_contiguous() and input.dim() == 2
+    assert output_s.dtype == torch.int32 and output_s.dim() == 2 and (output_s.stride(0) == 1 or output_s.size(0) == 1)
+    T, K = input.shape
+    lib.orc_per_token_group_quant_fp8_ue8m0(_ptr(input), _ptr(output_q), _ptr(output_s), _I64(T), _I64(K), _I64(group_size),
+                                            _I64(output_s.stride(1)), _F(eps), _F(fp8_min), _F(fp8_max), _I(_in_code(input)))
+
+
 def per_tensor_quant_fp8(input, output_q, output_s, is_static, lib=None):
     """sgl_per_tensor_quant_fp8 (per_tensor_quant_fp8.cu:90-120)."""
     lib = lib or load()

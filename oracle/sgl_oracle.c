@@ -709,6 +709,37 @@ void orc_per_token_group_quant_fp8(const void* x, uint8_t* q, float* s, int64_t 
   }
 }
 
+/* The SCALE_UE8M0 form of the same op (per_token_group_quant_8bit.cu:24-137, :140-215 with scale_ue8m0 = true; Triton
+ * twin fp8_kernel.py _per_token_group_quant_fp8_colmajor): the scale is rounded UP to a power of two,
+ *   y_s = exp2(ceil(log2(max(absmax / fp8_max, 1e-10))))            (:87-89)
+ * stored as its biased exponent byte (int)log2(y_s) + 127 (:92-96), four bytes to an int32, column-major: byte
+ * (col / 4) * scale_stride * 4 + row * 4 + col % 4 of the int32 [hidden / group / 4 (rounded up), aligned rows] buffer
+ * (:52-60; create_per_token_group_quant_fp8_output_scale, fp8_kernel.py:308-319); q = cast(clamp(x / y_s)).
+ * scale_stride = int32 elements between packed columns.  Bytes of groups that do not exist are left untouched. */
+void orc_per_token_group_quant_fp8_ue8m0(const void* x, uint8_t* q, uint8_t* s_packed, int64_t num_tokens, int64_t hidden,
+                                         int64_t group_size, int64_t scale_stride, float eps, float fp8_min, float fp8_max,
+                                         int dtype) {
+  const int64_t gpr = hidden / group_size;
+#pragma omp parallel for schedule(static)
+  for (int64_t g = 0; g < num_tokens * gpr; ++g) {
+    float amax = eps;
+    for (int64_t i = 0; i < group_size; ++i) {
+      const int64_t e = g * group_size + i;
+      const float v = dtype == 2 ? ((const float*)x)[e] : h_to_f32(((const uint16_t*)x)[e], dtype);
+      amax = fmaxf(amax, fabsf(v));
+    }
+    float y_s = amax / fp8_max;
+    y_s = exp2f(ceilf(log2f(fmaxf(y_s, 1e-10f))));
+    const int64_t row = g / gpr, col = g % gpr;
+    s_packed[(col / 4) * scale_stride * 4 + row * 4 + (col % 4)] = (uint8_t)(((int)log2f(y_s)) + 127);
+    for (int64_t i = 0; i < group_size; ++i) {
+      const int64_t e = g * group_size + i;
+      const float v = dtype == 2 ? ((const float*)x)[e] : h_to_f32(((const uint16_t*)x)[e], dtype);
+      q[e] = f32_to_e4m3(fminf(fmaxf(v / y_s, fp8_min), fp8_max));
+    }
+  }
+}
+
 /* sgl_per_tensor_quant_fp8, sgl-kernel/csrc/gemm/per_tensor_quant_fp8.cu:9-88: dynamic scale = max|x| / 448 (an
  * atomic max into *s, which the caller zeroes), q = cast(clamp(x * (1 / scale), -448, 448)). */
 void orc_per_tensor_quant_fp8(const void* x, uint8_t* q, float* s, int64_t n, int is_static, int dtype) {

@@ -105,6 +105,7 @@ class AttentionBackend:
 class MI355AttnBackend(AttentionBackend):
     def __init__(self, model_runner, skip_prefill: bool = False, flat_kv_indices: bool = False):
         super().__init__()
+        self.measure_skip_decode_kernel = False  # see forward_decode
         self.skip_prefill = skip_prefill
         self.flat_kv_indices = flat_kv_indices
         max_bs = model_runner.req_to_token_pool.size
@@ -300,6 +301,10 @@ class MI355AttnBackend(AttentionBackend):
         ignored and the caller quantises."""
         q = q.reshape(-1, layer.tp_q_head_num * layer.qk_head_dim)
         md = self.forward_metadata
+        if self.measure_skip_decode_kernel:
+            # measurement aid (bench.py): the step WITHOUT the decode attention launch (KV write included), so that the
+            # kernel's in-step cost can be taken as the difference of two graph-replayed steps; the output is uninitialised
+            return q.new_empty((q.shape[0], layer.tp_q_head_num * layer.v_head_dim))
         if (fp8_out and not self.flat_kv_indices and isinstance(md.num_kv_splits, int) and md.num_kv_splits > 1
                 and md.attn_logits is not None and layer.qk_head_dim == layer.v_head_dim
                 and (layer.tp_q_head_num * layer.v_head_dim) % 8 == 0

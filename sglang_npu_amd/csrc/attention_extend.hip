@@ -130,8 +130,11 @@ __device__ __forceinline__ float round_fp8(float x, bool e5) {
 // through QK^T, softmax and P.V and the two partial (m, l, O) are merged through LDS at the end.  Per-wave work per tile
 // halves, so the longest query block (the critical path of a short single-request prefill, where there is one
 // workgroup per CU or less) finishes in half the time; the workgroup covers 2 (GH = 2) or 1 head(s).
-template <int DTYPE, int D, typename IdxT, int GH, bool MASKED, bool KV8 = false, int KSPLIT = 1>
+// NSTAGE (round 3): K/V tiles in LDS; two everywhere (more tiles in flight at one workgroup per CU were measured slower for
+// the short single-request prefill, see dispatch()).
+template <int DTYPE, int D, typename IdxT, int GH, bool MASKED, bool KV8 = false, int KSPLIT = 1, int NSTAGE = 2>
 __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
+  static_assert(NSTAGE >= 2 && NSTAGE <= 4 && (!KV8 || NSTAGE == 2), "the FP8 staging area is laid out for two stages");
   using H = Half16<DTYPE>;
   using T = typename H::T;
   using x8 = typename H::x8;
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
   constexpr int BP = 32 * NPB;                  // query positions per workgroup
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  int32_t* idx_lds = reinterpret_cast<int32_t*>(smem + 2 * STAGE_BYTES);
+  int32_t* idx_lds = reinterpret_cast<int32_t*>(smem + NSTAGE * STAGE_BYTES);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -282,6 +285,20 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
     }
     // ---- online softmax; key of (th, r) = t*64 + 32th + (r&3) + 8(r>>2) + 4hh
     float m_tile = -INFINITY;
+    // tiles that lie wholly inside the valid keys and (extend stage, causal) wholly at or below this wave's first query
+    // position need no per-element mask: most tiles of a long block (wave-uniform test, the same values either way)
+    const bool unmasked_tile = !MASKED && !has_cap && (t + 1) * kBN <= n_keys &&
+                               !(phase == 1 && a.causal && (t + 1) * kBN - 1 > pw0);
+    if (unmasked_tile) {
+#pragma unroll
+      for (int ti = 0; ti < NTH; ++ti)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float s = s_acc[ti][r] * scale_log2;
+          s_acc[ti][r] = s;
+          m_tile = fmaxf(m_tile, s);
+        }
+    } else
 #pragma unroll
     for (int ti = 0; ti < NTH; ++ti)
 #pragma unroll
@@ -331,10 +348,15 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
       }
     l_run = l_run * alpha + psum;
     m_run = m_new;
+    // the running maximum moves in the first tiles of a row and then rarely: when NO lane of the wave has a new maximum
+    // alpha is exactly 1 everywhere and the 16 NDVB multiplies (a quarter of the tile's vector instructions) are skipped --
+    // bit-identical, since x * 1.0f == x
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
-    for (int i = 0; i < NDVB; ++i)
+      for (int i = 0; i < NDVB; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o_acc[i][r] *= alpha;
+        for (int r = 0; r < 16; ++r) o_acc[i][r] *= alpha;
+    }
     // ---- O^T += V^T P^T
     const int grp = lane >> 4;       // 16-lane group: column half (grp&1), k half hh = grp>>1
     const int q4 = (lane >> 2) & 3;  // row within a 4-row transposed block
@@ -366,19 +388,24 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
   // Every pass runs the same double-buffered loop.
   auto run_phase = [&](int phase, int t_begin, int t_end, int idx_off, int n_keys) __attribute__((always_inline)) {
     if (t_begin >= t_end) return;
-    issue(phase, t_begin, 0, idx_off, n_keys);
+    // prologue: NSTAGE - 1 tiles in flight
+#pragma unroll
+    for (int d = 0; d < NSTAGE - 1; ++d)
+      if (t_begin + d < t_end) issue(phase, t_begin + d, d, idx_off, n_keys);
+    int st = 0;
     for (int t = t_begin; t < t_end; ++t) {
-      const int st = (t - t_begin) & 1;
-      if (t + 1 < t_end) {
-        issue(phase, t + 1, st ^ 1, idx_off, n_keys);
-        wait_vmcnt<2 * PPW>();
-      } else {
-        wait_vmcnt<0>();
-      }
+      // the stage freed by the previous step's trailing barrier takes tile t + NSTAGE - 1
+      if (t + NSTAGE - 1 < t_end) issue(phase, t + NSTAGE - 1, st == 0 ? NSTAGE - 1 : st - 1, idx_off, n_keys);
+      const int behind = t_end - 1 - t;  // tiles issued after tile t that may stay in flight (at most NSTAGE - 1)
+      if (behind >= 3 && NSTAGE >= 4) wait_vmcnt<3 * 2 * PPW>();
+      else if (behind >= 2 && NSTAGE >= 3) wait_vmcnt<2 * 2 * PPW>();
+      else if (behind >= 1) wait_vmcnt<2 * PPW>();
+      else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();  // every wave's share of tile t has landed
       compute(phase, t, st, n_keys);
       wait_lgkmcnt0();
       __builtin_amdgcn_s_barrier();  // everyone is done reading stage st before it is refilled
+      st = st + 1 == NSTAGE ? 0 : st + 1;
     }
   };
 
@@ -581,10 +608,10 @@ __global__ __launch_bounds__(64) void extend_generic_kernel(ExtendArgs a, int D,
   }
 }
 
-template <int DTYPE, int D, typename IdxT, int GH, bool MASKED, bool KV8 = false, int KSPLIT = 1>
+template <int DTYPE, int D, typename IdxT, int GH, bool MASKED, bool KV8 = false, int KSPLIT = 1, int NSTAGE = 2>
 int launch_mfma(ExtendArgs a, int64_t batch, int max_len_extend, hipStream_t s) {
-  auto kern = extend_mfma_kernel<DTYPE, D, IdxT, GH, MASKED, KV8, KSPLIT>;
-  constexpr int lds = 2 * 2 * kBN * D * 2 + kIdxCap * 4;
+  auto kern = extend_mfma_kernel<DTYPE, D, IdxT, GH, MASKED, KV8, KSPLIT, NSTAGE>;
+  constexpr int lds = NSTAGE * 2 * kBN * D * 2 + kIdxCap * 4;
   static int attr_rc = check_hip(
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
       "hipFuncSetAttribute");
@@ -597,6 +624,8 @@ int launch_mfma(ExtendArgs a, int64_t batch, int max_len_extend, hipStream_t s) 
     set_error("extend_attention: grid too large");
     return SGL_MI355_ERR_INVALID_ARGUMENT;
   }
+  // (Tried, round 3: with 512 workgroups on 256 CUs, the second 256 in ASCENDING weight so that a CU gets ranks j and
+  //  511 - j instead of j and 256 + j -- no change, 35.9 vs 36.1 us at 1024 tokens: profiles/r03_extend_fold.txt.)
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, a);
   return check_hip(hipGetLastError(), "extend_mfma_kernel launch");
 }
@@ -653,12 +682,24 @@ int dispatch(ExtendArgs a, int64_t batch, int D, int Dv, int max_len_extend, hip
       const int64_t grid1 = batch * (a.num_heads / gh) * ((max_len_extend + bp1 - 1) / bp1);
       const bool ksplit = ks_env >= 0 ? ks_env != 0 : (grid1 <= 512 && max_len_extend >= 256);
       if (ksplit && !masked) {
+        // (Round 3: more tiles in flight -- NSTAGE 3 / 4, one workgroup per CU instead of two -- do NOT help: 38.8 / 38.9 us
+        //  against 35.8 at 1024 tokens, 83 against 54 at 1536 (profiles/r03_extend_nstage.txt).  The longest block's chain is
+        //  issue-bound -- ~1.4-2 us of MFMA + softmax + DMA address work per tile with two workgroups sharing the SIMDs --
+        //  not a chain of exposed DMA round trips.  SGL_MI355_EXTEND_NSTAGE=3|4 keeps the variants reachable for A/B.)
+        static const int ns_env = [] { const char* e = getenv("SGL_MI355_EXTEND_NSTAGE"); return e ? atoi(e) : 2; }();
+#define EXT_KS(DD, GG)                                                                                              \
+  do {                                                                                                              \
+    if (ns_env == 2) return launch_mfma<DTYPE, DD, int32_t, GG, false, false, 2, 2>(a, batch, max_len_extend, s);   \
+    if (ns_env == 3) return launch_mfma<DTYPE, DD, int32_t, GG, false, false, 2, 3>(a, batch, max_len_extend, s);   \
+    return launch_mfma<DTYPE, DD, int32_t, GG, false, false, 2, 4>(a, batch, max_len_extend, s);                    \
+  } while (0)
         if (D == 128) {
-          if (gh == 4) return launch_mfma<DTYPE, 128, int32_t, 2, false, false, 2>(a, batch, max_len_extend, s);
-          return launch_mfma<DTYPE, 128, int32_t, 1, false, false, 2>(a, batch, max_len_extend, s);
+          if (gh == 4) EXT_KS(128, 2);
+          EXT_KS(128, 1);
         }
-        if (gh == 4) return launch_mfma<DTYPE, 64, int32_t, 2, false, false, 2>(a, batch, max_len_extend, s);
-        return launch_mfma<DTYPE, 64, int32_t, 1, false, false, 2>(a, batch, max_len_extend, s);
+        if (gh == 4) EXT_KS(64, 2);
+        EXT_KS(64, 1);
+#undef EXT_KS
       }
     }
 #define EXT_LAUNCH(DD, GG)                                                             \

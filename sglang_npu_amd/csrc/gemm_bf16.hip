@@ -271,7 +271,11 @@ int launch16(const G16Args& p, hipStream_t s) {
   // weight-load cache policy (SGL_MI355_GEMM16_NT=0|1: A/B aid)
   // (measured, LM head 4096 x 128256, M = 1 / 16 / 64: nt 188 / 196 / 249 us, default policy 175 / 180 / 231 us: unlike
   //  the LDS-DMA K/V stream of the decode kernel, register loads do not gain from the hint)
-  static const int nt = [] { const char* e = getenv("SGL_MI355_GEMM16_NT"); return e ? atoi(e) : 0; }();
+  // Round 3, fragment-major weights (contiguous 1-KiB loads): there the hint DOES pay -- LM head, M = 1 / 16 / 64: 155 / 159 /
+  // 184 us with nt against 174 / 179 / 195 without (hipBLASLt 183-187 / 187-188 / 210; profiles/r03_lm_head_points.jsonl) --
+  // as it does for the unsplit FP8 streamer (gemm_fp8.hip).  Default: on for pre-shuffled weights, off for row-major ones.
+  static const int nt_env = [] { const char* e = getenv("SGL_MI355_GEMM16_NT"); return e ? atoi(e) : -1; }();
+  const int nt = nt_env >= 0 ? nt_env : (p.b_shuf ? 1 : 0);
 #define G16_GO(PH_)                                                                                   \
   do {                                                                                                \
     if constexpr (kCanNB2) {                                                                          \

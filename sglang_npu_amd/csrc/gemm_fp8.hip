@@ -36,6 +36,11 @@ namespace {
 
 constexpr float kFp8Max = 448.0f;
 
+// Which GEMM kernel family the last fp8_scaled_mm(_partials) call of this thread launched (sgl_mi355_fp8_last_kernel):
+// "skinny", "oneshot", "astat", "astat_direct", "wstream", "wstream_slab", "tiled", "tiled2", "tiled3".  A test aid: the
+// dispatch table of run_gemm is long, and tests/test_fp8_gpu.py names a shape that reaches each family.
+thread_local const char* g_last_kernel = "";
+
 // ------------------------------------------------------------------------------------------
 // per-token quant: one workgroup (256 threads) per row; two passes (second read is L2-hot)
 template <int DTYPE, int NT = 256>
@@ -542,6 +547,7 @@ int launch_oneshot(const GemmArgs& p, hipStream_t s, bool& used) {
   else if (S == 3) OS_GO(3);
   else OS_GO(4);
 #undef OS_GO
+  g_last_kernel = "oneshot";
   used = true;
   return check_hip(hipGetLastError(), "fp8_gemm_oneshot launch");
 }
@@ -1105,6 +1111,7 @@ int launch_wstream_ph(const GemmArgs& p, float* slabs, int SK, int phases_per_sl
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
       "hipFuncSetAttribute");
   if (attr_rc) return attr_rc;
+  g_last_kernel = SLAB ? "wstream_slab" : "wstream";
   hipLaunchKernelGGL(kern, dim3((unsigned)groups, (unsigned)SK), dim3(64 * (nc + 1)), lds, s, p, slabs,
                      phases_per_slice);
   int rc = check_hip(hipGetLastError(), "fp8_gemm_wstream launch");
@@ -1169,6 +1176,18 @@ int launch_wstream(const GemmArgs& p, float* slabs, int64_t slab_floats, hipStre
       pps = steps / fph;
     }
   }
+  {  // tuning aid: SGL_MI355_WSTREAM_SLAB_FORCE="PH,nc,SK" for the split-K (slab) form
+    static const char* sforce = getenv("SGL_MI355_WSTREAM_SLAB_FORCE");
+    int fph = 0, fnc = 0, fsk = 0;
+    if (sforce && slabs != nullptr && sscanf(sforce, "%d,%d,%d", &fph, &fnc, &fsk) == 3 && (fph == 4 || fph == 8 || fph == 16 || fph == 32) &&
+        fph * MB <= 32 && steps % fph == 0 && fnc >= 1 && fnc <= 8 && fsk >= 1) {
+      const int P = steps / fph;
+      PH = fph;
+      nc = fnc;
+      pps = (P + fsk - 1) / fsk;
+      SK = (P + pps - 1) / pps;
+    }
+  }
   if (PH == 0) return 0;
   if (p.a16 != nullptr && (slabs == nullptr || pps != 1)) return 0;  // the a16 fill covers single-phase slices only
   const int groups = (nblocks + nc - 1) / nc;
@@ -1223,6 +1242,7 @@ int launch_astat_direct(const GemmArgs& p, hipStream_t s, bool& used) {
     const int cost = ((blocks + 255) / 256) * c;
     if (cost < best) { best = cost; nw = c; }
   }
+  g_last_kernel = "astat_direct";
   hipLaunchKernelGGL(kern, dim3((unsigned)((nblocks + nw - 1) / nw)), dim3(64 * nw), lds, s, p, SK, steps_per_slice);
   used = true;
   return check_hip(hipGetLastError(), "fp8_gemm_astat_direct launch");
@@ -1300,6 +1320,7 @@ int launch_astat(const GemmArgs& p, float* slabs, int64_t slab_floats, hipStream
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
       "hipFuncSetAttribute");
   if (attr_rc) return attr_rc;
+  g_last_kernel = "astat";
   hipLaunchKernelGGL(kern, dim3((unsigned)(ngroups * SK)), dim3(64 * nwaves), lds, s, p, slabs, SK, steps_per_slice);
   int rc = check_hip(hipGetLastError(), "fp8_gemm_astat launch");
   if (rc) return rc;
@@ -1903,6 +1924,7 @@ int launch_skinny(const GemmArgs& p, hipStream_t s) {
       "hipFuncSetAttribute");
   if (attr_rc) return attr_rc;
   const unsigned grid = (unsigned)((p.N + 16 * NB - 1) / (16 * NB));
+  g_last_kernel = "skinny";
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WK), lds, s, p);
   return check_hip(hipGetLastError(), "fp8_gemm_skinny launch");
 }
@@ -2030,6 +2052,7 @@ int run_gemm(const GemmArgs& p, float* workspace, int64_t workspace_floats, hipS
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds3), "hipFuncSetAttribute"); \
     if (a3) return a3;                                                                                            \
     const unsigned g3 = (unsigned)(((p.M + tmb - 1) / tmb) * ((p.N + 255) / 256));                                \
+    g_last_kernel = "tiled3";                                                                                         \
     hipLaunchKernelGGL(k3, dim3(g3), dim3(256 * WM_), lds3, s, p3);                                               \
     return check_hip(hipGetLastError(), "fp8_gemm_tiled3 launch");                                                \
   }
@@ -2048,6 +2071,7 @@ int run_gemm(const GemmArgs& p, float* workspace, int64_t workspace_floats, hipS
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds2), "hipFuncSetAttribute"); \
     if (a2) return a2;                                                                                            \
     const unsigned g2 = (unsigned)(((p.M + tmb - 1) / tmb) * ((p.N + tnb - 1) / tnb));                            \
+    g_last_kernel = "tiled2";                                                                                         \
     hipLaunchKernelGGL(k2, dim3(g2), dim3(64 * WM_ * WN_), lds2, s, p);                                           \
     return check_hip(hipGetLastError(), "fp8_gemm_tiled2 launch");                                                \
   }
@@ -2070,6 +2094,7 @@ int run_gemm(const GemmArgs& p, float* workspace, int64_t workspace_floats, hipS
   }();
   if (attr_rc) return attr_rc;
   const unsigned grid = (unsigned)(((p.M + kTM - 1) / kTM) * ((p.N + kTN - 1) / kTN));
+  g_last_kernel = "tiled";
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, p);
   return check_hip(hipGetLastError(), "fp8_gemm_tiled launch");
 }
@@ -2315,3 +2340,5 @@ extern "C" int sgl_mi355_fp8_shuffle_weight(const void* src, void* dst, int64_t 
                      (const uint8_t*)src, (uint8_t*)dst, row_stride, (int)N, (int)K, inverse);
   return check_hip(hipGetLastError(), "fp8_shuffle_weight launch");
 }
+
+extern "C" const char* sgl_mi355_fp8_last_kernel(void) { return g_last_kernel; }

@@ -51,7 +51,12 @@ __device__ __forceinline__ uint2 pack8(const float* f) {
 
 // 16 lanes per group (four groups per wave), VPL 8-element vectors per lane: group_size = 128 * VPL / ... see launcher.
 // The group's elements stay in registers between the absmax pass and the quantising pass (one read of the input).
-template <int DTYPE, int VPL>
+// UE8M0 (round 3): the scale is rounded UP to a power of two, y_s = exp2(ceil(log2(max(absmax / fp8_max, 1e-10)))), and
+// stored as its biased exponent byte, four to an int32, column-major (per_token_group_quant_8bit.cu:52-60, 87-96): byte
+// (col / 4) * s_stride_group * 4 + row * 4 + col % 4 (s_stride_group = int32 elements between packed columns).  The
+// exponent comes from the float's bits -- ceil(log2 y) = exponent + (mantissa != 0) for a normal y, and y >= 1e-10 is one
+// -- which is what exp2f(ceilf(log2f(y))) evaluates to for every y a 16-bit absmax / 448 can be.
+template <int DTYPE, int VPL, bool UE8M0 = false>
 __global__ __launch_bounds__(256) void group_quant_kernel(
     const void* __restrict__ x, uint8_t* __restrict__ q, float* __restrict__ s, int64_t num_groups, int group_size,
     int groups_per_row, int64_t s_stride_row, int64_t s_stride_group, float eps, float fmin_, float fmax_) {
@@ -73,8 +78,18 @@ __global__ __launch_bounds__(256) void group_quant_kernel(
   }
 #pragma unroll
   for (int off = 8; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
-  const float y_s = amax / fmax_;
-  if (live && lane16 == 0) s[(g / groups_per_row) * s_stride_row + (g % groups_per_row) * s_stride_group] = y_s;
+  float y_s = amax / fmax_;
+  if constexpr (UE8M0) {
+    const uint32_t bits = __float_as_uint(fmaxf(y_s, 1e-10f));
+    const uint32_t e = (bits >> 23) + ((bits & 0x7FFFFFu) != 0u ? 1u : 0u);  // biased exponent of the next power of two
+    y_s = __uint_as_float(e << 23);
+    if (live && lane16 == 0) {
+      const int64_t row = g / groups_per_row, col = g % groups_per_row;
+      reinterpret_cast<uint8_t*>(s)[(col >> 2) * s_stride_group * 4 + row * 4 + (col & 3)] = (uint8_t)e;
+    }
+  } else {
+    if (live && lane16 == 0) s[(g / groups_per_row) * s_stride_row + (g % groups_per_row) * s_stride_group] = y_s;
+  }
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
     const int vi = lane16 + 16 * i;
@@ -138,13 +153,13 @@ __global__ __launch_bounds__(256) void tensor_quant_kernel(const void* __restric
   }
 }
 
-template <int DTYPE>
+template <int DTYPE, bool UE8M0 = false>
 int launch_group(const void* x, void* q, float* s, int64_t num_groups, int group_size, int groups_per_row, int64_t ssr,
                  int64_t ssg, float eps, float mn, float mx, hipStream_t st) {
   const unsigned blocks = (unsigned)((num_groups + 15) / 16);
   const int vpl = (group_size / 8 + 15) / 16;
 #define GQ(V)                                                                                                         \
-  hipLaunchKernelGGL((group_quant_kernel<DTYPE, V>), dim3(blocks), dim3(256), 0, st, x, (uint8_t*)q, s, num_groups, \
+  hipLaunchKernelGGL((group_quant_kernel<DTYPE, V, UE8M0>), dim3(blocks), dim3(256), 0, st, x, (uint8_t*)q, s, num_groups, \
                      group_size, groups_per_row, ssr, ssg, eps, mn, mx)
   if (vpl <= 1) GQ(1);
   else if (vpl <= 2) GQ(2);
@@ -168,16 +183,24 @@ extern "C" int sgl_mi355_per_token_group_quant_fp8(
   SGLM_CHECK_ARG(group_size >= 8 && group_size % 8 == 0 && group_size <= 1024 && hidden_dim % group_size == 0,
                  "per_token_group_quant_fp8: group_size (%ld) must be a multiple of 8, at most 1024, and divide the hidden "
                  "dimension (%ld)", (long)group_size, (long)hidden_dim);
-  if (scale_ue8m0) {
-    set_error("per_token_group_quant_fp8: UE8M0 (power-of-two, packed) scales are not built");
-    return SGL_MI355_ERR_UNSUPPORTED;
-  }
   SGLM_CHECK_ARG(fp8_max > 0.f && fp8_min < 0.f, "per_token_group_quant_fp8: bad fp8_min / fp8_max");
   if (num_tokens == 0) return 0;
   SGLM_CHECK_ARG(input && output_q && output_s, "per_token_group_quant_fp8: null tensor pointer");
   const int gpr = (int)(hidden_dim / group_size);
   const int64_t ng = num_tokens * gpr;
   hipStream_t st = as_stream(stream);
+  if (scale_ue8m0) {
+    // output_s: int32 [num_tokens][ceil(gpr / 4)] column-major (s_stride_token == 1: the kernel asserts is_column_major,
+    // per_token_group_quant_8bit.cu:171-186), s_stride_group = int32 elements between packed columns >= num_tokens
+    SGLM_CHECK_ARG((s_stride_token == 1 || num_tokens == 1) && s_stride_group >= num_tokens,
+                   "per_token_group_quant_fp8 (UE8M0): output_s must be the column-major packed int32 tensor "
+                   "(stride(0) == 1, stride(1) >= num_tokens; got %ld, %ld)", (long)s_stride_token, (long)s_stride_group);
+    if (dtype == SGL_MI355_BF16)
+      return launch_group<SGL_MI355_BF16, true>(input, output_q, output_s, ng, (int)group_size, gpr, 0, s_stride_group, eps, fp8_min, fp8_max, st);
+    if (dtype == SGL_MI355_FP16)
+      return launch_group<SGL_MI355_FP16, true>(input, output_q, output_s, ng, (int)group_size, gpr, 0, s_stride_group, eps, fp8_min, fp8_max, st);
+    return launch_group<2, true>(input, output_q, output_s, ng, (int)group_size, gpr, 0, s_stride_group, eps, fp8_min, fp8_max, st);
+  }
   if (dtype == SGL_MI355_BF16)
     return launch_group<SGL_MI355_BF16>(input, output_q, output_s, ng, (int)group_size, gpr, s_stride_token, s_stride_group, eps, fp8_min, fp8_max, st);
   if (dtype == SGL_MI355_FP16)

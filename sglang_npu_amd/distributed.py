@@ -28,7 +28,7 @@ logger = logging.getLogger(__name__)
 
 # How many collectives each data plane took since the last clear() -- bench.py reports it per step so that the first
 # multi-GPU run shows which backend every one of the 2 x layers + 1 all-reduces went through (keys: 'quickreduce',
-# 'p2p', 'p2p+norm', 'p2p+norm(partials)', 'rccl', 'stub').  Counted where Python dispatches, i.e. once per capture of a
+# 'p2p', 'p2p+norm', 'p2p+norm(partials)', 'rccl', 'stub'; 'all_gather(rccl)' for the LM head's gather).  Counted where Python dispatches, i.e. once per capture of a
 # graph, not per replay.
 import collections  # noqa: E402
 DISPATCH_COUNTS: "collections.Counter[str]" = collections.Counter()
@@ -426,6 +426,7 @@ class GroupCoordinator:
         inp = input_.contiguous()
         if inp.dim() == 0:
             inp = inp.view(1)
+        DISPATCH_COUNTS["all_gather(rccl)"] += 1
         flat = torch.empty((self.world_size * inp.shape[0],) + tuple(inp.shape[1:]), dtype=inp.dtype, device=inp.device)
         dist.all_gather_into_tensor(flat, inp, group=self.device_group)
         out = flat.view((self.world_size,) + tuple(input_.shape)).movedim(0, dim)

@@ -466,7 +466,8 @@ def sgl_per_token_group_quant_fp8(input: torch.Tensor, output_q: torch.Tensor, o
                                   eps: float, fp8_min: float, fp8_max: float, scale_ue8m0: bool = False) -> None:
     """sgl_kernel.sgl_per_token_group_quant_fp8(input, output_q, output_s, group_size, eps, fp8_min, fp8_max,
     scale_ue8m0) -- sgl-kernel/python/sgl_kernel/gemm.py:100-112, per_token_group_quant_8bit.cu:140-215.
-    output_s: fp32 [..., K / group_size], row-major or the reference's column-major (transposed-storage) form."""
+    output_s: fp32 [..., K / group_size], row-major or the reference's column-major (transposed-storage) form; with
+    scale_ue8m0 the packed int32 column-major tensor of power-of-two exponents (per_token_group_quant_8bit.cu:52-96)."""
     _need_gpu(input, output_q, output_s)
     if not input.is_contiguous() or not output_q.is_contiguous():
         raise RuntimeError("sgl_per_token_group_quant_fp8: input and output_q must be contiguous")
@@ -474,9 +475,16 @@ def sgl_per_token_group_quant_fp8(input: torch.Tensor, output_q: torch.Tensor, o
         raise RuntimeError("sgl_per_token_group_quant_fp8: output_q must be float8_e4m3fn with input's shape")
     K = input.size(-1)
     T = input.numel() // K
-    if output_s.dim() != 2 or output_s.dtype != torch.float32:
+    if scale_ue8m0:
+        # power-of-two scales as exponent bytes, four to an int32, column-major: the tensor of
+        # create_per_token_group_quant_fp8_output_scale(..., scale_ue8m0=True) (fp8_kernel.py:308-319)
+        if output_s.dim() != 2 or output_s.dtype != torch.int32 or K % group_size != 0 or \
+                tuple(output_s.shape) != (T, -(-(K // group_size) // 4)) or (T > 1 and output_s.stride(0) != 1):
+            raise RuntimeError("sgl_per_token_group_quant_fp8 (scale_ue8m0): output_s must be the column-major int32 "
+                               "[num_tokens, ceil(hidden_dim / group_size / 4)] tensor")
+    elif output_s.dim() != 2 or output_s.dtype != torch.float32:
         raise RuntimeError("sgl_per_token_group_quant_fp8: output_s must be a 2-D float32 tensor")  # CHECK_EQ(output_s.dim(), 2)
-    if K % group_size != 0 or tuple(output_s.shape) != (T, K // group_size):
+    elif K % group_size != 0 or tuple(output_s.shape) != (T, K // group_size):
         raise RuntimeError("sgl_per_token_group_quant_fp8: output_s must be [num_tokens, hidden_dim / group_size]")
     _lib.check(_lib.lib().sgl_mi355_per_token_group_quant_fp8(
         _ptr(input), _ptr(output_q), _ptr(output_s), _I64(T), _I64(K), _I64(group_size), _I64(output_s.stride(0)),
@@ -557,6 +565,13 @@ def is_wshuffled(w: torch.Tensor) -> bool:
 
 def fp8_shuffle_supported(N: int, K: int) -> bool:
     return N > 0 and K > 0 and N % 16 == 0 and K % 512 == 0
+
+
+def fp8_last_kernel() -> str:
+    """Kernel family launched by this thread's last fp8_scaled_mm / fp8_scaled_mm_partials call (test aid)."""
+    f = _lib.lib().sgl_mi355_fp8_last_kernel
+    f.restype = ctypes.c_char_p
+    return f().decode()
 
 
 def fp8_shuffle_weight(weight_nk: torch.Tensor, inverse: bool = False) -> torch.Tensor:

@@ -150,6 +150,13 @@ def _local_ranks_worker(world, q):
                     continue
                 g = torch.Generator().manual_seed(T * H + world)
                 parts = [(torch.randn(T, H, generator=g) * 0.5).to(dt).to(dev) for _ in range(world)]
+                # the fused-norm staging area is bound to ONE row length per communicator (row b <-> block b): another H
+                # is refused until the binding is dropped, which is legal here -- nothing is in flight on any rank
+                torch.cuda.synchronize()
+                for c in comms:
+                    if c._norm_h not in (None, H):
+                        assert not c.should_fuse_norm(parts[0])
+                    c.rebind_fused_norm()
                 res0 = torch.randn(T, H, generator=g).to(dt).to(dev)
                 w = (torch.rand(H, generator=g) + 0.5).to(dt).to(dev)
                 for quant in (False, True):
@@ -189,6 +196,9 @@ def _local_ranks_worker(world, q):
                 if H % (8 * world):
                     continue
                 g = torch.Generator().manual_seed(T + H + SK + world)
+                torch.cuda.synchronize()
+                for c in comms:
+                    c.rebind_fused_norm()
                 gps = []
                 for r in range(world):
                     ws = torch.randn(SK, T, H, generator=g).to(dev)

@@ -249,8 +249,44 @@ def test_group_quant_vs_oracle_and_per_token_limit(T, K, G):
         ops.sgl_per_token_group_quant_fp8(x.to(DEV), q, s1, K, 1e-10, -448.0, 448.0)
         ops.sgl_per_token_quant_fp8(x.to(DEV), torch.empty_like(q), s2)
         assert torch.equal(s1, s2)
-    with pytest.raises(NotImplementedError, match="UE8M0"):
+    with pytest.raises(RuntimeError, match="scale_ue8m0"):  # the UE8M0 form takes the packed int32 tensor, not fp32 scales
         ops.sgl_per_token_group_quant_fp8(x.to(DEV), q, s, G, 1e-10, -448.0, 448.0, True)
+
+
+def _ue8m0_scale_tensor(T, K, G, device):
+    """create_per_token_group_quant_fp8_output_scale(..., scale_ue8m0=True), fp8_kernel.py:308-319."""
+    align = lambda v, a: (v + a - 1) // a * a  # noqa: E731
+    return torch.zeros((align(K // G, 4) // 4, align(T, 4)), device=device, dtype=torch.int32).transpose(0, 1)[:T, :]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("T,K,G", [(1, 512, 128), (7, 7168, 128), (64, 4096, 128), (130, 1536, 64), (33, 384, 128)])
+def test_group_quant_ue8m0_packed_scales(T, K, G, dtype):
+    """sgl_per_token_group_quant_fp8(..., scale_ue8m0=True) (per_token_group_quant_8bit.cu:24-137): power-of-two scales as
+    exponent bytes packed four to an int32, column-major -- against the C oracle (the reference's exp2 / ceil / log2
+    formula) byte for byte, and against the formula written in torch."""
+    g = torch.Generator().manual_seed(T + K + G)
+    x = (torch.randn(T, K, generator=g) * torch.rand(T, 1, generator=g) * 30).to(dtype)
+    x[0, :G] = 0                       # an all-zero group: the 1e-10 floor
+    if T > 1:
+        x[1, :G] = 448.0 * 2.0 ** -3   # absmax / 448 an exact power of two: no rounding up
+    q_ref, s_ref = torch.empty(T, K, dtype=torch.uint8), _ue8m0_scale_tensor(T, K, G, "cpu")
+    oracle.per_token_group_quant_fp8_ue8m0(x, q_ref, s_ref, G, 1e-10, -448.0, 448.0)
+    q = torch.empty(T, K, dtype=torch.float8_e4m3fn, device=DEV)
+    s = _ue8m0_scale_tensor(T, K, G, DEV)
+    ops.sgl_per_token_group_quant_fp8(x.to(DEV), q, s, G, 1e-10, -448.0, 448.0, True)
+    assert torch.equal(s.cpu(), s_ref) and torch.equal(q.cpu().view(torch.uint8), q_ref)
+    # the formula itself, in torch: exponent bytes and the quantised values
+    gpr = K // G
+    amax = x.float().view(T, gpr, G).abs().amax(-1).clamp_min(1e-10)
+    e = torch.ceil(torch.log2((amax / 448.0).clamp_min(1e-10)))
+    packed = s.cpu().to(torch.int64) & 0xFFFFFFFF  # [T, ceil(gpr / 4)]: byte c % 4 of int32 c / 4 is group c's exponent
+    bytes_ = torch.stack([(packed[:, c // 4] >> (8 * (c % 4))) & 0xFF for c in range(gpr)], dim=1)
+    assert torch.equal(bytes_, (e + 127).to(torch.int64))
+    q_t = (x.float().view(T, gpr, G) / torch.exp2(e)[..., None]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    assert torch.equal(q.cpu().view(torch.uint8).view(T, gpr, G), q_t.view(torch.uint8))
+    if T > 1:
+        assert int(bytes_[1, 0]) == 127 - 3 and int(bytes_[0, 0]) == int(torch.ceil(torch.log2(torch.tensor(1e-10)))) + 127
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -307,3 +343,37 @@ def test_linear16_shuffle_rejects_other_shapes():
         ops.linear16_shuffle_weight(torch.zeros(1000, 512, device=DEV, dtype=torch.bfloat16))
     with pytest.raises(RuntimeError, match="K % 256 == 0"):
         ops.linear16_shuffle_weight(torch.zeros(1024, 896, device=DEV, dtype=torch.bfloat16))
+
+
+@pytest.mark.parametrize("M,N,K,shuffled,partials,family", [
+    (64, 28672, 4096, True, False, "wstream"),        # gate_up at decode: one column block per wave over all of K
+    (64, 4096, 14336, True, True, "wstream_slab"),    # down_proj at decode: split-K slabs
+    (64, 4096, 1024, False, False, "oneshot"),        # K <= 1024 at any width: every load issued up front
+    (16, 28672, 4096 + 64, False, False, "astat_direct"),  # wide N with a K tail, row-major weight
+    (16, 1024, 65536 + 64, False, False, "astat"),    # narrow N, very long K with a tail
+    (7, 48, 208, False, False, "skinny"),             # ragged little shapes (K % 16 == 0 is the op's own precondition)
+    (4096, 28672, 4096, True, False, "tiled3"),       # prefill on a pre-shuffled weight, >= 192 tiles of 128 x 256
+    (1024, 4096, 4096, True, False, "tiled2"),        # prefill with fewer tiles
+    (300, 512, 1008, False, False, "tiled"),          # K tail at M > 64
+])
+def test_every_gemm_kernel_family_is_reachable(M, N, K, shuffled, partials, family):
+    """run_gemm's dispatch table (gemm_fp8.hip) by name: each kernel generation that is still compiled in has a shape that
+    reaches it -- and gives the right product there (fp64 reference, one output ulp)."""
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    a = ((torch.rand(M, K, generator=g, device=DEV) - 0.5) * 8).to(torch.float8_e4m3fn)
+    w = ((torch.rand(N, K, generator=g, device=DEV) - 0.5) * 8).to(torch.float8_e4m3fn)
+    sa = torch.rand(M, 1, generator=g, device=DEV) * 1e-2 + 1e-3
+    sb = torch.rand(N, 1, generator=g, device=DEV) * 1e-2 + 1e-3
+    wt = ops.mark_wshuffled(ops.fp8_shuffle_weight(w).t()) if shuffled else w.t()
+    if partials:
+        part = ops.fp8_scaled_mm_partials(a, wt, sa, sb, torch.bfloat16)
+        assert part is not None
+        name = ops.fp8_last_kernel()
+        out = part.finalize()
+    else:
+        out = ops.fp8_scaled_mm(a, wt, sa, sb, torch.bfloat16)
+        name = ops.fp8_last_kernel()
+    assert name == family, (name, family)
+    rows = torch.tensor(sorted({0, M // 2, M - 1}), device=DEV)
+    ref = (a[rows].double() @ w.double().t()) * sb.double().view(1, -1) * sa[rows].double()
+    torch.testing.assert_close(out[rows].double(), ref, rtol=2.0 ** -7, atol=1e-3 * float(ref.abs().max()))

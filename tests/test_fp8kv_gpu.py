@@ -131,9 +131,10 @@ def test_decode_fp8_kv_exact_when_every_p_is_a_power_of_two(kv_dtype, Hq, Hkv, s
     got = o.float().cpu()
     t16 = truth.float().bfloat16().float()  # the correctly rounded answer
     ulp = 2.0 ** -7  # one bf16 ulp relative to the element (8 significant bits)
-    # one output ulp, plus the fp32 accumulation noise of a sum whose terms (random signs) may cancel: 2^-18 of sum p|v| / sum p
-    # -- four orders of magnitude below what a wrongly rounded P would cause (2^-4 per probability)
-    slack = (2.0 ** -18 * mag).float()
+    # one output ulp, plus the fp32 noise of a sum whose terms (random signs) may cancel: 2^-16 of sum p|v| / sum p (measured
+    # on the GPU: up to 2^-17.4 -- the online-softmax rescales go through v_exp_f32, ~1 ulp each, and compound over the
+    # tiles) -- still three to four orders of magnitude below what a wrongly rounded P would cause (2^-4 per probability)
+    slack = (2.0 ** -16 * mag).float()
     for name, want in (("closed form", t16), ("oracle", ref.float())):
         diff = (got - want).abs()
         assert bool((diff <= ulp * want.abs() + slack).all()), (name, float(((diff - ulp * want.abs()) / mag.float()).max()))
