@@ -354,14 +354,69 @@ def reference_cpu_container():
         return None
 
 
+def time_awq_decode_gemms(layers, B, device):
+    """`roofline_gemm` of the AWQ config: the four INT4 g128 dequant-GEMMs of a layer at M = B rows, each
+    as one captured graph that runs it once per layer on that layer's own packed weights; bytes = K*N/2 (nibbles) +
+    K/G*N/2 (zeros) + K/G*N*2 (scales) + 2*M*K + 2*M*N."""
+    from sglang_npu_amd import ops
+    names = [("qkv", lambda l: l.self_attn.qkv_proj), ("o", lambda l: l.self_attn.o_proj),
+             ("gate_up", lambda l: l.mlp.gate_up_proj), ("down", lambda l: l.mlp.down_proj)]
+    out = {"unit_hbm": "GB/s", "peak_hbm": HBM_PEAK_GBPS, "quant": "awq int4 g128 (k-packed copy, fp16 activations)", "shapes": []}
+    g = torch.Generator(device=device).manual_seed(7)
+    tot_us, tot_bytes = 0.0, 0
+    for name, pick in names:
+        lins = [pick(l) for l in layers]
+        wp, sz, G = lins[0].awq_packed
+        N, K = int(lins[0].awq_out_features), int(getattr(lins[0], "input_size_per_partition", lins[0].input_size))
+        x = torch.randn(B, K, device=device, generator=g).half()
+
+        def run():
+            for lin in lins:
+                ops.awq_gemm_packed(x, lin.awq_packed[0], lin.awq_packed[1], lin.awq_packed[2])
+
+        s = torch.cuda.Stream(device=device)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            run()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            run()
+        graph.replay()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            st.record()
+            graph.replay()
+            en.record()
+            torch.cuda.synchronize()
+            ts.append(st.elapsed_time(en) * 1e3 / len(lins))
+        ts.sort()
+        us = ts[len(ts) // 2]
+        nbytes = K * N // 2 + (K // G) * N // 2 + (K // G) * N * 2 + 2 * B * K + 2 * B * N
+        out["shapes"].append({"name": name, "K": K, "N": N, "decode": {"M": B, "us": round(us, 2), "GBps": round(nbytes / us / 1e3, 1),
+                                                                     "frac_hbm": round(nbytes / us / 1e3 / HBM_PEAK_GBPS, 4)}})
+        tot_us += us
+        tot_bytes += nbytes
+        del graph
+    out["decode_all_four"] = {"us": round(tot_us, 2), "frac_hbm": round(tot_bytes / tot_us / 1e3 / HBM_PEAK_GBPS, 4)}
+    out["note"] = ("event-timed in this run: one HIP graph per shape with one call per layer on that layer's packed weights, "
+                   "median of 5 replays / layers; includes the split-K finalize launch where the kernel uses it")
+    return out
+
+
 def time_decode_gemms(net, cfg, B, device, tp):
     """`roofline_gemm`: the four FP8 decode GEMMs of a layer, each as ONE captured HIP graph that runs it once per
     layer on that layer's own weights (32 different weight matrices: nothing is served from L2 / Infinity Cache the
     way a loop over one matrix would be), timed with HIP events over 5 replays; M = B rows for the HBM fraction
-    (bytes = M*K + K*N + 2*M*N + 4*(M+N)) and M = 4096 for the MFMA fraction (2*M*N*K flops
-    against the 5 PFLOP/s dense FP8 peak)."""
+    (bytes = M*K + K*N + 2*M*N + 4*(M+N)) and M = 1024 (the TTFT pass) and 4096 for the MFMA fraction
+    (2*M*N*K flops against the 5 PFLOP/s dense FP8 peak)."""
     from sglang_npu_amd import ops
     layers = list(net.layers)
+    if getattr(layers[0].mlp.gate_up_proj, "awq_packed", None) is not None:
+        return time_awq_decode_gemms(layers, B, device)
     if not hasattr(layers[0].mlp.gate_up_proj, "weight") or layers[0].mlp.gate_up_proj.weight.dtype != torch.float8_e4m3fn:
         return None
     names = [("qkv", lambda l: l.self_attn.qkv_proj), ("o", lambda l: l.self_attn.o_proj),
@@ -372,7 +427,7 @@ def time_decode_gemms(net, cfg, B, device, tp):
         lins = [pick(l) for l in layers]
         K, N = lins[0].weight.shape  # stored K-major [K, N]
         row = {"name": name, "K": int(K), "N": int(N)}
-        for M, key in ((B, "decode"), (4096, "prefill")):
+        for M, key in ((B, "decode"), (1024, "prefill_1024"), (4096, "prefill")):
             a = ((torch.rand(M, K, device=device, generator=g) - 0.5) * 8).to(torch.float8_e4m3fn)
             sa = torch.rand(M, 1, device=device, generator=g) * 1e-2 + 1e-3
 
@@ -494,6 +549,10 @@ def other_configs():
                         "workload": d["config"]["workload"]})
             if "launch_includes" in d["roofline"]:
                 out[-1]["decode_attention_launch_includes"] = d["roofline"]["launch_includes"]
+            rg = d.get("roofline_gemm")
+            if isinstance(rg, dict) and "decode_all_four" in rg:  # the config's own GEMM roofline (AWQ: config 4)
+                out[-1]["roofline_gemm_decode"] = {"all_four": rg["decode_all_four"],
+                                                   "shapes": {r["name"]: r["decode"] for r in rg.get("shapes", []) if "decode" in r}}
         except Exception as e:  # a side measurement: never take the headline down with it
             out.append({"config": name, "error": f"{type(e).__name__}: {str(e)[:200]}"})
     return out

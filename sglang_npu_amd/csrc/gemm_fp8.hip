@@ -1502,17 +1502,18 @@ __global__ __launch_bounds__(256) void fp8_gemm_tiled_kernel(GemmArgs p) {
 
 // Epilogue of the tiled kernels: each wave scales its (16 RI) x 64 accumulator tile, adds the bias and stores it in passes
 // of 64 rows through a wave-private [64][64] (+8 pad) LDS patch (9216 B) that turns the MFMA layout into 16-B row segments.
-template <int OUT_DTYPE, int RI>
-__device__ __forceinline__ void tiled_epilogue(const GemmArgs& p, char* smem, f32x4 (&acc)[RI][4], int m0, int n0, int wm,
+template <int OUT_DTYPE, int RI, int CB = 4>
+__device__ __forceinline__ void tiled_epilogue(const GemmArgs& p, char* smem, f32x4 (&acc)[RI][CB], int m0, int n0, int wm,
                                                int wn, int wave, int lane) {
+  // CB: 16-column blocks per wave (4: the 64-column wave tile; 3: the 48-column one of the 192-wide tiled3 tiles)
   using H = Half16<OUT_DTYPE>;
   using T = typename H::T;
   const int r16 = lane & 15, g = lane >> 4;
   T* ep = reinterpret_cast<T*>(smem) + wave * (64 * 72);
-  float sbv[4];
+  float sbv[CB];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int n = n0 + wn * 64 + 16 * j + r16;
+  for (int j = 0; j < CB; ++j) {
+    const int n = n0 + wn * 16 * CB + 16 * j + r16;
     sbv[j] = p.sb[n < p.N ? n : p.N - 1];
   }
   constexpr int RP = RI < 4 ? RI : 4;  // 16-row fragments per epilogue pass
@@ -1527,23 +1528,25 @@ __device__ __forceinline__ void tiled_epilogue(const GemmArgs& p, char* smem, f3
         const int m = mw0 + ml;
         const float sa = p.sa[m < p.M ? m : p.M - 1];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < CB; ++j) {
           const int nl = 16 * j + r16;
           float v = acc[RP * pass + i][j][r] * sbv[j] * sa;
           if (p.bias) {
-            const int n = n0 + wn * 64 + nl;
+            const int n = n0 + wn * 16 * CB + nl;
             v += H::to_f32(reinterpret_cast<const T*>(p.bias)[n < p.N ? n : p.N - 1]);
           }
           ep[ml * 72 + nl] = H::from_f32(v);
         }
       }
     wait_lgkmcnt0();  // wave-private patch: a wave-level LDS wait is enough
+    constexpr int SEG = 2 * CB;              // 16-byte row segments per patch row
+    constexpr int ITEMS = 16 * RP * SEG;     // segments of this pass
 #pragma unroll
-    for (int it = 0; it < 2 * RP; ++it) {
+    for (int it = 0; it < (ITEMS + 63) / 64; ++it) {
       const int c = lane + 64 * it;
-      const int ml = c >> 3, nl = (c & 7) * 8;
-      const int m = mw0 + ml, n = n0 + wn * 64 + nl;
-      if (m < p.M && n < p.N)
+      const int ml = c / SEG, nl = (c % SEG) * 8;
+      const int m = mw0 + ml, n = n0 + wn * 16 * CB + nl;
+      if (c < ITEMS && m < p.M && n < p.N)
         *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.out) + (int64_t)m * p.N + n) =
             *reinterpret_cast<const uint4*>(ep + ml * 72 + nl);
     }
@@ -1713,12 +1716,16 @@ __global__ __launch_bounds__(64 * WM * WN) void fp8_gemm_tiled2_kernel(GemmArgs 
 // (WM times).  k permutation inside a step: lane group g holds bytes [16g, +16) and [64 + 16g, +16) -- on both operands.
 // Shapes: 256 x 256 with 8 waves (2 x 4), or 128 x 256 with 4 waves (1 x 4: no weight byte is loaded twice) and TWO
 // workgroups per CU, whose barriers and first-fragment latencies then overlap each other's MFMAs.
-template <int OUT_DTYPE, int NSTAGE, int RI, int WM, int WN>
+// CB (round 3): 16-column blocks per wave.  4 = the 128 x 256 tile; 3 = a 128 x 192 tile for widths whose 256-column tiling
+// leaves a ragged last round (qkv 4096 -> 6144: 768 tiles of 256 on 512 slots = 1.5 rounds, 1024 tiles of 192 = exactly 2
+// rounds of three quarters the work; at M = 1024 256 tiles instead of 192: every CU has one).
+template <int OUT_DTYPE, int NSTAGE, int RI, int WM, int WN, int CB = 4>
 __global__ __launch_bounds__(64 * WM * WN, 2) void fp8_gemm_tiled3_kernel(GemmArgs p) {
   static_assert(NSTAGE >= 3, "the wait count below assumes A(kt) was issued before B(kt)");
+  static_assert(CB == 3 || CB == 4, "column blocks per wave");
   constexpr int NW = WM * WN;
   constexpr int TMB = 16 * RI * WM;     // block rows
-  constexpr int TNB = 64 * WN;          // block columns
+  constexpr int TNB = 16 * CB * WN;     // block columns
   constexpr int STAGE = TMB * 128;      // A tile: TMB rows x 128 B
   constexpr int UA = TMB / 8 / NW;      // 1-KiB DMA units (8 rows x 128 B) per wave and stage
   static_assert((TMB / 8) % NW == 0, "DMA units must divide over the waves");
@@ -1767,28 +1774,28 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void fp8_gemm_tiled3_kernel(GemmAr
   };
   // weight fragments: column block (n0 / 16 + 4 wn + j), k-step kt = 2 KiB at block * 16 K + 2048 kt; lane i takes bytes
   // 16 i.. of each KiB.  Blocks past N re-read the last one (their columns are never stored).
-  const uint8_t* b_blk[4];
+  const uint8_t* b_blk[CB];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    int nb = (n0 >> 4) + wn * 4 + j;
+  for (int j = 0; j < CB; ++j) {
+    int nb = (n0 >> 4) + wn * CB + j;
     nb = nb < (p.N >> 4) ? nb : (p.N >> 4) - 1;
     b_blk[j] = p.b + (int64_t)nb * 16 * p.K;
   }
   const int nk = p.K >> 7;
-  auto load_b = [&](Frag32 (&q)[4], int kt) __attribute__((always_inline)) {
+  auto load_b = [&](Frag32 (&q)[CB], int kt) __attribute__((always_inline)) {
     const uint32_t voff = (uint32_t)lane * 16 + (uint32_t)kt * 2048;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < CB; ++j) {
       asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(q[j].x[0]) : "v"(voff), "s"(b_blk[j]) : "memory");
       asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(q[j].x[1]) : "v"(voff), "s"(b_blk[j]) : "memory");
     }
   };
 
-  f32x4 acc[RI][4];
+  f32x4 acc[RI][CB];
 #pragma unroll
   for (int i = 0; i < RI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < CB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // A fragment offsets inside the stage: row (16 (RI wm + i) + r16), chunks g and 4 + g, swizzled as the DMA wrote them
   const int sw = (r16 >> 1) & 7;
@@ -1804,11 +1811,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void fp8_gemm_tiled3_kernel(GemmAr
   // SGLM_T3_DMA_LATE -- a stricter count is never wrong).  The same wait, at column 3, also proves this wave's DMAs of
   // step kt + 1 (older than the previous step's R_3), which is what the next barrier publishes.  Tail steps re-issue the last step's DMAs into
   // the dead stage and re-read the last weights, so the counts never change.
-  Frag32 bq[4];
+  Frag32 bq[CB];
+  constexpr int YB = 2 * (CB - 1);  // loads of the OTHER column blocks' refills (6 with four blocks per wave)
 #pragma unroll
   for (int st = 0; st < NSTAGE - 1; ++st) dma_stage(st, st < nk ? st : nk - 1);
   load_b(bq, 0);
-  wait_vmcnt<(NSTAGE - 2) * UA + 8>();  // stage 0 landed (this wave's part)
+  wait_vmcnt<(NSTAGE - 2) * UA + 2 * CB>();  // stage 0 landed (this wave's part)
 #ifndef SGLM_T3_ABL
 #define SGLM_T3_ABL 0  // timing ablations (WRONG RESULTS): 1 no barrier, 2 A fragments read once, 3 no weight refills, 4 no DMA, 5 DMA always of k-step 0 (L2-resident), 6 the flops as 32x32x64 MFMAs
 #endif
@@ -1821,6 +1829,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void fp8_gemm_tiled3_kernel(GemmAr
   }
 #endif
 #if SGLM_T3_ABL == 6
+  static_assert(CB == 4, "ablation 6 is written for four column blocks");
   f32x16 acc32[4][2];
 #pragma unroll
   for (int m = 0; m < 4; ++m)
@@ -1865,16 +1874,16 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void fp8_gemm_tiled3_kernel(GemmAr
 #endif
     const uint32_t voff = (uint32_t)lane * 16 + (uint32_t)(kt + 1 < nk ? kt + 1 : nk - 1) * 2048;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < CB; ++j) {
 #if SGLM_T3_ABL == 4
-      wait_frag<6>(bq[j]);
+      wait_frag<YB>(bq[j]);
 #elif SGLM_T3_ABL == 3
       wait_frag<0>(bq[j]);
 #elif SGLM_T3_DMA_LATE
-      if (j == 0) wait_frag<6>(bq[j]);
-      else wait_frag<6 + UA>(bq[j]);
+      if (j == 0) wait_frag<YB>(bq[j]);
+      else wait_frag<YB + UA>(bq[j]);
 #else
-      wait_frag<6 + UA>(bq[j]);
+      wait_frag<YB + UA>(bq[j]);
 #endif
 #if SGLM_T3_ABL == 6
       // the step's flops as 32x32x64 MFMAs on the same operand registers (garbage products): does the other shape hold a
@@ -1912,7 +1921,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void fp8_gemm_tiled3_kernel(GemmAr
       for (int r = 0; r < 4; ++r) acc[i][j][r] = acc32[i >> 1][j >> 1][(i & 1) * 8 + (j & 1) * 4 + r];
 #endif
   __syncthreads();  // all stages dead: the epilogue reuses the memory
-  tiled_epilogue<OUT_DTYPE, RI>(p, smem, acc, m0, n0, wm, wn, wave, lane);
+  tiled_epilogue<OUT_DTYPE, RI, CB>(p, smem, acc, m0, n0, wm, wn, wave, lane);
 }
 
 template <int OUT_DTYPE, int MB, int NB, int WK>
@@ -2038,26 +2047,36 @@ int run_gemm(const GemmArgs& p, float* workspace, int64_t workspace_floats, hipS
   // Column tiles per rasterisation group: 4 (1 / 2 / 4 / 8 / 16 at M = 4096 gate_up: 437 / 418 / 408 / 403 / 435 us).
   static const int v3_env = [] { const char* e = getenv("SGL_MI355_TILED_V3"); return e ? atoi(e) : -1; }();  // 0 off; 1 / 2 force 256x256x8 waves / 128x256x4 waves (A/B aid)
   static const int gn_env = [] { const char* e = getenv("SGL_MI355_T3_GN"); return e ? atoi(e) : 0; }();       // tuning aid
-  const unsigned grid_3 = (unsigned)(((p.M + 127) / 128) * ((p.N + 255) / 256));
+  // 128 x 256 tiles, or 128 x 192 where that leaves less work on the busiest CU: tiles per CU (rounded up) x tile width.  Only
+  // the qkv-like widths gain (4096 -> 6144, same box, 256- vs 192-wide: M = 1024 36.5 -> 33.9 us, 192 -> 256 tiles; M = 2048
+  // 53.0 -> 49.6, 384 -> 512 tiles); wherever the products tie the wider tile wins (M = 4096 93.2 vs 102.4) and forcing the
+  // narrow one elsewhere costs 10-20 % (profiles/r03_prefill_gemm_cb3.txt).  SGL_MI355_T3_CB=3|4 forces one (A/B aid).
+  static const int cb_env = [] { const char* e = getenv("SGL_MI355_T3_CB"); return e ? atoi(e) : 0; }();
+  const unsigned tiles_m3 = (unsigned)((p.M + 127) / 128);
+  const unsigned grid_4 = tiles_m3 * (unsigned)((p.N + 255) / 256), grid_c3 = tiles_m3 * (unsigned)((p.N + 191) / 192);
+  const unsigned cost4 = ((grid_4 + 255) / 256) * 4, cost3 = ((grid_c3 + 255) / 256) * 3;
+  const int cb = (cb_env == 3 || cb_env == 4) ? cb_env : (cost3 < cost4 ? 3 : 4);
+  const unsigned grid_3 = cb == 3 ? grid_c3 : grid_4;
   if (p.b_shuf && (p.K & 511) == 0 && (v3_env > 0 || (v3_env != 0 && grid_3 >= 192))) {
-#define TILED3_GO(WM_)                                                                                             \
+#define TILED3_GO(WM_, CB_)                                                                                        \
   {                                                                                                               \
     GemmArgs p3 = p;                                                                                              \
     p3.raster_gn = gn_env > 0 ? gn_env : 4;                                                                       \
-    auto k3 = fp8_gemm_tiled3_kernel<OUT_DTYPE, 3, 8, WM_, 4>;                                                    \
-    constexpr int tmb = 128 * WM_;                                                                                \
+    auto k3 = fp8_gemm_tiled3_kernel<OUT_DTYPE, 3, 8, WM_, 4, CB_>;                                               \
+    constexpr int tmb = 128 * WM_, tnb = 64 * CB_;                                                                \
     constexpr int lds_st = 3 * tmb * 128, lds_ep = WM_ * 4 * 64 * 72 * 2;                                         \
     constexpr int lds3 = lds_st > lds_ep ? lds_st : lds_ep;                                                       \
     static int a3 = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(k3),                              \
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds3), "hipFuncSetAttribute"); \
     if (a3) return a3;                                                                                            \
-    const unsigned g3 = (unsigned)(((p.M + tmb - 1) / tmb) * ((p.N + 255) / 256));                                \
-    g_last_kernel = "tiled3";                                                                                         \
+    const unsigned g3 = (unsigned)(((p.M + tmb - 1) / tmb) * ((p.N + tnb - 1) / tnb));                            \
+    g_last_kernel = "tiled3";                                                                                     \
     hipLaunchKernelGGL(k3, dim3(g3), dim3(256 * WM_), lds3, s, p3);                                               \
     return check_hip(hipGetLastError(), "fp8_gemm_tiled3 launch");                                                \
   }
-    if (v3_env == 1) TILED3_GO(2)
-    TILED3_GO(1)
+    if (v3_env == 1) TILED3_GO(2, 4)
+    if (cb == 3) TILED3_GO(1, 3)
+    TILED3_GO(1, 4)
 #undef TILED3_GO
   }
   if (v2 && (p.K & 127) == 0) {

@@ -281,6 +281,8 @@ class LlamaForCausalLM(torch.nn.Module):
             self.quant_config = W8A8Fp8Config(is_checkpoint_fp8_serialized=False)
         elif quantization == "awq":
             self.quant_config = AWQConfig(4, 128, True)
+            # synthetic weights are never reloaded: keep only the k-packed INT4 copy (quantization.py)
+            self.quant_config.release_checkpoint_layout = not os.environ.get("SGL_MI355_AWQ_KEEP_CHECKPOINT_LAYOUT")
         elif quantization is not None:
             raise ValueError(f"unknown quantization {quantization}")
         tp = get_tensor_model_parallel_world_size()

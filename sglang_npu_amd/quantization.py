@@ -314,14 +314,28 @@ class AWQLinearMethod(LinearMethodBase):
         if layer.qweight.is_cuda and not os.environ.get("SGL_MI355_AWQ_NO_REPACK") and \
                 ops.awq_packable(K, N, G, layer.scales.dtype):
             layer.awq_packed = ops.awq_repack(layer.qweight.data, layer.scales.data, layer.qzeros.data) + (G,)
+            layer.awq_out_features = N
+            # The k-packed copy serves every fp16 call (decode streamer and prefill tiles), so the checkpoint-layout tensors
+            # are dead weight in HBM afterwards (K*N/2 + K*N/32 bytes per layer, 3.6 GB on Llama-2-7B).  They are released
+            # only on request -- SGL_MI355_AWQ_RELEASE_CHECKPOINT_LAYOUT=1 or AWQConfig.release_checkpoint_layout -- because a
+            # live weight reload (update_weights_from_disk: the loaders copy into these parameters, then this hook runs
+            # again) needs them.
+            if (os.environ.get("SGL_MI355_AWQ_RELEASE_CHECKPOINT_LAYOUT") or
+                    getattr(self.quant_config, "release_checkpoint_layout", False)) and layer.scales.dtype == torch.float16:
+                for name in ("qweight", "qzeros", "scales"):
+                    getattr(layer, name).data = torch.empty(0, dtype=getattr(layer, name).dtype, device=layer.qweight.device)
 
     def apply(self, layer, x: torch.Tensor, bias: Optional[torch.Tensor] = None):
         # awq.py:401-418 computes awq_dequantize(...) then x @ W; here the dequant is fused into the GEMM
         qweight, scales, qzeros = layer.qweight, layer.scales, layer.qzeros
         pack_factor = self.quant_config.pack_factor
-        out_shape = x.shape[:-1] + (qweight.shape[-1] * pack_factor,)
-        reshaped_x = x.reshape(-1, x.shape[-1])
         packed = getattr(layer, "awq_packed", None)
+        n_out = layer.awq_out_features if packed is not None else qweight.shape[-1] * pack_factor
+        out_shape = x.shape[:-1] + (n_out,)
+        reshaped_x = x.reshape(-1, x.shape[-1])
+        if packed is not None and qweight.numel() == 0 and reshaped_x.dtype != torch.float16:
+            raise RuntimeError("AWQLinearMethod.apply: the checkpoint-layout tensors were released "
+                               "(SGL_MI355_AWQ_RELEASE_CHECKPOINT_LAYOUT); only fp16 activations are served")
         if packed is not None and reshaped_x.dtype == torch.float16:
             if reshaped_x.shape[0] <= 64:  # decode: weight-streaming kernel on the k-packed copy
                 out = ops.awq_gemm_packed(reshaped_x, packed[0], packed[1], packed[2], bias)

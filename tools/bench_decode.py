@@ -25,6 +25,13 @@ def run(B, Hq, Hkv, D, S, splits, layout, iters=20, dtype=torch.bfloat16, nlayer
     vbs = [torch.randn(n_tok, Hkv, D, device=dev, generator=g).to(dtype) for _ in range(nlayers)]
     if layout == "random":
         perm = torch.randperm(n_tok - 1, device=dev, generator=g) + 1
+    elif layout.startswith("page"):
+        # what a paged allocator with page_size P hands out (allocator.py:428-449): runs of P consecutive slots, the pages
+        # themselves scattered; the page table stays token-level (req_to_token has one entry per token whatever the page size)
+        P = int(layout[4:])
+        npages = (n_tok - 1) // P
+        order = torch.randperm(npages, device=dev, generator=g)
+        perm = (order[:, None] * P + torch.arange(P, device=dev)[None, :]).reshape(-1)[: B * S] + 1
     else:
         perm = torch.arange(1, n_tok, device=dev)
     r2t = perm.view(B, S).to(torch.int32).contiguous()
@@ -56,7 +63,13 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--headline", action="store_true", help="bs=64 32/8/128, S = 512 / 2048, random page table, one split")
+    ap.add_argument("--pages", action="store_true", help="bs=64 32/8/128 S=2048: token-level random vs page_size 16 / 64 / 128 vs identity")
     a = ap.parse_args()
+    if a.pages:
+        for layout in ("random", "page16", "page64", "page128", "identity", "random"):
+            ms, gbs = run(64, 32, 8, 128, 2048, 1, layout, iters=64, nlayers=8)
+            print(json.dumps(dict(layout=layout, us=round(ms * 1e3, 2), GBps=round(gbs, 1), frac=round(gbs / 8000, 4))), flush=True)
+        sys.exit(0)
     if a.headline:
         for S in (512, 2048, 4096):
             ms, gbs = run(64, 32, 8, 128, S, 1, "random", iters=64, nlayers=8)
