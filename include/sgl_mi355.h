@@ -567,6 +567,12 @@ int sgl_mi355_gemm16_nt(const void* x, const void* weight, const void* bias, voi
  * step).  N % 16 == 0, K % 256 == 0.  Results are bit-identical to sgl_mi355_gemm16_nt on the row-major weight. */
 int sgl_mi355_gemm16_nt_wshuffled(const void* x, const void* weight_shuffled, const void* bias, void* out, int64_t M,
                                   int64_t N, int64_t K, int64_t x_stride_m, int dtype, void* stream);
+/* The same with an fp32 workspace (>= 16 * M * N floats covers every shape): narrow N is cut along K over the workgroups
+ * (split-K slabs + a finalize launch that sums the slices in order, adds the bias and rounds once) -- the unquantised
+ * o_proj / down_proj / qkv of a bf16 model at decode sizes (layers/quantization/unquant.py: F.linear). */
+int sgl_mi355_gemm16_nt_wshuffled_splitk(const void* x, const void* weight_shuffled, const void* bias, void* out,
+                                         float* workspace, int64_t workspace_floats, int64_t M, int64_t N, int64_t K,
+                                         int64_t x_stride_m, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Replaces: sgl_per_token_group_quant_fp8(Tensor input, Tensor output_q, Tensor output_s, int group_size, float eps,

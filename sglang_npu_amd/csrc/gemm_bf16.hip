@@ -28,6 +28,8 @@ struct G16Args {
   void* out;         // [M][N] 16-bit
   int M, N, KB;      // KB = K * 2: contraction length in BYTES (128 per k-step)
   int throttle;      // producer: k-steps of activation DMA allowed in flight (0 = the whole phase at once)
+  float* slabs;      // split-K form: fp32 partials [slices][M][N] (SLAB kernels), summed by gemm16_finalize_kernel
+  int pps;           // ... phases per K slice
   int b_shuf;        // weights are FRAGMENT-MAJOR (round 3): the 2 KiB of a (16-column block, 64-k step) stored as
                      // [half][lane group g][row r16][16 B] -- the byte layout of the pre-shuffled FP8 weights
                      // (include/sgl_mi355.h), so a wave's load instruction covers one contiguous KiB
@@ -68,8 +70,12 @@ __device__ __forceinline__ void drain_segs(Seg32 (&q)[PB][NB]) {
     for (int j = 0; j < NB; ++j) asm volatile("" ::"v"(q[i][j].x[0]), "v"(q[i][j].x[1]));
 }
 
-template <int DTYPE, int MB, int PH, bool NT, int NB, int PB = 2, bool SHUF = false>
+// SLAB (round 3): K is split over blockIdx.y in whole phases; a workgroup writes the fp32 partial of its slice and
+// gemm16_finalize_kernel sums the slices in order, adds the bias and rounds once -- for narrow N (o_proj, down_proj, qkv of
+// the bf16 config), where one workgroup per 4-8 column blocks over all of K leaves most CUs idle.
+template <int DTYPE, int MB, int PH, bool NT, int NB, int PB = 2, bool SHUF = false, bool SLAB = false>
 __global__ __launch_bounds__(576) void gemm16_wstream_kernel(G16Args p) {
+  static_assert(!SLAB || NB == 1, "the split-K form is built for one column block per wave");
   static_assert(PH * MB <= 32, "one A buffer is at most 64 KiB");
   using H = Half16<DTYPE>;
   using T = typename H::T;
@@ -85,7 +91,10 @@ __global__ __launch_bounds__(576) void gemm16_wstream_kernel(G16Args p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int NC = (int)(blockDim.x >> 6) - 1;  // consumer waves; wave NC is the DMA producer
   const int r16 = lane & 15, g = lane >> 4;
-  const int nph = (p.KB >> 7) / PH;
+  const int P_total = (p.KB >> 7) / PH;
+  const int ph0 = SLAB ? (int)blockIdx.y * p.pps : 0;
+  const int ph1 = SLAB ? (ph0 + p.pps < P_total ? ph0 + p.pps : P_total) : P_total;
+  const int nph = ph1 - ph0;
   // NB 16-column blocks per consumer wave (NB = 2 at 64 rows: the activation image, re-read from L2 by every workgroup,
   // is then amortised over twice the weight bytes -- at M = 64 it is half as many bytes per k-step as 8 waves' weights)
   const int nb0 = (blockIdx.x * NC + wave) * NB;
@@ -118,11 +127,11 @@ __global__ __launch_bounds__(576) void gemm16_wstream_kernel(G16Args p) {
         else if (p.throttle == 4) wait_vmcnt<4 * UPS>();
       }
     };
-    dma_phase(0, 0);
+    dma_phase(ph0, 0);
     for (int lp = 0; lp < nph; ++lp) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // phase lp has landed
       __syncthreads();                                   // barrier #lp
-      if (lp + 1 < nph) dma_phase(lp + 1, (lp + 1) & 1);
+      if (lp + 1 < nph) dma_phase(ph0 + lp + 1, (lp + 1) & 1);
     }
     __syncthreads();  // the consumers' final barrier
     return;
@@ -139,12 +148,12 @@ __global__ __launch_bounds__(576) void gemm16_wstream_kernel(G16Args p) {
       lane_off[j] = (uint32_t)((int64_t)(n < p.N ? n : 0) * p.b_sn + 16 * g);
   }
   const int rot = (nb0 * 3) & (PH - 1);  // per-wave rotation of the sweep inside a phase
-  const int last = nph * PH - 1;
+  const int last = ph1 * PH - 1;
   const int sw = (r16 >> 1) & 7;
   const uint32_t o0 = r16 * 128 + 16 * (g ^ sw);
   const uint32_t o1 = r16 * 128 + 16 * ((4 + g) ^ sw);
 
-  int f_pf = 0;
+  int f_pf = ph0 * PH;
   auto refill = [&](Seg32 (&fr)[NB]) __attribute__((always_inline)) {
     const int f = f_pf < last ? f_pf : last;  // tail refills re-read the last step, never consumed
     const int ks = (f & ~(PH - 1)) + ((f + rot) & (PH - 1));
@@ -190,6 +199,22 @@ __global__ __launch_bounds__(576) void gemm16_wstream_kernel(G16Args p) {
 
   drain_segs(bq);
   __syncthreads();  // the A buffers are dead: reuse their memory
+  if constexpr (SLAB) {
+    float* ep = reinterpret_cast<float*>(smem) + wave * (ROWS * 20);  // [ROWS][16] (+4 pad)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ep[(16 * mb + 4 * g + r) * 20 + r16] = acc[0][mb][r];
+    wait_lgkmcnt0();
+    float* dst = p.slabs + (int64_t)blockIdx.y * p.M * p.N;
+    for (int c = lane; c < ROWS * 4; c += 64) {
+      const int m = c >> 2, q = c & 3;
+      const int nn = nb0 * 16 + q * 4;
+      if (m < p.M && nn < p.N)
+        *reinterpret_cast<f32x4*>(dst + (int64_t)m * p.N + nn) = *reinterpret_cast<const f32x4*>(ep + m * 20 + q * 4);
+    }
+    return;
+  }
   T* ep = reinterpret_cast<T*>(smem) + wave * (ROWS * 24);  // [ROWS][16] (+8 pad), one column block at a time
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
@@ -209,6 +234,46 @@ __global__ __launch_bounds__(576) void gemm16_wstream_kernel(G16Args p) {
             *reinterpret_cast<const uint4*>(ep + m * 24 + half * 8);
     }
     wait_lgkmcnt0();  // the patch is rewritten by the next column block
+  }
+}
+
+// sum of the K slices (in slice order) + bias, one rounding: the epilogue of the split-K form
+template <int DTYPE>
+__global__ __launch_bounds__(64) void gemm16_finalize_kernel(G16Args p, int SK) {
+  using H = Half16<DTYPE>;
+  using T = typename H::T;
+  const int64_t total = (int64_t)p.M * p.N / 8;
+  const int64_t sstride = (int64_t)p.M * p.N;
+  for (int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 64) {
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int s0 = 0; s0 < SK; s0 += 4) {  // four slices in flight
+      f32x4 a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float* src = p.slabs + (int64_t)(s0 + u < SK ? s0 + u : SK - 1) * sstride + i * 8;
+        a[u] = *reinterpret_cast<const f32x4*>(src);
+        b[u] = *reinterpret_cast<const f32x4*>(src + 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (s0 + u < SK) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[j] += a[u][j];
+            v[4 + j] += b[u][j];
+          }
+        }
+    }
+    const int64_t e = i * 8;
+    const int nn = (int)(e % p.N);
+    typename H::x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float r = v[j];
+      if (p.bias) r += H::to_f32(reinterpret_cast<const T*>(p.bias)[nn + j]);
+      o[j] = H::from_f32(r);
+    }
+    *reinterpret_cast<typename H::x8*>(reinterpret_cast<T*>(p.out) + e) = o;
   }
 }
 
@@ -239,6 +304,64 @@ int launch16_ph(const G16Args& p, int nc, int groups, hipStream_t s) {
     if (pb_env == 4) return launch16_k<DTYPE, MB, PH, NT, NB, 4, false>(p, nc, groups, s);
   }
   return launch16_k<DTYPE, MB, PH, NT, NB, 2, false>(p, nc, groups, s);
+}
+
+// Split-K form (pre-shuffled weights): (phase length, consumer waves, K slices) as gemm_fp8.hip launch_wstream picks them --
+// one workgroup per CU, fewest k-steps on the busiest CU -- then the finalize kernel.  `used` = false: the shape has no
+// split-K form (K / 64 not a multiple of a phase, or the workspace is too small); nothing was launched.
+template <int DTYPE, int MB, int PH, bool NT>
+int launch16_slab_k(const G16Args& p, int nc, int groups, int SK, hipStream_t s) {
+  auto kern = gemm16_wstream_kernel<DTYPE, MB, PH, NT, 1, 2, true, true>;
+  constexpr int stage = 2 * PH * 16 * MB * 128;
+  constexpr int patch = 8 * 16 * MB * 20 * 4;
+  constexpr int lds = stage > patch ? stage : patch;
+  static int attr_rc = check_hip(
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
+      "hipFuncSetAttribute");
+  if (attr_rc) return attr_rc;
+  hipLaunchKernelGGL(kern, dim3((unsigned)groups, (unsigned)SK), dim3(64 * (nc + 1)), lds, s, p);
+  int rc = check_hip(hipGetLastError(), "gemm16_wstream (split-K) launch");
+  if (rc) return rc;
+  const int64_t total = (int64_t)p.M * p.N / 8;
+  hipLaunchKernelGGL((gemm16_finalize_kernel<DTYPE>), dim3((unsigned)((total + 63) / 64)), dim3(64), 0, s, p, SK);
+  return check_hip(hipGetLastError(), "gemm16_finalize launch");
+}
+
+template <int DTYPE, int MB>
+int launch16_splitk(G16Args p, float* slabs, int64_t slab_floats, hipStream_t s, bool& used) {
+  used = false;
+  if (!p.b_shuf || slabs == nullptr || (p.N & 7) != 0) return 0;
+  const int steps = p.KB >> 7;
+  const int nblocks = (p.N + 15) / 16;
+  int PH = 0, nc = 8, SK = 1, pps = 0, best = 1 << 30;
+  for (int ph = 8; ph >= 4; ph >>= 1) {
+    if (ph * MB > 32 || steps % ph != 0) continue;
+    const int P = steps / ph;
+    for (int c = 8; c >= 4; --c) {
+      const int groups_c = (nblocks + c - 1) / c;
+      int sk_max = 256 / groups_c;
+      if (sk_max < 1) sk_max = 1;
+      if (sk_max > P) sk_max = P;
+      const int pp = (P + sk_max - 1) / sk_max;
+      const int sk = (P + pp - 1) / pp;
+      const int rounds = (groups_c * sk + 255) / 256;
+      const int cost = rounds * c * pp * (ph + 4);
+      if (cost < best) { best = cost; PH = ph; nc = c; SK = sk; pps = pp; }
+    }
+  }
+  if (PH == 0 || SK < 2 || slab_floats < (int64_t)SK * p.M * p.N) return 0;
+  p.slabs = slabs;
+  p.pps = pps;
+  const int groups = (nblocks + nc - 1) / nc;
+  // non-temporal weight loads: ahead for up to 32 rows and for long K at 64 (Llama-3-8B, M = 1 / 64, us, nt vs plain: o 10.6 /
+  // 16.1 vs 11.6 / 14.8, qkv 12.6 / 16.9 vs 13.4 / 16.6, down 24.9 / 32.1 vs 26.2 / 33.1; profiles/r03_linear16_shapes_splitk.txt)
+  static const int nt_env = [] { const char* e = getenv("SGL_MI355_GEMM16_SLAB_NT"); return e ? atoi(e) : -1; }();  // A/B aid
+  const int nt = nt_env >= 0 ? nt_env : ((MB < 4 || steps >= 128) ? 1 : 0);
+  used = true;
+  if (PH == 8) {
+    if constexpr (MB <= 4) return nt ? launch16_slab_k<DTYPE, MB, 8, true>(p, nc, groups, SK, s) : launch16_slab_k<DTYPE, MB, 8, false>(p, nc, groups, SK, s);
+  }
+  return nt ? launch16_slab_k<DTYPE, MB, 4, true>(p, nc, groups, SK, s) : launch16_slab_k<DTYPE, MB, 4, false>(p, nc, groups, SK, s);
 }
 
 template <int DTYPE, int MB>
@@ -299,7 +422,8 @@ int launch16(const G16Args& p, hipStream_t s) {
 using namespace sglm;
 
 static int gemm16_impl(const void* x, const void* weight, const void* bias, void* out, int64_t M, int64_t N, int64_t K,
-                       int64_t x_stride_m, int64_t w_stride_n, int b_shuf, int dtype, void* stream) {
+                       int64_t x_stride_m, int64_t w_stride_n, int b_shuf, int dtype, void* stream, float* workspace = nullptr,
+                       int64_t workspace_floats = 0) {
   SGLM_CHECK_ARG(dtype == SGL_MI355_BF16 || dtype == SGL_MI355_FP16, "gemm16_nt: dtype must be bfloat16 or float16");
   SGLM_CHECK_ARG(M >= 0 && M <= 64, "gemm16_nt: the weight-streaming kernel takes M <= 64 rows (got %ld)", (long)M);
   SGLM_CHECK_ARG(N > 0 && N % 8 == 0 && K > 0 && K % 256 == 0 && N < (1ll << 31) && K < (1ll << 30),
@@ -314,8 +438,22 @@ static int gemm16_impl(const void* x, const void* weight, const void* bias, void
                      reinterpret_cast<uintptr_t>(out) % 16 == 0, "gemm16_nt: operands must be 16-byte aligned");
   static const int throttle = [] { const char* e = getenv("SGL_MI355_GEMM16_THROTTLE"); return e ? atoi(e) : 0; }();  // A/B aid
   G16Args p{(const uint8_t*)x, x_stride_m * 2, (const uint8_t*)weight, w_stride_n * 2, bias, out, (int)M, (int)N, (int)(K * 2),
-            throttle, b_shuf};
+            throttle, nullptr, 0, b_shuf};
   hipStream_t s = as_stream(stream);
+  if (workspace != nullptr) {  // split-K form where the unsplit grid would leave CUs idle (fewer than ~200 workgroups)
+    bool used = false;
+    int rc = 0;
+    const bool narrow = (N + 15) / 16 < 8 * 200;
+    if (narrow) {
+#define G16_S(D)                                                                                   \
+      rc = M <= 16   ? launch16_splitk<D, 1>(p, workspace, workspace_floats, s, used)              \
+           : M <= 32 ? launch16_splitk<D, 2>(p, workspace, workspace_floats, s, used)              \
+                     : launch16_splitk<D, 4>(p, workspace, workspace_floats, s, used)
+      if (dtype == SGL_MI355_BF16) { G16_S(SGL_MI355_BF16); } else { G16_S(SGL_MI355_FP16); }
+#undef G16_S
+      if (rc || used) return rc;
+    }
+  }
 #define G16_D(D)                                   \
   do {                                             \
     if (M <= 16) return launch16<D, 1>(p, s);      \
@@ -337,4 +475,14 @@ extern "C" int sgl_mi355_gemm16_nt(const void* x, const void* weight, const void
 extern "C" int sgl_mi355_gemm16_nt_wshuffled(const void* x, const void* weight_shuffled, const void* bias, void* out, int64_t M,
                                              int64_t N, int64_t K, int64_t x_stride_m, int dtype, void* stream) {
   return gemm16_impl(x, weight_shuffled, bias, out, M, N, K, x_stride_m, K, 1, dtype, stream);
+}
+
+// ... with an fp32 workspace for the split-K form: narrow N (fewer than ~200 workgroups of 8 column blocks) is cut along K into
+// slices of whole phases, partial sums go to `workspace` (num_slices * M * N floats, at most 16 * M * N) and a finalize kernel
+// sums them in slice order, adds the bias and rounds once.  Wide N runs the unsplit kernel as sgl_mi355_gemm16_nt_wshuffled.
+extern "C" int sgl_mi355_gemm16_nt_wshuffled_splitk(const void* x, const void* weight_shuffled, const void* bias, void* out,
+                                                    float* workspace, int64_t workspace_floats, int64_t M, int64_t N, int64_t K,
+                                                    int64_t x_stride_m, int dtype, void* stream) {
+  SGLM_CHECK_ARG(workspace != nullptr && workspace_floats > 0, "gemm16_nt_wshuffled_splitk: null workspace");
+  return gemm16_impl(x, weight_shuffled, bias, out, M, N, K, x_stride_m, K, 1, dtype, stream, workspace, workspace_floats);
 }

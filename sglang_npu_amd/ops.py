@@ -820,6 +820,12 @@ def linear16(x: torch.Tensor, weight, bias: Optional[torch.Tensor] = None) -> to
             raise RuntimeError("linear16: x [M,K] must match the shuffled weight's dtype and K")
         M = x.size(0)
         out = torch.empty((M, weight.N), dtype=x.dtype, device=x.device)
+        if weight.N < 16 * 8 * 200 and 0 < M <= 64:  # narrow N: split-K slabs + finalize (csrc/gemm_bf16.hip launch16_splitk)
+            ws = _fp8_workspace.get(x.device, 16 * M * weight.N)
+            _lib.check(_lib.lib().sgl_mi355_gemm16_nt_wshuffled_splitk(
+                _ptr(x), _ptr(weight.data), _ptr(bias), _ptr(out), _ptr(ws), _I64(ws.numel()), _I64(M), _I64(weight.N),
+                _I64(weight.K), _I64(x.stride(0) if M > 1 else weight.K), _I(_dtype_code(x)), _stream(x)))
+            return out
         _lib.check(_lib.lib().sgl_mi355_gemm16_nt_wshuffled(
             _ptr(x), _ptr(weight.data), _ptr(bias), _ptr(out), _I64(M), _I64(weight.N), _I64(weight.K),
             _I64(x.stride(0) if M > 1 else weight.K), _I(_dtype_code(x)), _stream(x)))

@@ -82,9 +82,18 @@ class QuantizationConfig:
 
 
 # ----------------------------------------------------------------------------- unquantised
+# The unquantised decode linears of a bf16 model run the 16-bit weight streamer on a fragment-major copy (round 3): unsplit
+# for wide N, split-K slabs + finalize for narrow N.  Llama-3-8B, bf16, M = 1 / 16 / 64, us, streamer vs hipBLASLt
+# (profiles/r03_linear16_shapes_splitk.txt): qkv 12.6 / 13.3 / 16.6-16.9 vs 14.3 / 14.4 / 17.9; o 10.6 / 11.6 / 14.8 vs 15.5 /
+# 15.5 / 14.9-15.0; gate_up 39.0 / 40.0 / 41.9 vs 60.2 / 62.4 / 53.2; down 24.9 / 25.6 / 32.1 vs 26.5 / 27.4 / 41.4.
+# SGL_MI355_LINEAR16_MIN_N raises the narrowest layer that gets the copy (A/B aid).
+LINEAR16_MIN_N = int(os.environ.get("SGL_MI355_LINEAR16_MIN_N", "16"))
+
+
 class UnquantizedLinearMethod(LinearMethodBase):
-    """layers/quantization/unquant.py: F.linear.  Plain library GEMM (hipBLASLt through torch) -- the
-    bf16 plumbing config only; not part of the hand-written hot path."""
+    """layers/quantization/unquant.py: F.linear.  Batches of up to 64 rows run ops.linear16 on a fragment-major copy of the
+    weight built once after loading (round 3); larger batches (prefill) go to the library GEMM (hipBLASLt through torch) --
+    a 16-bit tiled GEMM is not part of the FP8 / INT4 hot path this backend is about."""
 
     def create_weights(self, layer, input_size_per_partition, output_partition_sizes, input_size, output_size,
                        params_dtype, **extra_weight_attrs):
@@ -92,10 +101,26 @@ class UnquantizedLinearMethod(LinearMethodBase):
             data=torch.empty(sum(output_partition_sizes), input_size_per_partition, dtype=params_dtype), input_dim=1,
             output_dim=0, weight_loader=extra_weight_attrs.get("weight_loader")))
 
+    def process_weights_after_loading(self, layer) -> None:
+        layer.weight_fm = None
+        w = layer.weight.data
+        if (w.is_cuda and w.dim() == 2 and w.dtype in (torch.bfloat16, torch.float16) and w.shape[0] >= LINEAR16_MIN_N
+                and ops.linear16_shuffle_supported(w.shape[0], w.shape[1]) and not os.environ.get("SGL_MI355_NO_LINEAR16_SHUFFLE")):
+            # a second copy (the row-major weight stays for batches above 64 rows and for reloads): +2 N K bytes per layer
+            layer.weight_fm = ops.linear16_shuffle_weight(w)
+            layer._weight_fm_of = w.data_ptr()
+
     def apply(self, layer, x, bias=None):
-        # (the 16-bit weight streamer ops.linear16 serves the LM head; for the four per-layer GEMMs of the bf16 plumbing
-        #  config it has no split-K form yet -- N = 4096 would run on 32 workgroups -- and the whole step measured
-        #  10.2 ms against 8.1 ms with the library GEMM, so the layers stay on F.linear)
+        fm = getattr(layer, "weight_fm", None)
+        if fm is not None and layer.weight.data_ptr() != layer._weight_fm_of:
+            # the parameter's storage was replaced after the copy was made (`.weight.data = ...` without running
+            # process_weights_after_loading again): the copy is stale -- drop it rather than multiply with old weights.
+            # (In-place reloads, `param.data.copy_`, are followed by process_weights_after_loading in SGLang's flow.)
+            layer.weight_fm = fm = None
+        if fm is not None and x.is_cuda and x.dtype == fm.dtype:
+            x2 = x.reshape(-1, x.shape[-1])
+            if 0 < x2.shape[0] <= 64 and x2.stride(-1) == 1:
+                return ops.linear16(x2, fm, bias).reshape(x.shape[:-1] + (fm.N,))
         return torch.nn.functional.linear(x, layer.weight, bias)
 
 

@@ -315,7 +315,8 @@ def test_linear16_lm_head_vs_fp64(M, N, K, dtype):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M", [1, 16, 17, 33, 64])
-@pytest.mark.parametrize("N,K", [(128256, 4096), (32000, 4096), (1008, 512), (4096, 1024), (151936, 1024)])
+@pytest.mark.parametrize("N,K", [(128256, 4096), (32000, 4096), (1008, 512), (4096, 1024), (151936, 1024), (4096, 14336),
+                                 (6144, 4096), (4096, 4096), (1280, 8192)])
 def test_linear16_on_fragment_major_weight_is_bit_identical(M, N, K, dtype):
     """The LM head on a weight re-laid once for contiguous 1-KiB loads (ops.linear16_shuffle_weight, round 3): the same
     products in the same order -- only the addresses of the weight loads differ -- so the SAME BITS as the row-major call
@@ -331,7 +332,15 @@ def test_linear16_on_fragment_major_weight_is_bit_identical(M, N, K, dtype):
     # the byte layout is the FP8 one applied to the [N][2K] byte image (include/sgl_mi355.h)
     b = w.view(torch.uint8).view(N // 16, 16, (2 * K) // 128, 2, 4, 16).permute(0, 2, 3, 4, 1, 5).contiguous()
     assert torch.equal(wsh.data.view(-1), b.view(-1))
-    assert torch.equal(ops.linear16(x, wsh, bias), ops.linear16(x, w, bias))
+    out = ops.linear16(x, wsh, bias)
+    if N >= 16 * 8 * 200:  # wide: the unsplit kernel on both layouts
+        assert torch.equal(out, ops.linear16(x, w, bias))
+    else:              # narrow: the fragment-major weight runs the split-K form (another fp32 summation order)
+        ref = x.double() @ w.double().t()
+        if bias is not None:
+            ref = ref + bias.double()
+        ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+        torch.testing.assert_close(out.double(), ref, rtol=ulp, atol=ulp * float(ref.abs().max()) * 0.05)
     # a strided source (rows of a wider buffer) is re-laid the same
     wide = torch.zeros(N, K + 256, device=DEV, dtype=dtype)
     wide[:, :K] = w
@@ -377,3 +386,45 @@ def test_every_gemm_kernel_family_is_reachable(M, N, K, shuffled, partials, fami
     rows = torch.tensor(sorted({0, M // 2, M - 1}), device=DEV)
     ref = (a[rows].double() @ w.double().t()) * sb.double().view(1, -1) * sa[rows].double()
     torch.testing.assert_close(out[rows].double(), ref, rtol=2.0 ** -7, atol=1e-3 * float(ref.abs().max()))
+
+
+def test_unquantized_wide_linear_uses_the_streamer_at_decode_sizes():
+    """UnquantizedLinearMethod (unquant.py): a wide column-parallel bf16 layer gets a fragment-major copy after loading and
+    runs ops.linear16 for up to 64 rows (narrow layers through its split-K form); larger batches and shapes without the layout
+    stay on F.linear.  One output ulp of fp64."""
+    from sglang_npu_amd.linear import MergedColumnParallelLinear, RowParallelLinear
+    g = torch.Generator(device=DEV).manual_seed(5)
+    K, I = 512, 8192
+    wide = MergedColumnParallelLinear(K, [I, I], params_dtype=torch.bfloat16).to(DEV)
+    wide.weight.data.copy_(torch.randn(2 * I, K, device=DEV, generator=g) * 0.05)
+    wide.quant_method.process_weights_after_loading(wide)
+    assert wide.weight_fm is not None and wide.weight_fm.data.shape == (2 * I // 16, 32 * K)
+    narrow = RowParallelLinear(K, 4096, params_dtype=torch.bfloat16).to(DEV)  # narrow N: the split-K form of the streamer
+    narrow.weight.data.copy_(torch.randn(4096, K, device=DEV, generator=g) * 0.05)
+    narrow.quant_method.process_weights_after_loading(narrow)
+    assert narrow.weight_fm is not None
+    odd = RowParallelLinear(K, 1000, params_dtype=torch.bfloat16).to(DEV)     # N % 16 != 0: no fragment-major layout, F.linear
+    odd.quant_method.process_weights_after_loading(odd)
+    assert odd.weight_fm is None
+    for M in (1, 33, 64, 100):
+        x = torch.randn(M, K, device=DEV, generator=g).bfloat16()
+        y, _ = narrow(x)
+        ref = x.double() @ narrow.weight.data.double().t()
+        torch.testing.assert_close(y.double(), ref, rtol=2.0 ** -7, atol=2.0 ** -7 * float(ref.abs().max()) * 0.05)
+    for M in (1, 7, 64, 65, 200):
+        x = torch.randn(M, K, device=DEV, generator=g).bfloat16()
+        y, _ = wide(x)
+        ref = x.double() @ wide.weight.data.double().t()
+        torch.testing.assert_close(y.double(), ref, rtol=2.0 ** -7, atol=2.0 ** -7 * float(ref.abs().max()) * 0.05)
+        if M <= 64:  # the streamer's fp32 summation order, not the library's: the same bits as a direct ops.linear16 call
+            assert torch.equal(y, ops.linear16(x, wide.weight.data))
+    y3, _ = wide(torch.randn(2, 3, K, device=DEV, generator=g).bfloat16())
+    assert y3.shape == (2, 3, 2 * I)
+    # replacing the parameter's storage without re-running process_weights_after_loading leaves a stale copy: it is dropped
+    # (F.linear on the new weights), never multiplied with
+    narrow.weight.data = (torch.randn(4096, K, device=DEV, generator=g) * 0.05).bfloat16()
+    x = torch.randn(5, K, device=DEV, generator=g).bfloat16()
+    y, _ = narrow(x)
+    assert narrow.weight_fm is None
+    ref = x.double() @ narrow.weight.data.double().t()
+    torch.testing.assert_close(y.double(), ref, rtol=2.0 ** -7, atol=2.0 ** -7 * float(ref.abs().max()) * 0.05)

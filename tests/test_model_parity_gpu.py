@@ -147,6 +147,7 @@ def test_qwen2_05b_shaped_prefill_and_greedy_decode_match_cpu_oracle():
                                  layer.mlp.down_proj)):
             gg = torch.Generator(device=DEV).manual_seed(100 * i + j)
             lin.weight.data = (torch.randn(lin.weight.shape, device=DEV, generator=gg) * 0.03).to(torch.bfloat16)
+            lin.quant_method.process_weights_after_loading(lin)  # new weights: rebuild the decode-layout copy (the loader contract)
     cpu = CpuOracleModel(net, cfg, n_tok)
     ids = torch.randint(0, 10000, (input_len,), device=DEV, generator=g)  # bench_one_batch.py:214-236
     rpi = torch.tensor([0], device=DEV)
