@@ -279,6 +279,22 @@ int sgl_mi355_decode_merge_quant_fp8(const float* attn_logits, int64_t num_seqs,
                                      int64_t num_kv_splits, void* output, int64_t o_stride_b, int64_t o_stride_h,
                                      void* out_q, float* out_s, int dtype, void* stream);
 
+/* One-split paged decode (round 3) whose last workgroup per request also quantises the finished row per token: out_q e4m3
+ * [num_seqs, num_heads * head_size] contiguous, out_s fp32 [num_seqs].
+ * Replaces: decode_attention_fwd (decode_attention.py:491-596) -> sgl_per_token_quant_fp8 (per_token_quant_fp8.cu:15-87);
+ *           bit-identical to sgl_mi355_decode_attention followed by sgl_mi355_per_token_quant_fp8 on `output`.
+ *   `output` (16-bit, written as well: it carries the heads to the quantising workgroup) needs strides % 4 == 0.
+ *   merge_counters int32 [num_seqs]: zero before the first call, left zero (same contract as
+ *   sgl_mi355_decode_attention_merged; the two may share the buffer on one stream).
+ *   Pairs-of-items kernel only (num_seqs * num_kv_heads > 256, head size 64 / 128, group <= 16, 16-bit pool); otherwise
+ *   SGL_MI355_ERR_UNSUPPORTED, nothing launched. */
+int sgl_mi355_decode_attention_quant(
+    const void* query, void* k_cache, void* v_cache, void* output, void* out_q, float* out_s, int32_t* merge_counters,
+    const void* req_to_token, int req_to_token_is64, const int64_t* req_pool_indices, const int64_t* seq_lens,
+    int64_t num_seqs, int64_t max_context_len, int64_t num_heads, int64_t num_kv_heads, int64_t head_size,
+    int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h,
+    int64_t o_stride_b, int64_t o_stride_h, float sm_scale, float logit_cap, int dtype, void* stream);
+
 /* Paged decode with kv-splits whose merge -- and, if out_q / out_s are given, the per-token FP8 quant of the merged row --
  * happens inside the SAME launch (no stage-2 kernel, no quant kernel).
  * Replaces: decode_attention_fwd stage 1 + stage 2 (decode_attention.py:404-488, 491-596; decode.cpp:812-860) [+

@@ -42,6 +42,13 @@ NUM_CUS = 256
 # workgroup's serial merge outweighs the launch there.  SGL_MI355_NO_SPLIT_MERGE_FUSION=1 keeps the separate launches.
 FUSE_SPLIT_MERGE = os.environ.get("SGL_MI355_NO_SPLIT_MERGE_FUSION", "0") in ("", "0")
 FUSE_SPLIT_MERGE_MAX_WGS = 8
+# SGL_MI355_DECODE_QUANT_FUSION=1: one-split decode (more items than CUs) in which the workgroup that finishes a request's
+# last head block also does the per-token FP8 quant of its row (sgl_mi355_decode_attention_quant) instead of a quant
+# launch.  OFF by default: with one workgroup per CU every request completes in the launch's last microseconds, so the
+# hand-over (write-through stores acknowledged -> counter -> coherent read-back, ~4 us: tools/exp/grid_sync_probe.hip)
+# lands on the critical path where the 4.8 us quant launch was -- headline step 6.146 ms with the separate launch, 6.164
+# with this (attention in-step 95.5 -> 97.7 us, same box, profiles/r03_decode_quant_in_launch.txt).
+FUSE_DECODE_QUANT = bool(os.environ.get("SGL_MI355_DECODE_QUANT_FUSION"))
 
 
 @dataclass
@@ -301,10 +308,34 @@ class MI355AttnBackend(AttentionBackend):
         ignored and the caller quantises."""
         q = q.reshape(-1, layer.tp_q_head_num * layer.qk_head_dim)
         md = self.forward_metadata
+        sliding = (getattr(layer, "sliding_window_size", None) is not None and layer.sliding_window_size > -1
+                   and md.window_kv_indices is not None)
+        # one split, more (request, kv head) items than CUs, 16-bit pool: the launch quantises the rows as well
+        quant_in_launch = (fp8_out and FUSE_DECODE_QUANT and not self.flat_kv_indices and not sliding
+                           and isinstance(md.num_kv_splits, int) and md.num_kv_splits == 1
+                           and layer.qk_head_dim == layer.v_head_dim and q.shape[0] <= self._merge_counters.numel()
+                           and q.shape[0] * layer.tp_k_head_num > NUM_CUS
+                           and forward_batch.token_to_kv_pool.get_key_buffer(layer.layer_id).dtype == q.dtype)
         if self.measure_skip_decode_kernel:
             # measurement aid (bench.py): the step WITHOUT the decode attention launch (KV write included), so that the
             # kernel's in-step cost can be taken as the difference of two graph-replayed steps; the output is uninitialised
+            # (in the form the skipped launch would have returned: the quantised pair when it quantises as well)
+            if quant_in_launch:
+                return (torch.empty((q.shape[0], q.shape[1]), dtype=torch.float8_e4m3fn, device=q.device),
+                        torch.ones((q.shape[0], 1), dtype=torch.float32, device=q.device))
             return q.new_empty((q.shape[0], layer.tp_q_head_num * layer.v_head_dim))
+        if quant_in_launch:
+            kb = forward_batch.token_to_kv_pool.get_key_buffer(layer.layer_id)
+            vb = forward_batch.token_to_kv_pool.get_value_buffer(layer.layer_id)
+            if save_kv_cache:
+                forward_batch.token_to_kv_pool.set_kv_buffer(layer, forward_batch.out_cache_loc, k, v)
+                save_kv_cache = False
+            q3 = q.view(-1, layer.tp_q_head_num, layer.qk_head_dim)
+            done = ops.decode_attention_paged_quant(q3, kb, vb, torch.empty_like(q3), self.req_to_token,
+                                                    forward_batch.req_pool_indices, forward_batch.seq_lens,
+                                                    self._merge_counters, layer.scaling, layer.logit_cap)
+            if done is not False:
+                return done
         if (fp8_out and not self.flat_kv_indices and isinstance(md.num_kv_splits, int) and md.num_kv_splits > 1
                 and md.attn_logits is not None and layer.qk_head_dim == layer.v_head_dim
                 and (layer.tp_q_head_num * layer.v_head_dim) % 8 == 0

@@ -126,6 +126,35 @@ __device__ __forceinline__ void split_range(const DecodeArgs& a, int b, int spli
   if (split >= splits) s1 = s0;  // no work
 }
 
+// Per-token FP8 quant of one 16-bit row staged in LDS (`row`, R elements, R % 8 == 0; `amax` = this thread's max |x| over
+// the elements it staged): scale = absmax / 448, q = clamp(x * (1 / scale)) -- sgl_per_token_quant_fp8's arithmetic
+// (per_token_quant_fp8.cu:15-87) on that row.  All NT threads of the workgroup call it; `red`: NT / 64 floats of LDS.
+template <int DTYPE>
+__device__ __forceinline__ void quant_staged_row(const typename Half16<DTYPE>::T* row, int R, float amax,
+                                                 uint8_t* __restrict__ out_q, float* __restrict__ out_s, int b, int tid,
+                                                 int NT, float* red) {
+  using H = Half16<DTYPE>;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+  if ((tid & 63) == 0) red[tid >> 6] = amax;
+  __syncthreads();
+  amax = red[0];
+  for (int i = 1; i < NT / 64; ++i) amax = fmaxf(amax, red[i]);
+  const float scale = amax / 448.0f;
+  if (tid == 0) out_s[b] = scale;
+  const float sinv = scale == 0.f ? 0.f : 1.0f / scale;
+  for (int v = tid; v < (R >> 3); v += NT) {
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = fminf(fmaxf(H::to_f32(row[8 * v + j]) * sinv, -448.0f), 448.0f);
+    int lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+    int hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+    reinterpret_cast<uint2*>(out_q + (int64_t)b * R)[v] = uint2{(unsigned)lo, (unsigned)hi};
+  }
+}
+
 template <int DTYPE, bool COHERENT>
 __device__ void merge_quant_row(const DecodeArgs& a, int Dv, uint8_t* __restrict__ out_q, float* __restrict__ out_s, int b,
                                 int tid, int NT, char* smem, float* red);
@@ -144,6 +173,12 @@ __device__ __forceinline__ void store_coherent(float* p, float v) {
 }
 __device__ __forceinline__ float load_coherent(const float* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T>
+__device__ __forceinline__ void store_coherent16(T* p, T v) {  // a 16-bit value, written through like store_coherent
+  static_assert(sizeof(T) == 2, "16-bit storage types");
+  __hip_atomic_store(reinterpret_cast<unsigned short*>(p), __builtin_bit_cast(unsigned short, v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
 }
 template <int DTYPE>
 __device__ __forceinline__ void arrive_and_merge(const DecodeArgs& a, int Dv, int b, int tid, int NT, char* smem, char* tail) {
@@ -627,7 +662,13 @@ __global__ __launch_bounds__(kWaves * 64) void decode_mfma_kernel(DecodeArgs a) 
 // tables and both Q blocks are fetched in the one prologue, every wave walks its tiles of the first item and continues
 // straight into its tiles of the second (the two-stage ring keeps prefetching across the boundary), and both merges run
 // at the end.  16-bit pools, one split, 4 waves; items longer than the staged window fall back to one item at a time.
-template <int DTYPE, int D, typename IdxT, bool KV8 = false, bool FUSED = false>
+//
+// QOUT: the per-token FP8 quant of the finished row (the w8a8 o_proj input) in the same launch.  A request's heads are
+// spread over Hkv items in different workgroups (and XCDs), so the 16-bit outputs are stored write-through (sc1), every
+// workgroup counts its items in on merge_counters[b], and the one that completes request b's count reads the row back
+// with coherent loads and quantises it with sgl_per_token_quant_fp8's arithmetic (quant_staged_row): same bits as the
+// quant launch it replaces, ~0.1 us of work for one workgroup in 32 instead of a 4.8 us launch behind the slowest one.
+template <int DTYPE, int D, typename IdxT, bool KV8 = false, bool FUSED = false, bool QOUT = false>
 __global__ __launch_bounds__(256) void decode_mfma_pair_kernel(DecodeArgs a, int num_items, FusedQkv fq) {
   using H = Half16<DTYPE>;
   using T = typename H::T;
@@ -1146,7 +1187,10 @@ __global__ __launch_bounds__(256) void decode_mfma_pair_kernel(DecodeArgs a, int
     if (len == 0 && !newtok[i]) {  // empty sequence: zero rows
       if (tid < nh) {
         T* o = reinterpret_cast<T*>(a.out) + (int64_t)it[i].b * a.o_sb + (int64_t)(it[i].h0 + tid) * a.o_sh;
-        for (int d = 0; d < D; ++d) o[d] = H::from_f32(0.f);
+        for (int d = 0; d < D; ++d) {
+          if constexpr (QOUT) store_coherent16(o + d, H::from_f32(0.f));
+          else o[d] = H::from_f32(0.f);
+        }
       }
       continue;
     }
@@ -1178,13 +1222,73 @@ __global__ __launch_bounds__(256) void decode_mfma_pair_kernel(DecodeArgs a, int
         val += v_new[i] * f;
       }
       const T ov = H::from_f32(val / L);
-      reinterpret_cast<T*>(a.out)[(int64_t)it[i].b * a.o_sb + (int64_t)(it[i].h0 + h) * a.o_sh + dv] = ov;
+      T* op = reinterpret_cast<T*>(a.out) + (int64_t)it[i].b * a.o_sb + (int64_t)(it[i].h0 + h) * a.o_sh + dv;
+      if constexpr (QOUT) store_coherent16(op, ov);
+      else *op = ov;
       amx = fmaxf(amx, fabsf(H::to_f32(ov)));
     }
     if (a.row_absmax != nullptr) {  // non-negative floats order like their bit patterns: an integer atomic max is exact
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) amx = fmaxf(amx, __shfl_xor(amx, off));
       if (lane == 0) atomicMax(reinterpret_cast<unsigned int*>(a.row_absmax) + it[i].b, __float_as_uint(amx));
+    }
+  }
+  if constexpr (QOUT) {
+    // LDS from here on (the merge staging is dead behind the barrier): [0, 8) last-arriver flags of the two items,
+    // [16, 32) reduction scratch, [64, 64 + 2 Hq D) the row being quantised
+    int* s_last = reinterpret_cast<int*>(smem);
+    float* s_red = reinterpret_cast<float*>(smem + 16);
+    T* row = reinterpret_cast<T*>(smem + 64);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's output stores are acknowledged
+    __syncthreads();                                  // ... and so are everyone's
+    if (tid == 0) {
+      const int target = a.num_kv_heads * nhb;  // items per request
+      const bool two = it[1].len >= 0;
+      const bool same = two && it[1].b == it[0].b;
+      const int old0 = __hip_atomic_fetch_add(a.merge_counters + it[0].b, same ? 2 : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool last0 = old0 + (same ? 2 : 1) == target;
+      bool last1 = false;
+      if (two && !same)
+        last1 = __hip_atomic_fetch_add(a.merge_counters + it[1].b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == target;
+      // the next launch starts from zero again (nobody else touches a completed counter before then)
+      if (last0) __hip_atomic_store(a.merge_counters + it[0].b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (last1) __hip_atomic_store(a.merge_counters + it[1].b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last[0] = last0;
+      s_last[1] = last1;
+    }
+    __syncthreads();
+    const int R = a.num_heads * D;
+#pragma unroll 1
+    for (int i = 0; i < 2; ++i) {
+      if (!s_last[i]) continue;  // workgroup-uniform
+      const int b = it[i].b;
+      // 8-byte coherent loads (four 16-bit values), all of a thread's in flight together
+      constexpr int U = 4;
+      float amax = 0.f;
+      for (int v0 = tid; v0 < (R >> 2); v0 += U * 256) {
+        unsigned long long w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int v = v0 + u * 256 < (R >> 2) ? v0 + u * 256 : (R >> 2) - 1;
+          const int h = (4 * v) / D, d = 4 * v - h * D;
+          w[u] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(
+                                       reinterpret_cast<const T*>(a.out) + (int64_t)b * a.o_sb + (int64_t)h * a.o_sh + d),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int v = v0 + u * 256;
+          if (v < (R >> 2)) {
+            *reinterpret_cast<unsigned long long*>(row + 4 * v) = w[u];
+            const x4 xv = __builtin_bit_cast(x4, w[u]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fabsf(H::to_f32(xv[j])));
+          }
+        }
+      }
+      __syncthreads();
+      quant_staged_row<DTYPE>(row, R, amax, a.mq_out_q, a.mq_out_s, b, tid, 256, s_red);
+      __syncthreads();  // the row and the scratch are free again
     }
   }
 }
@@ -1396,26 +1500,8 @@ __device__ void merge_quant_row(const DecodeArgs& a, int Dv, uint8_t* __restrict
       finish(e, h, d, acc);
     }
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
   if (out_q == nullptr) return;  // merge only (the 16-bit row went to a.out)
-  if ((tid & 63) == 0) red[tid >> 6] = amax;
-  __syncthreads();
-  amax = red[0];
-  for (int i = 1; i < NT / 64; ++i) amax = fmaxf(amax, red[i]);
-  const float scale = amax / 448.0f;
-  if (tid == 0) out_s[b] = scale;
-  const float sinv = scale == 0.f ? 0.f : 1.0f / scale;
-  for (int v = tid; v < (R >> 3); v += NT) {
-    float f[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) f[j] = fminf(fmaxf(H::to_f32(row[8 * v + j]) * sinv, -448.0f), 448.0f);
-    int lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false);
-    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
-    int hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0, false);
-    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
-    reinterpret_cast<uint2*>(out_q + (int64_t)b * R)[v] = uint2{(unsigned)lo, (unsigned)hi};
-  }
+  quant_staged_row<DTYPE>(row, R, amax, out_q, out_s, b, tid, NT, red);
 }
 
 template <int DTYPE, int NT>
@@ -1476,6 +1562,9 @@ thread_local float* tl_row_absmax = nullptr;
 // set by sgl_mi355_decode_attention_merged around its call of the regular entry point
 struct MergeFused { int32_t* counters; uint8_t* out_q; float* out_s; };
 thread_local MergeFused tl_merge{nullptr, nullptr, nullptr};
+// set by sgl_mi355_decode_attention_quant around its call of the regular entry point (one split: pairs-of-items kernel, QOUT)
+thread_local MergeFused tl_pair_quant{nullptr, nullptr, nullptr};
+thread_local bool tl_pair_quant_used = false;
 
 template <int DTYPE, int D, typename IdxT, bool DIRECT>
 int launch_mfma(const DecodeArgs& a, int64_t batch, hipStream_t stream) {
@@ -1495,6 +1584,23 @@ int launch_mfma(const DecodeArgs& a, int64_t batch, hipStream_t stream) {
       hipLaunchKernelGGL(kern, dim3((unsigned)((grid + 1) / 2)), dim3(256), lds, stream, a, (int)grid, *tl_fq);
       tl_fq_used = true;
       return check_hip(hipGetLastError(), "decode_mfma_pair_kernel (qkv partials) launch");
+    }
+    if (pair && !a.kv8 && tl_pair_quant.counters != nullptr) {  // + the per-token FP8 quant of the finished rows
+      auto kern = decode_mfma_pair_kernel<DTYPE, D, IdxT, false, false, true>;
+      constexpr int lds = mfma_lds_bytes<D, 4, 0>();
+      static int attr_rc = set_max_lds(kern, lds);
+      if (attr_rc != 0) return attr_rc;
+      if (64 + (int64_t)a.num_heads * D * 2 > lds) {
+        set_error("decode_attention_quant: a row of %d heads does not fit the workgroup's LDS", a.num_heads);
+        return SGL_MI355_ERR_UNSUPPORTED;
+      }
+      DecodeArgs aq = a;
+      aq.merge_counters = tl_pair_quant.counters;
+      aq.mq_out_q = tl_pair_quant.out_q;
+      aq.mq_out_s = tl_pair_quant.out_s;
+      hipLaunchKernelGGL(kern, dim3((unsigned)((grid + 1) / 2)), dim3(256), lds, stream, aq, (int)grid, FusedQkv{});
+      tl_pair_quant_used = true;
+      return check_hip(hipGetLastError(), "decode_mfma_pair_kernel (fp8 out) launch");
     }
     if (pair && !a.kv8) {
       auto kern = decode_mfma_pair_kernel<DTYPE, D, IdxT>;
@@ -1769,6 +1875,51 @@ extern "C" int sgl_mi355_decode_attention_absmax(
                                             k_stride_n, k_stride_h, v_stride_n, v_stride_h, 0, 0, 0, 0, o_stride_b,
                                             o_stride_h, sm_scale, logit_cap, dtype, stream);
   tl_row_absmax = nullptr;
+  return rc;
+}
+
+// sgl_mi355_decode_attention (page-table form, no KV write, one split, 16-bit pool) that ALSO leaves the per-token FP8
+// quant of the output rows -- out_q e4m3 [num_seqs][num_heads * head_size], out_s float32 [num_seqs]: exactly what
+// sgl_per_token_quant_fp8 (per_token_quant_fp8.cu:15-87) gives on `output` -- in the same launch: the workgroup that
+// finishes a request's last head block quantises its row (decode_mfma_pair_kernel, QOUT).  merge_counters: int32
+// [num_seqs], zero before the first call, left zero; one stream and one geometry at a time, like
+// sgl_mi355_decode_attention_merged's.  `output` is written too (it is how the heads reach the quantising workgroup), with
+// rows that 8-byte loads can read (o strides % 4 == 0).  Only the pairs-of-items kernel has the epilogue (num_seqs *
+// num_kv_heads > 256, head size 64 / 128, group <= 16): any other shape returns SGL_MI355_ERR_UNSUPPORTED without launching.
+extern "C" int sgl_mi355_decode_attention_quant(
+    const void* query, void* k_cache, void* v_cache, void* output, void* out_q, float* out_s, int32_t* merge_counters,
+    const void* req_to_token, int req_to_token_is64, const int64_t* req_pool_indices, const int64_t* seq_lens,
+    int64_t num_seqs, int64_t max_context_len, int64_t num_heads, int64_t num_kv_heads, int64_t head_size,
+    int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h,
+    int64_t o_stride_b, int64_t o_stride_h, float sm_scale, float logit_cap, int dtype, void* stream) {
+  SGLM_CHECK_ARG(output != nullptr && out_q != nullptr && out_s != nullptr && merge_counters != nullptr,
+                 "decode_attention_quant: null output / out_q / out_s / merge_counters");
+  SGLM_CHECK_ARG(num_heads > 0 && num_kv_heads > 0 && num_heads % num_kv_heads == 0, "decode_attention_quant: bad head counts");
+  DecodeArgs probe{};
+  probe.num_splits = 1;
+  const bool aligned = q_stride_b % 8 == 0 && q_stride_h % 8 == 0 && k_stride_n % 8 == 0 && k_stride_h % 8 == 0 &&
+                       v_stride_n % 8 == 0 && v_stride_h % 8 == 0 && o_stride_b % 4 == 0 && o_stride_h % 4 == 0 &&
+                       reinterpret_cast<uintptr_t>(query) % 16 == 0 && reinterpret_cast<uintptr_t>(k_cache) % 16 == 0 &&
+                       reinterpret_cast<uintptr_t>(v_cache) % 16 == 0 && reinterpret_cast<uintptr_t>(output) % 8 == 0 &&
+                       reinterpret_cast<uintptr_t>(out_q) % 8 == 0;
+  if (!(pair_eligible(probe, num_seqs * num_kv_heads) && (head_size == 128 || head_size == 64) &&
+        num_heads / num_kv_heads <= 16 && aligned && num_heads * head_size <= 16384)) {
+    set_error("decode_attention_quant: shape outside the pairs-of-items kernel (needs > 256 (request, kv head) items, head "
+              "size 64 / 128, group <= 16, aligned rows, at most 16384 elements per row)");
+    return SGL_MI355_ERR_UNSUPPORTED;
+  }
+  tl_pair_quant = MergeFused{merge_counters, static_cast<uint8_t*>(out_q), out_s};
+  tl_pair_quant_used = false;
+  const int rc = sgl_mi355_decode_attention(query, k_cache, v_cache, output, nullptr, nullptr, nullptr, nullptr, req_to_token,
+                                            req_to_token_is64, req_pool_indices, seq_lens, num_seqs, max_context_len,
+                                            num_heads, num_kv_heads, head_size, head_size, 1, q_stride_b, q_stride_h,
+                                            k_stride_n, k_stride_h, v_stride_n, v_stride_h, 0, 0, 0, 0, o_stride_b,
+                                            o_stride_h, sm_scale, logit_cap, dtype, stream);
+  tl_pair_quant = MergeFused{nullptr, nullptr, nullptr};
+  if (rc == 0 && !tl_pair_quant_used) {  // (cannot happen after the checks above; never report a quant that did not run)
+    set_error("decode_attention_quant: the launch did not take the pairs-of-items kernel");
+    return SGL_MI355_ERR_RUNTIME;
+  }
   return rc;
 }
 

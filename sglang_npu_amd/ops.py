@@ -215,6 +215,40 @@ def decode_attention_paged_absmax(q, k_buffer, v_buffer, o, row_absmax, req_to_t
     return True
 
 
+def decode_attention_paged_quant(q, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens, merge_counters,
+                                 sm_scale, logit_cap=0.0):
+    """decode_attention_paged (one split, 16-bit pool) whose launch also quantises the finished rows per token: returns
+    (q_fp8 [B, Hq * D] e4m3, scale [B, 1] float32) -- what sgl_per_token_quant_fp8 gives on `o`, bit for bit -- with `o`
+    (16-bit [B, Hq, D]) written as well.  merge_counters: int32 [>= B], zero before the first call and left zero
+    (decode_attention_paged_merged's buffer will do).  Returns False -- nothing launched -- when the batch is outside
+    the pairs-of-items kernel (sgl_mi355.h); the caller then runs decode_attention_paged and sgl_per_token_quant_fp8."""
+    _need_gpu(q, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens, merge_counters)
+    if req_pool_indices.dtype != torch.int64 or seq_lens.dtype != torch.int64:
+        raise RuntimeError("decode_attention_paged_quant: req_pool_indices and seq_lens must be int64")
+    for name, t in (("q", q), ("k_buffer", k_buffer), ("v_buffer", v_buffer), ("o", o)):
+        if t.dim() != 3 or t.stride(-1) != 1:
+            raise RuntimeError(f"decode_attention_paged_quant: {name} must be 3-D, contiguous at the last dimension")
+    B, Hq, D = q.shape
+    if merge_counters.dtype != torch.int32 or merge_counters.numel() < B or not merge_counters.is_contiguous():
+        raise RuntimeError("decode_attention_paged_quant: merge_counters must be contiguous int32 [>= B]")
+    if req_to_token.dim() != 2 or req_to_token.stride(1) != 1 or req_to_token.stride(0) != req_to_token.size(1):
+        raise RuntimeError("decode_attention_paged_quant: req_to_token must be a contiguous 2-D tensor")
+    if _kv_format(k_buffer, v_buffer, q) != 0 or v_buffer.size(2) != D or tuple(o.shape) != (B, Hq, D):
+        return False
+    out_q = torch.empty((B, Hq * D), dtype=torch.float8_e4m3fn, device=q.device)
+    out_s = torch.empty((B, 1), dtype=torch.float32, device=q.device)
+    rc = _lib.lib().sgl_mi355_decode_attention_quant(
+        _ptr(q), _ptr(k_buffer), _ptr(v_buffer), _ptr(o), _ptr(out_q), _ptr(out_s), _ptr(merge_counters),
+        _ptr(req_to_token), _I(_is64(req_to_token, "req_to_token")), _ptr(req_pool_indices), _ptr(seq_lens), _I64(B),
+        _I64(req_to_token.size(1)), _I64(Hq), _I64(k_buffer.size(1)), _I64(D), _I64(q.stride(0)), _I64(q.stride(1)),
+        _I64(k_buffer.stride(0)), _I64(k_buffer.stride(1)), _I64(v_buffer.stride(0)), _I64(v_buffer.stride(1)),
+        _I64(o.stride(0)), _I64(o.stride(1)), _F(sm_scale), _F(logit_cap), _I(_dtype_code(q)), _stream(q))
+    if rc == 2:
+        return False
+    _lib.check(rc)
+    return out_q, out_s
+
+
 def decode_attention_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens, attn_logits,
                            num_kv_splits, sm_scale, logit_cap=0.0):
     """Decode straight from the request page table (no flattened kv_indices, no KV write): the form

@@ -52,6 +52,51 @@ def test_attention_row_absmax_is_exact(B, Hq, Hk, D, dtype):
     assert bool((amax == 1e9).all())
 
 
+@pytest.mark.parametrize("B,Hq,Hk,D,dtype", [(64, 32, 8, 128, torch.bfloat16), (43, 28, 7, 128, torch.float16),
+                                               (48, 24, 6, 64, torch.bfloat16), (36, 128, 8, 128, torch.bfloat16),
+                                               (260, 16, 1, 64, torch.float16), (33, 8, 8, 128, torch.bfloat16)])
+def test_attention_quant_in_launch_equals_attention_then_quant(B, Hq, Hk, D, dtype):
+    """sgl_mi355_decode_attention_quant: the last workgroup of a request quantises its row.  Odd item counts (the last
+    workgroup holds one item), pairs that straddle two requests (odd kv-head counts), one item per request (Hk = 1: both
+    items of a workgroup complete a request), empty and beyond-the-window sequences; twice on the same counters."""
+    gen = torch.Generator().manual_seed(B + 1)
+    lens = torch.randint(1, 500, (B,), generator=gen)
+    lens[0], lens[1], lens[3] = 1, 33, 0
+    if B == 36:
+        lens[5] = 9000  # beyond the staged page-table window
+    q, kb, vb, r2t, rpi, lens = _attn_inputs(B, Hq, Hk, D, dtype, lens.tolist(), seed=B + D + 1)
+    o_ref = torch.empty(B, Hq, D, dtype=dtype, device=DEV)
+    ops.decode_attention_paged(q, kb, vb, o_ref, r2t, rpi, lens, None, 1, D ** -0.5, 0.0)
+    q_ref = torch.empty(B, Hq * D, dtype=torch.float8_e4m3fn, device=DEV)
+    s_ref = torch.empty(B, 1, dtype=torch.float32, device=DEV)
+    ops.sgl_per_token_quant_fp8(o_ref.view(B, Hq * D), q_ref, s_ref)
+    counters = torch.zeros(B + 3, dtype=torch.int32, device=DEV)
+    for _ in range(2):
+        o = torch.full_like(o_ref, 7.0)
+        done = ops.decode_attention_paged_quant(q, kb, vb, o, r2t, rpi, lens, counters, D ** -0.5, 0.0)
+        assert done is not False
+        oq, os_ = done
+        torch.cuda.synchronize()
+        assert torch.equal(o, o_ref)
+        assert torch.equal(os_, s_ref)
+        assert torch.equal(oq.view(torch.uint8), q_ref.view(torch.uint8))
+        assert not counters.any()  # left zero for the next launch
+    assert float(s_ref[3]) == 0.0 and not oq[3].view(torch.uint8).any()  # the empty sequence: zero row, scale 0
+
+
+def test_attention_quant_in_launch_declines_small_batches_and_fp8_pools():
+    q, kb, vb, r2t, rpi, lens = _attn_inputs(8, 32, 8, 128, torch.bfloat16, [50] * 8, seed=1)
+    o = torch.zeros(8, 32, 128, dtype=torch.bfloat16, device=DEV)
+    counters = torch.zeros(64, dtype=torch.int32, device=DEV)
+    assert ops.decode_attention_paged_quant(q, kb, vb, o, r2t, rpi, lens, counters, 0.1) is False
+    q, kb, vb, r2t, rpi, lens = _attn_inputs(64, 32, 8, 128, torch.bfloat16, [50] * 64, seed=2)
+    o = torch.zeros(64, 32, 128, dtype=torch.bfloat16, device=DEV)
+    kb8 = kb.to(torch.float8_e4m3fn)
+    assert ops.decode_attention_paged_quant(q, kb8, kb8.clone(), o, r2t, rpi, lens, counters, 0.1) is False
+    torch.cuda.synchronize()
+    assert not o.any() and not counters.any()
+
+
 def test_attention_absmax_declines_small_batches_and_fp8_pools():
     q, kb, vb, r2t, rpi, lens = _attn_inputs(8, 32, 8, 128, torch.bfloat16, [50] * 8, seed=1)
     o = torch.zeros(8, 32, 128, dtype=torch.bfloat16, device=DEV)
@@ -166,6 +211,53 @@ def test_model_step_is_bit_identical_with_and_without_the_fusion(monkeypatch):
         logits2 = net(ids, seq - 1, fb)  # a second step on the same buffers: the absmax rows were re-zeroed
         outs.append((logits.clone(), logits2.clone(), [pool.k_buffer[l].clone() for l in range(3)]))
     assert taken == [True] * 6, f"the a16 GEMM must have run in all three layers of both steps, got {taken}"
+    assert torch.isfinite(outs[1][0].float()).all()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for l in range(3):
+        assert torch.equal(outs[0][2][l], outs[1][2][l])
+
+
+def test_model_step_is_bit_identical_with_the_quant_in_the_attention_launch(monkeypatch):
+    """LlamaAttention.forward_fp8 -> MI355AttnBackend.forward_decode(fp8_out=True) with SGL_MI355_DECODE_QUANT_FUSION:
+    same logits and pool contents as with the separate quant launch, bit for bit; the fused launch really ran."""
+    from sglang_npu_amd import attention_backend as AB
+    from sglang_npu_amd import model as M
+    from sglang_npu_amd.harness import (ForwardBatch, ForwardMode, MHATokenToKVPool, ModelConfig, ModelRunnerLike,
+                                        ReqToTokenPool, ServerArgs, install_attention_backend)
+    cfg = ModelConfig(8, 8, 128, 1024, 2048, 3, 512, 256)
+    B = 40  # 40 requests x 8 kv heads = 320 items: the pairs-of-items kernel
+    outs, taken = [], []
+    real = ops.decode_attention_paged_quant
+
+    def counted(*a, **kw):
+        r = real(*a, **kw)
+        taken.append(r is not False)
+        return r
+
+    monkeypatch.setattr(ops, "decode_attention_paged_quant", counted)
+    for fuse in (False, True):
+        monkeypatch.setattr(AB, "FUSE_DECODE_QUANT", fuse)
+        net = M.LlamaForCausalLM(cfg, "w8a8_fp8", torch.bfloat16, DEV).load_dummy_weights()
+        net.defer_epilogues = True
+        r2t = ReqToTokenPool(B, 256, DEV)
+        pool = MHATokenToKVPool(B * 256 + 1, 1, torch.bfloat16, 8, 128, 3, DEV)
+        g = torch.Generator(device=DEV).manual_seed(0)
+        for l in range(3):
+            pool.k_buffer[l].normal_(generator=g)
+            pool.v_buffer[l].normal_(generator=g)
+        r2t.req_to_token.copy_((torch.randperm(B * 256, device=DEV, generator=g) + 1).view(B, 256).to(torch.int32))
+        runner = ModelRunnerLike(cfg, r2t, pool, DEV, 0, 1, ServerArgs())
+        backend = install_attention_backend(runner)
+        seq = (torch.arange(B, device=DEV) * 6 + 1).clamp(max=255)
+        ids = torch.arange(B, device=DEV) + 1
+        rows = torch.arange(B, device=DEV)
+        fb = ForwardBatch(ForwardMode.DECODE, B, ids, rows, seq, r2t.req_to_token[rows, seq - 1].long(), int(seq.sum()),
+                          seq.cpu(), seq - 1, req_to_token_pool=r2t, token_to_kv_pool=pool, attn_backend=backend)
+        backend.init_forward_metadata(fb)
+        logits = net(ids, seq - 1, fb)
+        logits2 = net(ids, seq - 1, fb)  # a second step: the arrival counters were left zero
+        outs.append((logits.clone(), logits2.clone(), [pool.k_buffer[l].clone() for l in range(3)]))
+    assert taken == [True] * 6, f"the quantising launch must have run in all three layers of both steps, got {taken}"
     assert torch.isfinite(outs[1][0].float()).all()
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     for l in range(3):
