@@ -417,6 +417,17 @@ int sgl_mi355_fp8_shuffle_weight(const void* src, void* dst, int64_t N, int64_t 
 int sgl_mi355_fp8_scaled_mm_wshuffled(const void* mat_a, const void* mat_b, const float* scales_a, const float* scales_b,
                                       const void* bias, void* out, float* workspace, int64_t workspace_floats, int64_t M,
                                       int64_t N, int64_t K, int64_t a_stride_m, int out_dtype, void* stream);
+
+/* Gated-MLP gate_up GEMM with the activation in its epilogue (round 3): out[m][i] = silu(y[m][i]) * y[m][N/2 + i] for
+ * y = sgl_mi355_fp8_scaled_mm_wshuffled(...) [M][N]; out is 16-bit [M][N/2], contiguous.
+ * Replaces: apply_fp8_linear's fp8_scaled_mm (fp8_utils.py:696-704) -> SiluAndMul (activation.py:59-83 / activation.cu:56-60)
+ *           in LlamaMLP.forward (models/llama.py:95-107); same roundings (GEMM result to the 16-bit dtype, silu to it, product to
+ *           it): bit-identical to the two calls.
+ *   Prefill sizes only (M > 64 and >= 192 tiles of 128 x 128 outputs), pre-shuffled weight, N % 32 == 0, K % 512 == 0;
+ *   otherwise SGL_MI355_ERR_UNSUPPORTED, nothing launched. */
+int sgl_mi355_fp8_scaled_mm_silu_mul_wshuffled(const void* mat_a, const void* mat_b, const float* scales_a,
+                                               const float* scales_b, const void* bias, void* out, int64_t M, int64_t N,
+                                               int64_t K, int64_t a_stride_m, int out_dtype, void* stream);
 int sgl_mi355_fp8_scaled_mm_partials_wshuffled(const void* mat_a, const void* mat_b, float* workspace,
                                                int64_t workspace_floats, int64_t M, int64_t N, int64_t K,
                                                int64_t a_stride_m, int32_t* num_slices, void* stream);

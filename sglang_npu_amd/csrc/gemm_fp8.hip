@@ -37,7 +37,7 @@ namespace {
 constexpr float kFp8Max = 448.0f;
 
 // Which GEMM kernel family the last fp8_scaled_mm(_partials) call of this thread launched (sgl_mi355_fp8_last_kernel):
-// "skinny", "oneshot", "astat", "astat_direct", "wstream", "wstream_slab", "tiled", "tiled2", "tiled3".  A test aid: the
+// "skinny", "oneshot", "astat", "astat_direct", "wstream", "wstream_slab", "tiled", "tiled2", "tiled3", "tiled3_silu".  A test aid: the
 // dispatch table of run_gemm is long, and tests/test_fp8_gpu.py names a shape that reaches each family.
 thread_local const char* g_last_kernel = "";
 
@@ -1530,10 +1530,14 @@ __device__ __forceinline__ void tiled_epilogue(const GemmArgs& p, char* smem, f3
 #pragma unroll
         for (int j = 0; j < CB; ++j) {
           const int nl = 16 * j + r16;
-          float v = acc[RP * pass + i][j][r] * sbv[j] * sa;
-          if (p.bias) {
-            const int n = n0 + wn * 16 * CB + nl;
-            v += H::to_f32(reinterpret_cast<const T*>(p.bias)[n < p.N ? n : p.N - 1]);
+          float v;
+          {
+#pragma clang fp contract(off)  // two products and a sum, never an fma: tiled_epilogue_silu must give the same bits
+            v = acc[RP * pass + i][j][r] * sbv[j] * sa;
+            if (p.bias) {
+              const int n = n0 + wn * 16 * CB + nl;
+              v = v + H::to_f32(reinterpret_cast<const T*>(p.bias)[n < p.N ? n : p.N - 1]);
+            }
           }
           ep[ml * 72 + nl] = H::from_f32(v);
         }
@@ -1549,6 +1553,74 @@ __device__ __forceinline__ void tiled_epilogue(const GemmArgs& p, char* smem, f3
       if (c < ITEMS && m < p.M && n < p.N)
         *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.out) + (int64_t)m * p.N + n) =
             *reinterpret_cast<const uint4*>(ep + ml * 72 + nl);
+    }
+    wait_lgkmcnt0();  // the patch is rewritten by the next pass
+  }
+}
+
+// Epilogue of the gate_up GEMM with SiLU(gate) * up folded in (fp8_gemm_tiled3_kernel, SILU): a wave holds gate columns
+// n0 + 32 wn + [0, 32) in column blocks 0, 1 and the up columns I + (the same) in blocks 2, 3, i.e. gate and up of one output
+// element sit in the same lane.  Both are finished and rounded to the 16-bit dtype as tiled_epilogue would store them, then
+// out = silu(g) * u with silu_mul_kernel's two roundings (elementwise.hip; activation.cu:56-60) -- the same bits as the GEMM
+// followed by sgl_mi355_silu_and_mul.  out is [M][I], I = N / 2; 64-row passes through a wave-private [64][32] (+8 pad) patch.
+template <int OUT_DTYPE, int RI>
+__device__ __forceinline__ void tiled_epilogue_silu(const GemmArgs& p, char* smem, f32x4 (&acc)[RI][4], int m0, int n0, int wm,
+                                                    int wn, int wave, int lane) {
+  using H = Half16<OUT_DTYPE>;
+  using T = typename H::T;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int I = p.N >> 1;
+  T* ep = reinterpret_cast<T*>(smem) + wave * (64 * 72);
+  float sbg[2], sbu[2], bg[2], bu[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int n = n0 + wn * 32 + 16 * j + r16;
+    n = n < I ? n : I - 1;
+    sbg[j] = p.sb[n];
+    sbu[j] = p.sb[I + n];
+    bg[j] = p.bias ? H::to_f32(reinterpret_cast<const T*>(p.bias)[n]) : 0.f;
+    bu[j] = p.bias ? H::to_f32(reinterpret_cast<const T*>(p.bias)[I + n]) : 0.f;
+  }
+  constexpr int RP = RI < 4 ? RI : 4;
+#pragma unroll
+  for (int pass = 0; pass < RI / RP; ++pass) {
+    const int mw0 = m0 + wm * 16 * RI + 16 * RP * pass;
+#pragma unroll
+    for (int i = 0; i < RP; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ml = 16 * i + 4 * g + r;
+        const int m = mw0 + ml;
+        const float sa = p.sa[m < p.M ? m : p.M - 1];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          // (acc * w_scale) * x_scale, then + bias as an operation of its own, as in tiled_epilogue (whose addition sits in
+          // another basic block): left to itself hipcc contracts the product and the sum here into one fma, one ulp off now and then
+          float gv, uv;
+          {
+#pragma clang fp contract(off)
+            gv = acc[RP * pass + i][j][r] * sbg[j] * sa;
+            uv = acc[RP * pass + i][j + 2][r] * sbu[j] * sa;
+            if (p.bias) {
+              gv = gv + bg[j];
+              uv = uv + bu[j];
+            }
+          }
+          const float af = H::to_f32(H::from_f32(gv));
+          const float sl = H::to_f32(H::from_f32(af / (1.0f + __expf(-af))));
+          ep[ml * 40 + 16 * j + r16] = H::from_f32(sl * H::to_f32(H::from_f32(uv)));
+        }
+      }
+    wait_lgkmcnt0();  // wave-private patch: a wave-level LDS wait is enough
+    constexpr int ITEMS = 16 * RP * 4;  // 16-byte segments of this pass (four per 32-column row)
+#pragma unroll
+    for (int it = 0; it < (ITEMS + 63) / 64; ++it) {
+      const int c = lane + 64 * it;
+      const int ml = c >> 2, nl = (c & 3) * 8;
+      const int m = mw0 + ml, n = n0 + wn * 32 + nl;
+      if (c < ITEMS && m < p.M && n < I)
+        *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.out) + (int64_t)m * I + n) =
+            *reinterpret_cast<const uint4*>(ep + ml * 40 + nl);
     }
     wait_lgkmcnt0();  // the patch is rewritten by the next pass
   }
@@ -1719,13 +1791,17 @@ __global__ __launch_bounds__(64 * WM * WN) void fp8_gemm_tiled2_kernel(GemmArgs 
 // CB (round 3): 16-column blocks per wave.  4 = the 128 x 256 tile; 3 = a 128 x 192 tile for widths whose 256-column tiling
 // leaves a ragged last round (qkv 4096 -> 6144: 768 tiles of 256 on 512 slots = 1.5 rounds, 1024 tiles of 192 = exactly 2
 // rounds of three quarters the work; at M = 1024 256 tiles instead of 192: every CU has one).
-template <int OUT_DTYPE, int NSTAGE, int RI, int WM, int WN, int CB = 4>
+// SILU (round 3, the gate_up GEMM of a gated MLP, W = [gate | up], N = 2 I): the tile is 128 rows x 128 OUTPUT columns -- every
+// wave streams the weight fragments of 32 gate columns and of the 32 up columns I further on (the same 2 KiB contiguous pieces,
+// just other blocks), and the epilogue writes silu(gate) * up, [M][I], instead of the [M][2 I] product (tiled_epilogue_silu).
+template <int OUT_DTYPE, int NSTAGE, int RI, int WM, int WN, int CB = 4, bool SILU = false>
 __global__ __launch_bounds__(64 * WM * WN, 2) void fp8_gemm_tiled3_kernel(GemmArgs p) {
   static_assert(NSTAGE >= 3, "the wait count below assumes A(kt) was issued before B(kt)");
   static_assert(CB == 3 || CB == 4, "column blocks per wave");
+  static_assert(!SILU || CB == 4, "gate and up: two column blocks each");
   constexpr int NW = WM * WN;
   constexpr int TMB = 16 * RI * WM;     // block rows
-  constexpr int TNB = 16 * CB * WN;     // block columns
+  constexpr int TNB = SILU ? 8 * CB * WN : 16 * CB * WN;  // block columns (SILU: output columns = gate columns)
   constexpr int STAGE = TMB * 128;      // A tile: TMB rows x 128 B
   constexpr int UA = TMB / 8 / NW;      // 1-KiB DMA units (8 rows x 128 B) per wave and stage
   static_assert((TMB / 8) % NW == 0, "DMA units must divide over the waves");
@@ -1736,7 +1812,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void fp8_gemm_tiled3_kernel(GemmAr
   const int wm = wave / WN, wn = wave % WN;
   const int r16 = lane & 15, g = lane >> 4;
 
-  const int tiles_m = (p.M + TMB - 1) / TMB, tiles_n = (p.N + TNB - 1) / TNB;
+  const int n_cols = SILU ? p.N >> 1 : p.N;  // columns the tiles cover
+  const int tiles_m = (p.M + TMB - 1) / TMB, tiles_n = (n_cols + TNB - 1) / TNB;
   const int nwg = tiles_m * tiles_n;
   int bid = blockIdx.x;
   {
@@ -1777,8 +1854,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void fp8_gemm_tiled3_kernel(GemmAr
   const uint8_t* b_blk[CB];
 #pragma unroll
   for (int j = 0; j < CB; ++j) {
-    int nb = (n0 >> 4) + wn * CB + j;
-    nb = nb < (p.N >> 4) ? nb : (p.N >> 4) - 1;
+    int nb;
+    if constexpr (SILU) {  // blocks 0, 1: gate columns n0 + 32 wn + [0, 32); blocks 2, 3: the up columns n_cols further on
+      nb = (n0 >> 4) + wn * 2 + (j & 1);
+      nb = (nb < (n_cols >> 4) ? nb : (n_cols >> 4) - 1) + (j >> 1) * (n_cols >> 4);
+    } else {
+      nb = (n0 >> 4) + wn * CB + j;
+      nb = nb < (p.N >> 4) ? nb : (p.N >> 4) - 1;
+    }
     b_blk[j] = p.b + (int64_t)nb * 16 * p.K;
   }
   const int nk = p.K >> 7;
@@ -1921,7 +2004,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void fp8_gemm_tiled3_kernel(GemmAr
       for (int r = 0; r < 4; ++r) acc[i][j][r] = acc32[i >> 1][j >> 1][(i & 1) * 8 + (j & 1) * 4 + r];
 #endif
   __syncthreads();  // all stages dead: the epilogue reuses the memory
-  tiled_epilogue<OUT_DTYPE, RI, CB>(p, smem, acc, m0, n0, wm, wn, wave, lane);
+  if constexpr (SILU) tiled_epilogue_silu<OUT_DTYPE, RI>(p, smem, acc, m0, n0, wm, wn, wave, lane);
+  else tiled_epilogue<OUT_DTYPE, RI, CB>(p, smem, acc, m0, n0, wm, wn, wave, lane);
 }
 
 template <int OUT_DTYPE, int MB, int NB, int WK>
@@ -2217,6 +2301,54 @@ extern "C" int sgl_mi355_fp8_scaled_mm_wshuffled(
     void* stream) {
   return fp8_scaled_mm_impl(1, mat_a, mat_b, scales_a, scales_b, bias, out, workspace, workspace_floats, M, N, K, a_stride_m,
                             K, out_dtype, stream);
+}
+
+// gate_up GEMM of a gated MLP with the activation folded into its epilogue: out[m][i] = silu(y[m][i]) * y[m][I + i], y =
+// fp8_scaled_mm(mat_a, mat_b, ...) [M][N], I = N / 2 -- rounded exactly like sgl_mi355_fp8_scaled_mm_wshuffled followed by
+// sgl_mi355_silu_and_mul (fp8_utils.py:696-704, activation.py:59-83), without the [M][N] round trip through HBM.  Prefill
+// sizes on a pre-shuffled weight only: at least 192 tiles of 128 rows x 128 output columns (M = 1024 x I = 14336: 896);
+// anything else returns SGL_MI355_ERR_UNSUPPORTED WITHOUT launching and the caller makes the two calls.
+template <int OUT_DTYPE>
+static int run_gemm_silu(const GemmArgs& p, hipStream_t s) {
+  GemmArgs p3 = p;
+  static const int gn_env = [] { const char* e = getenv("SGL_MI355_T3_GN"); return e ? atoi(e) : 0; }();  // tuning aid
+  p3.raster_gn = gn_env > 0 ? gn_env : 4;
+  auto k3 = fp8_gemm_tiled3_kernel<OUT_DTYPE, 3, 8, 1, 4, 4, true>;
+  constexpr int lds_st = 3 * 128 * 128, lds_ep = 4 * 64 * 72 * 2;
+  constexpr int lds3 = lds_st > lds_ep ? lds_st : lds_ep;
+  static int a3 = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(k3), hipFuncAttributeMaxDynamicSharedMemorySize, lds3),
+                            "hipFuncSetAttribute");
+  if (a3) return a3;
+  const unsigned g3 = (unsigned)(((p.M + 127) / 128) * (((p.N >> 1) + 127) / 128));
+  g_last_kernel = "tiled3_silu";
+  hipLaunchKernelGGL(k3, dim3(g3), dim3(256), lds3, s, p3);
+  return check_hip(hipGetLastError(), "fp8_gemm_tiled3 (silu * mul) launch");
+}
+
+extern "C" int sgl_mi355_fp8_scaled_mm_silu_mul_wshuffled(
+    const void* mat_a, const void* mat_b, const float* scales_a, const float* scales_b, const void* bias, void* out, int64_t M,
+    int64_t N, int64_t K, int64_t a_stride_m, int out_dtype, void* stream) {
+  SGLM_CHECK_ARG(out_dtype == SGL_MI355_BF16 || out_dtype == SGL_MI355_FP16, "fp8_scaled_mm_silu_mul: out_dtype must be Half or BFloat16");
+  SGLM_CHECK_ARG(M >= 0 && N > 0 && K > 0 && M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "fp8_scaled_mm_silu_mul: bad shape");
+  SGLM_CHECK_ARG(N % 32 == 0 && shuffle_shape_ok(N, K),
+                 "fp8_scaled_mm_silu_mul: N %% 32 == 0 (gate and up halves of whole 16-column blocks) and K %% 512 == 0 required (N=%ld K=%ld)",
+                 (long)N, (long)K);
+  SGLM_CHECK_ARG(a_stride_m % 16 == 0 && a_stride_m >= K, "fp8_scaled_mm_silu_mul: row stride must be >= K and a multiple of 16 bytes");
+  if (M == 0) return 0;
+  SGLM_CHECK_ARG(mat_a && mat_b && scales_a && scales_b && out, "fp8_scaled_mm_silu_mul: null tensor pointer");
+  SGLM_CHECK_ARG(reinterpret_cast<uintptr_t>(mat_a) % 16 == 0 && reinterpret_cast<uintptr_t>(mat_b) % 16 == 0 &&
+                     reinterpret_cast<uintptr_t>(out) % 16 == 0,
+                 "fp8_scaled_mm_silu_mul: operands must be 16-byte aligned");
+  const int64_t tiles = ((M + 127) / 128) * ((N / 2 + 127) / 128);
+  static const int min_tiles = [] { const char* e = getenv("SGL_MI355_SILU_GEMM_MIN_TILES"); return e ? atoi(e) : 192; }();  // tuning aid
+  if (M <= 64 || tiles < min_tiles) {
+    set_error("fp8_scaled_mm_silu_mul: only prefill sizes (M > 64, at least %d tiles of 128 x 128 outputs) have the fused form", min_tiles);
+    return SGL_MI355_ERR_UNSUPPORTED;
+  }
+  GemmArgs p{(const uint8_t*)mat_a, a_stride_m, (const uint8_t*)mat_b, K, scales_a, scales_b, bias, out, (int)M, (int)N, (int)K};
+  p.b_shuf = 1;
+  hipStream_t s = as_stream(stream);
+  return out_dtype == SGL_MI355_BF16 ? run_gemm_silu<SGL_MI355_BF16>(p, s) : run_gemm_silu<SGL_MI355_FP16>(p, s);
 }
 
 // Split-K partial sums only: workspace[slice][m][n] = sum over the slice's k of a[m][k] * b[n][k] (raw fp32, no

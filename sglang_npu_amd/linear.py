@@ -85,6 +85,12 @@ class ColumnParallelLinear(LinearBase):
 class MergedColumnParallelLinear(ColumnParallelLinear):
     """gate_up_proj: two column-parallel matrices stored as one."""
 
+    def forward_prequantized_silu_mul(self, qinput, x_scale, out_dtype):
+        """SiluAndMul(forward_prequantized(...)[0]) in the GEMM's own launch where the quant method has that form
+        (w8a8 FP8 at prefill sizes), else None."""
+        fn = getattr(self.quant_method, "apply_prequantized_silu_mul", None)
+        return fn(self, qinput, x_scale, out_dtype, self.bias) if fn is not None else None
+
 
 class QKVParallelLinear(ColumnParallelLinear):
     """Q/K/V projections fused; KV heads are replicated when there are fewer of them than ranks."""

@@ -91,6 +91,11 @@ DEFER_MIN_ROWS = int(os.environ.get("SGL_MI355_DEFER_MIN_ROWS", "32"))
 GATE_UP_PARTIALS_MAX_N = int(os.environ.get("SGL_MI355_GATE_UP_PARTIALS_MAX_N", "4096"))
 
 
+# prefill: the gate_up GEMM applies SiLU * mul in its epilogue (ops.fp8_scaled_mm_silu_mul) instead of writing [T, 2 I] for a
+# separate activation kernel.  SGL_MI355_NO_SILU_GEMM_FUSION=1 keeps the two launches.
+FUSE_SILU_GEMM = os.environ.get("SGL_MI355_NO_SILU_GEMM_FUSION", "0") in ("", "0")
+
+
 class LlamaMLP(torch.nn.Module):
     def __init__(self, hidden_size, intermediate_size, quant_config, dtype):
         super().__init__()
@@ -112,8 +117,17 @@ class LlamaMLP(torch.nn.Module):
             # narrow per-rank gate_up (Llama-3-8B at TP = 8: 4096 -> 3584): the split-K kernel + the epilogue inside
             # silu.mul beats the latency-bound single-pass GEMM (one rank's step 2.61 -> 2.57 ms); at 7168 columns it loses
             part = self.gate_up_proj.forward_prequantized_partials(xq, xs, out_dtype)
+        act = None
+        if part is None and FUSE_SILU_GEMM and xq.shape[0] > 64:
+            # prefill: SiLU * mul in the gate_up GEMM's epilogue (the [T, 2 I] product never goes to HBM), then the row quant
+            act = self.gate_up_proj.forward_prequantized_silu_mul(xq, xs, out_dtype)
         if part is not None:
             aq, a_s = ops.silu_and_mul_quant_fp8_from_partials(part)
+        elif act is not None:
+            a2 = act.view(-1, act.shape[-1])
+            aq = torch.empty_like(a2, dtype=torch.float8_e4m3fn)
+            a_s = torch.empty((a2.shape[0], 1), dtype=torch.float32, device=a2.device)
+            ops.sgl_per_token_quant_fp8(a2, aq, a_s)
         else:
             gate_up, _ = self.gate_up_proj.forward_prequantized(xq, xs, out_dtype)
             aq, a_s = ops.silu_and_mul_quant_fp8(gate_up)

@@ -682,6 +682,36 @@ def fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None) -> tor
     return out
 
 
+def fp8_scaled_mm_silu_mul(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None) -> Optional[torch.Tensor]:
+    """silu_and_mul(fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias)) in ONE launch -- the gate_up GEMM of a
+    gated MLP (mat_b = [gate | up] columns) with the activation in its epilogue: [M, N/2], bit-identical to the two calls.
+    Pre-shuffled weights at prefill sizes only (sgl_mi355.h); returns None -- nothing launched -- otherwise."""
+    _need_gpu(mat_a, mat_b, scales_a, scales_b, bias)
+    if mat_a.dim() != 2 or mat_b.dim() != 2 or mat_a.stride(1) != 1 or mat_a.size(1) != mat_b.size(0):
+        raise RuntimeError("fp8_scaled_mm_silu_mul: mat_a [M, K] row major and mat_b [K, N] required")
+    if mat_a.dtype != torch.float8_e4m3fn or mat_b.dtype != torch.float8_e4m3fn:
+        raise RuntimeError("mat_a and mat_b must be Float8_e4m3fn")
+    if out_dtype not in (torch.float16, torch.bfloat16):
+        raise RuntimeError("out_dtype must be Half or BFloat16")
+    M, K = mat_a.shape
+    N = mat_b.size(1)
+    if not is_wshuffled(mat_b) or M <= 64 or N % 32 or (N > 1 and mat_b.stride(1) != K):
+        return None
+    if scales_a.numel() != M or scales_b.numel() != N or not scales_a.is_contiguous() or not scales_b.is_contiguous() \
+            or scales_a.dtype != torch.float32 or scales_b.dtype != torch.float32:
+        raise RuntimeError("fp8_scaled_mm_silu_mul: scales must be contiguous float32 [M] / [N]")
+    if bias is not None and (bias.numel() != N or not bias.is_contiguous() or bias.dtype != out_dtype):
+        raise RuntimeError("bias must be contiguous [N] in the output dtype")
+    out = torch.empty((M, N // 2), dtype=out_dtype, device=mat_a.device)
+    rc = _lib.lib().sgl_mi355_fp8_scaled_mm_silu_mul_wshuffled(
+        _ptr(mat_a), _ptr(mat_b), _ptr(scales_a), _ptr(scales_b), _ptr(bias), _ptr(out), _I64(M), _I64(N), _I64(K),
+        _I64(mat_a.stride(0)), _I(0 if out_dtype == torch.bfloat16 else 1), _stream(mat_a))
+    if rc == 2:
+        return None
+    _lib.check(rc)
+    return out
+
+
 class GemmPartials:
     """An fp8_scaled_mm whose epilogue has not run yet: raw fp32 split-K partial sums in the shared workspace
     (sgl_mi355_fp8_scaled_mm_partials).  Must be consumed -- finalize() or one of the *_from_partials ops -- before the

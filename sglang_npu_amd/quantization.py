@@ -236,6 +236,14 @@ class W8A8Fp8LinearMethod(LinearMethodBase):
         return out.view(*qinput.shape[:-1], layer.weight.shape[1])
 
 
+    def apply_prequantized_silu_mul(self, layer, qinput: torch.Tensor, x_scale: torch.Tensor, out_dtype: torch.dtype,
+                                    bias: Optional[torch.Tensor] = None):
+        """SiluAndMul(apply_prequantized(...)) in one launch for a merged gate_up layer at prefill sizes
+        (ops.fp8_scaled_mm_silu_mul), or None when the shape has no such form (the caller then makes the two calls)."""
+        q2 = qinput.view(-1, qinput.shape[-1])
+        out = ops.fp8_scaled_mm_silu_mul(q2, layer.weight, x_scale, layer.weight_scale, out_dtype, bias)
+        return None if out is None else out.view(*qinput.shape[:-1], out.shape[-1])
+
     def apply_prequantized_partials(self, layer, qinput: torch.Tensor, x_scale: torch.Tensor, out_dtype: torch.dtype,
                                     bias: Optional[torch.Tensor] = None):
         """apply_prequantized without the epilogue: ops.GemmPartials for a fused consumer, or None when the shape has

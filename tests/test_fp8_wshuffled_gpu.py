@@ -143,3 +143,73 @@ def test_linear_method_shuffles_eligible_weights_only(monkeypatch):
     assert not ops.is_wshuffled(c.weight)
     d = make(512, 640, True)   # K % 512 != 0
     assert not ops.is_wshuffled(d.weight)
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 28672, 4096), (4096, 28672, 4096), (1000, 14400, 1024), (1537, 6176, 512),
+                                   (200, 2 * 16384, 512)])
+def test_gate_up_gemm_with_silu_mul_in_the_epilogue(M, N, K):
+    """sgl_mi355_fp8_scaled_mm_silu_mul_wshuffled (fp8_gemm_tiled3_kernel, SILU): the gate_up GEMM that writes
+    silu(gate) * up.  Bit-identical to fp8_scaled_mm on the same weight followed by silu_and_mul -- the Llama-3-8B prefill
+    shapes (M = 1024 / 4096), ragged M, I % 128 != 0, bias, fp16."""
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    dt = torch.bfloat16 if M % 2 == 0 else torch.float16
+    a, w = _rand_fp8((M, K), g), _rand_fp8((N, K), g)
+    sa = torch.rand(M, 1, generator=g, device=DEV) * 1e-2 + 1e-3
+    sb = torch.rand(N, 1, generator=g, device=DEV) * 1e-2 + 1e-3
+    bias = torch.randn(N, generator=g, device=DEV).to(dt) if (N // 2) % 128 else None
+    wsh = ops.mark_wshuffled(ops.fp8_shuffle_weight(w).t())
+    y = ops.fp8_scaled_mm(a, wsh, sa, sb, dt, bias)
+    ref = torch.empty(M, N // 2, dtype=dt, device=DEV)
+    ops.silu_and_mul(y, ref)
+    out = ops.fp8_scaled_mm_silu_mul(a, wsh, sa, sb, dt, bias)
+    assert out is not None and ops.fp8_last_kernel() == "tiled3_silu"
+    assert torch.equal(out, ref)
+    assert float(ref.float().abs().max()) > 0  # (not a comparison of zeros)
+    # ... and the row quant on it is what the fused silu * mul + quant kernel gives on y (the model's two prefill paths)
+    q_ref, s_ref = ops.silu_and_mul_quant_fp8(y)
+    q = torch.empty_like(out, dtype=torch.float8_e4m3fn)
+    s = torch.empty(M, 1, dtype=torch.float32, device=DEV)
+    ops.sgl_per_token_quant_fp8(out, q, s)
+    assert torch.equal(s, s_ref) and torch.equal(q.view(torch.uint8), q_ref.view(torch.uint8))
+
+
+def test_gate_up_gemm_with_silu_mul_declines_other_shapes():
+    g = torch.Generator(device=DEV).manual_seed(3)
+    a, w = _rand_fp8((64, 512), g), _rand_fp8((4096, 512), g)
+    sa, sb = torch.ones(64, 1, device=DEV), torch.ones(4096, 1, device=DEV)
+    wsh = ops.mark_wshuffled(ops.fp8_shuffle_weight(w).t())
+    assert ops.fp8_scaled_mm_silu_mul(a, wsh, sa, sb, torch.bfloat16) is None          # decode rows
+    a = _rand_fp8((512, 512), g)
+    sa = torch.ones(512, 1, device=DEV)
+    assert ops.fp8_scaled_mm_silu_mul(a, wsh, sa, sb, torch.bfloat16) is None          # 4 x 16 = 64 tiles: too few
+    assert ops.fp8_scaled_mm_silu_mul(a, w.t(), sa, sb, torch.bfloat16) is None        # row-major weight
+
+
+def test_prefill_mlp_is_bit_identical_with_and_without_the_silu_gemm_fusion(monkeypatch):
+    """LlamaMLP.forward_fp8 at a prefill size: the fused gate_up launch + row quant against gate_up GEMM + silu * mul + quant."""
+    from sglang_npu_amd import model as M
+    from sglang_npu_amd.harness import ModelConfig
+    cfg = ModelConfig(8, 8, 128, 1024, 3072, 1, 512, 2048)
+    net = M.LlamaForCausalLM(cfg, "w8a8_fp8", torch.bfloat16, DEV).load_dummy_weights()
+    mlp = net.layers[0].mlp
+    g = torch.Generator(device=DEV).manual_seed(11)
+    x = torch.randn(1024, 1024, device=DEV, generator=g).to(torch.bfloat16)
+    xq = torch.empty_like(x, dtype=torch.float8_e4m3fn)
+    xs = torch.empty(1024, 1, dtype=torch.float32, device=DEV)
+    ops.sgl_per_token_quant_fp8(x, xq, xs)
+    taken = []
+    real = ops.fp8_scaled_mm_silu_mul
+
+    def counted(*a, **kw):
+        r = real(*a, **kw)
+        taken.append(r is not None)
+        return r
+
+    monkeypatch.setattr(ops, "fp8_scaled_mm_silu_mul", counted)
+    outs = []
+    for fuse in (False, True):
+        monkeypatch.setattr(M, "FUSE_SILU_GEMM", fuse)
+        outs.append(mlp.forward_fp8(xq, xs, torch.bfloat16).clone())
+    assert taken == [True]
+    assert torch.isfinite(outs[0].float()).all() and float(outs[0].float().abs().max()) > 0
+    assert torch.equal(outs[0], outs[1])
