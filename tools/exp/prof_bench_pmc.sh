@@ -36,3 +36,18 @@ cp gpurun_out/pmc_r3/stats/*/*kernel_stats.csv gpurun_out/r03_bench_tp1_kernel_s
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/pmc_r3/trace -- python3 bench.py --steps 16 --warmup 2 --no-cpu-baseline --no-other-configs > gpurun_out/pmc_r3_trace.log 2>&1
 python3 tools/layer_breakdown.py gpurun_out/pmc_r3/trace/*/*kernel_trace.csv > gpurun_out/r03_layer_breakdown_decode.txt 2>&1
 cat gpurun_out/r03_layer_breakdown_decode.txt
+python3 tools/layer_breakdown.py gpurun_out/pmc_r3/trace/*/*kernel_trace.csv extend_mfma > gpurun_out/r03_layer_breakdown_prefill.txt 2>&1
+cat gpurun_out/r03_layer_breakdown_prefill.txt
+# the per-launch counter rows of the decode attention kernel (small), then drop the raw traces (tens of MB)
+python3 - <<'PY'
+import csv, glob
+for counter, d in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+    f = glob.glob(f"gpurun_out/pmc_r3/{d}/*/*counter_collection.csv")[0]
+    with open(f"gpurun_out/r03_decode_pmc_instep_{counter}.csv", "w", newline="") as out:
+        w = csv.writer(out)
+        w.writerow(["Dispatch_Id", "Kernel", "Grid_Size", "Counter_Name", "Counter_Value"])
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter and "decode_mfma_pair" in r["Kernel_Name"]:
+                w.writerow([r["Dispatch_Id"], r["Kernel_Name"][:58], r["Grid_Size"], counter, r["Counter_Value"]])
+PY
+rm -rf gpurun_out/pmc_r3
