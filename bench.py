@@ -435,6 +435,12 @@ def time_decode_gemms(net, cfg, B, device, tp):
                 for lin in lins:
                     ops.fp8_scaled_mm(a, lin.weight, sa, lin.weight_scale, torch.bfloat16)
 
+            def run_silu():  # what the prefill pass launches for gate_up: SiLU * mul in the GEMM's epilogue ([M, N/2] written)
+                for lin in lins:
+                    ops.fp8_scaled_mm_silu_mul(a, lin.weight, sa, lin.weight_scale, torch.bfloat16)
+
+            fused = (name == "gate_up" and M > B
+                     and ops.fp8_scaled_mm_silu_mul(a, lins[0].weight, sa, lins[0].weight_scale, torch.bfloat16) is not None)
             s = torch.cuda.Stream(device=device)
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
@@ -462,6 +468,29 @@ def time_decode_gemms(net, cfg, B, device, tp):
                         "frac_hbm": round(nbytes / us / 1e3 / HBM_PEAK_GBPS, 4),
                         "TFLOPs": round(flops / us / 1e6, 1), "frac_mfma": round(flops / us / 1e6 / 5000.0, 4)}
             del graph
+            if fused:  # the same flops, timed the same way, in the form the model runs at this size
+                with torch.cuda.stream(s):
+                    run_silu()
+                torch.cuda.current_stream().wait_stream(s)
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=s):
+                    run_silu()
+                graph.replay()
+                torch.cuda.synchronize()
+                ts = []
+                for _ in range(5):
+                    st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    st.record()
+                    graph.replay()
+                    en.record()
+                    torch.cuda.synchronize()
+                    ts.append(st.elapsed_time(en) * 1e3 / len(lins))
+                ts.sort()
+                us = ts[len(ts) // 2]
+                row[key]["with_silu_mul_epilogue"] = {"us": round(us, 2), "TFLOPs": round(flops / us / 1e6, 1),
+                                                      "frac_mfma": round(flops / us / 1e6 / 5000.0, 4)}
+                del graph
         out["shapes"].append(row)
     dec_bytes = sum(r["decode"]["M"] * r["K"] + r["K"] * r["N"] + 2 * r["decode"]["M"] * r["N"] for r in out["shapes"])
     dec_us = sum(r["decode"]["us"] for r in out["shapes"])
