@@ -49,6 +49,33 @@ def test_invalid_arguments_raise_runtime_error():
     assert rc == 1 and "multiple" in _lib.last_error()
 
 
+def test_round3_entry_points_check_their_arguments_before_any_launch():
+    """sgl_mi355_decode_attention_quant / sgl_mi355_fp8_scaled_mm_silu_mul_wshuffled: precondition failures are
+    SGL_MI355_ERR_INVALID_ARGUMENT (1), shapes outside the fused form SGL_MI355_ERR_UNSUPPORTED (2) -- both decided on
+    the host, nothing is launched (no GPU here)."""
+    from sglang_npu_amd import _lib
+    lib = _lib.lib()
+    z, f, vp = ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+    rc = lib.sgl_mi355_decode_attention_quant(
+        None, None, None, None, None, None, None, None, 0, None, None, z(64), z(4096), z(32), z(8), z(128), z(4096), z(128),
+        z(1024), z(128), z(1024), z(128), z(4096), z(128), f(0.1), f(0.0), 0, None)
+    assert rc == 1 and "null" in _lib.last_error()
+    fake = vp(0x10000)  # aligned, never dereferenced: the shape is refused first
+    rc = lib.sgl_mi355_decode_attention_quant(
+        fake, fake, fake, fake, fake, fake, fake, fake, 0, fake, fake, z(8), z(4096), z(32), z(8), z(128), z(4096), z(128),
+        z(1024), z(128), z(1024), z(128), z(4096), z(128), f(0.1), f(0.0), 0, None)
+    assert rc == 2 and "pairs-of-items" in _lib.last_error()  # 8 requests x 8 kv heads = 64 items: not more than 256
+    rc = lib.sgl_mi355_fp8_scaled_mm_silu_mul_wshuffled(fake, fake, fake, fake, None, fake, z(1024), z(28672 + 16), z(4096), z(4096),
+                                                        0, None)
+    assert rc == 1 and "N % 32" in _lib.last_error()
+    rc = lib.sgl_mi355_fp8_scaled_mm_silu_mul_wshuffled(fake, fake, fake, fake, None, fake, z(64), z(28672), z(4096), z(4096), 0, None)
+    assert rc == 2 and "prefill sizes" in _lib.last_error()
+    rc = lib.sgl_mi355_fp8_scaled_mm_silu_mul_wshuffled(fake, fake, fake, fake, None, fake, z(256), z(4096), z(4096), z(4096), 0, None)
+    assert rc == 2  # 2 x 16 tiles
+    rc = lib.sgl_mi355_fp8_scaled_mm_silu_mul_wshuffled(fake, fake, fake, fake, None, fake, z(0), z(4096), z(4096), z(4096), 0, None)
+    assert rc == 0  # no rows: nothing to do
+
+
 def test_ops_refuse_cpu_tensors():
     import torch
     from sglang_npu_amd import ops
