@@ -685,7 +685,12 @@ int dispatch(ExtendArgs a, int64_t batch, int D, int Dv, int max_len_extend, hip
         // (Round 3: more tiles in flight -- NSTAGE 3 / 4, one workgroup per CU instead of two -- do NOT help: 38.8 / 38.9 us
         //  against 35.8 at 1024 tokens, 83 against 54 at 1536 (profiles/r03_extend_nstage.txt).  The longest block's chain is
         //  issue-bound -- ~1.4-2 us of MFMA + softmax + DMA address work per tile with two workgroups sharing the SIMDs --
-        //  not a chain of exposed DMA round trips.  SGL_MI355_EXTEND_NSTAGE=3|4 keeps the variants reachable for A/B.)
+        //  not a chain of exposed DMA round trips.  The deeper variants are compiled only with -DSGLM_EXTEND_NSTAGE_VARIANTS=1,
+        //  where SGL_MI355_EXTEND_NSTAGE=3|4 selects them for A/B; the default library carries two stages only.)
+#ifndef SGLM_EXTEND_NSTAGE_VARIANTS
+#define SGLM_EXTEND_NSTAGE_VARIANTS 0
+#endif
+#if SGLM_EXTEND_NSTAGE_VARIANTS
         static const int ns_env = [] { const char* e = getenv("SGL_MI355_EXTEND_NSTAGE"); return e ? atoi(e) : 2; }();
 #define EXT_KS(DD, GG)                                                                                              \
   do {                                                                                                              \
@@ -693,6 +698,9 @@ int dispatch(ExtendArgs a, int64_t batch, int D, int Dv, int max_len_extend, hip
     if (ns_env == 3) return launch_mfma<DTYPE, DD, int32_t, GG, false, false, 2, 3>(a, batch, max_len_extend, s);   \
     return launch_mfma<DTYPE, DD, int32_t, GG, false, false, 2, 4>(a, batch, max_len_extend, s);                    \
   } while (0)
+#else
+#define EXT_KS(DD, GG) return launch_mfma<DTYPE, DD, int32_t, GG, false, false, 2, 2>(a, batch, max_len_extend, s)
+#endif
         if (D == 128) {
           if (gh == 4) EXT_KS(128, 2);
           EXT_KS(128, 1);
