@@ -870,8 +870,13 @@ __global__ __launch_bounds__(256) void decode_mfma_pair_kernel(DecodeArgs a, int
   // One stream over up to two segments: (sel0: idx window off0, n0 tokens, nt0 tiles of this wave) then (sel1: ...).
   // At the boundary the running state moves to *_first and the Q fragments switch.
   auto stream = [&](int sel0, int off0, int n0, int sel1, int off1, int n1) __attribute__((always_inline)) {
-    const int nt0 = n0 > 0 ? (ceil_div(n0, kTile) - wave + kWaves - 1) / kWaves : 0;
-    const int nt1 = n1 > 0 ? (ceil_div(n1, kTile) - wave + kWaves - 1) / kWaves : 0;
+    // tiles are dealt round-robin over the waves, and the second segment CONTINUES the first one's deal (its tile j goes to
+    // wave (tiles0 + j) % kWaves): the waves' totals differ by at most one tile.  With both segments starting at wave 0, two
+    // items of 65 tiles (ctx 2049..2080) gave wave 0 34 tiles and the others 32; now 33 / 33 / 32 / 32.
+    const int tiles0 = n0 > 0 ? ceil_div(n0, kTile) : 0;
+    const int w1 = (wave - tiles0) & (kWaves - 1);  // this wave's place in the second segment's deal
+    const int nt0 = n0 > 0 ? (tiles0 - wave + kWaves - 1) / kWaves : 0;
+    const int nt1 = n1 > 0 ? (ceil_div(n1, kTile) - w1 + kWaves - 1) / kWaves : 0;
     const int nvt = nt0 + nt1;
     if constexpr (KV8) {
       typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -881,7 +886,7 @@ __global__ __launch_bounds__(256) void decode_mfma_pair_kernel(DecodeArgs a, int
         const int sel = second ? sel1 : sel0;
         const int off = second ? off1 : off0;
         const int n = second ? n1 : n0;
-        const int tok0 = (wave + kWaves * jt) * kTile;
+        const int tok0 = ((second ? w1 : wave) + kWaves * jt) * kTile;
         const char* gb = sel ? (is_v ? it[1].vbase : it[1].kbase) : (is_v ? it[0].vbase : it[0].kbase);
         const int64_t rb = is_v ? v_row_bytes : k_row_bytes;
         const uint32_t dst8 = __builtin_amdgcn_readfirstlane(
@@ -926,7 +931,7 @@ __global__ __launch_bounds__(256) void decode_mfma_pair_kernel(DecodeArgs a, int
         const int st = vt & (kStages8 - 1);
         const char* kst = wave_lds + st * 2 * TILE8;
         const char* vst = kst + TILE8;
-        const int tok0 = (wave + kWaves * jt) * kTile;
+        const int tok0 = ((second ? w1 : wave) + kWaves * jt) * kTile;
         const int after = (nvt - 1 - vt) < (kStages8 - 1) ? (nvt - 1 - vt) : (kStages8 - 1);
         const bool refill = vt + kStages8 < nvt;
         wait_units(1 + 2 * after);
@@ -1010,7 +1015,7 @@ __global__ __launch_bounds__(256) void decode_mfma_pair_kernel(DecodeArgs a, int
       const int sel = second ? sel1 : sel0;
       const int off = second ? off1 : off0;
       const int n = second ? n1 : n0;
-      const int tok0 = (wave + kWaves * jt) * kTile;
+      const int tok0 = ((second ? w1 : wave) + kWaves * jt) * kTile;
       const char* gb = sel ? (is_v ? it[1].vbase : it[1].kbase) : (is_v ? it[0].vbase : it[0].kbase);
       const int64_t rb = is_v ? v_row_bytes : k_row_bytes;
       const uint32_t dst = __builtin_amdgcn_readfirstlane(
@@ -1044,7 +1049,7 @@ __global__ __launch_bounds__(256) void decode_mfma_pair_kernel(DecodeArgs a, int
       const int st = vt & 1;
       const char* kst = wave_lds + st * STAGE_BYTES;
       const char* vst = kst + TILE_BYTES;
-      const int tok0 = (wave + kWaves * jt) * kTile;
+      const int tok0 = ((second ? w1 : wave) + kWaves * jt) * kTile;
       const bool more1 = vt + 1 < nvt;
       const bool more2 = vt + 2 < nvt;
 
