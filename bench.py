@@ -42,7 +42,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PROFILED_ATTN_US = 94.78  # profiles/r03_bench_tp1_kernel_stats.csv: decode_mfma_pair_kernel, 2 496 launches of the profiled bench
+PROFILED_ATTN_US = 92.83  # profiles/r03_bench_tp1_kernel_stats.csv: decode_mfma_pair_kernel, 2 496 launches of the profiled bench
 PMC_SUMMARY = "r03_decode_pmc_instep.json"  # in-step counters of the profiled bench command, refreshed per round
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 
