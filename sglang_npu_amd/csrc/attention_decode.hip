@@ -96,6 +96,7 @@ struct DecodeArgs {
   int32_t* merge_counters;
   uint8_t* mq_out_q;  // optional e4m3 [B][Hq * Dv] ...
   float* mq_out_s;    // ... with its scale [B]
+  int pair_deal;      // pairs-of-items kernel: 1 = the second item continues the first one's deal of tiles (SGL_MI355_DECODE_PAIR_DEAL=0: both from wave 0, A/B aid)
 };
 
 // The qkv GEMM of the SAME decode step, still split-K partial sums (sgl_mi355_decode_attention_qkv_partials): the pair
@@ -874,7 +875,7 @@ __global__ __launch_bounds__(256) void decode_mfma_pair_kernel(DecodeArgs a, int
     // wave (tiles0 + j) % kWaves): the waves' totals differ by at most one tile.  With both segments starting at wave 0, two
     // items of 65 tiles (ctx 2049..2080) gave wave 0 34 tiles and the others 32; now 33 / 33 / 32 / 32.
     const int tiles0 = n0 > 0 ? ceil_div(n0, kTile) : 0;
-    const int w1 = (wave - tiles0) & (kWaves - 1);  // this wave's place in the second segment's deal
+    const int w1 = a.pair_deal ? (wave - tiles0) & (kWaves - 1) : wave;  // this wave's place in the second segment's deal
     const int nt0 = n0 > 0 ? (tiles0 - wave + kWaves - 1) / kWaves : 0;
     const int nt1 = n1 > 0 ? (ceil_div(n1, kTile) - w1 + kWaves - 1) / kWaves : 0;
     const int nvt = nt0 + nt1;
@@ -1559,6 +1560,11 @@ inline bool pair_eligible(const DecodeArgs& a, int64_t grid) {
   return a.num_splits == 1 && a.num_kv_splits == nullptr && (pair_env >= 0 ? pair_env != 0 : grid > 256);
 }
 
+inline int pair_deal_default() {  // DecodeArgs::pair_deal
+  static const int v = [] { const char* e = getenv("SGL_MI355_DECODE_PAIR_DEAL"); return e ? atoi(e) : 1; }();
+  return v;
+}
+
 // set by sgl_mi355_decode_attention_qkv_partials around its call of the regular entry point
 thread_local const FusedQkv* tl_fq = nullptr;
 thread_local bool tl_fq_used = false;
@@ -1747,6 +1753,7 @@ extern "C" int sgl_mi355_decode_attention(
   a.sm_scale = sm_scale; a.logit_cap = logit_cap; a.kv8 = tl_kv8;
   a.row_absmax = tl_row_absmax;
   a.merge_counters = tl_merge.counters; a.mq_out_q = tl_merge.out_q; a.mq_out_s = tl_merge.out_s;
+  a.pair_deal = pair_deal_default();
   hipStream_t s = as_stream(stream);
   return dtype == SGL_MI355_BF16
              ? run_decode<SGL_MI355_BF16>(a, num_seqs, (int)head_size, (int)head_size_v, req_to_token_is64 != 0, s)
@@ -1771,6 +1778,7 @@ extern "C" int sgl_mi355_decode_attention_fwd(
   a.k = k_buffer; a.k_sn = k_stride_n; a.k_sh = k_stride_h;
   a.v = v_buffer; a.v_sn = v_stride_n; a.v_sh = v_stride_h;
   a.out = o; a.o_sb = o_stride_b; a.o_sh = o_stride_h;
+  a.pair_deal = pair_deal_default();
   // attn_logits [B][Hq][max_kv_splits][Dv], attn_lse [B][Hq][max_kv_splits] (triton_backend.py:207-216)
   a.mid_o = attn_logits; a.mo_ss = head_size_v; a.mo_sh = max_kv_splits * head_size_v; a.mo_sb = num_heads * a.mo_sh;
   a.mid_lse = attn_lse; a.ml_ss = 1; a.ml_sh = max_kv_splits; a.ml_sb = num_heads * max_kv_splits;
