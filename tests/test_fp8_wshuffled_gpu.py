@@ -213,3 +213,38 @@ def test_prefill_mlp_is_bit_identical_with_and_without_the_silu_gemm_fusion(monk
     assert taken == [True]
     assert torch.isfinite(outs[0].float()).all() and float(outs[0].float().abs().max()) > 0
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("M,N,K,dt", [(256, 2 * 12288, 512, torch.bfloat16), (1024, 2 * 3072, 512, torch.float16)])
+def test_gate_up_gemm_with_silu_mul_against_the_oracle_chain(M, N, K, dt):
+    """The fused launch against the CPU oracle's own chain: orc_fp8_scaled_mm (fp8_gemm_kernel.cu:1071-1146 restated) then
+    orc_silu_and_mul (activation.cu:56-60) -- not only against this library's two launches."""
+    import oracle
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    a, w = _rand_fp8((M, K), g), _rand_fp8((N, K), g)
+    sa = torch.rand(M, 1, generator=g, device=DEV) * 1e-3 + 1e-4  # full-range e4m3 operands: y of order 1, nothing overflows fp16
+    sb = torch.rand(N, 1, generator=g, device=DEV) * 1e-3 + 1e-4
+    bias = (torch.randn(N, generator=g, device=DEV) * 0.1).to(dt)
+    out = ops.fp8_scaled_mm_silu_mul(a, ops.mark_wshuffled(ops.fp8_shuffle_weight(w).t()), sa, sb, dt, bias)
+    assert out is not None and ops.fp8_last_kernel() == "tiled3_silu"
+    y = oracle.fp8_scaled_mm(a.cpu(), w.cpu().t(), sa.cpu(), sb.cpu(), dt, bias.cpu())
+    ref = oracle.silu_and_mul(y).float()
+    assert bool(torch.isfinite(ref).all()) and float(ref.abs().max()) > 0.1
+    ulp = 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10
+    # The GEMM itself is held to (one output ulp) + 1e-3 max|y| against the oracle (test_fp8_scaled_mm_vs_oracle: fp32 sums of
+    # exact products in another order; the absolute part matters where a row's products cancel).  Carried through
+    # out = silu(g) u with |silu'| <= 1.1 and |silu(g)| <= |g|, plus the roundings of silu(g) and of the product:
+    yf = y.float()
+    gate, up = yf[:, : N // 2].abs(), yf[:, N // 2:].abs()
+    ymax = float(yf.abs().max())
+    dg, du = ulp * gate + 1e-3 * ymax, ulp * up + 1e-3 * ymax
+    tol = 1.1 * up * dg + gate * du + 3.0 * ulp * gate * up + 1e-6
+    err = (out.float().cpu() - ref).abs()
+    assert bool((err <= tol).all()), f"max excess {float((err - tol).max())}"
+    # ... and on the GEMM result this library itself produces, the fused launch is the oracle's silu_and_mul bit for bit but
+    # for the exp (expf there, the hardware exp2 path here: an ulp of silu(g) in a few elements per million)
+    y_gpu = ops.fp8_scaled_mm(a, ops.mark_wshuffled(ops.fp8_shuffle_weight(w).t()), sa, sb, dt, bias)
+    ref2 = oracle.silu_and_mul(y_gpu.cpu()).float()
+    diff = out.float().cpu() != ref2
+    assert float(diff.float().mean()) < 1e-3
+    assert bool(((out.float().cpu() - ref2).abs() <= 2.0 * ulp * ref2.abs() + 1e-6).all())
