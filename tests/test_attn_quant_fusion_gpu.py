@@ -188,6 +188,7 @@ def test_model_step_is_bit_identical_with_and_without_the_fusion(monkeypatch):
         return r
 
     monkeypatch.setattr(ops, "fp8_scaled_mm_partials_a16", counted)
+    monkeypatch.setattr(M, "FUSE_QKV_ATTN", False)  # (SGL_MI355_QKV_ATTN_FUSION=1 would take the attention first)
     for fuse in (False, True):
         monkeypatch.setattr(M, "FUSE_ATTN_QUANT", fuse)
         net = M.LlamaForCausalLM(cfg, "w8a8_fp8", torch.bfloat16, DEV).load_dummy_weights()
@@ -235,6 +236,8 @@ def test_model_step_is_bit_identical_with_the_quant_in_the_attention_launch(monk
         return r
 
     monkeypatch.setattr(ops, "decode_attention_paged_quant", counted)
+    monkeypatch.setattr(M, "FUSE_QKV_ATTN", False)  # (SGL_MI355_QKV_ATTN_FUSION=1 would take the attention first)
+    monkeypatch.setattr(M, "FUSE_ATTN_QUANT", False)
     for fuse in (False, True):
         monkeypatch.setattr(AB, "FUSE_DECODE_QUANT", fuse)
         net = M.LlamaForCausalLM(cfg, "w8a8_fp8", torch.bfloat16, DEV).load_dummy_weights()

@@ -210,7 +210,7 @@ def test_prefill_mlp_is_bit_identical_with_and_without_the_silu_gemm_fusion(monk
     for fuse in (False, True):
         monkeypatch.setattr(M, "FUSE_SILU_GEMM", fuse)
         outs.append(mlp.forward_fp8(xq, xs, torch.bfloat16).clone())
-    assert taken == [True]
+    assert taken == [ops.is_wshuffled(mlp.gate_up_proj.weight)]  # (row-major weights under SGL_MI355_NO_WSHUFFLE: two launches)
     assert torch.isfinite(outs[0].float()).all() and float(outs[0].float().abs().max()) > 0
     assert torch.equal(outs[0], outs[1])
 
