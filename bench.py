@@ -81,6 +81,13 @@ def build(args, device, tp):
            "qwen2-0.5b": M.QWEN2_05B}[args.model]
     dtype = torch.float16 if args.quant == "awq" else torch.bfloat16
     quant = None if args.quant == "none" else args.quant
+    if args.ctx + args.steps + args.warmup + 8 > cfg.context_len:
+        # positions index the rotary table (context_len rows): a run past the model's context would read beyond it -- the
+        # rotary ops, like upstream's, do not check positions on the device.  Off-default sweeps (--ctx 8192) get a longer table.
+        import dataclasses
+        cfg = dataclasses.replace(cfg, context_len=args.ctx + args.steps + args.warmup + 8)
+        print(f"[bench] --ctx {args.ctx} + steps exceeds the model's context length: rotary table extended to "
+              f"{cfg.context_len} positions", file=sys.stderr)
     net = M.LlamaForCausalLM(cfg, quant, dtype, str(device), num_layers=args.layers).load_dummy_weights()
     n_layers = len(net.layers)
     B, ctx = args.batch, args.ctx

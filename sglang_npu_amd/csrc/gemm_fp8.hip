@@ -1144,7 +1144,7 @@ int launch_wstream(const GemmArgs& p, float* slabs, int64_t slab_floats, hipStre
   // K / 128 not a multiple of 8 (e.g. 3584 = 28 steps): phases of 4 steps, four weight steps in flight
   // (phases of 2 steps for the split-K form -- 192 workgroups instead of 48 on the TP = 8 qkv shape 4096 x 768 -- were
   //  tried: one rank's TP = 4 / 8 step 3.07 -> 3.04 / 2.42 -> 2.45 ms, i.e. nothing; those shapes are launch-bound)
-  const int ph_min = (steps % 8 == 0) ? 8 : 4;
+  const int ph_min = (steps % 8 == 0 && MB <= 4) ? 8 : 4;  // (MB = 8: 128 rows x 4 steps is the 64-KiB buffer)
   for (int ph = 32 / MB; ph >= ph_min; ph >>= 1) {
     if (ph > ph_cap && ph > 8) continue;
     if (steps % ph != 0) continue;
@@ -1201,7 +1201,9 @@ int launch_wstream(const GemmArgs& p, float* slabs, int64_t slab_floats, hipStre
   if constexpr (MB == 1) { if (PH == 32) WS_GO(32); }
   if constexpr (MB <= 2) { if (PH == 16) WS_GO(16); }
   if (PH == 4) WS_GO(4);
-  WS_GO(8);
+  if constexpr (MB <= 4) WS_GO(8);
+  used = false;  // (MB = 8 has phases of four k-steps only)
+  return 0;
 #undef WS_GO
 }
 
@@ -2108,6 +2110,28 @@ int run_gemm(const GemmArgs& p, float* workspace, int64_t workspace_floats, hipS
     if (p.M <= 16) return dispatch_skinny<OUT_DTYPE, 1>(p, s);
     if (p.M <= 32) return dispatch_skinny<OUT_DTYPE, 2>(p, s);
     return dispatch_skinny<OUT_DTYPE, 4>(p, s);
+  }
+  if (p.M <= 128) {
+    // 65..128 rows (a decode batch of up to 128): still weight-bound, and the tiled kernels below would put these shapes on
+    // N / 128 CUs (down_proj 4096 x 14336 at M = 128: 32 tiles, 64.8 us).  The weight streamer with 128-row A phases (MB = 8,
+    // phases of four k-steps) keeps every CU streaming: direct form for wide N, split-K slabs + finalize otherwise.
+    static const bool no_wstream128 = getenv("SGL_MI355_NO_WSTREAM") != nullptr || getenv("SGL_MI355_NO_WSTREAM_M128") != nullptr;  // A/B aid
+    static const int direct_min_n128 = [] { const char* e = getenv("SGL_MI355_WSTREAM_MIN_N"); return e ? atoi(e) : 16 * 8 * 100; }();
+    if (!no_wstream128 && (p.K & 511) == 0) {
+      bool used = false;
+      if (p.N >= direct_min_n128) {
+        int rc = launch_wstream<OUT_DTYPE, 8>(p, nullptr, 0, s, used);
+        if (rc || used) return rc;
+      }
+      // split-K form from 8 Mi weights.  Eager launch loops, M = 128, us, tiled -> streamer: down_proj (4096 x 14336) 64.8 -> 25.8,
+      // gate_up direct 31.5 -> 30.1, but o_proj (4096 x 4096) 21.3 -> 30.9 and qkv 22.0 -> 23.3; in the graph-replayed model step
+      // (where the finalize launch costs a boundary, not a launch gap) taking all of them is still ahead: Llama-3-8B bs = 128
+      // 11.18 ms tiled -> 10.03 with down / gate_up only -> 9.86 with all four; bs = 96 8.86 -> 8.63 (same box)
+      if (workspace != nullptr && (int64_t)p.N * p.K >= ((int64_t)8 << 20)) {
+        int rc = launch_wstream<OUT_DTYPE, 8>(p, workspace, workspace_floats, s, used);
+        if (rc || used) return rc;
+      }
+    }
   }
   if (p.b_shuf && (p.K & 127) != 0) {
     set_error("fp8_scaled_mm (pre-shuffled weight): K must be a multiple of 128");

@@ -363,6 +363,12 @@ class LlamaForCausalLM(torch.nn.Module):
 
     # ------------------------------------------------------------------ forward
     def forward(self, input_ids, positions, forward_batch: ForwardBatch):
+        # positions index the rotary table on the device, unchecked (as in rotary_embedding.py:79-260): refuse on the host what
+        # would read past it whenever the batch carries host-side lengths
+        lens_cpu = getattr(forward_batch, "seq_lens_cpu", None)
+        if lens_cpu is not None and lens_cpu.numel() and int(lens_cpu.max()) > self.cfg.context_len:
+            raise RuntimeError(f"sequence of {int(lens_cpu.max())} tokens exceeds the model's context length "
+                               f"({self.cfg.context_len}): positions would index past the rotary table")
         hidden_states = self.embed(input_ids)
         residual = None
         fused = self.fuse_quant and (forward_batch.forward_mode.is_decode() or forward_batch.forward_mode.is_extend())

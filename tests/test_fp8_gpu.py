@@ -357,6 +357,9 @@ def test_linear16_shuffle_rejects_other_shapes():
 @pytest.mark.parametrize("M,N,K,shuffled,partials,family", [
     (64, 28672, 4096, True, False, "wstream"),        # gate_up at decode: one column block per wave over all of K
     (64, 4096, 14336, True, True, "wstream_slab"),    # down_proj at decode: split-K slabs
+    (128, 4096, 14336, True, False, "wstream_slab"),  # ... and for a batch of 65..128 rows: 128-row A phases (MB = 8) + finalize
+    (100, 28672, 4096, True, False, "wstream"),       # gate_up at 65..128 rows
+    (128, 4096, 14336, False, False, "wstream_slab"), # (row-major weight as well)
     (64, 4096, 1024, False, False, "oneshot"),        # K <= 1024 at any width: every load issued up front
     (16, 28672, 4096 + 64, False, False, "astat_direct"),  # wide N with a K tail, row-major weight
     (16, 1024, 65536 + 64, False, False, "astat"),    # narrow N, very long K with a tail
