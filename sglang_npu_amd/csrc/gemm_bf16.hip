@@ -1,4 +1,5 @@
-// 16-bit weight-streaming GEMM for decode-sized batches: out[M, N] = x[M, K] @ W[N, K]^T (+ bias), M <= 64.
+// 16-bit weight-streaming GEMM for decode-sized batches: out[M, N] = x[M, K] @ W[N, K]^T (+ bias), M <= 128
+// (up to 64 rows: MB <= 4 row blocks; 65..128: MB = 8 with phases of at most four k-steps, round 3).
 //
 // Replaces: the LM-head matmul of LogitsProcessor._get_logits -- `torch.matmul(hidden_states, lm_head.weight.T)`
 //   (python/sglang/srt/layers/logits_processor.py:430-505) -- which at Llama-3-8B is a 4096 x 128256 bf16 matrix:
@@ -123,8 +124,8 @@ __global__ __launch_bounds__(576) void gemm16_wstream_kernel(G16Args p) {
         // pace the image: a whole phase (64 KiB) issued at once crowds the consumers' weight loads out of the CU's
         // memory pipe for microseconds; it is not needed before the NEXT phase barrier
         if (p.throttle == 1) wait_vmcnt<UPS>();
-        else if (p.throttle == 2) wait_vmcnt<2 * UPS>();
-        else if (p.throttle == 4) wait_vmcnt<4 * UPS>();
+        else if (p.throttle == 2) wait_vmcnt<(2 * UPS <= 63 ? 2 * UPS : 63)>();
+        else if (p.throttle == 4) wait_vmcnt<(4 * UPS <= 63 ? 4 * UPS : 63)>();
       }
     };
     dma_phase(ph0, 0);
@@ -412,7 +413,9 @@ int launch16(const G16Args& p, hipStream_t s) {
   if constexpr (MB <= 2) { if (PH == 16) G16_GO(16); }
   if (PH == 4) G16_GO(4);
   if (PH == 2) G16_GO(2);
-  G16_GO(8);
+  if constexpr (MB <= 4) G16_GO(8);
+  set_error("gemm16: no phase length for K = %d elements at %d rows", p.KB / 2, p.M);
+  return SGL_MI355_ERR_INVALID_ARGUMENT;
 #undef G16_GO
 }
 
@@ -425,7 +428,7 @@ static int gemm16_impl(const void* x, const void* weight, const void* bias, void
                        int64_t x_stride_m, int64_t w_stride_n, int b_shuf, int dtype, void* stream, float* workspace = nullptr,
                        int64_t workspace_floats = 0) {
   SGLM_CHECK_ARG(dtype == SGL_MI355_BF16 || dtype == SGL_MI355_FP16, "gemm16_nt: dtype must be bfloat16 or float16");
-  SGLM_CHECK_ARG(M >= 0 && M <= 64, "gemm16_nt: the weight-streaming kernel takes M <= 64 rows (got %ld)", (long)M);
+  SGLM_CHECK_ARG(M >= 0 && M <= 128, "gemm16_nt: the weight-streaming kernel takes M <= 128 rows (got %ld)", (long)M);
   SGLM_CHECK_ARG(N > 0 && N % 8 == 0 && K > 0 && K % 256 == 0 && N < (1ll << 31) && K < (1ll << 30),
                  "gemm16_nt: N %% 8 == 0 and K %% 256 == 0 required (N=%ld K=%ld)", (long)N, (long)K);
   SGLM_CHECK_ARG(!b_shuf || N % 16 == 0, "gemm16_nt (pre-shuffled weight): N %% 16 == 0 required (N=%ld)", (long)N);
@@ -448,7 +451,8 @@ static int gemm16_impl(const void* x, const void* weight, const void* bias, void
 #define G16_S(D)                                                                                   \
       rc = M <= 16   ? launch16_splitk<D, 1>(p, workspace, workspace_floats, s, used)              \
            : M <= 32 ? launch16_splitk<D, 2>(p, workspace, workspace_floats, s, used)              \
-                     : launch16_splitk<D, 4>(p, workspace, workspace_floats, s, used)
+           : M <= 64 ? launch16_splitk<D, 4>(p, workspace, workspace_floats, s, used)              \
+                     : launch16_splitk<D, 8>(p, workspace, workspace_floats, s, used)
       if (dtype == SGL_MI355_BF16) { G16_S(SGL_MI355_BF16); } else { G16_S(SGL_MI355_FP16); }
 #undef G16_S
       if (rc || used) return rc;
@@ -458,7 +462,8 @@ static int gemm16_impl(const void* x, const void* weight, const void* bias, void
   do {                                             \
     if (M <= 16) return launch16<D, 1>(p, s);      \
     if (M <= 32) return launch16<D, 2>(p, s);      \
-    return launch16<D, 4>(p, s);                   \
+    if (M <= 64) return launch16<D, 4>(p, s);      \
+    return launch16<D, 8>(p, s);                   \
   } while (0)
   if (dtype == SGL_MI355_BF16) G16_D(SGL_MI355_BF16);
   G16_D(SGL_MI355_FP16);

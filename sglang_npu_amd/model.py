@@ -67,10 +67,11 @@ FUSE_QKV_ATTN = bool(os.environ.get("SGL_MI355_QKV_ATTN_FUSION"))
 
 # LM head (logits_processor.py:430-505): rows up to which the 16-bit weight streamer runs instead of the library GEMM.
 # Round 3: on the fragment-major copy of an UNTIED head (ops.linear16_shuffle_weight, built once after loading; the
-# row-major tensor stays for batches above 64 rows) the streamer is ahead of the library at every M <= 64
-# (profiles/r03_lm_head_points.jsonl); on a row-major weight it loses above 32 rows (213 vs 201 us at M = 64).
+# row-major tensor stays for batches above 128 rows) the streamer is ahead of the library at every M <= 128
+# (profiles/r03_lm_head_points.jsonl; M = 128 on its 128-row form: 223 vs 234 us); on a row-major weight it loses above 32
+# rows (213 vs 201 us at M = 64).
 LM_HEAD_STREAMER_MAX_ROWS = 32
-LM_HEAD_SHUFFLED_MAX_ROWS = int(os.environ.get("SGL_MI355_LM_HEAD_SHUFFLED_MAX_ROWS", "64"))
+LM_HEAD_SHUFFLED_MAX_ROWS = int(os.environ.get("SGL_MI355_LM_HEAD_SHUFFLED_MAX_ROWS", "128"))  # (M = 128: 223 us vs 234 library)
 SHUFFLE_LM_HEAD = not os.environ.get("SGL_MI355_NO_LM_HEAD_SHUFFLE")
 
 # SGL_MI355_ATTN_QUANT_FUSION=1: the per-token FP8 quant between the decode attention and o_proj folded into the two
@@ -426,7 +427,7 @@ class LlamaForCausalLM(torch.nn.Module):
         # LM head (logits_processor.py:430-505): the 16-bit weight streamer up to 32 rows (176 / 183 us at M = 1 / 16 on the
         # 128256 x 4096 head, library 181-184), the library GEMM above (M = 64: 200.6 us vs 212.6)
         rows = hidden_states.shape[0]
-        if getattr(self, "lm_head_shuffled", None) is not None and rows <= min(64, LM_HEAD_SHUFFLED_MAX_ROWS):
+        if getattr(self, "lm_head_shuffled", None) is not None and rows <= min(128, LM_HEAD_SHUFFLED_MAX_ROWS):
             logits = ops.linear16(hidden_states if hidden_states.is_contiguous() else hidden_states.contiguous(),
                                   self.lm_head_shuffled)
         elif rows <= LM_HEAD_STREAMER_MAX_ROWS and \

@@ -876,7 +876,7 @@ def decode_attention_qkv_partials(part: GemmPartials, positions, cos_sin_cache, 
 
 def linear16(x: torch.Tensor, weight, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """F.linear(x, weight, bias) = x @ weight.T for decode-sized batches of 16-bit operands: the LM head of
-    LogitsProcessor._get_logits (logits_processor.py:430-505) and unquantised decode linears.  x [M <= 64, K],
+    LogitsProcessor._get_logits (logits_processor.py:430-505) and unquantised decode linears.  x [M <= 128, K],
     weight [N, K] (K contiguous), both bf16 or both fp16."""
     if isinstance(weight, ShuffledWeight16):
         _need_gpu(x, weight.data, bias)
@@ -884,7 +884,7 @@ def linear16(x: torch.Tensor, weight, bias: Optional[torch.Tensor] = None) -> to
             raise RuntimeError("linear16: x [M,K] must match the shuffled weight's dtype and K")
         M = x.size(0)
         out = torch.empty((M, weight.N), dtype=x.dtype, device=x.device)
-        if weight.N < 16 * 8 * 200 and 0 < M <= 64:  # narrow N: split-K slabs + finalize (csrc/gemm_bf16.hip launch16_splitk)
+        if weight.N < 16 * 8 * 200 and 0 < M <= 128:  # narrow N: split-K slabs + finalize (csrc/gemm_bf16.hip launch16_splitk)
             ws = _fp8_workspace.get(x.device, 16 * M * weight.N)
             _lib.check(_lib.lib().sgl_mi355_gemm16_nt_wshuffled_splitk(
                 _ptr(x), _ptr(weight.data), _ptr(bias), _ptr(out), _ptr(ws), _I64(ws.numel()), _I64(M), _I64(weight.N),
@@ -909,7 +909,7 @@ def linear16(x: torch.Tensor, weight, bias: Optional[torch.Tensor] = None) -> to
 
 
 def linear16_supported(M: int, N: int, K: int) -> bool:
-    return 0 < M <= 64 and N % 8 == 0 and K % 256 == 0 and N * K * 2 < (1 << 32)
+    return 0 < M <= 128 and N % 8 == 0 and K % 256 == 0 and N * K * 2 < (1 << 32)
 
 
 class ShuffledWeight16:

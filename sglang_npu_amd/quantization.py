@@ -88,10 +88,12 @@ class QuantizationConfig:
 # 15.5 / 14.9-15.0; gate_up 39.0 / 40.0 / 41.9 vs 60.2 / 62.4 / 53.2; down 24.9 / 25.6 / 32.1 vs 26.5 / 27.4 / 41.4.
 # SGL_MI355_LINEAR16_MIN_N raises the narrowest layer that gets the copy (A/B aid).
 LINEAR16_MIN_N = int(os.environ.get("SGL_MI355_LINEAR16_MIN_N", "16"))
+# rows up to which an unquantised linear runs the 16-bit streamer (65..128: its 128-row form; above: the library GEMM)
+LINEAR16_MAX_ROWS = int(os.environ.get("SGL_MI355_LINEAR16_MAX_ROWS", "128"))
 
 
 class UnquantizedLinearMethod(LinearMethodBase):
-    """layers/quantization/unquant.py: F.linear.  Batches of up to 64 rows run ops.linear16 on a fragment-major copy of the
+    """layers/quantization/unquant.py: F.linear.  Batches of up to 128 rows run ops.linear16 on a fragment-major copy of the
     weight built once after loading (round 3); larger batches (prefill) go to the library GEMM (hipBLASLt through torch) --
     a 16-bit tiled GEMM is not part of the FP8 / INT4 hot path this backend is about."""
 
@@ -119,7 +121,7 @@ class UnquantizedLinearMethod(LinearMethodBase):
             layer.weight_fm = fm = None
         if fm is not None and x.is_cuda and x.dtype == fm.dtype:
             x2 = x.reshape(-1, x.shape[-1])
-            if 0 < x2.shape[0] <= 64 and x2.stride(-1) == 1:
+            if 0 < x2.shape[0] <= LINEAR16_MAX_ROWS and x2.stride(-1) == 1:
                 return ops.linear16(x2, fm, bias).reshape(x.shape[:-1] + (fm.N,))
         return torch.nn.functional.linear(x, layer.weight, bias)
 

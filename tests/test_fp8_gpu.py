@@ -290,7 +290,7 @@ def test_group_quant_ue8m0_packed_scales(T, K, G, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("M", [1, 7, 16, 33, 64])
+@pytest.mark.parametrize("M", [1, 7, 16, 33, 64, 65, 128])
 @pytest.mark.parametrize("N,K", [(128256, 4096), (32000, 4096), (1000, 512), (4096, 1024), (151936, 896 + 128)])
 def test_linear16_lm_head_vs_fp64(M, N, K, dtype):
     """LM head / unquantised decode linear (logits_processor.py:430-505): x @ W^T in 16 bit with fp32 accumulation.
@@ -309,12 +309,12 @@ def test_linear16_lm_head_vs_fp64(M, N, K, dtype):
     wide = torch.zeros(M, K + 64, device=DEV, dtype=dtype)
     wide[:, :K] = x
     assert torch.equal(ops.linear16(wide[:, :K], w, bias), out)
-    with pytest.raises(RuntimeError, match="M <= 64"):
-        ops.linear16(torch.zeros(65, K, device=DEV, dtype=dtype), w)
+    with pytest.raises(RuntimeError, match="M <= 128"):
+        ops.linear16(torch.zeros(129, K, device=DEV, dtype=dtype), w)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("M", [1, 16, 17, 33, 64])
+@pytest.mark.parametrize("M", [1, 16, 17, 33, 64, 100, 128])
 @pytest.mark.parametrize("N,K", [(128256, 4096), (32000, 4096), (1008, 512), (4096, 1024), (151936, 1024), (4096, 14336),
                                  (6144, 4096), (4096, 4096), (1280, 8192)])
 def test_linear16_on_fragment_major_weight_is_bit_identical(M, N, K, dtype):

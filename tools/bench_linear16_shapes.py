@@ -13,7 +13,7 @@ for name, K, N in shapes:
     nl = max(3, int(700e6 // (2 * K * N)))
     ws = [(torch.randn(N, K, device=dev, generator=g) * 0.02).bfloat16() for _ in range(nl)]
     wsh = [ops.linear16_shuffle_weight(w) for w in ws]
-    for M in (1, 16, 64):
+    for M in (1, 16, 64, 128):
         x = torch.randn(M, K, device=dev, generator=g).bfloat16()
 
         def timed(fn):

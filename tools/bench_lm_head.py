@@ -11,7 +11,7 @@ g = torch.Generator(device=dev).manual_seed(0)
 N, K = 128256, 4096
 ws = [(torch.randn(N, K, device=dev, generator=g) * 0.02).bfloat16() for _ in range(2)]
 wsh = [ops.linear16_shuffle_weight(w) for w in ws]  # fragment-major copies (round 3)
-for M in (1, 16, 64):
+for M in (1, 16, 64, 128):
     x = torch.randn(M, K, device=dev, generator=g).bfloat16()
 
     def t(fn, n=20):
