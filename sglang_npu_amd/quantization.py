@@ -88,6 +88,8 @@ class QuantizationConfig:
 # 15.5 / 14.9-15.0; gate_up 39.0 / 40.0 / 41.9 vs 60.2 / 62.4 / 53.2; down 24.9 / 25.6 / 32.1 vs 26.5 / 27.4 / 41.4.
 # SGL_MI355_LINEAR16_MIN_N raises the narrowest layer that gets the copy (A/B aid).
 LINEAR16_MIN_N = int(os.environ.get("SGL_MI355_LINEAR16_MIN_N", "16"))
+# rows up to which an AWQ layer runs its 64-row decode streamer in two passes instead of the tiled prefill kernel (0: never)
+AWQ_TWO_PASS_MAX_ROWS = int(os.environ.get("SGL_MI355_AWQ_TWO_PASS_MAX_ROWS", "128"))
 # rows up to which an unquantised linear runs the 16-bit streamer (65..128: its 128-row form; above: the library GEMM)
 LINEAR16_MAX_ROWS = int(os.environ.get("SGL_MI355_LINEAR16_MAX_ROWS", "128"))
 
@@ -372,8 +374,15 @@ class AWQLinearMethod(LinearMethodBase):
             raise RuntimeError("AWQLinearMethod.apply: the checkpoint-layout tensors were released "
                                "(SGL_MI355_AWQ_RELEASE_CHECKPOINT_LAYOUT); only fp16 activations are served")
         if packed is not None and reshaped_x.dtype == torch.float16:
-            if reshaped_x.shape[0] <= 64:  # decode: weight-streaming kernel on the k-packed copy
+            rows = reshaped_x.shape[0]
+            if rows <= 64:  # decode: weight-streaming kernel on the k-packed copy
                 out = ops.awq_gemm_packed(reshaped_x, packed[0], packed[1], packed[2], bias)
+            elif rows <= AWQ_TWO_PASS_MAX_ROWS:
+                # 65..128 rows: two passes of the 64-row streamer (rows are independent: the same bits as one call would give)
+                # -- the tiled kernel below puts a narrow layer on N / 128 CUs at this size (Llama-2-7B, bs = 128: 29.6 -> see
+                # profiles/r03_sweep.txt)
+                out = torch.cat([ops.awq_gemm_packed(reshaped_x[:64], packed[0], packed[1], packed[2], bias),
+                                 ops.awq_gemm_packed(reshaped_x[64:], packed[0], packed[1], packed[2], bias)], dim=0)
             else:  # prefill: 128 x 128 tiles on the fp16 MFMA, INT4 unpacked in registers -- no fp16 weight copy anywhere
                 out = ops.awq_gemm_packed_tiled(reshaped_x, packed[0], packed[1], packed[2], bias)
         else:

@@ -195,3 +195,23 @@ def test_awq_linear_method_prefill_keeps_int4_only():
         torch.testing.assert_close(y_dec.double(), ref[:7], rtol=2.0 ** -10, atol=2e-3 * float(ref.abs().max()))
     assert not hasattr(layer, "awq_dequant_cache")
     assert not any(t.dtype == torch.float16 and t.numel() >= K * N for t in vars(layer).values() if isinstance(t, torch.Tensor))
+
+
+@pytest.mark.parametrize("M", [65, 100, 128])
+def test_awq_linear_method_65_to_128_rows_is_two_passes_of_the_decode_kernel(M):
+    """AWQLinearMethod.apply for a decode batch of 65..128 rows: rows are independent, so the result must be the 64-row
+    streamer's on each chunk (bit for bit), with bias, and match x @ dequantize(W)."""
+    from sglang_npu_amd.quantization import AWQConfig
+    from sglang_npu_amd.linear import ColumnParallelLinear
+    K, N = 2048, 1024
+    layer = ColumnParallelLinear(K, [N], bias=True, params_dtype=torch.float16, quant_config=AWQConfig(4, 128, True)).to(DEV)
+    qw, qz, sc = _awq_case(K, N, 128, torch.Generator().manual_seed(21))
+    layer.qweight.data.copy_(qw), layer.qzeros.data.copy_(qz), layer.scales.data.copy_(sc)
+    layer.bias.data.copy_(torch.randn(N, generator=torch.Generator().manual_seed(3)).half())
+    layer.quant_method.process_weights_after_loading(layer)
+    x = torch.randn(M, K, generator=torch.Generator().manual_seed(M)).half().to(DEV)
+    y = layer(x)[0]
+    assert y.shape == (M, N)
+    assert torch.equal(y[:64], layer(x[:64])[0]) and torch.equal(y[64:], layer(x[64:])[0])
+    ref = x.double() @ ops.awq_dequantize(qw.to(DEV), sc.to(DEV), qz.to(DEV)).double() + layer.bias.double()
+    torch.testing.assert_close(y.double(), ref, rtol=2.0 ** -10, atol=2e-3 * float(ref.abs().max()))
