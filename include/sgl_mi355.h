@@ -372,7 +372,8 @@ int sgl_mi355_per_token_quant_fp8(
  *   columns); scales fp32 contiguous [M] / [N]; bias [N] in out dtype or NULL; out [M,N]
  *   contiguous bf16/fp16.  K % 16 == 0 and (N*2) % 16 == 0 as in the reference
  *   (fp8_gemm_kernel.cu:1086-1089,1108).  `workspace` (fp32, caller-owned, may be NULL) lets the
- *   M <= 64 path keep split-K partials: ceil(K/2048) * M * N floats are enough. */
+ *   M <= 128 path (the weight streamer: up to 64 rows, and 65..128 rows on 128-row phases, round 3) keep split-K
+ *   partials: ceil(K/2048) * M * N floats are enough. */
 int sgl_mi355_fp8_scaled_mm(
     const void* mat_a, const void* mat_b, const float* scales_a, const float* scales_b, const void* bias, void* out,
     float* workspace, int64_t workspace_floats,
@@ -432,7 +433,7 @@ int sgl_mi355_fp8_scaled_mm_partials_wshuffled(const void* mat_a, const void* ma
                                                int64_t workspace_floats, int64_t M, int64_t N, int64_t K,
                                                int64_t a_stride_m, int32_t* num_slices, void* stream);
 
-/* Split-K form of fp8_scaled_mm for fused consumers (decode, M <= 64).
+/* Split-K form of fp8_scaled_mm for fused consumers (decode, M <= 128).
  *   fp8_scaled_mm_partials leaves raw fp32 partial sums workspace[slice][M][N] and reports the slice count
  *   (SGL_MI355_ERR_UNSUPPORTED when the shape is not on the split-K weight-streaming path: the caller then uses
  *   sgl_mi355_fp8_scaled_mm).  The epilogue of fp8_gemm_kernel.cu:498-546 (x w_scale, x x_scale, + bias, one rounding)
@@ -583,7 +584,7 @@ int sgl_mi355_rotary_embedding_set_kv_fp8kv(const int64_t* positions, void* quer
  * Replaces: the LM-head product of LogitsProcessor._get_logits, `torch.matmul(hidden_states, lm_head.weight.T)`
  *           (python/sglang/srt/layers/logits_processor.py:430-505), and any unquantised decode linear
  *           (layers/quantization/unquant.py: F.linear): out[M, N] = x[M, K] @ weight[N, K]^T (+ bias).
- * 16-bit operands (dtype 0 bf16, 1 fp16), fp32 accumulation, M <= 64 (decode batches; the weight-streaming kernel of
+ * 16-bit operands (dtype 0 bf16, 1 fp16), fp32 accumulation, M <= 128 (decode batches; the weight-streaming kernel of
  * csrc/gemm_bf16.hip), N % 8 == 0, K % 256 == 0; strides in elements; out contiguous [M, N]. */
 int sgl_mi355_gemm16_nt(const void* x, const void* weight, const void* bias, void* out, int64_t M, int64_t N, int64_t K,
                         int64_t x_stride_m, int64_t w_stride_n, int dtype, void* stream);

@@ -2390,8 +2390,8 @@ static int fp8_scaled_mm_partials_impl(int b_shuf, const void* mat_a, const void
   SGLM_CHECK_ARG(mat_a && mat_b && reinterpret_cast<uintptr_t>(mat_a) % 16 == 0 && reinterpret_cast<uintptr_t>(mat_b) % 16 == 0,
                  "fp8_scaled_mm_partials: operands must be 16-byte aligned");
   *num_slices = 0;
-  if (M > 64) {
-    set_error("fp8_scaled_mm_partials: only the decode kernels (M <= 64) have a split-K form");
+  if (M > 128) {
+    set_error("fp8_scaled_mm_partials: only the decode kernels (M <= 128) have a split-K form");
     return SGL_MI355_ERR_UNSUPPORTED;
   }
   SGLM_CHECK_ARG(!b_shuf || shuffle_shape_ok(N, K), "fp8_scaled_mm_partials_wshuffled: N %% 16 == 0 and K %% 512 == 0 required");
@@ -2407,7 +2407,8 @@ static int fp8_scaled_mm_partials_impl(int b_shuf, const void* mat_a, const void
   int sk = 0;
   int rc = M <= 16   ? launch_wstream<SGL_MI355_BF16, 1>(p, workspace, workspace_floats, s, used, &sk)
            : M <= 32 ? launch_wstream<SGL_MI355_BF16, 2>(p, workspace, workspace_floats, s, used, &sk)
-                     : launch_wstream<SGL_MI355_BF16, 4>(p, workspace, workspace_floats, s, used, &sk);
+           : M <= 64 ? launch_wstream<SGL_MI355_BF16, 4>(p, workspace, workspace_floats, s, used, &sk)
+                     : launch_wstream<SGL_MI355_BF16, 8>(p, workspace, workspace_floats, s, used, &sk);  // 128-row phases
   if (rc) return rc;
   if (!used) {
     set_error("fp8_scaled_mm_partials: shape (M=%ld N=%ld K=%ld) is not on the split-K weight-streaming path", (long)M,

@@ -114,12 +114,12 @@ class LlamaMLP(torch.nn.Module):
     def forward_fp8(self, xq, xs, out_dtype, defer: bool = False):
         """Same computation with the activations kept in FP8 between the kernels (fused producers)."""
         part = None
-        if defer and xq.shape[0] <= 64 and self.gate_up_proj.output_size_per_partition <= GATE_UP_PARTIALS_MAX_N:
+        if defer and xq.shape[0] <= 128 and self.gate_up_proj.output_size_per_partition <= GATE_UP_PARTIALS_MAX_N:
             # narrow per-rank gate_up (Llama-3-8B at TP = 8: 4096 -> 3584): the split-K kernel + the epilogue inside
             # silu.mul beats the latency-bound single-pass GEMM (one rank's step 2.61 -> 2.57 ms); at 7168 columns it loses
             part = self.gate_up_proj.forward_prequantized_partials(xq, xs, out_dtype)
         act = None
-        if part is None and FUSE_SILU_GEMM and xq.shape[0] > 64:
+        if part is None and FUSE_SILU_GEMM and xq.shape[0] > 128:
             # prefill: SiLU * mul in the gate_up GEMM's epilogue (the [T, 2 I] product never goes to HBM), then the row quant
             act = self.gate_up_proj.forward_prequantized_silu_mul(xq, xs, out_dtype)
         if part is not None:

@@ -584,7 +584,7 @@ def _fp8_slab_floats(M: int, N: int, K: int) -> int:
 def reserve_gemm_workspace(device, rows: int = 64, cols: int = 28672) -> None:
     """Size this stream's split-K scratch (FP8 and AWQ decode GEMMs) for GEMMs of up to ``rows`` x ``cols`` outputs."""
     device = torch.device(device)
-    _fp8_workspace.get(device, 32 * min(rows, 64) * cols)
+    _fp8_workspace.get(device, 32 * min(rows, 64) * cols)  # (65..128 rows: at most 16 slices of 128 rows, the same bound)
     _awq_workspace.get(device, 16 * min(rows, 64) * cols)
 
 
@@ -738,9 +738,9 @@ def fp8_scaled_mm_partials(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=Non
     _need_gpu(mat_a, mat_b, scales_a, scales_b, bias)
     M, K = mat_a.shape
     N = mat_b.size(1)
-    if not (0 < M <= 64) or mat_a.stride(1) != 1 or mat_b.stride(0) != 1 or mat_b.size(0) != K:
+    if not (0 < M <= 128) or mat_a.stride(1) != 1 or mat_b.stride(0) != 1 or mat_b.size(0) != K:
         return None
-    ws = _fp8_workspace.get(mat_a.device, max(32 * M * N, _fp8_slab_floats(M, N, K)))
+    ws = _fp8_workspace.get(mat_a.device, max(32 * min(M, 64) * N, _fp8_slab_floats(M, N, K)))
     sk = ctypes.c_int32(0)
     if is_wshuffled(mat_b):
         if N > 1 and mat_b.stride(1) != K:

@@ -333,7 +333,7 @@ def test_deferred_gemm_epilogues_are_bit_identical(monkeypatch):
         assert torch.equal(outs[0][1][l], outs[1][1][l]) and torch.equal(outs[0][2][l], outs[1][2][l]), f"pool layer {l}"
 
 
-@pytest.mark.parametrize("M", [1, 16, 33, 64])
+@pytest.mark.parametrize("M", [1, 16, 33, 64, 100, 128])  # (65..128: the streamer's 128-row phases)
 @pytest.mark.parametrize("with_bias", [False, True])
 def test_from_partials_ops_equal_unfused_sequence(M, with_bias):
     """sgl_mi355_fp8_scaled_mm_partials + {finalize, rmsnorm_quant_fp8_from_partials, silu_and_mul_quant_fp8_from_partials,
