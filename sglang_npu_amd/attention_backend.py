@@ -146,6 +146,18 @@ class MI355AttnBackend(AttentionBackend):
         group = max(1, self.num_head // self.num_kv_head)
         wgs = bs * self.num_kv_head * ((group + 15) // 16)
         if wgs >= NUM_CUS:
+            # One split, pairs of items per workgroup: a round is 2 x NUM_CUS items.  A batch just past one round (65..96
+            # requests x 8 kv heads) would pay two full rounds for it; two or four kv-splits cut the items finer, and the
+            # half-empty last round costs a half / a quarter as much (+ the merge).  Measured, 32/8/128, us, 1 / 2 / 4 splits
+            # (tools/exp/decode_splits_probe.py): bs 65 at ctx 512 / 1024 / 2048 / 8192: 43.6 / 40.1 / 45.1, 75.1 / 65.9 / 65.6,
+            # 135.9 / 116.3 / 110.9, 515 / 434 / 394; bs 80: 44.3 / 44.5 / 52.0, 76.4 / 71.4 / 76.6, 140.1 / 126.2 / 129.8,
+            # 524 / 460 / 459; bs 96 at 2048: 152.5 / 148.8 / 154.0; at ctx 256 splitting never pays (27.6 / 27.9 / 35.6).
+            excess = wgs / (2.0 * NUM_CUS) - 1.0  # fraction of a second round
+            if 0.0 < excess <= 0.5 and self.max_kv_splits >= 2 and (max_seq_len is None or max_seq_len >= 512):
+                if excess <= 0.15 and self.max_kv_splits >= 4 and max_seq_len is not None and max_seq_len >= 2048:
+                    return 4
+                if excess <= 0.25 or (max_seq_len is not None and max_seq_len >= 2048):
+                    return 2
             return 1
         # one workgroup per CU: measured at bs=64, ctx=2048 (tools/sweep_decode_small.py) 64 (request, kv-head) pairs
         # run 23.5 us with 4 splits vs 32 with 8, 128 pairs 33.8 us with 2 splits vs 40 with 4 -- every extra split adds

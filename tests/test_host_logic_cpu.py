@@ -17,6 +17,14 @@ def _backend(num_heads, num_kv_heads, max_splits=8):
 def test_split_policy_fills_the_chip_without_over_splitting():
     assert _backend(32, 8).choose_num_kv_splits(64) == 1           # 512 workgroups already
     assert _backend(32, 8).choose_num_kv_splits(32) == 1           # 256 = one per CU
+    # just past one round of pairs (512 items): finer items instead of a second full round
+    assert _backend(32, 8).choose_num_kv_splits(65) == 2           # 520 items, length unknown (graph capture)
+    assert _backend(32, 8).choose_num_kv_splits(65, max_seq_len=4096) == 4
+    assert _backend(32, 8).choose_num_kv_splits(65, max_seq_len=300) == 1
+    assert _backend(32, 8).choose_num_kv_splits(80) == 2 and _backend(32, 8).choose_num_kv_splits(80, max_seq_len=4096) == 2
+    assert _backend(32, 8).choose_num_kv_splits(96) == 1 and _backend(32, 8).choose_num_kv_splits(96, max_seq_len=4096) == 2
+    assert _backend(32, 8).choose_num_kv_splits(112, max_seq_len=4096) == 1 and _backend(32, 8).choose_num_kv_splits(128) == 1
+    assert _backend(32, 32).choose_num_kv_splits(17) == 2          # MHA: 544 items
     assert _backend(8, 1).choose_num_kv_splits(64) == 4            # 70B TP8: 64 workgroups -> 4 splits = one per CU
     assert _backend(32, 8).choose_num_kv_splits(1, max_seq_len=600) == 2    # keep >= 256 tokens per split
     assert _backend(32, 8).choose_num_kv_splits(1, max_seq_len=100000) == 8
