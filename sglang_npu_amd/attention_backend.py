@@ -152,11 +152,17 @@ class MI355AttnBackend(AttentionBackend):
             # (tools/exp/decode_splits_probe.py): bs 65 at ctx 512 / 1024 / 2048 / 8192: 43.6 / 40.1 / 45.1, 75.1 / 65.9 / 65.6,
             # 135.9 / 116.3 / 110.9, 515 / 434 / 394; bs 80: 44.3 / 44.5 / 52.0, 76.4 / 71.4 / 76.6, 140.1 / 126.2 / 129.8,
             # 524 / 460 / 459; bs 96 at 2048: 152.5 / 148.8 / 154.0; at ctx 256 splitting never pays (27.6 / 27.9 / 35.6).
-            excess = wgs / (2.0 * NUM_CUS) - 1.0  # fraction of a second round
-            if 0.0 < excess <= 0.5 and self.max_kv_splits >= 2 and (max_seq_len is None or max_seq_len >= 512):
-                if excess <= 0.15 and self.max_kv_splits >= 4 and max_seq_len is not None and max_seq_len >= 2048:
-                    return 4
-                if excess <= 0.25 or (max_seq_len is not None and max_seq_len >= 2048):
+            # Just past TWO rounds the same holds on a smaller scale (bs 129 / 136 / 144 at ctx 2048: 227.8 / 225.5 / 225.7 ->
+            # 202.2 / 208.6 / 218.4 with two splits; from bs 160 one split is ahead again).
+            full = int(wgs // (2 * NUM_CUS))                     # whole rounds of pairs
+            excess = wgs / (2.0 * NUM_CUS) - full                # fraction of one more round
+            if excess > 0.0 and self.max_kv_splits >= 2 and (max_seq_len is None or max_seq_len >= 512):
+                if full == 1 and excess <= 0.5:
+                    if excess <= 0.15 and self.max_kv_splits >= 4 and max_seq_len is not None and max_seq_len >= 2048:
+                        return 4
+                    if excess <= 0.25 or (max_seq_len is not None and max_seq_len >= 2048):
+                        return 2
+                elif full == 2 and excess <= 0.125 and (max_seq_len is None or max_seq_len >= 1024):
                     return 2
             return 1
         # one workgroup per CU: measured at bs=64, ctx=2048 (tools/sweep_decode_small.py) 64 (request, kv-head) pairs

@@ -25,6 +25,9 @@ def test_split_policy_fills_the_chip_without_over_splitting():
     assert _backend(32, 8).choose_num_kv_splits(96) == 1 and _backend(32, 8).choose_num_kv_splits(96, max_seq_len=4096) == 2
     assert _backend(32, 8).choose_num_kv_splits(112, max_seq_len=4096) == 1 and _backend(32, 8).choose_num_kv_splits(128) == 1
     assert _backend(32, 32).choose_num_kv_splits(17) == 2          # MHA: 544 items
+    assert _backend(32, 8).choose_num_kv_splits(129) == 2 and _backend(32, 8).choose_num_kv_splits(136) == 2   # just past two rounds
+    assert _backend(32, 8).choose_num_kv_splits(144) == 1 and _backend(32, 8).choose_num_kv_splits(192) == 1
+    assert _backend(32, 8).choose_num_kv_splits(40) == 1           # 320 items: inside the first round
     assert _backend(8, 1).choose_num_kv_splits(64) == 4            # 70B TP8: 64 workgroups -> 4 splits = one per CU
     assert _backend(32, 8).choose_num_kv_splits(1, max_seq_len=600) == 2    # keep >= 256 tokens per split
     assert _backend(32, 8).choose_num_kv_splits(1, max_seq_len=100000) == 8
