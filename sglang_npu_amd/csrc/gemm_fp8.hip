@@ -858,7 +858,7 @@ __global__ __launch_bounds__(512) void fp8_gemm_astat_direct_kernel(GemmArgs p, 
 //     only ~10 B/clk from HBM, so an idle CU is lost bandwidth: N = 28672 -> 7 consumers x 256 workgroups).
 template <int OUT_DTYPE, int MB, int PH, bool SLAB>
 __global__ __launch_bounds__(576) void fp8_gemm_wstream_kernel(GemmArgs p, float* slabs, int phases_per_slice) {
-  static_assert(PH == 4 || PH == 8 || PH == 16 || PH == 32, "PH");
+  static_assert(PH == 2 || PH == 4 || PH == 8 || PH == 16 || PH == 32, "PH");
   static_assert(PH * MB <= 32, "one A buffer is at most 64 KiB");
   using H = Half16<OUT_DTYPE>;
   using T = typename H::T;
@@ -873,7 +873,7 @@ __global__ __launch_bounds__(576) void fp8_gemm_wstream_kernel(GemmArgs p, float
 #ifdef SGLM_WS_PB_SET
   constexpr int PB = SGLM_WS_PB;
 #else
-  constexpr int PB = SLAB ? 2 : 4;
+  constexpr int PB = (SLAB || PH < 4) ? 2 : 4;  // (never more than a phase: PH = 2 is the 256-row form)
 #endif
   constexpr int UPS = 2 * MB;                 // 1-KiB DMA units per k-step
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1106,7 +1106,10 @@ template <int OUT_DTYPE, int MB, int PH, bool SLAB>
 int launch_wstream_ph(const GemmArgs& p, float* slabs, int SK, int phases_per_slice, int nc, int groups, hipStream_t s,
                       bool finalize = true) {
   auto kern = fp8_gemm_wstream_kernel<OUT_DTYPE, MB, PH, SLAB>;
-  constexpr int lds = 2 * PH * 16 * MB * 128;
+  constexpr int lds_ab = 2 * PH * 16 * MB * 128;                       // the two A buffers
+  constexpr int lds_ep = 8 * 16 * MB * (SLAB ? 20 * 4 : 24 * 2);        // epilogue patches of up to 8 consumer waves
+  constexpr int lds = lds_ab > lds_ep ? lds_ab : lds_ep;
+  static_assert(lds <= 160 * 1024, "LDS");
   static int attr_rc = check_hip(
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
       "hipFuncSetAttribute");
@@ -1144,7 +1147,7 @@ int launch_wstream(const GemmArgs& p, float* slabs, int64_t slab_floats, hipStre
   // K / 128 not a multiple of 8 (e.g. 3584 = 28 steps): phases of 4 steps, four weight steps in flight
   // (phases of 2 steps for the split-K form -- 192 workgroups instead of 48 on the TP = 8 qkv shape 4096 x 768 -- were
   //  tried: one rank's TP = 4 / 8 step 3.07 -> 3.04 / 2.42 -> 2.45 ms, i.e. nothing; those shapes are launch-bound)
-  const int ph_min = (steps % 8 == 0 && MB <= 4) ? 8 : 4;  // (MB = 8: 128 rows x 4 steps is the 64-KiB buffer)
+  const int ph_min = MB >= 16 ? 2 : (steps % 8 == 0 && MB <= 4) ? 8 : 4;  // (MB = 8 / 16: 4 / 2 steps are the 64-KiB buffer)
   for (int ph = 32 / MB; ph >= ph_min; ph >>= 1) {
     if (ph > ph_cap && ph > 8) continue;
     if (steps % ph != 0) continue;
@@ -1160,7 +1163,7 @@ int launch_wstream(const GemmArgs& p, float* slabs, int64_t slab_floats, hipStre
         sk = (P + pp - 1) / pp;
       }
       const int rounds = (groups_c * sk + 255) / 256;
-      const int cost = rounds * c * pp * (ph + 4);
+      const int cost = rounds * c * pp * (ph + (MB >= 16 ? 1 : 4));  // (a barrier per two steps is the only form at 256 rows)
       if (cost < best) { best = cost; PH = ph; nc = c; SK = sk; pps = pp; }
     }
     if (slabs == nullptr) break;  // the longest phase that divides K
@@ -1200,9 +1203,10 @@ int launch_wstream(const GemmArgs& p, float* slabs, int64_t slab_floats, hipStre
                : launch_wstream_ph<OUT_DTYPE, MB, PH_, false>(p, nullptr, 1, pps, nc, groups, s)
   if constexpr (MB == 1) { if (PH == 32) WS_GO(32); }
   if constexpr (MB <= 2) { if (PH == 16) WS_GO(16); }
-  if (PH == 4) WS_GO(4);
+  if constexpr (MB <= 8) { if (PH == 4) WS_GO(4); }
   if constexpr (MB <= 4) WS_GO(8);
-  used = false;  // (MB = 8 has phases of four k-steps only)
+  if constexpr (MB == 16) { if (PH == 2) WS_GO(2); }
+  used = false;  // (MB = 8 / 16 have phases of four / two k-steps only)
   return 0;
 #undef WS_GO
 }
@@ -2129,6 +2133,27 @@ int run_gemm(const GemmArgs& p, float* workspace, int64_t workspace_floats, hipS
       // 11.18 ms tiled -> 10.03 with down / gate_up only -> 9.86 with all four; bs = 96 8.86 -> 8.63 (same box)
       if (workspace != nullptr && (int64_t)p.N * p.K >= ((int64_t)8 << 20)) {
         int rc = launch_wstream<OUT_DTYPE, 8>(p, workspace, workspace_floats, s, used);
+        if (rc || used) return rc;
+      }
+    }
+  }
+  if (p.M <= 256) {
+    // 129..256 rows: the same again with a 256-row A image and phases of two k-steps (MB = 16).  Measured: see DESIGN 4.8.9.
+    static const bool no_wstream256 = getenv("SGL_MI355_NO_WSTREAM") != nullptr || getenv("SGL_MI355_NO_WSTREAM_M256") != nullptr;  // A/B aid
+    static const int direct_min_n256 = [] { const char* e = getenv("SGL_MI355_WSTREAM_MIN_N"); return e ? atoi(e) : 16 * 8 * 100; }();
+    // At 256 rows the streamer is MFMA- / LDS-bound itself (64 MFMAs and 32 KB of fragment reads per wave and k-step), so only
+    // the long-K, narrow-N layers gain, where the tiled kernels run on N / 128 CUs (eager loops, M = 256, us, tiled -> streamer:
+    // down_proj 4096 x 14336 64.4 -> 37.7; gate_up 44.9 -> 54.7, qkv 22.4 -> 27.7, o 20.8 -> 25.7 stay tiled).
+    // SGL_MI355_WSTREAM_M256_ALL=1 takes it for every shape (A/B aid).
+    static const bool all256 = getenv("SGL_MI355_WSTREAM_M256_ALL") != nullptr;
+    if (!no_wstream256 && (p.K & 511) == 0) {
+      bool used = false;
+      if (all256 && p.N >= direct_min_n256) {
+        int rc = launch_wstream<OUT_DTYPE, 16>(p, nullptr, 0, s, used);
+        if (rc || used) return rc;
+      }
+      if (workspace != nullptr && (int64_t)p.N * p.K >= ((int64_t)(all256 ? 8 : 40) << 20) && (all256 || p.K >= 2 * p.N)) {
+        int rc = launch_wstream<OUT_DTYPE, 16>(p, workspace, workspace_floats, s, used);
         if (rc || used) return rc;
       }
     }

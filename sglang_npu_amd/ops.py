@@ -663,7 +663,7 @@ def fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None) -> tor
     out = torch.empty((M, N), dtype=out_dtype, device=mat_a.device)
     b_stride_n = mat_b.stride(1) if N > 1 else K
     ws = None
-    if 0 < M <= 128:  # split-K partials of the decode-time weight streamer (up to 128 rows: gemm_fp8.hip run_gemm)
+    if 0 < M <= 256:  # split-K partials of the decode-time weight streamer (up to 256 rows: gemm_fp8.hip run_gemm)
         ws = _fp8_workspace.get(mat_a.device, _fp8_slab_floats(M, N, K))
     if is_wshuffled(mat_b):  # bytes in the fragment-major layout (fp8_shuffle_weight); shape/strides still say [K, N]
         if b_stride_n != K:

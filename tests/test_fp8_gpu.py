@@ -73,7 +73,7 @@ def _rand_fp8(shape, g):
     return ((torch.rand(shape, generator=g) - 0.5) * 2 * 448).clamp(-448, 448).to(torch.float8_e4m3fn)
 
 
-@pytest.mark.parametrize("M", [1, 7, 16, 33, 64, 65, 128, 200, 512])
+@pytest.mark.parametrize("M", [1, 7, 16, 33, 64, 65, 128, 129, 200, 256, 512])
 @pytest.mark.parametrize("N,K", [(128, 512), (6144, 4096), (4096, 1024), (1280, 8192), (72, 144), (4096, 14336)])
 def test_fp8_scaled_mm_vs_oracle(M, N, K):
     g = torch.Generator().manual_seed(M * 1000 + N + K)
@@ -359,6 +359,7 @@ def test_linear16_shuffle_rejects_other_shapes():
     (64, 4096, 14336, True, True, "wstream_slab"),    # down_proj at decode: split-K slabs
     (128, 4096, 14336, True, False, "wstream_slab"),  # ... and for a batch of 65..128 rows: 128-row A phases (MB = 8) + finalize
     (100, 28672, 4096, True, False, "wstream"),       # gate_up at 65..128 rows
+    (256, 4096, 14336, True, False, "wstream_slab"),  # ... and 129..256 rows: 256-row A phases of two k-steps (MB = 16)
     (128, 4096, 14336, False, False, "wstream_slab"), # (row-major weight as well)
     (64, 4096, 1024, False, False, "oneshot"),        # K <= 1024 at any width: every load issued up front
     (16, 28672, 4096 + 64, False, False, "astat_direct"),  # wide N with a K tail, row-major weight

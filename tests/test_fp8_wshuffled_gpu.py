@@ -54,7 +54,7 @@ SHAPES = [(6144, 4096), (4096, 4096), (28672, 4096), (4096, 14336), (1024, 512),
           (512, 7168)]
 
 
-@pytest.mark.parametrize("M", [1, 7, 16, 17, 32, 33, 64, 65, 100, 128, 200, 1000])  # 65..128: the streamer's 128-row phases
+@pytest.mark.parametrize("M", [1, 7, 16, 17, 32, 33, 64, 65, 100, 128, 129, 200, 256, 1000])  # 65..128 / 129..256: the streamer's 128- / 256-row forms
 @pytest.mark.parametrize("N,K", SHAPES)
 def test_fp8_scaled_mm_on_shuffled_weight(M, N, K):
     g = torch.Generator(device=DEV).manual_seed(M * 1000 + N + K)
