@@ -432,3 +432,27 @@ def test_unquantized_wide_linear_uses_the_streamer_at_decode_sizes():
     assert narrow.weight_fm is None
     ref = x.double() @ narrow.weight.data.double().t()
     torch.testing.assert_close(y.double(), ref, rtol=2.0 ** -7, atol=2.0 ** -7 * float(ref.abs().max()) * 0.05)
+
+
+@pytest.mark.parametrize("M", [7, 64, 100, 128, 200, 256, 300])
+@pytest.mark.parametrize("N,K,shuffled", [(4096, 14336, True), (6144, 4096, True), (28672, 1024, True), (1280, 3584, False)])
+def test_fp8_scaled_mm_takes_rows_of_a_wider_activation_buffer(M, N, K, shuffled):
+    """mat_a as a strided view (rows of a wider buffer, stride(0) > K), the form the model hands over when the activation is
+    a slice: every kernel family on the way (weight streamer with 64- / 128- / 256-row phases, tiled) must read the rows it
+    is given -- same bits as on a compact copy."""
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    wide = ((torch.rand(M, K + 256, generator=g, device=DEV) - 0.5) * 8).to(torch.float8_e4m3fn)
+    a = wide[:, :K]
+    assert a.stride(0) == K + 256
+    w = ((torch.rand(N, K, generator=g, device=DEV) - 0.5) * 8).to(torch.float8_e4m3fn)
+    sa = torch.rand(M, 1, generator=g, device=DEV) * 1e-2 + 1e-3
+    sb = torch.rand(N, 1, generator=g, device=DEV) * 1e-2 + 1e-3
+    wt = ops.mark_wshuffled(ops.fp8_shuffle_weight(w).t()) if shuffled else w.t()
+    out = ops.fp8_scaled_mm(a, wt, sa, sb, torch.bfloat16)
+    name = ops.fp8_last_kernel()
+    ref = ops.fp8_scaled_mm(a.contiguous(), wt, sa, sb, torch.bfloat16)
+    assert ops.fp8_last_kernel() == name
+    assert torch.equal(out, ref)
+    rows = torch.tensor(sorted({0, M // 2, M - 1}), device=DEV)
+    truth = (a[rows].double() @ w.double().t()) * sb.double().view(1, -1) * sa[rows].double()
+    torch.testing.assert_close(out[rows].double(), truth, rtol=2.0 ** -7, atol=1e-3 * float(truth.abs().max()))
