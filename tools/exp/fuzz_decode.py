@@ -1,0 +1,74 @@
+"""Random-configuration check of the paged decode attention against an fp32 torch reference (gathered K/V, softmax in fp32,
+P rounded to the 16-bit dtype before P.V as the kernels do).  Not a test: a bug hunt over shapes the parametrised tests do not
+list.  Prints every failing configuration; exit code 1 if any."""
+import os, sys, random
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from sglang_npu_amd import ops
+DEV = "cuda"
+rng = random.Random(int(os.environ.get("SEED", "0")))
+N = int(os.environ.get("N", "150"))
+bad = 0
+for it in range(N):
+    D = rng.choice([64, 128])
+    Hkv = rng.choice([1, 2, 4, 7, 8, 32])
+    group = rng.choice([1, 2, 4, 7, 8, 16])
+    Hq = Hkv * group
+    B = rng.choice([1, 2, 3, 5, 8, 17, 33, 40, 64, 65, 70, 96, 129])
+    if B * Hq * D > 2_000_000:
+        B = max(1, 2_000_000 // (Hq * D))
+    dtype = rng.choice([torch.bfloat16, torch.float16])
+    maxlen = rng.choice([1, 31, 33, 100, 257, 600, 1500, 4100, 9000])
+    lens = [rng.randint(0 if rng.random() < 0.1 else 1, maxlen) for _ in range(B)]
+    if rng.random() < 0.3:
+        lens = [rng.choice([maxlen, max(1, maxlen - 1)])] * B
+    if sum(lens) * Hkv * D * 2 * 2 > 3_000_000_000:
+        continue
+    splits = rng.choice([1, 1, 1, 2, 3, 4, 8])
+    total = sum(lens)
+    g = torch.Generator(device=DEV).manual_seed(it)
+    rows = total + 5
+    kb = torch.randn(rows, Hkv, D, device=DEV, generator=g).to(dtype)
+    vb = torch.randn(rows, Hkv, D, device=DEV, generator=g).to(dtype)
+    q = torch.randn(B, Hq, D, device=DEV, generator=g).to(dtype)
+    perm = (torch.randperm(rows - 1, device=DEV, generator=g) + 1)[:total].to(torch.int32)
+    width = max(lens) + 3
+    r2t = torch.zeros(B, width, dtype=torch.int32, device=DEV)
+    off = 0
+    for b, n in enumerate(lens):
+        r2t[b, :n] = perm[off:off + n]
+        off += n
+    rpi = torch.arange(B, device=DEV)
+    seq = torch.tensor(lens, dtype=torch.int64, device=DEV)
+    o = torch.full((B, Hq, D), 7.0, dtype=dtype, device=DEV)
+    logits = torch.zeros(B, Hq, splits, D + 1, device=DEV) if splits > 1 else None
+    scale = D ** -0.5
+    try:
+        ops.decode_attention_paged(q, kb, vb, o, r2t, rpi, seq, logits, splits, scale, 0.0)
+        torch.cuda.synchronize()
+    except Exception as e:  # noqa: BLE001
+        print("EXC", dict(it=it, B=B, Hq=Hq, Hkv=Hkv, D=D, dtype=str(dtype), maxlen=maxlen, splits=splits), repr(e)[:200])
+        bad += 1
+        continue
+    # reference
+    ref = torch.zeros(B, Hq, D, device=DEV)
+    for b, n in enumerate(lens):
+        if n == 0:
+            continue
+        idx = r2t[b, :n].long()
+        k = kb[idx].float()  # [n, Hkv, D]
+        v = vb[idx]
+        qq = q[b].float().view(Hkv, group, D)
+        s = torch.einsum("hgd,nhd->hgn", qq, k) * scale
+        p = torch.softmax(s, dim=-1)
+        ref[b] = torch.einsum("hgn,nhd->hgd", p, v.float()).reshape(Hq, D)
+    ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    err = (o.float() - ref).abs()
+    tol = 3e-3 + 4 * ulp * ref.abs() + (2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11) * 3.0  # P rounding on values of N(0,1) V
+    if not bool((err <= tol).all()) or not bool(torch.isfinite(o.float()).all()):
+        w = (err - tol).argmax()
+        print("MISMATCH", dict(it=it, B=B, Hq=Hq, Hkv=Hkv, D=D, dtype=str(dtype), maxlen=maxlen, splits=splits, lens=lens[:6]),
+              "max err", float(err.max()), "excess", float((err - tol).max()))
+        bad += 1
+print("configs", N, "bad", bad)
+sys.exit(1 if bad else 0)
