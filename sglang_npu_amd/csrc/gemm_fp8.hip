@@ -217,7 +217,10 @@ __device__ __forceinline__ void wait_frag(Frag32& f) {
 // applied where the fragment is CONSUMED -- masking at the load site would itself be an immediate use
 // of the loaded value and pin a wait right behind the load.
 __device__ __forceinline__ uint4 ld16(const uint8_t* p, int k, int kend) {
-  const int kc = k < kend ? k : (kend - 16 > 0 ? kend - 16 : 0);  // stay inside the row
+  // stay inside the row: p carries this lane's 16 g offset and kend = K - 16 g, so p + (kend - 16) is the row's LAST chunk
+  // (K >= 16) whatever g is -- also when the lane's own offset lies beyond a short row (K < 128: kend - 16 < 0; clamping that to
+  // 0 read up to 112 bytes past the row, i.e. past the allocation on the tensor's last row)
+  const int kc = k < kend ? k : kend - 16;
   return *reinterpret_cast<const uint4*>(p + kc);
 }
 __device__ __forceinline__ uint4 mask16(uint4 v, int k, int kend) {
