@@ -33,8 +33,19 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else _P(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)  # the current stream's handle without building a Stream object
+
+
+def _stream_handle(device: torch.device) -> int:
+    """Raw handle of the current HIP stream of `device` (what torch.cuda.current_stream(device).cuda_stream returns, at a
+    tenth of the host cost: 0.3 us against 3.8 us per call, and every op makes one or two)."""
+    if _raw_stream is not None and device.index is not None:
+        return _raw_stream(device.index)
+    return torch.cuda.current_stream(device).cuda_stream
+
+
 def _stream(t: torch.Tensor):
-    return _P(torch.cuda.current_stream(t.device).cuda_stream)
+    return _P(_stream_handle(t.device))
 
 
 def _need_gpu(*ts):
@@ -556,7 +567,7 @@ class _ScratchPool:
         self.floor, self._cur, self._retired = floor_floats, {}, []
 
     def get(self, device: torch.device, need_floats: int) -> torch.Tensor:
-        key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+        key = (device.index, _stream_handle(device))
         cur = self._cur.get(key)
         if cur is None or cur.numel() < need_floats:
             if cur is not None:
