@@ -37,7 +37,12 @@ import os
 import sys
 import time
 
-import torch
+# Kernel arguments in device memory: the HIP runtime then skips a host-visible kernarg fetch per launch.  Nothing changes for the
+# graph-replayed decode step; the eagerly launched prefill (TTFT) pass is ~4 % shorter (9.9-10.0 -> 9.5 ms, same box).  Must be in
+# the environment before the runtime initialises; an explicit setting of the caller wins.
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
