@@ -16,8 +16,9 @@ timed region.  Data is synthetic: random-init weights with the reference's dummy
 random-permutation page table (worst case for HBM), context length CTX per request.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (paged decode attention):
-achieved = algorithmic bytes per launch / its average launch duration, measured with HIP events
-around every launch of it in an instrumented (eager) pass over the same K steps.
+achieved = algorithmic bytes per launch / its average launch duration, measured with HIP events around every launch of it
+in an instrumented (eager) pass over the same K steps (`roofline.method` says which figure is primary and gives the
+in-step difference-of-graphs figure beside it).
 `roofline_gemm` = the four decode GEMMs at M = bs (HBM fraction) and at M = 4096 (MFMA fraction), event-timed
 in this run over the model's own per-layer weights.
 `value` is the fused call order (`--call-order fused`: norm+quant / RoPE+KV-write / SiLU+quant producers, GEMM
@@ -25,7 +26,8 @@ epilogues inside their consumers); `dropin_ms_per_step` is the SAME model driven
 (RMSNorm -> LinearMethodBase.apply [quant + GEMM] -> RoPE -> AttentionBackend.forward(save_kv_cache=True) -> ...,
 models/llama.py:94-98,186-191,245-268), i.e. what an untouched SGLang model file gets from the drop-in classes.
 `cpu_baseline` = the CPU oracle (a port of the reference's CPU algorithm, oracle/) timed on the
-host cores on a bounded sample (1 of the 32 layers' hot path, 2 warm-ups + median of 7), scaled to the full step;
+host cores on a bounded sample (1 of the 32 layers' hot path, 3 warm-ups + median of 10), scaled to the full step; its GEMM leg is
+the faster of the C port and the reference's own fallback formula (fp8_utils.py:479-507) in plain torch on the same cores;
 `reference_cpu_container` quotes the compiled reference's own timing in the build container
 (tools/time_reference_cpu.py -> profiles/r02_reference_cpu_container.json).
 """
@@ -47,9 +49,24 @@ import torch  # noqa: E402
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PROFILED_ATTN_US = 92.83  # profiles/r03_bench_tp1_kernel_stats.csv: decode_mfma_pair_kernel, 2 496 launches of the profiled bench
+PROFILED_STATS_GLOB = "r[0-9][0-9]_bench_tp1_kernel_stats.csv"  # rocprofv3 --kernel-trace --stats of `bench.py`, one per round
 PMC_SUMMARY = "r03_decode_pmc_instep.json"  # in-step counters of the profiled bench command, refreshed per round
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def profiled_attn_us():
+    """Average busy time of the decode attention kernel in the newest committed rocprofv3 summary of this command
+    (profiles/rNN_bench_tp1_kernel_stats.csv), or None -- read from the file, not a literal."""
+    import csv
+    import glob
+    try:
+        path = sorted(glob.glob(os.path.join(ROOT, "profiles", PROFILED_STATS_GLOB)))[-1]
+        for row in csv.DictReader(open(path)):
+            if row.get("Name", "").find("decode_mfma_pair_kernel") >= 0:
+                return {"us": round(float(row["AverageNs"]) / 1e3, 2), "launches": int(row["Calls"]), "source": os.path.basename(path)}
+    except (OSError, IndexError, KeyError, ValueError):
+        pass
+    return None
 
 
 def parse():
@@ -345,12 +362,62 @@ def cpu_baseline(cfg, B, ctx, n_layers_full):
         t, n = med(lin)
         t_lin += t
         n_lin = min(n_lin, n)
-    t_layer = t_attn + t_lin
-    return {"value": round(B / (t_layer * n_layers_full), 3), "unit": "tokens/s", "cores": cores, "kind": "port",
-            "sample": f"1 of {n_layers_full} layers (decode attention {t_attn * 1e3:.1f} ms, blocked form of decode.cpp:942-985, "
-                      f"+ 4 quant-GEMMs {t_lin * 1e3:.1f} ms at bs={B}, ctx={ctx}; 3 warm-ups, median of "
-                      f"{min(n_attn, n_lin)}), scaled x{n_layers_full}; norms/LM head not counted; host threads = "
-                      f"min(OpenMP threads, affinity, cgroup quota)"}
+    # The reference's own CPU formula for the quant-GEMM (fp8_utils.py:479-507 `_apply_fallback_scaled_mm`: the unscaled
+    # product in fp32, then `* x_scale * weight_scale.t()` (+ bias) -> dtype) with plain torch on the same host cores.
+    # `torch._scaled_mm` itself is a scalar loop on CPU in this torch (60 s for one gate_up call), so the product is
+    # `torch.matmul` on operands dequantised ONCE outside the timed region (weights are static): in fp32 (the formula's
+    # accumulator type, bit-comparable) and in bf16 (AMX where the host has it; e4m3 values are exact in bf16, the product is
+    # rounded to bf16 before the scales -- the fastest thing plain torch can do, not bit-comparable).  VERDICT r3 #6.
+    gemm_torch = {}
+    try:
+        old_threads = torch.get_num_threads()
+        torch.set_num_threads(cores)
+        t32 = t16 = 0.0
+        n32 = 10
+        for (K, N) in [(H, (Hq + 2 * Hkv) * D), (Hq * D, H), (H, 2 * I), (I, H)]:
+            x = torch.randn(B, K, generator=g).bfloat16()
+            w = ((torch.rand(N, K, generator=g) - 0.5) * 8).to(torch.float8_e4m3fn)
+            sb = (torch.rand(N, 1, generator=g) * 1e-2)
+            wf, wb = w.float(), w.bfloat16()
+
+            def quant():  # torch_per_token_quant_fp8 of sgl-kernel/tests/test_per_token_quant_fp8.py:14-22
+                xf = x.float()
+                s_ = xf.abs().amax(dim=1, keepdim=True).clamp(min=1e-10) / 448.0
+                return (xf / s_).clamp(-448.0, 448.0).to(torch.float8_e4m3fn), s_
+
+            def lin32():
+                q_, s_ = quant()
+                return ((q_.float() @ wf.t()) * s_ * sb.t()).bfloat16()
+
+            def lin16():
+                q_, s_ = quant()
+                return ((q_.bfloat16() @ wb.t()).float() * s_ * sb.t()).bfloat16()
+
+            a_, n_ = med(lin32)
+            t32 += a_
+            n32 = min(n32, n_)
+            a_, n_ = med(lin16)
+            t16 += a_
+            n32 = min(n32, n_)
+            del wf, wb
+        torch.set_num_threads(old_threads)
+        gemm_torch = {"gemm_torch_ms": round(t32 * 1e3, 2), "gemm_torch_bf16_ms": round(t16 * 1e3, 2),
+                      "gemm_port_ms": round(t_lin * 1e3, 2), "gemm_torch_reps": n32}
+    except Exception as e:  # noqa: BLE001  (a torch build without CPU fp8 casts: the port's number stands)
+        gemm_torch = {"gemm_torch_error": repr(e)[:200]}
+    t_lin_best = min([t_lin] + [gemm_torch[k] / 1e3 for k in ("gemm_torch_ms", "gemm_torch_bf16_ms") if k in gemm_torch])
+    t_layer = t_attn + t_lin_best
+    which = ("the C port" if t_lin_best == t_lin else
+             "torch.matmul in bf16 on dequantised operands" if gemm_torch.get("gemm_torch_bf16_ms", 1e30) / 1e3 == t_lin_best
+             else "torch.matmul in fp32 on dequantised operands")
+    out = {"value": round(B / (t_layer * n_layers_full), 3), "unit": "tokens/s", "cores": cores, "kind": "port",
+           "sample": f"1 of {n_layers_full} layers (decode attention {t_attn * 1e3:.1f} ms, blocked form of decode.cpp:942-985, "
+                     f"+ 4 quant-GEMMs {t_lin_best * 1e3:.1f} ms [{which}; the reference's fallback formula "
+                     f"fp8_utils.py:479-507; C port {t_lin * 1e3:.1f} ms] at bs={B}, ctx={ctx}; 3 warm-ups, median of "
+                     f"{min(n_attn, n_lin)}), scaled x{n_layers_full}; norms/LM head not counted; host threads = "
+                     f"min(OpenMP threads, affinity, cgroup quota)"}
+    out.update(gemm_torch)
+    return out
 
 
 def reference_cpu_container():
@@ -364,6 +431,70 @@ def reference_cpu_container():
                 "source": "tools/time_reference_cpu.py -> profiles/r02_reference_cpu_container.json (build container)"}
     except (OSError, KeyError, IndexError, ValueError):
         return None
+
+
+def time_extend_kernel(cfg, device, tp):
+    """`roofline_extend`: the ragged prefix + extend ("prefill") attention kernel of north_star, event-timed in this run like
+    `roofline_gemm` (one HIP graph of 8 launches per case, median of 5 replays / 8).  Cases: the TTFT shape
+    (one request, 1024 new tokens, no prefix), 4096 new tokens, and a radix-cache hit (4 requests x 512 new tokens behind
+    2048 cached tokens each, gathered through a random-permutation page table) -- geometry of this model per rank, bf16,
+    through the Triton-form entry point (extend_attention.py:306-438).  flops = 4 B Hq D (L P + L (L + 1) / 2) against the
+    2.5 PFLOP/s dense bf16 MFMA peak; the prefix stage's gathered K/V bytes (B P Hkv 2 D 2) over the whole launch are a lower
+    bound of its gather rate."""
+    from sglang_npu_amd import ops
+    Hq, Hkv, D = cfg.num_attention_heads // tp, cfg.get_num_kv_heads(tp), cfg.head_dim
+    out = {"unit": "TFLOP/s", "peak": 2500.0, "bound": "mfma", "kernel": "extend_mfma_kernel (csrc/attention_extend.hip)",
+           "geometry": f"Hq={Hq} Hkv={Hkv} D={D} bf16, causal", "cases": []}
+    for (B, L, P, name) in [(1, 1024, 0, "ttft_1024"), (1, 4096, 0, "prefill_4096"), (4, 512, 2048, "radix_hit_4x512_after_2048")]:
+        g = torch.Generator(device=device).manual_seed(B * 1000 + L + P)
+        n_tok = B * (L + P) + 1
+        kb = torch.randn(n_tok, Hkv, D, device=device, generator=g).bfloat16()
+        vb = torch.randn(n_tok, Hkv, D, device=device, generator=g).bfloat16()
+        perm = (torch.randperm(n_tok - 1, device=device, generator=g) + 1).to(torch.int32)
+        q = torch.randn(B * L, Hq, D, device=device, generator=g).bfloat16()
+        ke = torch.randn(B * L, Hkv, D, device=device, generator=g).bfloat16()
+        ve = torch.randn(B * L, Hkv, D, device=device, generator=g).bfloat16()
+        o = torch.zeros(B * L, Hq, D, dtype=torch.bfloat16, device=device)
+        qo_indptr = (torch.arange(B + 1, device=device) * L).to(torch.int32)
+        kv_indptr = (torch.arange(B + 1, device=device) * P).to(torch.int32)
+        kv_indices = perm[: B * P].contiguous() if P else torch.zeros(1, dtype=torch.int32, device=device)
+
+        def run(n=8):
+            for _ in range(n):
+                ops.extend_attention_fwd(q, ke, ve, o, kb, vb, qo_indptr, kv_indptr, kv_indices, None, True, None, L,
+                                         D ** -0.5, 0.0)
+
+        s = torch.cuda.Stream(device=device)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            run(2)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            run()
+        graph.replay()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            st.record()
+            graph.replay()
+            en.record()
+            torch.cuda.synchronize()
+            ts.append(st.elapsed_time(en) * 1e3 / 8)
+        ts.sort()
+        us = ts[len(ts) // 2]
+        flops = 4.0 * B * Hq * D * (L * P + L * (L + 1) / 2)
+        case = {"name": name, "B": B, "extend_len": L, "prefix_len": P, "us": round(us, 2),
+                "TFLOPs": round(flops / us / 1e6, 1), "frac_mfma": round(flops / us / 1e6 / 2500.0, 4)}
+        if P:
+            case["prefix_kv_gathered_GBps_lower_bound"] = round(B * P * Hkv * 2 * D * 2 / us / 1e3, 1)
+        out["cases"].append(case)
+        del graph
+    out["note"] = ("event-timed in this run: one HIP graph of 8 launches per case, median of 5 replays / 8; counters of the same "
+                   "kernel (SQ_VALU_MFMA_BUSY_CYCLES, SQ_WAIT_INST_ANY): profiles/r04_extend_pmc.txt")
+    return out
 
 
 def time_awq_decode_gemms(layers, B, device):
@@ -429,7 +560,8 @@ def time_decode_gemms(net, cfg, B, device, tp):
     layers = list(net.layers)
     if getattr(layers[0].mlp.gate_up_proj, "awq_packed", None) is not None:
         return time_awq_decode_gemms(layers, B, device)
-    if not hasattr(layers[0].mlp.gate_up_proj, "weight") or layers[0].mlp.gate_up_proj.weight.dtype != torch.float8_e4m3fn:
+    w0 = getattr(layers[0].mlp.gate_up_proj, "weight", None)
+    if w0 is None or not (w0.dtype == torch.float8_e4m3fn or ops.is_wshuffled(w0)):  # row-major [K, N] view or fragment-major uint8
         return None
     names = [("qkv", lambda l: l.self_attn.qkv_proj), ("o", lambda l: l.self_attn.o_proj),
              ("gate_up", lambda l: l.mlp.gate_up_proj), ("down", lambda l: l.mlp.down_proj)]
@@ -437,7 +569,7 @@ def time_decode_gemms(net, cfg, B, device, tp):
     g = torch.Generator(device=device).manual_seed(7)
     for name, pick in names:
         lins = [pick(l) for l in layers]
-        K, N = lins[0].weight.shape  # stored K-major [K, N]
+        K, N = ops.fp8_weight_kn(lins[0].weight)
         row = {"name": name, "K": int(K), "N": int(N)}
         for M, key in ((B, "decode"), (1024, "prefill_1024"), (4096, "prefill")):
             a = ((torch.rand(M, K, device=device, generator=g) - 0.5) * 8).to(torch.float8_e4m3fn)
@@ -786,11 +918,19 @@ def main():
     kv_esz = 1 if args.kv_dtype in ("fp8_e4m3", "fp8_e5m2") else 2
     alg_bytes = args.batch * ctx_mid * hkv * 2 * d * kv_esz + 4 * args.batch * ctx_mid + 2 * args.batch * hq * 2 * d
     eager_event_ms = attn_ms
+    frac_eager = alg_bytes / (eager_event_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
+    frac_instep, instep_used = None, False
     if attn_instep_ms is not None and attn_instep_ms > 0:
         # the lengths of the difference runs: ctx + 2 warm-ups + n_d steps, mean ctx + 2 + n_d / 2
         ctx_d = args.ctx + 2 + min(args.steps, 16) / 2
-        alg_bytes = args.batch * ctx_d * hkv * 2 * d * kv_esz + 4 * args.batch * ctx_d + 2 * args.batch * hq * 2 * d
-        attn_ms = attn_instep_ms
+        alg_d = args.batch * ctx_d * hkv * 2 * d * kv_esz + 4 * args.batch * ctx_d + 2 * args.batch * hq * 2 * d
+        frac_instep = alg_d / (attn_instep_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
+        # the difference of two short timed runs carries their noise and second-order effects (the skipped pass
+        # feeds uninitialised rows downstream, one kernel boundary disappears).  It is the primary figure only while it
+        # agrees with the conservative one -- events around each eager launch, which read long by the host's launch gaps,
+        # never short: the in-step time must lie within [0.85, 1.02] x the eager time.  Otherwise the eager figure stands.
+        if 0.85 * eager_event_ms <= attn_instep_ms <= 1.02 * eager_event_ms:
+            alg_bytes, attn_ms, instep_used = alg_d, attn_instep_ms, True
     achieved = alg_bytes / (attn_ms * 1e-3) / 1e9
     # HBM traffic of that kernel from the committed rocprofv3 --pmc passes (bench.py cannot run the profiler on
     # itself): measured bytes / algorithmic bytes of the same kernel at the same geometry, applied to this launch.
@@ -832,11 +972,17 @@ def main():
                      "avg_launch_us": round(attn_ms * 1e3, 2), "launches_timed": n_launch,
                      "algorithmic_bytes_per_launch": int(alg_bytes),
                      "method": ("in-step: (graph-replayed step - the same step without the decode attention launch) / layers, "
-                                "HIP events on the launch stream around min(steps,16) replays each"
-                                if attn_instep_ms is not None and attn_instep_ms > 0 else
-                                "HIP events around each eager launch of the kernel on the launch stream"),
+                                "HIP events on the launch stream around min(steps,16) replays each; accepted because it lies "
+                                "within [0.85, 1.02] x the eager per-launch event time"
+                                if instep_used else
+                                "HIP events around each eager launch of the kernel on the launch stream"
+                                + ("" if frac_instep is None else " (the in-step difference disagreed with it by more than the "
+                                                                   "stated tolerance and is only reported)")),
                      "eager_event_launch_us": round(eager_event_ms * 1e3, 2),
-                     "rocprofv3_avg_busy_us_same_command": PROFILED_ATTN_US},
+                     "frac_eager_events": round(frac_eager, 4),
+                     "instep_difference_us": round(attn_instep_ms * 1e3, 2) if attn_instep_ms else None,
+                     "frac_instep_difference": round(frac_instep, 4) if frac_instep is not None else None,
+                     "rocprofv3_avg_busy_us_same_command": profiled_attn_us()},
     }
     if time_attention_kernel.merged_launches:
         out["roofline"]["launch_includes"] = ("kv-split merge + per-token FP8 quant of the output (one launch: "
@@ -847,6 +993,11 @@ def main():
         out["roofline_gemm"] = time_decode_gemms(net, cfg, args.batch, device, tp)
     except Exception as e:  # a diagnostic: never take the headline down with it
         out["roofline_gemm"] = {"error": f"{type(e).__name__}: {e}"}
+    if args.quant != "awq" and not dist_on:
+        try:
+            out["roofline_extend"] = time_extend_kernel(cfg, device, tp)
+        except Exception as e:  # a diagnostic: never take the headline down with it
+            out["roofline_extend"] = {"error": f"{type(e).__name__}: {e}"}
     try:
         ttft_ms, ttft_len = time_ttft(net, runner, backend, device)
         if dist_on:

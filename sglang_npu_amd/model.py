@@ -29,6 +29,7 @@ from .distributed import (AllReduceHandle, get_tensor_model_parallel_rank, get_t
 from .harness import ForwardBatch, ModelConfig, RadixAttention
 from .layers import RMSNorm, RotaryEmbedding, SiluAndMul, VocabParallelEmbedding
 from .linear import MergedColumnParallelLinear, QKVParallelLinear, RowParallelLinear
+from .parameter import tracked
 from .quantization import AWQConfig, W8A8Fp8Config
 
 
@@ -310,7 +311,7 @@ class LlamaForCausalLM(torch.nn.Module):
         self.embed = None
         self.embed_tokens = None  # (TP = 1 only) the table as a plain tensor, for tests that read it
         self.lm_head = None
-        self.lm_head_shuffled = None
+        self._lm_head_fm = None  # ops.TrackedCopy16 of an untied head (its fragment-major copy for the 16-bit streamer)
         self.with_lm_head = with_lm_head
 
     # ------------------------------------------------------------------ synthetic weights
@@ -347,10 +348,12 @@ class LlamaForCausalLM(torch.nn.Module):
             self.embed_tokens = self.embed_tokens[:cfg.vocab_size]
         if self.with_lm_head:
             full = _dummy((cfg.vocab_size, cfg.hidden_size), dt, dev, -2e-2, 2e-2, seed=77)
-            self.lm_head = full[rank * self.vocab_per_rank:(rank + 1) * self.vocab_per_rank].contiguous()
-            self.lm_head_shuffled = None
+            # (a tracked parameter: the fragment-major copy next to it follows in-place updates, parameter.py / ops.TrackedCopy16)
+            self.lm_head = tracked(torch.nn.Parameter)(
+                full[rank * self.vocab_per_rank:(rank + 1) * self.vocab_per_rank].contiguous(), requires_grad=False)
+            self._lm_head_fm = None
             if SHUFFLE_LM_HEAD and ops.linear16_shuffle_supported(self.lm_head.shape[0], self.lm_head.shape[1]):
-                self.lm_head_shuffled = ops.linear16_shuffle_weight(self.lm_head)
+                self._lm_head_fm = ops.TrackedCopy16(self.lm_head)
         return self
 
     def _fill_awq(self, lin):
@@ -361,6 +364,21 @@ class LlamaForCausalLM(torch.nn.Module):
         lin.qzeros.data = torch.randint(0, imax, lin.qzeros.shape, dtype=torch.int32, device=self.device_str, generator=g)
         lin.scales.data = (torch.rand(lin.scales.shape, device=self.device_str, generator=g) * 2e-3).to(lin.scales.dtype)
         lin.quant_method.process_weights_after_loading(lin)
+
+    @property
+    def lm_head_shuffled(self):
+        """The valid fragment-major copy of the LM head (ops.ShuffledWeight16; re-shuffled in place when the head was
+        written since the copy was made) or None."""
+        t = self._lm_head_fm
+        if t is None:
+            return None
+        if t.src is not self.lm_head:
+            self._lm_head_fm = None
+            return None
+        fm = t.get()
+        if fm is None:
+            self._lm_head_fm = None
+        return fm
 
     # ------------------------------------------------------------------ forward
     def forward(self, input_ids, positions, forward_batch: ForwardBatch):
@@ -424,12 +442,13 @@ class LlamaForCausalLM(torch.nn.Module):
             hidden_states, _ = self.norm(hidden_states, residual)
         if not self.with_lm_head:
             return hidden_states
-        # LM head (logits_processor.py:430-505): the 16-bit weight streamer up to 32 rows (176 / 183 us at M = 1 / 16 on the
-        # 128256 x 4096 head, library 181-184), the library GEMM above (M = 64: 200.6 us vs 212.6)
+        # LM head (logits_processor.py:430-505): the 16-bit weight streamer on the fragment-major copy up to 128 rows (round 3:
+        # M = 1 / 16 / 64 155 / 159 / 184 us on the 128256 x 4096 head against 183-187 / 187-188 / 210 for the library GEMM),
+        # the row-major streamer when there is no copy, the library GEMM above that
         rows = hidden_states.shape[0]
-        if getattr(self, "lm_head_shuffled", None) is not None and rows <= min(128, LM_HEAD_SHUFFLED_MAX_ROWS):
-            logits = ops.linear16(hidden_states if hidden_states.is_contiguous() else hidden_states.contiguous(),
-                                  self.lm_head_shuffled)
+        head_fm = self.lm_head_shuffled if rows <= min(128, LM_HEAD_SHUFFLED_MAX_ROWS) else None
+        if head_fm is not None:
+            logits = ops.linear16(hidden_states if hidden_states.is_contiguous() else hidden_states.contiguous(), head_fm)
         elif rows <= LM_HEAD_STREAMER_MAX_ROWS and \
                 ops.linear16_supported(rows, self.lm_head.shape[0], self.lm_head.shape[1]):
             logits = ops.linear16(hidden_states, self.lm_head)

@@ -161,6 +161,50 @@ class PackedvLLMParameter(ModelWeightParameter):
         return size, off
 
 
+# ---------------------------------------------------------------------------- write tracking
+# Layers that keep a re-laid COPY of a 16-bit weight next to the row-major parameter (UnquantizedLinearMethod.weight_fm, the
+# LM head) must notice every way the parameter's bytes can change after the copy was made.  SGLang updates weights in place
+# without re-running process_weights_after_loading (model_runner.py:831-900 update_weights_from_distributed / _from_tensor,
+# :1777 _model_load_weights_direct -> default_weight_loader -> `param.data.copy_`), so neither the storage pointer nor the
+# loader hook is enough.  What every such path has in common is that it goes through `param.data` (an alias whose writes the
+# parameter's own version counter does not see) or writes the parameter itself (`param.copy_`, which bumps `_version`).
+# tracked(cls) makes a subclass of a parameter class whose `data` attribute counts every read and assignment of the alias:
+# write_epoch() = (those, _version, storage pointer) changes whenever the bytes MAY have changed -- conservative (a pure read
+# through `.data` also counts; the copy is then rebuilt once, which is only a weight-sized pass).
+_TENSOR_DATA = torch.Tensor.data
+_EPOCH = "_sgl_mi355_data_uses"
+_tracked_cache = {}
+
+
+def raw_data(p: torch.Tensor) -> torch.Tensor:
+    """`p.data` without counting as a possible write (this backend's own reads)."""
+    return _TENSOR_DATA.__get__(p)
+
+
+def tracked(cls):
+    """A subclass of the parameter class ``cls`` (same name, isinstance-compatible) whose ``.data`` uses are counted."""
+    sub = _tracked_cache.get(cls)
+    if sub is None:
+        def _get(self):
+            self.__dict__[_EPOCH] = self.__dict__.get(_EPOCH, 0) + 1
+            return _TENSOR_DATA.__get__(self)
+
+        def _set(self, value):
+            self.__dict__[_EPOCH] = self.__dict__.get(_EPOCH, 0) + 1
+            _TENSOR_DATA.__set__(self, value)
+
+        sub = type(cls.__name__, (cls,), {"data": property(_get, _set), "__module__": cls.__module__,
+                                          "_sgl_mi355_tracked": True})
+        _tracked_cache[cls] = sub
+    return sub
+
+
+def write_epoch(p: torch.Tensor):
+    """Changes whenever the bytes of ``p`` may have changed (see above).  For a parameter that is not tracked() only
+    in-place writes through the tensor itself and storage replacement are seen."""
+    return (p.__dict__.get(_EPOCH, 0) if hasattr(p, "__dict__") else 0, p._version, _TENSOR_DATA.__get__(p).data_ptr())
+
+
 _LOCAL = SimpleNamespace(
     BasevLLMParameter=BasevLLMParameter, _ColumnvLLMParameter=_ColumnvLLMParameter, RowvLLMParameter=RowvLLMParameter,
     ModelWeightParameter=ModelWeightParameter, GroupQuantScaleParameter=GroupQuantScaleParameter,

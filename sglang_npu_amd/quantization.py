@@ -28,7 +28,7 @@ import os
 import torch
 
 from . import ops
-from .parameter import classes as _param_classes, is_linear_layer
+from .parameter import classes as _param_classes, is_linear_layer, raw_data, tracked
 
 # FP8 weights are re-laid fragment-major after loading when the shape allows (N % 16 == 0, K % 512 == 0): decode GEMMs
 # 31.5 -> 25.9 us (gate_up, M = 64), the headline step 6.34 -> 6.16 ms.  SGL_MI355_NO_WSHUFFLE=1 keeps row-major weights.
@@ -101,26 +101,44 @@ class UnquantizedLinearMethod(LinearMethodBase):
 
     def create_weights(self, layer, input_size_per_partition, output_partition_sizes, input_size, output_size,
                        params_dtype, **extra_weight_attrs):
-        layer.register_parameter("weight", _param_classes().ModelWeightParameter(
+        # (tracked: uses of `.data` are counted, which is how an in-place update of this weight is noticed -- parameter.py)
+        layer.register_parameter("weight", tracked(_param_classes().ModelWeightParameter)(
             data=torch.empty(sum(output_partition_sizes), input_size_per_partition, dtype=params_dtype), input_dim=1,
             output_dim=0, weight_loader=extra_weight_attrs.get("weight_loader")))
 
     def process_weights_after_loading(self, layer) -> None:
-        layer.weight_fm = None
-        w = layer.weight.data
+        old = getattr(layer, "_weight_fm", None)
+        layer._weight_fm = None
+        w = raw_data(layer.weight)
         if (w.is_cuda and w.dim() == 2 and w.dtype in (torch.bfloat16, torch.float16) and w.shape[0] >= LINEAR16_MIN_N
                 and ops.linear16_shuffle_supported(w.shape[0], w.shape[1]) and not os.environ.get("SGL_MI355_NO_LINEAR16_SHUFFLE")):
-            # a second copy (the row-major weight stays for batches above 64 rows and for reloads): +2 N K bytes per layer
-            layer.weight_fm = ops.linear16_shuffle_weight(w)
-            layer._weight_fm_of = w.data_ptr()
+            # a second copy (the row-major weight stays for batches above 128 rows and for reloads): +2 N K bytes per layer.
+            # ops.TrackedCopy16 keeps it valid against in-place updates of the parameter: SGLang's
+            # update_weights_from_tensor / _from_distributed / _model_load_weights_direct write `param.data.copy_` and do NOT
+            # come back through this hook.  A re-run of this hook re-shuffles into the existing storage (graphs hold it).
+            if old is not None and old.src is layer.weight:
+                old.epoch = None  # force a re-shuffle into the existing storage
+                if old.get() is not None:
+                    layer._weight_fm = old
+            if layer._weight_fm is None:
+                layer._weight_fm = ops.TrackedCopy16(layer.weight)
+
+    @staticmethod
+    def weight_fm(layer):
+        """The layer's valid fragment-major copy (ops.ShuffledWeight16) or None."""
+        t = getattr(layer, "_weight_fm", None)
+        if t is None:
+            return None
+        if t.src is not layer.weight:  # the parameter OBJECT was replaced: this copy belongs to nothing
+            layer._weight_fm = None
+            return None
+        fm = t.get()
+        if fm is None:
+            layer._weight_fm = None
+        return fm
 
     def apply(self, layer, x, bias=None):
-        fm = getattr(layer, "weight_fm", None)
-        if fm is not None and layer.weight.data_ptr() != layer._weight_fm_of:
-            # the parameter's storage was replaced after the copy was made (`.weight.data = ...` without running
-            # process_weights_after_loading again): the copy is stale -- drop it rather than multiply with old weights.
-            # (In-place reloads, `param.data.copy_`, are followed by process_weights_after_loading in SGLang's flow.)
-            layer.weight_fm = fm = None
+        fm = self.weight_fm(layer)
         if fm is not None and x.is_cuda and x.dtype == fm.dtype:
             x2 = x.reshape(-1, x.shape[-1])
             if 0 < x2.shape[0] <= LINEAR16_MAX_ROWS and x2.stride(-1) == 1:
@@ -136,7 +154,7 @@ def apply_fp8_linear(input: torch.Tensor, weight: torch.Tensor, weight_scale: to
     if input_scale is not None:
         raise NotImplementedError("static activation scales (per-tensor) are not part of this path")
     input_2d = input.view(-1, input.shape[-1])
-    output_shape = [*input.shape[:-1], weight.shape[1]]
+    output_shape = [*input.shape[:-1], ops.fp8_weight_kn(weight)[1]]
     qinput = torch.empty_like(input_2d, dtype=torch.float8_e4m3fn)
     x_scale = torch.empty((input_2d.shape[0], 1), dtype=torch.float32, device=input.device)
     ops.sgl_per_token_quant_fp8(input_2d.contiguous(), qinput, x_scale)
@@ -211,7 +229,16 @@ class W8A8Fp8LinearMethod(LinearMethodBase):
     def process_weights_after_loading(self, layer) -> None:
         # w8a8_fp8.py:113-133
         weight = layer.weight
-        if self.quantization_config.is_checkpoint_fp8_serialized:
+        if ops.is_wshuffled(weight):
+            # re-entered on a layer this hook has already re-laid (the reference re-runs it after a reload,
+            # model_loader/loader.py:456, model_runner.py:731): back to the row-major [N, K] the code below starts from
+            weight = ops.fp8_shuffle_weight(raw_data(weight), inverse=True)
+            weight_scale = layer.weight_scale.detach()
+        elif weight.dtype == torch.float8_e4m3fn and weight.dim() == 2 and weight.stride(0) == 1 and weight.shape[0] > 1 \
+                and getattr(layer, "_sgl_mi355_weight_is_kn", False):
+            weight = weight.t()  # re-entered with the K-major [K, N] view this hook stored (no shuffle: N or K not divisible)
+            weight_scale = layer.weight_scale.detach()
+        elif self.quantization_config.is_checkpoint_fp8_serialized:
             weight_scale = layer.weight_scale.detach()
         else:
             weight, weight_scale = per_channel_quant_fp8_weight(layer.weight)
@@ -219,12 +246,14 @@ class W8A8Fp8LinearMethod(LinearMethodBase):
         if PRESHUFFLE_FP8_WEIGHTS and weight.is_cuda and weight.dtype == torch.float8_e4m3fn and ops.fp8_shuffle_supported(n, k):
             # MI355X repack (this hook is where the reference repacks too, e.g. aiter's shuffle_weight for its ROCm MoE
             # weights, fp8.py:780-783): fragment-major bytes, so that a decode wave's weight loads are 1 KiB contiguous
-            # instead of 16 rows x 64 B.  Shape and strides stay those of the [K, N] view; the tensor is tagged and only
-            # ops.fp8_scaled_mm / fp8_scaled_mm_partials (which check the tag) may read it.
-            weight = ops.fp8_shuffle_weight(weight.contiguous())
-            layer.weight = ops.mark_wshuffled(torch.nn.Parameter(weight.t(), requires_grad=False))
+            # instead of 16 rows x 64 B.  The parameter becomes a uint8 tensor [N / 16, 16 K] (round 4): the layout is
+            # carried by dtype and shape, survives .data / detach / deepcopy / state_dict, and anything that expects the
+            # [N, K] or [K, N] matrix (a loader, another kernel) fails on the shape instead of reading shuffled bytes.
+            layer.weight = torch.nn.Parameter(ops.fp8_shuffle_weight(weight.contiguous()), requires_grad=False)
+            layer._sgl_mi355_weight_is_kn = False
         else:
             layer.weight = torch.nn.Parameter(weight.t(), requires_grad=False)  # K-major [K, N] view
+            layer._sgl_mi355_weight_is_kn = True
         layer.weight_scale = torch.nn.Parameter(weight_scale.contiguous(), requires_grad=False)
         layer.input_scale = None
 
@@ -237,7 +266,7 @@ class W8A8Fp8LinearMethod(LinearMethodBase):
         the per-token FP8 activation (fused norm+quant / silu+quant kernels of this backend)."""
         q2 = qinput.view(-1, qinput.shape[-1])
         out = ops.fp8_scaled_mm(q2, layer.weight, x_scale, layer.weight_scale, out_dtype=out_dtype, bias=bias)
-        return out.view(*qinput.shape[:-1], layer.weight.shape[1])
+        return out.view(*qinput.shape[:-1], out.shape[-1])
 
 
     def apply_prequantized_silu_mul(self, layer, qinput: torch.Tensor, x_scale: torch.Tensor, out_dtype: torch.dtype,

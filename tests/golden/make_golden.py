@@ -648,6 +648,85 @@ def run_group_and_tensor_quant_cases():
     return out
 
 
+# ----------------------------------------------------------------------------- vocab-parallel embedding (round 4)
+def _ref_vocab_embedding_module():
+    """python/sglang/srt/layers/vocab_parallel_embedding.py loaded by path; its sglang imports (distributed state, quant
+    registry, AMX helpers -- nothing the pure functions below touch) are placeholder modules for the load."""
+    class _Any:
+        def __init__(self, *a, **k):
+            pass
+
+    ph = {
+        "sglang": [], "sglang.srt": [],
+        "sglang.srt.distributed": {"divide": lambda a, b: a // b, "get_tensor_model_parallel_rank": lambda: 0,
+                                   "get_tensor_model_parallel_world_size": lambda: 1, "parallel_state": None,
+                                   "tensor_model_parallel_all_reduce": lambda x: x},
+        "sglang.srt.distributed.device_communicators": [],
+        "sglang.srt.distributed.device_communicators.pynccl_allocator": {"use_symmetric_memory": None},
+        "sglang.srt.layers": [], "sglang.srt.layers.amx_utils": {"PackWeightMethod": _Any},
+        "sglang.srt.layers.dp_attention": {"get_attention_tp_rank": lambda: 0, "get_attention_tp_size": lambda: 1},
+        "sglang.srt.layers.parameter": {"BasevLLMParameter": _Any},
+        "sglang.srt.layers.quantization": [],
+        "sglang.srt.layers.quantization.base_config": {"QuantizationConfig": _Any, "QuantizeMethodBase": _Any,
+                                                       "method_has_implemented_embedding": lambda *a: False},
+        "sglang.srt.layers.quantization.unquant": {"UnquantizedEmbeddingMethod": _Any},
+        "sglang.srt.utils": {"cpu_has_amx_support": lambda: False, "get_compiler_backend": lambda: "eager",
+                             "is_cpu": lambda: True, "set_weight_attrs": lambda *a, **k: None},
+    }
+    return _load_by_path("ref_vocab_parallel_embedding", f"{REF}/python/sglang/srt/layers/vocab_parallel_embedding.py", ph)
+
+
+def run_vocab_embedding_cases():
+    """One rank's VocabParallelEmbedding.forward before the all-reduce (vocab_parallel_embedding.py:462-482) with the
+    REFERENCE's own get_masked_input_and_mask (:126-150), pad_vocab_size (:44-46) and shard ranges
+    (VocabParallelEmbedding._get_indices, :284-330): masked ids -> F.embedding on the rank's shard -> masked_fill_.
+    Original vocabulary only (no added / LoRA vocabulary), as the build's kernel.  The oracle's restatement is asserted
+    equal to it here; the GPU test reads the fixture."""
+    import oracle
+    m = _ref_vocab_embedding_module()
+    masked = getattr(m.get_masked_input_and_mask, "_torchdynamo_orig_callable", m.get_masked_input_and_mask)
+    out = {}
+    n = 0
+    for (vocab, H, tp, dtype, idt, seed) in [(1000, 64, 2, "bf16", "int64", 1), (1000, 64, 8, "fp16", "int32", 2),
+                                             (4099, 96, 4, "bf16", "int32", 3), (128, 32, 2, "fp16", "int64", 4)]:
+        g = torch.Generator().manual_seed(seed)
+        dt = torch.bfloat16 if dtype == "bf16" else torch.float16
+        padded = m.pad_vocab_size(vocab, m.DEFAULT_VOCAB_PADDING_SIZE)  # (:238-240; 64 divides by every tp used here)
+        assert padded % tp == 0
+        table = torch.randn(padded, H, generator=g).to(dt)
+        table[vocab:] = 0  # the loader zero-fills the padding rows (:459)
+        ids = torch.randint(0, vocab, (3, 41), generator=g)
+        per = padded // tp
+        edge = [0, vocab - 1] + [r * per for r in range(1, tp)] + [r * per - 1 for r in range(1, tp)]
+        ids.view(-1)[: len(edge)] = torch.tensor([min(e, vocab - 1) for e in edge])
+        ids = ids.to(torch.int32 if idt == "int32" else torch.int64)
+        total = torch.zeros(3, 41, H)
+        out[f"ids{n}"] = ids.numpy()
+        out[f"table{n}"] = u16(table)
+        out[f"dtype{n}"] = np.bytes_(dtype)
+        out[f"vocab{n}"] = np.int64(vocab)
+        out[f"tp{n}"] = np.int64(tp)
+        for r in range(tp):
+            si = m.VocabParallelEmbedding._get_indices(padded, padded, vocab, vocab, r, tp)
+            start, end = si.org_vocab_start_index, si.org_vocab_end_index
+            mi, mask = masked(ids, start, end, si.num_org_vocab_padding, si.added_vocab_start_index,
+                              si.added_vocab_end_index)
+            shard = table[r * per:(r + 1) * per].contiguous()
+            o = torch.nn.functional.embedding(mi.long(), shard)
+            o.masked_fill_(mask.unsqueeze(-1), 0)
+            mine = oracle.vocab_parallel_embedding(ids.long(), shard, start, end)
+            assert torch.equal(mine.view(torch.int16), o.view(torch.int16)), "oracle.vocab_parallel_embedding != reference"
+            out[f"start{n}_{r}"] = np.int64(start)
+            out[f"end{n}_{r}"] = np.int64(end)
+            out[f"o{n}_{r}"] = u16(o)
+            total += o.float()
+        # the all-reduce of the ranks' outputs is the plain lookup (every id belongs to exactly one shard)
+        assert torch.equal(total, torch.nn.functional.embedding(ids.long(), table).float())
+        n += 1
+    out["n"] = np.int64(n)
+    return out
+
+
 def write_elementwise(ref):
     t_norm, t_rope, t_ms, t_cpu = _ref_elementwise_helpers()
     np.savez_compressed(os.path.join(HERE, "rmsnorm.npz"), **run_norm_cases(ref, t_norm))
@@ -663,6 +742,9 @@ def main():
     if "--elementwise-only" in sys.argv:
         write_elementwise(ref)
         return
+    if "--vocab-embedding-only" in sys.argv:
+        np.savez_compressed(os.path.join(HERE, "vocab_parallel_embedding.npz"), **run_vocab_embedding_cases())
+        return
     awq_dequantize_torch, torch_scaled_mm, torch_per_token_quant_fp8 = _ref_helpers()
     for i, case in enumerate(DECODE_CASES):
         name, data = run_decode_case(ref, case, seed=1000 + i)
@@ -675,6 +757,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "awq.npz"), **run_awq_cases(awq_dequantize_torch))
     np.savez_compressed(os.path.join(HERE, "kv_indices.npz"), **run_kvindices_cases())
     write_elementwise(ref)
+    np.savez_compressed(os.path.join(HERE, "vocab_parallel_embedding.npz"), **run_vocab_embedding_cases())
     print("golden vectors written to", HERE)
 
 

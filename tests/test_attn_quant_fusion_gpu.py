@@ -121,7 +121,7 @@ def test_gemm_a16_equals_quant_then_partials(M, N, K, shuffled, dtype):
         x[2].zero_()  # an all-zero row: scale 0, quantised zeros
     w = ((torch.rand(N, K, device=DEV, generator=g) - 0.5) * 8).to(torch.float8_e4m3fn)
     sb = torch.rand(N, 1, device=DEV, generator=g) * 1e-2 + 1e-3
-    wt = ops.mark_wshuffled(ops.fp8_shuffle_weight(w).t()) if shuffled else w.t()
+    wt = ops.fp8_shuffle_weight(w) if shuffled else w.t()
     xq = torch.empty(M, K, dtype=torch.float8_e4m3fn, device=DEV)
     xs = torch.empty(M, 1, dtype=torch.float32, device=DEV)
     ops.sgl_per_token_quant_fp8(x, xq, xs)
@@ -147,7 +147,7 @@ def test_attention_then_o_proj_chain_is_bit_identical():
     g = torch.Generator(device=DEV).manual_seed(9)
     w = ((torch.rand(4096, Hq * D, device=DEV, generator=g) - 0.5) * 8).to(torch.float8_e4m3fn)
     sb = torch.rand(4096, 1, device=DEV, generator=g) * 1e-2 + 1e-3
-    wt = ops.mark_wshuffled(ops.fp8_shuffle_weight(w).t())
+    wt = ops.fp8_shuffle_weight(w)
     wn = (torch.rand(4096, device=DEV, generator=g) + 0.5).bfloat16()
     res0 = torch.randn(B, 4096, device=DEV, generator=g).bfloat16()
     # reference sequence

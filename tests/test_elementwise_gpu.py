@@ -171,6 +171,26 @@ def test_rope_neox_bit_exact_vs_reference_fixture():
         assert torch.equal(k.cpu().view(torch.int16), _z16(z, f"k_out{i}", dtype).view(torch.int16)), f"k case {i}"
 
 
+def test_vocab_parallel_embedding_bit_exact_vs_reference_fixture():
+    """ops.vocab_parallel_embedding against outputs of the REFERENCE's own get_masked_input_and_mask / shard ranges
+    (vocab_parallel_embedding.py:126-150, 284-330, 462-482; tests/golden/make_golden.py run_vocab_embedding_cases): every
+    rank's masked lookup, bf16 / fp16 tables, int32 / int64 ids, shard-edge ids, TP 2 / 4 / 8."""
+    from sglang_npu_amd.layers import pad_vocab_size, vocab_shard_range
+    z = np.load("tests/golden/vocab_parallel_embedding.npz")
+    for i in range(int(z["n"])):
+        dtype = z[f"dtype{i}"].item().decode()
+        table = _z16(z, f"table{i}", dtype)
+        ids = torch.from_numpy(z[f"ids{i}"])
+        vocab, tp = int(z[f"vocab{i}"]), int(z[f"tp{i}"])
+        per = table.shape[0] // tp
+        assert pad_vocab_size(vocab, 64) == table.shape[0]
+        for r in range(tp):
+            start, end = int(z[f"start{i}_{r}"]), int(z[f"end{i}_{r}"])
+            assert vocab_shard_range(vocab, table.shape[0], r, tp) == (start, end, per)  # the host-side shard arithmetic too
+            got = ops.vocab_parallel_embedding(ids.to(DEV), table[r * per:(r + 1) * per].contiguous().to(DEV), start, end)
+            assert torch.equal(got.cpu().view(torch.int16), _z16(z, f"o{i}_{r}", dtype).view(torch.int16)), f"case {i} rank {r}"
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
 @pytest.mark.parametrize("idt", [torch.int64, torch.int32])
 def test_vocab_parallel_embedding_vs_oracle(dtype, idt):

@@ -3,8 +3,13 @@
 * fp8_scaled_mm / fp8_scaled_mm_partials on a shuffled weight against the same call on the row-major weight:
   bit-identical wherever both run the same kernel (same products, same fp32 summation order -- only the addresses of the
   loads differ), within one output ulp where the shuffled weight forces another kernel, and against an fp64 product;
-* W8A8Fp8LinearMethod.process_weights_after_loading tags and shuffles eligible weights, leaves others row-major, and a
-  model step with shuffled weights equals the step with SGL_MI355_NO_WSHUFFLE semantics."""
+* W8A8Fp8LinearMethod.process_weights_after_loading shuffles eligible weights, leaves others row-major, and a
+  model step with shuffled weights equals the step with SGL_MI355_NO_WSHUFFLE semantics;
+* the layout is STRUCTURAL (round 4): a uint8 [N / 16, 16 K] tensor -- it survives .data / detach / deepcopy / state_dict,
+  and what is not that tensor is never read as shuffled bytes."""
+import copy
+
+
 import pytest
 import torch
 
@@ -22,7 +27,7 @@ def _shuffle_by_formula(w):
     """piece = ((n/16) * (K/128) + k/128) * 2 + (k%128)/64 ; inside = ((k%64)/16)*256 + (n%16)*16 + k%16."""
     N, K = w.shape
     b = w.view(torch.uint8).view(N // 16, 16, K // 128, 2, 4, 16)  # [nb, r16, ks, half, g, byte]
-    return b.permute(0, 2, 3, 4, 1, 5).contiguous().view(N, K)     # [nb, ks, half, g, r16, byte]
+    return b.permute(0, 2, 3, 4, 1, 5).contiguous().view(N // 16, 16 * K)  # [nb, ks, half, g, r16, byte]: one row per 16-column block
 
 
 @pytest.mark.parametrize("N,K", [(16, 512), (48, 1024), (4096, 4096), (1280, 3584), (28672, 4096)])
@@ -30,10 +35,15 @@ def test_shuffle_weight_layout_and_inverse(N, K):
     g = torch.Generator(device=DEV).manual_seed(N + K)
     w = torch.randint(0, 256, (N, K), dtype=torch.uint8, device=DEV, generator=g).view(torch.float8_e4m3fn)
     sh = ops.fp8_shuffle_weight(w)
-    assert ops.is_wshuffled(sh) and sh.shape == w.shape
-    assert torch.equal(sh.view(torch.uint8), _shuffle_by_formula(w))
+    assert ops.is_wshuffled(sh) and sh.dtype == torch.uint8 and sh.shape == (N // 16, 16 * K)
+    assert ops.fp8_weight_kn(sh) == (K, N) and ops.fp8_weight_kn(w.t()) == (K, N)
+    assert torch.equal(sh, _shuffle_by_formula(w))
     back = ops.fp8_shuffle_weight(sh, inverse=True)
-    assert not ops.is_wshuffled(back) and torch.equal(back.view(torch.uint8), w.view(torch.uint8))
+    assert not ops.is_wshuffled(back) and back.dtype == torch.float8_e4m3fn and back.shape == (N, K)
+    assert torch.equal(back.view(torch.uint8), w.view(torch.uint8))
+    # into existing storage (what a reload under captured graphs needs)
+    again = torch.zeros_like(sh)
+    assert ops.fp8_shuffle_weight(w, out=again) is again and torch.equal(again, sh)
     # a strided source (rows of a wider buffer) is re-laid the same
     wide = torch.zeros(N, K + 256, dtype=torch.uint8, device=DEV).view(torch.float8_e4m3fn)
     wide[:, :K] = w
@@ -64,7 +74,7 @@ def test_fp8_scaled_mm_on_shuffled_weight(M, N, K):
     sb = torch.rand(N, 1, generator=g, device=DEV) * 1e-3 + 1e-4
     bias = torch.randn(N, generator=g, device=DEV).to(dt) if M % 2 else None
     plain = ops.fp8_scaled_mm(a, w.t(), sa, sb, dt, bias)
-    wsh = ops.mark_wshuffled(ops.fp8_shuffle_weight(w).t())
+    wsh = ops.fp8_shuffle_weight(w)
     out = ops.fp8_scaled_mm(a, wsh, sa, sb, dt, bias)
     ref = (a.double() @ w.double().t()) * sb.double().view(1, -1) * sa.double()
     if bias is not None:
@@ -91,7 +101,7 @@ def test_prefill_shapes_on_shuffled_weight(M, N, K):
     sb = torch.rand(N, 1, generator=g, device=DEV) * 1e-3 + 1e-4
     bias = torch.randn(N, generator=g, device=DEV).to(dt) if N % 32 else None
     plain = ops.fp8_scaled_mm(a, w.t(), sa, sb, dt, bias)
-    out = ops.fp8_scaled_mm(a, ops.mark_wshuffled(ops.fp8_shuffle_weight(w).t()), sa, sb, dt, bias)
+    out = ops.fp8_scaled_mm(a, ops.fp8_shuffle_weight(w), sa, sb, dt, bias)
     assert torch.equal(out, plain)
     rows = torch.tensor([0, 1, 127, 128, M // 2, M - 2, M - 1], device=DEV)  # fp64 truth on a few rows (incl. the ragged edge)
     ref = (a[rows].double() @ w.double().t()) * sb.double().view(1, -1) * sa[rows].double()
@@ -109,7 +119,7 @@ def test_headline_decode_shapes_are_bit_identical_to_row_major(M, N, K):
     a, w = _rand_fp8((M, K), g), _rand_fp8((N, K), g)
     sa = torch.rand(M, 1, generator=g, device=DEV) * 1e-3 + 1e-4
     sb = torch.rand(N, 1, generator=g, device=DEV) * 1e-3 + 1e-4
-    wsh = ops.mark_wshuffled(ops.fp8_shuffle_weight(w).t())
+    wsh = ops.fp8_shuffle_weight(w)
     assert torch.equal(ops.fp8_scaled_mm(a, wsh, sa, sb, torch.bfloat16), ops.fp8_scaled_mm(a, w.t(), sa, sb, torch.bfloat16))
     p0 = ops.fp8_scaled_mm_partials(a, w.t(), sa, sb, torch.bfloat16)
     if p0 is not None:
@@ -135,10 +145,17 @@ def test_linear_method_shuffles_eligible_weights_only(monkeypatch):
     x = torch.randn(40, 1024, device=DEV, dtype=torch.bfloat16)
     a, b = make(512, 1024, True), make(512, 1024, False)
     assert ops.is_wshuffled(a.weight) and not ops.is_wshuffled(b.weight)
-    assert a.weight.shape == b.weight.shape == (1024, 512)
-    assert torch.equal(ops.fp8_shuffle_weight(a.weight.t(), inverse=True).view(torch.uint8), b.weight.t().contiguous().view(torch.uint8))
+    assert a.weight.shape == (512 // 16, 16 * 1024) and a.weight.dtype == torch.uint8 and b.weight.shape == (1024, 512)
+    assert torch.equal(ops.fp8_shuffle_weight(a.weight.data, inverse=True).view(torch.uint8), b.weight.t().contiguous().view(torch.uint8))
     ya, yb = a(x)[0], b(x)[0]
     torch.testing.assert_close(ya.float(), yb.float(), rtol=2.0 ** -6, atol=1e-3 * float(yb.float().abs().max()))
+    # the hook is idempotent: re-entered on its own result (the reference re-runs it after a reload, loader.py:456) it
+    # un-shuffles, and shuffles again -- same bytes, same output
+    before = a.weight.data.clone()
+    a.quant_method.process_weights_after_loading(a)
+    assert ops.is_wshuffled(a.weight) and torch.equal(a.weight.data, before) and torch.equal(a(x)[0], ya)
+    b.quant_method.process_weights_after_loading(b)
+    assert b.weight.shape == (1024, 512) and torch.equal(b(x)[0], yb)
     c = make(520, 1024, True)  # N % 16 != 0: stays row-major
     assert not ops.is_wshuffled(c.weight)
     d = make(512, 640, True)   # K % 512 != 0
@@ -157,7 +174,7 @@ def test_gate_up_gemm_with_silu_mul_in_the_epilogue(M, N, K):
     sa = torch.rand(M, 1, generator=g, device=DEV) * 1e-2 + 1e-3
     sb = torch.rand(N, 1, generator=g, device=DEV) * 1e-2 + 1e-3
     bias = torch.randn(N, generator=g, device=DEV).to(dt) if (N // 2) % 128 else None
-    wsh = ops.mark_wshuffled(ops.fp8_shuffle_weight(w).t())
+    wsh = ops.fp8_shuffle_weight(w)
     y = ops.fp8_scaled_mm(a, wsh, sa, sb, dt, bias)
     ref = torch.empty(M, N // 2, dtype=dt, device=DEV)
     ops.silu_and_mul(y, ref)
@@ -177,7 +194,7 @@ def test_gate_up_gemm_with_silu_mul_declines_other_shapes():
     g = torch.Generator(device=DEV).manual_seed(3)
     a, w = _rand_fp8((64, 512), g), _rand_fp8((4096, 512), g)
     sa, sb = torch.ones(64, 1, device=DEV), torch.ones(4096, 1, device=DEV)
-    wsh = ops.mark_wshuffled(ops.fp8_shuffle_weight(w).t())
+    wsh = ops.fp8_shuffle_weight(w)
     assert ops.fp8_scaled_mm_silu_mul(a, wsh, sa, sb, torch.bfloat16) is None          # decode rows
     a = _rand_fp8((512, 512), g)
     sa = torch.ones(512, 1, device=DEV)
@@ -225,7 +242,7 @@ def test_gate_up_gemm_with_silu_mul_against_the_oracle_chain(M, N, K, dt):
     sa = torch.rand(M, 1, generator=g, device=DEV) * 1e-3 + 1e-4  # full-range e4m3 operands: y of order 1, nothing overflows fp16
     sb = torch.rand(N, 1, generator=g, device=DEV) * 1e-3 + 1e-4
     bias = (torch.randn(N, generator=g, device=DEV) * 0.1).to(dt)
-    out = ops.fp8_scaled_mm_silu_mul(a, ops.mark_wshuffled(ops.fp8_shuffle_weight(w).t()), sa, sb, dt, bias)
+    out = ops.fp8_scaled_mm_silu_mul(a, ops.fp8_shuffle_weight(w), sa, sb, dt, bias)
     assert out is not None and ops.fp8_last_kernel() == "tiled3_silu"
     y = oracle.fp8_scaled_mm(a.cpu(), w.cpu().t(), sa.cpu(), sb.cpu(), dt, bias.cpu())
     ref = oracle.silu_and_mul(y).float()
@@ -243,8 +260,56 @@ def test_gate_up_gemm_with_silu_mul_against_the_oracle_chain(M, N, K, dt):
     assert bool((err <= tol).all()), f"max excess {float((err - tol).max())}"
     # ... and on the GEMM result this library itself produces, the fused launch is the oracle's silu_and_mul bit for bit but
     # for the exp (expf there, the hardware exp2 path here: an ulp of silu(g) in a few elements per million)
-    y_gpu = ops.fp8_scaled_mm(a, ops.mark_wshuffled(ops.fp8_shuffle_weight(w).t()), sa, sb, dt, bias)
+    y_gpu = ops.fp8_scaled_mm(a, ops.fp8_shuffle_weight(w), sa, sb, dt, bias)
     ref2 = oracle.silu_and_mul(y_gpu.cpu()).float()
     diff = out.float().cpu() != ref2
     assert float(diff.float().mean()) < 1e-3
     assert bool(((out.float().cpu() - ref2).abs() <= 2.0 * ulp * ref2.abs() + 1e-6).all())
+
+
+def test_shuffled_layout_is_structural_not_a_tag():
+    """whatever drops Python attributes (.data, .detach(), deepcopy, a state_dict round trip) keeps the
+    layout, because the layout IS the dtype and shape; and nothing else is taken for it."""
+    from sglang_npu_amd import quantization as Q
+    from sglang_npu_amd.linear import RowParallelLinear
+    N, K = 1024, 2048
+    lin = RowParallelLinear(K, N, bias=False, quant_config=Q.W8A8Fp8Config(is_checkpoint_fp8_serialized=False),
+                            params_dtype=torch.bfloat16).to(DEV)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    w16 = (torch.randn(N, K, device=DEV, generator=g) * 0.05).bfloat16()
+    lin.weight.data.copy_(w16)
+    lin.quant_method.process_weights_after_loading(lin)
+    assert ops.is_wshuffled(lin.weight)
+    x = torch.randn(33, K, device=DEV, generator=g).bfloat16()
+    y = lin(x)[0]
+    # the truth: the same per-channel quantised weight, row-major
+    wq, ws = Q.per_channel_quant_fp8_weight(w16)
+    xq = torch.empty_like(x, dtype=torch.float8_e4m3fn)
+    xs = torch.empty(33, 1, dtype=torch.float32, device=DEV)
+    ops.sgl_per_token_quant_fp8(x, xq, xs)
+    ref = ops.fp8_scaled_mm(xq, wq.t(), xs, ws, torch.bfloat16)
+    torch.testing.assert_close(y.float(), ref.float(), rtol=2.0 ** -6, atol=1e-3 * float(ref.float().abs().max()))
+    # every attribute-dropping copy is still the shuffled weight and multiplies the same
+    for w in (lin.weight.data, lin.weight.detach(), copy.deepcopy(lin.weight), lin.weight.data.clone()):
+        assert ops.is_wshuffled(w)
+        assert torch.equal(ops.fp8_scaled_mm(xq, w, xs, lin.weight_scale, torch.bfloat16), y)
+    twin = copy.deepcopy(lin)
+    assert ops.is_wshuffled(twin.weight) and torch.equal(twin(x)[0], y)
+    sd = {k: v.clone() for k, v in lin.state_dict().items()}
+    lin.weight.data.zero_()
+    lin.load_state_dict(sd)
+    assert ops.is_wshuffled(lin.weight) and torch.equal(lin(x)[0], y)
+    # the [N, K] / [K, N] matrix does not fit into the parameter: an in-place reload fails on the shape (loudly) ...
+    with pytest.raises(RuntimeError):
+        lin.weight.data.copy_(wq)
+    with pytest.raises(RuntimeError):
+        lin.weight.data.copy_(wq.t())
+    # ... the same bytes seen as FP8 or under another shape are refused by the GEMM, never multiplied as row-major
+    with pytest.raises(RuntimeError, match="column major|cannot be multiplied"):
+        ops.fp8_scaled_mm(xq, lin.weight.data.view(torch.float8_e4m3fn), xs, lin.weight_scale, torch.bfloat16)
+    with pytest.raises(RuntimeError, match="fragment-major"):
+        ops.fp8_scaled_mm(xq, lin.weight.data.view(N, K), xs, lin.weight_scale, torch.bfloat16)  # uint8 but [N, K], K % 8192 != 0
+    with pytest.raises(RuntimeError, match="fragment-major"):
+        ops.fp8_scaled_mm(xq, lin.weight.data.t(), xs, lin.weight_scale, torch.bfloat16)         # not contiguous
+    with pytest.raises(RuntimeError, match="cannot be multiplied"):
+        ops.fp8_scaled_mm(xq[:, :1024].contiguous(), lin.weight.data, xs, lin.weight_scale, torch.bfloat16)

@@ -322,3 +322,22 @@ def test_group_and_tensor_quant_oracle_bit_exact_vs_reference_fixture():
         assert torch.equal(s, torch.from_numpy(z[f"ts{i}"])) and torch.equal(q, torch.from_numpy(z[f"tq{i}"]))
         oracle.per_tensor_quant_fp8(x, q, torch.from_numpy(z[f"ts_static{i}"].copy()), True)
         assert torch.equal(q, torch.from_numpy(z[f"tq_static{i}"]))
+
+
+def test_vocab_parallel_embedding_oracle_vs_reference_fixture():
+    """oracle.vocab_parallel_embedding against the fixture made with the reference's own get_masked_input_and_mask and shard
+    ranges (vocab_parallel_embedding.py:126-150, 284-330): exact, every rank of every case."""
+    z = np.load("tests/golden/vocab_parallel_embedding.npz")
+    for i in range(int(z["n"])):
+        dt = torch.bfloat16 if z[f"dtype{i}"].item().decode() == "bf16" else torch.float16
+        table = torch.from_numpy(z[f"table{i}"].view(np.int16).copy()).view(dt)
+        ids = torch.from_numpy(z[f"ids{i}"]).long()
+        tp = int(z[f"tp{i}"])
+        per = table.shape[0] // tp
+        total = torch.zeros(*ids.shape, table.shape[1])
+        for r in range(tp):
+            o = oracle.vocab_parallel_embedding(ids, table[r * per:(r + 1) * per].contiguous(), int(z[f"start{i}_{r}"]),
+                                                int(z[f"end{i}_{r}"]))
+            assert torch.equal(o.view(torch.int16), torch.from_numpy(z[f"o{i}_{r}"].view(np.int16).copy()))
+            total += o.float()
+        assert torch.equal(total, table[ids].float())

@@ -6,7 +6,7 @@ from sglang_npu_amd import ops
 DEV = "cuda"
 g = torch.Generator(device=DEV).manual_seed(0)
 M, K, N, L = 64, 4096, 4096, 32
-ws = [ops.mark_wshuffled(ops.fp8_shuffle_weight(((torch.rand(N, K, device=DEV, generator=g) - 0.5) * 8).to(torch.float8_e4m3fn)).t()) for _ in range(L)]
+ws = [ops.fp8_shuffle_weight(((torch.rand(N, K, device=DEV, generator=g) - 0.5) * 8).to(torch.float8_e4m3fn)) for _ in range(L)]
 sb = torch.rand(N, 1, device=DEV, generator=g) * 1e-2 + 1e-3
 x = torch.randn(M, K, device=DEV, generator=g).bfloat16()
 amax = x.float().abs().amax(dim=1).contiguous()

@@ -11,7 +11,7 @@ dev = "cuda:0"
 g = torch.Generator(device=dev).manual_seed(0)
 K, I = 4096, 14336
 NW = 4
-ws = [ops.mark_wshuffled(ops.fp8_shuffle_weight(((torch.rand(2 * I, K, device=dev, generator=g) - 0.5) * 8).to(torch.float8_e4m3fn)).t())
+ws = [ops.fp8_shuffle_weight(((torch.rand(2 * I, K, device=dev, generator=g) - 0.5) * 8).to(torch.float8_e4m3fn))
       for _ in range(NW)]
 sb = torch.rand(2 * I, device=dev, generator=g) * 1e-2
 

@@ -14,7 +14,7 @@ which = os.environ.get("SHAPES", "down,o").split(",")
 shapes = {"down": (14336, 4096), "o": (4096, 4096)}
 for name in which:
     K, N = shapes[name]
-    ws = [ops.mark_wshuffled(ops.fp8_shuffle_weight(((torch.rand(N, K, device=dev, generator=g) - 0.5) * 8).to(torch.float8_e4m3fn)).t())
+    ws = [ops.fp8_shuffle_weight(((torch.rand(N, K, device=dev, generator=g) - 0.5) * 8).to(torch.float8_e4m3fn))
           for _ in range(L)]
     sb = torch.rand(N, 1, device=dev, generator=g) * 1e-2
     a = ((torch.rand(M, K, device=dev, generator=g) - 0.5) * 8).to(torch.float8_e4m3fn)

@@ -24,7 +24,7 @@ Ms = [int(x) for x in os.environ.get("MS", "1024,4096").split(",")]
 for (K, N) in [(4096, 6144), (4096, 4096), (4096, 28672), (14336, 4096)]:
     nw = max(2, int(600e6 // (K * N)))
     ws = [((torch.rand(N, K, device=dev, generator=g) - 0.5) * 8).to(torch.float8_e4m3fn) for _ in range(nw)]
-    wsh = [ops.mark_wshuffled(ops.fp8_shuffle_weight(w).t()) for w in ws]
+    wsh = [ops.fp8_shuffle_weight(w) for w in ws]
     sb = torch.rand(N, device=dev, generator=g) * 1e-2
     for M in Ms:
         a = ((torch.rand(M, K, device=dev, generator=g) - 0.5) * 8).to(torch.float8_e4m3fn)

@@ -20,7 +20,7 @@ for tp in [int(x) for x in os.environ.get("TP_LIST", "1,2,4,8").split(",")]:
         ws = [((torch.rand(N, K, device=dev, generator=g) - 0.5) * 8).to(torch.float8_e4m3fn) for _ in range(nw)]
         if os.environ.get("WSHUF") and ops.fp8_shuffle_supported(N, K):  # the pre-shuffled layout (what the linear method stores)
             ws = [ops.fp8_shuffle_weight(w) for w in ws]
-            tag = lambda w: ops.mark_wshuffled(w.t())
+            tag = lambda w: w
         else:
             tag = lambda w: w.t()
         wt = [tag(w) for w in ws]

@@ -15,7 +15,7 @@ r2t = (torch.randperm(n_tok - 1, device=dev, generator=g) + 1).view(B, S).to(tor
 rpi, seq = torch.arange(B, device=dev), torch.full((B,), S, device=dev)
 o = torch.zeros(B, Hq, D, dtype=torch.bfloat16, device=dev)
 K, N = 4096, 28672
-ws = [ops.mark_wshuffled(ops.fp8_shuffle_weight(((torch.rand(N, K, device=dev, generator=g) - 0.5) * 8).to(torch.float8_e4m3fn)).t())
+ws = [ops.fp8_shuffle_weight(((torch.rand(N, K, device=dev, generator=g) - 0.5) * 8).to(torch.float8_e4m3fn))
       for _ in range(NL)]
 a8 = ((torch.rand(B, K, device=dev, generator=g) - 0.5) * 8).to(torch.float8_e4m3fn)
 sa, sb = torch.rand(B, 1, device=dev, generator=g) * 1e-2, torch.rand(N, 1, device=dev, generator=g) * 1e-2

@@ -26,7 +26,7 @@ for it in range(N_CASES):
     sb = torch.rand(N, 1, generator=g, device=DEV) * 1e-2 + 1e-3
     bias = torch.randn(N, generator=g, device=DEV).to(dt) if rng.random() < 0.4 else None
     shuf = rng.random() < 0.6 and ops.fp8_shuffle_supported(N, K)
-    wt = ops.mark_wshuffled(ops.fp8_shuffle_weight(w).t()) if shuf else w.t()
+    wt = ops.fp8_shuffle_weight(w) if shuf else w.t()
     if os.environ.get("TRACE"):  # one line per case BEFORE it runs: a GPU fault kills the process, the log names the shape
         print("CASE", dict(it=it, M=M, N=N, K=K, shuf=shuf, pad=pad, dt=str(dt), bias=bias is not None), flush=True)
     try:

@@ -10,7 +10,7 @@ g = torch.Generator(device=dev).manual_seed(0)
 M = int(os.environ.get("M", 1024))
 for K, N in ((14336, 4096), (4096, 4096)):
     a = ((torch.rand(M, K, device=dev, generator=g) - 0.5) * 8).to(torch.float8_e4m3fn)
-    ws = [ops.mark_wshuffled(ops.fp8_shuffle_weight(((torch.rand(N, K, device=dev, generator=g) - 0.5) * 8).to(torch.float8_e4m3fn)).t())
+    ws = [ops.fp8_shuffle_weight(((torch.rand(N, K, device=dev, generator=g) - 0.5) * 8).to(torch.float8_e4m3fn))
           for _ in range(4)]
     sa = torch.rand(M, device=dev, generator=g) * 1e-2
     sb = torch.rand(N, device=dev, generator=g) * 1e-2

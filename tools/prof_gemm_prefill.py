@@ -9,7 +9,7 @@ dev = "cuda:0"
 g = torch.Generator(device=dev).manual_seed(0)
 M, K, N = int(os.environ.get("M", 8192)), 4096, 28672
 a = ((torch.rand(M, K, device=dev, generator=g) - 0.5) * 8).to(torch.float8_e4m3fn)
-ws = [ops.mark_wshuffled(ops.fp8_shuffle_weight(((torch.rand(N, K, device=dev, generator=g) - 0.5) * 8).to(torch.float8_e4m3fn)).t())
+ws = [ops.fp8_shuffle_weight(((torch.rand(N, K, device=dev, generator=g) - 0.5) * 8).to(torch.float8_e4m3fn))
       for _ in range(4)]
 sa = torch.rand(M, device=dev, generator=g) * 1e-2
 sb = torch.rand(N, device=dev, generator=g) * 1e-2
