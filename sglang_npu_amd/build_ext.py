@@ -39,8 +39,18 @@ def _stale(out, srcs):
     return any(os.path.getmtime(s) > t for s in srcs)
 
 
+def _file_flags(src):
+    """Per-file compiler flags: a `// hipcc-flags: ...` comment in the first lines of the source."""
+    flags = []
+    with open(src) as f:
+        for _, line in zip(range(8), f):
+            if line.startswith("// hipcc-flags:"):
+                flags += line[len("// hipcc-flags:"):].split()
+    return flags
+
+
 def _compile(src, obj, extra):
-    cmd = [HIPCC] + CXXFLAGS + extra + ["-c", src, "-o", obj]
+    cmd = [HIPCC] + CXXFLAGS + _file_flags(src) + extra + ["-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     return src, r.returncode, r.stdout + r.stderr
 

@@ -234,35 +234,79 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
   const char* kext = reinterpret_cast<const char*>(a.ke) + (q_start * a.ke_st + (int64_t)kvh * a.ke_sh) * 2;
   const char* vext = reinterpret_cast<const char*>(a.ve) + (q_start * a.ve_st + (int64_t)kvh * a.ve_sh) * 2;
 
+  // DMA addressing (round 4).  Of the ~305 vector instructions this kernel issued per 32-MFMA tile, 60 were 64-bit
+  // address arithmetic for its eight DMA pieces (SQ counters, profiles/r04_extend_pipelined_negative.txt).  Now:
+  //   * new tokens (contiguous rows): a wave-uniform 64-bit base per piece (scalar ALU) + a per-lane 32-bit offset =
+  //     row-in-piece x row stride + the swizzled 16-byte chunk, one multiply-add per piece (lds_dma16_s);
+  //   * prefix (gathered rows): pool base + slot x row stride as ONE 32 x 32 -> 64-bit multiply-add per piece.
+  // The row strides in bytes fit 32 bits (the dispatcher checks); pieces that reach past the last key of a ragged tile
+  // keep the clamped per-lane form.
+  const uint32_t ke_rowb = (uint32_t)(a.ke_st * 2), ve_rowb = (uint32_t)(a.ve_st * 2);
+  const uint32_t kb_rowb = (uint32_t)(a.kb_sn * 2), vb_rowb = (uint32_t)(a.vb_sn * 2);
+  // byte offset of this lane's swizzled chunk in K piece i of the wave (kept in registers, except in the FP8-pool kernels,
+  // which have none to spare and recompute it); V's is the same for every piece: swz_v looks at row & 3 (D = 128) /
+  // (row >> 1) & 1 (D = 64), i.e. at the row in the piece
+  uint32_t ksw_reg[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) ksw_reg[i] = swz_k<D>(dma_pos, (wave * PPW + i) * ROWS_PER_DMA + dma_row) * 16;
+  auto ksw_of = [&](int i) __attribute__((always_inline)) -> uint32_t { return ksw_reg[i]; };
+  const uint32_t vsw = swz_v<D>(dma_pos, dma_row) * 16;
   // issue this wave's share (PPW K pieces + PPW V pieces) of tile `t` of the given phase into `stage`
   auto issue = [&](int phase, int t, int stage, int idx_off, int n_keys) __attribute__((always_inline)) {
-    const uint32_t kdst = __builtin_amdgcn_readfirstlane(lds_addr_of(smem + stage * STAGE_BYTES));
+    const uint32_t kdst = __builtin_amdgcn_readfirstlane(lds_addr_of(smem + stage * STAGE_BYTES)) + wave * (PPW * 1024);
     const uint32_t vdst = kdst + TILE_BYTES;
-    int64_t koff[PPW], voff[PPW];
-    const char *kb_ = phase == 0 ? kpool : kext, *vb_ = phase == 0 ? vpool : vext;
+    const int row0 = t * kBN + wave * (PPW * ROWS_PER_DMA);  // first key of this wave's first piece
+    if constexpr (KV8) {
+      // (the FP8-pool kernels have no registers to spare for the forms below: the first version's arithmetic, extend stage only)
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-      const int row = (wave * PPW + i) * ROWS_PER_DMA + dma_row;
-      int kidx = t * kBN + row;
-      kidx = kidx < n_keys ? kidx : n_keys - 1;  // tail rows re-read a valid key; masked in the softmax
-      if (phase == 0) {
-        const int64_t slot = idx_lds[kidx - idx_off];
-        koff[i] = slot * a.kb_sn * 2;
-        voff[i] = slot * a.vb_sn * 2;
-      } else {
-        koff[i] = (int64_t)kidx * a.ke_st * 2;
-        voff[i] = (int64_t)kidx * a.ve_st * 2;
+      for (int i = 0; i < PPW; ++i) {
+        const int row = (wave * PPW + i) * ROWS_PER_DMA + dma_row;
+        int kidx = t * kBN + row;
+        kidx = kidx < n_keys ? kidx : n_keys - 1;
+        lds_dma16(kext + (int64_t)kidx * a.ke_st * 2 + swz_k<D>(dma_pos, row) * 16, kdst + i * 1024);
       }
-    }
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-      const int row = (wave * PPW + i) * ROWS_PER_DMA + dma_row;
-      lds_dma16(kb_ + koff[i] + swz_k<D>(dma_pos, row) * 16, kdst + (wave * PPW + i) * 1024);
-    }
+      for (int i = 0; i < PPW; ++i) {
+        const int row = (wave * PPW + i) * ROWS_PER_DMA + dma_row;
+        int kidx = t * kBN + row;
+        kidx = kidx < n_keys ? kidx : n_keys - 1;
+        lds_dma16(vext + (int64_t)kidx * a.ve_st * 2 + swz_v<D>(dma_pos, row) * 16, vdst + i * 1024);
+      }
+    } else if (phase == 0) {
+      const char* ka[PPW];
+      const char* va[PPW];
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-      const int row = (wave * PPW + i) * ROWS_PER_DMA + dma_row;
-      lds_dma16(vb_ + voff[i] + swz_v<D>(dma_pos, row) * 16, vdst + (wave * PPW + i) * 1024);
+      for (int i = 0; i < PPW; ++i) {
+        int kidx = row0 + i * ROWS_PER_DMA + dma_row;
+        kidx = kidx < n_keys ? kidx : n_keys - 1;  // tail rows re-read a valid key; masked in the softmax
+        const uint32_t slot = (uint32_t)idx_lds[kidx - idx_off];
+        ka[i] = kpool + ((uint64_t)slot * kb_rowb + ksw_of(i));
+        va[i] = vpool + ((uint64_t)slot * vb_rowb + vsw);
+      }
+#pragma unroll
+      for (int i = 0; i < PPW; ++i) lds_dma16(ka[i], kdst + i * 1024);
+#pragma unroll
+      for (int i = 0; i < PPW; ++i) lds_dma16(va[i], vdst + i * 1024);
+    } else if (row0 + PPW * ROWS_PER_DMA <= n_keys) {  // (wave-uniform) every row of the wave's pieces is a real key
+#pragma unroll
+      for (int i = 0; i < PPW; ++i)
+        lds_dma16_s(kext + (uint64_t)(uint32_t)(row0 + i * ROWS_PER_DMA) * ke_rowb, dma_row * ke_rowb + ksw_of(i), kdst + i * 1024);
+#pragma unroll
+      for (int i = 0; i < PPW; ++i)
+        lds_dma16_s(vext + (uint64_t)(uint32_t)(row0 + i * ROWS_PER_DMA) * ve_rowb, dma_row * ve_rowb + vsw, vdst + i * 1024);
+    } else {  // the ragged last tile
+#pragma unroll
+      for (int i = 0; i < PPW; ++i) {
+        int kidx = row0 + i * ROWS_PER_DMA + dma_row;
+        kidx = kidx < n_keys ? kidx : n_keys - 1;
+        lds_dma16(kext + ((uint64_t)(uint32_t)kidx * ke_rowb + ksw_of(i)), kdst + i * 1024);
+      }
+#pragma unroll
+      for (int i = 0; i < PPW; ++i) {
+        int kidx = row0 + i * ROWS_PER_DMA + dma_row;
+        kidx = kidx < n_keys ? kidx : n_keys - 1;
+        lds_dma16(vext + ((uint64_t)(uint32_t)kidx * ve_rowb + vsw), vdst + i * 1024);
+      }
     }
   };
 
@@ -669,7 +713,11 @@ int dispatch(ExtendArgs a, int64_t batch, int D, int Dv, int max_len_extend, hip
       return SGL_MI355_ERR_UNSUPPORTED;
     }
   }
-  if (D == Dv && aligned && (D == 128 || D == 64)) {
+  // (row strides below 2^26 elements: the MFMA kernel's DMA offsets are 32-bit byte counts)
+  const int64_t max_row = int64_t(1) << 26;
+  const bool rows32 = a.ke_st > 0 && a.ve_st > 0 && a.kb_sn > 0 && a.vb_sn > 0 && a.ke_st < max_row && a.ve_st < max_row &&
+                      a.kb_sn < max_row && a.vb_sn < max_row;
+  if (D == Dv && aligned && rows32 && (D == 128 || D == 64)) {
     const int gh = (a.group % 4 == 0) ? 4 : (a.group % 2 == 0 ? 2 : 1);
     const bool masked = a.mask != nullptr || a.window > 0;
     if constexpr (std::is_same<IdxT, int32_t>::value) {

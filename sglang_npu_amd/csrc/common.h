@@ -98,6 +98,27 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, uint32_t lds_addr) {
       : "memory");
 }
 
+// The same piece addressed as a wave-uniform 64-bit base (SGPR pair, scalar ALU) + a per-lane 32-bit byte offset: no 64-bit
+// vector arithmetic per piece (round 4; the extend kernel's contiguous new-token rows).
+__device__ __forceinline__ void lds_dma16_s(const void* sbase, uint32_t voff, uint32_t lds_addr) {
+  lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
+  const uint64_t b = (uint64_t)(uintptr_t)sbase;
+  // (the builtin returns int: through uint32_t, or the low half is SIGN-extended over the high one)
+  const uint32_t blo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b);
+  const uint32_t bhi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+  const uint64_t bs = ((uint64_t)bhi << 32) | (uint64_t)blo;
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(bs), "s"(lds_addr)
+      : "memory");
+}
+
 // The same piece with the non-temporal cache policy: for bytes that ONE CU reads once (the KV stream of a decode
 // step): they should not displace what other kernels of the step keep in L2 / Infinity Cache.
 __device__ __forceinline__ void lds_dma16_nt(const void* gsrc, uint32_t lds_addr) {
