@@ -470,8 +470,62 @@ __global__ __launch_bounds__(256) void rope_kv_neox_kernel(
   }
 }
 
+// The same with 16-byte accesses (round 4; 16-bit pools): D/16 lanes per (token, head), each rotating eight adjacent pairs
+// (x[8 l .. +8], x[D/2 + 8 l .. +8]) and copying sixteen value elements -- a wave covers 8 (D = 128) or 16 (D = 64) heads
+// with a quarter of the memory instructions; at 1024 prefill tokens the 4-byte form took 8.9 us for 27 MB.  Same
+// arithmetic and roundings element by element.
+template <int DTYPE, typename LocT, int D>
+__global__ __launch_bounds__(256) void rope_kv_neox16_kernel(
+    typename Half16<DTYPE>::T* __restrict__ q, typename Half16<DTYPE>::T* __restrict__ k,
+    const typename Half16<DTYPE>::T* __restrict__ v, char* __restrict__ kb, char* __restrict__ vb,
+    const int64_t* __restrict__ positions, const LocT* __restrict__ loc, const float* __restrict__ cache, int64_t T,
+    int Hq, int Hk, int64_t q_st, int64_t k_st, int64_t v_st, int64_t kb_sn, int64_t kb_sh, int64_t vb_sn,
+    int64_t vb_sh) {
+  using Hh = Half16<DTYPE>;
+  using T16 = typename Hh::T;
+  using x8 = typename Hh::x8;
+  constexpr int LPH = D / 16, HPW = 64 / LPH, half = D / 2;
+  const int lane = threadIdx.x & 63, sub = lane / LPH, l = lane % LPH;
+  const int64_t item = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * HPW + sub;
+  if (item >= T * (int64_t)(Hq + Hk)) return;
+  const int h = (int)(item % (Hq + Hk));
+  const int64_t t = item / (Hq + Hk);
+  const bool is_k = h >= Hq;
+  T16* base = is_k ? k + t * k_st + (int64_t)(h - Hq) * D : q + t * q_st + (int64_t)h * D;
+  const float* cs = cache + positions[t] * D;
+  const f32x4 c0 = *reinterpret_cast<const f32x4*>(cs + 8 * l), c1 = *reinterpret_cast<const f32x4*>(cs + 8 * l + 4);
+  const f32x4 s0 = *reinterpret_cast<const f32x4*>(cs + half + 8 * l), s1 = *reinterpret_cast<const f32x4*>(cs + half + 8 * l + 4);
+  const x8 x1 = *reinterpret_cast<const x8*>(base + 8 * l), x2 = *reinterpret_cast<const x8*>(base + half + 8 * l);
+  x8 o1, o2;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float r1, r2;
+    rope_pair(Hh::to_f32(x1[j]), Hh::to_f32(x2[j]), j < 4 ? c0[j & 3] : c1[j & 3], j < 4 ? s0[j & 3] : s1[j & 3], r1, r2);
+    o1[j] = Hh::from_f32(r1);
+    o2[j] = Hh::from_f32(r2);
+  }
+  *reinterpret_cast<x8*>(base + 8 * l) = o1;
+  *reinterpret_cast<x8*>(base + half + 8 * l) = o2;
+  if (is_k && kb) {
+    char* kdst = kb + ((int64_t)loc[t] * kb_sn + (int64_t)(h - Hq) * kb_sh) * 2;
+    char* vdst = vb + ((int64_t)loc[t] * vb_sn + (int64_t)(h - Hq) * vb_sh) * 2;
+    const T16* vs = v + t * v_st + (int64_t)(h - Hq) * D;
+    const x8 v0 = *reinterpret_cast<const x8*>(vs + 16 * l), v1 = *reinterpret_cast<const x8*>(vs + 16 * l + 8);
+    *reinterpret_cast<x8*>(kdst + 2 * (8 * l)) = o1;
+    *reinterpret_cast<x8*>(kdst + 2 * (half + 8 * l)) = o2;
+    *reinterpret_cast<x8*>(vdst + 2 * (16 * l)) = v0;
+    *reinterpret_cast<x8*>(vdst + 2 * (16 * l + 8)) = v1;
+  }
+}
+
 // few long rows (decode batches, H >= 4096, at most 2048 vectors of 8): 512 / 1024 threads per row
-inline bool rms_wide(int64_t T, int nv) { return T <= 2048 && nv >= 512 && nv <= 2048; }
+// Up to 512 rows (round 4; was 2048): at 1024 prefill rows of 4096 the 256-thread form (two chunks per thread, half the
+// waves per barrier) takes 9.2 us against 10.3 (tools/bench_prefill_elementwise.py); the from-partials form exists up to 128
+// rows only, so both still follow the same rule.  SGL_MI355_RMS_WIDE_MAX_T overrides (A/B aid).
+inline bool rms_wide(int64_t T, int nv) {
+  static const int64_t max_t = [] { const char* e = getenv("SGL_MI355_RMS_WIDE_MAX_T"); return e ? atoll(e) : 512ll; }();
+  return T <= max_t && nv >= 512 && nv <= 2048;
+}
 
 // Any row length (the reference's own tests use 111 and 500, sgl-kernel/tests/test_norm.py:53): scalar accesses, two
 // passes over the row (sum of squares; then normalise -- recomputing x + residual from the inputs so that the norm is
@@ -738,6 +792,37 @@ static int rope_set_kv_impl(int kv8,
                     reinterpret_cast<uintptr_t>(query) % 4 == 0 && reinterpret_cast<uintptr_t>(key) % 4 == 0 &&
                     reinterpret_cast<uintptr_t>(value) % 4 == 0 && reinterpret_cast<uintptr_t>(k_buffer) % 4 == 0 &&
                     reinterpret_cast<uintptr_t>(v_buffer) % 4 == 0 && reinterpret_cast<uintptr_t>(cos_sin_cache) % 8 == 0;
+  // ... and its 16-byte form: 16-bit pool, every row 16-byte aligned (SGL_MI355_ROPE16=0: the 4-byte form, A/B aid)
+  static const bool rope16_on = [] { const char* e = getenv("SGL_MI355_ROPE16"); return !e || atoi(e) != 0; }();
+  const bool fast16 = fast && rope16_on && !kv8 && q_stride_t % 8 == 0 && k_stride_t % 8 == 0 && v_stride_t % 8 == 0 &&
+                      kb_stride_n % 8 == 0 && kb_stride_h % 8 == 0 && vb_stride_n % 8 == 0 && vb_stride_h % 8 == 0 &&
+                      reinterpret_cast<uintptr_t>(query) % 16 == 0 && reinterpret_cast<uintptr_t>(key) % 16 == 0 &&
+                      reinterpret_cast<uintptr_t>(value) % 16 == 0 && reinterpret_cast<uintptr_t>(k_buffer) % 16 == 0 &&
+                      reinterpret_cast<uintptr_t>(v_buffer) % 16 == 0 && reinterpret_cast<uintptr_t>(cos_sin_cache) % 16 == 0;
+  if (fast16) {
+    const int hpw = head_size == 128 ? 8 : 16;
+    const unsigned grid16 = (unsigned)((items + 4 * hpw - 1) / (4 * hpw));
+#define ROPE16(DT, TT, LT, DD)                                                                                          \
+  hipLaunchKernelGGL((rope_kv_neox16_kernel<DT, LT, DD>), dim3(grid16), dim3(256), 0, s, (TT*)query, (TT*)key,           \
+                     (const TT*)value, (char*)k_buffer, (char*)v_buffer, positions, (const LT*)loc, cos_sin_cache,       \
+                     num_tokens, (int)num_q_heads, (int)num_k_heads, q_stride_t, k_stride_t, v_stride_t, kb_stride_n,    \
+                     kb_stride_h, vb_stride_n, vb_stride_h)
+#define ROPE16_D(DT, TT, LT)                          \
+  do {                                                \
+    if (head_size == 128) ROPE16(DT, TT, LT, 128);    \
+    else ROPE16(DT, TT, LT, 64);                      \
+  } while (0)
+    if (dtype == SGL_MI355_BF16) {
+      if (loc_is64) ROPE16_D(SGL_MI355_BF16, __bf16, int64_t);
+      else ROPE16_D(SGL_MI355_BF16, __bf16, int32_t);
+    } else {
+      if (loc_is64) ROPE16_D(SGL_MI355_FP16, _Float16, int64_t);
+      else ROPE16_D(SGL_MI355_FP16, _Float16, int32_t);
+    }
+#undef ROPE16_D
+#undef ROPE16
+    return check_hip(hipGetLastError(), "rotary_embedding_set_kv (16-byte) launch");
+  }
   if (fast) {
     const int hpw = head_size == 128 ? 2 : 4;
     const unsigned gridf = (unsigned)((items + 4 * hpw - 1) / (4 * hpw));

@@ -8,7 +8,10 @@ from sglang_npu_amd import ops
 dev = "cuda:0"
 g = torch.Generator(device=dev).manual_seed(0)
 B, S = 64, 2048
-for name, Hq, Hkv, D, splits in [("70b/tp8", 8, 1, 128, 4), ("8b/tp8", 4, 1, 128, 4), ("8b/tp4", 8, 2, 128, 2), ("8b bs=16", 32, 8, 128, 2)]:
+CASES = [("70b/tp8", 8, 1, 128, 4), ("8b/tp8", 4, 1, 128, 4), ("8b/tp4", 8, 2, 128, 2), ("8b bs=16", 32, 8, 128, 2)]
+if os.environ.get("SPLITS"):  # A/B aid: the 70B TP=8 rank geometry at other split counts (with SGL_MI355_DECODE_WAVES=2|4)
+    CASES = [("70b/tp8", 8, 1, 128, int(x)) for x in os.environ["SPLITS"].split(",")]
+for name, Hq, Hkv, D, splits in CASES:
     Bn = 16 if "bs=16" in name else B
     n_tok = Bn * S + 1
     NL = 8
