@@ -396,6 +396,12 @@ int sgl_mi355_awq_gemm(const void* x, const int32_t* qweight, const void* scales
                        const void* bias, void* out, float* workspace, int64_t workspace_floats,
                        int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, void* stream);
 
+/* 1 when the library was built with -DSGLM_OPTIN_FUSIONS=1, i.e. carries the kernels of the opt-in fusions that measured
+ * no faster than the separate launches (sgl_mi355_decode_attention_qkv_partials, _decode_attention_absmax +
+ * _fp8_scaled_mm_partials_a16, _decode_attention_quant); 0 in the default build, where those entry points return
+ * SGL_MI355_ERR_UNSUPPORTED without launching and the callers make the separate calls. */
+int sgl_mi355_has_optin_fusions(void);
+
 /* Test aid: the kernel family the last sgl_mi355_fp8_scaled_mm* call of the calling thread launched ("skinny", "oneshot",
  * "astat", "astat_direct", "wstream", "wstream_slab", "tiled", "tiled2", "tiled3"; "" before the first call). */
 const char* sgl_mi355_fp8_last_kernel(void);

@@ -1587,6 +1587,7 @@ int launch_mfma(const DecodeArgs& a, int64_t batch, hipStream_t stream) {
     // vs 25.6 / 57.5 / 103.0 / 375 one item per workgroup; 2048 items (MHA, 32 kv heads): 363 vs 375 us with the 2-wave
     // workgroups.  SGL_MI355_DECODE_PAIR=0|1 overrides (tuning aid).
     const bool pair = pair_eligible(a, grid);
+#if SGLM_OPTIN_FUSIONS
     if (pair && !a.kv8 && tl_fq != nullptr) {  // + the qkv GEMM epilogue, RoPE and the KV write in the prologue
       auto kern = decode_mfma_pair_kernel<DTYPE, D, IdxT, false, true>;
       constexpr int lds = mfma_lds_bytes<D, 4, 0>();
@@ -1613,6 +1614,7 @@ int launch_mfma(const DecodeArgs& a, int64_t batch, hipStream_t stream) {
       tl_pair_quant_used = true;
       return check_hip(hipGetLastError(), "decode_mfma_pair_kernel (fp8 out) launch");
     }
+#endif  // SGLM_OPTIN_FUSIONS
     if (pair && !a.kv8) {
       auto kern = decode_mfma_pair_kernel<DTYPE, D, IdxT>;
       constexpr int lds = mfma_lds_bytes<D, 4, 0>();
@@ -1868,6 +1870,10 @@ extern "C" int sgl_mi355_decode_attention_absmax(
     int64_t max_context_len, int64_t num_heads, int64_t num_kv_heads, int64_t head_size, int64_t q_stride_b,
     int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h, int64_t o_stride_b,
     int64_t o_stride_h, float sm_scale, float logit_cap, int dtype, void* stream) {
+#if !SGLM_OPTIN_FUSIONS
+  set_error("%s: an opt-in fusion, not in this build of the library (build with -DSGLM_OPTIN_FUSIONS=1)", "decode_attention_absmax");
+  return SGL_MI355_ERR_UNSUPPORTED;
+#else
   SGLM_CHECK_ARG(row_absmax != nullptr && output != nullptr, "decode_attention_absmax: null output / row_absmax");
   SGLM_CHECK_ARG(num_heads > 0 && num_kv_heads > 0 && num_heads % num_kv_heads == 0, "decode_attention_absmax: bad head counts");
   DecodeArgs probe{};
@@ -1889,6 +1895,7 @@ extern "C" int sgl_mi355_decode_attention_absmax(
                                             o_stride_h, sm_scale, logit_cap, dtype, stream);
   tl_row_absmax = nullptr;
   return rc;
+#endif
 }
 
 // sgl_mi355_decode_attention (page-table form, no KV write, one split, 16-bit pool) that ALSO leaves the per-token FP8
@@ -1905,6 +1912,10 @@ extern "C" int sgl_mi355_decode_attention_quant(
     int64_t num_seqs, int64_t max_context_len, int64_t num_heads, int64_t num_kv_heads, int64_t head_size,
     int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h,
     int64_t o_stride_b, int64_t o_stride_h, float sm_scale, float logit_cap, int dtype, void* stream) {
+#if !SGLM_OPTIN_FUSIONS
+  set_error("%s: an opt-in fusion, not in this build of the library (build with -DSGLM_OPTIN_FUSIONS=1)", "decode_attention_quant");
+  return SGL_MI355_ERR_UNSUPPORTED;
+#else
   SGLM_CHECK_ARG(output != nullptr && out_q != nullptr && out_s != nullptr && merge_counters != nullptr,
                  "decode_attention_quant: null output / out_q / out_s / merge_counters");
   SGLM_CHECK_ARG(num_heads > 0 && num_kv_heads > 0 && num_heads % num_kv_heads == 0, "decode_attention_quant: bad head counts");
@@ -1934,6 +1945,7 @@ extern "C" int sgl_mi355_decode_attention_quant(
     return SGL_MI355_ERR_RUNTIME;
   }
   return rc;
+#endif
 }
 
 // Decode attention straight off the qkv GEMM's split-K partial sums: one launch does the GEMM epilogue, RoPE on q/k,
@@ -1950,6 +1962,10 @@ extern "C" int sgl_mi355_decode_attention_qkv_partials(
     int64_t num_heads, int64_t num_kv_heads, int64_t head_size, int64_t k_stride_n, int64_t k_stride_h,
     int64_t v_stride_n, int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h, float sm_scale, float logit_cap,
     int dtype, void* stream) {
+#if !SGLM_OPTIN_FUSIONS
+  set_error("%s: an opt-in fusion, not in this build of the library (build with -DSGLM_OPTIN_FUSIONS=1)", "decode_attention_qkv_partials");
+  return SGL_MI355_ERR_UNSUPPORTED;
+#else
   int rc = check_common(num_seqs, num_heads, num_kv_heads, head_size, head_size, 1, dtype);
   if (rc) return rc;
   if (num_seqs == 0) return 0;
@@ -1986,6 +2002,7 @@ extern "C" int sgl_mi355_decode_attention_qkv_partials(
     return SGL_MI355_ERR_RUNTIME;
   }
   return rc;
+#endif
 }
 
 extern "C" int sgl_mi355_decode_attention_fwd_fp8kv(
@@ -2038,6 +2055,8 @@ extern "C" int sgl_mi355_decode_attention_fwd_fp8kv_e5m2(
   tl_kv8 = 0;
   return rc;
 }
+
+extern "C" int sgl_mi355_has_optin_fusions(void) { return SGLM_OPTIN_FUSIONS; }
 
 extern "C" int sgl_mi355_decode_merge_quant_fp8(const float* attn_logits, int64_t num_seqs, int64_t num_heads,
                                                 int64_t head_size_v, int64_t num_kv_splits, void* output,

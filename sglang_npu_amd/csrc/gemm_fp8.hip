@@ -2473,6 +2473,10 @@ extern "C" int sgl_mi355_fp8_scaled_mm_partials_a16(const void* mat_a16, int64_t
                                                     int64_t b_stride_n, float* workspace, int64_t workspace_floats,
                                                     int64_t M, int64_t N, int64_t K, int a_dtype, int32_t* num_slices,
                                                     void* stream) {
+#if !SGLM_OPTIN_FUSIONS
+  set_error("%s: an opt-in fusion, not in this build of the library (build with -DSGLM_OPTIN_FUSIONS=1)", "fp8_scaled_mm_partials_a16");
+  return SGL_MI355_ERR_UNSUPPORTED;
+#else
   SGLM_CHECK_ARG(num_slices != nullptr && workspace != nullptr, "fp8_scaled_mm_partials_a16: null workspace / num_slices");
   SGLM_CHECK_ARG(a_dtype == SGL_MI355_BF16 || a_dtype == SGL_MI355_FP16, "fp8_scaled_mm_partials_a16: activations must be bf16 / fp16");
   SGLM_CHECK_ARG(M > 0 && N > 0 && K > 0 && N < (1ll << 31) && K < (1ll << 31) && K % 16 == 0, "fp8_scaled_mm_partials_a16: bad shape");
@@ -2509,6 +2513,7 @@ extern "C" int sgl_mi355_fp8_scaled_mm_partials_a16(const void* mat_a16, int64_t
   }
   *num_slices = sk;
   return 0;
+#endif
 }
 
 extern "C" int sgl_mi355_fp8_scaled_mm_finalize(const float* partials, int64_t num_slices, const float* scales_a,

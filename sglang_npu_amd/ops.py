@@ -630,6 +630,11 @@ def fp8_shuffle_supported(N: int, K: int) -> bool:
     return N > 0 and K > 0 and N % 16 == 0 and K % 512 == 0
 
 
+def has_optin_fusions() -> bool:
+    """True when the loaded library carries the opt-in fusion kernels (-DSGLM_OPTIN_FUSIONS=1 variant builds)."""
+    return bool(_lib.lib().sgl_mi355_has_optin_fusions())
+
+
 def fp8_last_kernel() -> str:
     """Kernel family launched by this thread's last fp8_scaled_mm / fp8_scaled_mm_partials call (test aid)."""
     f = _lib.lib().sgl_mi355_fp8_last_kernel

@@ -14,9 +14,22 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "optin_fusions: needs a library built with -DSGLM_OPTIN_FUSIONS=1 (variant build); "
+                                       "skipped on the default library, whose entry points for them return UNSUPPORTED")
 
 
 def pytest_collection_modifyitems(config, items):
+    if any("optin_fusions" in item.keywords for item in items):
+        try:
+            from sglang_npu_amd import ops
+            have = ops.has_optin_fusions()
+        except Exception:  # noqa: BLE001  (no library here: the gpu marker below decides)
+            have = False
+        if not have:
+            skip_f = pytest.mark.skip(reason="opt-in fusion kernels are not in this build (-DSGLM_OPTIN_FUSIONS=1)")
+            for item in items:
+                if "optin_fusions" in item.keywords:
+                    item.add_marker(skip_f)
     # `-m gpu` tests must never silently pass without a GPU.
     if torch.cuda.is_available():
         return

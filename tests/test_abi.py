@@ -56,15 +56,18 @@ def test_round3_entry_points_check_their_arguments_before_any_launch():
     from sglang_npu_amd import _lib
     lib = _lib.lib()
     z, f, vp = ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+    fake = vp(0x10000)  # aligned, never dereferenced: the shape is refused first
     rc = lib.sgl_mi355_decode_attention_quant(
         None, None, None, None, None, None, None, None, 0, None, None, z(64), z(4096), z(32), z(8), z(128), z(4096), z(128),
         z(1024), z(128), z(1024), z(128), z(4096), z(128), f(0.1), f(0.0), 0, None)
-    assert rc == 1 and "null" in _lib.last_error()
-    fake = vp(0x10000)  # aligned, never dereferenced: the shape is refused first
-    rc = lib.sgl_mi355_decode_attention_quant(
-        fake, fake, fake, fake, fake, fake, fake, fake, 0, fake, fake, z(8), z(4096), z(32), z(8), z(128), z(4096), z(128),
-        z(1024), z(128), z(1024), z(128), z(4096), z(128), f(0.1), f(0.0), 0, None)
-    assert rc == 2 and "pairs-of-items" in _lib.last_error()  # 8 requests x 8 kv heads = 64 items: not more than 256
+    if lib.sgl_mi355_has_optin_fusions():
+        assert rc == 1 and "null" in _lib.last_error()
+        rc = lib.sgl_mi355_decode_attention_quant(
+            fake, fake, fake, fake, fake, fake, fake, fake, 0, fake, fake, z(8), z(4096), z(32), z(8), z(128), z(4096), z(128),
+            z(1024), z(128), z(1024), z(128), z(4096), z(128), f(0.1), f(0.0), 0, None)
+        assert rc == 2 and "pairs-of-items" in _lib.last_error()  # 8 requests x 8 kv heads = 64 items: not more than 256
+    else:  # the default build: the opt-in fusions' entry points decline everything, without touching their arguments
+        assert rc == 2 and "opt-in fusion" in _lib.last_error()
     rc = lib.sgl_mi355_fp8_scaled_mm_silu_mul_wshuffled(fake, fake, fake, fake, None, fake, z(1024), z(28672 + 16), z(4096), z(4096),
                                                         0, None)
     assert rc == 1 and "N % 32" in _lib.last_error()

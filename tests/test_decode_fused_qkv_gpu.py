@@ -10,7 +10,8 @@ import torch
 
 from conftest import tol_for
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.optin_fusions]  # (skipped unless the loaded library was built with
+# -DSGLM_OPTIN_FUSIONS=1: tests/conftest.py; the default library returns UNSUPPORTED from these entry points)
 DEV = "cuda"
 
 
