@@ -217,3 +217,84 @@ def install_attention_backend(model_runner, backend_cls=None):
         from .attention_backend import MI355AttnBackend as backend_cls
     model_runner.attn_backend = backend_cls(model_runner)
     return model_runner.attn_backend
+
+
+class PrefillGraphRunner:
+    """Short single-request prefills replayed from HIP graphs captured at bucketed token counts (round 4, VERDICT r3 ask 7).
+
+    An eager prefill of 64 ... 256 tokens is host-bound: ~20 op calls per layer at 6-9 us of Python + ctypes each against
+    a few us of GPU work (profiles/r03_prefill_sweep.txt: 5.7-6.0 ms whatever the length).  The reference captures decode
+    batches only (cuda_graph_runner.py:238-300), so this runner is a HARNESS-side aid -- the counterpart, for an SGLang
+    deployment, would be a bucketed-prefill capture hook next to its CudaGraphRunner -- built on what the backend already
+    guarantees for captured decode steps: the caller's stream, no allocation or host sync inside an op, scratch from
+    per-stream pools.
+
+    One request, empty prefix.  A prompt of n tokens runs the graph of the smallest bucket >= n: ids are padded with token 0,
+    the padded rows' K/V go to the pool's padding slot 0, the attention kernel reads n from the device-side qo_indptr (rows
+    >= n are not attended), and the last REAL position is selected on the device, so the result for n == bucket is
+    bit-identical to the eager pass and for n < bucket equal up to the GEMMs' row-count-dependent tiling."""
+
+    def __init__(self, net, runner, backend, device, buckets=(64, 128, 256, 512)):
+        self.net, self.runner, self.backend, self.device = net, runner, backend, torch.device(device)
+        self.buckets = tuple(sorted(buckets))
+        self._graphs = {}
+
+    def _capture(self, bucket: int):
+        from .layers import greedy_sample
+        dev = self.device
+        st = {
+            "ids": torch.zeros(bucket, dtype=torch.int64, device=dev),
+            "pos": torch.arange(bucket, device=dev),
+            "loc": torch.zeros(bucket, dtype=torch.int64, device=dev),
+            "rpi": torch.zeros(1, dtype=torch.int64, device=dev),
+            "seq": torch.full((1,), bucket, dtype=torch.int64, device=dev),
+            "ext": torch.full((1,), bucket, dtype=torch.int64, device=dev),
+            "zero": torch.zeros(1, dtype=torch.int64, device=dev),
+            "tok": torch.zeros(1, dtype=torch.int64, device=dev),
+        }
+        fb = ForwardBatch(ForwardMode.EXTEND, 1, st["ids"], st["rpi"], st["seq"], st["loc"], bucket, st["seq"].cpu(), st["pos"],
+                          extend_num_tokens=bucket, extend_seq_lens=st["ext"], extend_prefix_lens=st["zero"],
+                          extend_start_loc=st["zero"].clone(), extend_prefix_lens_cpu=[0], extend_seq_lens_cpu=[bucket],
+                          req_to_token_pool=self.runner.req_to_token_pool, token_to_kv_pool=self.runner.token_to_kv_pool,
+                          attn_backend=self.backend)
+        self.backend.init_forward_metadata(fb)       # grid extents from the bucket; qo_indptr / kv_indptr are static buffers
+        md = self.backend.forward_metadata           # kept: the graph holds its tensors' addresses
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):                        # warm-up on the capture stream (per-stream scratch reaches its size)
+                logits = self.net(st["ids"], st["pos"], fb)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            logits = self.net(st["ids"], st["pos"], fb)
+            st["tok"].copy_(greedy_sample(logits[-1:]))
+        st.update(graph=g, fb=fb, md=md, logits=logits)
+        self._graphs[bucket] = st
+        return st
+
+    def bucket_for(self, n: int) -> Optional[int]:
+        for b in self.buckets:
+            if n <= b:
+                return b
+        return None
+
+    def run(self, ids: torch.Tensor, slots: torch.Tensor):
+        """ids [n] token ids, slots [n] KV-pool rows of the request's tokens (req_to_token[r, :n]).  Returns (logits [1, V] of
+        the last real position, sampled token [1]) -- views of static buffers, valid until the next run of the same bucket."""
+        n = ids.numel()
+        b = self.bucket_for(n)
+        if b is None:
+            raise ValueError(f"prompt of {n} tokens exceeds the largest captured bucket ({self.buckets[-1]})")
+        st = self._graphs.get(b) or self._capture(b)
+        st["ids"].zero_()
+        st["ids"][:n].copy_(ids)
+        st["loc"].zero_()                                # padded rows write their K/V into the padding slot
+        st["loc"][:n].copy_(slots)
+        st["ext"].fill_(n)
+        st["seq"].fill_(n)
+        self.backend.forward_metadata = st["md"]
+        st["md"].qo_indptr[1:2].fill_(n)                # the attention kernel's row count (device side)
+        st["graph"].replay()
+        return st["logits"], st["tok"]

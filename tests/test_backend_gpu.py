@@ -389,3 +389,64 @@ def test_from_partials_ops_equal_unfused_sequence(M, with_bias):
     part = ops.fp8_scaled_mm_partials(a, w.t(), sa, sb, torch.bfloat16, bias)
     q4 = ops.rope_set_kv_from_partials(part, pos, Hq, Hk, D, cache, kb8.view(torch.float8_e4m3fn), vb8.view(torch.float8_e4m3fn), loc, True)
     assert torch.equal(q4, q1) and torch.equal(kb8, kb8_ref) and torch.equal(vb8, vb8_ref)
+
+
+def test_prefill_graph_runner_matches_the_eager_prefill():
+    """harness.PrefillGraphRunner (round 4): a short single-request prefill replayed from a HIP graph captured at a bucketed
+    token count.  n == bucket: logits and the KV-pool rows bit-identical to the eager pass; n < bucket (padded with token 0,
+    padded rows' K/V into slot 0, the attention reading n from the device-side qo_indptr): the same greedy token, logits within
+    the 16-bit tolerance (the GEMMs tile 128 rows differently from n rows), the request's pool rows bit-identical, nothing
+    written outside them but the padding slot; a second prompt through the same graph."""
+    from sglang_npu_amd import model as M
+    from sglang_npu_amd.harness import (ForwardBatch, ForwardMode, MHATokenToKVPool, ModelConfig, ModelRunnerLike,
+                                        PrefillGraphRunner, ReqToTokenPool, ServerArgs, install_attention_backend)
+    cfg = ModelConfig(8, 2, 128, 1024, 2048, 2, 512, 1024)
+    net = M.LlamaForCausalLM(cfg, "w8a8_fp8", torch.bfloat16, DEV).load_dummy_weights()
+    n_tok = 601
+    r2t_pool = ReqToTokenPool(2, 300, DEV)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    r2t_pool.req_to_token.copy_((torch.randperm(n_tok - 1, device=DEV, generator=g) + 1)[:600].view(2, 300).to(torch.int32))
+
+    def fresh_pool():
+        return MHATokenToKVPool(n_tok, 1, torch.bfloat16, 2, 128, 2, DEV)
+
+    def eager(ids, pool):
+        n = ids.numel()
+        runner = ModelRunnerLike(cfg, r2t_pool, pool, DEV, 0, 1, ServerArgs())
+        backend = install_attention_backend(runner)
+        seq = torch.full((1,), n, dtype=torch.int64, device=DEV)
+        zero = torch.zeros(1, dtype=torch.int64, device=DEV)
+        fb = ForwardBatch(ForwardMode.EXTEND, 1, ids, zero.clone(), seq, r2t_pool.req_to_token[0, :n].to(torch.int64), n,
+                          seq.cpu(), torch.arange(n, device=DEV), extend_num_tokens=n, extend_seq_lens=seq.clone(),
+                          extend_prefix_lens=zero, extend_start_loc=zero.clone(), extend_prefix_lens_cpu=[0],
+                          extend_seq_lens_cpu=[n], req_to_token_pool=r2t_pool, token_to_kv_pool=pool, attn_backend=backend)
+        backend.init_forward_metadata(fb)
+        return net(ids, torch.arange(n, device=DEV), fb).clone()
+
+    pool_g = fresh_pool()
+    runner = ModelRunnerLike(cfg, r2t_pool, pool_g, DEV, 0, 1, ServerArgs())
+    backend = install_attention_backend(runner)
+    pg = PrefillGraphRunner(net, runner, backend, DEV, buckets=(128, 256))
+    for n in (128, 77, 128, 200):
+        ids = torch.randint(0, 512, (n,), device=DEV, generator=g)
+        pool_e = fresh_pool()
+        ref = eager(ids, pool_e)
+        for b in pool_g.k_buffer + pool_g.v_buffer:
+            b.zero_()
+        slots = r2t_pool.req_to_token[0, :n].to(torch.int64)
+        logits, tok = pg.run(ids, slots)
+        torch.cuda.synchronize()
+        assert int(tok) == int(ref.float().argmax())
+        if n in pg.buckets:
+            assert torch.equal(logits, ref)
+        else:
+            torch.testing.assert_close(logits.float(), ref.float(), rtol=2.0 ** -6, atol=1e-3 * float(ref.float().abs().max()) + 1e-3)
+        for l in range(2):
+            ke, kg = pool_e.get_key_buffer(l), pool_g.get_key_buffer(l)
+            ve, vg = pool_e.get_value_buffer(l), pool_g.get_value_buffer(l)
+            if l == 0 or n in pg.buckets:  # (layer 1's K/V come from layer 0's output: equal only where the GEMMs tile alike)
+                assert torch.equal(kg[slots], ke[slots]) and torch.equal(vg[slots], ve[slots])
+            untouched = torch.ones(kg.shape[0], dtype=torch.bool, device=DEV)
+            untouched[slots] = False
+            untouched[0] = False
+            assert not bool(kg[untouched].any()) and not bool(vg[untouched].any())
