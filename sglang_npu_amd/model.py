@@ -89,6 +89,8 @@ def _unreduced(h) -> bool:
 
 # fewest decode rows for which GEMM epilogues are deferred into the consumer kernels (tuning: SGL_MI355_DEFER_MIN_ROWS)
 DEFER_MIN_ROWS = int(os.environ.get("SGL_MI355_DEFER_MIN_ROWS", "32"))
+# short prefills (extend passes of at most this many new tokens) defer the o_proj / down_proj epilogues too (0: never)
+DEFER_EXTEND_MAX_ROWS = int(os.environ.get("SGL_MI355_DEFER_EXTEND_MAX_ROWS", "128"))
 # widest per-rank gate_up (2 * intermediate / tp) that goes through split-K partials + fused SiLU (tuning: SGL_MI355_GATE_UP_PARTIALS_MAX_N)
 GATE_UP_PARTIALS_MAX_N = int(os.environ.get("SGL_MI355_GATE_UP_PARTIALS_MAX_N", "4096"))
 
@@ -175,7 +177,8 @@ class LlamaAttention(torch.nn.Module):
         norm; the returned hidden state may then be a GemmPartials."""
         pool = forward_batch.token_to_kv_pool
         kb, vb = pool.get_key_buffer(self.attn.layer_id), pool.get_value_buffer(self.attn.layer_id)
-        part = self.qkv_proj.forward_prequantized_partials(xq, xs, out_dtype) if defer else None
+        part = (self.qkv_proj.forward_prequantized_partials(xq, xs, out_dtype)
+                if defer and forward_batch.forward_mode.is_decode() else None)
         attn_output = None
         if part is not None and FUSE_QKV_ATTN and forward_batch.forward_mode.is_decode():
             # ... and all of that inside the decode attention kernel's prologue, when the batch has the shape for it
@@ -396,8 +399,13 @@ class LlamaForCausalLM(torch.nn.Module):
         # ... and only for more than 32 rows: the split-K kernels the partials come from are the best GEMM there, while
         # smaller batches have faster single-pass kernels (whole step, ms: bs=1 3.59 vs 4.88 deferred, bs=16 4.24 vs 4.62,
         # bs=32 5.24 vs 5.23, bs=48 6.58 vs 6.44, bs=64 7.17 vs 7.06)
-        defer = (fused and self.defer_epilogues and forward_batch.forward_mode.is_decode()
-                 and input_ids.shape[0] > DEFER_MIN_ROWS)
+        # ... and (round 4) for SHORT prefills too: up to 128 new tokens the GEMMs are the same split-K weight streamers,
+        # and o_proj / down_proj leave their epilogues to the next norm (two finalize launches of ~5 us less per layer; the
+        # qkv GEMM keeps its own epilogue there: the extend kernel reads the new tokens' K / V as tensors, not from the pool)
+        rows_in = input_ids.shape[0]
+        defer = (fused and self.defer_epilogues and rows_in > DEFER_MIN_ROWS
+                 and (forward_batch.forward_mode.is_decode()
+                      or (forward_batch.forward_mode.is_extend() and rows_in <= DEFER_EXTEND_MAX_ROWS)))
         if defer and FUSE_ATTN_QUANT:  # one zeroed row-absmax vector per layer (the attention kernels max into it)
             rows = input_ids.shape[0]
             if self._attn_absmax is None or self._attn_absmax.shape[1] < rows:  # sized by the batch (never under capture: the

@@ -450,3 +450,42 @@ def test_prefill_graph_runner_matches_the_eager_prefill():
             untouched[slots] = False
             untouched[0] = False
             assert not bool(kg[untouched].any()) and not bool(vg[untouched].any())
+
+
+@pytest.mark.parametrize("n", [33, 100, 128])
+def test_short_prefill_with_deferred_epilogues_is_bit_identical(n, monkeypatch):
+    """Round 4: an extend pass of 33 ... 128 new tokens leaves the o_proj / down_proj GEMM epilogues to the next norm
+    (`*_from_partials` consumers, as the decode step does): the same logits and pool rows, bit for bit, as with the
+    finalize launches (SGL_MI355_DEFER_EXTEND_MAX_ROWS=0)."""
+    from sglang_npu_amd import model as M, ops
+    from sglang_npu_amd.harness import (ForwardBatch, ForwardMode, MHATokenToKVPool, ModelConfig, ModelRunnerLike,
+                                        ReqToTokenPool, ServerArgs, install_attention_backend)
+    cfg = ModelConfig(8, 2, 128, 1024, 2048, 2, 512, 1024)
+    net = M.LlamaForCausalLM(cfg, "w8a8_fp8", torch.bfloat16, DEV).load_dummy_weights()
+    g = torch.Generator(device=DEV).manual_seed(n)
+    r2t_pool = ReqToTokenPool(1, 300, DEV)
+    r2t_pool.req_to_token.copy_((torch.randperm(400, device=DEV, generator=g) + 1)[:300].view(1, 300).to(torch.int32))
+    ids = torch.randint(0, 512, (n,), device=DEV, generator=g)
+    outs = []
+    calls = []
+    real = ops.rmsnorm_quant_fp8_from_partials
+    monkeypatch.setattr(ops, "rmsnorm_quant_fp8_from_partials", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    for max_rows in (0, 128):
+        monkeypatch.setattr(M, "DEFER_EXTEND_MAX_ROWS", max_rows)
+        pool = MHATokenToKVPool(401, 1, torch.bfloat16, 2, 128, 2, DEV)
+        runner = ModelRunnerLike(cfg, r2t_pool, pool, DEV, 0, 1, ServerArgs())
+        backend = install_attention_backend(runner)
+        seq = torch.full((1,), n, dtype=torch.int64, device=DEV)
+        zero = torch.zeros(1, dtype=torch.int64, device=DEV)
+        fb = ForwardBatch(ForwardMode.EXTEND, 1, ids, zero.clone(), seq, r2t_pool.req_to_token[0, :n].to(torch.int64), n,
+                          seq.cpu(), torch.arange(n, device=DEV), extend_num_tokens=n, extend_seq_lens=seq.clone(),
+                          extend_prefix_lens=zero, extend_start_loc=zero.clone(), extend_prefix_lens_cpu=[0],
+                          extend_seq_lens_cpu=[n], req_to_token_pool=r2t_pool, token_to_kv_pool=pool, attn_backend=backend)
+        backend.init_forward_metadata(fb)
+        before = len(calls)
+        logits = net(ids, torch.arange(n, device=DEV), fb).clone()
+        outs.append((logits, [b.clone() for b in pool.k_buffer + pool.v_buffer], len(calls) - before))
+    assert outs[0][2] == 0 and outs[1][2] > 0  # the second pass really went through the from-partials norms
+    assert torch.equal(outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(a, b)
