@@ -50,7 +50,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PROFILED_STATS_GLOB = "r[0-9][0-9]_bench_tp1_kernel_stats.csv"  # rocprofv3 --kernel-trace --stats of `bench.py`, one per round
-PMC_SUMMARY = "r03_decode_pmc_instep.json"  # in-step counters of the profiled bench command, refreshed per round
+PMC_SUMMARY = "r04_decode_pmc_instep.json"  # in-step counters of the profiled bench command, refreshed per round
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 
 
