@@ -689,32 +689,49 @@ def allreduce_latency_vs_size(tp_group, device, world):
         dist.all_reduce(ref, group=tp_group.device_group)
         row = {"bytes": nbytes, "bound_us": round(2 * (world - 1) / world * nbytes / link_bw * 1e6, 3)}
         for name, fn in planes:
+            # every rank issues the same group collectives whatever fails locally: a local exception in the
+            # timing loop becomes a status, the ranks agree on it (MIN) BEFORE the MAX all-reduce of the medians
+            err, med, exact, takes = None, 0.0, None, True
             try:
                 x = src.clone()
                 out = fn(x)
-                if out is None:  # this plane does not take the size (staging area / thresholds)
-                    continue
-                torch.cuda.synchronize(device)
-                exact = bool(torch.equal(out, ref)) if name != "quickreduce" else None
-                ts = []
-                for it in range(23):
-                    x.copy_(src)
-                    dist.barrier(group=tp_group.device_group) if it == 0 else None
-                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    a.record()
-                    fn(x)
-                    b.record()
-                    b.synchronize()
-                    if it >= 3:
-                        ts.append(a.elapsed_time(b) * 1e3)
-                ts.sort()
-                t = torch.tensor([ts[len(ts) // 2]], device=device, dtype=torch.float64)
+                if out is None:  # this plane does not take the size (staging area / thresholds): a shape-only decision,
+                    takes = False  # identical on all ranks
+                else:
+                    torch.cuda.synchronize(device)
+                    exact = bool(torch.equal(out, ref)) if name != "quickreduce" else None
+            except Exception as e:  # noqa: BLE001
+                err = f"{type(e).__name__}: {str(e)[:120]}"
+            if not takes:
+                continue
+            ok = torch.tensor([0 if err else 1], device=device, dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=tp_group.device_group)
+            if int(ok.item()) == 1:
+                try:
+                    ts = []
+                    for it in range(23):
+                        x.copy_(src)
+                        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        a.record()
+                        fn(x)
+                        b.record()
+                        b.synchronize()
+                        if it >= 3:
+                            ts.append(a.elapsed_time(b) * 1e3)
+                    ts.sort()
+                    med = ts[len(ts) // 2]
+                except Exception as e:  # noqa: BLE001  (RCCL raises on every rank or none; the P2P kernels fail closed)
+                    err = f"{type(e).__name__}: {str(e)[:120]}"
+                t = torch.tensor([med if err is None else -1.0], device=device, dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX, group=tp_group.device_group)
-                row[name + "_us"] = round(float(t.item()), 2)
-                if exact is not None:
-                    row[name + "_exact"] = exact
-            except Exception as e:  # a diagnostic: report and go on (every rank takes the same path: shapes only)
-                row[name + "_error"] = f"{type(e).__name__}: {str(e)[:120]}"
+                bad = torch.tensor([1 if err else 0], device=device, dtype=torch.int32)
+                dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=tp_group.device_group)
+                if int(bad.item()) == 0:
+                    row[name + "_us"] = round(float(t.item()), 2)
+                    if exact is not None:
+                        row[name + "_exact"] = exact
+                    continue
+            row[name + "_error"] = err or "failed on another rank"
         rows.append(row)
     return {"dtype": "bf16", "world": world, "link_model": "7 xGMI links x 153 GB/s per GPU", "method": "3 warm-ups + median of 20 "
             "event-timed calls per (size, data plane), max over ranks", "planes": [p[0] for p in planes], "points": rows}

@@ -470,16 +470,37 @@ def init_distributed_environment(backend: Optional[str] = None, device: Optional
     return _TP
 
 
-def _bring_up_custom_ar(tp: "GroupCoordinator", make_comm, verify: bool = True, steps_of=None) -> bool:
+def _preflight_library() -> None:
+    """Everything CustomAllreduce's constructor does BEFORE its first group collective and that can fail on one rank only."""
+    from . import _lib
+    lib = _lib.lib()
+    for sym in ("sgl_mi355_ar_create", "sgl_mi355_ar_get_ipc_handle", "sgl_mi355_ar_open_peers", "sgl_mi355_ar_all_reduce"):
+        getattr(lib, sym)
+
+
+def _bring_up_custom_ar(tp: "GroupCoordinator", make_comm, verify: bool = True, steps_of=None, preflight=None) -> bool:
     """Build the P2P communicator (`make_comm()`), verify it against the process group and install it on `tp` only if
     EVERY rank agrees; otherwise close it everywhere and leave RCCL as the data plane.  All ranks issue the same group
     collectives in the same order whatever fails locally (a rank that bailed out early used to pair its
     `flag` all-reduce with a peer's bf16 all-reduce and hang the job at init)."""
     ca, err = None, None
+    # Pre-flight (ADVICE r3): what can fail on ONE rank before the constructor's first collective -- the kernel library not
+    # loading, an ABI mismatch -- is found out and agreed on FIRST.  A rank that raised there used to go straight to the
+    # agreement below while its peers sat in the constructor's object all-gather: a hang at init.
+    pre_err = None
+    try:
+        (preflight or _preflight_library)()
+    except Exception as e:  # noqa: BLE001
+        pre_err = f"{type(e).__name__}: {e}"
+    if not _agree(tp, pre_err is None):
+        if tp.rank_in_group == 0:
+            print(f"[sglang_npu_amd] P2P all-reduce not used ({pre_err or 'the kernel library did not load on some rank'}); "
+                  f"using RCCL", flush=True)
+        return False
     try:
         ca = make_comm()  # lockstep inside (_exchange_ipc_handles)
         err = ca.init_error
-    except Exception as e:  # library missing, ctypes signature mismatch: before any collective of the constructor
+    except Exception as e:  # (after the pre-flight only a failure BEHIND the constructor's collectives can land here)
         err = f"{type(e).__name__}: {e}"
     ok = _agree(tp, ca is not None and not ca.disabled)
     if ok and verify:
@@ -511,12 +532,27 @@ def _verification_steps(ca: "CustomAllreduce", qr: "QuickAllReduce", tp: "GroupC
     grp = tp.device_group
     steps = []
 
+    # Every step issues its group collectives UNCONDITIONALLY and with fixed shapes -- operands that could not be built
+    # locally are replaced by zeros of the declared shape, the P2P call sits in a try of its own -- so that a local
+    # exception can never pair this rank's next agreement with a peer's reference all-reduce.
+    def reference_sum(shape, dtype, make):
+        x, failed = None, False
+        try:
+            x = make()
+        except Exception:  # noqa: BLE001
+            failed = True
+        ref = x.clone() if x is not None else torch.zeros(shape, device=dev, dtype=dtype)
+        dist.all_reduce(ref, group=grp)
+        return x, ref, failed
+
     def plain(n):
         def fn():
-            g = torch.Generator(device=dev).manual_seed(100 + rank)
-            x = torch.randint(-3, 4, (n,), device=dev, generator=g).to(torch.bfloat16)
-            ref = x.clone()
-            dist.all_reduce(ref, group=grp)
+            def make():
+                g = torch.Generator(device=dev).manual_seed(100 + rank)
+                return torch.randint(-3, 4, (n,), device=dev, generator=g).to(torch.bfloat16)
+            x, ref, failed = reference_sum((n,), torch.bfloat16, make)
+            if failed:
+                return False
             good = True
             for _ in range(2):  # both halves of the double buffer
                 out = ca.custom_all_reduce(x)
@@ -530,13 +566,18 @@ def _verification_steps(ca: "CustomAllreduce", qr: "QuickAllReduce", tp: "GroupC
     T, H = 64, 1024 * world
 
     def operands():
-        g = torch.Generator(device=dev).manual_seed(7)
-        part = torch.randint(-2, 3, (T, H), device=dev, generator=g).to(torch.bfloat16) * (rank + 1)
-        res = torch.randint(-2, 3, (T, H), device=dev, generator=g).to(torch.bfloat16)
-        w = torch.ones(H, device=dev, dtype=torch.bfloat16)
-        red = part.clone()
-        dist.all_reduce(red, group=grp)
-        return part, res, w, red
+        built = {}
+
+        def make():
+            g = torch.Generator(device=dev).manual_seed(7)
+            built["part"] = torch.randint(-2, 3, (T, H), device=dev, generator=g).to(torch.bfloat16) * (rank + 1)
+            built["res"] = torch.randint(-2, 3, (T, H), device=dev, generator=g).to(torch.bfloat16)
+            built["w"] = torch.ones(H, device=dev, dtype=torch.bfloat16)
+            return built["part"]
+        part, red, failed = reference_sum((T, H), torch.bfloat16, make)  # (the collective is issued either way)
+        if failed:
+            raise RuntimeError("verification operands could not be built on this rank")
+        return part, built["res"], built["w"], red
 
     def fused_norm():
         part, res, w, red = operands()
@@ -566,15 +607,26 @@ def _verification_steps(ca: "CustomAllreduce", qr: "QuickAllReduce", tp: "GroupC
     if not qr.disabled:
         def quick():
             n = 32 * 4096
-            g = torch.Generator(device=dev).manual_seed(1000 + rank)
-            x = torch.randint(1, 24, (n,), device=dev, generator=g).to(torch.bfloat16)
-            exact = x.float()
-            dist.all_reduce(exact, group=grp)
-            out = qr.quick_all_reduce(x)
-            torch.cuda.synchronize(dev)
+
+            def make():
+                g = torch.Generator(device=dev).manual_seed(1000 + rank)
+                return torch.randint(1, 24, (n,), device=dev, generator=g).to(torch.bfloat16).float()
+            xf, exact, failed = reference_sum((n,), torch.float32, make)
+            out = None
+            if not failed:
+                try:
+                    out = qr.quick_all_reduce(xf.to(torch.bfloat16))
+                    torch.cuda.synchronize(dev)
+                except Exception:  # noqa: BLE001 -- the two collectives below are still issued
+                    out = None
+            local_ok = out is not None
+            if out is None:
+                out = torch.zeros(n, device=dev, dtype=torch.bfloat16)
             lo, hi = out.float(), out.float()
             dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=grp)  # (issued by every rank whatever `out` holds)
             dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=grp)
+            if not local_ok:
+                return False
             same = torch.equal(lo, hi)  # every rank decoded the same bytes
             close = bool(((out.float() - exact).abs() <= 1.25 * world + 0.5 * world * exact.abs()).all())
             exact_fp = qr.qr_quant_level != QuickReduceRegime.FP or torch.equal(out.float(), exact)

@@ -295,6 +295,7 @@ class LlamaForCausalLM(torch.nn.Module):
         self.fuse_quant = fuse_quant and quantization == "w8a8_fp8"
         self.defer_epilogues = not os.environ.get("SGL_MI355_NO_DEFER")  # GEMM epilogues inside the consumer kernels
         self._attn_absmax = None  # [layers, 64] float32, see FUSE_ATTN_QUANT
+        self._attn_absmax_retired = []  # earlier, smaller buffers that captured graphs may still address
         self.quant_config = None
         if quantization == "w8a8_fp8":
             self.quant_config = W8A8Fp8Config(is_checkpoint_fp8_serialized=False)
@@ -408,8 +409,15 @@ class LlamaForCausalLM(torch.nn.Module):
                       or (forward_batch.forward_mode.is_extend() and rows_in <= DEFER_EXTEND_MAX_ROWS)))
         if defer and FUSE_ATTN_QUANT:  # one zeroed row-absmax vector per layer (the attention kernels max into it)
             rows = input_ids.shape[0]
-            if self._attn_absmax is None or self._attn_absmax.shape[1] < rows:  # sized by the batch (never under capture: the
-                # first, eager, pass of a batch size allocates it)
+            if self._attn_absmax is None or self._attn_absmax.shape[1] < rows:
+                # sized by the batch.  A graph captured for a smaller batch holds the OLD buffer's address (its zero_() and
+                # the attention kernels' atomic max): replaced buffers are kept alive, never freed, and the
+                # buffer never grows under capture (the first, eager, pass of a batch size allocates it)
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("the attention row-absmax buffer cannot grow while a graph is being captured: run "
+                                       "one eager step at this batch size first")
+                if self._attn_absmax is not None:
+                    self._attn_absmax_retired.append(self._attn_absmax)
                 self._attn_absmax = torch.zeros((len(self.layers), max(64, rows)), dtype=torch.float32,
                                                 device=hidden_states.device)
             self._attn_absmax.zero_()

@@ -166,6 +166,25 @@ def _bringup_worker(rank, world, port, q):
         n = len(made)
         assert D._bring_up_custom_ar(tp, make(fail_rank=0, raises=True), steps_of=steps_ok) is False and tp.ca_comm is None
         assert len(made) == n + (1 if rank != 0 else 0) and (rank == 0 or made[-1].closed)
+        # --- the library fails to load on ONE rank.  The constructor stands in for the real one: it starts with
+        # an object all-gather (as _exchange_ipc_handles does); a rank that skipped it would leave its peer there for
+        # ever -- the pre-flight agreement makes EVERY rank skip the constructor instead
+        constructed = []
+        def make_collective():
+            constructed.append(rank)
+            got = [None] * world
+            dist.all_gather_object(got, rank, group=grp)
+            return FakeComm()
+        def preflight(fail_rank):
+            def f():
+                if rank == fail_rank:
+                    raise OSError("libsgl_mi355.so: cannot open shared object file")
+            return f
+        assert D._bring_up_custom_ar(tp, make_collective, steps_of=steps_ok, preflight=preflight(1)) is False
+        assert constructed == [] and tp.ca_comm is None
+        assert D._bring_up_custom_ar(tp, make_collective, steps_of=steps_ok, preflight=preflight(None)) is True
+        assert constructed == [rank]
+        tp.ca_comm = tp.qr_comm = None
         # the group is still usable afterwards (no collective left unpaired)
         t = torch.full((4,), float(rank + 1))
         dist.all_reduce(t, group=grp)
