@@ -598,12 +598,17 @@ int sgl_mi355_gemm16_nt(const void* x, const void* weight, const void* bias, voi
  * sgl_mi355_fp8_shuffle_weight(src, dst, N, 2 * K bytes, row stride in bytes, ...) -- the layout is defined on 128-byte
  * k-steps, i.e. 64 16-bit values here -- so that a decode wave's load instruction covers one contiguous KiB (what
  * process_weights_after_loading of an untied ParallelLMHead may do once, logits_processor.py:430-505 reads it every
- * step).  N % 16 == 0, K % 256 == 0.  Results are bit-identical to sgl_mi355_gemm16_nt on the row-major weight. */
+ * step).  N % 16 == 0, K % 256 == 0.  Up to 128 rows the results are bit-identical to sgl_mi355_gemm16_nt on the row-major
+ * weight.  M > 128 (round 4; prefill of an unquantised model, layers/quantization/unquant.py:111-123 F.linear): the tiled
+ * kernel of csrc/gemm_bf16.hip (A through LDS by LDS-DMA, weight fragments global -> registers, 128 x 256 or 128 x 128
+ * tiles), same arithmetic contract: fp32 accumulation, + bias in fp32, one rounding. */
 int sgl_mi355_gemm16_nt_wshuffled(const void* x, const void* weight_shuffled, const void* bias, void* out, int64_t M,
                                   int64_t N, int64_t K, int64_t x_stride_m, int dtype, void* stream);
 /* The same with an fp32 workspace (>= 16 * M * N floats covers every shape): narrow N is cut along K over the workgroups
  * (split-K slabs + a finalize launch that sums the slices in order, adds the bias and rounds once) -- the unquantised
- * o_proj / down_proj / qkv of a bf16 model at decode sizes (layers/quantization/unquant.py: F.linear). */
+ * o_proj / down_proj / qkv of a bf16 model at decode sizes (layers/quantization/unquant.py: F.linear).  M > 128: the tiled
+ * kernel cuts K into up to 640 / (tiles of 128 x 128) slices of at least 16 k-steps where its tiles would cover half the chip
+ * or less for 64 k-steps or more (workspace: slices * M * N floats; too small a workspace runs the unsplit kernel). */
 int sgl_mi355_gemm16_nt_wshuffled_splitk(const void* x, const void* weight_shuffled, const void* bias, void* out,
                                          float* workspace, int64_t workspace_floats, int64_t M, int64_t N, int64_t K,
                                          int64_t x_stride_m, int dtype, void* stream);

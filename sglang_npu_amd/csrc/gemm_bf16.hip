@@ -419,6 +419,255 @@ int launch16(const G16Args& p, hipStream_t s) {
 #undef G16_GO
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Tiled form for MORE than 128 rows (round 4): prefill of an unquantised model, LM head over many rows -- until now
+// `F.linear` -> the vendor library (layers/quantization/unquant.py:111-123).  Fragment-major weights only (the copy the decode
+// streamer reads: a wave's load instruction is one contiguous KiB).  The structure is gemm_fp8.hip's fp8_gemm_tiled3_kernel with
+// 16-bit operands -- the byte geometry is the same (a k-step is 128 B of a row = 64 values, two v_mfma_f32_16x16x32 per
+// fragment pair on 16-B chunks g and 4 + g of both operands):
+//   * A goes global -> LDS by LDS-DMA, three stages, [row][128 B] image with the 16-B chunk index XOR-swizzled by
+//     (row >> 1) & 7 on the source side; fragments by ds_read_b128;
+//   * B never touches LDS: each wave streams the weight fragments of its own 64 columns global -> VGPR, every fragment
+//     refilled one k-step ahead right behind its last MFMA, hand-counted vmcnt (loads retire in order);
+//   * block tile (16 RI WM) x (64 WN): 128 x 256 with four waves and TWO workgroups per CU, 256 x 256 with eight waves, or
+//     128 x 128 (RI 4, 2 x 2 waves) where the wider tiles would leave CUs without one;
+//   * fp32 accumulation, + bias in fp32, one rounding; stores in 16-B row segments through a wave-private LDS patch;
+//   * SLAB: K is cut over blockIdx.y into slices of p.pps k-steps, each workgroup writes the fp32 partial of its slice and
+//     gemm16_finalize_kernel sums the slices in order, adds the bias and rounds once -- for the shapes whose tiles would
+//     otherwise cover a fraction of the chip for a long K loop (o_proj / down_proj at a few hundred rows).
+template <int DTYPE, int RI, int WM, int WN, bool SLAB = false>
+__global__ __launch_bounds__(64 * WM * WN, 2) void gemm16_tiled_kernel(G16Args p, int raster_gn) {
+  using H = Half16<DTYPE>;
+  using T = typename H::T;
+  using x8 = typename H::x8;
+  constexpr int NSTAGE = 3;
+  constexpr int CB = 4;                 // 16-column blocks per wave
+  constexpr int NW = WM * WN;
+  constexpr int TMB = 16 * RI * WM;     // block rows
+  constexpr int TNB = 16 * CB * WN;     // block columns
+  constexpr int STAGE = TMB * 128;      // A tile: TMB rows x 128 B
+  constexpr int UA = TMB / 8 / NW;      // 1-KiB DMA units (8 rows x 128 B) per wave and stage
+  static_assert((TMB / 8) % NW == 0, "DMA units must divide over the waves");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int r16 = lane & 15, g = lane >> 4;
+
+  const int tiles_m = (p.M + TMB - 1) / TMB, tiles_n = (p.N + TNB - 1) / TNB;
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {  // consecutive workgroup ids of one XCD (ids congruent mod 8) take consecutive tiles
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  int tm, tn;
+  {  // groups of raster_gn column tiles, row tile fastest across the group's columns: an XCD's resident tiles share both operands
+    const int gsz = raster_gn * tiles_m;
+    const int grp = bid / gsz, r = bid - grp * gsz;
+    const int left = tiles_n - grp * raster_gn;
+    const int gn = left < raster_gn ? left : raster_gn;
+    tm = r / gn;
+    tn = grp * raster_gn + (r - tm * gn);
+  }
+  const int m0 = tm * TMB, n0 = tn * TNB;
+
+  const uint8_t* a_src[UA];
+#pragma unroll
+  for (int u = 0; u < UA; ++u) {
+    const int row = (UA * wave + u) * 8 + (lane >> 3);  // tile-local row
+    const int j = (lane & 7) ^ ((row >> 1) & 7);
+    int m = m0 + row;
+    m = m < p.M ? m : p.M - 1;  // rows past the edge re-read a valid row; never stored
+    a_src[u] = p.a + (int64_t)m * p.a_sm + 16 * j;
+  }
+  const uint32_t smem_base = lds_addr_of(smem);
+  auto dma_stage = [&](int stage, int kt) __attribute__((always_inline)) {
+    const uint32_t dst = smem_base + stage * STAGE;
+#pragma unroll
+    for (int u = 0; u < UA; ++u) lds_dma16(a_src[u] + (int64_t)kt * 128, dst + (UA * wave + u) * 1024);
+  };
+  // weight fragments: column block (n0 / 16 + 4 wn + j), k-step kt = 2 KiB at block * 16 KB + 2048 kt; lane i takes bytes
+  // 16 i.. of each KiB.  Blocks past N re-read the last one (their columns are never stored).
+  const uint8_t* b_blk[CB];
+#pragma unroll
+  for (int j = 0; j < CB; ++j) {
+    int nb = (n0 >> 4) + wn * CB + j;
+    nb = nb < (p.N >> 4) ? nb : (p.N >> 4) - 1;
+    b_blk[j] = p.b + (int64_t)nb * 16 * p.KB;
+  }
+  const int kt0 = SLAB ? (int)blockIdx.y * p.pps : 0;
+  const int nk = SLAB ? ((p.KB >> 7) < kt0 + p.pps ? (p.KB >> 7) : kt0 + p.pps) : (p.KB >> 7);  // this workgroup: k-steps [kt0, nk)
+
+  f32x4 acc[RI][CB];
+#pragma unroll
+  for (int i = 0; i < RI; ++i)
+#pragma unroll
+    for (int j = 0; j < CB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // A fragment offsets inside the stage: row (16 (RI wm + i) + r16), chunks g and 4 + g, swizzled as the DMA wrote them
+  const int sw = (r16 >> 1) & 7;
+  const uint32_t a_row = (wm * 16 * RI + r16) * 128;
+  const uint32_t c0 = 16 * (g ^ sw), c1 = 16 * ((4 + g) ^ sw);
+
+  // VMEM issue order per step: the A DMAs of step kt + 2 (UA per wave), then refills R_0..R_3 (two loads each), each behind
+  // its column block's MFMAs.  In
+  // front of column block j "R_j of the previous step has landed" is vmcnt(6) for j = 0 (R_1..R_3 of the previous step are
+  // younger) and vmcnt(6 + UA) after it; the wait at the last column also proves this wave's DMAs of step kt + 1, which is
+  // what the next barrier publishes.  Tail steps re-issue the last step's DMAs into the dead stage and re-read the last
+  // weights, so the counts never change.
+  Seg32 bq[CB];
+  constexpr int YB = 2 * (CB - 1);
+#pragma unroll
+  for (int st = 0; st < NSTAGE - 1; ++st) dma_stage(st, kt0 + st < nk ? kt0 + st : nk - 1);
+  {
+    const uint32_t voff = (uint32_t)lane * 16 + (uint32_t)kt0 * 2048;
+#pragma unroll
+    for (int j = 0; j < CB; ++j) wload<true>(bq[j], b_blk[j], voff);
+  }
+  wait_vmcnt<(NSTAGE - 2) * UA + 2 * CB>();  // stage 0 landed (this wave's part)
+#pragma clang loop unroll(disable)
+  for (int kt = kt0; kt < nk; ++kt) {
+    __syncthreads();  // everyone's DMAs of stage kt landed; everyone finished reading the stage refilled below
+    const char* sa_ = smem + ((kt - kt0) % NSTAGE) * STAGE + a_row;
+    Seg32 af[RI];
+#pragma unroll
+    for (int i = 0; i < RI; ++i) {
+      af[i].v[0] = *reinterpret_cast<const uint4*>(sa_ + i * 2048 + c0);
+      af[i].v[1] = *reinterpret_cast<const uint4*>(sa_ + i * 2048 + c1);
+    }
+    const uint32_t voff = (uint32_t)lane * 16 + (uint32_t)(kt + 1 < nk ? kt + 1 : nk - 1) * 2048;
+#pragma unroll
+    for (int j = 0; j < CB; ++j) {
+      if (j == 0) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(bq[j].x[0]), "+v"(bq[j].x[1]) : "n"(YB) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(bq[j].x[0]), "+v"(bq[j].x[1]) : "n"(YB + UA) : "memory");
+      const x8 b0 = __builtin_bit_cast(x8, bq[j].v[0]), b1 = __builtin_bit_cast(x8, bq[j].v[1]);
+#pragma unroll
+      for (int i = 0; i < RI; ++i) acc[i][j] = H::mfma16(__builtin_bit_cast(x8, af[i].v[0]), b0, acc[i][j]);
+#pragma unroll
+      for (int i = 0; i < RI; ++i) acc[i][j] = H::mfma16(__builtin_bit_cast(x8, af[i].v[1]), b1, acc[i][j]);
+      if (j == 0) {
+        const int kn = kt + NSTAGE - 1;
+        dma_stage((kn - kt0) % NSTAGE, kn < nk ? kn : nk - 1);
+      }
+      wload<true>(bq[j], b_blk[j], voff);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the never-consumed tail refills and DMAs
+#pragma unroll
+  for (int j = 0; j < CB; ++j) asm volatile("" ::"v"(bq[j].x[0]), "v"(bq[j].x[1]));
+  __syncthreads();  // all stages dead: the epilogue reuses the memory
+
+  if constexpr (SLAB) {
+    // fp32 partial of this K slice: 16 rows at a time through a wave-private [16][64] (+4 pad) patch, 16-B segments
+    float* fp = reinterpret_cast<float*>(smem) + wave * (16 * 68);
+    float* dst = p.slabs + (int64_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < RI; ++i) {
+#pragma unroll
+      for (int j = 0; j < CB; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) fp[(4 * g + r) * 68 + 16 * j + r16] = acc[i][j][r];
+      wait_lgkmcnt0();
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int c = lane + 64 * it;  // 256 segments of four floats
+        const int ml = c >> 4, nl = (c & 15) * 4;
+        const int m = m0 + wm * 16 * RI + 16 * i + ml, n = n0 + wn * 16 * CB + nl;
+        if (m < p.M && n < p.N)  // N % 16 == 0: a segment is all-in or all-out
+          *reinterpret_cast<f32x4*>(dst + (int64_t)m * p.N + n) = *reinterpret_cast<const f32x4*>(fp + ml * 68 + nl);
+      }
+      wait_lgkmcnt0();
+    }
+    return;
+  }
+  // epilogue: passes of 64 rows through a wave-private [64][64] (+8 pad) patch that turns the MFMA layout into 16-B segments
+  T* ep = reinterpret_cast<T*>(smem) + wave * (64 * 72);
+  constexpr int RP = RI < 4 ? RI : 4;
+#pragma unroll
+  for (int pass = 0; pass < RI / RP; ++pass) {
+    const int mw0 = m0 + wm * 16 * RI + 16 * RP * pass;
+#pragma unroll
+    for (int j = 0; j < CB; ++j) {
+      const int n = n0 + wn * 16 * CB + 16 * j + r16;
+      const float bv = p.bias ? H::to_f32(reinterpret_cast<const T*>(p.bias)[n < p.N ? n : p.N - 1]) : 0.f;
+#pragma unroll
+      for (int i = 0; i < RP; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ep[(16 * i + 4 * g + r) * 72 + 16 * j + r16] = H::from_f32(acc[RP * pass + i][j][r] + bv);
+    }
+    wait_lgkmcnt0();  // wave-private patch: a wave-level LDS wait is enough
+    constexpr int SEG = 2 * CB;            // 16-byte row segments per patch row
+    constexpr int ITEMS = 16 * RP * SEG;
+#pragma unroll
+    for (int it = 0; it < (ITEMS + 63) / 64; ++it) {
+      const int c = lane + 64 * it;
+      const int ml = c / SEG, nl = (c % SEG) * 8;
+      const int m = mw0 + ml, n = n0 + wn * 16 * CB + nl;
+      if (c < ITEMS && m < p.M && n < p.N)
+        *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.out) + (int64_t)m * p.N + n) =
+            *reinterpret_cast<const uint4*>(ep + ml * 72 + nl);
+    }
+    wait_lgkmcnt0();  // the patch is rewritten by the next pass
+  }
+}
+
+template <int DTYPE, int RI, int WM, int WN, bool SLAB = false>
+int launch16_tiled_k(const G16Args& p, int SK, hipStream_t s) {
+  auto kern = gemm16_tiled_kernel<DTYPE, RI, WM, WN, SLAB>;
+  constexpr int tmb = 16 * RI * WM, tnb = 64 * WN;
+  constexpr int lds_st = 3 * tmb * 128, lds_ep = SLAB ? WM * WN * 16 * 68 * 4 : WM * WN * 64 * 72 * 2;
+  constexpr int lds = lds_st > lds_ep ? lds_st : lds_ep;
+  static int attr_rc = check_hip(
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
+      "hipFuncSetAttribute");
+  if (attr_rc) return attr_rc;
+  static const int gn_env = [] { const char* e = getenv("SGL_MI355_G16T_GN"); return e ? atoi(e) : 0; }();  // tuning aid
+  const unsigned grid = (unsigned)(((p.M + tmb - 1) / tmb) * ((p.N + tnb - 1) / tnb));
+  hipLaunchKernelGGL(kern, dim3(grid, (unsigned)SK), dim3(64 * WM * WN), lds, s, p, gn_env > 0 ? gn_env : 4);
+  int rc = check_hip(hipGetLastError(), "gemm16_tiled_kernel launch");
+  if (rc || !SLAB) return rc;
+  const int64_t total = (int64_t)p.M * p.N / 8;
+  const int64_t blocks = (total + 63) / 64;
+  hipLaunchKernelGGL((gemm16_finalize_kernel<DTYPE>), dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(64), 0, s, p, SK);
+  return check_hip(hipGetLastError(), "gemm16_finalize launch");
+}
+
+// Tile choice: 128 x 256 (four waves, two workgroups per CU) from 192 such tiles, else 128 x 128; where even those leave the
+// chip part empty or one workgroup per CU for a long K loop (at most 128 tiles from 64 k-steps, at most 256 from 128) and
+// the caller gave a workspace, K is cut into slices (about 512-768 workgroups in all, at least 16 k-steps each) + the finalize launch.
+// A/B aids: SGL_MI355_G16T_TILE=1|2|3 forces 256x256 / 128x256 / 128x128; SGL_MI355_G16T_SK=n forces n slices (1: never split).
+template <int DTYPE>
+int launch16_tiled(G16Args p, float* slabs, int64_t slab_floats, hipStream_t s) {
+  static const int tile_env = [] { const char* e = getenv("SGL_MI355_G16T_TILE"); return e ? atoi(e) : 0; }();
+  static const int sk_env = [] { const char* e = getenv("SGL_MI355_G16T_SK"); return e ? atoi(e) : 0; }();
+  const int64_t t128w = (int64_t)((p.M + 127) / 128) * ((p.N + 255) / 256);
+  const int64_t t128 = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
+  const int tile = tile_env >= 1 && tile_env <= 3 ? tile_env : (t128w >= 192 ? 2 : 3);
+  const int steps = p.KB >> 7;
+  if (tile == 3 && slabs != nullptr && sk_env != 1) {
+    // (measured: with 64 k-steps a split pays up to 128 tiles -- o_proj at 256 / 512 rows 35.8 / 37.1 -> 22.0 / 33.1 us, but 192
+    //  or 256 tiles 50.0 / 40.3 -> 61.7 / 47.1; from 128 k-steps up to 256 tiles: down_proj 14336 at 1024 rows 156 -> 146)
+    const bool split = (t128 <= 128 && steps >= 64) || (t128 <= 256 && steps >= 128);
+    int sk = sk_env > 1 ? sk_env : (split ? (int)(640 / t128) : 1);
+    if (sk > steps / 16) sk = steps / 16;
+    if (sk >= 2) {
+      const int pps = (steps + sk - 1) / sk;
+      sk = (steps + pps - 1) / pps;
+      if (sk >= 2 && (int64_t)sk * p.M * p.N <= slab_floats) {
+        p.slabs = slabs;
+        p.pps = pps;
+        return launch16_tiled_k<DTYPE, 4, 2, 2, true>(p, sk, s);
+      }
+    }
+  }
+  if (tile == 1) return launch16_tiled_k<DTYPE, 8, 2, 4>(p, 1, s);
+  if (tile == 2) return launch16_tiled_k<DTYPE, 8, 1, 4>(p, 1, s);
+  return launch16_tiled_k<DTYPE, 4, 2, 2>(p, 1, s);
+}
+
 }  // namespace
 }  // namespace sglm
 
@@ -428,7 +677,9 @@ static int gemm16_impl(const void* x, const void* weight, const void* bias, void
                        int64_t x_stride_m, int64_t w_stride_n, int b_shuf, int dtype, void* stream, float* workspace = nullptr,
                        int64_t workspace_floats = 0) {
   SGLM_CHECK_ARG(dtype == SGL_MI355_BF16 || dtype == SGL_MI355_FP16, "gemm16_nt: dtype must be bfloat16 or float16");
-  SGLM_CHECK_ARG(M >= 0 && M <= 128, "gemm16_nt: the weight-streaming kernel takes M <= 128 rows (got %ld)", (long)M);
+  SGLM_CHECK_ARG(M >= 0 && (M <= 128 || b_shuf) && M < (1ll << 31),
+                 "gemm16_nt: row-major weights go through the weight-streaming kernel, M <= 128 rows (got %ld); more rows need the "
+                 "fragment-major weight (sgl_mi355_gemm16_nt_wshuffled)", (long)M);
   SGLM_CHECK_ARG(N > 0 && N % 8 == 0 && K > 0 && K % 256 == 0 && N < (1ll << 31) && K < (1ll << 30),
                  "gemm16_nt: N %% 8 == 0 and K %% 256 == 0 required (N=%ld K=%ld)", (long)N, (long)K);
   SGLM_CHECK_ARG(!b_shuf || N % 16 == 0, "gemm16_nt (pre-shuffled weight): N %% 16 == 0 required (N=%ld)", (long)N);
@@ -443,6 +694,11 @@ static int gemm16_impl(const void* x, const void* weight, const void* bias, void
   G16Args p{(const uint8_t*)x, x_stride_m * 2, (const uint8_t*)weight, w_stride_n * 2, bias, out, (int)M, (int)N, (int)(K * 2),
             throttle, nullptr, 0, b_shuf};
   hipStream_t s = as_stream(stream);
+  if (M > 128) {  // prefill-sized batches: the tiled kernel
+    SGLM_CHECK_ARG(M * N < (1ll << 40), "gemm16_nt: output too large");
+    if (dtype == SGL_MI355_BF16) return launch16_tiled<SGL_MI355_BF16>(p, workspace, workspace_floats, s);
+    return launch16_tiled<SGL_MI355_FP16>(p, workspace, workspace_floats, s);
+  }
   if (workspace != nullptr) {  // split-K form where the unsplit grid would leave CUs idle (fewer than ~200 workgroups)
     bool used = false;
     int rc = 0;

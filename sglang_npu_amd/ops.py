@@ -9,6 +9,7 @@ the host and nothing falls back to PyTorch.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional
 
 import torch
@@ -936,8 +937,11 @@ def linear16(x: torch.Tensor, weight, bias: Optional[torch.Tensor] = None) -> to
             raise RuntimeError("linear16: x [M,K] must match the shuffled weight's dtype and K")
         M = x.size(0)
         out = torch.empty((M, weight.N), dtype=x.dtype, device=x.device)
-        if weight.N < 16 * 8 * 200 and 0 < M <= 128:  # narrow N: split-K slabs + finalize (csrc/gemm_bf16.hip launch16_splitk)
-            ws = _fp8_workspace.get(x.device, 16 * M * weight.N)
+        slices = _linear16_tiled_slices(M, weight.N, weight.K) if M > 128 else 0
+        if (weight.N < 16 * 8 * 200 and 0 < M <= 128) or slices >= 2:
+            # narrow N at decode sizes: split-K slabs + finalize (csrc/gemm_bf16.hip launch16_splitk); more than 128 rows: the
+            # tiled kernel, K cut into slices where its tiles would leave the chip part empty (launch16_tiled)
+            ws = _fp8_workspace.get(x.device, (16 if M <= 128 else slices) * M * weight.N)
             _lib.check(_lib.lib().sgl_mi355_gemm16_nt_wshuffled_splitk(
                 _ptr(x), _ptr(weight.data), _ptr(bias), _ptr(out), _ptr(ws), _I64(ws.numel()), _I64(M), _I64(weight.N),
                 _I64(weight.K), _I64(x.stride(0) if M > 1 else weight.K), _I(_dtype_code(x)), _stream(x)))
@@ -958,6 +962,27 @@ def linear16(x: torch.Tensor, weight, bias: Optional[torch.Tensor] = None) -> to
         _ptr(x), _ptr(weight), _ptr(bias), _ptr(out), _I64(M), _I64(N), _I64(K), _I64(x.stride(0) if M > 1 else K),
         _I64(weight.stride(0) if N > 1 else K), _I(_dtype_code(x)), _stream(x)))
     return out
+
+
+_G16T_SK = int(os.environ.get("SGL_MI355_G16T_SK", "0") or 0)  # (read once, like the library reads it)
+_G16T_TILE = os.environ.get("SGL_MI355_G16T_TILE", "")
+
+
+def _linear16_tiled_slices(M: int, N: int, K: int) -> int:
+    """K slices the tiled 16-bit GEMM may take for this shape (the rule of csrc/gemm_bf16.hip launch16_tiled: the workspace
+    must hold that many fp32 partials).  SGL_MI355_G16T_SK forces a count (A/B aid)."""
+    steps = K // 64
+    forced = _G16T_SK
+    if forced == 1:
+        return 0
+    t128w = -(-M // 128) * -(-N // 256)
+    t128 = -(-M // 128) * -(-N // 128)
+    if t128w >= 192 and _G16T_TILE != "3":
+        return 0
+    split = (t128 <= 128 and steps >= 64) or (t128 <= 256 and steps >= 128)
+    sk = forced if forced > 1 else (640 // t128 if split else 1)
+    sk = min(sk, steps // 16)
+    return sk if sk >= 2 and sk * M * N <= (1 << 26) else 0
 
 
 def linear16_supported(M: int, N: int, K: int) -> bool:

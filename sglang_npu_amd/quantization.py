@@ -90,14 +90,19 @@ class QuantizationConfig:
 LINEAR16_MIN_N = int(os.environ.get("SGL_MI355_LINEAR16_MIN_N", "16"))
 # rows up to which an AWQ layer runs its 64-row decode streamer in two passes instead of the tiled prefill kernel (0: never)
 AWQ_TWO_PASS_MAX_ROWS = int(os.environ.get("SGL_MI355_AWQ_TWO_PASS_MAX_ROWS", "128"))
-# rows up to which an unquantised linear runs the 16-bit streamer (65..128: its 128-row form; above: the library GEMM)
-LINEAR16_MAX_ROWS = int(os.environ.get("SGL_MI355_LINEAR16_MAX_ROWS", "128"))
+# rows up to which an unquantised linear runs the 16-bit streamer (65..128: its 128-row form)
+LINEAR16_MAX_ROWS = min(128, int(os.environ.get("SGL_MI355_LINEAR16_MAX_ROWS", "128")))
+# above that: the tiled 16-bit kernel on the same fragment-major copy (round 4, csrc/gemm_bf16.hip gemm16_tiled_kernel), or the
+# library GEMM on the row-major weight (F.linear -> hipBLASLt, what the reference runs: unquant.py:111-123).
+LINEAR16_TILED = os.environ.get("SGL_MI355_LINEAR16_TILED", "0") not in ("", "0")
 
 
 class UnquantizedLinearMethod(LinearMethodBase):
     """layers/quantization/unquant.py: F.linear.  Batches of up to 128 rows run ops.linear16 on a fragment-major copy of the
-    weight built once after loading (round 3); larger batches (prefill) go to the library GEMM (hipBLASLt through torch) --
-    a 16-bit tiled GEMM is not part of the FP8 / INT4 hot path this backend is about."""
+    weight built once after loading (round 3).  Larger batches (prefill): the library GEMM (hipBLASLt through torch) by
+    default, or with SGL_MI355_LINEAR16_TILED=1 the tiled 16-bit kernel on the same copy (round 4) -- within 0.86-1.30x of
+    the library on the Llama shapes at 256..8192 rows (profiles/r04_linear16_tiled_vs_library.txt: ahead on one shape class,
+    5-14 % behind on most), so the library GEMM stays the default."""
 
     def create_weights(self, layer, input_size_per_partition, output_partition_sizes, input_size, output_size,
                        params_dtype, **extra_weight_attrs):
@@ -141,7 +146,8 @@ class UnquantizedLinearMethod(LinearMethodBase):
         fm = self.weight_fm(layer)
         if fm is not None and x.is_cuda and x.dtype == fm.dtype:
             x2 = x.reshape(-1, x.shape[-1])
-            if 0 < x2.shape[0] <= LINEAR16_MAX_ROWS and x2.stride(-1) == 1:
+            rows = x2.shape[0]
+            if (0 < rows <= LINEAR16_MAX_ROWS or (rows > 128 and LINEAR16_TILED)) and x2.stride(-1) == 1:
                 return ops.linear16(x2, fm, bias).reshape(x.shape[:-1] + (fm.N,))
         return torch.nn.functional.linear(x, layer.weight, bias)
 

@@ -309,7 +309,7 @@ def test_linear16_lm_head_vs_fp64(M, N, K, dtype):
     wide = torch.zeros(M, K + 64, device=DEV, dtype=dtype)
     wide[:, :K] = x
     assert torch.equal(ops.linear16(wide[:, :K], w, bias), out)
-    with pytest.raises(RuntimeError, match="M <= 128"):
+    with pytest.raises(RuntimeError, match="M <= 128"):  # (more rows: the tiled kernel, on the fragment-major weight only)
         ops.linear16(torch.zeros(129, K, device=DEV, dtype=dtype), w)
 
 
