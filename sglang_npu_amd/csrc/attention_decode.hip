@@ -1566,16 +1566,16 @@ inline int pair_deal_default() {  // DecodeArgs::pair_deal
 }
 
 // set by sgl_mi355_decode_attention_qkv_partials around its call of the regular entry point
-thread_local const FusedQkv* tl_fq = nullptr;
-thread_local bool tl_fq_used = false;
+[[maybe_unused]] thread_local const FusedQkv* tl_fq = nullptr;  // (read only in builds with SGLM_OPTIN_FUSIONS)
+[[maybe_unused]] thread_local bool tl_fq_used = false;
 // set by sgl_mi355_decode_attention_absmax around its call of the regular entry point
 thread_local float* tl_row_absmax = nullptr;
 // set by sgl_mi355_decode_attention_merged around its call of the regular entry point
 struct MergeFused { int32_t* counters; uint8_t* out_q; float* out_s; };
 thread_local MergeFused tl_merge{nullptr, nullptr, nullptr};
 // set by sgl_mi355_decode_attention_quant around its call of the regular entry point (one split: pairs-of-items kernel, QOUT)
-thread_local MergeFused tl_pair_quant{nullptr, nullptr, nullptr};
-thread_local bool tl_pair_quant_used = false;
+[[maybe_unused]] thread_local MergeFused tl_pair_quant{nullptr, nullptr, nullptr};
+[[maybe_unused]] thread_local bool tl_pair_quant_used = false;
 
 template <int DTYPE, int D, typename IdxT, bool DIRECT>
 int launch_mfma(const DecodeArgs& a, int64_t batch, hipStream_t stream) {

@@ -72,7 +72,7 @@ __device__ __forceinline__ f16x8 unpack8(uint32_t w, h2 zb2, h2 sc2) {
   return r;
 }
 
-constexpr int kTN = 128, kBK = 64;
+constexpr int kTN = 128;
 constexpr int kOpW = kTN * 32;            // 4 KiB
 constexpr int kOpS = 4 * 256;             // 1 KiB: 64 dwords per wave
 

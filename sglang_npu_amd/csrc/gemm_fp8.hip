@@ -445,7 +445,6 @@ __global__ __launch_bounds__(512) void fp8_gemm_oneshot_kernel(GemmArgs p) {
   const int WK = blockDim.x >> 6;
   const int r16 = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.x * 16;
-  const int n = n0 + r16;
   const WFrag wf = wfrag_addr(p, blockIdx.x, lane);
   uint32_t aoff[MB];
 #pragma unroll
@@ -1649,8 +1648,6 @@ __device__ __forceinline__ void tiled_epilogue_silu(const GemmArgs& p, char* sme
 //   RI 8, 2x4 waves: 256x256 with 8 waves, 2 stages (0.75x the LDS fragment reads per flop of the 64x64 wave tile)
 template <int OUT_DTYPE, int NSTAGE, int RI, int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN) void fp8_gemm_tiled2_kernel(GemmArgs p) {
-  using H = Half16<OUT_DTYPE>;
-  using T = typename H::T;
   constexpr int NW = WM * WN;
   constexpr int TMB = 16 * RI * WM;     // block rows
   constexpr int TNB = 64 * WN;          // block columns
