@@ -61,7 +61,11 @@ __device__ __forceinline__ uint2 pack8_fp8(const float* f) {
 // plain and the from-partials form, so that both reduce the sum of squares in the same order (bit-identical results).
 //   x: [T,H] input; residual: nullable, in/out (residual = x + residual, rounded to dtype);
 //   out: nullable 16-bit output; out_q/out_s: nullable FP8 output + per-row scale.
-template <int DTYPE, int VPT, bool FROM_PARTIALS = false, int NT = 256>
+#ifndef SGLM_ABL_ROWSPLIT
+#define SGLM_ABL_ROWSPLIT 0  // timing ablation (WRONG RESULTS): the from-partials row owners of decode batches as FOUR workgroups per row, each
+                             // a quarter of the columns, no exchange of the row statistics (what would a row split buy at best?)
+#endif
+template <int DTYPE, int VPT, bool FROM_PARTIALS = false, int NT = 256, int RS = 1>
 __global__ __launch_bounds__(NT) void rmsnorm_kernel(
     const typename Half16<DTYPE>::T* x /* may alias out */, typename Half16<DTYPE>::T* residual,
     const typename Half16<DTYPE>::T* __restrict__ weight, typename Half16<DTYPE>::T* out,
@@ -69,15 +73,16 @@ __global__ __launch_bounds__(NT) void rmsnorm_kernel(
   using Hh = Half16<DTYPE>;
   using x8 = typename Hh::x8;
   __shared__ float red[NT / 64];
-  const int64_t row = blockIdx.x;
-  const int nv = H >> 3;
+  const int64_t row = blockIdx.x / RS;
+  const int nv = (H >> 3) / RS;                      // vectors of this workgroup's share of the row
+  const int vbase = (int)(blockIdx.x % RS) * nv;
   float v[VPT][8];
   x8 wq[VPT];  // weights fetched with the row, not behind the first reduction (one memory round trip less)
   float ss = 0.f;
 #pragma unroll
   for (int i = 0; i < VPT; ++i) {
-    const int vi = threadIdx.x + NT * i;
-    if (vi < nv) {
+    const int vi = vbase + threadIdx.x + NT * i;
+    if (vi - vbase < nv) {
       // every load of the row is issued before the first use: weight, residual and (FROM_PARTIALS) all slices
       wq[i] = reinterpret_cast<const x8*>(weight)[vi];
       x8 rv;
@@ -106,8 +111,8 @@ __global__ __launch_bounds__(NT) void rmsnorm_kernel(
   float amax = 0.f;
 #pragma unroll
   for (int i = 0; i < VPT; ++i) {
-    const int vi = threadIdx.x + NT * i;
-    if (vi < nv) {
+    const int vi = vbase + threadIdx.x + NT * i;
+    if (vi - vbase < nv) {
       const x8 wv = wq[i];
       x8 o;
 #pragma unroll
@@ -126,8 +131,8 @@ __global__ __launch_bounds__(NT) void rmsnorm_kernel(
     const float sinv = scale == 0.f ? 0.f : 1.0f / scale;
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
-      const int vi = threadIdx.x + NT * i;
-      if (vi < nv) {
+      const int vi = vbase + threadIdx.x + NT * i;
+      if (vi - vbase < nv) {
         float f[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) f[j] = fminf(fmaxf(v[i][j] * sinv, -kFp8Max), kFp8Max);
@@ -142,21 +147,22 @@ __global__ __launch_bounds__(NT) void rmsnorm_kernel(
 // the row is latency- and ALU-bound (an exp and a divide per element), not bandwidth-bound.
 // FROM_PARTIALS: x is not materialised -- gate and up columns come from the split-K partials of the gate_up GEMM
 // (gemm_row8: slice sums + the reference epilogue, rounded to the 16-bit dtype first, so bit-identical to the unfused path).
-template <int DTYPE, int VPT, int NT, bool FROM_PARTIALS = false>
+template <int DTYPE, int VPT, int NT, bool FROM_PARTIALS = false, int RS = 1>
 __global__ __launch_bounds__(NT) void silu_mul_kernel(
     const typename Half16<DTYPE>::T* __restrict__ x, typename Half16<DTYPE>::T* __restrict__ out,
     uint8_t* __restrict__ out_q, float* __restrict__ out_s, int d, PartialSrc ps = PartialSrc{}) {
   using Hh = Half16<DTYPE>;
   using x8 = typename Hh::x8;
   __shared__ float red[NT / 64];
-  const int64_t row = blockIdx.x;
-  const int nv = d >> 3;
+  const int64_t row = blockIdx.x / RS;
+  const int nv = (d >> 3) / RS;
+  const int vbase = (int)(blockIdx.x % RS) * nv;
   float v[VPT][8];
   float amax = 0.f;
 #pragma unroll
   for (int i = 0; i < VPT; ++i) {
-    const int vi = threadIdx.x + NT * i;
-    if (vi < nv) {
+    const int vi = vbase + threadIdx.x + NT * i;
+    if (vi - vbase < nv) {
       x8 a, b;
       if constexpr (FROM_PARTIALS) {
         a = gemm_row8<DTYPE>(ps, row, vi * 8);
@@ -186,8 +192,8 @@ __global__ __launch_bounds__(NT) void silu_mul_kernel(
     const float sinv = scale == 0.f ? 0.f : 1.0f / scale;
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
-      const int vi = threadIdx.x + NT * i;
-      if (vi < nv) {
+      const int vi = vbase + threadIdx.x + NT * i;
+      if (vi - vbase < nv) {
         float f[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) f[j] = fminf(fmaxf(v[i][j] * sinv, -kFp8Max), kFp8Max);
@@ -602,6 +608,17 @@ int launch_rmsnorm_partials(const PartialSrc& ps, void* residual, const void* we
 #define RMSP_LAUNCH_W(V, NT_)                                                                                        \
   hipLaunchKernelGGL((rmsnorm_kernel<DTYPE, V, true, NT_>), dim3((unsigned)T), dim3(NT_), 0, s, (const T16*)nullptr,  \
                      (T16*)residual, (const T16*)weight, (T16*)nullptr, (uint8_t*)out_q, out_s, (int)H, eps, ps)
+#if SGLM_ABL_ROWSPLIT
+  if (rms_wide(T, nv) && nv % 256 == 0 && nv <= 1024) {  // four workgroups per row, 256 threads or fewer each
+    if (nv <= 512)
+      hipLaunchKernelGGL((rmsnorm_kernel<DTYPE, 1, true, 128, 4>), dim3((unsigned)T * 4), dim3(128), 0, s, (const T16*)nullptr,
+                         (T16*)residual, (const T16*)weight, (T16*)nullptr, (uint8_t*)out_q, out_s, (int)H, eps, ps);
+    else
+      hipLaunchKernelGGL((rmsnorm_kernel<DTYPE, 1, true, 256, 4>), dim3((unsigned)T * 4), dim3(256), 0, s, (const T16*)nullptr,
+                         (T16*)residual, (const T16*)weight, (T16*)nullptr, (uint8_t*)out_q, out_s, (int)H, eps, ps);
+    return check_hip(hipGetLastError(), "rmsnorm_from_partials launch");
+  }
+#endif
   if (rms_wide(T, nv)) {
     if (nv <= 512) RMSP_LAUNCH_W(1, 512);
     else if (nv <= 1024) RMSP_LAUNCH_W(1, 1024);
@@ -648,6 +665,17 @@ int launch_silu_partials(const PartialSrc& ps, void* out_q, float* out_s, int64_
 #define SILU_P(V, NT_)                                                                                              \
   hipLaunchKernelGGL((silu_mul_kernel<DTYPE, V, NT_, true>), dim3((unsigned)T), dim3(NT_), 0, s, (const T16*)nullptr, \
                      (T16*)nullptr, (uint8_t*)out_q, out_s, (int)d, ps)
+#if SGLM_ABL_ROWSPLIT
+  if (nv % 1024 == 0 || nv == 448) {  // (448: the 70B TP=8 rank's 3584 columns)
+    if (nv == 448)
+      hipLaunchKernelGGL((silu_mul_kernel<DTYPE, 1, 128, true, 4>), dim3((unsigned)T * 4), dim3(128), 0, s, (const T16*)nullptr,
+                         (T16*)nullptr, (uint8_t*)out_q, out_s, (int)d, ps);
+    else
+      hipLaunchKernelGGL((silu_mul_kernel<DTYPE, 1, 256, true, 4>), dim3((unsigned)T * 4), dim3(256), 0, s, (const T16*)nullptr,
+                         (T16*)nullptr, (uint8_t*)out_q, out_s, (int)d, ps);
+    return check_hip(hipGetLastError(), "silu_and_mul_quant_fp8_from_partials launch");
+  }
+#endif
   if (nv >= 1024) {
     const int vpt = (nv + 1023) / 1024;
     if (vpt <= 1) SILU_P(1, 1024);
