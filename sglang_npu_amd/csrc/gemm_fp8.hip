@@ -1522,7 +1522,14 @@ __device__ __forceinline__ void tiled_epilogue(const GemmArgs& p, char* smem, f3
 #pragma unroll
   for (int j = 0; j < CB; ++j) {
     const int n = n0 + wn * 16 * CB + 16 * j + r16;
+#ifndef SGLM_EPI_ABL_NOSCALE
+#define SGLM_EPI_ABL_NOSCALE 0  // timing ablation (WRONG RESULTS): the tiled epilogues without their scale loads
+#endif
+#if SGLM_EPI_ABL_NOSCALE
+    sbv[j] = 1.0f + (float)n * 1e-9f;
+#else
     sbv[j] = p.sb[n < p.N ? n : p.N - 1];
+#endif
   }
   constexpr int RP = RI < 4 ? RI : 4;  // 16-row fragments per epilogue pass
 #pragma unroll
@@ -1534,7 +1541,11 @@ __device__ __forceinline__ void tiled_epilogue(const GemmArgs& p, char* smem, f3
       for (int r = 0; r < 4; ++r) {
         const int ml = 16 * i + 4 * g + r;
         const int m = mw0 + ml;
+#if SGLM_EPI_ABL_NOSCALE
+        const float sa = 1.0f + (float)m * 1e-9f;
+#else
         const float sa = p.sa[m < p.M ? m : p.M - 1];
+#endif
 #pragma unroll
         for (int j = 0; j < CB; ++j) {
           const int nl = 16 * j + r16;
@@ -1800,22 +1811,31 @@ __global__ __launch_bounds__(64 * WM * WN) void fp8_gemm_tiled2_kernel(GemmArgs 
 // SILU (round 3, the gate_up GEMM of a gated MLP, W = [gate | up], N = 2 I): the tile is 128 rows x 128 OUTPUT columns -- every
 // wave streams the weight fragments of 32 gate columns and of the 32 up columns I further on (the same 2 KiB contiguous pieces,
 // just other blocks), and the epilogue writes silu(gate) * up, [M][I], instead of the [M][2 I] product (tiled_epilogue_silu).
-template <int OUT_DTYPE, int NSTAGE, int RI, int WM, int WN, int CB = 4, bool SILU = false>
-__global__ __launch_bounds__(64 * WM * WN, 2) void fp8_gemm_tiled3_kernel(GemmArgs p) {
+// KS = 2 (round 4): TWO wave groups per workgroup, group kg taking the k-steps 2 i + kg of the SAME tile (its own A image per
+// step, its own weight fragments: no byte enters the CU twice) and handing its accumulators to group 0 through LDS at the end.
+// For the shapes that give every CU exactly one 128-row tile (M = 1024 qkv: 256 tiles of 128 x 192), where the four-wave
+// workgroup leaves one wave per SIMD and every LDS / barrier / first-fragment latency is exposed; two co-resident waves per
+// SIMD are what the two-workgroups-per-CU form has from 512 tiles on.  Sums the k-steps in another order than KS = 1.
+template <int OUT_DTYPE, int NSTAGE, int RI, int WM, int WN, int CB = 4, bool SILU = false, int KS = 1>
+__global__ __launch_bounds__(64 * WM * WN * KS, 2) void fp8_gemm_tiled3_kernel(GemmArgs p) {
   static_assert(NSTAGE >= 3, "the wait count below assumes A(kt) was issued before B(kt)");
   static_assert(CB == 3 || CB == 4, "column blocks per wave");
   static_assert(!SILU || CB == 4, "gate and up: two column blocks each");
-  constexpr int NW = WM * WN;
+  static_assert(KS == 1 || (KS == 2 && !SILU), "one or two k groups");
+  constexpr int NW = WM * WN * KS;
   constexpr int TMB = 16 * RI * WM;     // block rows
   constexpr int TNB = SILU ? 8 * CB * WN : 16 * CB * WN;  // block columns (SILU: output columns = gate columns)
-  constexpr int STAGE = TMB * 128;      // A tile: TMB rows x 128 B
-  constexpr int UA = TMB / 8 / NW;      // 1-KiB DMA units (8 rows x 128 B) per wave and stage
-  static_assert((TMB / 8) % NW == 0, "DMA units must divide over the waves");
+  constexpr int OPA = TMB * 128;        // one A image: TMB rows x 128 B
+  constexpr int STAGE = KS * OPA;       // a stage holds the images of KS consecutive k-steps
+  constexpr int UA = KS * TMB / 8 / NW; // 1-KiB DMA units (8 rows x 128 B) per wave and stage
+  static_assert((KS * TMB / 8) % NW == 0, "DMA units must divide over the waves");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
+  const int kg = wave / (WM * WN);      // k group of this wave
+  const int wave_t = wave % (WM * WN);  // its place in the tile
+  const int wm = wave_t / WN, wn = wave_t % WN;
   const int r16 = lane & 15, g = lane >> 4;
 
   const int n_cols = SILU ? p.N >> 1 : p.N;  // columns the tiles cover
@@ -1843,17 +1863,19 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void fp8_gemm_tiled3_kernel(GemmAr
   const uint8_t* a_src[UA];
 #pragma unroll
   for (int u = 0; u < UA; ++u) {
-    const int row = (UA * wave + u) * 8 + (lane >> 3);  // tile-local row
+    const int q = UA * wave + u;                         // unit of the stage: image q / (TMB / 8), rows 8 (q % (TMB / 8))..
+    const int row = (q % (TMB / 8)) * 8 + (lane >> 3);   // tile-local row
     const int j = (lane & 7) ^ ((row >> 1) & 7);
     int m = m0 + row;
     m = m < p.M ? m : p.M - 1;  // rows past the edge re-read a valid row; never stored
-    a_src[u] = p.a + (int64_t)m * p.a_sm + 16 * j;
+    a_src[u] = p.a + (int64_t)m * p.a_sm + 16 * j + (q / (TMB / 8)) * 128;
   }
   const uint32_t smem_base = lds_addr_of(smem);
+  // (kt below counts loop iterations: KS k-steps each)
   auto dma_stage = [&](int stage, int kt) __attribute__((always_inline)) {
     const uint32_t dst = smem_base + stage * STAGE;
 #pragma unroll
-    for (int u = 0; u < UA; ++u) lds_dma16(a_src[u] + (int64_t)kt * 128, dst + (UA * wave + u) * 1024);
+    for (int u = 0; u < UA; ++u) lds_dma16(a_src[u] + (int64_t)kt * (128 * KS), dst + (UA * wave + u) * 1024);
   };
   // weight fragments: column block (n0 / 16 + 4 wn + j), k-step kt = 2 KiB at block * 16 K + 2048 kt; lane i takes bytes
   // 16 i.. of each KiB.  Blocks past N re-read the last one (their columns are never stored).
@@ -1870,9 +1892,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void fp8_gemm_tiled3_kernel(GemmAr
     }
     b_blk[j] = p.b + (int64_t)nb * 16 * p.K;
   }
-  const int nk = p.K >> 7;
+  const int nk = (p.K >> 7) / KS;  // loop iterations
   auto load_b = [&](Frag32 (&q)[CB], int kt) __attribute__((always_inline)) {
-    const uint32_t voff = (uint32_t)lane * 16 + (uint32_t)kt * 2048;
+    const uint32_t voff = (uint32_t)lane * 16 + (uint32_t)(KS * kt + kg) * 2048;
 #pragma unroll
     for (int j = 0; j < CB; ++j) {
       asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(q[j].x[0]) : "v"(voff), "s"(b_blk[j]) : "memory");
@@ -1953,7 +1975,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void fp8_gemm_tiled3_kernel(GemmAr
 #pragma unroll
     for (int i = 0; i < RI; ++i) asm volatile("" : "+v"(af[i].x[0]), "+v"(af[i].x[1]));
 #else
-    const char* sa_ = smem + (kt % NSTAGE) * STAGE + a_row;
+    const char* sa_ = smem + (kt % NSTAGE) * STAGE + kg * OPA + a_row;
     Frag32 af[RI];
 #pragma unroll
     for (int i = 0; i < RI; ++i) {
@@ -1961,7 +1983,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void fp8_gemm_tiled3_kernel(GemmAr
       af[i].v[1] = *reinterpret_cast<const uint4*>(sa_ + i * 2048 + c1);
     }
 #endif
-    const uint32_t voff = (uint32_t)lane * 16 + (uint32_t)(kt + 1 < nk ? kt + 1 : nk - 1) * 2048;
+    const uint32_t voff = (uint32_t)lane * 16 + (uint32_t)(KS * (kt + 1 < nk ? kt + 1 : nk - 1) + kg) * 2048;
 #pragma unroll
     for (int j = 0; j < CB; ++j) {
 #if SGLM_T3_ABL == 4
@@ -2010,8 +2032,31 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void fp8_gemm_tiled3_kernel(GemmAr
       for (int r = 0; r < 4; ++r) acc[i][j][r] = acc32[i >> 1][j >> 1][(i & 1) * 8 + (j & 1) * 4 + r];
 #endif
   __syncthreads();  // all stages dead: the epilogue reuses the memory
-  if constexpr (SILU) tiled_epilogue_silu<OUT_DTYPE, RI>(p, smem, acc, m0, n0, wm, wn, wave, lane);
-  else tiled_epilogue<OUT_DTYPE, RI, CB>(p, smem, acc, m0, n0, wm, wn, wave, lane);
+  if constexpr (KS == 2) {
+    // group 1 hands its accumulators over: element e of lane l at [e][l] of the receiving wave's region
+    float* hand = reinterpret_cast<float*>(smem) + wave_t * (RI * CB * 4 * 64);
+    if (kg == 1) {
+#pragma unroll
+      for (int i = 0; i < RI; ++i)
+#pragma unroll
+        for (int j = 0; j < CB; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) hand[((i * CB + j) * 4 + r) * 64 + lane] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (kg == 0) {
+#pragma unroll
+      for (int i = 0; i < RI; ++i)
+#pragma unroll
+        for (int j = 0; j < CB; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][j][r] += hand[((i * CB + j) * 4 + r) * 64 + lane];
+    }
+    __syncthreads();  // every wave is done with the hand-over area: the epilogue patches below overlap it
+    if (kg == 1) return;
+  }
+  if constexpr (SILU) tiled_epilogue_silu<OUT_DTYPE, RI>(p, smem, acc, m0, n0, wm, wn, wave_t, lane);
+  else tiled_epilogue<OUT_DTYPE, RI, CB>(p, smem, acc, m0, n0, wm, wn, wave_t, lane);
 }
 
 template <int OUT_DTYPE, int MB, int NB, int WK>
@@ -2207,6 +2252,29 @@ int run_gemm(const GemmArgs& p, float* workspace, int64_t workspace_floats, hipS
     hipLaunchKernelGGL(k3, dim3(g3), dim3(256 * WM_), lds3, s, p3);                                               \
     return check_hip(hipGetLastError(), "fp8_gemm_tiled3 launch");                                                \
   }
+    // one tile per CU or fewer (M = 1024 qkv: 256 tiles of 128 x 192): the eight-wave form with two k groups (see the kernel)
+    // SGL_MI355_T3_KS=1|2 forces one (A/B aid)
+    static const int ks_env = [] { const char* e = getenv("SGL_MI355_T3_KS"); return e ? atoi(e) : 0; }();
+    if (v3_env <= 0 && (ks_env == 2 || (ks_env != 1 && grid_3 <= 256))) {
+#define TILED3_KS2(CB_)                                                                                           \
+  {                                                                                                               \
+    GemmArgs p3 = p;                                                                                              \
+    p3.raster_gn = gn_env > 0 ? gn_env : 4;                                                                       \
+    auto k3 = fp8_gemm_tiled3_kernel<OUT_DTYPE, 3, 8, 1, 4, CB_, false, 2>;                                       \
+    constexpr int lds_st = 3 * 2 * 128 * 128, lds_hand = 4 * 8 * CB_ * 4 * 64 * 4;                                \
+    constexpr int lds3 = lds_st > lds_hand ? lds_st : lds_hand;                                                   \
+    static int a3 = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(k3),                              \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds3), "hipFuncSetAttribute"); \
+    if (a3) return a3;                                                                                            \
+    const unsigned g3 = (unsigned)(((p.M + 127) / 128) * ((p.N + 64 * CB_ - 1) / (64 * CB_)));                    \
+    g_last_kernel = "tiled3_ks2";                                                                                 \
+    hipLaunchKernelGGL(k3, dim3(g3), dim3(512), lds3, s, p3);                                                     \
+    return check_hip(hipGetLastError(), "fp8_gemm_tiled3 (two k groups) launch");                                 \
+  }
+      if (cb == 3) TILED3_KS2(3)
+      TILED3_KS2(4)
+#undef TILED3_KS2
+    }
     if (v3_env == 1) TILED3_GO(2, 4)
     if (cb == 3) TILED3_GO(1, 3)
     TILED3_GO(1, 4)

@@ -366,6 +366,7 @@ def test_linear16_shuffle_rejects_other_shapes():
     (16, 1024, 65536 + 64, False, False, "astat"),    # narrow N, very long K with a tail
     (7, 48, 208, False, False, "skinny"),             # ragged little shapes (K % 16 == 0 is the op's own precondition)
     (4096, 28672, 4096, True, False, "tiled3"),       # prefill on a pre-shuffled weight, >= 192 tiles of 128 x 256
+    (1024, 6144, 4096, True, False, "tiled3_ks2"),    # ... exactly one 128-row tile per CU: eight waves, two k groups
     (1024, 4096, 4096, True, False, "tiled2"),        # prefill with fewer tiles
     (300, 512, 1008, False, False, "tiled"),          # K tail at M > 64
 ])

@@ -89,7 +89,9 @@ def test_fp8_scaled_mm_on_shuffled_weight(M, N, K):
                                    # the headline prefill shapes bench.py's roofline_gemm times (Llama-3-8B gate_up / down at M = 4096)
                                    (4096, 28672, 4096), (4096, 4096, 14336), (4096, 6144, 4096),
                                    # and the TTFT pass (M = 1024): every shape the 1024-token prefill runs
-                                   (1024, 28672, 4096), (1024, 4096, 14336)])
+                                   (1024, 28672, 4096), (1024, 4096, 14336),
+                                   # exactly one 128-row tile per CU: the eight-wave form with two k groups (round 4)
+                                   (1024, 6144, 4096), (1000, 6144, 1024), (1024, 8192, 8192)])
 def test_prefill_shapes_on_shuffled_weight(M, N, K):
     """>= 192 tiles of 128 x 256 on a pre-shuffled weight: fp8_gemm_tiled3_kernel (weights global -> VGPR).  Same products
     and the same fp32 summation order over k as the row-major tiled kernel -> bit-identical; ragged M, N % 256 != 0."""
@@ -102,12 +104,16 @@ def test_prefill_shapes_on_shuffled_weight(M, N, K):
     bias = torch.randn(N, generator=g, device=DEV).to(dt) if N % 32 else None
     plain = ops.fp8_scaled_mm(a, w.t(), sa, sb, dt, bias)
     out = ops.fp8_scaled_mm(a, ops.fp8_shuffle_weight(w), sa, sb, dt, bias)
-    assert torch.equal(out, plain)
+    ulp = 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10
+    if ops.fp8_last_kernel() == "tiled3_ks2":  # two k groups: even and odd k-steps summed apart, then added
+        assert ((M + 127) // 128) * min((N + 255) // 256, (N + 191) // 192) <= 256
+        torch.testing.assert_close(out.float(), plain.float(), rtol=2 * ulp, atol=1e-3 * float(plain.float().abs().max()))
+    else:
+        assert torch.equal(out, plain)
     rows = torch.tensor([0, 1, 127, 128, M // 2, M - 2, M - 1], device=DEV)  # fp64 truth on a few rows (incl. the ragged edge)
     ref = (a[rows].double() @ w.double().t()) * sb.double().view(1, -1) * sa[rows].double()
     if bias is not None:
         ref = ref + bias.double()
-    ulp = 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10
     torch.testing.assert_close(out[rows].float(), ref.float(), rtol=ulp, atol=1e-3 * float(ref.abs().max()))
 
 
