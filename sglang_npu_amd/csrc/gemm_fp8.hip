@@ -1833,6 +1833,13 @@ __global__ __launch_bounds__(64 * WM * WN * KS, 2) void fp8_gemm_tiled3_kernel(G
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifndef SGLM_T3_TIMING
+#define SGLM_T3_TIMING 0  // instrumentation build (tools/exp/gemm_phase_times.py): `bias` is a uint64 buffer, four 100-MHz timestamps per workgroup
+#endif
+#if SGLM_T3_TIMING
+  const uint64_t t_start = __builtin_amdgcn_s_memrealtime();
+  uint64_t t_loop = 0, t_loop_end = 0;
+#endif
   const int kg = wave / (WM * WN);      // k group of this wave
   const int wave_t = wave % (WM * WN);  // its place in the tile
   const int wm = wave_t / WN, wn = wave_t % WN;
@@ -1949,6 +1956,9 @@ __global__ __launch_bounds__(64 * WM * WN * KS, 2) void fp8_gemm_tiled3_kernel(G
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc32[m][n][r] = 0.f;
 #endif
+#if SGLM_T3_TIMING
+  t_loop = __builtin_amdgcn_s_memrealtime();
+#endif
 #pragma clang loop unroll(disable)
   for (int kt = 0; kt < nk; ++kt) {
 #if SGLM_T3_ABL != 1
@@ -2023,6 +2033,14 @@ __global__ __launch_bounds__(64 * WM * WN * KS, 2) void fp8_gemm_tiled3_kernel(G
     }
   }
   drain_frags(bq);  // the never-consumed tail refills (and the tail DMAs)
+#if SGLM_T3_TIMING
+  t_loop_end = __builtin_amdgcn_s_memrealtime();
+  GemmArgs pt = p;
+  pt.bias = nullptr;
+#define SGLM_T3_P pt
+#else
+#define SGLM_T3_P p
+#endif
 #if SGLM_T3_ABL == 6
 #pragma unroll
   for (int i = 0; i < RI; ++i)
@@ -2055,8 +2073,16 @@ __global__ __launch_bounds__(64 * WM * WN * KS, 2) void fp8_gemm_tiled3_kernel(G
     __syncthreads();  // every wave is done with the hand-over area: the epilogue patches below overlap it
     if (kg == 1) return;
   }
-  if constexpr (SILU) tiled_epilogue_silu<OUT_DTYPE, RI>(p, smem, acc, m0, n0, wm, wn, wave_t, lane);
-  else tiled_epilogue<OUT_DTYPE, RI, CB>(p, smem, acc, m0, n0, wm, wn, wave_t, lane);
+  if constexpr (SILU) tiled_epilogue_silu<OUT_DTYPE, RI>(SGLM_T3_P, smem, acc, m0, n0, wm, wn, wave_t, lane);
+  else tiled_epilogue<OUT_DTYPE, RI, CB>(SGLM_T3_P, smem, acc, m0, n0, wm, wn, wave_t, lane);
+#undef SGLM_T3_P
+#if SGLM_T3_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the output stores have left
+  if (tid == 0 && p.bias != nullptr) {
+    uint64_t* tb = reinterpret_cast<uint64_t*>(const_cast<void*>(p.bias)) + 4 * (int64_t)blockIdx.x;
+    tb[0] = t_start; tb[1] = t_loop; tb[2] = t_loop_end; tb[3] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 template <int OUT_DTYPE, int MB, int NB, int WK>
