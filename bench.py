@@ -460,12 +460,17 @@ def time_extend_kernel(cfg, device, tp):
     2048 cached tokens each, gathered through a random-permutation page table) -- geometry of this model per rank, bf16,
     through the Triton-form entry point (extend_attention.py:306-438).  flops = 4 B Hq D (L P + L (L + 1) / 2) against the
     2.5 PFLOP/s dense bf16 MFMA peak; the prefix stage's gathered K/V bytes (B P Hkv 2 D 2) over the whole launch are a lower
-    bound of its gather rate."""
+    bound of its gather rate.  Round 4 adds a short suffix behind a long cached prefix (one request, 128 new tokens after 4096:
+    a later chunk of a chunked prefill, a multi-turn radix hit) -- the launch that has too few (query block, head group) items
+    to fill the chip; the attention backend passes the host's prefix bound + scratch and the kernel cuts every item's keys into
+    ranges over several workgroups (`us` = that call, `us_unsplit` = the same call without them)."""
     from sglang_npu_amd import ops
     Hq, Hkv, D = cfg.num_attention_heads // tp, cfg.get_num_kv_heads(tp), cfg.head_dim
     out = {"unit": "TFLOP/s", "peak": 2500.0, "bound": "mfma", "kernel": "extend_mfma_kernel (csrc/attention_extend.hip)",
            "geometry": f"Hq={Hq} Hkv={Hkv} D={D} bf16, causal", "cases": []}
-    for (B, L, P, name) in [(1, 1024, 0, "ttft_1024"), (1, 4096, 0, "prefill_4096"), (4, 512, 2048, "radix_hit_4x512_after_2048")]:
+    scratch = ops.ExtendPartsScratch(device)
+    for (B, L, P, name) in [(1, 1024, 0, "ttft_1024"), (1, 4096, 0, "prefill_4096"), (4, 512, 2048, "radix_hit_4x512_after_2048"),
+                            (1, 128, 4096, "suffix_128_after_4096")]:
         g = torch.Generator(device=device).manual_seed(B * 1000 + L + P)
         n_tok = B * (L + P) + 1
         kb = torch.randn(n_tok, Hkv, D, device=device, generator=g).bfloat16()
@@ -479,39 +484,45 @@ def time_extend_kernel(cfg, device, tp):
         kv_indptr = (torch.arange(B + 1, device=device) * P).to(torch.int32)
         kv_indices = perm[: B * P].contiguous() if P else torch.zeros(1, dtype=torch.int32, device=device)
 
-        def run(n=8):
-            for _ in range(n):
-                ops.extend_attention_fwd(q, ke, ve, o, kb, vb, qo_indptr, kv_indptr, kv_indices, None, True, None, L,
-                                         D ** -0.5, 0.0)
+        def timed(kw):
+            def run(n=8):
+                for _ in range(n):
+                    ops.extend_attention_fwd(q, ke, ve, o, kb, vb, qo_indptr, kv_indptr, kv_indices, None, True, None, L,
+                                             D ** -0.5, 0.0, **kw)
 
-        s = torch.cuda.Stream(device=device)
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            run(2)
-        torch.cuda.current_stream().wait_stream(s)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=s):
-            run()
-        graph.replay()
-        torch.cuda.synchronize()
-        ts = []
-        for _ in range(5):
-            st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            st.record()
-            graph.replay()
-            en.record()
+            s = torch.cuda.Stream(device=device)
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                run(2)
+            torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
-            ts.append(st.elapsed_time(en) * 1e3 / 8)
-        ts.sort()
-        us = ts[len(ts) // 2]
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=s):
+                run()
+            graph.replay()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(5):
+                st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                st.record()
+                graph.replay()
+                en.record()
+                torch.cuda.synchronize()
+                ts.append(st.elapsed_time(en) * 1e3 / 8)
+            ts.sort()
+            del graph
+            return ts[len(ts) // 2]
+
+        # as the attention backend calls it: the host's bound of the prefix lengths + its scratch
+        us = timed(dict(max_prefix_len=P, parts_scratch=scratch))
         flops = 4.0 * B * Hq * D * (L * P + L * (L + 1) / 2)
         case = {"name": name, "B": B, "extend_len": L, "prefix_len": P, "us": round(us, 2),
                 "TFLOPs": round(flops / us / 1e6, 1), "frac_mfma": round(flops / us / 1e6 / 2500.0, 4)}
         if P:
             case["prefix_kv_gathered_GBps_lower_bound"] = round(B * P * Hkv * 2 * D * 2 / us / 1e3, 1)
+        if name.startswith("suffix"):
+            case["us_unsplit"] = round(timed({}), 2)
         out["cases"].append(case)
-        del graph
     out["note"] = ("event-timed in this run: one HIP graph of 8 launches per case, median of 5 replays / 8; counters of the same "
                    "kernel (SQ_VALU_MFMA_BUSY_CYCLES, SQ_WAIT_INST_ANY): profiles/r04_extend_pmc.txt")
     return out

@@ -177,6 +177,31 @@ int sgl_mi355_decode_attention_fwd_fp8kv(
     int64_t head_size_v, int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h,
     int64_t v_stride_n, int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h, float sm_scale, float logit_cap,
     int dtype, void* stream);
+/* sgl_mi355_extend_attention_fwd with what lets a launch of FEW, LONG items use the whole chip (round 4).  The Triton kernel
+ * (extend_attention.py:41-303) runs one program per (request, head, 64-row query block) over all of its keys; one short request
+ * behind a long cached prefix (chunked prefill's later chunks, scheduler.py:1425-1430; a radix-cache hit with a short suffix) is
+ * 16-64 such programs of 20-250 key tiles each.  Here, with at most 128 (32-row query block, head group) items whose longest
+ * has 12 key tiles or more, every item's tiles are cut into up to 4 consecutive ranges (8 up to 32 items) over as many
+ * workgroups; each stores its (O, m, l), and the one that completes the item's count merges all of them in range order
+ * (deterministic; not bit-identical to the unsplit sum order).  max_prefix_len: an upper bound of the batch's prefix lengths as
+ * the host knows them (forward_batch.extend_prefix_lens_cpu; the kernel reads the true ones from kv_indptr).  workspace: fp32
+ * scratch, items * parts * 2 owner waves * 4224 floats (17.3 MB at most); counters: int32, >= 128, ZERO before the first call, left
+ * zero.  Both belong to the caller and must not be shared with a launch that may overlap this one.  16-bit pools, head size
+ * 128, no custom mask / sliding window; any other call, a null or too small workspace, or SGL_MI355_EXTEND_PARTS=0 runs
+ * exactly as sgl_mi355_extend_attention_fwd. */
+int sgl_mi355_extend_attention_fwd_parts(
+    const void* q_extend, const void* k_extend, const void* v_extend, void* o_extend,
+    const void* k_buffer, const void* v_buffer,
+    const int32_t* qo_indptr, const int32_t* kv_indptr, const int32_t* kv_indices, int is_causal,
+    int64_t max_len_extend, int64_t batch, int64_t num_heads, int64_t num_kv_heads,
+    int64_t head_size, int64_t head_size_v,
+    int64_t q_stride_t, int64_t q_stride_h, int64_t ke_stride_t, int64_t ke_stride_h,
+    int64_t ve_stride_t, int64_t ve_stride_h, int64_t o_stride_t, int64_t o_stride_h,
+    int64_t kb_stride_n, int64_t kb_stride_h, int64_t vb_stride_n, int64_t vb_stride_h,
+    float sm_scale, float logit_cap,
+    const uint8_t* custom_mask, const int64_t* mask_indptr, int skip_prefix_custom_mask, int64_t sliding_window_size,
+    int dtype, void* stream,
+    int64_t max_prefix_len, float* workspace, int64_t workspace_floats, int32_t* counters, int64_t num_counters);
 /* extend_attention_fwd over an e4m3 pool (same argument list as sgl_mi355_extend_attention_fwd; pool strides in
  * elements = bytes).  As the Triton kernel computes it (extend_attention.py:149, :200): in the PREFIX stage Q and P are
  * rounded to e4m3 (blocks of 64 keys), products are fp8 x fp8 with fp32 accumulation; the extend stage is the 16-bit

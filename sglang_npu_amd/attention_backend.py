@@ -49,6 +49,10 @@ FUSE_SPLIT_MERGE_MAX_WGS = 8
 # lands on the critical path where the 4.8 us quant launch was -- headline step 6.146 ms with the separate launch, 6.164
 # with this (attention in-step 95.5 -> 97.7 us, same box, profiles/r03_decode_quant_in_launch.txt).
 FUSE_DECODE_QUANT = bool(os.environ.get("SGL_MI355_DECODE_QUANT_FUSION"))
+# extend launches with few, long items (one short request behind a long cached prefix; the heaviest query blocks of a single
+# 1024-token prefill) cut every item's keys into up to four ranges over as many workgroups (csrc/attention_extend.hip PARTS).
+# SGL_MI355_EXTEND_PARTS=0: never.
+EXTEND_PARTS = os.environ.get("SGL_MI355_EXTEND_PARTS", "1") not in ("", "0")
 
 
 @dataclass
@@ -68,6 +72,9 @@ class ForwardMetadata:
     window_num_kv_splits: int = 1
     window_attn_logits: Optional[torch.Tensor] = None
     window_attn_lse: Optional[torch.Tensor] = None
+    # extend: the longest cached prefix of the batch when the host knows it (extend_prefix_lens_cpu); lets the extend kernel cut
+    # few, long items into KV-range parts (ops.extend_attention_fwd, round 4)
+    max_prefix_len: Optional[int] = None
 
 
 class AttentionBackend:
@@ -133,6 +140,9 @@ class MI355AttnBackend(AttentionBackend):
             self.qo_indptr = torch.zeros((max_bs + 1,), dtype=torch.int32, device=self.device)
         # arrival counters of the in-launch split merge (ops.decode_attention_paged_merged): zero here, left zero by every call
         self._merge_counters = torch.zeros((max_bs,), dtype=torch.int32, device=self.device)
+        # partials + arrival counters of the extend kernel's KV-range parts (this backend's launches are on one stream)
+        self._extend_parts = (ops.ExtendPartsScratch(self.device) if (not skip_prefill and EXTEND_PARTS
+                                                                     and torch.device(self.device).type == "cuda") else None)
         self.forward_metadata: Optional[ForwardMetadata] = None
         self._graph = None  # static buffers once init_cuda_graph_state has run
 
@@ -246,6 +256,8 @@ class MI355AttnBackend(AttentionBackend):
             max_extend_len = (max(forward_batch.extend_seq_lens_cpu) if forward_batch.extend_seq_lens_cpu is not None
                               else int(torch.max(forward_batch.extend_seq_lens).item()))
             md = ForwardMetadata(None, None, max_extend_len, 1, kv_indptr, kv_indices, qo_indptr)
+            if forward_batch.extend_prefix_lens_cpu is not None:
+                md.max_prefix_len = max(forward_batch.extend_prefix_lens_cpu) if bs else 0
             if self.sliding_window_size is not None:  # triton_backend.py:301-311
                 md.window_kv_indptr, md.window_kv_indices, _ = self._window_buffer(
                     forward_batch.extend_prefix_lens, forward_batch.req_pool_indices, bs)
@@ -476,5 +488,6 @@ class MI355AttnBackend(AttentionBackend):
             forward_batch.token_to_kv_pool.get_key_buffer(layer.layer_id),
             forward_batch.token_to_kv_pool.get_value_buffer(layer.layer_id),
             md.qo_indptr, kv_indptr, kv_indices, md.custom_mask, causal, md.mask_indptr, md.max_extend_len,
-            layer.scaling, layer.logit_cap, sliding_window_size)
+            layer.scaling, layer.logit_cap, sliding_window_size,
+            max_prefix_len=md.max_prefix_len if kv_indices is md.kv_indices else None, parts_scratch=self._extend_parts)
         return o

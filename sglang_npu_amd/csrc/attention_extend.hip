@@ -62,6 +62,12 @@ struct ExtendArgs {
   int skip_prefix_mask;        // SKIP_PREFIX_CUSTOM_MASK
   int window;                  // SLIDING_WINDOW_SIZE (prefix stage only: q <= n + window)
   int kv8;                     // 1 / 2: pool rows are e4m3fn / e5m2 bytes (strides in elements = bytes)
+  // KV-range parts (round 4, PARTS kernels): an item = (query block, head group, request) whose prefix + extend tiles number
+  // more than part_tiles is cut into up to smax consecutive tile ranges, one workgroup each; every part stores its
+  // (O, m, l) and counts itself in on part_counters[item]; the one that completes the count merges all of them in part order.
+  float* part_ws;              // [item][smax][owner wave][(Dv / 32) * 16 + 2][64] floats
+  int32_t* part_counters;      // [items], zero before the first launch; left zero
+  int smax, part_tiles;
 };
 
 __device__ __forceinline__ void seq_info(const ExtendArgs& a, int b, int64_t& idx_base, int& prefix, int& ext,
@@ -132,9 +138,14 @@ __device__ __forceinline__ float round_fp8(float x, bool e5) {
 // workgroup per CU or less) finishes in half the time; the workgroup covers 2 (GH = 2) or 1 head(s).
 // NSTAGE (round 3): K/V tiles in LDS; two everywhere (more tiles in flight at one workgroup per CU were measured slower for
 // the short single-request prefill, see dispatch()).
-template <int DTYPE, int D, typename IdxT, int GH, bool MASKED, bool KV8 = false, int KSPLIT = 1, int NSTAGE = 2>
+// PARTS (round 4): the tiles of an item are cut into consecutive ranges over several workgroups (ExtendArgs::part_ws) -- for
+// the launches that leave most of the chip idle behind a long serial chain: one short request behind a long cached prefix
+// (32-64 workgroups of 20-70 tiles each) and the heaviest query blocks of a single 1024-token prefill.
+template <int DTYPE, int D, typename IdxT, int GH, bool MASKED, bool KV8 = false, int KSPLIT = 1, int NSTAGE = 2,
+          bool PARTS = false>
 __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
   static_assert(NSTAGE >= 2 && NSTAGE <= 4 && (!KV8 || NSTAGE == 2), "the FP8 staging area is laid out for two stages");
+  static_assert(!PARTS || (!KV8 && !MASKED), "KV-range parts: 16-bit pools, no custom mask / window");
   using H = Half16<DTYPE>;
   using T = typename H::T;
   using x8 = typename H::x8;
@@ -164,8 +175,14 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
   // blockIdx.x = mblk' * (B * Hq/GH) + (b * Hq/GH + hgrp): ALL the heavy (late, long-prefix) query blocks of every
   // request and head group are dispatched before any lighter one (longest-processing-time-first over the whole grid)
   const int hgroups = a.num_heads / GH;
-  const int nbh = (int)(gridDim.x / a.num_mblocks);  // B * hgroups
   int bid = blockIdx.x;
+  int part = 0;
+  if constexpr (PARTS) {  // the parts of an item are neighbours in the launch order: dispatched, and done, at about the same time
+    part = bid % a.smax;
+    bid /= a.smax;
+  }
+  const int item = bid;
+  const int nbh = (int)(gridDim.x / (PARTS ? a.smax : 1) / a.num_mblocks);  // B * hgroups
   const int mblk = a.num_mblocks - 1 - (bid / nbh);
   bid %= nbh;
   const int hgrp = bid % hgroups;
@@ -218,6 +235,18 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
   }
   const int nt1 = (prefix + kBN - 1) / kBN;
   const int nt2 = (n_ext_keys + kBN - 1) / kBN;
+  // this workgroup's tiles: [pt0, pt1) of the item's nt1 + nt2 (prefix tiles first)
+  int pt0 = 0, pt1 = nt1 + nt2, nparts = 1;
+  if constexpr (PARTS) {
+    const int ntot = nt1 + nt2;
+    nparts = (ntot + a.part_tiles - 1) / a.part_tiles;
+    nparts = nparts < 1 ? 1 : (nparts > a.smax ? a.smax : nparts);
+    if (part >= nparts) return;
+    const int per = (ntot + nparts - 1) / nparts;
+    pt0 = part * per;
+    pt1 = pt0 + per < ntot ? pt0 + per : ntot;
+    if (pt0 >= pt1) { pt0 = pt1 = 0; }  // (an empty trailing part still counts itself in below)
+  }
 
   float m_run = -INFINITY, l_run = 0.f;
   f32x16 o_acc[NDVB];
@@ -517,6 +546,9 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
 
   for (int i0 = 0; i0 < prefix; i0 += kIdxCap) {
     const int n = (prefix - i0) < kIdxCap ? (prefix - i0) : kIdxCap;
+    if constexpr (PARTS) {  // passes outside this part's range are skipped (workgroup-uniform)
+      if ((i0 + n + kBN - 1) / kBN <= pt0 || i0 / kBN >= pt1) continue;
+    }
     {
       const IdxT* src = reinterpret_cast<const IdxT*>(a.indices) + idx_base + i0;
       for (int i = tid; i < n; i += 256) idx_lds[i] = (int32_t)src[i];
@@ -525,18 +557,30 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
     if constexpr (KV8) {
       run_phase8(i0 / kBN, (i0 + n + kBN - 1) / kBN, i0, i0 + n);
     } else {
-      run_phase(0, i0 / kBN, (i0 + n + kBN - 1) / kBN, i0, i0 + n);  // kIdxCap is a multiple of kBN
+      if constexpr (PARTS) {
+        const int tb = i0 / kBN > pt0 ? i0 / kBN : pt0;
+        const int te = (i0 + n + kBN - 1) / kBN < pt1 ? (i0 + n + kBN - 1) / kBN : pt1;
+        run_phase(0, tb, te, i0, i0 + n);
+      } else {
+        run_phase(0, i0 / kBN, (i0 + n + kBN - 1) / kBN, i0, i0 + n);  // kIdxCap is a multiple of kBN
+      }
     }
     __syncthreads();
   }
   if constexpr (KV8) {
     if (prefix > 0) load_q(false);
   }
-  (void)nt1;
-  run_phase(1, 0, nt2, 0, n_ext_keys);
+  if constexpr (PARTS) {
+    const int tb = pt0 > nt1 ? pt0 - nt1 : 0;
+    const int te = pt1 > nt1 ? pt1 - nt1 : 0;
+    run_phase(1, tb, te, 0, n_ext_keys);
+  } else {
+    run_phase(1, 0, nt2, 0, n_ext_keys);
+  }
 
   // ---- epilogue: out = acc / l ; lane (col = qrow, hh), reg r -> dv = 32*dvb + (r&3) + 8(r>>2) + 4hh
   l_run += __shfl_xor(l_run, 32);
+  bool owner = true;  // this wave holds a (head, position block)'s result
   if constexpr (KSPLIT == 2) {
     // merge the two key halves: wave kh = 1 hands (O, m, l) to its partner through LDS, element i of lane l at [i][l]
     __syncthreads();  // every wave is past its last tile: the stages are dead
@@ -550,16 +594,89 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
       mo[(NDVB * 16 + 1) * 64 + lane] = l_run;
     }
     __syncthreads();
-    if (kh == 1) return;
-    const float m_b = mo[(NDVB * 16) * 64 + lane], l_b = mo[(NDVB * 16 + 1) * 64 + lane];
-    const float m_new = fmaxf(m_run, m_b);
-    const float m_safe = m_new == -INFINITY ? 0.f : m_new;
-    const float fa = __builtin_amdgcn_exp2f(m_run - m_safe), fb = __builtin_amdgcn_exp2f(m_b - m_safe);
-    l_run = l_run * fa + l_b * fb;
+    if constexpr (!PARTS) {
+      if (kh == 1) return;
+    }
+    owner = kh == 0;  // (PARTS: the other waves stay for the barriers below)
+    if (owner) {
+      const float m_b = mo[(NDVB * 16) * 64 + lane], l_b = mo[(NDVB * 16 + 1) * 64 + lane];
+      const float m_new = fmaxf(m_run, m_b);
+      const float m_safe = m_new == -INFINITY ? 0.f : m_new;
+      const float fa = __builtin_amdgcn_exp2f(m_run - m_safe), fb = __builtin_amdgcn_exp2f(m_b - m_safe);
+      l_run = l_run * fa + l_b * fb;
+      m_run = m_new;
 #pragma unroll
-    for (int i = 0; i < NDVB; ++i)
+      for (int i = 0; i < NDVB; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o_acc[i][r] = o_acc[i][r] * fa + mo[(16 * i + r) * 64 + lane] * fb;
+        for (int r = 0; r < 16; ++r) o_acc[i][r] = o_acc[i][r] * fa + mo[(16 * i + r) * 64 + lane] * fb;
+    }
+  }
+  if constexpr (PARTS) {
+    if (nparts > 1) {  // (workgroup-uniform)
+      // Every part stores its (O, m, l) write-through (agent-scope relaxed atomics = sc1: the other parts may run on
+      // another XCD, and a device-scope fence costs more than it saves -- attention_decode.hip arrive_and_merge), counts
+      // itself in, and the part that completes the count merges ALL parts in part order (its own included: the result does
+      // not depend on which part came last).
+      constexpr int OW = GH * NPB;                 // owner waves per workgroup
+      constexpr int PART = (NDVB * 16 + 2) * 64;   // floats per stored partial
+      float* base = a.part_ws + ((int64_t)item * a.smax * OW + (wave % OW)) * PART;
+      // a partial = (NDVB * 8 + 1) pairs per lane, pair e of lane l at [e][l]: 8-byte stores / loads, 512 B per wave-instruction
+      typedef unsigned long long u64;
+      auto pack2 = [](float x, float y) -> u64 {
+        return (u64)__builtin_bit_cast(unsigned, x) | ((u64)__builtin_bit_cast(unsigned, y) << 32);
+      };
+      if (owner) {
+        u64* mine = reinterpret_cast<u64*>(base + (int64_t)part * OW * PART);
+#pragma unroll
+        for (int i = 0; i < NDVB; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; r += 2)
+            __hip_atomic_store(mine + (8 * i + (r >> 1)) * 64 + lane, pack2(o_acc[i][r], o_acc[i][r + 1]), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine + (NDVB * 8) * 64 + lane, pack2(m_run, l_run), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's stores are acknowledged
+      __syncthreads();                                  // ... and everyone's; idx_lds is dead
+      int* s_last = reinterpret_cast<int*>(idx_lds);
+      if (tid == 0) {
+        const int old = __hip_atomic_fetch_add(a.part_counters + item, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *s_last = old == nparts - 1;
+        // the next launch starts from zero again (nobody else touches the counter before then)
+        if (old == nparts - 1) __hip_atomic_store(a.part_counters + item, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+      if (!*s_last || !owner) return;
+      m_run = -INFINITY;
+      l_run = 0.f;
+#pragma unroll
+      for (int i = 0; i < NDVB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o_acc[i][r] = 0.f;
+      for (int q = 0; q < nparts; ++q) {
+        const u64* pq = reinterpret_cast<const u64*>(base + (int64_t)q * OW * PART);
+        u64 w[NDVB * 8 + 1];  // every load of the part in flight before the first use
+#pragma unroll
+        for (int e = 0; e < NDVB * 8 + 1; ++e)
+          w[e] = __hip_atomic_load(pq + e * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float m_b = __builtin_bit_cast(float, (unsigned)w[NDVB * 8]);
+        const float l_b = __builtin_bit_cast(float, (unsigned)(w[NDVB * 8] >> 32));
+        const float m_new = fmaxf(m_run, m_b);
+        const float m_safe = m_new == -INFINITY ? 0.f : m_new;
+        const float fa = __builtin_amdgcn_exp2f(m_run - m_safe), fb = __builtin_amdgcn_exp2f(m_b - m_safe);
+        l_run = l_run * fa + l_b * fb;
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < NDVB; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            const u64 v = w[8 * i + (r >> 1)];
+            o_acc[i][r] = o_acc[i][r] * fa + __builtin_bit_cast(float, (unsigned)v) * fb;
+            o_acc[i][r + 1] = o_acc[i][r + 1] * fa + __builtin_bit_cast(float, (unsigned)(v >> 32)) * fb;
+          }
+      }
+    } else if (!owner) {
+      return;
+    }
   }
   if (q_ok) {
     const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
@@ -652,9 +769,10 @@ __global__ __launch_bounds__(64) void extend_generic_kernel(ExtendArgs a, int D,
   }
 }
 
-template <int DTYPE, int D, typename IdxT, int GH, bool MASKED, bool KV8 = false, int KSPLIT = 1, int NSTAGE = 2>
+template <int DTYPE, int D, typename IdxT, int GH, bool MASKED, bool KV8 = false, int KSPLIT = 1, int NSTAGE = 2,
+          bool PARTS = false>
 int launch_mfma(ExtendArgs a, int64_t batch, int max_len_extend, hipStream_t s) {
-  auto kern = extend_mfma_kernel<DTYPE, D, IdxT, GH, MASKED, KV8, KSPLIT, NSTAGE>;
+  auto kern = extend_mfma_kernel<DTYPE, D, IdxT, GH, MASKED, KV8, KSPLIT, NSTAGE, PARTS>;
   constexpr int lds = NSTAGE * 2 * kBN * D * 2 + kIdxCap * 4;
   static int attr_rc = check_hip(
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
@@ -662,7 +780,7 @@ int launch_mfma(ExtendArgs a, int64_t batch, int max_len_extend, hipStream_t s) 
   if (attr_rc) return attr_rc;
   constexpr int BP = 32 * (4 / (GH * KSPLIT));
   a.num_mblocks = (max_len_extend + BP - 1) / BP;
-  const int64_t grid = batch * (a.num_heads / GH) * a.num_mblocks;
+  const int64_t grid = batch * (a.num_heads / GH) * a.num_mblocks * (PARTS ? a.smax : 1);
   if (grid <= 0) return 0;
   if (grid >= (1ll << 31)) {
     set_error("extend_attention: grid too large");
@@ -674,8 +792,47 @@ int launch_mfma(ExtendArgs a, int64_t batch, int max_len_extend, hipStream_t s) 
   return check_hip(hipGetLastError(), "extend_mfma_kernel launch");
 }
 
+// what the caller of the _parts entry point knows about the batch and lends to the launch
+struct PartsHint {
+  int64_t max_prefix_len = 0;
+  int64_t ws_floats = 0, n_counters = 0;
+};
+
+// KV-range parts for this form (GH heads x NPB position blocks per workgroup, D = 128)?  Sets a.smax / a.part_tiles.
+// Only launches that leave the chip part empty behind long chains: at most 128 items whose longest has 12 tiles or more;
+// up to 4 parts per item, 8 up to 32 items (the merging workgroup reads them all back: more parts, longer tail),
+// parts of at least 4 tiles.  SGL_MI355_EXTEND_PARTS=0 switches it off, SGL_MI355_EXTEND_SMAX=n sets the cap, SGL_MI355_EXTEND_PARTS_MAX_ITEMS=n
+// the item limit (A/B aids).
+inline bool plan_parts(ExtendArgs& a, const PartsHint& h, int64_t batch, int GH, int NPB, int max_len_extend) {
+  static const int parts_env = [] { const char* e = getenv("SGL_MI355_EXTEND_PARTS"); return e ? atoi(e) : 1; }();
+  static const int smax_env = [] { const char* e = getenv("SGL_MI355_EXTEND_SMAX"); return e ? atoi(e) : 0; }();
+  if (!parts_env || a.part_ws == nullptr || a.part_counters == nullptr) return false;
+  const int BP = 32 * NPB;
+  const int64_t items = batch * (a.num_heads / GH) * ((max_len_extend + BP - 1) / BP);
+  const int64_t ntot_max = (h.max_prefix_len + kBN - 1) / kBN + (max_len_extend + kBN - 1) / kBN;
+  // (measured, profiles/r04_extend_parts.txt: with more than 128 items the partials' write-through stores and the merging
+  //  workgroups' reads cost more than the shorter chains give back -- 4 requests of 128 new tokens behind 1024-token prefixes
+  //  27.9 -> 45.7 us, the single 1024-token prefill 27.0 -> 33.8; one such request 24.9 -> 20.4, behind 4096 / 16384 tokens
+  //  74.9 / 262.6 -> 34.4 / 89.8)
+  static const int items_env = [] { const char* e = getenv("SGL_MI355_EXTEND_PARTS_MAX_ITEMS"); return e ? atoi(e) : 128; }();
+  if (items > items_env || items > 512 || ntot_max < 12 || items > h.n_counters) return false;
+  // parts per item: 4, 8 up to 32 items (same box, us, 4 -> 8 parts: 64 new tokens behind 8192 50.7 -> 39.6, one kv head's rank
+  // 30.2 -> 29.0; but 64 items 34.5 -> 38.2, 128 items 44.2 -> 68.0: the merging workgroup reads every part back)
+  const int64_t cap = smax_env > 0 ? smax_env : (items <= 32 ? 8 : 4);
+  int64_t smax = 1024 / items;
+  smax = smax > cap ? cap : smax;
+  if (smax > (ntot_max + 3) / 4) smax = (ntot_max + 3) / 4;
+  if (smax < 2) return false;
+  const int64_t part_floats = (128 / 32 * 16 + 2) * 64;
+  if (items * smax * GH * NPB * part_floats > h.ws_floats) return false;
+  a.smax = (int)smax;
+  a.part_tiles = (int)((ntot_max + smax - 1) / smax);
+  if (a.part_tiles < 4) a.part_tiles = 4;
+  return true;
+}
+
 template <int DTYPE, typename IdxT>
-int dispatch(ExtendArgs a, int64_t batch, int D, int Dv, int max_len_extend, hipStream_t s) {
+int dispatch(ExtendArgs a, int64_t batch, int D, int Dv, int max_len_extend, hipStream_t s, const PartsHint& hint = PartsHint{}) {
   const bool aligned = (a.q_st % 8 == 0) && (a.q_sh % 8 == 0) && (a.ke_st % 8 == 0) && (a.ke_sh % 8 == 0) &&
                        (a.ve_st % 8 == 0) && (a.ve_sh % 8 == 0) && (a.kb_sn % 8 == 0) && (a.kb_sh % 8 == 0) &&
                        (a.vb_sn % 8 == 0) && (a.vb_sh % 8 == 0) && (a.o_st % 4 == 0) && (a.o_sh % 4 == 0) &&
@@ -728,7 +885,19 @@ int dispatch(ExtendArgs a, int64_t batch, int D, int Dv, int max_len_extend, hip
       static const int ks_env = [] { const char* e = getenv("SGL_MI355_EXTEND_KSPLIT"); return e ? atoi(e) : -1; }();
       const int bp1 = 32 * (4 / gh);
       const int64_t grid1 = batch * (a.num_heads / gh) * ((max_len_extend + bp1 - 1) / bp1);
-      const bool ksplit = ks_env >= 0 ? ks_env != 0 : (grid1 <= 512 && max_len_extend >= 256);
+      // Round 4: short extends as well while the unsplit form has at most 128 workgroups (half a workgroup per CU): same box, us,
+      // unsplit -> split: one request of 64 / 128 / 192 new tokens 9.1 / 10.1 / 11.5 -> 7.4 / 8.1 / 9.1; 128 new tokens behind
+      // a 1024- / 4096-token prefix 32.6 / 97.1 -> 24.6 / 74.2; four such requests 34.6 -> 28.9; eight tie (38.5 / 39.0),
+      // sixteen lose (58.5 -> 94.4)  (profiles/r04_extend_short_ksplit.txt)
+      const bool ksplit = ks_env >= 0 ? ks_env != 0 : ((grid1 <= 512 && max_len_extend >= 256) || grid1 <= 128);
+      if (ksplit && !masked && D == 128) {
+        const int ghk = gh == 4 ? 2 : 1;
+        if (plan_parts(a, hint, batch, ghk, 4 / (ghk * 2), max_len_extend)) {
+          if (ghk == 2) return launch_mfma<DTYPE, 128, int32_t, 2, false, false, 2, 2, true>(a, batch, max_len_extend, s);
+          return launch_mfma<DTYPE, 128, int32_t, 1, false, false, 2, 2, true>(a, batch, max_len_extend, s);
+        }
+      }
+      // (the forms without the key split start at 129 workgroups: never few enough items for parts)
       if (ksplit && !masked) {
         // (Round 3: more tiles in flight -- NSTAGE 3 / 4, one workgroup per CU instead of two -- do NOT help: 38.8 / 38.9 us
         //  against 35.8 at 1024 tokens, 83 against 54 at 1536 (profiles/r03_extend_nstage.txt).  The longest block's chain is
@@ -804,7 +973,8 @@ static int extend_fwd_impl(int kv8,
     int64_t ve_stride_t, int64_t ve_stride_h, int64_t o_stride_t, int64_t o_stride_h, int64_t kb_stride_n,
     int64_t kb_stride_h, int64_t vb_stride_n, int64_t vb_stride_h, float sm_scale, float logit_cap,
     const uint8_t* custom_mask, const int64_t* mask_indptr, int skip_prefix_custom_mask, int64_t sliding_window_size,
-    int dtype, void* stream) {
+    int dtype, void* stream, int64_t max_prefix_len = 0, float* workspace = nullptr, int64_t workspace_floats = 0,
+    int32_t* counters = nullptr, int64_t num_counters = 0) {
   int rc = check_common(batch, num_heads, num_kv_heads, head_size, head_size_v, max_len_extend, dtype);
   if (rc) return rc;
   if (batch == 0 || max_len_extend == 0) return 0;
@@ -826,10 +996,44 @@ static int extend_fwd_impl(int kv8,
   a.mask = custom_mask; a.mask_indptr = mask_indptr; a.skip_prefix_mask = skip_prefix_custom_mask;
   a.window = sliding_window_size > 0 ? (int)sliding_window_size : 0;
   a.kv8 = kv8;
+  PartsHint hint;
+  if (workspace != nullptr && counters != nullptr && !kv8 && max_prefix_len >= 0) {
+    a.part_ws = workspace;
+    a.part_counters = counters;
+    hint.max_prefix_len = max_prefix_len;
+    hint.ws_floats = workspace_floats;
+    hint.n_counters = num_counters;
+  }
   hipStream_t s = as_stream(stream);
   return dtype == SGL_MI355_BF16
-             ? dispatch<SGL_MI355_BF16, int32_t>(a, batch, (int)head_size, (int)head_size_v, (int)max_len_extend, s)
-             : dispatch<SGL_MI355_FP16, int32_t>(a, batch, (int)head_size, (int)head_size_v, (int)max_len_extend, s);
+             ? dispatch<SGL_MI355_BF16, int32_t>(a, batch, (int)head_size, (int)head_size_v, (int)max_len_extend, s, hint)
+             : dispatch<SGL_MI355_FP16, int32_t>(a, batch, (int)head_size, (int)head_size_v, (int)max_len_extend, s, hint);
+}
+
+// The same with what lets short launches use the whole chip (round 4): max_prefix_len = an upper bound of the batch's cached
+// prefix lengths (the kernel reads the true ones from kv_indptr; the bound only sizes the split), an fp32 workspace and
+// int32 counters (ZERO before the first call; the kernel leaves them zero), both owned by the caller and not shared with a
+// launch that may run concurrently.  With at most 512 (query block, head group) items whose longest has 8 key tiles or
+// more, every item's tiles are cut into up to 4 consecutive ranges over as many workgroups; each stores its (O, m, l), the
+// last one to finish merges them in range order (deterministic).  16-bit pools, head size 128, no custom mask / window; anything else, a
+// null workspace or one that is too small runs exactly as sgl_mi355_extend_attention_fwd.
+extern "C" int sgl_mi355_extend_attention_fwd_parts(
+    const void* q_extend, const void* k_extend, const void* v_extend, void* o_extend, const void* k_buffer,
+    const void* v_buffer, const int32_t* qo_indptr, const int32_t* kv_indptr, const int32_t* kv_indices, int is_causal,
+    int64_t max_len_extend, int64_t batch, int64_t num_heads, int64_t num_kv_heads, int64_t head_size,
+    int64_t head_size_v, int64_t q_stride_t, int64_t q_stride_h, int64_t ke_stride_t, int64_t ke_stride_h,
+    int64_t ve_stride_t, int64_t ve_stride_h, int64_t o_stride_t, int64_t o_stride_h, int64_t kb_stride_n,
+    int64_t kb_stride_h, int64_t vb_stride_n, int64_t vb_stride_h, float sm_scale, float logit_cap,
+    const uint8_t* custom_mask, const int64_t* mask_indptr, int skip_prefix_custom_mask, int64_t sliding_window_size,
+    int dtype, void* stream, int64_t max_prefix_len, float* workspace, int64_t workspace_floats, int32_t* counters,
+    int64_t num_counters) {
+  SGLM_CHECK_ARG(max_prefix_len >= 0 && workspace_floats >= 0 && num_counters >= 0, "extend_attention_fwd_parts: negative size");
+  return extend_fwd_impl(0, q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices,
+                         is_causal, max_len_extend, batch, num_heads, num_kv_heads, head_size, head_size_v, q_stride_t,
+                         q_stride_h, ke_stride_t, ke_stride_h, ve_stride_t, ve_stride_h, o_stride_t, o_stride_h,
+                         kb_stride_n, kb_stride_h, vb_stride_n, vb_stride_h, sm_scale, logit_cap, custom_mask, mask_indptr,
+                         skip_prefix_custom_mask, sliding_window_size, dtype, stream, max_prefix_len, workspace,
+                         workspace_floats, counters, num_counters);
 }
 
 extern "C" int sgl_mi355_extend_attention_fwd(

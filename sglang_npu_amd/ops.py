@@ -399,11 +399,25 @@ def _check3(name, t):
         raise RuntimeError(f"{name} must be 3-D, contiguous at the last dimension")
 
 
+class ExtendPartsScratch:
+    """Scratch of the KV-range-parts form of the extend kernel (sgl_mi355_extend_attention_fwd_parts): fp32 partials and
+    zeroed int32 counters, owned by ONE caller (an attention backend) and never shared between launches that may overlap."""
+    __slots__ = ("workspace", "counters")
+
+    def __init__(self, device, megabytes: int = 20, num_counters: int = 1024):  # (512 parts x 2 owner waves x 16.9 KB = 17.3 MB at most)
+        self.workspace = torch.empty(megabytes * (1 << 20) // 4, dtype=torch.float32, device=device)
+        self.counters = torch.zeros(num_counters, dtype=torch.int32, device=device)
+
+
 def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices,
                          custom_mask, is_causal, mask_indptr, max_len_extend, sm_scale=None, logit_cap=0.0,
-                         skip_prefix_custom_mask=True, sliding_window_size=-1):
+                         skip_prefix_custom_mask=True, sliding_window_size=-1, *, max_prefix_len: Optional[int] = None,
+                         parts_scratch: Optional[ExtendPartsScratch] = None):
     """extend_attention_fwd(...) -- python/sglang/srt/layers/attention/triton_ops/extend_attention.py:306-438,
-    same arguments in the same order (custom_mask: bool/uint8 [sum ext*(prefix+ext)], mask_indptr int64 [B+1])."""
+    same arguments in the same order (custom_mask: bool/uint8 [sum ext*(prefix+ext)], mask_indptr int64 [B+1]).
+    Keyword-only additions: max_prefix_len (an upper bound of the batch's cached prefix lengths, known on the host) and
+    parts_scratch let launches with few, long items spread every item's keys over several workgroups (include/sgl_mi355.h
+    sgl_mi355_extend_attention_fwd_parts); without them the call is the reference's."""
     cm = mi = None
     if custom_mask is not None:
         if mask_indptr is None:
@@ -424,9 +438,8 @@ def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buf
         raise RuntimeError("extend_attention_fwd: qo_indptr, kv_indptr and kv_indices must be int32")
     D = q_extend.size(2)
     sm_scale = sm_scale if sm_scale is not None else 1.0 / (D ** 0.5)
-    # FP8 (e4m3) KV pool: the prefix stage reads FP8 rows with q and p rounded to FP8 (extend_attention.py:149, :200)
-    fn = _kv_fn("sgl_mi355_extend_attention_fwd", _kv_format(k_buffer, v_buffer, q_extend))
-    _lib.check(fn(
+    fmt = _kv_format(k_buffer, v_buffer, q_extend)
+    args = (
         _ptr(q_extend), _ptr(k_extend), _ptr(v_extend), _ptr(o_extend), _ptr(k_buffer), _ptr(v_buffer),
         _ptr(qo_indptr), _ptr(kv_indptr), _ptr(kv_indices), _I(1 if is_causal else 0), _I64(max_len_extend),
         _I64(qo_indptr.numel() - 1), _I64(q_extend.size(1)), _I64(k_extend.size(1)), _I64(D), _I64(v_extend.size(2)),
@@ -434,7 +447,15 @@ def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buf
         _I64(v_extend.stride(0)), _I64(v_extend.stride(1)), _I64(o_extend.stride(0)), _I64(o_extend.stride(1)),
         _I64(k_buffer.stride(0)), _I64(k_buffer.stride(1)), _I64(v_buffer.stride(0)), _I64(v_buffer.stride(1)),
         _F(sm_scale), _F(logit_cap), _ptr(cm), _ptr(mi), _I(1 if skip_prefix_custom_mask else 0), _I64(window),
-        _I(_dtype_code(q_extend)), _stream(q_extend)))
+        _I(_dtype_code(q_extend)), _stream(q_extend))
+    if parts_scratch is not None and max_prefix_len is not None and fmt == 0 and cm is None and window <= 0:
+        ws, ctr = parts_scratch.workspace, parts_scratch.counters
+        _need_gpu(ws, ctr)
+        _lib.check(_lib.lib().sgl_mi355_extend_attention_fwd_parts(
+            *args, _I64(int(max_prefix_len)), _ptr(ws), _I64(ws.numel()), _ptr(ctr), _I64(ctr.numel())))
+        return
+    # FP8 (e4m3) KV pool: the prefix stage reads FP8 rows with q and p rounded to FP8 (extend_attention.py:149, :200)
+    _lib.check(_kv_fn("sgl_mi355_extend_attention_fwd", fmt)(*args))
 
 
 def merge_state(prefix_output, prefix_lse, suffix_output, suffix_lse, output=None, output_lse=None):

@@ -32,11 +32,13 @@ def test_extend_op_form_vs_golden(name):
         assert err_ref <= 2 * bound, f"{name}: |hip - reference kernel| = {err_ref:.3e}"
 
 
-def _case(B, Hq, Hkv, D, max_prefix, max_ext, dtype, seed, zero_prefix=False):
+def _case(B, Hq, Hkv, D, max_prefix, max_ext, dtype, seed, zero_prefix=False, pin_first_prefix=False):
     g = torch.Generator().manual_seed(seed)
     prefix = torch.randint(0, max_prefix + 1, (B,), generator=g)
     if zero_prefix:
         prefix.zero_()
+    if pin_first_prefix:  # the first request has the longest prefix the case allows
+        prefix[0] = max_prefix
     ext = torch.randint(1, max_ext + 1, (B,), generator=g)
     ext[0] = max_ext
     seq = prefix + ext

@@ -10,7 +10,10 @@ dev = "cuda:0"
 CASES = [(1, 32, 8, 256, 0), (1, 32, 8, 512, 0), (1, 32, 8, 1024, 0), (1, 32, 8, 2048, 0), (1, 32, 8, 4096, 0),
          (1, 32, 8, 8192, 0), (4, 32, 8, 512, 2048), (4, 32, 8, 2048, 0), (8, 8, 1, 1024, 0), (1, 32, 32, 1024, 0),
          (16, 32, 8, 128, 1024)]
-VARIANTS = [("kernel", None)]
+if os.environ.get("CASES"):  # "B,Hq,Hkv,L,P;..." replaces the list
+    CASES = [tuple(int(x) for x in c.split(",")) for c in os.environ["CASES"].split(";")]
+VARIANTS = [("kernel", None), ("parts", "parts")]  # parts: with the host's prefix bound + scratch (KV-range parts where they apply)
+scratch = ops.ExtendPartsScratch(dev)
 for (B, Hq, Hkv, L, P) in CASES:
     D = 128
     g = torch.Generator(device=dev).manual_seed(0)
@@ -28,7 +31,8 @@ for (B, Hq, Hkv, L, P) in CASES:
     row = dict(B=B, Hq=Hq, Hkv=Hkv, L=L, prefix=P)
     flops = 4.0 * B * Hq * D * (L * P + L * (L + 1) / 2)
     for name, var in VARIANTS:
-        f = lambda: ops.extend_attention_fwd(q, ke, ve, o, kb, vb, qo, kvp, idx, None, True, None, L, D ** -0.5, 0.0)
+        kw = dict(max_prefix_len=P, parts_scratch=scratch) if var == "parts" else {}
+        f = lambda: ops.extend_attention_fwd(q, ke, ve, o, kb, vb, qo, kvp, idx, None, True, None, L, D ** -0.5, 0.0, **kw)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
