@@ -36,7 +36,7 @@ cp gpurun_out/pmc_r4/stats/*/*kernel_stats.csv gpurun_out/r04_bench_tp1_kernel_s
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/pmc_r4/trace -- python3 bench.py --steps 16 --warmup 2 --no-cpu-baseline --no-other-configs > gpurun_out/pmc_r4_trace.log 2>&1
 python3 tools/layer_breakdown.py gpurun_out/pmc_r4/trace/*/*kernel_trace.csv > gpurun_out/r04_layer_breakdown_decode.txt 2>&1
 cat gpurun_out/r04_layer_breakdown_decode.txt
-python3 tools/layer_breakdown.py gpurun_out/pmc_r4/trace/*/*kernel_trace.csv "extend_mfma_kernel<0, 128, int, 2, false, false, 2" > gpurun_out/r04_layer_breakdown_prefill.txt 2>&1
+python3 tools/layer_breakdown.py gpurun_out/pmc_r4/trace/*/*kernel_trace.csv "extend_mfma_kernel<0, 128, int, 2, false, false, 2" fp8_gemm_tiled3 > gpurun_out/r04_layer_breakdown_prefill.txt 2>&1
 cat gpurun_out/r04_layer_breakdown_prefill.txt
 # the per-launch counter rows of the decode attention kernel (small), then drop the raw traces (tens of MB)
 python3 - <<'PY'
@@ -52,6 +52,6 @@ for counter, d in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
 PY
 rm -rf gpurun_out/pmc_r4
 
-python3 tools/layer_breakdown.py gpurun_out/pmc_r4/trace/*/*kernel_trace.csv "extend_mfma_kernel<0, 128, int, 4, false, false, 1" > gpurun_out/r04_layer_breakdown_prefill_128.txt 2>&1
+python3 tools/layer_breakdown.py gpurun_out/pmc_r4/trace/*/*kernel_trace.csv "extend_mfma_kernel<0, 128, int, 2, false, false, 2" "fp8_gemm_wstream_kernel<0, 8" > gpurun_out/r04_layer_breakdown_prefill_128.txt 2>&1
 cat gpurun_out/r04_layer_breakdown_prefill_128.txt
 rm -rf gpurun_out/pmc_r4

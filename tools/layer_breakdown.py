@@ -4,14 +4,16 @@ to the next kernel's start; its own duration is End - Start).
 
     rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof -- python3 bench.py --steps 16 --warmup 2 \
         --no-cpu-baseline --no-other-configs
-    python tools/layer_breakdown.py gpurun_out/prof/*/*kernel_trace.csv [anchor-substring]
+    python tools/layer_breakdown.py gpurun_out/prof/*/*kernel_trace.csv [anchor-substring [must-contain-substring]]
 
 A layer = the kernels from one launch of the anchor kernel (default: the decode attention kernel) to the next one; the
-median layer (by total span) of all complete layers in the trace is printed."""
+median layer (by total span) of all complete layers in the trace is printed.  must-contain: only layers in which some kernel's
+name has that substring (two pass shapes that share the anchor kernel, e.g. 1024- and 128-token prefills, differ in their GEMMs)."""
 import csv, glob, statistics, sys
 
 path = sys.argv[1]
 anchor = sys.argv[2] if len(sys.argv) > 2 else "decode_mfma"
+must = sys.argv[3] if len(sys.argv) > 3 else None
 rows = []
 for r in csv.DictReader(open(path)):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
@@ -20,6 +22,8 @@ idx = [i for i, r in enumerate(rows) if anchor in r[2]]
 layers = []
 for a, b in zip(idx, idx[1:]):
     if 6 <= b - a <= 14:  # a decoder layer is 7-12 launches; the steps' first / last layers carry the LM head etc.
+        if must is not None and not any(must in rows[i][2] for i in range(a, b)):
+            continue
         span = rows[b][0] - rows[a][0]
         layers.append((span, a, b))
 if not layers:
