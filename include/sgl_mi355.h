@@ -181,11 +181,12 @@ int sgl_mi355_decode_attention_fwd_fp8kv(
  * (extend_attention.py:41-303) runs one program per (request, head, 64-row query block) over all of its keys; one short request
  * behind a long cached prefix (chunked prefill's later chunks, scheduler.py:1425-1430; a radix-cache hit with a short suffix) is
  * 16-64 such programs of 20-250 key tiles each.  Here, with at most 128 (32-row query block, head group) items whose longest
- * has 12 key tiles or more, every item's tiles are cut into up to 4 consecutive ranges (8 up to 32 items) over as many
- * workgroups; each stores its (O, m, l), and the one that completes the item's count merges all of them in range order
+ * has 12 key tiles or more (up to 256 items from 48 tiles: two ranges), every item's tiles are cut into up to 4 consecutive
+ * ranges (8 up to 32 items) over as many workgroups; each stores its (O, m, l), and the one that completes the item's count
+ * merges all of them in range order
  * (deterministic; not bit-identical to the unsplit sum order).  max_prefix_len: an upper bound of the batch's prefix lengths as
  * the host knows them (forward_batch.extend_prefix_lens_cpu; the kernel reads the true ones from kv_indptr).  workspace: fp32
- * scratch, items * parts * 2 owner waves * 4224 floats (17.3 MB at most); counters: int32, >= 128, ZERO before the first call, left
+ * scratch, items * parts * 2 owner waves * 4224 floats (17.3 MB at most); counters: int32, >= 256, ZERO before the first call, left
  * zero.  Both belong to the caller and must not be shared with a launch that may overlap this one.  16-bit pools, head size
  * 128, no custom mask / sliding window; any other call, a null or too small workspace, or SGL_MI355_EXTEND_PARTS=0 runs
  * exactly as sgl_mi355_extend_attention_fwd. */

@@ -799,8 +799,8 @@ struct PartsHint {
 };
 
 // KV-range parts for this form (GH heads x NPB position blocks per workgroup, D = 128)?  Sets a.smax / a.part_tiles.
-// Only launches that leave the chip part empty behind long chains: at most 128 items whose longest has 12 tiles or more;
-// up to 4 parts per item, 8 up to 32 items (the merging workgroup reads them all back: more parts, longer tail),
+// Only launches that leave the chip part empty behind long chains: at most 128 items whose longest has 12 tiles or more
+// (up to 256 from 48 tiles, two parts); up to 4 parts per item, 8 up to 32 items (the merging workgroup reads them all back: more parts, longer tail),
 // parts of at least 4 tiles.  SGL_MI355_EXTEND_PARTS=0 switches it off, SGL_MI355_EXTEND_SMAX=n sets the cap, SGL_MI355_EXTEND_PARTS_MAX_ITEMS=n
 // the item limit (A/B aids).
 inline bool plan_parts(ExtendArgs& a, const PartsHint& h, int64_t batch, int GH, int NPB, int max_len_extend) {
@@ -814,11 +814,15 @@ inline bool plan_parts(ExtendArgs& a, const PartsHint& h, int64_t batch, int GH,
   //  workgroups' reads cost more than the shorter chains give back -- 4 requests of 128 new tokens behind 1024-token prefixes
   //  27.9 -> 45.7 us, the single 1024-token prefill 27.0 -> 33.8; one such request 24.9 -> 20.4, behind 4096 / 16384 tokens
   //  74.9 / 262.6 -> 34.4 / 89.8)
-  static const int items_env = [] { const char* e = getenv("SGL_MI355_EXTEND_PARTS_MAX_ITEMS"); return e ? atoi(e) : 128; }();
-  if (items > items_env || items > 512 || ntot_max < 12 || items > h.n_counters) return false;
+  //  Up to 256 items TWO parts still pay once the chains are long (48 tiles): 4 x 128 / 2 x 256 / 1 x 512 new tokens behind 4096
+  //  84.2 / 83.4 / 82.2 -> 77.4 / 68.3 / 66.2 us, 3 x 128 behind 8192 138.5 -> 105.7; three parts give it back (81.1 / 81.4 / 80.2).
+  static const int items_env = [] { const char* e = getenv("SGL_MI355_EXTEND_PARTS_MAX_ITEMS"); return e ? atoi(e) : 0; }();
+  const bool few = items <= (items_env > 0 ? items_env : 128);
+  const bool some = items_env <= 0 && items <= 256 && ntot_max >= 48;
+  if (!(few || some) || items > 512 || ntot_max < 12 || items > h.n_counters) return false;
   // parts per item: 4, 8 up to 32 items (same box, us, 4 -> 8 parts: 64 new tokens behind 8192 50.7 -> 39.6, one kv head's rank
   // 30.2 -> 29.0; but 64 items 34.5 -> 38.2, 128 items 44.2 -> 68.0: the merging workgroup reads every part back)
-  const int64_t cap = smax_env > 0 ? smax_env : (items <= 32 ? 8 : 4);
+  const int64_t cap = smax_env > 0 ? smax_env : (items <= 32 ? 8 : (few ? 4 : 2));
   int64_t smax = 1024 / items;
   smax = smax > cap ? cap : smax;
   if (smax > (ntot_max + 3) / 4) smax = (ntot_max + 3) / 4;

@@ -24,17 +24,20 @@ def _run(d, B, meta, max_ext, causal, scratch, max_prefix):
     return o
 
 
-# (B, Hq, Hkv, longest prefix, longest extend, dtype, parts expected): at most 128 items of 12 tiles or more take the parts form
+# (B, Hq, Hkv, longest prefix, longest extend, dtype, parts expected): at most 128 items of 12 tiles or more (256 from 48 tiles)
+# take the parts form
 CASES = [(1, 32, 8, 4096, 128, torch.bfloat16, True),    # a short suffix behind a long cached prefix: 64 items x 4 parts
          (1, 32, 8, 1000, 100, torch.bfloat16, True),    # ragged everything
          (1, 8, 1, 3000, 200, torch.bfloat16, True),     # one kv head (a TP rank): group 8
          (1, 32, 32, 1500, 90, torch.bfloat16, True),    # MHA: one head per workgroup, two position blocks
          (1, 16, 8, 5000, 64, torch.float16, True),      # group 2; a prefix of more than one page-table pass (4096 entries)
          (2, 32, 8, 9000, 33, torch.bfloat16, True),     # two requests, one query block each, three passes
+         (2, 32, 8, 4096, 256, torch.bfloat16, True),    # 256 items of 68 tiles: two parts each
          # ... and what stays unsplit: the TTFT shape (512 items), several requests, short chains
          (1, 32, 8, 0, 1024, torch.bfloat16, False), (1, 32, 8, 0, 1000, torch.float16, False),
          (3, 32, 8, 2500, 130, torch.bfloat16, False), (8, 8, 1, 700, 300, torch.bfloat16, False),
-         (6, 32, 8, 1200, 128, torch.bfloat16, False), (1, 32, 8, 500, 128, torch.bfloat16, False)]
+         (6, 32, 8, 1200, 128, torch.bfloat16, False), (1, 32, 8, 500, 128, torch.bfloat16, False),
+         (4, 32, 8, 1024, 128, torch.bfloat16, False)]   # 256 items of 18 tiles: chains too short for two parts
 
 
 @pytest.mark.parametrize("B,Hq,Hkv,max_prefix,max_ext,dtype,expect_parts", CASES)
