@@ -257,22 +257,26 @@ def time_attention_kernel(loop, steps):
     return sum(keep) / len(keep), len(durations)
 
 
-def time_ttft(net, runner, backend, device, input_len=1024, reps=7):
+def time_ttft(net, runner, backend, device, input_len=1024, reps=7, prefix_len=0):
     """p50 time-to-first-token at bs=1: one EXTEND (prefill) pass of `input_len` new tokens with an empty
-    prefix through the whole model + greedy sample, device-synchronised (bench_one_batch.py:380-405)."""
+    prefix through the whole model + greedy sample, device-synchronised (bench_one_batch.py:380-405).
+    prefix_len > 0: the new tokens follow that many cached ones (a radix-cache hit / a later chunk of a chunked prefill); the pool
+    rows of the prefix hold what the bench put there (N(0,1))."""
     from sglang_npu_amd.harness import ForwardBatch, ForwardMode
     from sglang_npu_amd.layers import greedy_sample
     r2t = runner.req_to_token_pool.req_to_token
     input_len = min(input_len, r2t.size(1) - 1)
+    prefix_len = max(0, min(prefix_len, r2t.size(1) - 1 - input_len))
     ids = torch.randint(0, 10000, (input_len,), device=device)
-    pos = torch.arange(input_len, device=device)
+    pos = torch.arange(prefix_len, prefix_len + input_len, device=device)
     rpi = torch.zeros(1, dtype=torch.int64, device=device)
-    seq = torch.full((1,), input_len, dtype=torch.int64, device=device)
-    loc = r2t[0, :input_len].to(torch.int64)
+    seq = torch.full((1,), prefix_len + input_len, dtype=torch.int64, device=device)
+    loc = r2t[0, prefix_len:prefix_len + input_len].to(torch.int64)
     zero = torch.zeros(1, dtype=torch.int64, device=device)
+    ext = torch.full((1,), input_len, dtype=torch.int64, device=device)
     fb = ForwardBatch(ForwardMode.EXTEND, 1, ids, rpi, seq, loc, input_len, seq.cpu(), pos,
-                      extend_num_tokens=input_len, extend_seq_lens=seq.clone(), extend_prefix_lens=zero,
-                      extend_start_loc=zero.clone(), extend_prefix_lens_cpu=[0], extend_seq_lens_cpu=[input_len],
+                      extend_num_tokens=input_len, extend_seq_lens=ext, extend_prefix_lens=zero + prefix_len,
+                      extend_start_loc=zero.clone(), extend_prefix_lens_cpu=[prefix_len], extend_seq_lens_cpu=[input_len],
                       req_to_token_pool=runner.req_to_token_pool, token_to_kv_pool=runner.token_to_kv_pool,
                       attn_backend=backend)
     times = []
@@ -1063,6 +1067,18 @@ def main():
             # the headline prompt length replayed the same way (informational: ttft_ms_p50 stays the eager pass, which is what a
             # drop-in backend gets from SGLang -- cuda_graph_runner.py captures decode only)
             out["ttft_ms_p50_graph"] = round(time_ttft_graph(net, runner, backend, device, ttft_len, reps=5), 3)
+            # a short message behind a cached conversation (radix hit): 128 new tokens after as long a prefix as the bench's
+            # context holds; the extend kernel's KV-range parts against the same pass without them
+            pfx = max(0, min(args.ctx - 128, 4096))
+            if pfx >= 1024:
+                t_hit, _ = time_ttft(net, runner, backend, device, input_len=128, prefix_len=pfx)
+                parts, backend._extend_parts = backend._extend_parts, None
+                try:
+                    t_hit_plain, _ = time_ttft(net, runner, backend, device, input_len=128, prefix_len=pfx)
+                finally:
+                    backend._extend_parts = parts
+                out["ttft_ms_p50_128_after_prefix"] = {"prefix_len": pfx, "eager_ms": round(t_hit, 3),
+                                                       "eager_ms_without_kv_range_parts": round(t_hit_plain, 3)}
     except Exception as e:
         out["ttft_ms_p50"] = None
         out["config"]["ttft"] = f"failed: {type(e).__name__}: {e}"
