@@ -293,19 +293,21 @@ def time_ttft(net, runner, backend, device, input_len=1024, reps=7, prefix_len=0
     return times[len(times) // 2], input_len
 
 
-def time_ttft_graph(net, runner, backend, device, input_len=128, reps=9):
+def time_ttft_graph(net, runner, backend, device, input_len=128, reps=9, prefix_len=0):
     """p50 time-to-first-token of a SHORT prompt (bs=1, `input_len` tokens, empty prefix) replayed from a HIP graph captured
-    at that token count (harness.PrefillGraphRunner): the eager pass is host-bound at this size (VERDICT r3 ask 7)."""
+    at that token count (harness.PrefillGraphRunner): the eager pass is host-bound at this size (VERDICT r3 ask 7).
+    prefix_len > 0: the same behind that many cached tokens (graph captured for that prefix bound)."""
     from sglang_npu_amd.harness import PrefillGraphRunner
     r2t = runner.req_to_token_pool.req_to_token
     ids = torch.randint(0, 10000, (input_len,), device=device)
-    slots = r2t[0, :input_len].to(torch.int64)
-    pg = PrefillGraphRunner(net, runner, backend, device, buckets=(input_len,))
+    slots = r2t[0, prefix_len:prefix_len + input_len].to(torch.int64)
+    pre = r2t[0, :prefix_len].to(torch.int64) if prefix_len else None
+    pg = PrefillGraphRunner(net, runner, backend, device, buckets=(input_len,), prefix_buckets=(prefix_len,))
     times = []
     for i in range(reps + 2):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        _, tok = pg.run(ids, slots)
+        _, tok = pg.run(ids, slots, pre)
         tok.item()
         if i >= 2:
             times.append((time.perf_counter() - t0) * 1e3)
@@ -1072,13 +1074,18 @@ def main():
             pfx = max(0, min(args.ctx - 128, 4096))
             if pfx >= 1024:
                 t_hit, _ = time_ttft(net, runner, backend, device, input_len=128, prefix_len=pfx)
+                g_hit = time_ttft_graph(net, runner, backend, device, 128, reps=7, prefix_len=pfx)
                 parts, backend._extend_parts = backend._extend_parts, None
                 try:
                     t_hit_plain, _ = time_ttft(net, runner, backend, device, input_len=128, prefix_len=pfx)
+                    g_hit_plain = time_ttft_graph(net, runner, backend, device, 128, reps=7, prefix_len=pfx)
                 finally:
                     backend._extend_parts = parts
-                out["ttft_ms_p50_128_after_prefix"] = {"prefix_len": pfx, "eager_ms": round(t_hit, 3),
-                                                       "eager_ms_without_kv_range_parts": round(t_hit_plain, 3)}
+                out["ttft_ms_p50_128_after_prefix"] = {
+                    "prefix_len": pfx, "eager_ms": round(t_hit, 3), "eager_ms_without_kv_range_parts": round(t_hit_plain, 3),
+                    "graph_ms": round(g_hit, 3), "graph_ms_without_kv_range_parts": round(g_hit_plain, 3),
+                    "note": "the eager pass is host-bound (~4.6 ms of launches); graph_ms = the same pass replayed from a graph "
+                            "captured for this prefix bound (harness.PrefillGraphRunner)"}
     except Exception as e:
         out["ttft_ms_p50"] = None
         out["config"]["ttft"] = f"failed: {type(e).__name__}: {e}"

@@ -229,36 +229,43 @@ class PrefillGraphRunner:
     guarantees for captured decode steps: the caller's stream, no allocation or host sync inside an op, scratch from
     per-stream pools.
 
-    One request, empty prefix.  A prompt of n tokens runs the graph of the smallest bucket >= n: ids are padded with token 0,
+    One request.  A prompt of n tokens runs the graph of the smallest bucket >= n: ids are padded with token 0,
     the padded rows' K/V go to the pool's padding slot 0, the attention kernel reads n from the device-side qo_indptr (rows
     >= n are not attended), and the last REAL position is selected on the device, so the result for n == bucket is
-    bit-identical to the eager pass and for n < bucket equal up to the GEMMs' row-count-dependent tiling."""
+    bit-identical to the eager pass and for n < bucket equal up to the GEMMs' row-count-dependent tiling.
+    A cached prefix (a radix hit: `prefix_slots` in run()) runs the graph captured for the smallest `prefix_buckets` entry that
+    holds it: that bound sizes the static kv_indices buffer and is what the extend kernel's KV-range parts are planned from (the
+    true prefix length is read from kv_indptr on the device), so any prefix up to the bound replays the same launches."""
 
-    def __init__(self, net, runner, backend, device, buckets=(64, 128, 256, 512)):
+    def __init__(self, net, runner, backend, device, buckets=(64, 128, 256, 512), prefix_buckets=(0,)):
         self.net, self.runner, self.backend, self.device = net, runner, backend, torch.device(device)
         self.buckets = tuple(sorted(buckets))
+        self.prefix_buckets = tuple(sorted(prefix_buckets))
         self._graphs = {}
 
-    def _capture(self, bucket: int):
+    def _capture(self, bucket: int, pbucket: int = 0):
         from .layers import greedy_sample
         dev = self.device
         st = {
             "ids": torch.zeros(bucket, dtype=torch.int64, device=dev),
-            "pos": torch.arange(bucket, device=dev),
+            "pos": torch.arange(pbucket, pbucket + bucket, device=dev),
             "loc": torch.zeros(bucket, dtype=torch.int64, device=dev),
             "rpi": torch.zeros(1, dtype=torch.int64, device=dev),
-            "seq": torch.full((1,), bucket, dtype=torch.int64, device=dev),
+            "seq": torch.full((1,), pbucket + bucket, dtype=torch.int64, device=dev),
             "ext": torch.full((1,), bucket, dtype=torch.int64, device=dev),
+            "pre": torch.full((1,), pbucket, dtype=torch.int64, device=dev),
             "zero": torch.zeros(1, dtype=torch.int64, device=dev),
             "tok": torch.zeros(1, dtype=torch.int64, device=dev),
         }
         fb = ForwardBatch(ForwardMode.EXTEND, 1, st["ids"], st["rpi"], st["seq"], st["loc"], bucket, st["seq"].cpu(), st["pos"],
-                          extend_num_tokens=bucket, extend_seq_lens=st["ext"], extend_prefix_lens=st["zero"],
-                          extend_start_loc=st["zero"].clone(), extend_prefix_lens_cpu=[0], extend_seq_lens_cpu=[bucket],
+                          extend_num_tokens=bucket, extend_seq_lens=st["ext"], extend_prefix_lens=st["pre"],
+                          extend_start_loc=st["zero"].clone(), extend_prefix_lens_cpu=[pbucket], extend_seq_lens_cpu=[bucket],
                           req_to_token_pool=self.runner.req_to_token_pool, token_to_kv_pool=self.runner.token_to_kv_pool,
                           attn_backend=self.backend)
-        self.backend.init_forward_metadata(fb)       # grid extents from the bucket; qo_indptr / kv_indptr are static buffers
-        md = self.backend.forward_metadata           # kept: the graph holds its tensors' addresses
+        self.backend.init_forward_metadata(fb)       # grid extents from the buckets; qo_indptr / kv_indptr are static buffers,
+        md = self.backend.forward_metadata           # kv_indices is sized by the prefix bucket.  Kept: the graph holds the addresses
+        if pbucket:
+            md.kv_indices.zero_()                    # (request row 0's page-table entries so far: the padding slot is harmless)
         s = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -271,7 +278,7 @@ class PrefillGraphRunner:
             logits = self.net(st["ids"], st["pos"], fb)
             st["tok"].copy_(greedy_sample(logits[-1:]))
         st.update(graph=g, fb=fb, md=md, logits=logits)
-        self._graphs[bucket] = st
+        self._graphs[(bucket, pbucket)] = st
         return st
 
     def bucket_for(self, n: int) -> Optional[int]:
@@ -280,21 +287,31 @@ class PrefillGraphRunner:
                 return b
         return None
 
-    def run(self, ids: torch.Tensor, slots: torch.Tensor):
-        """ids [n] token ids, slots [n] KV-pool rows of the request's tokens (req_to_token[r, :n]).  Returns (logits [1, V] of
-        the last real position, sampled token [1]) -- views of static buffers, valid until the next run of the same bucket."""
+    def run(self, ids: torch.Tensor, slots: torch.Tensor, prefix_slots: Optional[torch.Tensor] = None):
+        """ids [n] new token ids, slots [n] KV-pool rows they are written to (req_to_token[r, p:p + n]); prefix_slots [p]: the
+        pool rows of the request's cached tokens (req_to_token[r, :p]), None = empty prefix.  Returns (logits [1, V] of the
+        last real position, sampled token [1]) -- views of static buffers, valid until the next run of the same bucket."""
         n = ids.numel()
+        p = 0 if prefix_slots is None else prefix_slots.numel()
         b = self.bucket_for(n)
         if b is None:
             raise ValueError(f"prompt of {n} tokens exceeds the largest captured bucket ({self.buckets[-1]})")
-        st = self._graphs.get(b) or self._capture(b)
+        pb = next((x for x in self.prefix_buckets if p <= x), None)
+        if pb is None:
+            raise ValueError(f"prefix of {p} tokens exceeds the largest captured prefix bucket ({self.prefix_buckets[-1]})")
+        st = self._graphs.get((b, pb)) or self._capture(b, pb)
         st["ids"].zero_()
         st["ids"][:n].copy_(ids)
         st["loc"].zero_()                                # padded rows write their K/V into the padding slot
         st["loc"][:n].copy_(slots)
         st["ext"].fill_(n)
-        st["seq"].fill_(n)
+        st["seq"].fill_(p + n)
         self.backend.forward_metadata = st["md"]
         st["md"].qo_indptr[1:2].fill_(n)                # the attention kernel's row count (device side)
+        if pb:
+            torch.arange(p, p + b, out=st["pos"])       # rotary positions of the new tokens
+            st["pre"].fill_(p)
+            st["md"].kv_indptr[1:2].fill_(p)            # ... and the prefix length the kernel reads
+            st["md"].kv_indices[:p].copy_(prefix_slots)
         st["graph"].replay()
         return st["logits"], st["tok"]

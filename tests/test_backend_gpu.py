@@ -489,3 +489,65 @@ def test_short_prefill_with_deferred_epilogues_is_bit_identical(n, monkeypatch):
     assert torch.equal(outs[0][0], outs[1][0])
     for a, b in zip(outs[0][1], outs[1][1]):
         assert torch.equal(a, b)
+
+def test_prefill_graph_runner_behind_a_cached_prefix():
+    """harness.PrefillGraphRunner with prefix_buckets (round 4): a radix hit -- n new tokens behind p cached ones -- replayed
+    from the graph captured for (token bucket, prefix bucket).  p == the prefix bucket and n == the token bucket: bit-identical
+    to the eager pass (same launches, the extend kernel's KV-range parts planned from the same bound); a shorter prefix
+    through the same graph: the same greedy token, logits within the 16-bit tolerance (the parts are planned from the bucket's
+    bound, the eager pass from the true length); the new tokens' pool rows equal."""
+    from sglang_npu_amd import model as M
+    from sglang_npu_amd.harness import (ForwardBatch, ForwardMode, MHATokenToKVPool, ModelConfig, ModelRunnerLike,
+                                        PrefillGraphRunner, ReqToTokenPool, ServerArgs, install_attention_backend)
+    cfg = ModelConfig(8, 2, 128, 1024, 2048, 2, 512, 4096)
+    net = M.LlamaForCausalLM(cfg, "w8a8_fp8", torch.bfloat16, DEV).load_dummy_weights()
+    n_tok, width = 2601, 2600
+    r2t_pool = ReqToTokenPool(1, width, DEV)
+    g = torch.Generator(device=DEV).manual_seed(9)
+    r2t_pool.req_to_token.copy_((torch.randperm(n_tok - 1, device=DEV, generator=g) + 1)[:width].view(1, width).to(torch.int32))
+    rows = MHATokenToKVPool(n_tok, 1, torch.bfloat16, 2, 128, 2, DEV).get_key_buffer(0).shape[0]
+    kv0 = [torch.randn(rows, 2, 128, device=DEV, generator=g).to(torch.bfloat16) for _ in range(4)]  # the cached tokens' K / V
+
+    def fresh_pool():
+        pool = MHATokenToKVPool(n_tok, 1, torch.bfloat16, 2, 128, 2, DEV)
+        for l in range(2):
+            pool.get_key_buffer(l).copy_(kv0[2 * l])
+            pool.get_value_buffer(l).copy_(kv0[2 * l + 1])
+        return pool
+
+    def eager(ids, p, pool):
+        n = ids.numel()
+        runner = ModelRunnerLike(cfg, r2t_pool, pool, DEV, 0, 1, ServerArgs())
+        backend = install_attention_backend(runner)
+        seq = torch.full((1,), p + n, dtype=torch.int64, device=DEV)
+        zero = torch.zeros(1, dtype=torch.int64, device=DEV)
+        pos = torch.arange(p, p + n, device=DEV)
+        fb = ForwardBatch(ForwardMode.EXTEND, 1, ids, zero.clone(), seq, r2t_pool.req_to_token[0, p:p + n].to(torch.int64), n,
+                          seq.cpu(), pos, extend_num_tokens=n, extend_seq_lens=torch.full((1,), n, dtype=torch.int64, device=DEV),
+                          extend_prefix_lens=zero + p, extend_start_loc=zero.clone(), extend_prefix_lens_cpu=[p],
+                          extend_seq_lens_cpu=[n], req_to_token_pool=r2t_pool, token_to_kv_pool=pool, attn_backend=backend)
+        backend.init_forward_metadata(fb)
+        return net(ids, pos, fb).clone()
+
+    pool_g = fresh_pool()
+    runner = ModelRunnerLike(cfg, r2t_pool, pool_g, DEV, 0, 1, ServerArgs())
+    backend = install_attention_backend(runner)
+    pg = PrefillGraphRunner(net, runner, backend, DEV, buckets=(128,), prefix_buckets=(0, 2048))
+    for n, p in ((128, 2048), (128, 1500), (100, 2048), (128, 0), (128, 2048)):
+        ids = torch.randint(0, 512, (n,), device=DEV, generator=g)
+        pool_e = fresh_pool()
+        ref = eager(ids, p, pool_e)
+        for l in range(2):
+            pool_g.get_key_buffer(l).copy_(kv0[2 * l])
+            pool_g.get_value_buffer(l).copy_(kv0[2 * l + 1])
+        slots = r2t_pool.req_to_token[0, p:p + n].to(torch.int64)
+        pre = r2t_pool.req_to_token[0, :p].to(torch.int64) if p else None
+        logits, tok = pg.run(ids, slots, pre)
+        torch.cuda.synchronize()
+        assert int(tok) == int(ref.float().argmax())
+        if n == 128 and p in (0, 2048):
+            assert torch.equal(logits, ref)
+        else:
+            torch.testing.assert_close(logits.float(), ref.float(), rtol=2.0 ** -6, atol=1e-3 * float(ref.float().abs().max()) + 1e-3)
+        ke, kg = pool_e.get_key_buffer(0), pool_g.get_key_buffer(0)
+        assert torch.equal(kg[slots], ke[slots])
