@@ -80,6 +80,12 @@ __device__ __forceinline__ uint32_t* counter_ptr(const ArArgs& a) {
 __device__ __forceinline__ bool block_barrier(const ArArgs& a, int slot, uint32_t val) {
   __shared__ int failed;
   if (threadIdx.x == 0) failed = 0;
+  // Every thread's stores into the staging area must be ACKNOWLEDGED before one of the first `world` threads publishes the
+  // flag: the workgroup barrier below orders execution, not the completion of other waves' stores, and a fence by the
+  // signalling thread covers what has reached the cache, not what another wave still has in flight.  (Round 4: the
+  // 8-ranks-in-one-process test saw one stale 16-byte vector of a peer's row once in several full runs -- the PARTIALS
+  // form of the fused norm, whose phase-A stores are issued late, behind the split-K slab loads.)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x < a.world) {
     const int t = threadIdx.x;
