@@ -3,7 +3,11 @@
 with RadixAttention-style token-level paged KV (BASELINE.json configs[1]/[2]) on N MI355X GPUs.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by torch.distributed.run, one rank per GPU, TP = N over RCCL/xGMI)
+    N > 1, either way one rank per GPU, TP = N over RCCL/xGMI:
+      * the plain command above: this process becomes the LAUNCHER (launch_ranks below) -- it starts the N ranks as child
+        processes before anything touches the GPU, relays rank 0's JSON line and fails if a rank fails
+        (the reference's harness spawns its TP ranks itself too: bench_one_batch.py:509-545);
+      * python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...: the ranks are given (RANK / WORLD_SIZE set).
 
 One "step" = one decode step of the whole batch: for each of the 32 layers
   fused-add RMSNorm -> per-token FP8 quant -> qkv GEMM (fp8_scaled_mm) -> RoPE -> KV-pool write ->
@@ -84,9 +88,10 @@ def parse():
     ap.add_argument("--emulate-tp", type=int, default=0,
                     help="debug only: run ONE rank's share of a TP=N step on this GPU with the all-reduce stubbed to "
                          "identity (per-rank kernel rehearsal on a 1-GPU box; invalidates the number)")
-    ap.add_argument("--call-order", default="fused", choices=["fused", "reference"],
-                    help="which call order `value` reports: the backend's fused producers (default) or the reference's "
-                         "unfused operator order; the other one is reported beside it")
+    ap.add_argument("--call-order", default="reference", choices=["fused", "reference"],
+                    help="which call order `value` reports: the reference's operator order (default: what an untouched SGLang "
+                         "model file gets from the drop-in classes) or this repo's fused producers; the other one is reported "
+                         "beside it (value_fused / value_dropin)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
@@ -785,6 +790,132 @@ def other_configs():
     return out
 
 
+def _free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _tail(path, n=25):
+    try:
+        return "".join(open(path, errors="replace").readlines()[-n:])
+    except OSError:
+        return ""
+
+
+def _run_rank_children(cmd, n, env, tag, timeout_s, log_dir):
+    """Start `cmd` once per rank (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment, each child the leader of its
+    own process group), wait for all of them.  The first non-zero exit or the deadline ends the others: SIGTERM to exactly
+    the process groups started here, SIGKILL ten seconds later.  Returns (ok, reason, [(stdout path, stderr path)])."""
+    import signal
+    import subprocess
+    port = _free_port()
+    procs, files = [], []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_PORT=str(port))
+        out_p, err_p = os.path.join(log_dir, f"{tag}.rank{r}.out"), os.path.join(log_dir, f"{tag}.rank{r}.err")
+        files.append((out_p, err_p))
+        procs.append(subprocess.Popen(cmd, cwd=ROOT, env=e, stdout=open(out_p, "w"), stderr=open(err_p, "w"),
+                                      stdin=subprocess.DEVNULL, start_new_session=True))
+    deadline = time.time() + timeout_s
+    reason, beat = None, time.time() + 30
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            reason = f"{tag}: rank {bad[0][0]} exited with code {bad[0][1]}"
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.time() > deadline:
+            reason = f"{tag}: not finished after {timeout_s:.0f} s"
+            break
+        if time.time() > beat:  # (a silent command is taken for a hung one)
+            print(f"[bench launcher] {tag}: {sum(c is None for c in codes)} of {n} ranks running", file=sys.stderr, flush=True)
+            beat = time.time() + 30
+        time.sleep(0.2)
+    if reason is not None:
+        for sig, grace in ((signal.SIGTERM, 10.0), (signal.SIGKILL, 5.0)):
+            live = [p for p in procs if p.poll() is None]
+            for p in live:
+                try:
+                    os.killpg(p.pid, sig)  # the group this launcher created for that rank, nothing else
+                except (ProcessLookupError, PermissionError):
+                    pass
+            t_end = time.time() + grace
+            while time.time() < t_end and any(p.poll() is None for p in live):
+                time.sleep(0.1)
+    return reason is None, reason, files
+
+
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` with N > 1 and no RANK / WORLD_SIZE in the environment: be the launcher.
+
+    The reference's harness spawns one process per TP rank itself (bench_one_batch.py:509-545); so does this.  The parent
+    never initialises the GPU (no HIP call, no torch.cuda call): it only starts children --
+      phase 0  N short-lived probes (sglang_npu_amd._probe_graph_ar): can this job's process-group all-reduce be captured
+               into a HIP graph?  (asked in throw-away processes: a failed capture leaves a sticky HIP error);
+      phase 1  the N ranks: this script again with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set and the
+               probe's answer in SGL_MI355_BENCH_AR_GRAPH.
+    Rank 0's JSON line is relayed on stdout with a `launcher` object added.  Exit code 0 only if every rank exits 0 -- except
+    that a failure AFTER rank 0 has checkpointed the finished headline measurement (SGL_MI355_BENCH_PARTIAL) still prints
+    that line, marked `incomplete`: a side measurement must not take the timed K steps down with it."""
+    import shutil
+    import tempfile
+    n, t0 = args.gpus, time.time()
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what hipIpcGetMemHandle / RCCL need on this host driver
+    if env.get("SGL_MI355_SHARE_GPU"):  # rehearsal on a 1-GPU box: RCCL refuses two ranks on one device, gloo carries the group
+        env.setdefault("SGL_MI355_DIST_BACKEND", "gloo")
+    log_dir = tempfile.mkdtemp(prefix="sgl_mi355_bench_")
+    budget = float(env.get("SGL_MI355_BENCH_LAUNCH_TIMEOUT", "1100"))
+    info = {"mode": "self-launched: the parent started one child process per rank and never touched the GPU "
+                    "(bench_one_batch.py:509-545 does the same)", "ranks": n}
+    try:
+        graph_ok = False
+        if not args.no_graph:
+            ok, why, files = _run_rank_children([sys.executable, "-m", "sglang_npu_amd._probe_graph_ar"], n, env, "probe",
+                                                min(240.0, budget / 3), log_dir)
+            graph_ok = ok
+            info["probe_graph_capturable_allreduce"] = ok
+            if not ok:
+                info["probe_note"] = why
+                print(f"[bench launcher] {why}: the step runs eagerly\n{_tail(files[0][1], 8)}", file=sys.stderr, flush=True)
+        partial = os.path.join(log_dir, "rank0_partial.json")
+        env_r = dict(env, SGL_MI355_BENCH_AR_GRAPH="1" if graph_ok else "0", SGL_MI355_BENCH_PARTIAL=partial,
+                     SGL_MI355_BENCH_T0=str(t0), SGL_MI355_BENCH_BUDGET_S=str(budget))
+        cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+        ok, why, files = _run_rank_children(cmd, n, env_r, "ranks", max(60.0, budget - (time.time() - t0)), log_dir)
+        for r, (_, err_p) in enumerate(files):  # the ranks' diagnostics go where ours go
+            txt = _tail(err_p, 60 if not ok else 12)
+            if txt.strip():
+                print(f"----- rank {r} stderr (tail) -----\n{txt}", file=sys.stderr, flush=True)
+        line = None
+        try:
+            line = [l for l in open(files[0][0]).read().splitlines() if l.startswith("{")][-1]
+        except (OSError, IndexError):
+            pass
+        if line is None and os.path.exists(partial):
+            line = open(partial).read().strip() or None
+            info["incomplete"] = f"{why or 'rank 0 printed no line'}; this is rank 0's checkpoint after the timed region"
+        if line is None:
+            print(f"[bench launcher] no result: {why or 'rank 0 printed no JSON line'}", file=sys.stderr, flush=True)
+            return 1
+        d = json.loads(line)
+        if not ok and "incomplete" not in info:
+            info["incomplete"] = why
+        info["wall_s"] = round(time.time() - t0, 1)
+        d["launcher"] = info
+        print(json.dumps(d), flush=True)
+        return 0
+    finally:
+        shutil.rmtree(log_dir, ignore_errors=True)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -794,11 +925,16 @@ def main():
     if (world == 1 and args.gpus == 1 and not args.no_other_configs and args.model == "llama3-8b" and
             args.quant == "w8a8_fp8" and args.emulate_tp == 0 and args.layers is None and args.kv_dtype == "auto"):
         others = other_configs()
+    if args.gpus > 1 and world == 1 and "RANK" not in os.environ:
+        raise SystemExit(launch_ranks(args))  # becomes the parent of N rank processes; never touches the GPU itself
     if world != args.gpus:
-        if args.gpus > 1 and world == 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"bench.py --gpus {args.gpus} inside a job of WORLD_SIZE={world}: they must agree")
     use_graph = not args.no_graph
-    if use_graph and world > 1:
+    if use_graph and world > 1 and os.environ.get("SGL_MI355_BENCH_AR_GRAPH") in ("0", "1"):
+        use_graph = os.environ["SGL_MI355_BENCH_AR_GRAPH"] == "1"  # the launcher's phase 0 already asked
+        if not use_graph and rank == 0:
+            print("[bench] all-reduce is not graph-capturable with this backend; running the step eagerly", file=sys.stderr)
+    elif use_graph and world > 1:
         # Ask a throw-away child per rank whether the communicator's all-reduce can be stream-captured
         # (RCCL can; a failed capture would leave a sticky HIP error in THIS process, so we never try here).
         import subprocess
@@ -816,6 +952,9 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     if os.environ.get("SGL_MI355_SHARE_GPU"):  # rehearsal on a 1-GPU box: every rank uses device 0
         local_rank = 0
+    elif torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) are visible "
+                         f"(a rehearsal with all ranks on ONE GPU: SGL_MI355_SHARE_GPU=1)")
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     from sglang_npu_amd import _lib
@@ -865,11 +1004,44 @@ def main():
         barrier()
         return max_over_ranks(time.perf_counter() - t0)
 
+    kv_esz = 1 if args.kv_dtype in ("fp8_e4m3", "fp8_e5m2") else 2
+    partial_path = os.environ.get("SGL_MI355_BENCH_PARTIAL") if rank == 0 else None
+
+    def checkpoint(d):
+        """Rank 0 leaves the line as it stands for the launcher (launch_ranks): once the timed region is done, a failure in a
+        later side measurement on any rank must not lose it."""
+        if partial_path:
+            tmp = partial_path + ".tmp"
+            with open(tmp, "w") as f:
+                f.write(json.dumps(d))
+            os.replace(tmp, partial_path)
+
     # ---- the contract's timed region: W warm-up steps, then exactly K steps between barriers
     set_call_order(want_fused)
     elapsed = timed(args.warmup, args.steps)
     ms_per_step = elapsed / args.steps * 1e3
     value = args.batch * args.steps / elapsed
+    order_name = ("this repo's fused entry points (norm+quant / RoPE+KV-write / SiLU+quant producers, GEMM epilogues inside their "
+                  "consumers)" if want_fused else
+                  "the reference's operator order, i.e. what an untouched SGLang models/llama.py gets from the drop-in classes")
+    out = {
+        "metric": "output tokens/s (decode, whole model step) + p50 TTFT", "value": round(value, 1), "unit": "tokens/s",
+        "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": ("fp8_e4m3 (GEMM) / bf16 (attention" + (", KV)" if kv_esz == 2 else "), " + args.kv_dtype + " KV"))
+        if args.quant == "w8a8_fp8" else args.quant,
+        "data": "synthetic (dummy-loader random weights, N(0,1) KV, random-permutation page table)",
+        "config": {"workload": f"{args.model} {args.quant} decode bs={args.batch} ctx={args.ctx} TP={tp} "
+                               f"(token-level paged KV, {'HIP graph replay' if loop.graph is not None else 'eager launches'}); "
+                               f"`value` = {order_name}",
+                   "global_batch": args.batch, "seq_len": args.ctx, "layers": len(net.layers),
+                   "parallelism": f"tp{tp}" + (" (ONE rank emulated on one GPU, collectives stubbed: not a job number)"
+                                               if args.emulate_tp > 1 and not dist_on else "")},
+        "call_order": "fused" if want_fused else "reference",
+        "world_size_seen": torch.distributed.get_world_size() if dist_on else 1,
+        "dist_backend": torch.distributed.get_backend() if dist_on else None,
+    }
+    checkpoint(out)
 
     # ---- the other call order, and a device-synchronised per-step median (bench_one_batch.py:380-424 shape)
     other = None
@@ -879,6 +1051,18 @@ def main():
         other = timed(2, n_other) / n_other * 1e3
         set_call_order(want_fused)
     fused_ms, dropin_ms = (ms_per_step, other) if want_fused else (other, ms_per_step)
+    out.update({
+        "value_dropin": round(args.batch / dropin_ms * 1e3, 1) if dropin_ms else None,
+        "value_fused": round(args.batch / fused_ms * 1e3, 1) if fused_ms else None,
+        "fused_ms_per_step": round(fused_ms, 4) if fused_ms is not None else None,
+        "dropin_ms_per_step": round(dropin_ms, 4) if dropin_ms is not None else None,
+        "dropin_tokens_per_s": round(args.batch / dropin_ms * 1e3, 1) if dropin_ms else None,
+        "dropin_note": "value_dropin / dropin_ms_per_step: the model in the reference's operator order (RMSNorm -> apply() "
+                       "[per-token quant + fp8_scaled_mm] -> RoPE -> attn_backend.forward(save_kv_cache=True) -> ... ), what "
+                       "SGLang's untouched models/llama.py gets from the drop-in classes; value_fused / fused_ms_per_step: the "
+                       "same model through this repo's fused entry points (needs its own model file); whichever is not `value` "
+                       "ran min(steps,10) steps after 2 warm-ups"})
+    checkpoint(out)
     sync_ts = []
     loop.rewind(args.ctx)  # the page table has room for ctx + steps + warmup + 8 positions only
     for _ in range(min(args.steps, 10) + 2):
@@ -941,6 +1125,8 @@ def main():
             ar_info["latency_vs_size"] = allreduce_latency_vs_size(tp_group, device, world)
         except Exception as e:
             ar_info["latency_vs_size"] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
+        out["allreduce"] = ar_info
+        checkpoint(out)
 
     # ---- roofline of the dominant kernel: paged decode attention (HBM-bound)
     ctx_mid = args.ctx + args.warmup + args.steps + args.steps // 2  # mean sequence length of the instrumented pass
@@ -969,7 +1155,6 @@ def main():
             backend.measure_skip_decode_kernel = False
             loop.rewind(args.ctx)
             loop.capture()
-    kv_esz = 1 if args.kv_dtype in ("fp8_e4m3", "fp8_e5m2") else 2
     alg_bytes = args.batch * ctx_mid * hkv * 2 * d * kv_esz + 4 * args.batch * ctx_mid + 2 * args.batch * hq * 2 * d
     eager_event_ms = attn_ms
     frac_eager = alg_bytes / (eager_event_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
@@ -999,25 +1184,7 @@ def main():
                            f"passes), ratio {pmc['traffic_over_algorithmic']} to the algorithmic bytes of the lengths the run visits")
     except (OSError, KeyError, ValueError):
         pass
-    out = {
-        "metric": "output tokens/s (decode, whole model step) + p50 TTFT", "value": round(value, 1), "unit": "tokens/s",
-        "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": ("fp8_e4m3 (GEMM) / bf16 (attention" + (", KV)" if kv_esz == 2 else "), " + args.kv_dtype + " KV"))
-        if args.quant == "w8a8_fp8" else args.quant,
-        "data": "synthetic (dummy-loader random weights, N(0,1) KV, random-permutation page table)",
-        "config": {"workload": f"{args.model} {args.quant} decode bs={args.batch} ctx={args.ctx} TP={tp} "
-                               f"(token-level paged KV, {'HIP graph replay' if loop.graph is not None else 'eager launches'})",
-                   "global_batch": args.batch, "seq_len": args.ctx, "layers": len(net.layers),
-                   "parallelism": f"tp{tp}" + (" (ONE rank emulated on one GPU, collectives stubbed: not a job number)"
-                                               if args.emulate_tp > 1 and not dist_on else "")},
-        "call_order": "fused" if want_fused else "reference",
-        "fused_ms_per_step": round(fused_ms, 4) if fused_ms is not None else None,
-        "dropin_ms_per_step": round(dropin_ms, 4) if dropin_ms is not None else None,
-        "dropin_tokens_per_s": round(args.batch / dropin_ms * 1e3, 1) if dropin_ms else None,
-        "dropin_note": "the same model in the reference's operator order (RMSNorm -> apply() [per-token quant + "
-                       "fp8_scaled_mm] -> RoPE -> attn_backend.forward(save_kv_cache=True) -> ... ), what SGLang's "
-                       "untouched models/llama.py gets from the drop-in classes; min(steps,10) steps after 2 warm-ups",
+    out.update({
         "median_step_ms_synced": round(median_synced_ms, 4),
         "roofline": {"bound": "hbm", "kernel": "decode_mfma_pair_kernel / decode_mfma_kernel (paged decode attention)",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -1037,12 +1204,11 @@ def main():
                      "instep_difference_us": round(attn_instep_ms * 1e3, 2) if attn_instep_ms else None,
                      "frac_instep_difference": round(frac_instep, 4) if frac_instep is not None else None,
                      "rocprofv3_avg_busy_us_same_command": profiled_attn_us()},
-    }
+    })
+    checkpoint(out)
     if time_attention_kernel.merged_launches:
         out["roofline"]["launch_includes"] = ("kv-split merge + per-token FP8 quant of the output (one launch: "
                                               "sgl_mi355_decode_attention_merged); the bytes are the KV bytes alone")
-    if ar_info is not None:
-        out["allreduce"] = ar_info
     try:
         out["roofline_gemm"] = time_decode_gemms(net, cfg, args.batch, device, tp)
     except Exception as e:  # a diagnostic: never take the headline down with it
@@ -1089,6 +1255,7 @@ def main():
     except Exception as e:
         out["ttft_ms_p50"] = None
         out["config"]["ttft"] = f"failed: {type(e).__name__}: {e}"
+    checkpoint(out)
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(cfg, args.batch, args.ctx, cfg.num_hidden_layers)
@@ -1103,6 +1270,14 @@ def main():
     want_70b = (dist_on and args.model == "llama3-8b" and args.quant == "w8a8_fp8" and args.layers is None
                 and os.environ.get("SGL_MI355_BENCH_NO_70B", "0") in ("", "0")
                 and (world == 8 or os.environ.get("SGL_MI355_BENCH_EXTRA_70B", "0") not in ("", "0")))
+    if want_70b:
+        # the launcher's wall-clock budget (launch_ranks): rank 0's clock decides for everybody whether there is time left
+        t_b0, t_bud = float(os.environ.get("SGL_MI355_BENCH_T0", "0") or 0), float(os.environ.get("SGL_MI355_BENCH_BUDGET_S", "0") or 0)
+        go = torch.tensor([0.0 if (t_b0 and t_bud and time.time() - t_b0 > 0.55 * t_bud) else 1.0], device=device, dtype=torch.float64)
+        torch.distributed.broadcast(go, src=0)
+        if float(go.item()) != 1.0:
+            want_70b = False
+            out["config5_llama3_70b"] = {"skipped": "more than 55 % of the launcher's time budget was spent before this stage"}
     if want_70b:
         import copy
         res = {"workload": f"llama3-70b w8a8_fp8 decode bs={args.batch} ctx={args.ctx} TP={tp}, random weights, the same loop"}
@@ -1124,18 +1299,27 @@ def main():
         if float(t.item()) == 1.0:
             try:
                 n70 = min(args.steps, 16)
-                set_call_order(can_fuse)
+                first = want_fused and can_fuse   # the same call order as the headline `value`, then the other one
+                set_call_order(first)
                 ms70 = timed(3, n70) / n70 * 1e3
                 tp_group.stub_all_reduce = True
-                set_call_order(can_fuse)
+                set_call_order(first)
                 stub70 = timed(2, min(n70, 6)) / min(n70, 6) * 1e3
                 tp_group.stub_all_reduce = False
-                res.update({"ms_per_step": round(ms70, 4), "tokens_per_s": round(args.batch / ms70 * 1e3, 1),
+                res.update({"call_order": "fused" if first else "reference",
+                            "ms_per_step": round(ms70, 4), "tokens_per_s": round(args.batch / ms70 * 1e3, 1),
                             "ms_per_step_allreduce_stubbed": round(stub70, 4),
                             "allreduce_overhead_frac": round(max(0.0, (ms70 - stub70) / ms70), 4),
                             "layers": len(net.layers), "collectives_per_step": 2 * len(net.layers) + 1,
                             "message_bytes": args.batch * cfg70.hidden_size * 2,
                             "graph": loop.graph is not None})
+                out["config5_llama3_70b"] = res
+                checkpoint(out)
+                if can_fuse:
+                    set_call_order(not first)
+                    ms_o = timed(3, min(n70, 8)) / min(n70, 8) * 1e3
+                    res["fused_ms_per_step" if not first else "dropin_ms_per_step"] = round(ms_o, 4)
+                    res["fused_tokens_per_s" if not first else "dropin_tokens_per_s"] = round(args.batch / ms_o * 1e3, 1)
             except Exception as e:
                 res["error"] = f"{type(e).__name__}: {str(e)[:200]}"
             finally:

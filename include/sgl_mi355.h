@@ -34,7 +34,7 @@ extern "C" {
 #define SGL_MI355_ERR_RUNTIME 3          /* a HIP runtime call failed                */
 
 /* ABI version of this header; bumped on any signature change. */
-#define SGL_MI355_ABI_VERSION 10
+#define SGL_MI355_ABI_VERSION 11
 int sgl_mi355_abi_version(void);
 
 /* Copies the calling thread's last error message (NUL-terminated) into buf. Returns its length. */
@@ -685,6 +685,10 @@ int sgl_mi355_ar_get_ipc_handle(void* comm, void* handle_out);
 int sgl_mi355_ar_open_peers(void* comm, const void* all_handles);
 int sgl_mi355_ar_set_peers_local(void* comm, void* const* comms);
 int sgl_mi355_ar_set_spin_limit(int64_t spins);
+/* Test hook (no reference counterpart): the last wave of every workgroup of the all-reduce kernels idles `iters` x ~3.4 us in
+ * front of its staging stores, which makes the store / flag ordering the custom all-reduce depends on (the Signal barriers of
+ * custom_all_reduce_hip.cuh:176-259) the order of every call instead of a rare interleaving; 0 = off (the default). */
+int sgl_mi355_ar_set_test_delay(int64_t iters);
 int sgl_mi355_ar_all_reduce(void* comm, const void* inp, void* out, int64_t nbytes, int dtype, void* stream);
 /* QuickReduce-class all-reduce for prefill-size messages (MI355X counterpart of qr_all_reduce, quick_all_reduce.cu:60-110,
  * driven by device_communicators/quick_all_reduce.py:216-260): two-shot over the same IPC staging area, the message cut

@@ -58,6 +58,7 @@ struct ArArgs {
   uint32_t* status_host; // its mirror in host-mapped pinned memory (written once, when a wait gives up)
   unsigned spin_limit;
   int family;            // staging area / flags / counters of this kernel family (kFam*); data_off already points into it
+  int test_delay;        // test hook (sgl_mi355_ar_set_test_delay): 0 in production
 };
 
 // header: signals uint32 [kFamilies][2 slots][kMaxRanks][kMaxBlocks] at offset 0; counters uint32 [kFamilies][kMaxBlocks]
@@ -76,6 +77,16 @@ __device__ __forceinline__ uint32_t* counter_ptr(const ArArgs& a) {
   return reinterpret_cast<uint32_t*>(a.peer[a.rank] + kCounterOff) + a.family * kMaxBlocks + blockIdx.x;
 }
 
+// Test hook for the staging-store / flag ordering (round 4's defect, see block_barrier): the LAST wave of every workgroup idles
+// `test_delay` x ~3.4 us (s_sleep 127 = 8128 cycles) in front of its phase-A staging stores, so that on every call those stores
+// are the last thing issued before the workgroup barrier -- in flight while wave 0 is ready to publish the flags the moment the
+// barrier opens.  What was a rare interleaving (late stores behind the split-K slab loads of the PARTIALS form) becomes the
+// order of every workgroup of every call (tests/test_custom_allreduce_gpu.py).  One scalar compare when the hook is off.
+__device__ __forceinline__ void test_delay_last_wave(const ArArgs& a) {
+  if (a.test_delay > 0 && (int)(threadIdx.x >> 6) == (int)(blockDim.x >> 6) - 1)
+    for (int i = 0; i < a.test_delay; ++i) __builtin_amdgcn_s_sleep(127);
+}
+
 // Returns false when this rank's communicator is (or has just become) failed: the caller must not read peer data.
 __device__ __forceinline__ bool block_barrier(const ArArgs& a, int slot, uint32_t val) {
   __shared__ int failed;
@@ -85,7 +96,9 @@ __device__ __forceinline__ bool block_barrier(const ArArgs& a, int slot, uint32_
   // signalling thread covers what has reached the cache, not what another wave still has in flight.  (Round 4: the
   // 8-ranks-in-one-process test saw one stale 16-byte vector of a peer's row once in several full runs -- the PARTIALS
   // form of the fused norm, whose phase-A stores are issued late, behind the split-K slab loads.)
+#ifndef SGLM_AR_NO_STAGING_WAIT  // (defined only in the variant build that shows the regression test catching the defect)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
   __syncthreads();
   if (threadIdx.x < a.world) {
     const int t = threadIdx.x;
@@ -156,6 +169,7 @@ __global__ __launch_bounds__(kThreads) void all_reduce_kernel(ArArgs a, const ui
   bool ok = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0;
   if (ok) {
     // phase A: publish my input
+    test_delay_last_wave(a);
     for (int64_t i = tid; i < n16; i += nthr) reinterpret_cast<uint4*>(my_data)[i] = inp[i];
     ok = block_barrier(a, 0, call);
   }
@@ -306,6 +320,7 @@ __global__ __launch_bounds__(kThreads) void quick_reduce_kernel(ArArgs a, const 
   bool ok = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0;
   if (ok) {
     // phase A: my chunk, quantised (n_units % 4 == 0 and nthr % 4 == 0: a block's 4 threads move together)
+    test_delay_last_wave(a);
     for (int64_t u = tid; u < n_units; u += nthr) {
       float f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       A::add(f, inp[u]);
@@ -427,6 +442,7 @@ __global__ __launch_bounds__(kNormThreads) void ar_add_rmsnorm_kernel(
   if (ok) {
     // phase A (ps.partials: my rows are still a split-K GEMM -- its epilogue runs here, rounded to the 16-bit dtype exactly as
     // fp8_gemm_finalize_kernel would have, so the sum over ranks sees the same addends)
+    test_delay_last_wave(a);
     for (int row = blockIdx.x; row < T; row += gridDim.x)
       for (int vi = tid; vi < nv; vi += kNormThreads)
         if constexpr (PARTIALS)
@@ -613,6 +629,14 @@ extern "C" int sgl_mi355_ar_set_peers_local(void* comm, void* const* comms /* wo
   return 0;
 }
 
+static int g_test_delay = 0;
+// Test hook: see test_delay_last_wave.  iters x ~3.4 us of idling per call and workgroup; 0 (the default) switches it off.
+extern "C" int sgl_mi355_ar_set_test_delay(int64_t iters) {
+  SGLM_CHECK_ARG(iters >= 0 && iters <= 4096, "ar_set_test_delay: 0 .. 4096");
+  g_test_delay = (int)iters;
+  return 0;
+}
+
 static unsigned g_spin_limit = kSpinLimit;
 extern "C" int sgl_mi355_ar_set_spin_limit(int64_t spins) {
   SGLM_CHECK_ARG(spins > 0 && spins <= (int64_t)kSpinLimit, "ar_set_spin_limit: 1 .. %u", kSpinLimit);
@@ -643,7 +667,7 @@ extern "C" int sgl_mi355_ar_all_reduce(void* comm, const void* inp, void* out, i
   for (int r = 0; r < c->world; ++r) a.peer[r] = c->peer[r];
   a.family = kFamPlain;
   a.data_off = c->data_off + (size_t)kFamPlain * 2 * c->half_bytes; a.half_bytes = c->half_bytes; a.rank = c->rank; a.world = c->world;
-  a.status = reinterpret_cast<uint32_t*>(c->base + kStatusOff); a.status_host = c->status_dev; a.spin_limit = g_spin_limit;
+  a.status = reinterpret_cast<uint32_t*>(c->base + kStatusOff); a.status_host = c->status_dev; a.spin_limit = g_spin_limit; a.test_delay = g_test_delay;
   const int64_t n16 = nbytes / 16;
   const int two_shot = nbytes > 256 * 1024 && c->world > 1;
   int blocks = (int)((n16 + kThreads - 1) / kThreads);
@@ -676,7 +700,7 @@ extern "C" int sgl_mi355_ar_quick_all_reduce(void* comm, const void* inp, void* 
   for (int r = 0; r < c->world; ++r) a.peer[r] = c->peer[r];
   a.family = kFamQuick;
   a.data_off = c->data_off + (size_t)kFamQuick * 2 * c->half_bytes; a.half_bytes = c->half_bytes; a.rank = c->rank; a.world = c->world;
-  a.status = reinterpret_cast<uint32_t*>(c->base + kStatusOff); a.status_host = c->status_dev; a.spin_limit = g_spin_limit;
+  a.status = reinterpret_cast<uint32_t*>(c->base + kStatusOff); a.status_host = c->status_dev; a.spin_limit = g_spin_limit; a.test_delay = g_test_delay;
   hipStream_t s = as_stream(stream);
   const int bits = regime == 0 ? 16 : regime == 1 ? 8 : regime == 2 ? 6 : 4;
   // units of 8 values (16 B of input) per chunk: packed integers + one half per 4 units must fit the area of max_bytes
@@ -733,7 +757,7 @@ static int ar_fused_add_rmsnorm_impl(void* comm, const void* inp, const PartialS
   for (int r = 0; r < c->world; ++r) a.peer[r] = c->peer[r];
   a.family = kFamNorm;
   a.data_off = c->data_off + (size_t)kFamNorm * 2 * c->half_bytes; a.half_bytes = c->half_bytes; a.rank = c->rank; a.world = c->world;
-  a.status = reinterpret_cast<uint32_t*>(c->base + kStatusOff); a.status_host = c->status_dev; a.spin_limit = g_spin_limit;
+  a.status = reinterpret_cast<uint32_t*>(c->base + kStatusOff); a.status_host = c->status_dev; a.spin_limit = g_spin_limit; a.test_delay = g_test_delay;
   const int one_shot = nbytes <= 256 * 1024 || c->world == 1;
   const int blocks = (int)(num_tokens < kMaxBlocks ? num_tokens : kMaxBlocks);
   hipStream_t s = as_stream(stream);

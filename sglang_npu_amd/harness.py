@@ -307,11 +307,17 @@ class PrefillGraphRunner:
         st["ext"].fill_(n)
         st["seq"].fill_(p + n)
         self.backend.forward_metadata = st["md"]
+        # qo_indptr / kv_indptr are the backend's SHARED static buffers: any init_forward_metadata call since this graph's
+        # capture or last replay (an eager prefill behind a prefix, a flat-kv decode, another bucket) has overwritten them.
+        # Both pairs are written on every replay -- also the 0 prefix of a prefix-bucket-0 graph, whose 1-entry kv_indices
+        # a stale non-zero length would index far out of bounds.
+        st["md"].qo_indptr[0:1].zero_()
         st["md"].qo_indptr[1:2].fill_(n)                # the attention kernel's row count (device side)
+        st["md"].kv_indptr[0:1].zero_()
+        st["md"].kv_indptr[1:2].fill_(p)                # ... and the prefix length the kernel reads
         if pb:
             torch.arange(p, p + b, out=st["pos"])       # rotary positions of the new tokens
             st["pre"].fill_(p)
-            st["md"].kv_indptr[1:2].fill_(p)            # ... and the prefix length the kernel reads
             st["md"].kv_indices[:p].copy_(prefix_slots)
         st["graph"].replay()
         return st["logits"], st["tok"]

@@ -362,3 +362,90 @@ def test_quick_reduce_all_regimes_vs_oracle(world):
     msg = q.get(timeout=500)
     p.join(30)
     assert msg == "ok", msg
+
+
+def _staging_order_worker(world, q):
+    """Regression for round 4's staging-store race (commit 195e7bb; csrc/allreduce.hip block_barrier): with the test hook on,
+    the LAST wave of every workgroup issues its phase-A staging stores as late as possible -- right in front of the flag
+    barrier, on every call -- which is the interleaving that once delivered a stale 16-byte vector of a peer's row in the
+    8-rank in-process run of the PARTIALS form.  Integer-valued addends: every sum is exact in the 16-bit type and in fp32,
+    so ANY stale or torn peer vector changes the bits of the residual.  200 calls per form, alternating the two halves of
+    the double buffer and alternating payloads (a stale read of the previous call's vector in the same half is then wrong
+    by construction)."""
+    os.environ["GPU_MAX_HW_QUEUES"] = "16"
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        import ctypes
+        from sglang_npu_amd import _lib, ops
+        from sglang_npu_amd.distributed import CustomAllreduce
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        lib = _lib.lib()
+        comms = CustomAllreduce.connect_local(world, dev, max_size=1 << 20)
+        streams = [torch.cuda.Stream(device=dev) for _ in range(world)]
+        T, H, SK, dt = 32, 8192, 3, torch.bfloat16   # one row per workgroup, 16 waves of 64 lanes x 16 B per row
+        g = torch.Generator().manual_seed(world)
+        w = torch.ones(H, dtype=dt, device=dev)
+        # four payload sets (set k used by call i with i % 4 == k: the same half of the double buffer sees sets k and k + 2
+        # in turn); slabs of integer-valued fp32 partial sums with unit scales, sum of the slabs in [-6, 6]
+        sets = []
+        for k in range(4):
+            slabs = [torch.randint(-2, 3, (SK, T, H), generator=g).float().to(dev) for _ in range(world)]
+            addend = [s.sum(0) for s in slabs]
+            total = torch.stack(addend).sum(0)
+            sets.append((slabs, addend, total))
+        ones_t, ones_h = torch.ones(T, device=dev), torch.ones(H, device=dev)
+        res0 = torch.randint(-3, 4, (T, H), generator=g).to(dt).to(dev)
+        _lib.check(lib.sgl_mi355_ar_set_test_delay(ctypes.c_int64(2)))   # ~7 us of idling in front of the last wave's stores
+        # memory-channel noise on a stream of its own: queueing in the channels is what lets a late store land after a flag
+        noise_stream = torch.cuda.Stream(device=dev)
+        noise_a = torch.empty(192 << 20, dtype=torch.uint8, device=dev)
+        noise_b = torch.empty_like(noise_a)
+        try:
+            for form in ("partials", "plain", "all_reduce"):
+                bad = []
+                for i in range(200):
+                    slabs, addend, total = sets[i % 4]
+                    outs, ress = [], [res0.clone() for _ in range(world)]
+                    with torch.cuda.stream(noise_stream):
+                        noise_b.copy_(noise_a)
+                    for r in range(world):
+                        with torch.cuda.stream(streams[r]):
+                            if form == "partials":
+                                gp = ops.GemmPartials(slabs[r], SK, ones_t, ones_h, None, T, H, dt)
+                                outs.append(comms[r].fused_add_rmsnorm_partials(gp, ress[r], w, 1e-5))
+                            elif form == "plain":
+                                outs.append(comms[r].fused_add_rmsnorm(addend[r].to(dt), ress[r], w, 1e-5))
+                            else:
+                                outs.append(comms[r].custom_all_reduce(addend[r].to(dt).view(-1)).view(T, H))
+                    torch.cuda.synchronize()
+                    expect = total + (res0.float() if form != "all_reduce" else 0.0)  # |values| <= 6 * 8 + 3: exact in bf16
+                    for r in range(world):
+                        got = (ress[r] if form != "all_reduce" else outs[r]).float()
+                        if not torch.equal(got, expect):
+                            bad.append((i, r, int((got != expect).sum())))
+                assert not bad, f"{form}: stale or torn peer data in {len(bad)} (call, rank) pairs, first {bad[:4]}"
+                torch.cuda.synchronize()
+                for c in comms:
+                    c.rebind_fused_norm()
+        finally:
+            _lib.check(lib.sgl_mi355_ar_set_test_delay(ctypes.c_int64(0)))
+        assert not any(c.timed_out() for c in comms)
+        for c in comms:
+            c.close()
+        q.put("ok")
+    except Exception:
+        import traceback
+        q.put(traceback.format_exc())
+
+
+@pytest.mark.timeout(600)
+def test_staging_stores_are_ordered_before_the_flags_with_the_last_wave_delayed():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_staging_order_worker, args=(8, q))
+    p.start()
+    msg = q.get(timeout=540)
+    p.join(30)
+    assert msg == "ok", msg

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 import oracle
-from conftest import golden_names, load_golden, tol_for, tol_pair
+from conftest import assert_elem_close, count_beyond, golden_names, load_golden, p_rounding_term
 from sglang_npu_amd import ops
 
 pytestmark = pytest.mark.gpu
@@ -24,12 +24,20 @@ def test_extend_op_form_vs_golden(name):
                          t["extend_seq_lens"].to(torch.int32), t["extend_start_loc"].to(torch.int32), max_len_extend,
                          g["sm_scale"], 0.0)
     torch.cuda.synchronize()
-    bound = tol_for(g["dtype"], g["o_f32"])
-    err = (o.float().cpu() - g["o_f32"]).abs().max().item()
-    assert err <= 2 * bound, f"{name}: |hip - f32 truth| = {err:.3e} > {2 * bound:.3e}"
-    if g["ref_valid"]:
-        err_ref = (o.float().cpu() - g["o_ref"].float()).abs().max().item()
-        assert err_ref <= 2 * bound, f"{name}: |hip - reference kernel| = {err_ref:.3e}"
+    # per element: 1e-3 + ulp |ref_i| + the P-rounding term (conftest.p_rounding_term: the probabilities enter the PV MFMA in
+    # the 16-bit type, here as in the reference's extend.cpp, whose own output is 0.1-0.3 % of elements beyond the strict
+    # bound on these fixtures -- tests/test_oracle_golden.py keeps that statement checked)
+    a = torch.zeros(g["q_extend"].size(0), Hq, Dv, dtype=g["q_extend"].dtype)
+    oracle.extend_attention(g["q_extend"], g["k_extend"], g["v_extend"].abs(), a, g["k_buffer"], g["v_buffer"].abs(),
+                            g["req_to_token"], g["req_pool_indices"], g["seq_lens"], g["extend_seq_lens"],
+                            g["extend_start_loc"], max_len_extend, g["sm_scale"], 0.0, p_round=False)
+    assert_elem_close(o, g["o_f32"], g["dtype"], what=f"{name}: hip vs the fp32 truth", extra=p_rounding_term(g["dtype"], a))
+    if g["ref_valid"]:  # the compiled reference kernel's own 16-bit output: two rounded results
+        assert_elem_close(o, g["o_ref"], g["dtype"], pair=True, what=f"{name}: hip vs the reference kernel",
+                          extra=p_rounding_term(g["dtype"], a, pair=True))
+        # ... and under the STRICT bound the HIP kernel leaves no more elements outside than the reference kernel does
+        n_ref, n_hip = count_beyond(g["o_ref"], g["o_f32"], g["dtype"]), count_beyond(o, g["o_f32"], g["dtype"])
+        assert n_hip <= n_ref + 8, f"{name}: {n_hip} hip elements beyond 1e-3 + ulp |f32_i|, the reference kernel has {n_ref}"
 
 
 def _case(B, Hq, Hkv, D, max_prefix, max_ext, dtype, seed, zero_prefix=False, pin_first_prefix=False):
@@ -62,6 +70,15 @@ def _case(B, Hq, Hkv, D, max_prefix, max_ext, dtype, seed, zero_prefix=False, pi
     return dict(q=q, ke=ke, ve=ve, kb=kb, vb=vb, r2t=r2t, rpi=torch.arange(B), seq=seq, ext=ext, start=start, prefix=prefix)
 
 
+def _p_term(c, dtype, scale, cap=0.0, pair=True, **kw):
+    """conftest.p_rounding_term for a _case: the oracle's attention of |V| with unrounded probabilities."""
+    T, Hq, D = c["q"].shape
+    a = torch.zeros(T, Hq, D, dtype=dtype)
+    oracle.extend_attention(c["q"], c["ke"], c["ve"].abs(), a, c["kb"], c["vb"].abs(), c["r2t"], c["rpi"], c["seq"], c["ext"],
+                            c["start"], int(c["ext"].max()), scale, cap, p_round=False, **kw)
+    return p_rounding_term(dtype, a, pair=pair)
+
+
 @pytest.mark.parametrize("Hq,Hkv,D", [(32, 8, 128), (8, 1, 128), (32, 32, 128), (14, 2, 64), (6, 2, 128), (3, 1, 64)])
 @pytest.mark.parametrize("zero_prefix", [False, True])
 def test_extend_backend_form_vs_oracle(Hq, Hkv, D, zero_prefix):
@@ -83,9 +100,7 @@ def test_extend_backend_form_vs_oracle(Hq, Hkv, D, zero_prefix):
     o = torch.zeros(T, Hq, D, dtype=dtype, device=DEV)
     ops.extend_attention_fwd(d["q"], d["ke"], d["ve"], o, d["kb"], d["vb"], qo_indptr, kv_indptr, kv_indices, None,
                              True, None, int(c["ext"].max()), D ** -0.5, 0.0)
-    bound = tol_pair(dtype, o_ref)
-    err = (o.float().cpu() - o_ref.float()).abs().max().item()
-    assert err <= bound, f"|hip - oracle| = {err:.3e} > {bound:.3e}"
+    assert_elem_close(o, o_ref, dtype, pair=True, what="hip vs oracle", extra=_p_term(c, dtype, D ** -0.5))
 
 
 def test_extend_long_prefix_multi_pass_and_fp16_cap():
@@ -103,7 +118,7 @@ def test_extend_long_prefix_multi_pass_and_fp16_cap():
     o = torch.zeros(T, Hq, D, dtype=dtype, device=DEV)
     ops.extend_attention(d["q"], d["ke"], d["ve"], o, d["kb"], d["vb"], d["r2t"].long(), d["rpi"], d["seq"], d["ext"],
                          d["start"], int(c["ext"].max()), 0.2, 25.0)
-    assert (o.float().cpu() - o_ref.float()).abs().max().item() <= tol_pair(dtype, o_ref)
+    assert_elem_close(o, o_ref, dtype, pair=True, what="hip vs oracle", extra=_p_term(c, dtype, 0.2, 25.0))
 
 
 def test_extend_full_size_properties():
@@ -127,27 +142,34 @@ def test_extend_full_size_properties():
     start = torch.arange(B, device=DEV) * L
     o_full = torch.zeros(B * L, Hq, D, dtype=dtype, device=DEV)
     ops.extend_attention(q, ke, ve, o_full, kb, vb, r2t, rpi, full, full, start, L, D ** -0.5, 0.0)
+    # the P-rounding allowance at this size: the attention of |V| from the kernel itself (the oracle would take minutes; a
+    # smooth positive quantity, its own 16-bit rounding is covered by the factor 1.01)
+    a_full = torch.zeros_like(o_full)
+    ops.extend_attention(q, ke, ve.abs(), a_full, kb, vb.abs(), r2t, rpi, full, full, start, L, D ** -0.5, 0.0)
+    a_full = a_full.float() * 1.01
     # (1) second half with the first half cached
     h = L // 2
     sel = (torch.arange(B, device=DEV)[:, None] * L + h + torch.arange(h, device=DEV)[None]).view(-1)
     o_half = torch.zeros(B * h, Hq, D, dtype=dtype, device=DEV)
     ops.extend_attention(q[sel].contiguous(), ke[sel].contiguous(), ve[sel].contiguous(), o_half, kb, vb, r2t, rpi,
                          full, torch.full((B,), h, device=DEV), torch.arange(B, device=DEV) * h, h, D ** -0.5, 0.0)
-    bound = tol_pair(dtype, o_full)
-    assert (o_half.float() - o_full[sel].float()).abs().max().item() <= bound
+    assert_elem_close(o_half, o_full[sel], dtype, pair=True, what="second half behind a cached first half vs the full pass",
+                      extra=p_rounding_term(dtype, a_full[sel], pair=True))
     # (2) last row == decode
     last = start + L - 1
     o_dec = torch.zeros(B, Hq, D, dtype=dtype, device=DEV)
     ops.decode_attention(q[last].contiguous(), kb, vb, o_dec, None, None, None, torch.zeros(B, Hq, 1, D + 1, device=DEV),
                          r2t, rpi, full, D ** -0.5, 0.0)
-    assert (o_dec.float() - o_full[last].float()).abs().max().item() <= bound
+    assert_elem_close(o_dec, o_full[last], dtype, pair=True, what="decode of the last row vs the full pass",
+                      extra=p_rounding_term(dtype, a_full[last], pair=True))
     # (3) oracle on one short slice: request 1, rows [0, 96)
     rows = 96
     o_ref = torch.zeros(rows, Hq, D, dtype=dtype)
     oracle.extend_attention(q[L:L + rows].cpu(), ke[L:L + rows].cpu(), ve[L:L + rows].cpu(), o_ref, kb.cpu(), vb.cpu(),
                             r2t.cpu(), torch.tensor([1]), torch.tensor([rows]), torch.tensor([rows]), torch.tensor([0]),
                             rows, D ** -0.5, 0.0)
-    assert (o_full[L:L + rows].float().cpu() - o_ref.float()).abs().max().item() <= tol_pair(dtype, o_ref)
+    assert_elem_close(o_full[L:L + rows], o_ref, dtype, pair=True, what="full size vs oracle on one slice",
+                      extra=p_rounding_term(dtype, a_full[L:L + rows], pair=True))
 
 
 def _triton_meta(d, B):
@@ -200,14 +222,14 @@ def test_extend_custom_mask(Hq, Hkv, D, kind, skip_prefix):
     o = torch.zeros(T, Hq, D, dtype=dtype, device=DEV)
     ops.extend_attention_fwd(d["q"], d["ke"], d["ve"], o, d["kb"], d["vb"], qo_indptr, kv_indptr, kv_indices,
                              mask.to(DEV), True, mask_indptr.to(DEV), int(c["ext"].max()), D ** -0.5, 0.0, skip_prefix)
-    bound = tol_pair(dtype, o_ref)
-    assert (o.float().cpu() - o_ref.float()).abs().max().item() <= bound
+    term = _p_term(c, dtype, D ** -0.5, custom_mask=mask, mask_indptr=mask_indptr, skip_prefix_custom_mask=skip_prefix)
+    assert_elem_close(o, o_ref, dtype, pair=True, what="hip vs oracle (custom mask)", extra=term)
     if kind == "causal":
         o_plain = torch.zeros_like(o)
         ops.extend_attention_fwd(d["q"], d["ke"], d["ve"], o_plain, d["kb"], d["vb"], qo_indptr, kv_indptr, kv_indices,
                                  None, True, None, int(c["ext"].max()), D ** -0.5, 0.0)
         # same math; the unmasked launch may take the key-split variant (other summation order), so not bit-equal
-        assert (o.float() - o_plain.float()).abs().max().item() <= 2.0 ** -7 * float(o_plain.float().abs().max())
+        assert_elem_close(o, o_plain, dtype, pair=True, what="all-visible mask vs no mask", extra=term)
 
 
 @pytest.mark.parametrize("Hq,Hkv,D", [(32, 8, 128), (6, 2, 128), (4, 4, 80)])
@@ -226,12 +248,13 @@ def test_extend_sliding_window(Hq, Hkv, D, window):
     o = torch.zeros(T, Hq, D, dtype=dtype, device=DEV)
     ops.extend_attention_fwd(d["q"], d["ke"], d["ve"], o, d["kb"], d["vb"], qo_indptr, kv_indptr, kv_indices, None,
                              True, None, int(c["ext"].max()), D ** -0.5, 0.0, True, window)
-    assert (o.float().cpu() - o_ref.float()).abs().max().item() <= tol_pair(dtype, o_ref)
+    term = _p_term(c, dtype, D ** -0.5, sliding_window_size=window)
+    assert_elem_close(o, o_ref, dtype, pair=True, what="hip vs oracle", extra=term)
     if window >= 100000:
         o_plain = torch.zeros_like(o)
         ops.extend_attention_fwd(d["q"], d["ke"], d["ve"], o_plain, d["kb"], d["vb"], qo_indptr, kv_indptr, kv_indices,
                                  None, True, None, int(c["ext"].max()), D ** -0.5, 0.0)
-        assert (o.float() - o_plain.float()).abs().max().item() <= 2.0 ** -7 * float(o_plain.float().abs().max())
+        assert_elem_close(o, o_plain, dtype, pair=True, what="window larger than every length vs no window", extra=term)
 
 
 def test_extend_non_causal_vs_oracle():
@@ -247,7 +270,7 @@ def test_extend_non_causal_vs_oracle():
     o = torch.zeros(T, Hq, D, dtype=dtype, device=DEV)
     ops.extend_attention_fwd(d["q"], d["ke"], d["ve"], o, d["kb"], d["vb"], qo_indptr, kv_indptr, kv_indices, None,
                              False, None, int(c["ext"].max()), D ** -0.5, 0.0)
-    assert (o.float().cpu() - o_ref.float()).abs().max().item() <= tol_pair(dtype, o_ref)
+    assert_elem_close(o, o_ref, dtype, pair=True, what="hip vs oracle", extra=_p_term(c, dtype, D ** -0.5, causal=False))
 
 
 def test_extend_mask_argument_checks():

@@ -7,9 +7,9 @@ import pytest
 import torch
 
 import oracle
-from conftest import tol_pair
+from conftest import assert_elem_close
 from sglang_npu_amd import ops
-from test_extend_gpu import _case, _triton_meta
+from test_extend_gpu import _case, _p_term, _triton_meta
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -57,9 +57,9 @@ def test_parts_match_the_oracle_and_the_unsplit_launch(B, Hq, Hkv, max_prefix, m
     hint = int(c["prefix"].max())
     plain = _run(d, B, meta, int(c["ext"].max()), causal, None, None)
     parts = _run(d, B, meta, int(c["ext"].max()), causal, scratch, hint)
-    tol = tol_pair(dtype, o_ref)
-    assert (plain.float().cpu() - o_ref.float()).abs().max().item() <= tol
-    assert (parts.float().cpu() - o_ref.float()).abs().max().item() <= tol
+    term = _p_term(c, dtype, D ** -0.5, causal=causal)  # per-element P-rounding allowance (conftest.p_rounding_term)
+    assert_elem_close(plain, o_ref, dtype, pair=True, what="unsplit launch vs oracle", extra=term)
+    assert_elem_close(parts, o_ref, dtype, pair=True, what="KV-range parts vs oracle", extra=term)
     # the parts form really ran (the workspace was written) wherever the plan says it should
     assert bool(torch.isfinite(scratch.workspace).any()) == expect_parts
     # deterministic (the merge runs in range order whichever workgroup finishes last), and the counters are zero again
@@ -68,7 +68,7 @@ def test_parts_match_the_oracle_and_the_unsplit_launch(B, Hq, Hkv, max_prefix, m
     assert int(scratch.counters.abs().sum()) == 0
     # a bound that overstates the prefix only changes the split, not the result beyond rounding
     loose = _run(d, B, meta, int(c["ext"].max()), causal, scratch, hint + 3000)
-    assert (loose.float().cpu() - o_ref.float()).abs().max().item() <= tol
+    assert_elem_close(loose, o_ref, dtype, pair=True, what="parts planned from a loose bound vs oracle", extra=term)
 
 
 def test_parts_fall_back_where_the_form_does_not_apply():

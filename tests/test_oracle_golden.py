@@ -8,7 +8,7 @@ import pytest
 import torch
 
 import oracle
-from conftest import golden_names, load_golden, tol_for
+from conftest import assert_elem_close, count_beyond, golden_names, load_golden, p_rounding_term
 
 
 @pytest.mark.parametrize("name", golden_names("decode_"))
@@ -26,10 +26,9 @@ def test_decode_oracle_vs_reference(name):
     exp_v[g["loc"]] = g["value"]
     assert torch.equal(kb.view(torch.int16), exp_k.view(torch.int16))
     assert torch.equal(vb.view(torch.int16), exp_v.view(torch.int16))
-    bound = tol_for(g["dtype"], g["o_f32"])
-    assert (o.float() - g["o_f32"]).abs().max().item() <= bound
+    assert_elem_close(o, g["o_f32"], g["dtype"], what=f"{name}: oracle vs the fp32 truth")
     if g["ref_valid"]:
-        assert (o.float() - g["o_ref"].float()).abs().max().item() <= 2 * bound
+        assert_elem_close(o, g["o_ref"], g["dtype"], pair=True, what=f"{name}: oracle vs the compiled reference kernel")
 
 
 @pytest.mark.parametrize("name", golden_names("decode_"))
@@ -47,10 +46,9 @@ def test_decode_blocked_port_vs_reference_and_token_loop(name):
                                 g["req_to_token"], g["req_pool_indices"], g["seq_lens"], g["sm_scale"], g["logit_cap"],
                                 blocked=blocked)
         outs.append(o.float())
-    bound = tol_for(g["dtype"], g["o_f32"])
-    assert (outs[1] - g["o_f32"]).abs().max().item() <= bound
+    assert_elem_close(outs[1], g["o_f32"], g["dtype"], what=f"{name}: blocked oracle vs the fp32 truth")
     if g["ref_valid"]:
-        assert (outs[1] - g["o_ref"].float()).abs().max().item() <= 2 * bound
+        assert_elem_close(outs[1], g["o_ref"], g["dtype"], pair=True, what=f"{name}: blocked oracle vs the compiled reference")
     ulp = 2.0 ** -7 if g["dtype"] == "bf16" else 2.0 ** -10
     d = (outs[1] - outs[0]).abs()
     assert bool((d <= ulp * outs[0].abs() + 1e-6).all()), float(d.max())
@@ -65,10 +63,24 @@ def test_extend_oracle_vs_reference(name):
     oracle.extend_attention(g["q_extend"], g["k_extend"], g["v_extend"], o, g["k_buffer"], g["v_buffer"],
                             g["req_to_token"], g["req_pool_indices"], g["seq_lens"], g["extend_seq_lens"],
                             g["extend_start_loc"], max_len_extend, g["sm_scale"], 0.0)
-    bound = tol_for(g["dtype"], g["o_f32"])
-    assert (o.float() - g["o_f32"]).abs().max().item() <= 2 * bound
+    # The reference's extend kernel rounds the softmax numerators to the 16-bit type for its PV GEMM; its own output
+    # (o_ref) is 0.1-0.3 % of elements beyond the strict per-element bound of the fp32 truth on these fixtures (checked
+    # below, so the statement stays true).  The per-element allowance for that rounding is derived, not fitted:
+    # half an ulp of every p_j times |v_j|, i.e. the same attention evaluated on |V| (conftest.p_rounding_term).
+    a = torch.zeros_like(o)
+    oracle.extend_attention(g["q_extend"], g["k_extend"], g["v_extend"].abs(), a, g["k_buffer"], g["v_buffer"].abs(),
+                            g["req_to_token"], g["req_pool_indices"], g["seq_lens"], g["extend_seq_lens"],
+                            g["extend_start_loc"], max_len_extend, g["sm_scale"], 0.0, p_round=False)
+    assert_elem_close(o, g["o_f32"], g["dtype"], what=f"{name}: oracle vs the fp32 truth",
+                      extra=p_rounding_term(g["dtype"], a))
     if g["ref_valid"]:
-        assert (o.float() - g["o_ref"].float()).abs().max().item() <= 2 * bound
+        assert_elem_close(g["o_ref"], g["o_f32"], g["dtype"], what=f"{name}: compiled reference vs the fp32 truth",
+                          extra=p_rounding_term(g["dtype"], a))
+        assert_elem_close(o, g["o_ref"], g["dtype"], pair=True, what=f"{name}: oracle vs the compiled reference kernel",
+                          extra=p_rounding_term(g["dtype"], a, pair=True))
+        # the restatement is no further from the truth than the kernel it restates (strict bound, element counts)
+        n_ref, n_orc = count_beyond(g["o_ref"], g["o_f32"], g["dtype"]), count_beyond(o, g["o_f32"], g["dtype"])
+        assert n_orc <= n_ref + 8, f"{name}: {n_orc} oracle elements beyond the strict bound, the reference kernel has {n_ref}"
 
 
 def test_kv_indices_exact():
@@ -199,7 +211,8 @@ def test_extend_oracle_masks_vs_dense_torch(mode):
     s = torch.einsum("ehd,nhd->hen", q.float(), K) * D ** -0.5
     s = s.masked_fill(~vis[None], float("-inf"))
     ref = torch.einsum("hen,nhd->ehd", torch.softmax(s, -1), V)
-    assert (o.float() - ref).abs().max().item() <= tol_for("bf16", ref)
+    absv = torch.einsum("hen,nhd->ehd", torch.softmax(s, -1), V.abs())  # the P-rounding allowance, per element
+    assert_elem_close(o, ref, "bf16", what="oracle vs an fp32 evaluation", extra=p_rounding_term("bf16", absv))
 
 
 def test_extend_fp8kv_oracle_reduces_to_the_16bit_oracle():
