@@ -86,8 +86,9 @@ def parse():
     ap.add_argument("--kv-dtype", default="auto", choices=["auto", "fp8_e4m3", "fp8_e5m2"],
                     help="KV pool dtype (server_args.py --kv-cache-dtype); the headline number is 'auto' = the model dtype")
     ap.add_argument("--emulate-tp", type=int, default=0,
-                    help="debug only: run ONE rank's share of a TP=N step on this GPU with the all-reduce stubbed to "
-                         "identity (per-rank kernel rehearsal on a 1-GPU box; invalidates the number)")
+                    help="debug only: run ONE rank's share of a TP=N step on this GPU: plain collectives are identities, the "
+                         "fused all-reduce + add + RMSNorm kernels run on a one-rank communicator (the launches of a real "
+                         "rank, minus the peers' bytes; per-rank kernel rehearsal on a 1-GPU box; invalidates the number)")
     ap.add_argument("--call-order", default="reference", choices=["fused", "reference"],
                     help="which call order `value` reports: the reference's operator order (default: what an untouched SGLang "
                          "model file gets from the drop-in classes) or this repo's fused producers; the other one is reported "
@@ -540,54 +541,64 @@ def time_extend_kernel(cfg, device, tp):
 
 
 def time_awq_decode_gemms(layers, B, device):
-    """`roofline_gemm` of the AWQ config: the four INT4 g128 dequant-GEMMs of a layer at M = B rows, each
-    as one captured graph that runs it once per layer on that layer's own packed weights; bytes = K*N/2 (nibbles) +
-    K/G*N/2 (zeros) + K/G*N*2 (scales) + 2*M*K + 2*M*N."""
+    """`roofline_gemm` of the AWQ config (SURVEY 8d config 4, M in {1, 64, 512}): the four INT4 g128 dequant-GEMMs of a layer, each
+    as one captured graph that runs it once per layer on that layer's own packed weights, through the kernel AWQLinearMethod.apply
+    picks for the row count (M <= 64: the k-packed weight streamer; M = 512: 128 x 128 tiles on the fp16 MFMA with the INT4
+    unpacked in registers); bytes = K*N/2 (nibbles) + K/G*N/2 (zeros) + K/G*N*2 (scales) + 2*M*K + 2*M*N, flops = 2*M*N*K
+    against the 2.5 PFLOP/s dense fp16 MFMA peak."""
     from sglang_npu_amd import ops
     names = [("qkv", lambda l: l.self_attn.qkv_proj), ("o", lambda l: l.self_attn.o_proj),
              ("gate_up", lambda l: l.mlp.gate_up_proj), ("down", lambda l: l.mlp.down_proj)]
-    out = {"unit_hbm": "GB/s", "peak_hbm": HBM_PEAK_GBPS, "quant": "awq int4 g128 (k-packed copy, fp16 activations)", "shapes": []}
+    out = {"unit_hbm": "GB/s", "peak_hbm": HBM_PEAK_GBPS, "unit_mfma": "TFLOP/s", "peak_mfma": 2500.0,
+           "quant": "awq int4 g128 (k-packed copy, fp16 activations)", "shapes": []}
     g = torch.Generator(device=device).manual_seed(7)
     tot_us, tot_bytes = 0.0, 0
     for name, pick in names:
         lins = [pick(l) for l in layers]
         wp, sz, G = lins[0].awq_packed
         N, K = int(lins[0].awq_out_features), int(getattr(lins[0], "input_size_per_partition", lins[0].input_size))
-        x = torch.randn(B, K, device=device, generator=g).half()
+        row = {"name": name, "K": K, "N": N}
+        for M, key in ((1, "m1"), (B, "decode"), (512, "m512")):
+            x = torch.randn(M, K, device=device, generator=g).half()
+            fn = ops.awq_gemm_packed if M <= 64 else ops.awq_gemm_packed_tiled
 
-        def run():
-            for lin in lins:
-                ops.awq_gemm_packed(x, lin.awq_packed[0], lin.awq_packed[1], lin.awq_packed[2])
+            def run():
+                for lin in lins:
+                    fn(x, lin.awq_packed[0], lin.awq_packed[1], lin.awq_packed[2])
 
-        s = torch.cuda.Stream(device=device)
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            run()
-        torch.cuda.current_stream().wait_stream(s)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=s):
-            run()
-        graph.replay()
-        torch.cuda.synchronize()
-        ts = []
-        for _ in range(5):
-            st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            st.record()
-            graph.replay()
-            en.record()
+            s = torch.cuda.Stream(device=device)
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                run()
+            torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
-            ts.append(st.elapsed_time(en) * 1e3 / len(lins))
-        ts.sort()
-        us = ts[len(ts) // 2]
-        nbytes = K * N // 2 + (K // G) * N // 2 + (K // G) * N * 2 + 2 * B * K + 2 * B * N
-        out["shapes"].append({"name": name, "K": K, "N": N, "decode": {"M": B, "us": round(us, 2), "GBps": round(nbytes / us / 1e3, 1),
-                                                                     "frac_hbm": round(nbytes / us / 1e3 / HBM_PEAK_GBPS, 4)}})
-        tot_us += us
-        tot_bytes += nbytes
-        del graph
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=s):
+                run()
+            graph.replay()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(5):
+                st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                st.record()
+                graph.replay()
+                en.record()
+                torch.cuda.synchronize()
+                ts.append(st.elapsed_time(en) * 1e3 / len(lins))
+            ts.sort()
+            us = ts[len(ts) // 2]
+            nbytes = K * N // 2 + (K // G) * N // 2 + (K // G) * N * 2 + 2 * M * K + 2 * M * N
+            flops = 2.0 * M * N * K
+            row[key] = {"M": M, "us": round(us, 2), "GBps": round(nbytes / us / 1e3, 1),
+                        "frac_hbm": round(nbytes / us / 1e3 / HBM_PEAK_GBPS, 4),
+                        "TFLOPs": round(flops / us / 1e6, 1), "frac_mfma": round(flops / us / 1e6 / 2500.0, 4)}
+            if key == "decode":
+                tot_us += us
+                tot_bytes += nbytes
+            del graph
+        out["shapes"].append(row)
     out["decode_all_four"] = {"us": round(tot_us, 2), "frac_hbm": round(tot_bytes / tot_us / 1e3 / HBM_PEAK_GBPS, 4)}
-    out["note"] = ("event-timed in this run: one HIP graph per shape with one call per layer on that layer's packed weights, "
+    out["note"] = ("event-timed in this run: one HIP graph per (shape, M) with one call per layer on that layer's packed weights, "
                    "median of 5 replays / layers; includes the split-K finalize launch where the kernel uses it")
     return out
 
@@ -597,7 +608,8 @@ def time_decode_gemms(net, cfg, B, device, tp):
     layer on that layer's own weights (32 different weight matrices: nothing is served from L2 / Infinity Cache the
     way a loop over one matrix would be), timed with HIP events over 5 replays; M = B rows for the HBM fraction
     (bytes = M*K + K*N + 2*M*N + 4*(M+N)) and M = 1024 (the TTFT pass) and 4096 for the MFMA fraction
-    (2*M*N*K flops against the 5 PFLOP/s dense FP8 peak)."""
+    (2*M*N*K flops against the 5 PFLOP/s dense FP8 peak); M = 1 and M = 512 complete SURVEY 8d's list {1, 64, 512, 4096} (every
+    row carries both fractions: which one binds follows from M)."""
     from sglang_npu_amd import ops
     layers = list(net.layers)
     if getattr(layers[0].mlp.gate_up_proj, "awq_packed", None) is not None:
@@ -613,7 +625,8 @@ def time_decode_gemms(net, cfg, B, device, tp):
         lins = [pick(l) for l in layers]
         K, N = ops.fp8_weight_kn(lins[0].weight)
         row = {"name": name, "K": int(K), "N": int(N)}
-        for M, key in ((B, "decode"), (1024, "prefill_1024"), (4096, "prefill")):
+        # M in {1, 64, 512, 4096} (sgl-kernel/benchmark/bench_fp8_gemm.py:22-34), + 1024 (the TTFT pass)
+        for M, key in ((1, "m1"), (B, "decode"), (512, "m512"), (1024, "prefill_1024"), (4096, "prefill")):
             a = ((torch.rand(M, K, device=device, generator=g) - 0.5) * 8).to(torch.float8_e4m3fn)
             sa = torch.rand(M, 1, device=device, generator=g) * 1e-2 + 1e-3
 
@@ -756,7 +769,10 @@ def allreduce_latency_vs_size(tp_group, device, world):
             row[name + "_error"] = err or "failed on another rank"
         rows.append(row)
     return {"dtype": "bf16", "world": world, "link_model": "7 xGMI links x 153 GB/s per GPU", "method": "3 warm-ups + median of 20 "
-            "event-timed calls per (size, data plane), max over ranks", "planes": [p[0] for p in planes], "points": rows}
+            "event-timed calls per (size, data plane), max over ranks", "planes": [p[0] for p in planes], "points": rows,
+            "quickreduce_parity": "parity-unpinned: the QuickReduce codec is checked bit for bit against oracle/quick_reduce.py, a "
+                                  "restatement of quick_all_reduce.cuh:71-440 that no reference fixture pins, and against the "
+                                  "reference test's bound (test_quick_allreduce.py:131-165); rccl / p2p are exact sums"}
 
 
 def other_configs():
@@ -766,7 +782,8 @@ def other_configs():
     import subprocess
     runs = [("config 2: llama3-8b bf16 TP=1", ["--quant", "none"]),
             ("config 4: llama2-7b AWQ INT4 g128 TP=1", ["--model", "llama2-7b", "--quant", "awq"]),
-            ("config 5 (ONE rank of TP=8 on one GPU, collectives stubbed -- not a job number): llama3-70b w8a8_fp8",
+            ("config 5 (ONE rank of TP=8 on one GPU: the real rank's kernel sequence incl. the fused all-reduce + norm on a one-rank "
+             "communicator, no peers' bytes -- not a job number): llama3-70b w8a8_fp8",
              ["--model", "llama3-70b", "--emulate-tp", "8"])]
     out = []
     for name, extra in runs:
@@ -776,15 +793,18 @@ def other_configs():
             r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=240)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
             d = json.loads(line)
-            out.append({"config": name, "ms_per_step": d["ms_per_step"], "tokens_per_s": d["value"],
+            out.append({"config": name, "ms_per_step": d["ms_per_step"], "tokens_per_s": d["value"], "call_order": d.get("call_order"),
+                        "dropin_ms_per_step": d.get("dropin_ms_per_step"), "fused_ms_per_step": d.get("fused_ms_per_step"),
                         "ttft_ms_p50": d.get("ttft_ms_p50"), "decode_attention_frac_hbm": d["roofline"]["frac"],
+                        "decode_attention_us": d["roofline"].get("avg_launch_us"),
                         "workload": d["config"]["workload"]})
             if "launch_includes" in d["roofline"]:
                 out[-1]["decode_attention_launch_includes"] = d["roofline"]["launch_includes"]
             rg = d.get("roofline_gemm")
             if isinstance(rg, dict) and "decode_all_four" in rg:  # the config's own GEMM roofline (AWQ: config 4)
                 out[-1]["roofline_gemm_decode"] = {"all_four": rg["decode_all_four"],
-                                                   "shapes": {r["name"]: r["decode"] for r in rg.get("shapes", []) if "decode" in r}}
+                                                   "shapes": {r["name"]: {k: v for k, v in r.items() if isinstance(v, dict)}
+                                                              for r in rg.get("shapes", []) if "decode" in r}}
         except Exception as e:  # a side measurement: never take the headline down with it
             out.append({"config": name, "error": f"{type(e).__name__}: {str(e)[:200]}"})
     return out
@@ -964,7 +984,14 @@ def main():
     if args.emulate_tp > 1 and world == 1:
         from sglang_npu_amd.distributed import GroupCoordinator, set_tp_group
         tp_group = GroupCoordinator(None, 0, args.emulate_tp, device)
-        tp_group.stub_all_reduce = True  # all-reduce and all-gather become identities
+        tp_group.stub_all_reduce = True  # the plain all-reduce and all-gather become identities ...
+        # ... but the row-parallel layers still hand their output / split-K partials to the fused all-reduce + add + RMSNorm
+        # (+ FP8 quant) kernel, on a communicator whose only rank is this one: the launches of a real rank (no standalone
+        # finalize kernel), minus the peers' bytes
+        from sglang_npu_amd.distributed import CustomAllreduce
+        if os.environ.get("SGL_MI355_EMULATE_PLAIN_STUB", "0") in ("", "0"):
+            tp_group.ca_comm = CustomAllreduce.single_rank(device)
+            tp_group.fuse_under_stub = True
         set_tp_group(tp_group)
     tp = tp_group.world_size
     dist_on = world > 1  # a real multi-process job (false under --emulate-tp)
@@ -1035,7 +1062,7 @@ def main():
                                f"(token-level paged KV, {'HIP graph replay' if loop.graph is not None else 'eager launches'}); "
                                f"`value` = {order_name}",
                    "global_batch": args.batch, "seq_len": args.ctx, "layers": len(net.layers),
-                   "parallelism": f"tp{tp}" + (" (ONE rank emulated on one GPU, collectives stubbed: not a job number)"
+                   "parallelism": f"tp{tp}" + (" (ONE rank emulated on one GPU, fused all-reduce + norm on a one-rank communicator: not a job number)"
                                                if args.emulate_tp > 1 and not dist_on else "")},
         "call_order": "fused" if want_fused else "reference",
         "world_size_seen": torch.distributed.get_world_size() if dist_on else 1,

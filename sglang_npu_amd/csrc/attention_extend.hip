@@ -144,7 +144,7 @@ __device__ __forceinline__ float round_fp8(float x, bool e5) {
 template <int DTYPE, int D, typename IdxT, int GH, bool MASKED, bool KV8 = false, int KSPLIT = 1, int NSTAGE = 2,
           bool PARTS = false>
 __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
-  static_assert(NSTAGE >= 2 && NSTAGE <= 4 && (!KV8 || NSTAGE == 2), "the FP8 staging area is laid out for two stages");
+  static_assert(NSTAGE == 2, "two LDS stages: the tile loop is unrolled over them (run_phase), the FP8 staging area is laid out for them");
   static_assert(!PARTS || (!KV8 && !MASKED), "KV-range parts: 16-bit pools, no custom mask / window");
   using H = Half16<DTYPE>;
   using T = typename H::T;
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
     for (int r = 0; r < 16; ++r) o_acc[i][r] = 0.f;
 
   const float scale_log2 = a.sm_scale * kLog2e;
-  const bool has_cap = a.logit_cap > 0.f;
+  const bool has_cap = MASKED && a.logit_cap > 0.f;  // (the dispatcher sends a logit cap to the MASKED kernels)
   const int dma_row = lane / CH, dma_pos = lane % CH;
   const char* kpool = reinterpret_cast<const char*>(a.kb) + (int64_t)kvh * a.kb_sh * 2;
   const char* vpool = reinterpret_cast<const char*>(a.vb) + (int64_t)kvh * a.vb_sh * 2;
@@ -339,7 +339,11 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
     }
   };
 
-  auto compute = [&](int phase, int t, int stage, int n_keys) __attribute__((always_inline)) {
+  // `stage` arrives as std::integral_constant: with the stage a compile-time constant every LDS read of the tile is a
+  // lane-constant address register + an immediate offset (round 5: the v_add_u32 that re-based the address registers on the
+  // runtime stage every tile are gone; the tile loop is unrolled over its two stages instead).
+  auto compute = [&](int phase, int t, auto stage_c, int n_keys) __attribute__((always_inline)) {
+    constexpr int stage = decltype(stage_c)::value;
     const char* kst = smem + stage * STAGE_BYTES;
     const char* vst = kst + TILE_BYTES;
     // ---- S^T = K Q^T for the two 32-key halves
@@ -404,7 +408,15 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
         s_acc[ti][r] = s;
         m_tile = fmaxf(m_tile, s);
       }
-    m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32));
+    {  // the other 32-lane half holds the other keys of the same query row: one v_permlane32_swap (round 5) instead of a
+       // ds_bpermute round trip through the LDS pipe + 5 address instructions in the middle of the softmax chain.
+       // Inline asm on purpose: this hipcc folds __builtin_amdgcn_permlane32_swap(x, x) to {x, x} (as if swapping a value with
+       // itself did nothing -- it exchanges the two HALVES), which silently leaves every row with the maximum of half 0 only.
+       // a = {m.lo, m.lo}, b = {m.hi, m.hi} afterwards; s_nop 1: the VALU-write -> permlane-swap hazard of the ISA.
+      float ma = m_tile, mb = m_tile;
+      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(ma), "+v"(mb));
+      m_tile = fmaxf(ma, mb);
+    }
     const float m_new = fmaxf(m_run, m_tile);
     // a row may have seen no visible key yet (its first tile fully masked): keep everything at zero
     const float m_safe = m_new == -INFINITY ? 0.f : m_new;
@@ -460,25 +472,26 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
   // tile sequence: stage 1 (prefix, in passes of kIdxCap page-table entries), then stage 2 (new tokens)
   // Every pass runs the same double-buffered loop.
   auto run_phase = [&](int phase, int t_begin, int t_end, int idx_off, int n_keys) __attribute__((always_inline)) {
+    static_assert(NSTAGE == 2, "the tile loop is unrolled over two stages");
     if (t_begin >= t_end) return;
-    // prologue: NSTAGE - 1 tiles in flight
-#pragma unroll
-    for (int d = 0; d < NSTAGE - 1; ++d)
-      if (t_begin + d < t_end) issue(phase, t_begin + d, d, idx_off, n_keys);
-    int st = 0;
-    for (int t = t_begin; t < t_end; ++t) {
-      // the stage freed by the previous step's trailing barrier takes tile t + NSTAGE - 1
-      if (t + NSTAGE - 1 < t_end) issue(phase, t + NSTAGE - 1, st == 0 ? NSTAGE - 1 : st - 1, idx_off, n_keys);
-      const int behind = t_end - 1 - t;  // tiles issued after tile t that may stay in flight (at most NSTAGE - 1)
-      if (behind >= 3 && NSTAGE >= 4) wait_vmcnt<3 * 2 * PPW>();
-      else if (behind >= 2 && NSTAGE >= 3) wait_vmcnt<2 * 2 * PPW>();
-      else if (behind >= 1) wait_vmcnt<2 * PPW>();
-      else wait_vmcnt<0>();
+    issue(phase, t_begin, 0, idx_off, n_keys);  // prologue: one tile in flight
+    // one step = tile t out of stage S while tile t + 1 lands in the other stage
+    auto step = [&](int t, auto stage_c) __attribute__((always_inline)) {
+      constexpr int S = decltype(stage_c)::value;
+      if (t + 1 < t_end) {
+        issue(phase, t + 1, S ^ 1, idx_off, n_keys);  // the stage freed by the previous step's trailing barrier
+        wait_vmcnt<2 * PPW>();
+      } else {
+        wait_vmcnt<0>();
+      }
       __builtin_amdgcn_s_barrier();  // every wave's share of tile t has landed
-      compute(phase, t, st, n_keys);
+      compute(phase, t, stage_c, n_keys);
       wait_lgkmcnt0();
-      __builtin_amdgcn_s_barrier();  // everyone is done reading stage st before it is refilled
-      st = st + 1 == NSTAGE ? 0 : st + 1;
+      __builtin_amdgcn_s_barrier();  // everyone is done reading stage S before it is refilled
+    };
+    for (int t = t_begin; t < t_end; t += 2) {
+      step(t, std::integral_constant<int, 0>{});
+      if (t + 1 < t_end) step(t + 1, std::integral_constant<int, 1>{});
     }
   };
 
@@ -539,7 +552,7 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
       convert8(sb);
       wait_lgkmcnt0();
       __builtin_amdgcn_s_barrier();  // the 16-bit image of tile t is complete; staging sb may be refilled
-      compute(0, t, 0, n_keys);
+      compute(0, t, std::integral_constant<int, 0>{}, n_keys);
     }
     wait_lgkmcnt0();
   };
@@ -880,7 +893,8 @@ int dispatch(ExtendArgs a, int64_t batch, int D, int Dv, int max_len_extend, hip
                       a.kb_sn < max_row && a.vb_sn < max_row;
   if (D == Dv && aligned && rows32 && (D == 128 || D == 64)) {
     const int gh = (a.group % 4 == 0) ? 4 : (a.group % 2 == 0 ? 2 : 1);
-    const bool masked = a.mask != nullptr || a.window > 0;
+    // (a logit cap takes the MASKED instantiation too: its per-element tanh is not in the plain kernels at all -- round 5)
+    const bool masked = a.mask != nullptr || a.window > 0 || a.logit_cap > 0.f;
     if constexpr (std::is_same<IdxT, int32_t>::value) {
       // few workgroups (a short prefill of one or two requests): split every tile's keys over wave pairs so that the
       // longest query block, which sets the kernel time when there are at most about two workgroups per CU, takes half
@@ -903,25 +917,11 @@ int dispatch(ExtendArgs a, int64_t batch, int D, int Dv, int max_len_extend, hip
       }
       // (the forms without the key split start at 129 workgroups: never few enough items for parts)
       if (ksplit && !masked) {
-        // (Round 3: more tiles in flight -- NSTAGE 3 / 4, one workgroup per CU instead of two -- do NOT help: 38.8 / 38.9 us
-        //  against 35.8 at 1024 tokens, 83 against 54 at 1536 (profiles/r03_extend_nstage.txt).  The longest block's chain is
-        //  issue-bound -- ~1.4-2 us of MFMA + softmax + DMA address work per tile with two workgroups sharing the SIMDs --
-        //  not a chain of exposed DMA round trips.  The deeper variants are compiled only with -DSGLM_EXTEND_NSTAGE_VARIANTS=1,
-        //  where SGL_MI355_EXTEND_NSTAGE=3|4 selects them for A/B; the default library carries two stages only.)
-#ifndef SGLM_EXTEND_NSTAGE_VARIANTS
-#define SGLM_EXTEND_NSTAGE_VARIANTS 0
-#endif
-#if SGLM_EXTEND_NSTAGE_VARIANTS
-        static const int ns_env = [] { const char* e = getenv("SGL_MI355_EXTEND_NSTAGE"); return e ? atoi(e) : 2; }();
-#define EXT_KS(DD, GG)                                                                                              \
-  do {                                                                                                              \
-    if (ns_env == 2) return launch_mfma<DTYPE, DD, int32_t, GG, false, false, 2, 2>(a, batch, max_len_extend, s);   \
-    if (ns_env == 3) return launch_mfma<DTYPE, DD, int32_t, GG, false, false, 2, 3>(a, batch, max_len_extend, s);   \
-    return launch_mfma<DTYPE, DD, int32_t, GG, false, false, 2, 4>(a, batch, max_len_extend, s);                    \
-  } while (0)
-#else
+        // (Round 3: more tiles in flight -- three or four LDS stages, one workgroup per CU instead of two -- do NOT help: 38.8 /
+        //  38.9 us against 35.8 at 1024 tokens, 83 against 54 at 1536 (profiles/r03_extend_nstage.txt): the longest block's
+        //  chain is issue-bound, not a chain of exposed DMA round trips.  Since round 5 the tile loop is unrolled over exactly
+        //  two stages (immediate LDS offsets), and the deeper A/B variants are gone from the source.)
 #define EXT_KS(DD, GG) return launch_mfma<DTYPE, DD, int32_t, GG, false, false, 2, 2>(a, batch, max_len_extend, s)
-#endif
         if (D == 128) {
           if (gh == 4) EXT_KS(128, 2);
           EXT_KS(128, 1);

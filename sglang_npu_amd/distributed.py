@@ -114,9 +114,9 @@ class CustomAllreduce:
         self.world_size = dist.get_world_size(group) if world_size is None else world_size
         self.max_size = max_size
         self.device = device
-        if self.world_size == 1 or self.world_size > 8:
-            return
         self._lib, self._ct = _lib.lib(), ctypes
+        if self.world_size > 8 or (self.world_size == 1 and exchange):
+            return
         if not exchange:  # the caller wires the peers itself (connect_local)
             self._create()
             return
@@ -157,6 +157,17 @@ class CustomAllreduce:
             _lib.check(c._lib.sgl_mi355_ar_set_peers_local(c._comm, arr))
             c.disabled = False
         return comms
+
+    @classmethod
+    def single_rank(cls, device: torch.device, max_size: int = 16 * 1024 * 1024):
+        """A communicator of ONE rank (its only peer is itself): the all-reduce kernels run their whole protocol -- staging
+        stores, flag barriers, the reduction, the fused add + RMSNorm (+ FP8 quant) -- on the one GPU, with nothing to fetch
+        from peers.  For rehearsing ONE rank of a TP = N job on a 1-GPU box with the kernel SEQUENCE of the real job (bench.py
+        --emulate-tp N): the row-parallel layers hand their split-K partials to the fused all-reduce + norm kernel exactly as a
+        real rank does, instead of a finalize launch in front of an identity."""
+        c = cls(None, device, max_size, rank=0, world_size=1, exchange=False)
+        c.disabled = False
+        return c
 
     def should_custom_ar(self, inp: torch.Tensor) -> bool:
         if self.disabled or not inp.is_cuda or not inp.is_contiguous():
@@ -372,6 +383,15 @@ class GroupCoordinator:
         self.qr_comm: Optional["QuickAllReduce"] = None
         # measurement aid (overhead = (step with AR - step with AR stubbed to identity) / step)
         self.stub_all_reduce = False
+        # one-rank rehearsal of a TP = N job (bench.py --emulate-tp): the plain collectives are identities (stub_all_reduce) but
+        # the FUSED all-reduce + add + RMSNorm still runs, on a CustomAllreduce.single_rank communicator -- the launches of a
+        # real rank, minus the peers' bytes
+        self.fuse_under_stub = False
+
+    @property
+    def fused_collectives_on(self) -> bool:
+        """May a row-parallel layer leave its collective to the next norm's fused kernel?"""
+        return (not self.stub_all_reduce) or self.fuse_under_stub
 
     @property
     def side_stream(self):

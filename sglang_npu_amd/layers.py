@@ -38,12 +38,12 @@ class RMSNorm(torch.nn.Module):
         tp = get_tp_group()
         ca = tp.ca_comm
         if isinstance(x, ops.GemmPartials):  # the row-parallel GEMM left its epilogue here as well (needs_allreduce)
-            if (residual is not None and tp.world_size > 1 and not tp.stub_all_reduce and ca is not None
+            if (residual is not None and tp.world_size > 1 and tp.fused_collectives_on and ca is not None
                     and ca.should_fuse_norm_shape(x.M, x.N, x.out_dtype)):
                 r = ca.fused_add_rmsnorm_partials(x, residual, self.weight.data, self.variance_epsilon, quant_fp8)
                 return r, residual
             x = x.finalize()
-        if residual is not None and tp.world_size > 1 and not tp.stub_all_reduce and ca is not None and ca.should_fuse_norm(x):
+        if residual is not None and tp.world_size > 1 and tp.fused_collectives_on and ca is not None and ca.should_fuse_norm(x):
             r = ca.fused_add_rmsnorm(x, residual, self.weight.data, self.variance_epsilon, quant_fp8)
             return r, residual
         x = tensor_model_parallel_all_reduce(x)

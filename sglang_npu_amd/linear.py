@@ -153,7 +153,7 @@ class RowParallelLinear(LinearBase):
 
     def _can_fuse(self, out) -> bool:
         ca = get_tp_group().ca_comm
-        return (self.reduce_results and get_tensor_model_parallel_world_size() > 1 and not get_tp_group().stub_all_reduce
+        return (self.reduce_results and get_tensor_model_parallel_world_size() > 1 and get_tp_group().fused_collectives_on
                 and ca is not None and out.dim() == 2 and ca.should_fuse_norm(out))
 
     def _reduce(self, out, async_reduce: bool, can_fuse_mlp_allreduce: bool = False):
@@ -190,7 +190,7 @@ class RowParallelLinear(LinearBase):
         if get_tensor_model_parallel_world_size() > 1:
             tp = get_tp_group()
             ca = tp.ca_comm
-            if not (can_fuse_mlp_allreduce and self.reduce_results and not tp.stub_all_reduce and ca is not None
+            if not (can_fuse_mlp_allreduce and self.reduce_results and tp.fused_collectives_on and ca is not None
                     and qinput.dim() == 2
                     and ca.should_fuse_norm_shape(qinput.shape[0], self.output_size, out_dtype)):
                 return None

@@ -24,13 +24,18 @@ class HighArena:
 
     def __init__(self, gib: int = 6):
         self.buf = torch.empty(gib << 30, dtype=torch.uint8, device=DEV)
-        base = self.buf.data_ptr()
-        first = base if base & (1 << 31) else (base & ~0xFFFFFFFF) + (1 << 31)
-        if first < base:
-            first += 1 << 32
-        self.off = (first - base + 4095) & ~4095
-        self.end = min(self.buf.numel(), ((base + self.off) | 0x7FFFFFFF) + 1 - base)  # bit 31 stays set up to here
-        assert self.end - self.off >= 1 << 30, "no 1 GiB window with bit 31 set inside the arena"
+        base, size = self.buf.data_ptr(), self.buf.numel()
+        # windows of addresses with bit 31 set are [k * 4 GiB + 2 GiB, (k + 1) * 4 GiB); take the largest piece of one that lies
+        # inside the buffer (a 6 GiB buffer always holds at least 1 GiB of one, wherever it starts)
+        best = (0, 0)
+        k = base >> 32
+        for w in (k - 1, k, k + 1, k + 2):
+            lo, hi = max(base, (w << 32) + (1 << 31)), min(base + size, (w + 1) << 32)
+            if hi - lo > best[1] - best[0]:
+                best = (lo, hi)
+        assert best[1] - best[0] >= 1 << 30, "no 1 GiB window with bit 31 set inside the arena"
+        self.off = (best[0] - base + 4095) & ~4095
+        self.end = best[1] - base
 
     def put(self, t: torch.Tensor) -> torch.Tensor:
         n = t.numel() * t.element_size()
