@@ -536,7 +536,7 @@ def time_extend_kernel(cfg, device, tp):
             case["us_unsplit"] = round(timed({}), 2)
         out["cases"].append(case)
     out["note"] = ("event-timed in this run: one HIP graph of 8 launches per case, median of 5 replays / 8; counters of the same "
-                   "kernel (SQ_VALU_MFMA_BUSY_CYCLES, SQ_WAIT_INST_ANY): profiles/r04_extend_pmc.txt")
+                   "kernel (SQ_VALU_MFMA_BUSY_CYCLES, SQ_WAIT_INST_ANY): profiles/r05_extend_pmc.txt; per-tile instruction budget from the ISA: profiles/r05_extend_valu_budget.txt")
     return out
 
 
