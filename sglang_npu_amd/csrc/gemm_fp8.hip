@@ -2311,6 +2311,12 @@ int run_gemm(const GemmArgs& p, float* workspace, int64_t workspace_floats, hipS
 #undef TILED3_KS2
     }
     if (v3_env == 1) TILED3_GO(2, 4)
+    // Round 5: few row tiles x a very wide output (M = 1024 gate_up of Llama-3-8B: 4 x 112 tiles of 256 x 256 = 1.75 rounds of one
+    // eight-wave workgroup per CU) take the 256 x 256 form: 112.0 vs 124.4-126.8 us for the 128 x 256 form's 896 tiles (the same
+    // 1.75 rounds at two per CU, half the operand reuse per byte entering the CU), and ahead of the vendor library's 116.4
+    // (profiles/r05_prefill_gemm_forms.txt).  Everywhere else measured the 256 x 256 form loses (M = 1024 qkv / o / down: 53 / 50 /
+    // 147 us against 33 / 25 / 72; M = 4096 qkv / gate_up / down 108 / 418 / 186 against 92 / 393 / 180), so the rule is narrow.
+    if (v3_env < 0 && (p.M + 255) / 256 <= 4 && grid_b >= 384 && grid_b <= 512) TILED3_GO(2, 4)
     if (cb == 3) TILED3_GO(1, 3)
     TILED3_GO(1, 4)
 #undef TILED3_GO

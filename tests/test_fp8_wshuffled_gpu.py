@@ -91,7 +91,9 @@ def test_fp8_scaled_mm_on_shuffled_weight(M, N, K):
                                    # and the TTFT pass (M = 1024): every shape the 1024-token prefill runs
                                    (1024, 28672, 4096), (1024, 4096, 14336),
                                    # exactly one 128-row tile per CU: the eight-wave form with two k groups (round 4)
-                                   (1024, 6144, 4096), (1000, 6144, 1024), (1024, 8192, 8192)])
+                                   (1024, 6144, 4096), (1000, 6144, 1024), (1024, 8192, 8192),
+                                   # few row tiles x a very wide output: the 256 x 256 eight-wave form (round 5 dispatch rule), ragged both ways
+                                   (1000, 28000, 1024), (769, 32768, 512)])
 def test_prefill_shapes_on_shuffled_weight(M, N, K):
     """>= 192 tiles of 128 x 256 on a pre-shuffled weight: fp8_gemm_tiled3_kernel (weights global -> VGPR).  Same products
     and the same fp32 summation order over k as the row-major tiled kernel -> bit-identical; ragged M, N % 256 != 0."""
