@@ -569,6 +569,12 @@ int sgl_mi355_rmsnorm_quant_fp8(void* out_q, float* out_s, void* out, const void
 int sgl_mi355_silu_and_mul(void* out, const void* x, int64_t num_tokens, int64_t d, int dtype, void* stream);
 int sgl_mi355_silu_and_mul_quant_fp8(void* out_q, float* out_s, const void* x, int64_t num_tokens, int64_t d,
                                      int dtype, void* stream);
+/* The same pass returning BOTH the 16-bit activation of SiluAndMul.forward (activation.py:59-83) and its per-token FP8
+ * quantisation (the first half of apply_fp8_linear, fp8_utils.py:653-704, of the linear that consumes it): bit-identical to
+ * sgl_mi355_silu_and_mul followed by sgl_mi355_per_token_quant_fp8; lets the drop-in SiluAndMul hand an "FP8 companion" to
+ * the next W8A8Fp8LinearMethod.apply without a model-file change. */
+int sgl_mi355_silu_and_mul_with_quant_fp8(void* out, void* out_q, float* out_s, const void* x, int64_t num_tokens,
+                                          int64_t d, int dtype, void* stream);
 int sgl_mi355_rotary_embedding(const int64_t* positions, void* query, void* key, const float* cos_sin_cache,
                                int64_t num_tokens, int64_t num_q_heads, int64_t num_k_heads, int64_t head_size,
                                int64_t rot_dim, int64_t q_stride_t, int64_t k_stride_t, int is_neox, int dtype,

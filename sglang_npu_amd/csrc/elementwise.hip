@@ -771,6 +771,19 @@ extern "C" int sgl_mi355_silu_and_mul_quant_fp8(
                                  : launch_silu<SGL_MI355_FP16>(x, nullptr, out_q, out_s, num_tokens, d, as_stream(stream));
 }
 
+// SiluAndMul with BOTH results: the 16-bit activation the reference operator returns AND its per-token FP8 quantisation for
+// the FP8 linear that consumes it (the "FP8 companion" of layers.py / quantization.py): one pass, bit-identical to
+// sgl_mi355_silu_and_mul followed by sgl_mi355_per_token_quant_fp8.
+extern "C" int sgl_mi355_silu_and_mul_with_quant_fp8(
+    void* out, void* out_q, float* out_s, const void* x, int64_t num_tokens, int64_t d, int dtype, void* stream) {
+  int rc = check_rows("silu_and_mul_with_quant_fp8", num_tokens, d, 32768, dtype);
+  if (rc) return rc;
+  if (num_tokens == 0) return 0;
+  SGLM_CHECK_ARG(out && out_q && out_s && x, "silu_and_mul_with_quant_fp8: null tensor pointer");
+  return dtype == SGL_MI355_BF16 ? launch_silu<SGL_MI355_BF16>(x, out, out_q, out_s, num_tokens, d, as_stream(stream))
+                                 : launch_silu<SGL_MI355_FP16>(x, out, out_q, out_s, num_tokens, d, as_stream(stream));
+}
+
 extern "C" int sgl_mi355_rotary_embedding(
     const int64_t* positions, void* query, void* key, const float* cos_sin_cache, int64_t num_tokens,
     int64_t num_q_heads, int64_t num_k_heads, int64_t head_size, int64_t rot_dim, int64_t q_stride_t,

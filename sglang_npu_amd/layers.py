@@ -21,9 +21,25 @@ class RMSNorm(torch.nn.Module):
         self.weight = torch.nn.Parameter(torch.ones(hidden_size, dtype=dtype), requires_grad=False)
         self.variance_epsilon = eps
         self.hidden_size = hidden_size
+        # set by the first W8A8Fp8LinearMethod.apply that receives this layer's output (ops.take_fp8_companion): from then on
+        # the norm kernel also emits the per-token FP8 quantisation of its output, in the same pass
+        self.emit_fp8_companion = False
 
     def forward(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None
                 ) -> Union[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]]:
+        if ops.FP8_COMPANIONS and x.is_cuda and x.dim() == 2 and x.is_contiguous():
+            if self.emit_fp8_companion:
+                # one kernel: (add +) norm -> 16-bit `out` + (q, scale) = sgl_per_token_quant_fp8(out), bit for bit
+                q, s, out = ops.rmsnorm_quant_fp8(x, self.weight.data, self.variance_epsilon, residual=residual, want_out=True)
+                ops.attach_fp8_companion(out, q, s)
+                return out if residual is None else (out, residual)
+            if residual is not None:
+                ops.fused_add_rmsnorm(x, residual, self.weight.data, self.variance_epsilon)
+                x._sgl_mi355_producer = self
+                return x, residual
+            out = ops.rmsnorm(x, self.weight.data, self.variance_epsilon)
+            out._sgl_mi355_producer = self
+            return out
         if residual is not None:
             ops.fused_add_rmsnorm(x, residual, self.weight.data, self.variance_epsilon)
             return x, residual
@@ -58,7 +74,18 @@ class RMSNorm(torch.nn.Module):
 
 
 class SiluAndMul(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.emit_fp8_companion = False  # see RMSNorm
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if ops.FP8_COMPANIONS and x.is_cuda and x.is_contiguous():
+            if self.emit_fp8_companion:
+                out, q, s = ops.silu_and_mul_with_quant_fp8(x)
+                return ops.attach_fp8_companion(out, q, s)
+            out = ops.silu_and_mul(x)
+            out._sgl_mi355_producer = self
+            return out
         return ops.silu_and_mul(x)
 
 

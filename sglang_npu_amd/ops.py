@@ -1235,6 +1235,8 @@ def fused_add_rmsnorm(x: torch.Tensor, residual: torch.Tensor, weight: torch.Ten
     T, H = _rows(x)
     if residual.shape != x.shape or not residual.is_contiguous():
         raise RuntimeError("fused_add_rmsnorm: residual must match x and be contiguous")
+    for t in (x, residual):  # written in place through raw pointers (torch's version counter does not see it): any FP8 companion is stale
+        t.__dict__.pop("_sgl_mi355_fp8", None)
     _lib.check(_lib.lib().sgl_mi355_fused_add_rmsnorm(_ptr(x), _ptr(residual), _ptr(weight), _I64(T), _I64(H),
                                                       _F(eps), _I(_dtype_code(x)), _stream(x)))
 
@@ -1275,6 +1277,53 @@ def silu_and_mul_quant_fp8(x: torch.Tensor):
     return q, s
 
 
+def silu_and_mul_with_quant_fp8(x: torch.Tensor):
+    """SiLU*mul returning (out [T,d] 16-bit, q [T,d] e4m3fn, scale [T,1] f32) from one pass: `out` is what silu_and_mul
+    returns, (q, scale) what sgl_per_token_quant_fp8(out) would -- bit for bit."""
+    _need_gpu(x)
+    T, H2 = _rows(x)
+    d = H2 // 2
+    out = torch.empty(x.shape[:-1] + (d,), dtype=x.dtype, device=x.device)
+    q = torch.empty(x.shape[:-1] + (d,), dtype=torch.float8_e4m3fn, device=x.device)
+    s = torch.empty((T, 1), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().sgl_mi355_silu_and_mul_with_quant_fp8(_ptr(out), _ptr(q), _ptr(s), _ptr(x), _I64(T), _I64(d),
+                                                                _I(_dtype_code(x)), _stream(x)))
+    return out, q, s
+
+
+# ----------------------------------------------------------------------------- FP8 companions
+# A 16-bit activation that one of this backend's producers (RMSNorm, SiluAndMul) has ALSO quantised per token to FP8 in the
+# same pass carries that result as an attribute; W8A8Fp8LinearMethod.apply takes it instead of launching the quant kernel
+# again.  Model files stay untouched (the tensor travels from `self.input_layernorm(...)` to `self.qkv_proj(...)` as one
+# Python object) and results are bit-identical: the companion IS sgl_per_token_quant_fp8 of the tensor's values.
+# It is only valid while nobody has written to the tensor since: the version counter (shared by all views) and the storage
+# pointer are recorded and compared.  SGL_MI355_NO_FP8_COMPANION=1 switches the mechanism off.
+FP8_COMPANIONS = not os.environ.get("SGL_MI355_NO_FP8_COMPANION")
+
+
+def attach_fp8_companion(x: torch.Tensor, q: torch.Tensor, s: torch.Tensor, producer=None) -> torch.Tensor:
+    x._sgl_mi355_fp8 = (q, s, x._version, x.data_ptr())
+    if producer is not None:
+        x._sgl_mi355_producer = producer
+    return x
+
+
+def take_fp8_companion(x: torch.Tensor):
+    """(q2d, scale) if `x` still is what its producer quantised, else None.  A producer that did not emit one but could have
+    (it tagged the tensor with itself) is told to from now on: the next pass -- and every pass captured into a graph after the
+    usual eager warm-up -- saves the quant launch."""
+    comp = getattr(x, "_sgl_mi355_fp8", None)
+    if comp is not None:
+        q, s, version, ptr = comp
+        if version == x._version and ptr == x.data_ptr() and q.shape == x.shape:
+            return q.view(-1, q.shape[-1]), s
+        return None
+    prod = getattr(x, "_sgl_mi355_producer", None)
+    if prod is not None and FP8_COMPANIONS:
+        prod.emit_fp8_companion = True
+    return None
+
+
 _ARGMAX_WS = {}
 
 
@@ -1308,6 +1357,8 @@ def apply_rope_with_cos_sin_cache_inplace(positions, query, key, head_size, cos_
     _need_gpu(positions, query, key, cos_sin_cache)
     if cos_sin_cache.dtype != torch.float32 or not cos_sin_cache.is_contiguous():
         raise RuntimeError("cos_sin_cache should be float32")  # same check as the reference wrapper
+    for t in (query, key):  # (in place through raw pointers: see fused_add_rmsnorm)
+        t.__dict__.pop("_sgl_mi355_fp8", None)
     if positions.dtype != torch.int64:
         positions = positions.to(torch.int64)
     if query.stride(-1) != 1 or key.stride(-1) != 1:

@@ -264,6 +264,12 @@ class W8A8Fp8LinearMethod(LinearMethodBase):
         layer.input_scale = None
 
     def apply(self, layer, x: torch.Tensor, bias: Optional[torch.Tensor] = None):
+        # the producer of `x` (this backend's RMSNorm / SiluAndMul) may have quantised it already, in its own pass: the first
+        # half of apply_fp8_linear is then done (ops.take_fp8_companion: only while x is untouched since; bit-identical)
+        comp = ops.take_fp8_companion(x) if layer.input_scale is None else None
+        if comp is not None:
+            out = ops.fp8_scaled_mm(comp[0], layer.weight, comp[1], layer.weight_scale, out_dtype=x.dtype, bias=bias)
+            return out.view(*x.shape[:-1], out.shape[-1])
         return apply_fp8_linear(x, layer.weight, layer.weight_scale, input_scale=layer.input_scale, bias=bias)
 
     def apply_prequantized(self, layer, qinput: torch.Tensor, x_scale: torch.Tensor, out_dtype: torch.dtype,

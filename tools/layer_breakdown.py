@@ -19,9 +19,13 @@ for r in csv.DictReader(open(path)):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
 idx = [i for i, r in enumerate(rows) if anchor in r[2]]
+import os
+want = int(os.environ.get("LAYER_COUNT", "0"))  # only layers of exactly this many kernels (two call orders in one trace)
 layers = []
 for a, b in zip(idx, idx[1:]):
-    if 6 <= b - a <= 14:  # a decoder layer is 7-12 launches; the steps' first / last layers carry the LM head etc.
+    if want and b - a != want:
+        continue
+    if 6 <= b - a <= 16:  # a decoder layer is 7-12 launches; the steps' first / last layers carry the LM head etc.
         if must is not None and not any(must in rows[i][2] for i in range(a, b)):
             continue
         span = rows[b][0] - rows[a][0]
@@ -31,6 +35,8 @@ if not layers:
 layers.sort()
 span, a, b = layers[len(layers) // 2]
 counts = statistics.mode([l[2] - l[1] for l in layers])
+import collections
+print("# kernels per layer in this trace: " + ", ".join(f"{k}: {v} layers" for k, v in sorted(collections.Counter(b - a for a, b in zip(idx, idx[1:]) if b - a <= 20).items())))
 print(f"# median of {len(layers)} layers: {span / 1e3:.1f} us, {b - a} kernels (most common count {counts})")
 for i in range(a, b):
     st, en, name = rows[i]
