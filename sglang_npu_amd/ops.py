@@ -1059,20 +1059,51 @@ class TrackedCopy16:
     (parameter.write_epoch: uses of `.data`, in-place version, storage pointer) with the one the copy was made at and
     re-shuffles INTO THE SAME STORAGE when it moved -- graphs captured over the copy stay valid, and a weight update that
     SGLang applies in place without calling process_weights_after_loading (model_runner.py:831-900, 1777) is picked up by
-    the next eager call (a prefill)."""
-    __slots__ = ("src", "fm", "epoch", "rebuilds")
+    the next eager call (a prefill).
+    Limits: (1) a writer that holds an ALIAS taken earlier (`w = p.data` long ago, `w.copy_()` now) is invisible --
+    the alias has its own version counter; such a weight-update path must call `refresh_all()` (below) when it is done.
+    (2) Captured decode graphs multiply with whatever the copy's storage holds: the re-shuffle happens at the next EAGER use
+    or at `refresh_all()`, never inside a stream capture (a launch recorded there would re-run on every replay) -- during a
+    capture get() hands out the copy as it is."""
+    __slots__ = ("src", "fm", "epoch", "rebuilds", "__weakref__")
+    _live = None  # weak set of every live copy, for refresh_all()
 
     def __init__(self, src: torch.Tensor):
+        import weakref
         from .parameter import raw_data, write_epoch
         self.src = src
         self.fm = linear16_shuffle_weight(raw_data(src))
         self.epoch = write_epoch(src)
         self.rebuilds = 0
+        if TrackedCopy16._live is None:
+            TrackedCopy16._live = weakref.WeakSet()
+        TrackedCopy16._live.add(self)
+
+    @classmethod
+    def refresh_all(cls, force: bool = True) -> int:
+        """The hook for a weight-update path (model_runner.py:831-900 `update_weights_from_*`): re-shuffle every live copy
+        from its source NOW (force=True: whatever the epochs say -- covers writes through held aliases), into the same
+        storage, on the current stream.  Call it outside graph capture, after the update; returns the number of copies."""
+        from .parameter import raw_data, write_epoch
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("TrackedCopy16.refresh_all() inside a stream capture: call it eagerly after the weight update")
+        n = 0
+        for t in list(cls._live or ()):
+            w = raw_data(t.src)
+            if (w.dim() == 2 and tuple(w.shape) == (t.fm.N, t.fm.K) and w.dtype == t.fm.dtype and w.stride(1) == 1
+                    and w.device == t.fm.data.device and (force or write_epoch(t.src) != t.epoch)):
+                linear16_shuffle_weight(w, out=t.fm)
+                t.epoch = write_epoch(t.src)
+                t.rebuilds += 1
+                n += 1
+        return n
 
     def get(self) -> Optional[ShuffledWeight16]:
         from .parameter import raw_data, write_epoch
         e = write_epoch(self.src)
         if e != self.epoch:
+            if self.fm.data.is_cuda and torch.cuda.is_current_stream_capturing():
+                return self.fm  # never bake a re-shuffle into a graph: the next eager use (or refresh_all) brings it up to date
             w = raw_data(self.src)
             if (w.dim() != 2 or tuple(w.shape) != (self.fm.N, self.fm.K) or w.dtype != self.fm.dtype or w.stride(1) != 1
                     or w.device != self.fm.data.device):

@@ -235,16 +235,15 @@ class W8A8Fp8LinearMethod(LinearMethodBase):
     def process_weights_after_loading(self, layer) -> None:
         # w8a8_fp8.py:113-133
         weight = layer.weight
-        if ops.is_wshuffled(weight):
-            # re-entered on a layer this hook has already re-laid (the reference re-runs it after a reload,
-            # model_loader/loader.py:456, model_runner.py:731): back to the row-major [N, K] the code below starts from
-            weight = ops.fp8_shuffle_weight(raw_data(weight), inverse=True)
-            weight_scale = layer.weight_scale.detach()
-        elif weight.dtype == torch.float8_e4m3fn and weight.dim() == 2 and weight.stride(0) == 1 and weight.shape[0] > 1 \
-                and getattr(layer, "_sgl_mi355_weight_is_kn", False):
-            weight = weight.t()  # re-entered with the K-major [K, N] view this hook stored (no shuffle: N or K not divisible)
-            weight_scale = layer.weight_scale.detach()
-        elif self.quantization_config.is_checkpoint_fp8_serialized:
+        if ops.is_wshuffled(weight) or (weight.dtype == torch.float8_e4m3fn and weight.dim() == 2 and weight.stride(0) == 1
+                                        and weight.shape[0] > 1 and getattr(layer, "_sgl_mi355_weight_is_kn", False)):
+            # Re-entered on a layer this hook has already processed (the reference re-runs it after a reload,
+            # model_loader/loader.py:456, model_runner.py:731).  The parameter is the fragment-major uint8 [N / 16, 16 K] tensor
+            # (or the K-major [K, N] view) this hook stored: a real reload through the weight loaders fails on that shape before
+            # it gets here, so the bytes are the ones already laid out -- nothing to do, and the STORAGE must not change
+            # (captured HIP graphs hold its raw pointer).  In-place FP8 weight updates are unsupported.
+            return
+        if self.quantization_config.is_checkpoint_fp8_serialized:
             weight_scale = layer.weight_scale.detach()
         else:
             weight, weight_scale = per_channel_quant_fp8_weight(layer.weight)

@@ -476,6 +476,27 @@ def test_fragment_major_copy_follows_in_place_weight_updates():
     lin.load_state_dict(sd)
     check()
     assert tracked_copy.rebuilds > n0
+    # what the epoch cannot see -- a write through an alias taken EARLIER (its own version counter) -- is what the
+    # weight-update path's explicit hook is for: TrackedCopy16.refresh_all() re-shuffles every live copy into the same storage
+    alias = raw_data(lin.weight)
+    check()                                           # (the copy is up to date with the alias's current bytes)
+    alias.copy_(new())                                # invisible to the epoch
+    n1 = tracked_copy.rebuilds
+    assert ops.TrackedCopy16.refresh_all() >= 1 and tracked_copy.rebuilds == n1 + 1
+    check()
+    # ... and nothing is re-shuffled inside a stream capture (the launch would be baked into the graph): get() hands out the
+    # copy as it is, refresh_all() refuses
+    lin.weight.data.copy_(new())
+    n2 = tracked_copy.rebuilds
+    s_ = torch.cuda.Stream()
+    s_.wait_stream(torch.cuda.current_stream())
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr, stream=s_):
+        assert tracked_copy.get() is not None and tracked_copy.rebuilds == n2
+        with pytest.raises(RuntimeError, match="stream capture"):
+            ops.TrackedCopy16.refresh_all()
+    check()                                           # the next eager use brings it up to date
+    assert tracked_copy.rebuilds == n2 + 1
     # a parameter that no longer is this matrix: the copy is dropped, F.linear serves
     lin.weight.data = new()[:, :256].contiguous()
     assert lin.quant_method.weight_fm(lin) is None

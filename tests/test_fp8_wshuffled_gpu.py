@@ -157,19 +157,17 @@ def test_linear_method_shuffles_eligible_weights_only(monkeypatch):
     assert torch.equal(ops.fp8_shuffle_weight(a.weight.data, inverse=True).view(torch.uint8), b.weight.t().contiguous().view(torch.uint8))
     ya, yb = a(x)[0], b(x)[0]
     torch.testing.assert_close(ya.float(), yb.float(), rtol=2.0 ** -6, atol=1e-3 * float(yb.float().abs().max()))
-    # the hook is idempotent: re-entered on its own result (the reference re-runs it after a reload, loader.py:456) it
-    # un-shuffles, and shuffles again -- same bytes, same output
-    before = a.weight.data.clone()
-    monkeypatch.setattr(Q, "PRESHUFFLE_FP8_WEIGHTS", True)
-    a.quant_method.process_weights_after_loading(a)
-    assert ops.is_wshuffled(a.weight) and torch.equal(a.weight.data, before) and torch.equal(a(x)[0], ya)
-    monkeypatch.setattr(Q, "PRESHUFFLE_FP8_WEIGHTS", False)
-    b.quant_method.process_weights_after_loading(b)
-    assert b.weight.shape == (1024, 512) and torch.equal(b(x)[0], yb)
-    # ... and with the switch flipped in between the hook converts one form into the other
-    a.quant_method.process_weights_after_loading(a)
-    assert not ops.is_wshuffled(a.weight) and a.weight.shape == (1024, 512)
-    assert torch.equal(a.weight.t().contiguous().view(torch.uint8), b.weight.t().contiguous().view(torch.uint8))
+    # the hook is idempotent: re-entered on its own result (the reference re-runs it after a reload, loader.py:456) it returns
+    # at once -- same bytes, same output, and the SAME STORAGE (captured graphs hold its raw pointer), whatever the
+    # re-layout switch says by then
+    before, ptr_a, ptr_b = a.weight.data.clone(), a.weight.data_ptr(), b.weight.data_ptr()
+    for flag in (True, False):
+        monkeypatch.setattr(Q, "PRESHUFFLE_FP8_WEIGHTS", flag)
+        a.quant_method.process_weights_after_loading(a)
+        assert ops.is_wshuffled(a.weight) and a.weight.data_ptr() == ptr_a and torch.equal(a.weight.data, before)
+        assert torch.equal(a(x)[0], ya)
+        b.quant_method.process_weights_after_loading(b)
+        assert b.weight.shape == (1024, 512) and b.weight.data_ptr() == ptr_b and torch.equal(b(x)[0], yb)
     c = make(520, 1024, True)  # N % 16 != 0: stays row-major
     assert not ops.is_wshuffled(c.weight)
     d = make(512, 640, True)   # K % 512 != 0
