@@ -247,11 +247,13 @@ class CustomAllreduce:
         return (q, s) if quant_fp8 else out
 
     def fused_add_rmsnorm(self, inp: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float,
-                          quant_fp8: bool = False):
+                          quant_fp8: bool = False, with_fp8_companion: bool = False):
         """all_reduce(inp) + residual -> residual (in place); RMSNorm of the sum -> a new tensor, or with quant_fp8 its
         per-token e4m3 quantisation (q, scale).  One kernel; bit-identical to custom_all_reduce + fused_add_rmsnorm
         (+ sgl_per_token_quant_fp8).  The role of flashinfer_allreduce_residual_rmsnorm behind
-        RMSNorm.forward_with_allreduce_fusion (layers/layernorm.py:191-216)."""
+        RMSNorm.forward_with_allreduce_fusion (layers/layernorm.py:191-216).
+        with_fp8_companion (round 5): BOTH results from the one launch -- returns (out, q, scale); the drop-in RMSNorm attaches
+        (q, scale) to `out` for the FP8 linear that follows (ops.attach_fp8_companion)."""
         from . import _lib
         if self.timed_out():
             self.disabled = True
@@ -262,10 +264,10 @@ class CustomAllreduce:
         self._norm_h = H
         ct = self._ct
         out = q = s = None
-        if quant_fp8:
+        if quant_fp8 or with_fp8_companion:
             q = torch.empty((T, H), dtype=torch.float8_e4m3fn, device=inp.device)
             s = torch.empty((T, 1), dtype=torch.float32, device=inp.device)
-        else:
+        if not quant_fp8 or with_fp8_companion:
             out = torch.empty_like(inp)
         _lib.check(self._lib.sgl_mi355_ar_fused_add_rmsnorm(
             self._comm, ct.c_void_p(inp.data_ptr()), ct.c_void_p(residual.data_ptr()), ct.c_void_p(weight.data_ptr()),
@@ -273,6 +275,8 @@ class CustomAllreduce:
             ct.c_void_p(s.data_ptr()) if s is not None else None, ct.c_int64(T), ct.c_int64(H), ct.c_float(eps),
             ct.c_int(0 if inp.dtype == torch.bfloat16 else 1),
             ct.c_void_p(torch.cuda.current_stream(inp.device).cuda_stream)))
+        if with_fp8_companion:
+            return out, q, s
         return (q, s) if quant_fp8 else out
 
     @contextlib.contextmanager

@@ -60,6 +60,15 @@ class RMSNorm(torch.nn.Module):
                 return r, residual
             x = x.finalize()
         if residual is not None and tp.world_size > 1 and tp.fused_collectives_on and ca is not None and ca.should_fuse_norm(x):
+            if not quant_fp8 and ops.FP8_COMPANIONS:
+                # the reference call order under TP: the 16-bit result goes to an FP8 linear next -- once that linear has asked
+                # (emit_fp8_companion, see forward), the same launch also quantises it (out AND (q, scale))
+                if self.emit_fp8_companion:
+                    out, q, s = ca.fused_add_rmsnorm(x, residual, self.weight.data, self.variance_epsilon, with_fp8_companion=True)
+                    return ops.attach_fp8_companion(out, q, s), residual
+                out = ca.fused_add_rmsnorm(x, residual, self.weight.data, self.variance_epsilon)
+                out._sgl_mi355_producer = self
+                return out, residual
             r = ca.fused_add_rmsnorm(x, residual, self.weight.data, self.variance_epsilon, quant_fp8)
             return r, residual
         x = tensor_model_parallel_all_reduce(x)

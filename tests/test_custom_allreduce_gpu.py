@@ -186,6 +186,20 @@ def _local_ranks_worker(world, q):
                             assert torch.equal(outs[r][1], s_ref) and torch.equal(outs[r][0].view(torch.uint8), q_ref.view(torch.uint8))
                         else:
                             assert torch.equal(outs[r], x_ref), ("norm", dt, T, H, r)
+                # round 5: BOTH results from one launch (the FP8 companion of the drop-in RMSNorm under TP) = the two above
+                torch.cuda.synchronize()
+                res_ref = res0.clone()
+                q_ref, s_ref, x_ref = ops.rmsnorm_quant_fp8(ars[0], w, 1e-5, residual=res_ref, want_out=True)
+                torch.cuda.synchronize()
+                outs, ress = [], [res0.clone() for _ in range(world)]
+                for r in range(world):
+                    with torch.cuda.stream(streams[r]):
+                        outs.append(comms[r].fused_add_rmsnorm(parts[r], ress[r], w, 1e-5, with_fp8_companion=True))
+                torch.cuda.synchronize()
+                for r in range(world):
+                    o_, q_, s_ = outs[r]
+                    assert torch.equal(ress[r], res_ref) and torch.equal(o_, x_ref), ("both: norm", dt, T, H, r)
+                    assert torch.equal(s_, s_ref) and torch.equal(q_.view(torch.uint8), q_ref.view(torch.uint8)), ("both: quant", dt, T, H, r)
         # the same with every rank's addend still a split-K GEMM (ops.GemmPartials): the fused kernel runs the GEMM epilogue
         # while it stages the row -- bit-identical to finalize() + fused_add_rmsnorm; bias on rank 0 only (RowParallelLinear)
         # (rows kept at <= 32: all ranks' workgroups -- one per row, 1024 threads, 89 VGPRs in this form -- must be resident

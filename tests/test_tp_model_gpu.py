@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _run_stack(tp_rank, tp_world, device, fuse, async_ar, with_lm_head=False):
+def _run_stack(tp_rank, tp_world, device, fuse, async_ar, with_lm_head=False, reference_order=False, passes=1):
     """One prefill-free decode step of a 2-layer stack (with_lm_head=False: the output is the final hidden state;
     True: the vocab-parallel LM head's logits after the all-gather over the ranks, logits_processor.py:430-505)."""
     from sglang_npu_amd import model as M
@@ -61,9 +61,13 @@ def _run_stack(tp_rank, tp_world, device, fuse, async_ar, with_lm_head=False):
     fb = ForwardBatch(ForwardMode.DECODE, B, ids, rpi, seq, loc, B * ctx, None, pos, req_to_token_pool=r2t_pool,
                       token_to_kv_pool=kv_pool, attn_backend=backend)
     backend.init_forward_metadata(fb)
-    out = net(ids, pos, fb)
-    torch.cuda.synchronize()
-    return out.float().cpu()
+    if reference_order:  # models/llama.py's operator order through the drop-in classes (RMSNorm -> apply() -> RoPE -> attn ...)
+        net.fuse_quant = False
+    outs = []
+    for _ in range(passes):  # (the KV write of a decode step is idempotent: same slot, same values)
+        outs.append(net(ids, pos, fb).float().cpu())
+        torch.cuda.synchronize()
+    return outs[0] if passes == 1 else outs
 
 
 def _worker(rank, world, port, q):
@@ -83,6 +87,13 @@ def _worker(rank, world, port, q):
         for name, fuse, asy in (("sync", False, False), ("async", False, True), ("fused", True, False)):
             dist.barrier()
             outs[name] = _run_stack(rank, world, dev, fuse, asy)
+        # the reference call order, three passes: the first teaches the norms that FP8 linears follow them, from the second on
+        # the fused all-reduce + norm kernel also emits the FP8 companion (round 5) -- not one bit may move
+        dist.barrier()
+        ref_order = _run_stack(rank, world, dev, True, False, reference_order=True, passes=3)
+        assert torch.equal(ref_order[0], ref_order[1]) and torch.equal(ref_order[0], ref_order[2]), \
+            "FP8 companions changed the reference-order result under TP"
+        outs["reference_order"] = ref_order[0]
         assert torch.equal(outs["sync"], outs["async"]), "side-stream all-reduce changed the result"
         assert torch.equal(outs["sync"], outs["fused"]), "fused all-reduce + norm kernel changed the result"
         gathered = [None] * world
