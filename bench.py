@@ -1315,9 +1315,18 @@ def main():
             torch.cuda.empty_cache()
             a70 = copy.copy(args)
             a70.model = "llama3-70b"
+            # the fused all-reduce + norm staging area is bound to ONE row length per communicator (4096 from the 8B model):
+            # drop the binding while nothing is in flight on any rank, or every 70B collective would take the unfused path
+            torch.cuda.synchronize()
+            torch.distributed.barrier()
+            if tp_group.ca_comm is not None and not tp_group.ca_comm.disabled:
+                tp_group.ca_comm.rebind_fused_norm()
+            torch.distributed.barrier()
             net, cfg70, runner, backend, _ = build(a70, device, tp)
             loop = DecodeLoop(net, runner, backend, args.batch, args.ctx, device)
             can_fuse = net.fuse_quant
+            from sglang_npu_amd.distributed import DISPATCH_COUNTS as _DC0
+            _DC0.clear()
         except Exception as e:  # e.g. out of memory on one rank
             ok = 0.0
             res["error"] = f"{type(e).__name__}: {str(e)[:200]}"
@@ -1333,6 +1342,8 @@ def main():
                 set_call_order(first)
                 stub70 = timed(2, min(n70, 6)) / min(n70, 6) * 1e3
                 tp_group.stub_all_reduce = False
+                from sglang_npu_amd.distributed import DISPATCH_COUNTS as _DC
+                res["dispatch_since_capture"] = dict(_DC)  # (counted where Python dispatches: warm-ups + captures of this stage)
                 res.update({"call_order": "fused" if first else "reference",
                             "ms_per_step": round(ms70, 4), "tokens_per_s": round(args.batch / ms70 * 1e3, 1),
                             "ms_per_step_allreduce_stubbed": round(stub70, 4),

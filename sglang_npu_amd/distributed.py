@@ -429,6 +429,12 @@ class GroupCoordinator:
             return AllReduceHandle(input_)
         if not input_.is_cuda:
             return AllReduceHandle(self.all_reduce(input_))
+        if torch.cuda.is_current_stream_capturing() and not (
+                self.ca_comm is not None and not self.ca_comm.disabled and self.ca_comm.should_custom_ar(input_)):
+            # Under stream capture the process group's collective stays IN-STREAM: a fork to the side stream and back buys
+            # nothing inside a graph (the consumer is the next node anyway) and a library collective captured across two
+            # streams is the one pattern bench.py's capturability probe does not cover (round 5; first 8-GPU contact).
+            return AllReduceHandle(self.all_reduce(input_))
         side = self.side_stream
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream())
