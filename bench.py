@@ -54,7 +54,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PROFILED_STATS_GLOB = "r[0-9][0-9]_bench_tp1_kernel_stats.csv"  # rocprofv3 --kernel-trace --stats of `bench.py`, one per round
-PMC_SUMMARY = "r04_decode_pmc_instep.json"  # in-step counters of the profiled bench command, refreshed per round
+PMC_SUMMARY = "r05_decode_pmc_instep.json"  # in-step counters of the profiled bench command, refreshed per round
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 
 
@@ -1207,7 +1207,7 @@ def main():
         if tp == 1 and args.batch == 64 and (hq, hkv, d) == (32, 8, 128) and kv_esz == 2:
             traffic = int(alg_bytes * pmc["traffic_over_algorithmic"])
             traffic_src = (f"profiles/{PMC_SUMMARY}: FETCH_SIZE x2 (gfx950) + WRITE_SIZE of this kernel's launches INSIDE "
-                           f"the profiled `bench.py --steps 8 --warmup 2` step (tools/exp/prof_bench_pmc.sh, separate --pmc "
+                           f"the profiled `bench.py --steps 8 --warmup 2` step (tools/exp/prof_bench_r05.sh, separate --pmc "
                            f"passes), ratio {pmc['traffic_over_algorithmic']} to the algorithmic bytes of the lengths the run visits")
     except (OSError, KeyError, ValueError):
         pass
