@@ -85,6 +85,27 @@ __device__ __forceinline__ void seq_info(const ExtendArgs& a, int b, int64_t& id
   }
 }
 
+// Timing build (-DSGLM_EXT_TIMING=1, variant library only): wave 0 of the first kExtTimingWgs workgroups stamps s_memtime at
+// six points of every tile step into a debug buffer (ExtendArgs::part_ws of a launch without parts); each stamp sits behind a
+// v_readfirstlane of a value the phase produces, so that the in-order issue of the wave places it after the phase's results.
+// tools/exp/extend_phase_times.py reads the buffer through sgl_mi355_extend_timing_dump.
+#ifndef SGLM_EXT_TIMING
+#define SGLM_EXT_TIMING 0
+#endif
+#if SGLM_EXT_TIMING
+constexpr int kExtTimingWgs = 64, kExtTimingTiles = 80, kExtTimingStamps = 6;
+#define EXT_STAMP(slot, dep)                                                                                         \
+  do {                                                                                                               \
+    if (tstamp != nullptr && tstep < kExtTimingTiles) {                                                              \
+      asm volatile("" ::"s"(__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)(dep)))));                 \
+      const unsigned long long tnow = __builtin_readcyclecounter();                                                  \
+      if (lane == 0) tstamp[tstep * kExtTimingStamps + (slot)] = tnow;                                               \
+    }                                                                                                                \
+  } while (0)
+#else
+#define EXT_STAMP(slot, dep) do {} while (0)
+#endif
+
 template <int D>
 __device__ __forceinline__ int swz_k(int c, int row) {  // ds_read_b128 row reads, 32 rows per operand
   return (D == 128) ? (c ^ (row & 15)) : (c ^ ((row >> 1) & 7));
@@ -254,6 +275,14 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
   for (int i = 0; i < NDVB; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o_acc[i][r] = 0.f;
+#if SGLM_EXT_TIMING
+  unsigned long long* tstamp = nullptr;
+  int tstep = 0;
+  if constexpr (!PARTS) {
+    if (a.part_ws != nullptr && blockIdx.x < kExtTimingWgs && wave == 0)
+      tstamp = reinterpret_cast<unsigned long long*>(a.part_ws) + (int64_t)blockIdx.x * kExtTimingTiles * kExtTimingStamps;
+  }
+#endif
 
   const float scale_log2 = a.sm_scale * kLog2e;
   const bool has_cap = MASKED && a.logit_cap > 0.f;  // (the dispatcher sends a logit cap to the MASKED kernels)
@@ -339,10 +368,34 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
     }
   };
 
+  // One piece of this wave's share of extend-stage tile `t` (j < PPW: K piece j, else V piece j - PPW) into `stage`: the
+  // contiguous, all-rows-valid form only (scalar base + lane offset, no vector arithmetic).  Round 5: these are issued
+  // BETWEEN the MFMAs of the step that precedes the tile's (dma_between below) instead of in a block at the loop top, where
+  // stamps put them at ~160 cycles apiece = 1 300 cycles of every wave's step with nothing of its own in the matrix pipe
+  // (profiles/r05_extend_phase_times.txt; MI355X_MICROARCH.md: an LDS-DMA piece costs ~60 cycles of issue among bare MFMAs).
+  auto issue_piece = [&](int t, int stage, int j) __attribute__((always_inline)) {
+    const uint32_t kdst = __builtin_amdgcn_readfirstlane(lds_addr_of(smem + stage * STAGE_BYTES)) + wave * (PPW * 1024);
+    const int row0 = t * kBN + wave * (PPW * ROWS_PER_DMA);
+    if (j < PPW)
+      lds_dma16_s(kext + (uint64_t)(uint32_t)(row0 + j * ROWS_PER_DMA) * ke_rowb, dma_row * ke_rowb + ksw_of(j), kdst + j * 1024);
+    else
+      lds_dma16_s(vext + (uint64_t)(uint32_t)(row0 + (j - PPW) * ROWS_PER_DMA) * ve_rowb, dma_row * ve_rowb + vsw,
+                  kdst + TILE_BYTES + (j - PPW) * 1024);
+  };
+  // the 2 PPW pieces of the next tile spread over this step's MFMAs: one after every second QK^T MFMA, what is left after
+  // every second PV MFMA (GH = 4 form: 16 + 16 MFMAs, 8 pieces, all beside QK^T; key-split form: 8 + 8 MFMAs, 4 + 4)
+  constexpr int NQK = NTH * KS, NPV = NTH * 2 * NDVB;
+  constexpr int NP_QK = (2 * PPW) < (NQK / 2) ? (2 * PPW) : (NQK / 2);
+  constexpr int NP_PV = 2 * PPW - NP_QK;
+  static_assert(KV8 || NP_PV <= NPV / 2, "the pieces of a tile must fit between the MFMAs of a step");
+
   // `stage` arrives as std::integral_constant: with the stage a compile-time constant every LDS read of the tile is a
   // lane-constant address register + an immediate offset (round 5: the v_add_u32 that re-based the address registers on the
   // runtime stage every tile are gone; the tile loop is unrolled over its two stages instead).
-  auto compute = [&](int phase, int t, auto stage_c, int n_keys) __attribute__((always_inline)) {
+  // `inter` (wave-uniform, run time): issue tile t + 1's pieces (into the other stage) between this step's MFMAs -- a scalar
+  // branch around each piece, ONE body (two instantiations joined behind an `if` cost 32 v_mov_b64 per tile to reconcile
+  // the O accumulators' registers)
+  auto compute = [&](int phase, int t, auto stage_c, int n_keys, const bool inter) __attribute__((always_inline)) {
     constexpr int stage = decltype(stage_c)::value;
     const char* kst = smem + stage * STAGE_BYTES;
     const char* vst = kst + TILE_BYTES;
@@ -358,6 +411,11 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
       for (int s = 0; s < KS; ++s) {
         const x8 kf = *reinterpret_cast<const x8*>(kst + row * ROWB + swz_k<D>(2 * s + hh, row) * 16);
         s_acc[ti] = H::mfma32(kf, qf[s], s_acc[ti]);
+        if constexpr (!KV8) {
+          constexpr int every = NQK / NP_QK;
+          const int m = ti * KS + s;  // (compile-time after unrolling)
+          if (m % every == every - 1 && inter) issue_piece(t + 1, stage ^ 1, m / every);
+        }
       }
     }
     // ---- online softmax; key of (th, r) = t*64 + 32th + (r&3) + 8(r>>2) + 4hh
@@ -417,6 +475,7 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
       asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(ma), "+v"(mb));
       m_tile = fmaxf(ma, mb);
     }
+    EXT_STAMP(2, m_tile);  // QK^T MFMAs + scale + row maximum done
     const float m_new = fmaxf(m_run, m_tile);
     // a row may have seen no visible key yet (its first tile fully masked): keep everything at zero
     const float m_safe = m_new == -INFINITY ? 0.f : m_new;
@@ -433,6 +492,7 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
       }
     l_run = l_run * alpha + psum;
     m_run = m_new;
+    EXT_STAMP(3, psum);  // exp2 / row sum done (P packed)
     // the running maximum moves in the first tiles of a row and then rarely: when NO lane of the wave has a new maximum
     // alpha is exactly 1 everywhere and the 16 NDVB multiplies (a quarter of the tile's vector instructions) are skipped --
     // bit-identical, since x * 1.0f == x
@@ -465,6 +525,11 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
             vf[4 + j] = v_hi[j];
           }
           o_acc[dvb] = H::mfma32(vf, pf[ti][s2], o_acc[dvb]);
+          if constexpr (!KV8 && NP_PV > 0) {
+            constexpr int every = NP_PV > 0 ? NPV / NP_PV : 1;
+            const int m = (ti * 2 + s2) * NDVB + dvb;
+            if (m % every == every - 1 && inter) issue_piece(t + 1, stage ^ 1, NP_QK + m / every);
+          }
         }
       }
   };
@@ -478,16 +543,32 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
     // one step = tile t out of stage S while tile t + 1 lands in the other stage
     auto step = [&](int t, auto stage_c) __attribute__((always_inline)) {
       constexpr int S = decltype(stage_c)::value;
-      if (t + 1 < t_end) {
-        issue(phase, t + 1, S ^ 1, idx_off, n_keys);  // the stage freed by the previous step's trailing barrier
-        wait_vmcnt<2 * PPW>();
-      } else {
-        wait_vmcnt<0>();
+      // extend stage, 16-bit kernels: when every row of this wave's share of tile t + 1 is a real key, its pieces go out
+      // between this step's MFMAs (issue_piece); the ragged last tile and the prefix stage keep the block at the top
+      // (measured, same box, us, block at the top -> between the MFMAs: L = 4096 173.3 -> 168.5, 8192 554.9 -> 549.6, 4 x 2048
+      //  160.4 -> 160.7 on the GH = 4 form; the key-split form of short prefills LOSES 3-5 % -- 8 MFMAs per phase leave no room
+      //  beside them: L = 1024 24.7 -> 25.5 -- and keeps the block)
+      bool inter = false;
+      if constexpr (!KV8 && KSPLIT == 1) {
+        inter = phase == 1 && t + 1 < t_end && (t + 1) * kBN + (wave + 1) * (PPW * ROWS_PER_DMA) <= n_keys;
       }
+      if (t + 1 < t_end && !inter) {
+        issue(phase, t + 1, S ^ 1, idx_off, n_keys);  // the stage freed by the previous step's trailing barrier
+        wait_vmcnt<2 * PPW>();                        // tile t's pieces are older than these: landed
+      } else {
+        wait_vmcnt<0>();                              // nothing younger than tile t's pieces is in flight
+      }
+      EXT_STAMP(0, 0.f);             // own share of tile t landed
       __builtin_amdgcn_s_barrier();  // every wave's share of tile t has landed
-      compute(phase, t, stage_c, n_keys);
+      EXT_STAMP(1, 0.f);
+      compute(phase, t, stage_c, n_keys, inter);
       wait_lgkmcnt0();
+      EXT_STAMP(4, o_acc[NDVB - 1][15]);  // PV MFMAs done
       __builtin_amdgcn_s_barrier();  // everyone is done reading stage S before it is refilled
+      EXT_STAMP(5, 0.f);
+#if SGLM_EXT_TIMING
+      ++tstep;
+#endif
     };
     for (int t = t_begin; t < t_end; t += 2) {
       step(t, std::integral_constant<int, 0>{});
@@ -552,7 +633,7 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
       convert8(sb);
       wait_lgkmcnt0();
       __builtin_amdgcn_s_barrier();  // the 16-bit image of tile t is complete; staging sb may be refilled
-      compute(0, t, std::integral_constant<int, 0>{}, n_keys);
+      compute(0, t, std::integral_constant<int, 0>{}, n_keys, false);
     }
     wait_lgkmcnt0();
   };
@@ -782,6 +863,19 @@ __global__ __launch_bounds__(64) void extend_generic_kernel(ExtendArgs a, int D,
   }
 }
 
+#if SGLM_EXT_TIMING
+inline unsigned long long* ext_timing_buffer() {
+  static unsigned long long* buf = [] {
+    void* p = nullptr;
+    const size_t n = (size_t)kExtTimingWgs * kExtTimingTiles * kExtTimingStamps * 8;
+    if (hipMalloc(&p, n) != hipSuccess) return (unsigned long long*)nullptr;
+    (void)hipMemset(p, 0, n);
+    return (unsigned long long*)p;
+  }();
+  return buf;
+}
+#endif
+
 template <int DTYPE, int D, typename IdxT, int GH, bool MASKED, bool KV8 = false, int KSPLIT = 1, int NSTAGE = 2,
           bool PARTS = false>
 int launch_mfma(ExtendArgs a, int64_t batch, int max_len_extend, hipStream_t s) {
@@ -801,6 +895,11 @@ int launch_mfma(ExtendArgs a, int64_t batch, int max_len_extend, hipStream_t s) 
   }
   // (Tried, round 3: with 512 workgroups on 256 CUs, the second 256 in ASCENDING weight so that a CU gets ranks j and
   //  511 - j instead of j and 256 + j -- no change, 35.9 vs 36.1 us at 1024 tokens: profiles/r03_extend_fold.txt.)
+#if SGLM_EXT_TIMING
+  if constexpr (!PARTS) {
+    if (a.part_ws == nullptr) a.part_ws = reinterpret_cast<float*>(ext_timing_buffer());
+  }
+#endif
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, a);
   return check_hip(hipGetLastError(), "extend_mfma_kernel launch");
 }
@@ -967,6 +1066,20 @@ int check_common(int64_t batch, int64_t Hq, int64_t Hkv, int64_t D, int64_t Dv, 
 }  // namespace sglm
 
 using namespace sglm;
+
+#if SGLM_EXT_TIMING
+// timing build only: copy the stamps out (device-synchronising) and clear them
+extern "C" int sgl_mi355_extend_timing_dump(void* host_buf, int64_t bytes) {
+  const int64_t n = (int64_t)kExtTimingWgs * kExtTimingTiles * kExtTimingStamps * 8;
+  SGLM_CHECK_ARG(host_buf && bytes >= n, "extend_timing_dump: buffer of %ld bytes needed", (long)n);
+  unsigned long long* d = ext_timing_buffer();
+  SGLM_CHECK_ARG(d != nullptr, "extend_timing_dump: no debug buffer");
+  SGLM_CHECK_HIP(hipDeviceSynchronize());
+  SGLM_CHECK_HIP(hipMemcpy(host_buf, d, n, hipMemcpyDeviceToHost));
+  SGLM_CHECK_HIP(hipMemset(d, 0, n));
+  return 0;
+}
+#endif
 
 static int extend_fwd_impl(int kv8,
     

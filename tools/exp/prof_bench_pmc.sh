@@ -50,8 +50,8 @@ for counter, d in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
             if r["Counter_Name"] == counter and "decode_mfma_pair" in r["Kernel_Name"]:
                 w.writerow([r["Dispatch_Id"], r["Kernel_Name"][:58], r["Grid_Size"], counter, r["Counter_Value"]])
 PY
-rm -rf gpurun_out/pmc_r4
-
+# (round 5, ADVICE r4: this breakdown used to run AFTER the traces were deleted and wrote only an error; the round-5 profile
+#  set is tools/exp/prof_bench_r05.sh, which takes every breakdown before it drops the traces)
 python3 tools/layer_breakdown.py gpurun_out/pmc_r4/trace/*/*kernel_trace.csv "extend_mfma_kernel<0, 128, int, 2, false, false, 2" "fp8_gemm_wstream_kernel<0, 8" > gpurun_out/r04_layer_breakdown_prefill_128.txt 2>&1
 cat gpurun_out/r04_layer_breakdown_prefill_128.txt
 rm -rf gpurun_out/pmc_r4
