@@ -226,7 +226,7 @@ def time_attention_kernel(loop, steps):
     time_attention_kernel.merged_launches = False
     names = [n for n in dir(ops) if n.startswith("decode_attention") and callable(getattr(ops, n))]
     declines = {"decode_attention_qkv_partials": (False, None), "decode_attention_paged_absmax": (False, None),
-                "decode_attention_paged_merged": (False,)}
+                "decode_attention_paged_merged": (False,), "decode_attention_paged_newkv": (False,)}
     real = {n: getattr(ops, n) for n in names}
     pairs = []
 

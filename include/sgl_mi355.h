@@ -321,6 +321,20 @@ int sgl_mi355_decode_attention_quant(
     int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h,
     int64_t o_stride_b, int64_t o_stride_h, float sm_scale, float logit_cap, int dtype, void* stream);
 
+/* Paged decode WITH the step's KV write in the same launch: AttentionBackend.forward(..., save_kv_cache=True)
+ * (base_attn_backend.py:57-89 -> memory_pool.py:369-407 set_kv_buffer, then triton_backend.py:686-732) as ONE kernel.
+ * key / value: the new tokens' rows [B, Hk, D] (element strides key_stride_b / _h), RoPE already applied; loc[b]: the pool
+ * row they are written to, which MUST be the page-table entry of position seq_lens[b] - 1 (out_cache_loc of a decode
+ * batch).  The new token enters the softmax from the tensors, the stream covers the older tokens.  One split, the
+ * pairs-of-items kernel only: SGL_MI355_ERR_UNSUPPORTED (nothing launched, nothing written) otherwise -- the caller then
+ * calls sgl_mi355_set_kv_buffer and sgl_mi355_decode_attention. */
+int sgl_mi355_decode_attention_newkv(
+    const void* query, void* k_cache, void* v_cache, void* output, const void* key, const void* value, const void* loc,
+    int loc_is64, const void* req_to_token, int req_to_token_is64, const int64_t* req_pool_indices, const int64_t* seq_lens,
+    int64_t num_seqs, int64_t max_context_len, int64_t num_heads, int64_t num_kv_heads, int64_t head_size, int64_t q_stride_b,
+    int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h, int64_t key_stride_b,
+    int64_t key_stride_h, int64_t value_stride_b, int64_t value_stride_h, int64_t o_stride_b, int64_t o_stride_h,
+    float sm_scale, float logit_cap, int dtype, void* stream);
 /* Paged decode with kv-splits whose merge -- and, if out_q / out_s are given, the per-token FP8 quant of the merged row --
  * happens inside the SAME launch (no stage-2 kernel, no quant kernel).
  * Replaces: decode_attention_fwd stage 1 + stage 2 (decode_attention.py:404-488, 491-596; decode.cpp:812-860) [+

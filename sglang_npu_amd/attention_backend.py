@@ -49,6 +49,12 @@ FUSE_SPLIT_MERGE_MAX_WGS = 8
 # lands on the critical path where the 4.8 us quant launch was -- headline step 6.146 ms with the separate launch, 6.164
 # with this (attention in-step 95.5 -> 97.7 us, same box, profiles/r03_decode_quant_in_launch.txt).
 FUSE_DECODE_QUANT = bool(os.environ.get("SGL_MI355_DECODE_QUANT_FUSION"))
+# round 5, OPT-IN (SGL_MI355_DECODE_KV_WRITE_FUSION=1): forward_decode(save_kv_cache=True) writes the step's K / V rows from
+# INSIDE the attention launch when the batch runs the pairs-of-items kernel (ops.decode_attention_paged_newkv).  Parity-green
+# (tests/test_decode_newkv_gpu.py) but no faster: one launch fewer per layer, 6.357 / 6.373 ms against 6.377 ms per step on the
+# same box (profiles/r05_decode_kv_write_fusion.txt) -- the write and the new token's q.k sit at the head of the kernel's
+# dependency chain and cost what the 2.5 us set_kv launch did.  Default: set_kv_buffer + attention, the reference's two calls.
+FUSE_DECODE_KV_WRITE = bool(os.environ.get("SGL_MI355_DECODE_KV_WRITE_FUSION"))
 # extend launches with few, long items (one short request behind a long cached prefix; the heaviest query blocks of a single
 # 1024-token prefill) cut every item's keys into up to four ranges over as many workgroups (csrc/attention_extend.hip PARTS).
 # SGL_MI355_EXTEND_PARTS=0: never.
@@ -392,6 +398,23 @@ class MI355AttnBackend(AttentionBackend):
             o = q.new_empty((q.shape[0], layer.tp_q_head_num * layer.v_head_dim))
         else:
             o = torch.empty_like(q)
+        if (save_kv_cache and FUSE_DECODE_KV_WRITE and not sliding and md.kv_indices is None and k is not None
+                and isinstance(md.num_kv_splits, int) and md.num_kv_splits == 1 and layer.qk_head_dim == layer.v_head_dim
+                and getattr(layer, "k_scale", None) is None and getattr(layer, "v_scale", None) is None
+                and getattr(forward_batch.token_to_kv_pool, "store_dtype", None) == getattr(forward_batch.token_to_kv_pool, "dtype", 0)):
+            # opt-in: set_kv_buffer + decode attention as ONE launch (base_attn_backend.py:57-89 hands both to this call):
+            # the step's K / V rows go to the pool from inside the attention kernel, which takes the new token into the softmax
+            # straight from the tensors.  out_cache_loc of a decode batch IS the page-table entry of position seq_len - 1.
+            # Declines (False, nothing written) outside the pairs-of-items kernel; pools with their own write (scales, ...) keep it.
+            kb = forward_batch.token_to_kv_pool.get_key_buffer(layer.layer_id)
+            vb = forward_batch.token_to_kv_pool.get_value_buffer(layer.layer_id)
+            q3 = q.view(-1, layer.tp_q_head_num, layer.qk_head_dim)
+            k3 = k.view(-1, layer.tp_k_head_num, layer.qk_head_dim)
+            v3 = v.view(-1, layer.tp_k_head_num, layer.v_head_dim)
+            if ops.decode_attention_paged_newkv(q3, kb, vb, o.view(-1, layer.tp_q_head_num, layer.v_head_dim), k3, v3,
+                                                forward_batch.out_cache_loc, self.req_to_token, forward_batch.req_pool_indices,
+                                                forward_batch.seq_lens, layer.scaling, layer.logit_cap):
+                return o
         if save_kv_cache:
             forward_batch.token_to_kv_pool.set_kv_buffer(layer, forward_batch.out_cache_loc, k, v)
         md = self.forward_metadata

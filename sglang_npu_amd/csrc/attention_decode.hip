@@ -108,6 +108,11 @@ struct FusedQkv {
   const void* loc;           // [B] pool rows of the new tokens (int32 / int64)
   int loc_is64;
   const float* cos_sin;      // [max_pos][D] = cos | sin (rot_dim == D, neox pairs (d, d + D/2))
+  // FUSED == 2 (round 5, sgl_mi355_decode_attention_newkv): the new token's K / V rows are finished tensors (RoPE already
+  // applied by the caller's operator): [B, Hk, D] with these element strides.  Only `loc` above is used besides them.
+  const void* k_new;
+  const void* v_new;
+  int64_t kn_sb, kn_sh, vn_sb, vn_sh;
 };
 
 __device__ __forceinline__ void split_range(const DecodeArgs& a, int b, int split, int64_t& base, int& s0, int& s1) {
@@ -669,7 +674,12 @@ __global__ __launch_bounds__(kWaves * 64) void decode_mfma_kernel(DecodeArgs a) 
 // workgroup counts its items in on merge_counters[b], and the one that completes request b's count reads the row back
 // with coherent loads and quantises it with sgl_per_token_quant_fp8's arithmetic (quant_staged_row): same bits as the
 // quant launch it replaces, ~0.1 us of work for one workgroup in 32 instead of a 4.8 us launch behind the slowest one.
-template <int DTYPE, int D, typename IdxT, bool KV8 = false, bool FUSED = false, bool QOUT = false>
+// FUSED: 0 = every token comes from the pool; 1 = q / k / v of this step out of the qkv GEMM's partial sums (opt-in build);
+// 2 = the new token's K / V rows are tensors (fq.k_new / v_new): the launch writes them to the pool rows loc[b] for the steps
+// to come and takes them into the softmax as one more partial state at the merge, exactly like form 1 -- the stream covers
+// the len - 1 older tokens, and the KV-write launch in front of the attention disappears (the reference call order:
+// attn_backend.forward(save_kv_cache=True)).  Contract of form 2: loc[b] IS the page-table entry of position seq_lens[b] - 1.
+template <int DTYPE, int D, typename IdxT, bool KV8 = false, int FUSED = 0, bool QOUT = false>
 __global__ __launch_bounds__(256) void decode_mfma_pair_kernel(DecodeArgs a, int num_items, FusedQkv fq) {
   using H = Half16<DTYPE>;
   using T = typename H::T;
@@ -733,7 +743,7 @@ __global__ __launch_bounds__(256) void decode_mfma_pair_kernel(DecodeArgs a, int
     newtok[i] = FUSED && ok && s1 > 0;
     it[i].kbase = reinterpret_cast<const char*>(a.k) + (int64_t)kvh * a.k_sh * KVB;
     it[i].vbase = reinterpret_cast<const char*>(a.v) + (int64_t)kvh * a.v_sh * KVB;
-    if constexpr (!FUSED) {
+    if constexpr (FUSED != 1) {
       const T* qp = reinterpret_cast<const T*>(a.q) + (int64_t)b * a.q_sb + (int64_t)(it[i].h0 + hl) * a.q_sh;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
@@ -753,7 +763,45 @@ __global__ __launch_bounds__(256) void decode_mfma_pair_kernel(DecodeArgs a, int
     const IdxT* src = reinterpret_cast<const IdxT*>(a.indices) + it[i].base;
     for (int e = tid; e < n; e += 256) idx_lds[i * CAP + e] = (int32_t)src[e];
   }
-  if constexpr (FUSED) {
+  if constexpr (FUSED == 2) {
+    // The new token of each item: score of every head against its K row (fp32 dot of the 16-bit values, the products the
+    // MFMA would form), its V element for this thread's output column, and both rows into the pool -- loads that depend on
+    // b alone, in flight beside the page-table loads above.
+    static_assert(!KV8 && 256 % D == 0, "new-token form: 16-bit pools, head size dividing 256");
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      s_new[i] = 0.f;
+      v_new[i] = 0.f;
+      if (!newtok[i]) continue;  // (workgroup-uniform)
+      const int b = it[i].b, kvh = it[i].h0 / a.group;
+      const int64_t row = fq.loc_is64 ? reinterpret_cast<const int64_t*>(fq.loc)[b]
+                                      : (int64_t) reinterpret_cast<const int32_t*>(fq.loc)[b];
+      const T* kn = reinterpret_cast<const T*>(fq.k_new) + (int64_t)b * fq.kn_sb + (int64_t)kvh * fq.kn_sh;
+      const T* vn = reinterpret_cast<const T*>(fq.v_new) + (int64_t)b * fq.vn_sb + (int64_t)kvh * fq.vn_sh;
+      float dot = 0.f;
+      if (hl < it[i].nh) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const x8 kv = *reinterpret_cast<const x8*>(kn + 32 * ks + 8 * g);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) dot += H::to_f32(qfs[i][ks][j]) * H::to_f32(kv[j]);
+        }
+      }
+      dot += __shfl_xor(dot, 16);
+      dot += __shfl_xor(dot, 32);
+      s_new[i] = has_cap ? a.logit_cap * tanhf(dot * a.sm_scale / a.logit_cap) * kLog2e : dot * scale_log2;
+      v_new[i] = H::to_f32(vn[tid % D]);
+      // the pool rows for the steps to come (several head blocks of one kv head write the same bytes: harmless)
+      if (tid < D / 8) {
+        T* kp = reinterpret_cast<T*>(const_cast<void*>(a.k)) + row * a.k_sn + (int64_t)kvh * a.k_sh;
+        *reinterpret_cast<x8*>(kp + 8 * tid) = *reinterpret_cast<const x8*>(kn + 8 * tid);
+      } else if (tid < D / 4) {
+        T* vp = reinterpret_cast<T*>(const_cast<void*>(a.v)) + row * a.v_sn + (int64_t)kvh * a.v_sh;
+        *reinterpret_cast<x8*>(vp + 8 * (tid - D / 8)) = *reinterpret_cast<const x8*>(vn + 8 * (tid - D / 8));
+      }
+    }
+  }
+  if constexpr (FUSED == 1) {
     // q/k/v of this step come out of the qkv GEMM's partial sums.  Tasks of 8 columns (and their RoPE partners D/2 columns
     // on) are dealt over the 256 threads: per item nh q heads x HC chunk pairs, HC k chunk pairs, 2 HC v chunks.  Rotated
     // q, k and v are staged in LDS (wave 0's ring, before any DMA lands there): [item][16 heads | k | v][D].  k and v also
@@ -1568,6 +1616,9 @@ inline int pair_deal_default() {  // DecodeArgs::pair_deal
 // set by sgl_mi355_decode_attention_qkv_partials around its call of the regular entry point
 [[maybe_unused]] thread_local const FusedQkv* tl_fq = nullptr;  // (read only in builds with SGLM_OPTIN_FUSIONS)
 [[maybe_unused]] thread_local bool tl_fq_used = false;
+// set by sgl_mi355_decode_attention_newkv around its call of the regular entry point (FUSED == 2 of the pair kernel)
+[[maybe_unused]] thread_local const FusedQkv* tl_newkv = nullptr;
+[[maybe_unused]] thread_local bool tl_newkv_used = false;
 // set by sgl_mi355_decode_attention_absmax around its call of the regular entry point
 thread_local float* tl_row_absmax = nullptr;
 // set by sgl_mi355_decode_attention_merged around its call of the regular entry point
@@ -1613,6 +1664,15 @@ int launch_mfma(const DecodeArgs& a, int64_t batch, hipStream_t stream) {
       hipLaunchKernelGGL(kern, dim3((unsigned)((grid + 1) / 2)), dim3(256), lds, stream, aq, (int)grid, FusedQkv{});
       tl_pair_quant_used = true;
       return check_hip(hipGetLastError(), "decode_mfma_pair_kernel (fp8 out) launch");
+    }
+    if (pair && !a.kv8 && tl_newkv != nullptr) {  // + the new token's K / V rows: pool write + one more partial state at the merge
+      auto kern = decode_mfma_pair_kernel<DTYPE, D, IdxT, false, 2>;
+      constexpr int lds = mfma_lds_bytes<D, 4, 0>();
+      static int attr_rc = set_max_lds(kern, lds);
+      if (attr_rc != 0) return attr_rc;
+      hipLaunchKernelGGL(kern, dim3((unsigned)((grid + 1) / 2)), dim3(256), lds, stream, a, (int)grid, *tl_newkv);
+      tl_newkv_used = true;
+      return check_hip(hipGetLastError(), "decode_mfma_pair_kernel (new-token K/V) launch");
     }
 #endif  // SGLM_OPTIN_FUSIONS
     if (pair && !a.kv8) {
@@ -1999,6 +2059,64 @@ extern "C" int sgl_mi355_decode_attention_qkv_partials(
   tl_fq = nullptr;
   if (rc == 0 && !tl_fq_used) {
     set_error("decode_attention_qkv_partials: internal error, the dispatcher did not take the fused kernel");
+    return SGL_MI355_ERR_RUNTIME;
+  }
+  return rc;
+#endif
+}
+
+// Paged decode (the request page table, one split) WITH the KV write of the step inside the same launch -- what
+// AttentionBackend.forward(..., save_kv_cache=True) does in two steps (memory_pool.py:369-407 set_kv_buffer, then the decode
+// kernel, triton_backend.py:686-732).  key / value [B, Hk, D] are the new tokens' finished rows (RoPE applied); loc[b] is the
+// pool row they go to and MUST be the page-table entry of position seq_lens[b] - 1 (out_cache_loc of a decode batch: always).
+// The launch writes both rows to the pool for the steps to come and takes the new token into the softmax from the tensors
+// (one more partial state at the merge) instead of streaming it back from the pool.  Pairs-of-items kernel only: returns
+// SGL_MI355_ERR_UNSUPPORTED -- nothing launched, nothing written -- for batches outside it (at most 256 (request, kv head
+// block) items, FP8 pools, head sizes other than 64 / 128, unaligned rows); the caller then makes the two calls.
+extern "C" int sgl_mi355_decode_attention_newkv(
+    const void* query, void* k_cache, void* v_cache, void* output, const void* key, const void* value, const void* loc,
+    int loc_is64, const void* req_to_token, int req_to_token_is64, const int64_t* req_pool_indices, const int64_t* seq_lens,
+    int64_t num_seqs, int64_t max_context_len, int64_t num_heads, int64_t num_kv_heads, int64_t head_size, int64_t q_stride_b,
+    int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h, int64_t key_stride_b,
+    int64_t key_stride_h, int64_t value_stride_b, int64_t value_stride_h, int64_t o_stride_b, int64_t o_stride_h,
+    float sm_scale, float logit_cap, int dtype, void* stream) {
+#if !SGLM_OPTIN_FUSIONS
+  set_error("%s: an opt-in fusion, not in this build of the library (build with -DSGLM_OPTIN_FUSIONS=1)", "decode_attention_newkv");
+  return SGL_MI355_ERR_UNSUPPORTED;
+#else
+  int rc = check_common(num_seqs, num_heads, num_kv_heads, head_size, head_size, 1, dtype);
+  if (rc) return rc;
+  if (num_seqs == 0) return 0;
+  SGLM_CHECK_ARG(query && k_cache && v_cache && output && key && value && loc && req_to_token && req_pool_indices && seq_lens,
+                 "decode_attention_newkv: null tensor pointer");
+  DecodeArgs probe{};
+  probe.num_splits = 1;
+  const int64_t group = num_heads / num_kv_heads, nhb = (group + 15) / 16;
+  const bool ok = pair_eligible(probe, num_seqs * num_kv_heads * nhb) && (head_size == 128 || head_size == 64) &&
+                  k_stride_n % 8 == 0 && k_stride_h % 8 == 0 && v_stride_n % 8 == 0 && v_stride_h % 8 == 0 &&
+                  key_stride_b % 8 == 0 && key_stride_h % 8 == 0 && value_stride_b % 8 == 0 && value_stride_h % 8 == 0 &&
+                  q_stride_b % 8 == 0 && q_stride_h % 8 == 0 && reinterpret_cast<uintptr_t>(k_cache) % 16 == 0 &&
+                  reinterpret_cast<uintptr_t>(v_cache) % 16 == 0 && reinterpret_cast<uintptr_t>(key) % 16 == 0 &&
+                  reinterpret_cast<uintptr_t>(value) % 16 == 0 && reinterpret_cast<uintptr_t>(query) % 16 == 0;
+  if (!ok) {
+    set_error("decode_attention_newkv: batch outside the fused form (needs > 256 (request, kv head block) items, head size "
+              "64 / 128, 16-byte aligned rows)");
+    return SGL_MI355_ERR_UNSUPPORTED;
+  }
+  FusedQkv fq{};
+  fq.loc = loc; fq.loc_is64 = loc_is64;
+  fq.k_new = key; fq.v_new = value;
+  fq.kn_sb = key_stride_b; fq.kn_sh = key_stride_h; fq.vn_sb = value_stride_b; fq.vn_sh = value_stride_h;
+  tl_newkv = &fq;
+  tl_newkv_used = false;
+  rc = sgl_mi355_decode_attention(query, k_cache, v_cache, output, nullptr, nullptr, nullptr, nullptr, req_to_token,
+                                  req_to_token_is64, req_pool_indices, seq_lens, num_seqs, max_context_len, num_heads,
+                                  num_kv_heads, head_size, head_size, 1, q_stride_b, q_stride_h, k_stride_n, k_stride_h,
+                                  v_stride_n, v_stride_h, 0, 0, 0, 0, o_stride_b, o_stride_h, sm_scale, logit_cap, dtype, stream);
+  tl_newkv = nullptr;
+  if (rc == 0 && !tl_newkv_used) {
+    // (the dispatcher took another kernel after all -- e.g. SGL_MI355_DECODE_PAIR=0: the attention ran WITHOUT the new token)
+    set_error("decode_attention_newkv: internal error, the dispatcher did not take the pairs-of-items kernel");
     return SGL_MI355_ERR_RUNTIME;
   }
   return rc;

@@ -261,6 +261,41 @@ def decode_attention_paged_quant(q, k_buffer, v_buffer, o, req_to_token, req_poo
     return out_q, out_s
 
 
+def decode_attention_paged_newkv(q, k_buffer, v_buffer, o, key, value, loc, req_to_token, req_pool_indices, seq_lens,
+                                 sm_scale, logit_cap=0.0) -> bool:
+    """decode_attention_paged (one split, 16-bit pool) that ALSO writes the step's new K / V rows: set_kv_buffer +
+    decode attention as one launch (sgl_mi355_decode_attention_newkv).  key / value [B, Hk, D] (last dimension contiguous):
+    the new tokens' rows, RoPE applied; loc [B] int32 / int64: their pool rows, which MUST be the page-table entries of
+    positions seq_lens - 1 (a decode batch's out_cache_loc).  Returns False -- nothing launched, nothing written -- when the
+    batch is outside the pairs-of-items kernel; the caller then makes the two calls."""
+    _need_gpu(q, k_buffer, v_buffer, o, key, value, loc, req_to_token, req_pool_indices, seq_lens)
+    if req_pool_indices.dtype != torch.int64 or seq_lens.dtype != torch.int64:
+        raise RuntimeError("decode_attention_paged_newkv: req_pool_indices and seq_lens must be int64")
+    for name, t in (("q", q), ("k_buffer", k_buffer), ("v_buffer", v_buffer), ("o", o), ("key", key), ("value", value)):
+        if t.dim() != 3 or t.stride(-1) != 1:
+            raise RuntimeError(f"decode_attention_paged_newkv: {name} must be 3-D, contiguous at the last dimension")
+    B, Hq, D = q.shape
+    Hk = k_buffer.size(1)
+    if req_to_token.dim() != 2 or req_to_token.stride(1) != 1 or req_to_token.stride(0) != req_to_token.size(1):
+        raise RuntimeError("decode_attention_paged_newkv: req_to_token must be a contiguous 2-D tensor")
+    if loc.numel() != B or not loc.is_contiguous():
+        raise RuntimeError("decode_attention_paged_newkv: loc must hold one pool row per request")
+    if (_kv_format(k_buffer, v_buffer, q) != 0 or v_buffer.size(2) != D or tuple(o.shape) != (B, Hq, D)
+            or tuple(key.shape) != (B, Hk, D) or tuple(value.shape) != (B, Hk, D) or key.dtype != q.dtype or value.dtype != q.dtype):
+        return False
+    rc = _lib.lib().sgl_mi355_decode_attention_newkv(
+        _ptr(q), _ptr(k_buffer), _ptr(v_buffer), _ptr(o), _ptr(key), _ptr(value), _ptr(loc), _I(_is64(loc, "loc")),
+        _ptr(req_to_token), _I(_is64(req_to_token, "req_to_token")), _ptr(req_pool_indices), _ptr(seq_lens), _I64(B),
+        _I64(req_to_token.size(1)), _I64(Hq), _I64(Hk), _I64(D), _I64(q.stride(0)), _I64(q.stride(1)),
+        _I64(k_buffer.stride(0)), _I64(k_buffer.stride(1)), _I64(v_buffer.stride(0)), _I64(v_buffer.stride(1)),
+        _I64(key.stride(0)), _I64(key.stride(1)), _I64(value.stride(0)), _I64(value.stride(1)), _I64(o.stride(0)),
+        _I64(o.stride(1)), _F(sm_scale), _F(logit_cap), _I(_dtype_code(q)), _stream(q))
+    if rc == 2:
+        return False
+    _lib.check(rc)
+    return True
+
+
 def decode_attention_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens, attn_logits,
                            num_kv_splits, sm_scale, logit_cap=0.0):
     """Decode straight from the request page table (no flattened kv_indices, no KV write): the form

@@ -8,7 +8,7 @@ pinned to the oracle in test_backend_gpu.py / test_decode_gpu.py."""
 import pytest
 import torch
 
-from conftest import assert_elem_close
+from conftest import assert_elem_close, p_rounding_term
 
 pytestmark = [pytest.mark.gpu, pytest.mark.optin_fusions]  # (skipped unless the loaded library was built with
 # -DSGLM_OPTIN_FUSIONS=1: tests/conftest.py; the default library returns UNSUPPORTED from these entry points)
@@ -112,8 +112,10 @@ def test_fused_qkv_decode_equals_two_launches(B, Hq, Hk, D, dtype, with_bias, ca
     torch.cuda.synchronize()
     assert torch.equal(kb, kb_ref) and torch.equal(vb, vb_ref), "RoPE + KV write must be bit-exact"
     truth = _truth_f32(q_rot, kb_ref, vb_ref, s, scale, cap)
-    assert_elem_close(o, truth, dtype, what="fused launch vs the fp32 truth")
-    assert_elem_close(o, o_ref, dtype, pair=True, what="fused launch vs the two launches")
+    # the P-rounding allowance of conftest.p_rounding_term: this attention on |V| (short requests: a handful of comparable p_j)
+    term = p_rounding_term(dtype, _truth_f32(q_rot, kb_ref, vb_ref.abs(), s, scale, cap))
+    assert_elem_close(o, truth, dtype, what="fused launch vs the fp32 truth", extra=term)
+    assert_elem_close(o, o_ref, dtype, pair=True, what="fused launch vs the two launches", extra=2 * term)  # both sides round P
 
 
 def test_fused_qkv_decode_declines_outside_its_form():
