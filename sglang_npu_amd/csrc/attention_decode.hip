@@ -43,6 +43,9 @@ constexpr int kStages = 2;
 constexpr int kMaxIdx = 2048;    // page-table entries staged in LDS per pass (x kWaves/2)
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
+#ifndef SGLM_DEC_TIMING
+#define SGLM_DEC_TIMING 0
+#endif
 
 // K/V tile pieces go in with the NON-TEMPORAL cache policy: every K/V row is read once per step by one CU, and without
 // the hint the stream (537 MB per launch at bs=64, ctx 2048) churns L2 and the Infinity Cache.  Same-box A/B
@@ -97,7 +100,25 @@ struct DecodeArgs {
   uint8_t* mq_out_q;  // optional e4m3 [B][Hq * Dv] ...
   float* mq_out_s;    // ... with its scale [B]
   int pair_deal;      // pairs-of-items kernel: 1 = the second item continues the first one's deal of tiles (SGL_MI355_DECODE_PAIR_DEAL=0: both from wave 0, A/B aid)
+#if SGLM_DEC_TIMING
+  unsigned long long* tstamp;  // timing build: [kDecTimingWgs][kDecTimingStamps] s_memtime stamps of wave 0 (split kernel)
+#endif
 };
+
+// Timing build (-DSGLM_DEC_TIMING=1, variant library only): wave 0 of the first kDecTimingWgs workgroups of the split kernel
+// stamps s_memtime at its phase boundaries; tools/exp/decode_phase_times.py reads them through sgl_mi355_decode_timing_dump.
+#if SGLM_DEC_TIMING
+constexpr int kDecTimingWgs = 1024, kDecTimingStamps = 16;
+#define DEC_STAMP(slot)                                                                          \
+  do {                                                                                           \
+    if (a.tstamp != nullptr && threadIdx.x < 64 && blockIdx.x < kDecTimingWgs) {                 \
+      const unsigned long long tnow = __builtin_readcyclecounter();                              \
+      if (threadIdx.x == 0) a.tstamp[blockIdx.x * kDecTimingStamps + (slot)] = tnow;             \
+    }                                                                                            \
+  } while (0)
+#else
+#define DEC_STAMP(slot) do {} while (0)
+#endif
 
 // The qkv GEMM of the SAME decode step, still split-K partial sums (sgl_mi355_decode_attention_qkv_partials): the pair
 // kernel finishes it in its prologue -- epilogue, RoPE on q and k, k/v rows into the pool at loc[b] -- instead of a
@@ -192,6 +213,7 @@ __device__ __forceinline__ void arrive_and_merge(const DecodeArgs& a, int Dv, in
   float* s_red = reinterpret_cast<float*>(tail + 16);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's partial stores are acknowledged
   __syncthreads();                                  // ... and so are everyone's; every wave is done with the LDS
+  DEC_STAMP(6);
   if (tid == 0) {
     const int nhb = (a.group + 15) >> 4;
     const int target = a.num_kv_heads * nhb * a.num_splits;
@@ -201,7 +223,14 @@ __device__ __forceinline__ void arrive_and_merge(const DecodeArgs& a, int Dv, in
     if (old == target - 1) __hip_atomic_store(a.merge_counters + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
-  if (*s_last) merge_quant_row<DTYPE, true>(a, Dv, a.mq_out_q, a.mq_out_s, b, tid, NT, smem, s_red);
+  DEC_STAMP(7);
+  if (*s_last) {
+    merge_quant_row<DTYPE, true>(a, Dv, a.mq_out_q, a.mq_out_s, b, tid, NT, smem, s_red);
+#if SGLM_DEC_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DEC_STAMP(8);
+#endif
+  }
 }
 
 // 16-B chunk swizzle of a [token][D] 16-bit tile (see DESIGN.md "LDS image"):
@@ -274,9 +303,14 @@ __global__ __launch_bounds__(kWaves * 64) void decode_mfma_kernel(DecodeArgs a) 
   const int h0 = kvh * a.group + hb * 16;
   const int nh = (a.group - hb * 16) < 16 ? (a.group - hb * 16) : 16;
 
+  DEC_STAMP(0);
   int64_t base;
   int s0, s1;
   split_range(a, b, split, base, s0, s1);
+#if SGLM_DEC_TIMING
+  asm volatile("" ::"s"(__builtin_amdgcn_readfirstlane(s1)));
+  DEC_STAMP(1);
+#endif
 
   if (s0 >= s1) {
     // Empty split: tell the merge pass to ignore it.  (With DIRECT_OUT an empty range
@@ -345,6 +379,7 @@ __global__ __launch_bounds__(kWaves * 64) void decode_mfma_kernel(DecodeArgs a) 
       for (int i = tid; i < n_pass; i += kWaves * 64) idx_lds[i] = (int32_t)src[i];
     }
     __syncthreads();
+    if (p0 == s0) DEC_STAMP(2);
 
     const int ntiles = ceil_div(n_pass, kTile);
     const int nt = (ntiles - wave + kWaves - 1) / kWaves;  // tiles wave, wave+4, ... of this pass
@@ -526,6 +561,7 @@ __global__ __launch_bounds__(kWaves * 64) void decode_mfma_kernel(DecodeArgs a) 
 
       // ---- wait for K(jt): younger ops allowed in flight = V(jt) [+ K,V(jt+1)]
       if (more1) wait_vmcnt<3 * NIQ>(); else wait_vmcnt<NIQ>();
+      if (jt == 0 && p0 == s0) DEC_STAMP(3);
 
       // ---- S^T = K Q^T  (rows = tokens, cols = heads)
       f32x4 s_acc[2];
@@ -611,8 +647,13 @@ __global__ __launch_bounds__(kWaves * 64) void decode_mfma_kernel(DecodeArgs a) 
   // ---- reduce l over the 4 lane groups, then merge the 4 waves through LDS
   l_run += __shfl_xor(l_run, 16);
   l_run += __shfl_xor(l_run, 32);
+#if SGLM_DEC_TIMING
+  asm volatile("" ::"s"(__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, o_acc[NDV - 1][3]))));
+  DEC_STAMP(4);
+#endif
 
   __syncthreads();  // every wave is done with its ring (all DMA waited, all reads retired)
+  DEC_STAMP(5);
   float* mrg_o = reinterpret_cast<float*>(smem);               // [wave][16][D]
   float* mrg_m = mrg_o + kWaves * 16 * D;                      // [wave][16]
   float* mrg_l = mrg_m + kWaves * 16;                          // [wave][16]
@@ -1584,6 +1625,19 @@ inline int pick_waves(int64_t workgroups) {
   return workgroups > 1024 ? 2 : 4;
 }
 
+#if SGLM_DEC_TIMING
+inline unsigned long long* dec_timing_buffer() {
+  static unsigned long long* buf = [] {
+    void* p = nullptr;
+    const size_t n = (size_t)kDecTimingWgs * kDecTimingStamps * 8;
+    if (hipMalloc(&p, n) != hipSuccess) return (unsigned long long*)nullptr;
+    (void)hipMemset(p, 0, n);
+    return (unsigned long long*)p;
+  }();
+  return buf;
+}
+#endif
+
 template <typename K>
 int set_max_lds(K kernel, int bytes) {
   return check_hip(
@@ -1597,6 +1651,12 @@ int launch_mfma_w(const DecodeArgs& a, int64_t grid, hipStream_t stream) {
   constexpr int lds = mfma_lds_bytes<D, kWaves, KV8>();
   static int attr_rc = set_max_lds(kern, lds);
   if (attr_rc != 0) return attr_rc;
+#if SGLM_DEC_TIMING
+  DecodeArgs at = a;
+  at.tstamp = dec_timing_buffer();
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kWaves * 64), lds, stream, at);
+  return check_hip(hipGetLastError(), "decode_mfma_kernel launch");
+#endif
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kWaves * 64), lds, stream, a);
   return check_hip(hipGetLastError(), "decode_mfma_kernel launch");
 }
@@ -2175,6 +2235,20 @@ extern "C" int sgl_mi355_decode_attention_fwd_fp8kv_e5m2(
 }
 
 extern "C" int sgl_mi355_has_optin_fusions(void) { return SGLM_OPTIN_FUSIONS; }
+
+#if SGLM_DEC_TIMING
+// timing build only: copy the stamps out (device-synchronising) and clear them
+extern "C" int sgl_mi355_decode_timing_dump(void* host_buf, int64_t bytes) {
+  const int64_t n = (int64_t)kDecTimingWgs * kDecTimingStamps * 8;
+  SGLM_CHECK_ARG(host_buf && bytes >= n, "decode_timing_dump: buffer of %ld bytes needed", (long)n);
+  unsigned long long* d = dec_timing_buffer();
+  SGLM_CHECK_ARG(d != nullptr, "decode_timing_dump: no debug buffer");
+  SGLM_CHECK_HIP(hipDeviceSynchronize());
+  SGLM_CHECK_HIP(hipMemcpy(host_buf, d, n, hipMemcpyDeviceToHost));
+  SGLM_CHECK_HIP(hipMemset(d, 0, n));
+  return 0;
+}
+#endif
 
 extern "C" int sgl_mi355_decode_merge_quant_fp8(const float* attn_logits, int64_t num_seqs, int64_t num_heads,
                                                 int64_t head_size_v, int64_t num_kv_splits, void* output,
