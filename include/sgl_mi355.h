@@ -34,7 +34,7 @@ extern "C" {
 #define SGL_MI355_ERR_RUNTIME 3          /* a HIP runtime call failed                */
 
 /* ABI version of this header; bumped on any signature change. */
-#define SGL_MI355_ABI_VERSION 11
+#define SGL_MI355_ABI_VERSION 12
 int sgl_mi355_abi_version(void);
 
 /* Copies the calling thread's last error message (NUL-terminated) into buf. Returns its length. */
@@ -497,6 +497,15 @@ int sgl_mi355_fp8_scaled_mm_finalize(const float* partials, int64_t num_slices, 
                                      const float* scales_b, const void* bias, void* out, int64_t M, int64_t N,
                                      int out_dtype, void* stream);
 int sgl_mi355_rmsnorm_quant_fp8_from_partials(void* out_q, float* out_s, void* residual, const float* partials,
+                                              int64_t num_slices, const float* scales_a, const float* scales_b,
+                                              const void* bias, const void* weight, int64_t num_tokens, int64_t hidden,
+                                              float eps, int dtype, void* stream);
+/* The same launch with the 16-bit normed row written too: what RMSNorm.forward(x, residual) (layernorm.py:59-172,
+ * fused_add_rmsnorm) returns when x is a row-parallel FP8 GEMM still in split-K partials.  out [T, hidden] required;
+ * out_q / out_s nullable (the per-token FP8 quantisation of `out`, per_token_quant_fp8.cu:15-87, for an FP8 linear that
+ * follows).  Replaces: sgl_mi355_fp8_scaled_mm_finalize + sgl_mi355_fused_add_rmsnorm (+ sgl_mi355_per_token_quant_fp8),
+ * bit-identical.  Used by the drop-in call order through sglang_npu_amd/deferred.py. */
+int sgl_mi355_fused_add_rmsnorm_from_partials(void* out, void* out_q, float* out_s, void* residual, const float* partials,
                                               int64_t num_slices, const float* scales_a, const float* scales_b,
                                               const void* bias, const void* weight, int64_t num_tokens, int64_t hidden,
                                               float eps, int dtype, void* stream);

@@ -598,24 +598,24 @@ int launch_rmsnorm(const void* x, void* residual, const void* weight, void* out,
 
 template <int DTYPE>
 int launch_rmsnorm_partials(const PartialSrc& ps, void* residual, const void* weight, void* out_q, float* out_s, int64_t T,
-                            int64_t H, float eps, hipStream_t s) {
+                            int64_t H, float eps, hipStream_t s, void* out = nullptr) {
   using T16 = typename Half16<DTYPE>::T;
   const int nv = (int)(H >> 3);
   const int vpt = (nv + 255) / 256;
 #define RMSP_LAUNCH(V)                                                                                              \
   hipLaunchKernelGGL((rmsnorm_kernel<DTYPE, V, true>), dim3((unsigned)T), dim3(256), 0, s, (const T16*)nullptr,       \
-                     (T16*)residual, (const T16*)weight, (T16*)nullptr, (uint8_t*)out_q, out_s, (int)H, eps, ps)
+                     (T16*)residual, (const T16*)weight, (T16*)out, (uint8_t*)out_q, out_s, (int)H, eps, ps)
 #define RMSP_LAUNCH_W(V, NT_)                                                                                        \
   hipLaunchKernelGGL((rmsnorm_kernel<DTYPE, V, true, NT_>), dim3((unsigned)T), dim3(NT_), 0, s, (const T16*)nullptr,  \
-                     (T16*)residual, (const T16*)weight, (T16*)nullptr, (uint8_t*)out_q, out_s, (int)H, eps, ps)
+                     (T16*)residual, (const T16*)weight, (T16*)out, (uint8_t*)out_q, out_s, (int)H, eps, ps)
 #if SGLM_ABL_ROWSPLIT
   if (rms_wide(T, nv) && nv % 256 == 0 && nv <= 1024) {  // four workgroups per row, 256 threads or fewer each
     if (nv <= 512)
       hipLaunchKernelGGL((rmsnorm_kernel<DTYPE, 1, true, 128, 4>), dim3((unsigned)T * 4), dim3(128), 0, s, (const T16*)nullptr,
-                         (T16*)residual, (const T16*)weight, (T16*)nullptr, (uint8_t*)out_q, out_s, (int)H, eps, ps);
+                         (T16*)residual, (const T16*)weight, (T16*)out, (uint8_t*)out_q, out_s, (int)H, eps, ps);
     else
       hipLaunchKernelGGL((rmsnorm_kernel<DTYPE, 1, true, 256, 4>), dim3((unsigned)T * 4), dim3(256), 0, s, (const T16*)nullptr,
-                         (T16*)residual, (const T16*)weight, (T16*)nullptr, (uint8_t*)out_q, out_s, (int)H, eps, ps);
+                         (T16*)residual, (const T16*)weight, (T16*)out, (uint8_t*)out_q, out_s, (int)H, eps, ps);
     return check_hip(hipGetLastError(), "rmsnorm_from_partials launch");
   }
 #endif
@@ -972,6 +972,26 @@ extern "C" int sgl_mi355_rmsnorm_quant_fp8_from_partials(
   return dtype == SGL_MI355_BF16
              ? launch_rmsnorm_partials<SGL_MI355_BF16>(ps, residual, weight, out_q, out_s, num_tokens, hidden, eps, as_stream(stream))
              : launch_rmsnorm_partials<SGL_MI355_FP16>(ps, residual, weight, out_q, out_s, num_tokens, hidden, eps, as_stream(stream));
+}
+
+// The same launch with the 16-bit normed row written as well -- what RMSNorm.forward(x, residual) returns (layernorm.py:82-85,
+// fused_add_rmsnorm: residual <- x + residual, out <- norm(residual) * weight) when x is a row-parallel FP8 GEMM still in
+// split-K partials (round 5: the drop-in call order hands them over as a deferred tensor, sglang_npu_amd/deferred.py).
+// out_q / out_s nullable: the per-token FP8 companion of `out` for an FP8 linear that follows.  Bit-identical to
+// sgl_mi355_fp8_scaled_mm_finalize + sgl_mi355_fused_add_rmsnorm (+ sgl_per_token_quant_fp8).
+extern "C" int sgl_mi355_fused_add_rmsnorm_from_partials(
+    void* out /* required */, void* out_q /* nullable */, float* out_s /* with out_q */, void* residual /* in/out, required */,
+    const float* partials, int64_t num_slices, const float* scales_a, const float* scales_b, const void* bias /* nullable */,
+    const void* weight, int64_t num_tokens, int64_t hidden, float eps, int dtype, void* stream) {
+  int rc = check_rows("fused_add_rmsnorm_from_partials", num_tokens, hidden, 16384, dtype);
+  if (rc) return rc;
+  if (num_tokens == 0) return 0;
+  SGLM_CHECK_ARG(out && residual && partials && scales_a && scales_b && weight && num_slices >= 1 && (out_q == nullptr || out_s),
+                 "fused_add_rmsnorm_from_partials: null tensor pointer / bad slice count");
+  PartialSrc ps{partials, (int)num_slices, num_tokens * hidden, scales_a, scales_b, bias, (int)hidden};
+  return dtype == SGL_MI355_BF16
+             ? launch_rmsnorm_partials<SGL_MI355_BF16>(ps, residual, weight, out_q, out_s, num_tokens, hidden, eps, as_stream(stream), out)
+             : launch_rmsnorm_partials<SGL_MI355_FP16>(ps, residual, weight, out_q, out_s, num_tokens, hidden, eps, as_stream(stream), out);
 }
 
 static int rope_set_kv_partials_impl(int kv8,

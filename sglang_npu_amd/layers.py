@@ -13,6 +13,7 @@ from typing import Optional, Tuple, Union
 import torch
 
 from . import ops
+from .deferred import DeferredEpilogue
 
 
 class RMSNorm(torch.nn.Module):
@@ -27,6 +28,26 @@ class RMSNorm(torch.nn.Module):
 
     def forward(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None
                 ) -> Union[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]]:
+        if x.__class__ is not torch.Tensor and isinstance(x, DeferredEpilogue):
+            # a row-parallel FP8 GEMM of this backend still in split-K partials (deferred.py): its epilogue runs inside the norm
+            # kernel -- finalize + fused_add_rmsnorm (+ the per-token FP8 quant the next FP8 linear asked for), bit-identical
+            part = x.pending_partials()
+            if (part is not None and residual is not None and residual.is_cuda and residual.is_contiguous()
+                    and tuple(residual.shape) == (part.M, part.N) and residual.dtype == part.out_dtype
+                    and self.weight.dtype == part.out_dtype):
+                if ops.FP8_COMPANIONS and self.emit_fp8_companion:
+                    out, q, s = ops.fused_add_rmsnorm_from_partials(part, residual, self.weight.data, self.variance_epsilon, True)
+                    ops.attach_fp8_companion(out, q, s)
+                else:
+                    out = ops.fused_add_rmsnorm_from_partials(part, residual, self.weight.data, self.variance_epsilon)
+                    out._sgl_mi355_producer = self
+                x.resolve(out)  # (the reference's fused_add_rmsnorm is in place: x now IS the normed row)
+                return out, residual
+            x = x.materialize()
+        elif residual is not None:
+            prod = getattr(x, "_sgl_mi355_epilogue_producer", None)
+            if prod is not None:
+                prod._sgl_mi355_defer_epilogue = True  # from the next pass on this GEMM leaves its epilogue to this norm
         if ops.FP8_COMPANIONS and x.is_cuda and x.dim() == 2 and x.is_contiguous():
             if self.emit_fp8_companion:
                 # one kernel: (add +) norm -> 16-bit `out` + (q, scale) = sgl_per_token_quant_fp8(out), bit for bit

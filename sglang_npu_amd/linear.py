@@ -140,6 +140,10 @@ class RowParallelLinear(LinearBase):
         self.quant_method.create_weights(self, self.input_size_per_partition, [output_size], input_size, output_size,
                                          params_dtype, weight_loader=self.weight_loader)
         self.bias = torch.nn.Parameter(torch.zeros(output_size, dtype=params_dtype), requires_grad=False) if bias else None
+        # no collective behind this GEMM: its decode-time epilogue may be left to the RMSNorm that consumes the output
+        # (quantization.W8A8Fp8LinearMethod.apply, deferred.py); under TP the all-reduce needs the finished output
+        self._sgl_mi355_may_defer = tp == 1
+        self._sgl_mi355_defer_epilogue = False
 
     def weight_loader(self, param, loaded_weight: torch.Tensor):
         """linear.py:1264-1283: this rank's slice along the parameter's input dimension; per-output-channel scales

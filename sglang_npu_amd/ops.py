@@ -10,11 +10,13 @@ from __future__ import annotations
 
 import ctypes
 import os
+import weakref
 from typing import Optional
 
 import torch
 
 from . import _lib
+from .deferred import DEFERRED_EPILOGUES, DeferredEpilogue
 
 _P = ctypes.c_void_p
 _I64 = ctypes.c_int64
@@ -31,7 +33,11 @@ def _dtype_code(t: torch.Tensor) -> int:
 
 
 def _ptr(t: Optional[torch.Tensor]):
-    return None if t is None else _P(t.data_ptr())
+    if t is None:
+        return None
+    if t.__class__ is not torch.Tensor and isinstance(t, DeferredEpilogue):
+        t = t.materialize()  # (a GEMM output still in partials reached an op that wants its bytes: finish it, deferred.py)
+    return _P(t.data_ptr())
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)  # the current stream's handle without building a Stream object
@@ -622,9 +628,26 @@ class _ScratchPool:
 
     def __init__(self, floor_floats: int):
         self.floor, self._cur, self._retired = floor_floats, {}, []
+        self._pending = {}  # key -> weakref of the DeferredEpilogue whose partial sums are in the buffer right now
+
+    def set_pending(self, device: torch.device, deferred) -> None:
+        key = (device.index, _stream_handle(device))
+        self._pending[key] = weakref.ref(deferred)
+        deferred._on_resolve = lambda d, key=key: self._clear_pending(key, d)
+
+    def _clear_pending(self, key, deferred) -> None:
+        ref = self._pending.get(key)
+        if ref is not None and ref() is deferred:
+            del self._pending[key]
 
     def get(self, device: torch.device, need_floats: int) -> torch.Tensor:
         key = (device.index, _stream_handle(device))
+        ref = self._pending.pop(key, None)
+        if ref is not None:
+            d = ref()
+            if d is not None:
+                d._on_resolve = None
+                d.materialize()  # the buffer is about to be overwritten: finish the GEMM that still lives in it (deferred.py)
         cur = self._cur.get(key)
         if cur is None or cur.numel() < need_floats:
             if cur is not None:
@@ -908,6 +931,33 @@ def rmsnorm_quant_fp8_from_partials(part: GemmPartials, residual: torch.Tensor, 
         _ptr(q), _ptr(s), _ptr(residual), _ptr(part.ws), _I64(part.num_slices), _ptr(part.x_scale), _ptr(part.w_scale),
         _ptr(part.bias), _ptr(weight), _I64(part.M), _I64(part.N), _F(eps), _I(_dtype_code(residual)), _stream(residual)))
     return q, s
+
+
+def fused_add_rmsnorm_from_partials(part: GemmPartials, residual: torch.Tensor, weight: torch.Tensor, eps: float,
+                                    with_fp8: bool = False):
+    """fused_add_rmsnorm of (GEMM output, residual) with the GEMM epilogue included: returns the normed 16-bit row `out`
+    [M,H] (and, with_fp8, (out, q, scale) = its per-token FP8 quantisation as well); `residual` is updated in place
+    (layernorm.py:82-85).  Bit-identical to part.finalize() + fused_add_rmsnorm (+ sgl_per_token_quant_fp8)."""
+    _need_gpu(residual, weight)
+    if residual.shape != (part.M, part.N) or not residual.is_contiguous() or residual.dtype != part.out_dtype:
+        raise RuntimeError("fused_add_rmsnorm_from_partials: residual must be a contiguous [M,N] tensor in the GEMM's out dtype")
+    if weight.dtype != residual.dtype or weight.numel() != part.N or not weight.is_contiguous():
+        raise RuntimeError("fused_add_rmsnorm_from_partials: weight must be a contiguous [N] tensor in the same dtype")
+    out = torch.empty((part.M, part.N), dtype=part.out_dtype, device=residual.device)
+    q = torch.empty((part.M, part.N), dtype=torch.float8_e4m3fn, device=residual.device) if with_fp8 else None
+    s = torch.empty((part.M, 1), dtype=torch.float32, device=residual.device) if with_fp8 else None
+    _lib.check(_lib.lib().sgl_mi355_fused_add_rmsnorm_from_partials(
+        _ptr(out), _ptr(q), _ptr(s), _ptr(residual), _ptr(part.ws), _I64(part.num_slices), _ptr(part.x_scale), _ptr(part.w_scale),
+        _ptr(part.bias), _ptr(weight), _I64(part.M), _I64(part.N), _F(eps), _I(_dtype_code(residual)), _stream(residual)))
+    return (out, q, s) if with_fp8 else out
+
+
+def defer_epilogue(part: GemmPartials) -> DeferredEpilogue:
+    """`part` as a tensor for model code (deferred.py): finished by the RMSNorm that consumes it, by the first foreign operation
+    on it, or -- at the latest -- by the workspace pool before the next GEMM reuses the buffer the partial sums live in."""
+    d = DeferredEpilogue(part)
+    _fp8_workspace.set_pending(part.ws.device, d)
+    return d
 
 
 def silu_and_mul_quant_fp8_from_partials(part: GemmPartials):

@@ -32,6 +32,9 @@ from .parameter import classes as _param_classes, is_linear_layer, raw_data, tra
 
 # FP8 weights are re-laid fragment-major after loading when the shape allows (N % 16 == 0, K % 512 == 0): decode GEMMs
 # 31.5 -> 25.9 us (gate_up, M = 64), the headline step 6.34 -> 6.16 ms.  SGL_MI355_NO_WSHUFFLE=1 keeps row-major weights.
+# batches of more than this many rows leave row-parallel epilogues to the consumer (model.DEFER_MIN_ROWS, same switch: below it
+# the single-pass GEMM kernels beat split-K + consumer epilogue)
+DEFER_MIN_ROWS = int(os.environ.get("SGL_MI355_DEFER_MIN_ROWS", "32"))
 PRESHUFFLE_FP8_WEIGHTS = not os.environ.get("SGL_MI355_NO_WSHUFFLE")
 
 
@@ -266,10 +269,30 @@ class W8A8Fp8LinearMethod(LinearMethodBase):
         # the producer of `x` (this backend's RMSNorm / SiluAndMul) may have quantised it already, in its own pass: the first
         # half of apply_fp8_linear is then done (ops.take_fp8_companion: only while x is untouched since; bit-identical)
         comp = ops.take_fp8_companion(x) if layer.input_scale is None else None
+        # A row-parallel layer with no collective behind it (linear.RowParallelLinear marks itself) whose output goes straight
+        # into this backend's RMSNorm: at decode sizes the GEMM is a split-K weight streamer, and once that norm has asked
+        # (layers.RMSNorm.forward -> _sgl_mi355_defer_epilogue) the epilogue is left to it -- the output travels through the
+        # model code as a DeferredEpilogue tensor (deferred.py; bit-identical, one launch less per GEMM).
+        may_defer = (ops.DEFERRED_EPILOGUES and getattr(layer, "_sgl_mi355_may_defer", False) and layer.input_scale is None
+                     and x.dim() == 2 and x.is_cuda and DEFER_MIN_ROWS < x.shape[0] <= 128)
+        if may_defer and getattr(layer, "_sgl_mi355_defer_epilogue", False):
+            if comp is None:
+                x2 = x if x.is_contiguous() else x.contiguous()
+                q = torch.empty_like(x2, dtype=torch.float8_e4m3fn)
+                sc = torch.empty((x2.shape[0], 1), dtype=torch.float32, device=x.device)
+                ops.sgl_per_token_quant_fp8(x2, q, sc)
+                comp = (q, sc)
+            part = ops.fp8_scaled_mm_partials(comp[0], layer.weight, comp[1], layer.weight_scale, x.dtype, bias)
+            if part is not None:
+                return ops.defer_epilogue(part)
         if comp is not None:
             out = ops.fp8_scaled_mm(comp[0], layer.weight, comp[1], layer.weight_scale, out_dtype=x.dtype, bias=bias)
-            return out.view(*x.shape[:-1], out.shape[-1])
-        return apply_fp8_linear(x, layer.weight, layer.weight_scale, input_scale=layer.input_scale, bias=bias)
+            out = out.view(*x.shape[:-1], out.shape[-1])
+        else:
+            out = apply_fp8_linear(x, layer.weight, layer.weight_scale, input_scale=layer.input_scale, bias=bias)
+        if may_defer:
+            out._sgl_mi355_epilogue_producer = layer  # the RMSNorm that receives this tensor tells the layer (see above)
+        return out
 
     def apply_prequantized(self, layer, qinput: torch.Tensor, x_scale: torch.Tensor, out_dtype: torch.dtype,
                            bias: Optional[torch.Tensor] = None):

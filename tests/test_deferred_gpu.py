@@ -1,0 +1,238 @@
+"""GPU: deferred GEMM epilogues in the reference call order (deferred.py).  A row-parallel FP8 linear of this backend whose
+output goes straight into this backend's RMSNorm (models/llama.py: o_proj -> post_attention_layernorm, down_proj -> the next
+layer's input_layernorm) leaves its epilogue to the norm kernel from the second pass on -- through untouched model code, as a
+tensor that finishes itself the moment anybody else touches it.  Everything must be bit-identical to the explicit sequence
+finalize -> fused_add_rmsnorm (-> sgl_per_token_quant_fp8)."""
+import pytest
+import torch
+
+from sglang_npu_amd import deferred, ops
+from sglang_npu_amd.deferred import DeferredEpilogue
+from sglang_npu_amd.layers import RMSNorm
+from sglang_npu_amd.linear import ColumnParallelLinear, RowParallelLinear
+from sglang_npu_amd.quantization import W8A8Fp8Config
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _row_linear(k, n, g, dtype, bias=False):
+    lin = RowParallelLinear(k, n, bias=bias, params_dtype=dtype, quant_config=W8A8Fp8Config(is_checkpoint_fp8_serialized=False)).to(DEV)
+    w = (torch.rand(n, k, generator=g, device=DEV) * 2e-2 - 1e-2).to(dtype)
+    lin.weight.weight_loader(lin.weight, w)
+    if bias:
+        lin.bias.data = torch.randn(n, generator=g, device=DEV).to(dtype)
+    lin.quant_method.process_weights_after_loading(lin)
+    return lin
+
+
+def _norm(h, g, dtype):
+    norm = RMSNorm(h, 1e-5, dtype).to(DEV)
+    norm.weight.data = (torch.rand(h, generator=g, device=DEV) + 0.5).to(dtype)
+    return norm
+
+
+def _explicit(lin, norm, x, r, with_fp8):
+    """The sequence the deferred form replaces, on the same split-K partial sums."""
+    q = torch.empty_like(x, dtype=torch.float8_e4m3fn)
+    s = torch.empty(x.shape[0], 1, device=DEV)
+    ops.sgl_per_token_quant_fp8(x, q, s)
+    part = ops.fp8_scaled_mm_partials(q, lin.weight, s, lin.weight_scale, x.dtype, lin.bias)
+    assert part is not None
+    y = part.finalize()
+    r = r.clone()
+    ops.fused_add_rmsnorm(y, r, norm.weight.data, norm.variance_epsilon)
+    if not with_fp8:
+        return y, r, None, None
+    yq = torch.empty_like(y, dtype=torch.float8_e4m3fn)
+    ys = torch.empty(y.shape[0], 1, device=DEV)
+    ops.sgl_per_token_quant_fp8(y, yq, ys)
+    return y, r, yq, ys
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("T,K,H,bias", [(64, 4096, 4096, False), (64, 14336, 4096, False), (128, 2048, 1024, True), (33, 1024, 8192, False)])
+def test_from_partials_norm_kernel_is_bit_identical(dtype, T, K, H, bias):
+    g = torch.Generator(device=DEV).manual_seed(T + K)
+    lin, norm = _row_linear(K, H, g, dtype, bias), _norm(H, g, dtype)
+    x = torch.randn(T, K, generator=g, device=DEV).to(dtype)
+    r0 = torch.randn(T, H, generator=g, device=DEV).to(dtype)
+    for with_fp8 in (False, True):
+        y_ref, r_ref, q_ref, s_ref = _explicit(lin, norm, x, r0, with_fp8)
+        q = torch.empty_like(x, dtype=torch.float8_e4m3fn)
+        s = torch.empty(T, 1, device=DEV)
+        ops.sgl_per_token_quant_fp8(x, q, s)
+        part = ops.fp8_scaled_mm_partials(q, lin.weight, s, lin.weight_scale, dtype, lin.bias)
+        r = r0.clone()
+        got = ops.fused_add_rmsnorm_from_partials(part, r, norm.weight.data, norm.variance_epsilon, with_fp8)
+        out = got[0] if with_fp8 else got
+        assert torch.equal(out, y_ref) and torch.equal(r, r_ref)
+        if with_fp8:
+            assert torch.equal(got[1].view(torch.uint8), q_ref.view(torch.uint8)) and torch.equal(got[2], s_ref)
+
+
+def test_linear_then_norm_protocol_through_plain_calls(monkeypatch):
+    """Pass 0: the linear finishes its own output and the norm tells it; passes 1, 2: the output is a DeferredEpilogue, no
+    finalize launch runs, results equal the explicit sequence bit for bit; the next FP8 linear's companion still works."""
+    dtype, T, K, H = torch.bfloat16, 64, 14336, 4096
+    g = torch.Generator(device=DEV).manual_seed(1)
+    lin, norm = _row_linear(K, H, g, dtype), _norm(H, g, dtype)
+    nxt = ColumnParallelLinear(H, [1024], params_dtype=dtype, quant_config=W8A8Fp8Config(is_checkpoint_fp8_serialized=False)).to(DEV)
+    nxt.weight.data.copy_((torch.rand(1024, H, generator=g, device=DEV) * 2e-2 - 1e-2).to(dtype))
+    nxt.quant_method.process_weights_after_loading(nxt)
+    x = torch.randn(T, K, generator=g, device=DEV).to(dtype)
+    r0 = torch.randn(T, H, generator=g, device=DEV).to(dtype)
+    finalizes = []
+    real = ops.GemmPartials.finalize
+    monkeypatch.setattr(ops.GemmPartials, "finalize", lambda self: (finalizes.append(1), real(self))[1])
+    kinds, outs = [], []
+    for it in range(4):
+        r = r0.clone()
+        y, _ = lin(x)                       # models/llama.py: hidden_states = self.mlp(hidden_states)
+        kinds.append(type(y))
+        h, r = norm(y, r)                   # ... hidden_states, residual = self.input_layernorm(hidden_states, residual)
+        z, _ = nxt(h)                       # ... qkv, _ = self.qkv_proj(hidden_states)
+        outs.append((h.clone(), r.clone(), z.clone()))
+        if isinstance(y, DeferredEpilogue):
+            assert y.pending_partials() is None and torch.equal(y + 0, h), "in place: the handle now holds the normed row"
+    torch.cuda.synchronize()
+    assert kinds == [torch.Tensor, DeferredEpilogue, DeferredEpilogue, DeferredEpilogue] and not finalizes
+    assert lin._sgl_mi355_defer_epilogue and norm.emit_fp8_companion
+    y_ref, r_ref, q_ref, s_ref = _explicit(lin, norm, x, r0, True)
+    finalizes.clear()
+    for h, r, z in outs[1:]:
+        assert torch.equal(h, y_ref) and torch.equal(r, r_ref)
+    assert torch.equal(outs[2][2], outs[3][2])
+    z_ref = ops.fp8_scaled_mm(q_ref, nxt.weight, s_ref, nxt.weight_scale, out_dtype=dtype)
+    assert torch.equal(outs[3][2], z_ref), "the FP8 companion of the deferred norm feeds the next linear"
+    # pass 0 (single-pass or split-K + finalize, whatever the dispatcher took) agrees within GEMM rounding
+    assert (outs[0][0].float() - y_ref.float()).abs().max() < 0.05
+
+
+def test_any_other_consumer_gets_the_finished_gemm(monkeypatch):
+    dtype, T, K, H = torch.bfloat16, 64, 4096, 4096
+    g = torch.Generator(device=DEV).manual_seed(2)
+    lin, norm = _row_linear(K, H, g, dtype), _norm(H, g, dtype)
+    x = torch.randn(T, K, generator=g, device=DEV).to(dtype)
+    r0 = torch.randn(T, H, generator=g, device=DEV).to(dtype)
+    norm(lin(x)[0], r0.clone())  # pass 0: the norm asks
+    q = torch.empty_like(x, dtype=torch.float8_e4m3fn)
+    s = torch.empty(T, 1, device=DEV)
+    ops.sgl_per_token_quant_fp8(x, q, s)
+    want = ops.fp8_scaled_mm_partials(q, lin.weight, s, lin.weight_scale, dtype, None).finalize()
+    y, _ = lin(x)
+    assert isinstance(y, DeferredEpilogue) and y.pending_partials() is not None
+    assert torch.equal(y * 2, want * 2) and y.pending_partials() is None          # a torch op
+    y, _ = lin(x)
+    r = r0.clone()
+    ops.fused_add_rmsnorm(y, r, norm.weight.data, 1e-5)                             # one of this library's raw-pointer ops
+    ref = want.clone()
+    r2 = r0.clone()
+    ops.fused_add_rmsnorm(ref, r2, norm.weight.data, 1e-5)
+    assert torch.equal(y + 0, ref) and torch.equal(r, r2)
+    y, _ = lin(x)
+    h = norm(y)                                                                     # a norm without residual: plain path
+    assert torch.equal(h, ops.rmsnorm(want, norm.weight.data, 1e-5))
+    # the NEXT GEMM on the stream reuses the workspace: a tensor still pending is finished first
+    y, _ = lin(x)
+    assert y.pending_partials() is not None
+    other, _ = lin(torch.randn(T, K, generator=g, device=DEV).to(dtype))
+    assert y.pending_partials() is None and torch.equal(y + 0, want)
+    assert isinstance(other, DeferredEpilogue)
+    # switched off: plain tensors again
+    monkeypatch.setattr(ops, "DEFERRED_EPILOGUES", False)
+    y, _ = lin(x)
+    assert type(y) is torch.Tensor
+
+
+def test_rows_outside_the_window_and_tensor_parallel_layers_never_defer():
+    dtype, K, H = torch.bfloat16, 4096, 4096
+    g = torch.Generator(device=DEV).manual_seed(3)
+    lin, norm = _row_linear(K, H, g, dtype), _norm(H, g, dtype)
+    for T in (8, 32, 200):
+        x = torch.randn(T, K, generator=g, device=DEV).to(dtype)
+        for _ in range(2):
+            y, _ = lin(x)
+            assert type(y) is torch.Tensor
+            norm(y, torch.zeros(T, H, device=DEV, dtype=dtype))
+    assert not lin._sgl_mi355_defer_epilogue
+    col = ColumnParallelLinear(K, [H], params_dtype=dtype, quant_config=W8A8Fp8Config(is_checkpoint_fp8_serialized=False)).to(DEV)
+    col.weight.data.copy_((torch.rand(H, K, generator=g, device=DEV) * 2e-2 - 1e-2).to(dtype))
+    col.quant_method.process_weights_after_loading(col)
+    x = torch.randn(64, K, generator=g, device=DEV).to(dtype)
+    for _ in range(2):
+        y, _ = col(x)
+        assert type(y) is torch.Tensor
+        norm(y, torch.zeros(64, H, device=DEV, dtype=dtype))
+
+
+def test_graph_capture_and_replay_of_the_deferred_pair():
+    dtype, T, K, H = torch.bfloat16, 64, 14336, 4096
+    g = torch.Generator(device=DEV).manual_seed(4)
+    lin, norm = _row_linear(K, H, g, dtype), _norm(H, g, dtype)
+    x = torch.randn(T, K, generator=g, device=DEV).to(dtype)
+    r = torch.randn(T, H, generator=g, device=DEV).to(dtype)
+    x_in, r_in = x.clone(), r.clone()
+    for _ in range(2):  # eager warm-up: the protocol settles
+        norm(lin(x_in)[0], r_in.clone())
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        norm(lin(x_in)[0], r_in.clone())  # (the side stream's workspace exists before capture)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            y = lin(x_in)[0]
+            assert isinstance(y, DeferredEpilogue)
+            h, r_out = norm(y, r_in)
+    torch.cuda.current_stream().wait_stream(side)
+    for seed in (10, 11):
+        gg = torch.Generator(device=DEV).manual_seed(seed)
+        x2 = torch.randn(T, K, generator=gg, device=DEV).to(dtype)
+        r2 = torch.randn(T, H, generator=gg, device=DEV).to(dtype)
+        x_in.copy_(x2)
+        r_in.copy_(r2)
+        graph.replay()
+        torch.cuda.synchronize()
+        y_ref, r_ref, _, _ = _explicit(lin, norm, x2, r2, False)
+        assert torch.equal(h, y_ref) and torch.equal(r_in, r_ref)
+
+
+def test_reference_order_model_step_with_and_without_deferral(monkeypatch):
+    """A decode step of the synthetic model in the REFERENCE call order at bs = 64: o_proj and down_proj hand their epilogues
+    to the norms from the second pass on.  Same KV pool, logits within GEMM rounding of the undeferred pass (o_proj's single-pass
+    kernel sums K in another order than split-K does), deterministic, and identical under a second model built the same way."""
+    from sglang_npu_amd import model as M
+    from sglang_npu_amd.harness import (ForwardBatch, ForwardMode, MHATokenToKVPool, ModelConfig, ModelRunnerLike, ReqToTokenPool,
+                                        ServerArgs, install_attention_backend)
+    cfg = ModelConfig(8, 2, 128, 1024, 2048, 3, 512, 256)
+    B = 64
+    res = {}
+    for on in (False, True):
+        monkeypatch.setattr(ops, "DEFERRED_EPILOGUES", on)
+        net = M.LlamaForCausalLM(cfg, "w8a8_fp8", torch.bfloat16, DEV, fuse_quant=False).load_dummy_weights()
+        r2t = ReqToTokenPool(B, 256, DEV)
+        pool = MHATokenToKVPool(B * 256 + 1, 1, torch.bfloat16, 2, 128, 3, DEV)
+        g = torch.Generator(device=DEV).manual_seed(0)
+        for l in range(3):
+            pool.k_buffer[l].normal_(generator=g)
+            pool.v_buffer[l].normal_(generator=g)
+        r2t.req_to_token.copy_((torch.randperm(B * 256, device=DEV, generator=g) + 1).view(B, 256).to(torch.int32))
+        backend = install_attention_backend(ModelRunnerLike(cfg, r2t, pool, DEV, 0, 1, ServerArgs()))
+        seq = torch.randint(1, 200, (B,), device=DEV, generator=g)
+        ids = torch.randint(0, 500, (B,), device=DEV, generator=g)
+        rows = torch.arange(B, device=DEV)
+        fb = ForwardBatch(ForwardMode.DECODE, B, ids, rows, seq, r2t.req_to_token[rows, seq - 1].long(), int(seq.sum()), seq.cpu(),
+                          seq - 1, req_to_token_pool=r2t, token_to_kv_pool=pool, attn_backend=backend)
+        backend.init_forward_metadata(fb)
+        seen = []
+        real = deferred.DeferredEpilogue.resolve
+        monkeypatch.setattr(deferred.DeferredEpilogue, "resolve", lambda self, v: (seen.append(1), real(self, v))[1])
+        logits = [net(ids, seq - 1, fb).clone() for _ in range(3)]
+        monkeypatch.setattr(deferred.DeferredEpilogue, "resolve", real)
+        res[on] = (logits, pool.k_buffer[2].clone(), len(seen))
+    assert res[False][2] == 0 and res[True][2] == 2 * 2 * 3, "o_proj + down_proj of 3 layers, passes 1 and 2"
+    assert torch.equal(res[True][0][1], res[True][0][2]), "deterministic once the protocol has settled"
+    assert torch.equal(res[False][0][0], res[True][0][0]), "pass 0 runs the undeferred kernels"
+    a, b = res[False][0][2].float(), res[True][0][2].float()
+    assert torch.isfinite(b).all() and (a - b).abs().max() <= 2e-2 * max(1.0, float(a.abs().max()))
+    assert (a.argmax(-1) == b.argmax(-1)).float().mean() > 0.9
