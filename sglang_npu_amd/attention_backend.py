@@ -28,7 +28,7 @@ import os
 
 import torch
 
-from . import ops
+from . import deferred, ops
 from .harness import AttentionType, ForwardBatch, ForwardMode
 
 NUM_CUS = 256
@@ -337,11 +337,45 @@ class MI355AttnBackend(AttentionBackend):
         return 1
 
     # ---------------------------------------------------------------- forward
+    @staticmethod
+    def _plain_kv_write(layer, forward_batch, q) -> bool:
+        """set_kv_buffer of this step is a plain copy into a 16-bit pool (no scales, no cast) and the heads are uniform: the
+        forms the fused RoPE + KV-write from GEMM partials covers."""
+        pool = forward_batch.token_to_kv_pool
+        return (layer.qk_head_dim == layer.v_head_dim and getattr(layer, "k_scale", None) is None
+                and getattr(layer, "v_scale", None) is None
+                and getattr(pool, "store_dtype", None) == getattr(pool, "dtype", 0) == q.dtype
+                and forward_batch.out_cache_loc is not None)
+
     def forward_decode(self, q, k, v, layer, forward_batch: ForwardBatch, save_kv_cache=True, fp8_out: bool = False):
         """fp8_out (MI355X extension, passed through RadixAttention's **kwargs): the caller wants the per-token FP8
         quantisation of the output (the w8a8 o_proj input).  When the kv-splits are merged anyway, the merge kernel
         quantises in the same pass and (q_fp8, scale) is returned instead of the 16-bit tensor; otherwise the flag is
         ignored and the caller quantises."""
+        if save_kv_cache and k is not None and self._plain_kv_write(layer, forward_batch, q):
+            q_size, kv_size = layer.tp_q_head_num * layer.qk_head_dim, layer.tp_k_head_num * layer.qk_head_dim
+            if q.__class__ is not torch.Tensor:
+                # q / k / v are the column ranges of a qkv projection still in split-K partials, RoPE recorded (deferred.py:
+                # untouched model code did qkv.split, rotary_emb, RadixAttention's views): finish the GEMM, rotate and write
+                # the KV rows in ONE launch (what this repo's fused call order does), then attend on the real q
+                root = deferred.qkv_root(q, k, v, q_size, kv_size)
+                if root is not None:
+                    positions, rot = root._rope[0], root._rope[1]
+                    pool = forward_batch.token_to_kv_pool
+                    q = ops.rope_set_kv_from_partials(root.pending_partials(), positions, layer.tp_q_head_num, layer.tp_k_head_num,
+                                                      layer.qk_head_dim, rot.cos_sin_cache, pool.get_key_buffer(layer.layer_id),
+                                                      pool.get_value_buffer(layer.layer_id), forward_batch.out_cache_loc,
+                                                      rot.is_neox_style)
+                    root.consume()
+                    k = v = None
+                    save_kv_cache = False
+            else:
+                # a plain q: the view of a finished qkv tensor.  Tell the projection that produced it that this backend could
+                # have taken the epilogue (its next output then comes as partials, quantization.W8A8Fp8LinearMethod.apply)
+                prod = getattr(getattr(q, "_base", None), "_sgl_mi355_epilogue_producer", None)
+                if prod is not None and getattr(prod, "head_size", None) == layer.qk_head_dim and deferred.DEFERRED_EPILOGUES:
+                    prod._sgl_mi355_defer_epilogue = True
+        q, k, v = deferred.materialize(q), deferred.materialize(k), deferred.materialize(v)
         q = q.reshape(-1, layer.tp_q_head_num * layer.qk_head_dim)
         md = self.forward_metadata
         sliding = (getattr(layer, "sliding_window_size", None) is not None and layer.sliding_window_size > -1
@@ -485,6 +519,8 @@ class MI355AttnBackend(AttentionBackend):
         return o if done else None
 
     def forward_extend(self, q, k, v, layer, forward_batch: ForwardBatch, save_kv_cache=True, **kwargs):
+        # (column ranges of a qkv projection still in partials, deferred.py: the extend kernel reads K / V as tensors -- finish it)
+        q, k, v = deferred.materialize(q), deferred.materialize(k), deferred.materialize(v)
         if layer.qk_head_dim != layer.v_head_dim:
             o = q.new_empty((q.shape[0], layer.tp_q_head_num * layer.v_head_dim))
         else:

@@ -14,6 +14,11 @@ first runs the plain finalize launch and proceeds on the real tensor (`__torch_d
 anything but the GEMM's output; `data_ptr()` raises instead of returning garbage.  The partial sums live in the stream's
 split-K workspace: the workspace pool finishes a still-pending tensor BEFORE it hands the buffer to the next GEMM
 (ops._ScratchPool.get), under graph capture too (the finalize launch is captured where it happens).
+The qkv projection goes the same way to the attention backend (models/llama.py:186-189): `qkv.split(...)` on the lazy tensor
+gives lazy column ranges (DeferredCols), `RotaryEmbedding.forward` records the rotation instead of applying it,
+RadixAttention's `.view(-1, heads, head_dim)` stays lazy, and `MI355AttnBackend.forward_decode` finishes GEMM + RoPE + KV-pool
+write in one launch (rope_set_kv_from_partials).  Anybody else who reads q / k / v first gets finalize + the recorded RoPE, i.e.
+the reference's own sequence; reading the qkv handle AFTER the backend consumed it raises (there is no tensor any more).
 SGL_MI355_NO_DEFERRED_EPILOGUE=1 switches the mechanism off (the linear finishes its own output as before)."""
 from __future__ import annotations
 
@@ -24,6 +29,42 @@ import torch
 from torch.utils._pytree import tree_map
 
 DEFERRED_EPILOGUES = not os.environ.get("SGL_MI355_NO_DEFERRED_EPILOGUE")
+
+
+_aten = torch.ops.aten
+
+
+def _dispatch(func, args, kwargs):
+    """Every operation on a lazy tensor of this module lands here.  Two are answered lazily, because untouched model code does
+    them between the qkv projection and the attention backend (models/llama.py:186-189, radix_attention.py:94-101):
+    `qkv.split([q, kv, kv], dim=-1)` on a pending root and `.view(-1, heads, head_dim)` on one of its column ranges.  Everything
+    else runs on the finished tensors."""
+    kwargs = kwargs or {}
+    if func is _aten.split_with_sizes.default and args and isinstance(args[0], DeferredEpilogue) and args[0].is_pending():
+        root, sizes = args[0], [int(x) for x in args[1]]
+        dim = args[2] if len(args) > 2 else kwargs.get("dim", 0)
+        if dim in (-1, 1) and sum(sizes) == root._part.N and all(x > 0 for x in sizes):
+            out, off = [], 0
+            for n in sizes:
+                out.append(DeferredCols(root, off, off + n, (root._part.M, n)))
+                off += n
+            return out
+    if func in (_aten.view.default, _aten._unsafe_view.default, _aten.reshape.default) and args \
+            and isinstance(args[0], DeferredCols) and args[0]._root.is_pending():
+        t, shape = args[0], [int(x) for x in args[1]]
+        m, n = t._root._part.M, t._c1 - t._c0
+        if shape.count(-1) == 1:
+            known = 1
+            for x in shape:
+                known *= x if x != -1 else 1
+            if known > 0 and (m * n) % known == 0:
+                shape[shape.index(-1)] = m * n // known
+        if tuple(shape) == (m, n) or (len(shape) == 3 and shape[0] == m and shape[1] * shape[2] == n and min(shape) > 0):
+            return DeferredCols(t._root, t._c0, t._c1, tuple(shape))
+
+    def unwrap(x):
+        return x.materialize() if isinstance(x, (DeferredEpilogue, DeferredCols)) else x
+    return func(*tree_map(unwrap, args), **tree_map(unwrap, kwargs))
 
 
 class DeferredEpilogue(torch.Tensor):
@@ -38,11 +79,24 @@ class DeferredEpilogue(torch.Tensor):
         self._part = part        # ops.GemmPartials (anything with M, N, out_dtype, ws and finalize())
         self._value: Optional[torch.Tensor] = None
         self._on_resolve = on_resolve
+        self._rope = None        # (positions, RotaryEmbedding, q columns, k columns): RoPE recorded, not applied yet (qkv form)
+        self._consumed = False   # the attention backend took the partials (RoPE + KV write); there is no tensor any more
 
-    # ---- the consumer's side (RMSNorm.forward)
+    # ---- the consumer's side (RMSNorm.forward, MI355AttnBackend.forward_decode)
+    def is_pending(self) -> bool:
+        return self._value is None and not self._consumed
+
     def pending_partials(self):
         """The partial sums if nobody has finished them yet, else None."""
-        return self._part if self._value is None else None
+        return self._part if self.is_pending() else None
+
+    def consume(self) -> None:
+        """The consumer used the partial sums for something that leaves no tensor behind (the qkv projection whose q went
+        into the attention launch rotated, k / v into the KV pool).  Reading the handle afterwards is an error, not garbage."""
+        self._consumed, self._part = True, None
+        if self._on_resolve is not None:
+            self._on_resolve(self)
+            self._on_resolve = None
 
     def resolve(self, value: torch.Tensor) -> None:
         """The consumer finished the GEMM inside its own kernel; `value` is what this tensor now holds under the reference's
@@ -54,21 +108,81 @@ class DeferredEpilogue(torch.Tensor):
 
     # ---- everybody else
     def materialize(self) -> torch.Tensor:
+        if self._consumed:
+            raise RuntimeError("this qkv projection's output was consumed by the fused RoPE + KV-write of the attention backend "
+                               "(deferred.py) and is read again afterwards: set SGL_MI355_NO_DEFERRED_EPILOGUE=1 for this model")
         if self._value is None:
-            self.resolve(self._part.finalize())
+            value, rope = self._part.finalize(), self._rope
+            self.resolve(value)
+            if rope is not None:  # rotary_emb(positions, q, k) was called on the column ranges: in place, as the reference does
+                positions, rot, (q0, q1), (k0, k1) = rope
+                rot.forward(positions, value[:, q0:q1], value[:, k0:k1])
         return self._value
 
     @classmethod
     def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
-        def unwrap(x):
-            return x.materialize() if isinstance(x, cls) else x
-        return func(*tree_map(unwrap, args), **tree_map(unwrap, kwargs or {}))
+        return _dispatch(func, args, kwargs)
 
     def __repr__(self):  # (the default repr would dispatch and materialise)
-        state = "pending" if self._value is None else "resolved"
+        state = "consumed" if self._consumed else "pending" if self._value is None else "resolved"
         return f"DeferredEpilogue({tuple(self.shape)}, {self.dtype}, {state})"
 
 
+class DeferredCols(torch.Tensor):
+    """Columns [c0, c1) of a pending DeferredEpilogue -- what `qkv.split(...)` hands the model -- optionally viewed as
+    [tokens, heads, head_dim] (RadixAttention.forward).  Strides are those of the real view (row stride = the GEMM's N)."""
+    __torch_function__ = torch._C._disabled_torch_function_impl
+
+    @staticmethod
+    def __new__(cls, root, c0, c1, shape):
+        n_total = root.shape[1]
+        strides = (n_total, 1) if len(shape) == 2 else (n_total, shape[2], 1)
+        return torch.Tensor._make_wrapper_subclass(cls, shape, strides=strides, dtype=root.dtype, device=root.device,
+                                                   requires_grad=False)
+
+    def __init__(self, root, c0, c1, shape):
+        self._root, self._c0, self._c1 = root, c0, c1
+
+    def materialize(self) -> torch.Tensor:
+        v = self._root.materialize()[:, self._c0:self._c1]
+        return v if tuple(v.shape) == tuple(self.shape) else v.view(self.shape)
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        return _dispatch(func, args, kwargs)
+
+    def __repr__(self):
+        return f"DeferredCols([{self._c0}:{self._c1}] of {self._root!r}, shape {tuple(self.shape)})"
+
+
+def rope_target(query, key):
+    """RotaryEmbedding.forward(positions, query, key) on two column ranges of ONE pending root without a RoPE recorded yet:
+    the root, else None."""
+    if not (isinstance(query, DeferredCols) and isinstance(key, DeferredCols)):
+        return None
+    root = query._root
+    if key._root is not root or not root.is_pending() or root._rope is not None or query.dim() != 2 or key.dim() != 2:
+        return None
+    return root
+
+
+def qkv_root(q, k, v, q_size: int, kv_size: int):
+    """attn_backend.forward(q, k, v, ...) on the three column ranges [q | k | v] of ONE pending root whose RoPE is recorded
+    on exactly the q and k ranges: the root, else None."""
+    if not (isinstance(q, DeferredCols) and isinstance(k, DeferredCols) and isinstance(v, DeferredCols)):
+        return None
+    root = q._root
+    if k._root is not root or v._root is not root or not root.is_pending() or root._rope is None:
+        return None
+    n = root.shape[1]
+    if (q._c0, q._c1, k._c0, k._c1, v._c0, v._c1) != (0, q_size, q_size, q_size + kv_size, q_size + kv_size, n) \
+            or n != q_size + 2 * kv_size:
+        return None
+    if root._rope[2] != (0, q_size) or root._rope[3] != (q_size, q_size + kv_size):
+        return None
+    return root
+
+
 def materialize(x):
-    """x itself, or the real tensor behind a DeferredEpilogue (for this package's own ops, which take raw pointers)."""
-    return x.materialize() if isinstance(x, DeferredEpilogue) else x
+    """x itself, or the real tensor behind a lazy one (for this package's own ops, which take raw pointers)."""
+    return x.materialize() if isinstance(x, (DeferredEpilogue, DeferredCols)) else x

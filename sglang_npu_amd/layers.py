@@ -13,7 +13,7 @@ from typing import Optional, Tuple, Union
 import torch
 
 from . import ops
-from .deferred import DeferredEpilogue
+from .deferred import DeferredEpilogue, rope_target
 
 
 class RMSNorm(torch.nn.Module):
@@ -131,6 +131,15 @@ class RotaryEmbedding(torch.nn.Module):
         self.register_buffer("cos_sin_cache", cache.to(device) if device is not None else cache, persistent=False)
 
     def forward(self, positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor):
+        if query.__class__ is not torch.Tensor:
+            root = rope_target(query, key)
+            if (root is not None and self.rotary_dim == self.head_size and query.shape[1] % self.head_size == 0
+                    and key.shape[1] % self.head_size == 0 and positions.is_cuda):
+                # q / k are column ranges of a qkv projection still in split-K partials (deferred.py): the rotation is recorded
+                # and happens where the partials are finished -- inside the attention backend's RoPE + KV-write launch, or with
+                # this very method on the finished tensor if anybody else reads q / k first.  In place, so q / k are returned.
+                root._rope = (positions, self, (query._c0, query._c1), (key._c0, key._c1))
+                return query, key
         ops.apply_rope_with_cos_sin_cache_inplace(positions, query, key, self.head_size, self.cos_sin_cache,
                                                   self.is_neox_style)
         return query, key

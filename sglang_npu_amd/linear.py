@@ -107,6 +107,10 @@ class QKVParallelLinear(ColumnParallelLinear):
         self.num_kv_head_replicas = rep
         sizes = [total_num_heads * head_size, total_num_kv_heads * rep * head_size, total_num_kv_heads * rep * head_size]
         super().__init__(hidden_size, sizes, bias, params_dtype, quant_config, prefix)
+        # column-parallel, no collective: at decode sizes the epilogue may be left to the attention backend's fused RoPE +
+        # KV-write (deferred.py: the output travels as a lazy tensor through split / rotary_emb / RadixAttention); any TP size
+        self._sgl_mi355_may_defer = True
+        self._sgl_mi355_defer_epilogue = False
 
     def weight_loader(self, param, loaded_weight: torch.Tensor, loaded_shard_id=None):
         """linear.py:877-913: shard ids "q" / "k" / "v"; the checkpoint's k / v hold ``total_num_kv_heads`` heads and

@@ -16,7 +16,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from .deferred import DEFERRED_EPILOGUES, DeferredEpilogue
+from .deferred import DEFERRED_EPILOGUES, DeferredCols, DeferredEpilogue
 
 _P = ctypes.c_void_p
 _I64 = ctypes.c_int64
@@ -35,7 +35,7 @@ def _dtype_code(t: torch.Tensor) -> int:
 def _ptr(t: Optional[torch.Tensor]):
     if t is None:
         return None
-    if t.__class__ is not torch.Tensor and isinstance(t, DeferredEpilogue):
+    if t.__class__ is not torch.Tensor and isinstance(t, (DeferredEpilogue, DeferredCols)):
         t = t.materialize()  # (a GEMM output still in partials reached an op that wants its bytes: finish it, deferred.py)
     return _P(t.data_ptr())
 

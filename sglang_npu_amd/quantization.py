@@ -291,7 +291,11 @@ class W8A8Fp8LinearMethod(LinearMethodBase):
         else:
             out = apply_fp8_linear(x, layer.weight, layer.weight_scale, input_scale=layer.input_scale, bias=bias)
         if may_defer:
-            out._sgl_mi355_epilogue_producer = layer  # the RMSNorm that receives this tensor tells the layer (see above)
+            # the consumer that receives this tensor (RMSNorm), or a view of it whose ._base it is (the attention backend behind
+            # qkv.split), tells the layer that it could have taken the epilogue (see above)
+            out._sgl_mi355_epilogue_producer = layer
+            if out._base is not None:
+                out._base._sgl_mi355_epilogue_producer = layer
         return out
 
     def apply_prequantized(self, layer, qinput: torch.Tensor, x_scale: torch.Tensor, out_dtype: torch.dtype,

@@ -224,15 +224,131 @@ def test_reference_order_model_step_with_and_without_deferral(monkeypatch):
         fb = ForwardBatch(ForwardMode.DECODE, B, ids, rows, seq, r2t.req_to_token[rows, seq - 1].long(), int(seq.sum()), seq.cpu(),
                           seq - 1, req_to_token_pool=r2t, token_to_kv_pool=pool, attn_backend=backend)
         backend.init_forward_metadata(fb)
-        seen = []
-        real = deferred.DeferredEpilogue.resolve
+        seen, eaten = [], []
+        real, real_c = deferred.DeferredEpilogue.resolve, deferred.DeferredEpilogue.consume
         monkeypatch.setattr(deferred.DeferredEpilogue, "resolve", lambda self, v: (seen.append(1), real(self, v))[1])
+        monkeypatch.setattr(deferred.DeferredEpilogue, "consume", lambda self: (eaten.append(1), real_c(self))[1])
         logits = [net(ids, seq - 1, fb).clone() for _ in range(3)]
         monkeypatch.setattr(deferred.DeferredEpilogue, "resolve", real)
-        res[on] = (logits, pool.k_buffer[2].clone(), len(seen))
+        monkeypatch.setattr(deferred.DeferredEpilogue, "consume", real_c)
+        res[on] = (logits, pool.k_buffer[2].clone(), len(seen), len(eaten))
     assert res[False][2] == 0 and res[True][2] == 2 * 2 * 3, "o_proj + down_proj of 3 layers, passes 1 and 2"
+    assert res[False][3] == 0 and res[True][3] == 2 * 3, "qkv_proj of 3 layers, passes 1 and 2"
     assert torch.equal(res[True][0][1], res[True][0][2]), "deterministic once the protocol has settled"
     assert torch.equal(res[False][0][0], res[True][0][0]), "pass 0 runs the undeferred kernels"
     a, b = res[False][0][2].float(), res[True][0][2].float()
     assert torch.isfinite(b).all() and (a - b).abs().max() <= 2e-2 * max(1.0, float(a.abs().max()))
     assert (a.argmax(-1) == b.argmax(-1)).float().mean() > 0.9
+
+
+def _qkv_setup(B, Hq, Hk, D, hidden, dtype, seed):
+    from sglang_npu_amd.harness import (ForwardBatch, ForwardMode, MHATokenToKVPool, ModelConfig, ModelRunnerLike, RadixAttention,
+                                        ReqToTokenPool, ServerArgs, install_attention_backend)
+    from sglang_npu_amd.layers import RotaryEmbedding
+    from sglang_npu_amd.linear import QKVParallelLinear
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    cfg = ModelConfig(Hq, Hk, D, hidden, 2 * hidden, 1, 512, 512)
+    qkv = QKVParallelLinear(hidden, D, Hq, Hk, params_dtype=dtype, quant_config=W8A8Fp8Config(is_checkpoint_fp8_serialized=False)).to(DEV)
+    qkv.weight.data.copy_((torch.rand((Hq + 2 * Hk) * D, hidden, generator=g, device=DEV) * 4e-2 - 2e-2).to(dtype))
+    qkv.quant_method.process_weights_after_loading(qkv)
+    rot = RotaryEmbedding(D, D, 512, 10000.0, True, dtype, DEV)
+    attn = RadixAttention(Hq, D, D ** -0.5, Hk, 0)
+    r2t = ReqToTokenPool(B, 512, DEV)
+    pool = MHATokenToKVPool(B * 512 + 1, 1, dtype, Hk, D, 1, DEV)
+    r2t.req_to_token.copy_((torch.randperm(B * 512, device=DEV, generator=g) + 1).view(B, 512).to(torch.int32))
+    pool.k_buffer[0].normal_(generator=g)
+    pool.v_buffer[0].normal_(generator=g)
+    backend = install_attention_backend(ModelRunnerLike(cfg, r2t, pool, DEV, 0, 1, ServerArgs()))
+    seq = torch.randint(1, 400, (B,), device=DEV, generator=g)
+    rows = torch.arange(B, device=DEV)
+    fb = ForwardBatch(ForwardMode.DECODE, B, None, rows, seq, r2t.req_to_token[rows, seq - 1].long(), int(seq.sum()), seq.cpu(),
+                      seq - 1, req_to_token_pool=r2t, token_to_kv_pool=pool, attn_backend=backend)
+    backend.init_forward_metadata(fb)
+    x = torch.randn(B, hidden, generator=g, device=DEV).to(dtype)
+    return qkv, rot, attn, pool, fb, x, seq - 1
+
+
+def _llama_attention_forward(qkv_proj, rot, attn, positions, hidden_states, fb, q_size, kv_size):
+    """models/llama.py:186-189, verbatim."""
+    qkv, _ = qkv_proj(hidden_states)
+    q, k, v = qkv.split([q_size, kv_size, kv_size], dim=-1)
+    q, k = rot(positions, q, k)
+    return attn(q, k, v, fb), qkv
+
+
+@pytest.mark.parametrize("B,Hq,Hk,D,hidden,dtype", [(64, 32, 8, 128, 4096, torch.bfloat16), (96, 8, 1, 128, 2048, torch.float16),
+                                                    (40, 16, 16, 64, 1024, torch.bfloat16)])
+def test_qkv_chain_through_untouched_model_code(B, Hq, Hk, D, hidden, dtype, monkeypatch):
+    """qkv_proj -> split -> rotary_emb -> RadixAttention -> backend: pass 0 plain (the backend tells the projection), from pass 1
+    the projection's output is lazy, RoPE is recorded, RadixAttention's views stay lazy and the backend finishes GEMM + RoPE +
+    KV write in one launch.  Pool and output bit-identical to the explicit sequence on the same split-K partial sums."""
+    qkv_proj, rot, attn, pool, fb, x, positions = _qkv_setup(B, Hq, Hk, D, hidden, dtype, seed=B)
+    q_size, kv_size = Hq * D, Hk * D
+    k0, v0 = pool.k_buffer[0].clone(), pool.v_buffer[0].clone()
+    # the explicit sequence
+    q8 = torch.empty_like(x, dtype=torch.float8_e4m3fn)
+    s8 = torch.empty(B, 1, device=DEV)
+    ops.sgl_per_token_quant_fp8(x, q8, s8)
+    part = ops.fp8_scaled_mm_partials(q8, qkv_proj.weight, s8, qkv_proj.weight_scale, dtype, None)
+    assert part is not None
+    ref = part.finalize()
+    rq, rk, rv = ref.split([q_size, kv_size, kv_size], dim=-1)
+    ops.apply_rope_with_cos_sin_cache_inplace(positions, rq, rk, D, rot.cos_sin_cache, True)
+    o_ref = attn(rq, rk, rv, fb).clone()
+    k_ref, v_ref = pool.k_buffer[0].clone(), pool.v_buffer[0].clone()
+    launches = []
+    real = ops.rope_set_kv_from_partials
+    monkeypatch.setattr(ops, "rope_set_kv_from_partials", lambda *a, **k: (launches.append(1), real(*a, **k))[1])
+    kinds = []
+    for it in range(3):
+        pool.k_buffer[0].copy_(k0)
+        pool.v_buffer[0].copy_(v0)
+        o, qkv = _llama_attention_forward(qkv_proj, rot, attn, positions, x, fb, q_size, kv_size)
+        kinds.append(type(qkv))
+        torch.cuda.synchronize()
+        if it:
+            assert torch.equal(pool.k_buffer[0], k_ref) and torch.equal(pool.v_buffer[0], v_ref), "KV rows must be bit-identical"
+            assert torch.equal(o, o_ref)
+            with pytest.raises(RuntimeError, match="consumed"):
+                qkv + 0
+        else:
+            assert (o.float() - o_ref.float()).abs().max() < 0.05
+    assert kinds == [torch.Tensor, DeferredEpilogue, DeferredEpilogue] and len(launches) == 2
+    assert qkv_proj._sgl_mi355_defer_epilogue
+
+
+def test_qkv_chain_falls_back_to_the_plain_sequence_when_anybody_looks(monkeypatch):
+    B, Hq, Hk, D, hidden, dtype = 64, 16, 4, 128, 2048, torch.bfloat16
+    qkv_proj, rot, attn, pool, fb, x, positions = _qkv_setup(B, Hq, Hk, D, hidden, dtype, seed=7)
+    q_size, kv_size = Hq * D, Hk * D
+    k0, v0 = pool.k_buffer[0].clone(), pool.v_buffer[0].clone()
+    _llama_attention_forward(qkv_proj, rot, attn, positions, x, fb, q_size, kv_size)  # pass 0
+    pool.k_buffer[0].copy_(k0)
+    pool.v_buffer[0].copy_(v0)
+    o_ref, _ = _llama_attention_forward(qkv_proj, rot, attn, positions, x, fb, q_size, kv_size)  # pass 1: the fused form
+    o_ref = o_ref.clone()
+    k_ref = pool.k_buffer[0].clone()
+    # a model that scales q between RoPE and attention: q is read, so everything is finished the reference's way
+    pool.k_buffer[0].copy_(k0)
+    pool.v_buffer[0].copy_(v0)
+    qkv, _ = qkv_proj(x)
+    assert isinstance(qkv, DeferredEpilogue)
+    q, k, v = qkv.split([q_size, kv_size, kv_size], dim=-1)
+    q, k = rot(positions, q, k)
+    q = q * 1.0
+    assert type(q) is torch.Tensor and qkv.pending_partials() is None
+    o = attn(q, k, v, fb)
+    assert torch.equal(o, o_ref) and torch.equal(pool.k_buffer[0], k_ref)
+    # the next GEMM on the stream while q / k / v are still lazy with RoPE recorded: finished (GEMM + RoPE) before the reuse
+    pool.k_buffer[0].copy_(k0)
+    pool.v_buffer[0].copy_(v0)
+    qkv, _ = qkv_proj(x)
+    q, k, v = qkv.split([q_size, kv_size, kv_size], dim=-1)
+    q, k = rot(positions, q, k)
+    qkv_proj(torch.randn(B, hidden, device=DEV).to(dtype))
+    assert qkv.pending_partials() is None
+    o = attn(q, k, v, fb)
+    assert torch.equal(o, o_ref) and torch.equal(pool.k_buffer[0], k_ref)
+    # prefill of the same projection (more than 128 rows): never lazy
+    big, _ = qkv_proj(torch.randn(300, hidden, device=DEV).to(dtype))
+    assert type(big) is torch.Tensor
