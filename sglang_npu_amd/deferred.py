@@ -10,7 +10,7 @@ whose partial sums are finished by a separate `finalize` launch (~5 us) that the
 `DeferredEpilogue` lets the drop-in classes do the same without touching the model: `W8A8Fp8LinearMethod.apply` returns one
 (once the RMSNorm that consumed this layer's previous output has asked for it) and `RMSNorm.forward` consumes it.  It is a
 wrapper tensor subclass: shape / dtype / device are real, there is no storage, and ANY torch operation on it from anybody else
-first runs the plain finalize launch and proceeds on the real tensor (`__torch_dispatch__`) -- so it is never observable as
+first runs the plain finalize launch (and the all-reduce, see below) and proceeds on the real tensor (`__torch_dispatch__`) -- so it is never observable as
 anything but the GEMM's output; `data_ptr()` raises instead of returning garbage.  The partial sums live in the stream's
 split-K workspace: the workspace pool finishes a still-pending tensor BEFORE it hands the buffer to the next GEMM
 (ops._ScratchPool.get), under graph capture too (the finalize launch is captured where it happens).
@@ -19,6 +19,11 @@ gives lazy column ranges (DeferredCols), `RotaryEmbedding.forward` records the r
 RadixAttention's `.view(-1, heads, head_dim)` stays lazy, and `MI355AttnBackend.forward_decode` finishes GEMM + RoPE + KV-pool
 write in one launch (rope_set_kv_from_partials).  Anybody else who reads q / k / v first gets finalize + the recorded RoPE, i.e.
 the reference's own sequence; reading the qkv handle AFTER the backend consumed it raises (there is no tensor any more).
+Under tensor parallelism `RowParallelLinear.forward(x)` -- called without flags, as models/llama.py:97,190 does -- owns the
+all-reduce (linear.py:1302-1303).  Once the norm has asked, it returns this rank's finished GEMM output as a lazy tensor with
+`needs_allreduce`: the RMSNorm runs all-reduce + residual add + norm as ONE kernel on the P2P communicator
+(RMSNorm.forward_with_allreduce_fusion, the role upstream reserves for `can_fuse_mlp_allreduce`, which llama.py does not
+pass); anybody else gets the plain all-reduce first, exactly what the linear would have done.
 SGL_MI355_NO_DEFERRED_EPILOGUE=1 switches the mechanism off (the linear finishes its own output as before)."""
 from __future__ import annotations
 
@@ -71,12 +76,17 @@ class DeferredEpilogue(torch.Tensor):
     __torch_function__ = torch._C._disabled_torch_function_impl  # only __torch_dispatch__ below sees operations
 
     @staticmethod
-    def __new__(cls, part, on_resolve=None):
-        return torch.Tensor._make_wrapper_subclass(cls, (part.M, part.N), dtype=part.out_dtype, device=part.ws.device,
-                                                   requires_grad=False)
+    def __new__(cls, part=None, on_resolve=None, local=None, needs_allreduce=False):
+        if part is not None:
+            shape, dtype, device = (part.M, part.N), part.out_dtype, part.ws.device
+        else:
+            shape, dtype, device = tuple(local.shape), local.dtype, local.device
+        return torch.Tensor._make_wrapper_subclass(cls, shape, dtype=dtype, device=device, requires_grad=False)
 
-    def __init__(self, part, on_resolve=None):
-        self._part = part        # ops.GemmPartials (anything with M, N, out_dtype, ws and finalize())
+    def __init__(self, part=None, on_resolve=None, local=None, needs_allreduce=False):
+        self._part = part        # ops.GemmPartials (anything with M, N, out_dtype, ws and finalize()) ...
+        self._local = local      # ... or this rank's finished GEMM output whose tensor-parallel all-reduce has not run
+        self.needs_allreduce = needs_allreduce  # RowParallelLinear under TP: the collective belongs to whoever finishes this
         self._value: Optional[torch.Tensor] = None
         self._on_resolve = on_resolve
         self._rope = None        # (positions, RotaryEmbedding, q columns, k columns): RoPE recorded, not applied yet (qkv form)
@@ -90,6 +100,10 @@ class DeferredEpilogue(torch.Tensor):
         """The partial sums if nobody has finished them yet, else None."""
         return self._part if self.is_pending() else None
 
+    def pending_local(self):
+        """This rank's unreduced GEMM output if nobody has all-reduced it yet, else None."""
+        return self._local if self.is_pending() else None
+
     def consume(self) -> None:
         """The consumer used the partial sums for something that leaves no tensor behind (the qkv projection whose q went
         into the attention launch rotated, k / v into the KV pool).  Reading the handle afterwards is an error, not garbage."""
@@ -101,7 +115,7 @@ class DeferredEpilogue(torch.Tensor):
     def resolve(self, value: torch.Tensor) -> None:
         """The consumer finished the GEMM inside its own kernel; `value` is what this tensor now holds under the reference's
         in-place semantics (fused_add_rmsnorm overwrites its input with the normed row)."""
-        self._value, self._part = value, None
+        self._value, self._part, self._local = value, None, None
         if self._on_resolve is not None:
             self._on_resolve(self)
             self._on_resolve = None
@@ -112,7 +126,10 @@ class DeferredEpilogue(torch.Tensor):
             raise RuntimeError("this qkv projection's output was consumed by the fused RoPE + KV-write of the attention backend "
                                "(deferred.py) and is read again afterwards: set SGL_MI355_NO_DEFERRED_EPILOGUE=1 for this model")
         if self._value is None:
-            value, rope = self._part.finalize(), self._rope
+            value, rope = (self._part.finalize() if self._part is not None else self._local), self._rope
+            if self.needs_allreduce:  # linear.py:1302-1303, the collective untouched model code expects from the linear itself
+                from .distributed import tensor_model_parallel_all_reduce
+                value = tensor_model_parallel_all_reduce(value)
             self.resolve(value)
             if rope is not None:  # rotary_emb(positions, q, k) was called on the column ranges: in place, as the reference does
                 positions, rot, (q0, q1), (k0, k1) = rope

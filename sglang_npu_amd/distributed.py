@@ -218,7 +218,7 @@ class CustomAllreduce:
         self._norm_h = None
 
     def fused_add_rmsnorm_partials(self, part, residual: torch.Tensor, weight: torch.Tensor, eps: float,
-                                   quant_fp8: bool = False):
+                                   quant_fp8: bool = False, with_fp8_companion: bool = False):
         """fused_add_rmsnorm whose addend is still an ops.GemmPartials (the row-parallel GEMM's split-K sums): its epilogue
         runs while the row is staged (sgl_mi355_ar_fused_add_rmsnorm_partials).  Bit-identical to part.finalize() followed
         by fused_add_rmsnorm; the finalize launch is gone."""
@@ -233,10 +233,10 @@ class CustomAllreduce:
         ct = self._ct
         dev = residual.device
         out = q = s = None
-        if quant_fp8:
+        if quant_fp8 or with_fp8_companion:
             q = torch.empty((T, H), dtype=torch.float8_e4m3fn, device=dev)
             s = torch.empty((T, 1), dtype=torch.float32, device=dev)
-        else:
+        if not quant_fp8 or with_fp8_companion:  # (with_fp8_companion: BOTH from the one launch, as in fused_add_rmsnorm below)
             out = torch.empty((T, H), dtype=part.out_dtype, device=dev)
         ptr = lambda t: ct.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
         _lib.check(self._lib.sgl_mi355_ar_fused_add_rmsnorm_partials(
@@ -244,6 +244,8 @@ class CustomAllreduce:
             ptr(residual), ptr(weight), ptr(out), ptr(q), ptr(s), ct.c_int64(T), ct.c_int64(H), ct.c_float(eps),
             ct.c_int(0 if part.out_dtype == torch.bfloat16 else 1),
             ct.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        if with_fp8_companion:
+            return out, q, s
         return (q, s) if quant_fp8 else out
 
     def fused_add_rmsnorm(self, inp: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float,

@@ -31,6 +31,19 @@ class RMSNorm(torch.nn.Module):
         if x.__class__ is not torch.Tensor and isinstance(x, DeferredEpilogue):
             # a row-parallel FP8 GEMM of this backend still in split-K partials (deferred.py): its epilogue runs inside the norm
             # kernel -- finalize + fused_add_rmsnorm (+ the per-token FP8 quant the next FP8 linear asked for), bit-identical
+            if x.needs_allreduce and x.is_pending():
+                # a row-parallel layer's unreduced output under tensor parallelism: the collective, the residual add and the norm
+                # as one kernel where the P2P communicator takes the shape (forward_with_allreduce_fusion falls back to
+                # all-reduce + norm otherwise) -- what upstream reaches through can_fuse_mlp_allreduce (layernorm.py:191-216)
+                src = x.pending_partials()
+                if src is None:
+                    src = x.pending_local()
+                    src._sglang_needs_allreduce_fusion = True
+                else:
+                    src.needs_allreduce = True
+                res = self.forward_with_allreduce_fusion(src, residual)
+                x.resolve(res[0] if isinstance(res, tuple) else res)
+                return res
             part = x.pending_partials()
             if (part is not None and residual is not None and residual.is_cuda and residual.is_contiguous()
                     and tuple(residual.shape) == (part.M, part.N) and residual.dtype == part.out_dtype
@@ -77,6 +90,14 @@ class RMSNorm(torch.nn.Module):
         if isinstance(x, ops.GemmPartials):  # the row-parallel GEMM left its epilogue here as well (needs_allreduce)
             if (residual is not None and tp.world_size > 1 and tp.fused_collectives_on and ca is not None
                     and ca.should_fuse_norm_shape(x.M, x.N, x.out_dtype)):
+                if not quant_fp8 and ops.FP8_COMPANIONS:  # the reference call order (see the tensor form below)
+                    if self.emit_fp8_companion:
+                        out, q, s = ca.fused_add_rmsnorm_partials(x, residual, self.weight.data, self.variance_epsilon,
+                                                                  with_fp8_companion=True)
+                        return ops.attach_fp8_companion(out, q, s), residual
+                    out = ca.fused_add_rmsnorm_partials(x, residual, self.weight.data, self.variance_epsilon)
+                    out._sgl_mi355_producer = self
+                    return out, residual
                 r = ca.fused_add_rmsnorm_partials(x, residual, self.weight.data, self.variance_epsilon, quant_fp8)
                 return r, residual
             x = x.finalize()

@@ -19,6 +19,7 @@ import torch
 
 from .distributed import (get_tensor_model_parallel_rank, get_tensor_model_parallel_world_size, get_tp_group,
                           tensor_model_parallel_all_reduce)
+from .deferred import DEFERRED_EPILOGUES, DeferredEpilogue
 from .quantization import QuantizationConfig, UnquantizedLinearMethod
 
 
@@ -146,8 +147,20 @@ class RowParallelLinear(LinearBase):
         self.bias = torch.nn.Parameter(torch.zeros(output_size, dtype=params_dtype), requires_grad=False) if bias else None
         # no collective behind this GEMM: its decode-time epilogue may be left to the RMSNorm that consumes the output
         # (quantization.W8A8Fp8LinearMethod.apply, deferred.py); under TP the all-reduce needs the finished output
-        self._sgl_mi355_may_defer = tp == 1
+        self._sgl_mi355_may_defer = True
         self._sgl_mi355_defer_epilogue = False
+
+    def _sgl_mi355_partials_ok(self, rows: int, dtype) -> bool:
+        """May W8A8Fp8LinearMethod.apply leave this GEMM as split-K partials (deferred.py)?  Without a collective: always.  Under
+        TP only where the next norm can take them into the fused all-reduce + add + RMSNorm kernel, and only where the GEMM
+        would run split-K + finalize anyway (the rule of forward_prequantized_partials below)."""
+        if get_tensor_model_parallel_world_size() == 1:
+            return True
+        tp = get_tp_group()
+        ca = tp.ca_comm
+        return (self.reduce_results and tp.fused_collectives_on and ca is not None
+                and ca.should_fuse_norm_shape(rows, self.output_size, dtype)
+                and self.output_size * self.input_size_per_partition >= ((20 if rows > 32 else 40) << 20))
 
     def weight_loader(self, param, loaded_weight: torch.Tensor):
         """linear.py:1264-1283: this rank's slice along the parameter's input dimension; per-output-channel scales
@@ -185,6 +198,21 @@ class RowParallelLinear(LinearBase):
     def forward(self, x, async_reduce: bool = False, can_fuse_mlp_allreduce: bool = False):
         bias_ = None if (get_tensor_model_parallel_rank() > 0) else self.bias
         out = self.quant_method.apply(self, x, bias_)
+        if type(out) is not torch.Tensor and isinstance(out, DeferredEpilogue) and get_tensor_model_parallel_world_size() > 1:
+            if self.reduce_results and not async_reduce and not can_fuse_mlp_allreduce:
+                out.needs_allreduce = True  # split-K partials of this rank's addend: whoever finishes them owes the collective
+                return out, None
+            out = out.materialize()  # (a caller with its own plan for the collective gets the finished local sum)
+        if (self.reduce_results and not async_reduce and not can_fuse_mlp_allreduce and DEFERRED_EPILOGUES
+                and get_tensor_model_parallel_world_size() > 1 and type(out) is torch.Tensor):
+            # the call untouched model code makes (models/llama.py:97,190): the all-reduce is this layer's.  When the RMSNorm that
+            # consumed the previous output has asked and the P2P communicator takes the shape, hand it the unreduced sum as a
+            # lazy tensor (deferred.py): it runs all-reduce + add + norm as one kernel; anybody else gets the plain collective
+            if self._sgl_mi355_defer_epilogue and self._can_fuse(out):
+                return DeferredEpilogue(local=out, needs_allreduce=True), None
+            res = self._reduce_now(out, False)
+            res._sgl_mi355_epilogue_producer = self
+            return res, None
         return self._reduce(out, async_reduce, can_fuse_mlp_allreduce), None
 
     def forward_prequantized_partials(self, qinput, x_scale, out_dtype, can_fuse_mlp_allreduce: bool = False):

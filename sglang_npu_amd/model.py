@@ -109,9 +109,10 @@ class LlamaMLP(torch.nn.Module):
         self.act_fn = SiluAndMul()
 
     def forward(self, x):
+        # models/llama.py:94-98, verbatim: no flags -- what the drop-in classes make of it is their business (deferred.py)
         gate_up, _ = self.gate_up_proj(x)
         x = self.act_fn(gate_up)
-        x, _ = self.down_proj(x, async_reduce=ASYNC_AR, can_fuse_mlp_allreduce=FUSE_AR_NORM)
+        x, _ = self.down_proj(x)
         return x
 
     def forward_fp8(self, xq, xs, out_dtype, defer: bool = False):
@@ -167,7 +168,7 @@ class LlamaAttention(torch.nn.Module):
         q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
         q, k = self.rotary_emb(positions, q, k)
         attn_output = self.attn(q, k, v, forward_batch)
-        output, _ = self.o_proj(attn_output, async_reduce=ASYNC_AR, can_fuse_mlp_allreduce=FUSE_AR_NORM)
+        output, _ = self.o_proj(attn_output)  # (models/llama.py:186-191, verbatim)
         return output
 
     def forward_fp8(self, positions, xq, xs, forward_batch: ForwardBatch, out_dtype, defer: bool = False):
@@ -243,19 +244,14 @@ class LlamaDecoderLayer(torch.nn.Module):
         self.post_attention_layernorm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps, dtype)
 
     def forward(self, positions, hidden_states, forward_batch, residual):
-        hidden_states = _arrived(hidden_states)  # the previous layer's down_proj all-reduce
+        # models/llama.py:245-268, verbatim (the reference call order): plain calls, no tags looked at, no handles waited for
         if residual is None:
             residual = hidden_states
             hidden_states = self.input_layernorm(hidden_states)
-        elif _unreduced(hidden_states):  # communicator.py:190-199
-            hidden_states, residual = self.input_layernorm.forward_with_allreduce_fusion(hidden_states, residual)
         else:
             hidden_states, residual = self.input_layernorm(hidden_states, residual)
-        hidden_states = _arrived(self.self_attn(positions, hidden_states, forward_batch))
-        if _unreduced(hidden_states):
-            hidden_states, residual = self.post_attention_layernorm.forward_with_allreduce_fusion(hidden_states, residual)
-        else:
-            hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
+        hidden_states = self.self_attn(positions, hidden_states, forward_batch)
+        hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
         hidden_states = self.mlp(hidden_states)
         return hidden_states, residual
 

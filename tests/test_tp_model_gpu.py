@@ -89,10 +89,18 @@ def _worker(rank, world, port, q):
             outs[name] = _run_stack(rank, world, dev, fuse, asy)
         # the reference call order, three passes: the first teaches the norms that FP8 linears follow them, from the second on
         # the fused all-reduce + norm kernel also emits the FP8 companion (round 5) -- not one bit may move
+        # ... and (deferred.py) from the second pass on o_proj / down_proj -- called WITHOUT flags, as models/llama.py does --
+        # hand their unreduced output to the norm as a lazy tensor: all-reduce + add + norm in one kernel, 4 per pass here
         dist.barrier()
+        fused_count = lambda: D.DISPATCH_COUNTS["p2p+norm"] + D.DISPATCH_COUNTS["p2p+norm(partials)"]  # noqa: E731
+        fused_before, partials_before = fused_count(), D.DISPATCH_COUNTS["p2p+norm(partials)"]
         ref_order = _run_stack(rank, world, dev, True, False, reference_order=True, passes=3)
         assert torch.equal(ref_order[0], ref_order[1]) and torch.equal(ref_order[0], ref_order[2]), \
-            "FP8 companions changed the reference-order result under TP"
+            "FP8 companions / the lazy all-reduce changed the reference-order result under TP"
+        assert fused_count() - fused_before == 8, \
+            f"untouched call order: {fused_count() - fused_before} fused all-reduce + norm launches, expected 8"
+        # (down_proj, 28 Mi weights per rank, comes as split-K partials; o_proj, 8 Mi, as its finished local sum)
+        assert D.DISPATCH_COUNTS["p2p+norm(partials)"] - partials_before == 4
         outs["reference_order"] = ref_order[0]
         assert torch.equal(outs["sync"], outs["async"]), "side-stream all-reduce changed the result"
         assert torch.equal(outs["sync"], outs["fused"]), "fused all-reduce + norm kernel changed the result"
