@@ -1086,7 +1086,8 @@ def main():
         "dropin_tokens_per_s": round(args.batch / dropin_ms * 1e3, 1) if dropin_ms else None,
         "dropin_note": "value_dropin / dropin_ms_per_step: the model in the reference's operator order (RMSNorm -> apply() "
                        "[per-token quant + fp8_scaled_mm] -> RoPE -> attn_backend.forward(save_kv_cache=True) -> ... ), what "
-                       "SGLang's untouched models/llama.py gets from the drop-in classes; value_fused / fused_ms_per_step: the "
+                       "SGLang's untouched models/llama.py gets from the drop-in classes (which hand FP8 companions and still-unfinished "
+                       "GEMM epilogues / all-reduces to each other as tensors, sglang_npu_amd/deferred.py); value_fused / fused_ms_per_step: the "
                        "same model through this repo's fused entry points (needs its own model file); whichever is not `value` "
                        "ran min(steps,10) steps after 2 warm-ups"})
     checkpoint(out)
