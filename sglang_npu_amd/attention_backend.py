@@ -347,6 +347,20 @@ class MI355AttnBackend(AttentionBackend):
                 and getattr(pool, "store_dtype", None) == getattr(pool, "dtype", 0) == q.dtype
                 and forward_batch.out_cache_loc is not None)
 
+    @staticmethod
+    def _rope_and_write(root, layer, forward_batch, q_size: int, kv_size: int):
+        """q / k / v are the column ranges of a FINISHED qkv projection behind a lazy handle with RoPE recorded (deferred.py): rotate
+        q / k in place and write the KV rows in one launch; the handle then holds what the reference's in-place rotary_emb leaves."""
+        qkv = root.pending_local()
+        positions, rot = root._rope[0], root._rope[1]
+        pool = forward_batch.token_to_kv_pool
+        q, k, v = qkv[:, :q_size], qkv[:, q_size:q_size + kv_size], qkv[:, q_size + kv_size:]
+        ops.apply_rope_and_set_kv_buffer(positions, q, k, v, layer.qk_head_dim, rot.cos_sin_cache, pool.get_key_buffer(layer.layer_id),
+                                         pool.get_value_buffer(layer.layer_id), forward_batch.out_cache_loc, rot.is_neox_style)
+        root._rope = None
+        root.resolve(qkv)
+        return q, k.view(-1, layer.tp_k_head_num, layer.qk_head_dim), v.view(-1, layer.tp_v_head_num, layer.v_head_dim)
+
     def forward_decode(self, q, k, v, layer, forward_batch: ForwardBatch, save_kv_cache=True, fp8_out: bool = False):
         """fp8_out (MI355X extension, passed through RadixAttention's **kwargs): the caller wants the per-token FP8
         quantisation of the output (the w8a8 o_proj input).  When the kv-splits are merged anyway, the merge kernel
@@ -359,7 +373,7 @@ class MI355AttnBackend(AttentionBackend):
                 # untouched model code did qkv.split, rotary_emb, RadixAttention's views): finish the GEMM, rotate and write
                 # the KV rows in ONE launch (what this repo's fused call order does), then attend on the real q
                 root = deferred.qkv_root(q, k, v, q_size, kv_size)
-                if root is not None:
+                if root is not None and root.pending_partials() is not None:
                     positions, rot = root._rope[0], root._rope[1]
                     pool = forward_batch.token_to_kv_pool
                     q = ops.rope_set_kv_from_partials(root.pending_partials(), positions, layer.tp_q_head_num, layer.tp_k_head_num,
@@ -368,6 +382,9 @@ class MI355AttnBackend(AttentionBackend):
                                                       rot.is_neox_style)
                     root.consume()
                     k = v = None
+                    save_kv_cache = False
+                elif root is not None:
+                    q, k, v = self._rope_and_write(root, layer, forward_batch, q_size, kv_size)
                     save_kv_cache = False
             else:
                 # a plain q: the view of a finished qkv tensor.  Tell the projection that produced it that this backend could
@@ -519,7 +536,20 @@ class MI355AttnBackend(AttentionBackend):
         return o if done else None
 
     def forward_extend(self, q, k, v, layer, forward_batch: ForwardBatch, save_kv_cache=True, **kwargs):
-        # (column ranges of a qkv projection still in partials, deferred.py: the extend kernel reads K / V as tensors -- finish it)
+        if save_kv_cache and k is not None and self._plain_kv_write(layer, forward_batch, q):
+            q_size, kv_size = layer.tp_q_head_num * layer.qk_head_dim, layer.tp_k_head_num * layer.qk_head_dim
+            if q.__class__ is not torch.Tensor:
+                # the column ranges of a finished qkv projection behind a lazy handle, RoPE recorded (deferred.py): RoPE + KV-pool
+                # write as one launch; the extend kernel then reads the rotated K / V as tensors
+                root = deferred.qkv_root(q, k, v, q_size, kv_size)
+                if root is not None and root.pending_local() is not None and not root.needs_allreduce:
+                    q, k, v = self._rope_and_write(root, layer, forward_batch, q_size, kv_size)
+                    save_kv_cache = False
+            else:
+                prod = getattr(getattr(q, "_base", None), "_sgl_mi355_epilogue_producer", None)
+                if prod is not None and getattr(prod, "head_size", None) == layer.qk_head_dim and deferred.DEFERRED_EPILOGUES:
+                    prod._sgl_mi355_defer_epilogue = True
+        # (anything else lazy, e.g. a qkv projection still in split-K partials: the extend kernel reads K / V as tensors -- finish it)
         q, k, v = deferred.materialize(q), deferred.materialize(k), deferred.materialize(v)
         if layer.qk_head_dim != layer.v_head_dim:
             o = q.new_empty((q.shape[0], layer.tp_q_head_num * layer.v_head_dim))

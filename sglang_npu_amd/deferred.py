@@ -19,6 +19,10 @@ gives lazy column ranges (DeferredCols), `RotaryEmbedding.forward` records the r
 RadixAttention's `.view(-1, heads, head_dim)` stays lazy, and `MI355AttnBackend.forward_decode` finishes GEMM + RoPE + KV-pool
 write in one launch (rope_set_kv_from_partials).  Anybody else who reads q / k / v first gets finalize + the recorded RoPE, i.e.
 the reference's own sequence; reading the qkv handle AFTER the backend consumed it raises (there is no tensor any more).
+At prefill sizes the gate_up projection hands SiluAndMul its result the same way (models/llama.py:94-96): once SiluAndMul has
+asked, the GEMM runs with SiLU(gate) * up in its epilogue (the [T, 2I] product never goes to HBM), the lazy tensor carries that
+activation (`silu_act`) for SiluAndMul.forward, and anybody else who reads the gate_up matrix gets it computed then (a closure
+over the same FP8 operands launches the plain GEMM: rare, correct, one GEMM slower).
 Under tensor parallelism `RowParallelLinear.forward(x)` -- called without flags, as models/llama.py:97,190 does -- owns the
 all-reduce (linear.py:1302-1303).  Once the norm has asked, it returns this rank's finished GEMM output as a lazy tensor with
 `needs_allreduce`: the RMSNorm runs all-reduce + residual add + norm as ONE kernel on the P2P communicator
@@ -48,16 +52,16 @@ def _dispatch(func, args, kwargs):
     if func is _aten.split_with_sizes.default and args and isinstance(args[0], DeferredEpilogue) and args[0].is_pending():
         root, sizes = args[0], [int(x) for x in args[1]]
         dim = args[2] if len(args) > 2 else kwargs.get("dim", 0)
-        if dim in (-1, 1) and sum(sizes) == root._part.N and all(x > 0 for x in sizes):
+        if root.dim() == 2 and dim in (-1, 1) and sum(sizes) == root.shape[1] and all(x > 0 for x in sizes):
             out, off = [], 0
             for n in sizes:
-                out.append(DeferredCols(root, off, off + n, (root._part.M, n)))
+                out.append(DeferredCols(root, off, off + n, (root.shape[0], n)))
                 off += n
             return out
     if func in (_aten.view.default, _aten._unsafe_view.default, _aten.reshape.default) and args \
             and isinstance(args[0], DeferredCols) and args[0]._root.is_pending():
         t, shape = args[0], [int(x) for x in args[1]]
-        m, n = t._root._part.M, t._c1 - t._c0
+        m, n = t._root.shape[0], t._c1 - t._c0
         if shape.count(-1) == 1:
             known = 1
             for x in shape:
@@ -76,16 +80,20 @@ class DeferredEpilogue(torch.Tensor):
     __torch_function__ = torch._C._disabled_torch_function_impl  # only __torch_dispatch__ below sees operations
 
     @staticmethod
-    def __new__(cls, part=None, on_resolve=None, local=None, needs_allreduce=False):
+    def __new__(cls, part=None, on_resolve=None, local=None, needs_allreduce=False, compute=None, like=None):
         if part is not None:
             shape, dtype, device = (part.M, part.N), part.out_dtype, part.ws.device
-        else:
+        elif local is not None:
             shape, dtype, device = tuple(local.shape), local.dtype, local.device
-        return torch.Tensor._make_wrapper_subclass(cls, shape, dtype=dtype, device=device, requires_grad=False)
+        else:
+            shape, dtype, device = like
+        return torch.Tensor._make_wrapper_subclass(cls, tuple(shape), dtype=dtype, device=device, requires_grad=False)
 
-    def __init__(self, part=None, on_resolve=None, local=None, needs_allreduce=False):
+    def __init__(self, part=None, on_resolve=None, local=None, needs_allreduce=False, compute=None, like=None):
         self._part = part        # ops.GemmPartials (anything with M, N, out_dtype, ws and finalize()) ...
         self._local = local      # ... or this rank's finished GEMM output whose tensor-parallel all-reduce has not run
+        self._compute = compute  # ... or a closure that launches the GEMM (prefill gate_up whose SiLU * up went into the GEMM's
+        self.silu_act = None     #     epilogue instead: `silu_act` holds that result for SiluAndMul, the matrix itself was never written)
         self.needs_allreduce = needs_allreduce  # RowParallelLinear under TP: the collective belongs to whoever finishes this
         self._value: Optional[torch.Tensor] = None
         self._on_resolve = on_resolve
@@ -115,7 +123,7 @@ class DeferredEpilogue(torch.Tensor):
     def resolve(self, value: torch.Tensor) -> None:
         """The consumer finished the GEMM inside its own kernel; `value` is what this tensor now holds under the reference's
         in-place semantics (fused_add_rmsnorm overwrites its input with the normed row)."""
-        self._value, self._part, self._local = value, None, None
+        self._value, self._part, self._local, self._compute = value, None, None, None
         if self._on_resolve is not None:
             self._on_resolve(self)
             self._on_resolve = None
@@ -126,7 +134,9 @@ class DeferredEpilogue(torch.Tensor):
             raise RuntimeError("this qkv projection's output was consumed by the fused RoPE + KV-write of the attention backend "
                                "(deferred.py) and is read again afterwards: set SGL_MI355_NO_DEFERRED_EPILOGUE=1 for this model")
         if self._value is None:
-            value, rope = (self._part.finalize() if self._part is not None else self._local), self._rope
+            value = (self._part.finalize() if self._part is not None else self._local if self._local is not None
+                     else self._compute())
+            rope = self._rope
             if self.needs_allreduce:  # linear.py:1302-1303, the collective untouched model code expects from the linear itself
                 from .distributed import tensor_model_parallel_all_reduce
                 value = tensor_model_parallel_all_reduce(value)

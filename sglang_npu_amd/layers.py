@@ -130,6 +130,15 @@ class SiluAndMul(torch.nn.Module):
         self.emit_fp8_companion = False  # see RMSNorm
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.__class__ is not torch.Tensor and isinstance(x, DeferredEpilogue):
+            act = x.silu_act if x.is_pending() else None
+            if act is not None:
+                return act  # the gate_up GEMM ran with this activation in its epilogue (deferred.py); x stays a valid handle
+            x = x.materialize()
+        else:
+            prod = getattr(x, "_sgl_mi355_epilogue_producer", None)
+            if prod is not None and getattr(prod, "_sgl_mi355_may_fuse_silu", False):
+                prod._sgl_mi355_fuse_silu = True  # from the next pass on that GEMM computes SiLU * up itself
         if ops.FP8_COMPANIONS and x.is_cuda and x.is_contiguous():
             if self.emit_fp8_companion:
                 out, q, s = ops.silu_and_mul_with_quant_fp8(x)

@@ -19,7 +19,8 @@ import torch
 
 from .distributed import (get_tensor_model_parallel_rank, get_tensor_model_parallel_world_size, get_tp_group,
                           tensor_model_parallel_all_reduce)
-from .deferred import DEFERRED_EPILOGUES, DeferredEpilogue
+from . import deferred
+from .deferred import DeferredEpilogue
 from .quantization import QuantizationConfig, UnquantizedLinearMethod
 
 
@@ -86,6 +87,14 @@ class ColumnParallelLinear(LinearBase):
 class MergedColumnParallelLinear(ColumnParallelLinear):
     """gate_up_proj: two column-parallel matrices stored as one."""
 
+    def __init__(self, input_size, output_sizes: List[int], bias: bool = False, params_dtype=torch.bfloat16,
+                 quant_config=None, prefix: str = ""):
+        super().__init__(input_size, output_sizes, bias, params_dtype, quant_config, prefix)
+        # [gate | up] of equal width: SiLU(gate) * up may run in the prefill GEMM's epilogue once the SiluAndMul that consumes
+        # the output has asked (quantization.W8A8Fp8LinearMethod.apply, deferred.py)
+        self._sgl_mi355_may_fuse_silu = len(output_sizes) == 2 and output_sizes[0] == output_sizes[1]
+        self._sgl_mi355_fuse_silu = False
+
     def forward_prequantized_silu_mul(self, qinput, x_scale, out_dtype):
         """SiluAndMul(forward_prequantized(...)[0]) in the GEMM's own launch where the quant method has that form
         (w8a8 FP8 at prefill sizes), else None."""
@@ -112,6 +121,20 @@ class QKVParallelLinear(ColumnParallelLinear):
         # KV-write (deferred.py: the output travels as a lazy tensor through split / rotary_emb / RadixAttention); any TP size
         self._sgl_mi355_may_defer = True
         self._sgl_mi355_defer_epilogue = False
+
+    def forward(self, x):
+        out = self.quant_method.apply(self, x, self.bias)
+        if deferred.DEFERRED_EPILOGUES and type(out) is torch.Tensor and out.dim() == 2 and out.is_cuda:
+            # outside the FP8 split-K window (prefill, small decode batches, 16-bit and AWQ weights) the finished tensor goes out
+            # behind a lazy handle all the same once the attention backend has asked: rotary_emb then RECORDS the rotation and the
+            # backend runs RoPE + KV-pool write as one launch (ops.apply_rope_and_set_kv_buffer) instead of two -- and nobody
+            # can see the unrotated q / k meanwhile, every access goes through the handle (deferred.py)
+            if self._sgl_mi355_defer_epilogue:
+                return DeferredEpilogue(local=out), None
+            out._sgl_mi355_epilogue_producer = self  # (the backend finds it through q._base on the first plain pass)
+            if out._base is not None:
+                out._base._sgl_mi355_epilogue_producer = self
+        return out, None
 
     def weight_loader(self, param, loaded_weight: torch.Tensor, loaded_shard_id=None):
         """linear.py:877-913: shard ids "q" / "k" / "v"; the checkpoint's k / v hold ``total_num_kv_heads`` heads and
@@ -203,7 +226,7 @@ class RowParallelLinear(LinearBase):
                 out.needs_allreduce = True  # split-K partials of this rank's addend: whoever finishes them owes the collective
                 return out, None
             out = out.materialize()  # (a caller with its own plan for the collective gets the finished local sum)
-        if (self.reduce_results and not async_reduce and not can_fuse_mlp_allreduce and DEFERRED_EPILOGUES
+        if (self.reduce_results and not async_reduce and not can_fuse_mlp_allreduce and deferred.DEFERRED_EPILOGUES
                 and get_tensor_model_parallel_world_size() > 1 and type(out) is torch.Tensor):
             # the call untouched model code makes (models/llama.py:97,190): the all-reduce is this layer's.  When the RMSNorm that
             # consumed the previous output has asked and the P2P communicator takes the shape, hand it the unreduced sum as a

@@ -16,7 +16,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from .deferred import DEFERRED_EPILOGUES, DeferredCols, DeferredEpilogue
+from .deferred import DeferredCols, DeferredEpilogue
 
 _P = ctypes.c_void_p
 _I64 = ctypes.c_int64

@@ -27,7 +27,7 @@ import os
 
 import torch
 
-from . import ops
+from . import deferred, ops
 from .parameter import classes as _param_classes, is_linear_layer, raw_data, tracked
 
 # FP8 weights are re-laid fragment-major after loading when the shape allows (N % 16 == 0, K % 512 == 0): decode GEMMs
@@ -273,7 +273,7 @@ class W8A8Fp8LinearMethod(LinearMethodBase):
         # into this backend's RMSNorm: at decode sizes the GEMM is a split-K weight streamer, and once that norm has asked
         # (layers.RMSNorm.forward -> _sgl_mi355_defer_epilogue) the epilogue is left to it -- the output travels through the
         # model code as a DeferredEpilogue tensor (deferred.py; bit-identical, one launch less per GEMM).
-        may_defer = (ops.DEFERRED_EPILOGUES and getattr(layer, "_sgl_mi355_may_defer", False) and layer.input_scale is None
+        may_defer = (deferred.DEFERRED_EPILOGUES and getattr(layer, "_sgl_mi355_may_defer", False) and layer.input_scale is None
                      and x.dim() == 2 and x.is_cuda and DEFER_MIN_ROWS < x.shape[0] <= 128)
         if may_defer and hasattr(layer, "_sgl_mi355_partials_ok"):
             may_defer = layer._sgl_mi355_partials_ok(x.shape[0], x.dtype)
@@ -287,11 +287,32 @@ class W8A8Fp8LinearMethod(LinearMethodBase):
             part = ops.fp8_scaled_mm_partials(comp[0], layer.weight, comp[1], layer.weight_scale, x.dtype, bias)
             if part is not None:
                 return ops.defer_epilogue(part)
+        # A merged gate_up projection at prefill sizes whose output goes straight into this backend's SiluAndMul: once that has
+        # asked (_sgl_mi355_fuse_silu), SiLU(gate) * up runs in the GEMM's epilogue and the [T, 2I] matrix is never written
+        # (deferred.py: the lazy output carries the activation; the matrix is computed only if somebody else reads it)
+        may_silu = (deferred.DEFERRED_EPILOGUES and getattr(layer, "_sgl_mi355_may_fuse_silu", False) and layer.input_scale is None
+                    and x.dim() == 2 and x.is_cuda and x.shape[0] > 128 and ops.is_wshuffled(layer.weight))
+        if may_silu and getattr(layer, "_sgl_mi355_fuse_silu", False):
+            if comp is None:
+                x2 = x if x.is_contiguous() else x.contiguous()
+                q = torch.empty_like(x2, dtype=torch.float8_e4m3fn)
+                sc = torch.empty((x2.shape[0], 1), dtype=torch.float32, device=x.device)
+                ops.sgl_per_token_quant_fp8(x2, q, sc)
+                comp = (q, sc)
+            act = ops.fp8_scaled_mm_silu_mul(comp[0], layer.weight, comp[1], layer.weight_scale, x.dtype, bias)
+            if act is not None:
+                q_, s_, w_, ws_, dt_ = comp[0], comp[1], layer.weight, layer.weight_scale, x.dtype
+                lazy = ops.DeferredEpilogue(compute=lambda: ops.fp8_scaled_mm(q_, w_, s_, ws_, out_dtype=dt_, bias=bias),
+                                            like=((x.shape[0], 2 * act.shape[-1]), x.dtype, x.device))
+                lazy.silu_act = act
+                return lazy
         if comp is not None:
             out = ops.fp8_scaled_mm(comp[0], layer.weight, comp[1], layer.weight_scale, out_dtype=x.dtype, bias=bias)
             out = out.view(*x.shape[:-1], out.shape[-1])
         else:
             out = apply_fp8_linear(x, layer.weight, layer.weight_scale, input_scale=layer.input_scale, bias=bias)
+        if may_silu:
+            out._sgl_mi355_epilogue_producer = layer  # SiluAndMul.forward tells the layer (see above)
         if may_defer:
             # the consumer that receives this tensor (RMSNorm), or a view of it whose ._base it is (the attention backend behind
             # qkv.split), tells the layer that it could have taken the epilogue (see above)

@@ -84,3 +84,27 @@ def test_workspace_pool_finishes_the_pending_tensor_before_the_buffer_is_reused(
     del d3
     gc.collect()
     assert pool.get(dev, 8) is buf and p3.finalized == 0
+
+
+def test_split_and_view_stay_lazy_on_a_finished_local_tensor_too():
+    """The qkv projection outside the split-K window: a finished tensor behind a handle (local=...), same lazy split / view."""
+    from sglang_npu_amd.deferred import DeferredCols, qkv_root, rope_target
+    local = torch.arange(4 * 16, dtype=torch.float32).view(4, 16).clone()
+    d = DeferredEpilogue(local=local)
+    q, k, v = d.split([8, 4, 4], dim=-1)
+    assert all(isinstance(t, DeferredCols) for t in (q, k, v)) and q.stride() == (16, 1) and d.pending_local() is local
+    assert rope_target(q, k) is d
+
+    class Rot:
+        def forward(self, pos, q_, k_):
+            q_.mul_(-1)
+            k_.add_(1000)
+            return q_, k_
+    d._rope = (None, Rot(), (0, 8), (8, 12))
+    k3, v3 = k.view(-1, 2, 2), v.view(-1, 2, 2)
+    assert isinstance(k3, DeferredCols) and k3.stride() == (16, 2, 1) and qkv_root(q, k3, v3, 8, 4) is d
+    assert qkv_root(q, k3, v3, 8, 8) is None
+    got = v3 + 0          # somebody looks: the recorded rotation is applied, in place, by the module that recorded it
+    assert torch.equal(got, local[:, 12:].view(4, 2, 2)) and torch.equal(q + 0, -torch.arange(64.).view(4, 16)[:, :8])
+    assert torch.equal((k3 + 0).reshape(4, 4), torch.arange(64.).view(4, 16)[:, 8:12] + 1000)
+    assert d.materialize() is local

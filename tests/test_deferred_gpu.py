@@ -140,7 +140,7 @@ def test_any_other_consumer_gets_the_finished_gemm(monkeypatch):
     assert y.pending_partials() is None and torch.equal(y + 0, want)
     assert isinstance(other, DeferredEpilogue)
     # switched off: plain tensors again
-    monkeypatch.setattr(ops, "DEFERRED_EPILOGUES", False)
+    monkeypatch.setattr(deferred, "DEFERRED_EPILOGUES", False)
     y, _ = lin(x)
     assert type(y) is torch.Tensor
 
@@ -208,7 +208,7 @@ def test_reference_order_model_step_with_and_without_deferral(monkeypatch):
     B = 64
     res = {}
     for on in (False, True):
-        monkeypatch.setattr(ops, "DEFERRED_EPILOGUES", on)
+        monkeypatch.setattr(deferred, "DEFERRED_EPILOGUES", on)
         net = M.LlamaForCausalLM(cfg, "w8a8_fp8", torch.bfloat16, DEV, fuse_quant=False).load_dummy_weights()
         r2t = ReqToTokenPool(B, 256, DEV)
         pool = MHATokenToKVPool(B * 256 + 1, 1, torch.bfloat16, 2, 128, 3, DEV)
@@ -349,6 +349,117 @@ def test_qkv_chain_falls_back_to_the_plain_sequence_when_anybody_looks(monkeypat
     assert qkv.pending_partials() is None
     o = attn(q, k, v, fb)
     assert torch.equal(o, o_ref) and torch.equal(pool.k_buffer[0], k_ref)
-    # prefill of the same projection (more than 128 rows): never lazy
+    # prefill of the same projection (more than 128 rows): its own GEMM finishes it; the handle only keeps q / k out of sight
+    # until the recorded rotation has run (next test)
     big, _ = qkv_proj(torch.randn(300, hidden, device=DEV).to(dtype))
-    assert type(big) is torch.Tensor
+    assert isinstance(big, DeferredEpilogue) and big.pending_partials() is None and big.pending_local() is not None
+
+
+@pytest.mark.parametrize("T,H,I", [(1024, 4096, 14336), (300, 2048, 1536), (513, 4096, 3584)])
+def test_prefill_gate_up_hands_silu_and_mul_its_result(T, H, I, monkeypatch):
+    """models/llama.py:94-96 at prefill sizes: pass 0 plain (SiluAndMul tells the projection), from pass 1 the GEMM computes
+    SiLU(gate) * up in its epilogue and the [T, 2I] matrix is not written; bit-identical activation, and the matrix itself is
+    still there for anybody who asks."""
+    from sglang_npu_amd.layers import SiluAndMul
+    from sglang_npu_amd.linear import MergedColumnParallelLinear
+    dtype = torch.bfloat16
+    g = torch.Generator(device=DEV).manual_seed(T)
+    up = MergedColumnParallelLinear(H, [I, I], params_dtype=dtype, quant_config=W8A8Fp8Config(is_checkpoint_fp8_serialized=False)).to(DEV)
+    up.weight.data.copy_((torch.rand(2 * I, H, generator=g, device=DEV) * 4e-2 - 2e-2).to(dtype))
+    up.quant_method.process_weights_after_loading(up)
+    if not ops.is_wshuffled(up.weight):
+        pytest.skip("this shape keeps the K-major weight: no SiLU epilogue form")
+    act_fn = SiluAndMul()
+    x = torch.randn(T, H, generator=g, device=DEV).to(dtype)
+    q8 = torch.empty_like(x, dtype=torch.float8_e4m3fn)
+    s8 = torch.empty(T, 1, device=DEV)
+    ops.sgl_per_token_quant_fp8(x, q8, s8)
+    if ops.fp8_scaled_mm_silu_mul(q8, up.weight, s8, up.weight_scale, dtype, None) is None:
+        # the epilogue form declines this shape: the projection must simply stay plain, pass after pass
+        for _ in range(3):
+            gate_up, _ = up(x)
+            assert type(gate_up) is torch.Tensor
+            act_fn(gate_up)
+        return
+    plain_gemms = []
+    real = ops.fp8_scaled_mm
+    monkeypatch.setattr(ops, "fp8_scaled_mm", lambda *a, **k: (plain_gemms.append(1), real(*a, **k))[1])
+    kinds, acts = [], []
+    for it in range(3):
+        gate_up, _ = up(x)
+        kinds.append(type(gate_up))
+        acts.append(act_fn(gate_up).clone())
+    assert kinds == [torch.Tensor, DeferredEpilogue, DeferredEpilogue] and len(plain_gemms) == 1
+    assert torch.equal(acts[0], acts[1]) and torch.equal(acts[1], acts[2]), "SiLU in the epilogue must not move a bit"
+    gate_up, _ = up(x)
+    mat = gate_up + 0  # somebody reads the matrix: computed now, by the plain GEMM on the same FP8 operands
+    assert len(plain_gemms) == 2 and tuple(mat.shape) == (T, 2 * I)
+    assert torch.equal(ops.silu_and_mul(mat), acts[0]) and torch.equal(act_fn(gate_up), acts[0])
+    # decode sizes never take this form
+    small, _ = up(x[:64].contiguous())
+    assert type(small) is torch.Tensor
+
+
+@pytest.mark.parametrize("quant", ["fp8", "none"])
+@pytest.mark.parametrize("mode,B,T", [("decode", 8, 8), ("extend", 3, 200)])
+def test_finished_qkv_behind_a_lazy_handle_gets_rope_and_kv_write_in_one_launch(quant, mode, B, T, monkeypatch):
+    """Outside the split-K window (a small decode batch, a prefill; FP8 or 16-bit weights) the qkv projection is finished by
+    its own GEMM, but from the second pass on it travels behind a lazy handle: rotary_emb records, the backend runs
+    apply_rope_and_set_kv_buffer (one launch for RoPE + KV write) -- bit-identical pool and output."""
+    from sglang_npu_amd.harness import (ForwardBatch, ForwardMode, MHATokenToKVPool, ModelConfig, ModelRunnerLike, RadixAttention,
+                                        ReqToTokenPool, ServerArgs, install_attention_backend)
+    from sglang_npu_amd.layers import RotaryEmbedding
+    from sglang_npu_amd.linear import QKVParallelLinear
+    Hq, Hk, D, hidden, dtype = 16, 4, 128, 2048, torch.bfloat16
+    g = torch.Generator(device=DEV).manual_seed(B * 7 + T)
+    cfg = ModelConfig(Hq, Hk, D, hidden, 2 * hidden, 1, 512, 512)
+    qc = W8A8Fp8Config(is_checkpoint_fp8_serialized=False) if quant == "fp8" else None
+    qkv_proj = QKVParallelLinear(hidden, D, Hq, Hk, params_dtype=dtype, quant_config=qc).to(DEV)
+    qkv_proj.weight.data.copy_((torch.rand((Hq + 2 * Hk) * D, hidden, generator=g, device=DEV) * 4e-2 - 2e-2).to(dtype))
+    qkv_proj.quant_method.process_weights_after_loading(qkv_proj)
+    rot = RotaryEmbedding(D, D, 512, 10000.0, True, dtype, DEV)
+    attn = RadixAttention(Hq, D, D ** -0.5, Hk, 0)
+    r2t = ReqToTokenPool(B, 512, DEV)
+    pool = MHATokenToKVPool(B * 512 + 1, 1, dtype, Hk, D, 1, DEV)
+    r2t.req_to_token.copy_((torch.randperm(B * 512, device=DEV, generator=g) + 1).view(B, 512).to(torch.int32))
+    pool.k_buffer[0].normal_(generator=g)
+    pool.v_buffer[0].normal_(generator=g)
+    backend = install_attention_backend(ModelRunnerLike(cfg, r2t, pool, DEV, 0, 1, ServerArgs()))
+    rows = torch.arange(B, device=DEV)
+    if mode == "decode":
+        seq = torch.randint(1, 400, (B,), device=DEV, generator=g)
+        positions = seq - 1
+        fb = ForwardBatch(ForwardMode.DECODE, B, None, rows, seq, r2t.req_to_token[rows, seq - 1].long(), int(seq.sum()), seq.cpu(),
+                          positions, req_to_token_pool=r2t, token_to_kv_pool=pool, attn_backend=backend)
+    else:
+        prefix = torch.tensor([0, 30, 5], device=DEV)
+        ext = torch.tensor([T - 60, 40, 20], device=DEV)
+        seq = prefix + ext
+        positions = torch.cat([torch.arange(int(prefix[b]), int(seq[b]), device=DEV) for b in range(B)])
+        loc = torch.cat([r2t.req_to_token[b, prefix[b]:seq[b]] for b in range(B)]).long()
+        start = torch.zeros(B, dtype=torch.int64, device=DEV)
+        start[1:] = torch.cumsum(ext[:-1], 0)
+        fb = ForwardBatch(ForwardMode.EXTEND, B, None, rows, seq, loc, int(seq.sum()), seq.cpu(), positions, extend_num_tokens=T,
+                          extend_seq_lens=ext, extend_prefix_lens=prefix, extend_start_loc=start,
+                          extend_prefix_lens_cpu=prefix.tolist(), extend_seq_lens_cpu=ext.tolist(), req_to_token_pool=r2t,
+                          token_to_kv_pool=pool, attn_backend=backend)
+    backend.init_forward_metadata(fb)
+    x = torch.randn(T, hidden, generator=g, device=DEV).to(dtype)
+    q_size, kv_size = Hq * D, Hk * D
+    k0, v0 = pool.k_buffer[0].clone(), pool.v_buffer[0].clone()
+    fused, plain_rope = [], []
+    real_f, real_r = ops.apply_rope_and_set_kv_buffer, ops.apply_rope_with_cos_sin_cache_inplace
+    monkeypatch.setattr(ops, "apply_rope_and_set_kv_buffer", lambda *a, **k: (fused.append(1), real_f(*a, **k))[1])
+    monkeypatch.setattr(ops, "apply_rope_with_cos_sin_cache_inplace", lambda *a, **k: (plain_rope.append(1), real_r(*a, **k))[1])
+    res = []
+    for it in range(3):
+        pool.k_buffer[0].copy_(k0)
+        pool.v_buffer[0].copy_(v0)
+        o, qkv = _llama_attention_forward(qkv_proj, rot, attn, positions, x, fb, q_size, kv_size)
+        torch.cuda.synchronize()
+        res.append((o.clone(), pool.k_buffer[0].clone(), pool.v_buffer[0].clone(), type(qkv), (qkv + 0).clone()))
+    assert [r[3] for r in res] == [torch.Tensor, DeferredEpilogue, DeferredEpilogue]
+    assert len(plain_rope) == 1 and len(fused) == 2, "pass 0: rotary_emb + set_kv_buffer; passes 1, 2: one launch for both"
+    for r in res[1:]:
+        assert torch.equal(r[0], res[0][0]) and torch.equal(r[1], res[0][1]) and torch.equal(r[2], res[0][2])
+        assert torch.equal(r[4], res[0][4]), "the handle holds what the reference's in-place rotary_emb leaves in qkv"
