@@ -482,12 +482,23 @@ class MI355AttnBackend(AttentionBackend):
                                      md.num_kv_splits, layer.scaling, layer.logit_cap)
         else:
             if (isinstance(md.num_kv_splits, int) and md.num_kv_splits > 1 and md.attn_logits is not None
-                    and layer.qk_head_dim == layer.v_head_dim and self._fuse_split_merge(md.num_kv_splits, q3.shape[0])
-                    and ops.decode_attention_paged_merged(q3, kb, vb, o3, self.req_to_token, forward_batch.req_pool_indices,
-                                                          forward_batch.seq_lens, md.attn_logits[:q3.shape[0]],
-                                                          md.num_kv_splits, self._merge_counters, layer.scaling,
-                                                          layer.logit_cap) is not False):
-                return o
+                    and layer.qk_head_dim == layer.v_head_dim and self._fuse_split_merge(md.num_kv_splits, q3.shape[0])):
+                # the in-launch merge of the kv-splits.  FP8 companion (ops.attach_fp8_companion, the reference call order): once the
+                # w8a8 o_proj that receives this tensor has asked (layer.emit_fp8_companion, set through the producer tag below),
+                # the merging workgroup also quantises the row per token -- `o` AND (q, scale) from the one launch, bit-identical
+                # to sgl_per_token_quant_fp8 on `o`
+                want_comp = (ops.FP8_COMPANIONS and getattr(layer, "emit_fp8_companion", False)
+                             and (layer.tp_q_head_num * layer.v_head_dim) % 8 == 0)
+                done = ops.decode_attention_paged_merged(q3, kb, vb, o3, self.req_to_token, forward_batch.req_pool_indices,
+                                                         forward_batch.seq_lens, md.attn_logits[:q3.shape[0]],
+                                                         md.num_kv_splits, self._merge_counters, layer.scaling,
+                                                         layer.logit_cap, fp8_out=want_comp)
+                if done is not False:
+                    if want_comp:
+                        ops.attach_fp8_companion(o, done[0], done[1])
+                    elif ops.FP8_COMPANIONS:
+                        o._sgl_mi355_producer = layer
+                    return o
             ops.decode_attention_paged(q3, kb, vb, o3, self.req_to_token, forward_batch.req_pool_indices,
                                        forward_batch.seq_lens, md.attn_logits, md.num_kv_splits, layer.scaling,
                                        layer.logit_cap)

@@ -85,3 +85,45 @@ def test_companions_can_be_switched_off(monkeypatch):
     x = torch.randn(8, 512, device=DEV).bfloat16()
     out = norm(x)
     assert ops.take_fp8_companion(out) is None and not hasattr(out, "_sgl_mi355_producer")
+
+
+def test_decode_attention_with_kv_splits_emits_the_companion_for_o_proj():
+    """Fewer (request, kv head) items than CUs: the kv-splits are merged inside the attention launch, and once the FP8 o_proj
+    that receives the output has asked, the merging workgroup quantises the row as well (attn -> o_proj, models/llama.py:189-190,
+    untouched): no quant launch from the second pass on, not one bit different."""
+    from sglang_npu_amd.harness import (ForwardBatch, ForwardMode, MHATokenToKVPool, ModelConfig, ModelRunnerLike, RadixAttention,
+                                        ReqToTokenPool, ServerArgs, install_attention_backend)
+    B, Hq, Hk, D, dtype = 64, 8, 1, 128, torch.bfloat16   # one rank of Llama-3-70B at TP 8
+    g = torch.Generator(device=DEV).manual_seed(5)
+    cfg = ModelConfig(Hq, Hk, D, Hq * D, 1024, 1, 512, 2048)
+    r2t = ReqToTokenPool(B, 2048, DEV)
+    pool = MHATokenToKVPool(B * 2048 + 1, 1, dtype, Hk, D, 1, DEV)
+    r2t.req_to_token.copy_((torch.randperm(B * 2048, device=DEV, generator=g) + 1).view(B, 2048).to(torch.int32))
+    pool.k_buffer[0].normal_(generator=g)
+    pool.v_buffer[0].normal_(generator=g)
+    backend = install_attention_backend(ModelRunnerLike(cfg, r2t, pool, DEV, 0, 1, ServerArgs()))
+    attn = RadixAttention(Hq, D, D ** -0.5, Hk, 0)
+    o_proj = _fp8_linear(RowParallelLinear, Hq * D, 4096, g, dtype)
+    rows = torch.arange(B, device=DEV)
+    seq = torch.randint(900, 2000, (B,), device=DEV, generator=g)
+    fb = ForwardBatch(ForwardMode.DECODE, B, None, rows, seq, r2t.req_to_token[rows, seq - 1].long(), int(seq.sum()), seq.cpu(),
+                      seq - 1, req_to_token_pool=r2t, token_to_kv_pool=pool, attn_backend=backend)
+    backend.init_forward_metadata(fb)
+    assert backend.forward_metadata.num_kv_splits > 1 and backend._fuse_split_merge(backend.forward_metadata.num_kv_splits, B)
+    qkv = torch.randn(B, (Hq + 2 * Hk) * D, generator=g, device=DEV).to(dtype)
+    q, k, v = qkv.split([Hq * D, Hk * D, Hk * D], dim=-1)
+    quant_calls = []
+    real = ops.sgl_per_token_quant_fp8
+    ops.sgl_per_token_quant_fp8 = lambda *a, **kw: (quant_calls.append(1), real(*a, **kw))[1]
+    try:
+        outs = []
+        for it in range(3):
+            n0 = len(quant_calls)
+            o = attn(q, k, v, fb)
+            z, _ = o_proj(o)
+            torch.cuda.synchronize()
+            outs.append((o.clone(), (z + 0).clone(), len(quant_calls) - n0))
+        assert [x[2] for x in outs] == [1, 0, 0] and attn.emit_fp8_companion
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[1][1], outs[2][1])
+    finally:
+        ops.sgl_per_token_quant_fp8 = real
