@@ -227,6 +227,7 @@ class MI355AttnBackend(AttentionBackend):
         bs = forward_batch.batch_size
         if forward_batch.spec_info is not None:
             raise NotImplementedError("MI355AttnBackend: speculative decoding metadata is not implemented")
+        deferred.hint_decode = forward_batch.forward_mode.is_decode()  # (what the pass that follows is: see deferred.hint_decode)
         if forward_batch.forward_mode.is_decode_or_idle():
             max_len = int(forward_batch.seq_lens_cpu.max()) if forward_batch.seq_lens_cpu is not None else None
             splits = self.choose_num_kv_splits(bs, max_len)
@@ -293,6 +294,7 @@ class MI355AttnBackend(AttentionBackend):
         assert encoder_lens is None, "Not supported"
         if not forward_mode.is_decode_or_idle() or spec_info is not None:
             raise ValueError(f"Invalid forward mode: {forward_mode=} for CUDA Graph capture.")
+        deferred.hint_decode = forward_mode.is_decode()
         splits = self.choose_num_kv_splits(bs)  # depends on bs only: identical at capture and replay
         g = self._graph
         logits = lse = None

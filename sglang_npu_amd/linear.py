@@ -25,6 +25,15 @@ from .quantization import QuantizationConfig, UnquantizedLinearMethod
 
 
 class LinearBase(torch.nn.Module):
+    # hand-over switches of deferred.py, read on every apply(): class-level defaults so that the lookups never fall through to
+    # nn.Module.__getattr__ (a raised AttributeError per miss, ~1 us each, seven per decoder layer in an eager pass)
+    _sgl_mi355_may_defer = False       # may leave its decode-time epilogue to the consumer (row-parallel, qkv)
+    _sgl_mi355_defer_epilogue = False  # ... and the consumer has asked
+    _sgl_mi355_may_fuse_silu = False   # gate_up: SiLU * up may run in the prefill GEMM's epilogue
+    _sgl_mi355_fuse_silu = False       # ... and SiluAndMul has asked
+    _sgl_mi355_is_qkv = False
+    _sgl_mi355_partials_ok = None      # optional predicate (rows, dtype) -> bool
+
     def __init__(self, input_size: int, output_size: int, params_dtype: torch.dtype = torch.bfloat16,
                  quant_config: Optional[QuantizationConfig] = None, prefix: str = ""):
         super().__init__()
@@ -121,6 +130,7 @@ class QKVParallelLinear(ColumnParallelLinear):
         # KV-write (deferred.py: the output travels as a lazy tensor through split / rotary_emb / RadixAttention); any TP size
         self._sgl_mi355_may_defer = True
         self._sgl_mi355_defer_epilogue = False
+        self._sgl_mi355_is_qkv = True
 
     def forward(self, x):
         out = self.quant_method.apply(self, x, self.bias)
@@ -129,7 +139,9 @@ class QKVParallelLinear(ColumnParallelLinear):
             # behind a lazy handle all the same once the attention backend has asked: rotary_emb then RECORDS the rotation and the
             # backend runs RoPE + KV-pool write as one launch (ops.apply_rope_and_set_kv_buffer) instead of two -- and nobody
             # can see the unrotated q / k meanwhile, every access goes through the handle (deferred.py)
-            if self._sgl_mi355_defer_epilogue:
+            # (only where it cannot cost more host time than it saves on the GPU: under graph capture, or in a pass long enough
+            #  to be GPU-bound -- the lazy split / views are ~15 us of Python per layer against one ~5 us launch)
+            if self._sgl_mi355_defer_epilogue and (out.shape[0] >= 256 or torch.cuda.is_current_stream_capturing()):
                 return DeferredEpilogue(local=out), None
             out._sgl_mi355_epilogue_producer = self  # (the backend finds it through q._base on the first plain pass)
             if out._base is not None:

@@ -275,8 +275,12 @@ class W8A8Fp8LinearMethod(LinearMethodBase):
         # model code as a DeferredEpilogue tensor (deferred.py; bit-identical, one launch less per GEMM).
         may_defer = (deferred.DEFERRED_EPILOGUES and getattr(layer, "_sgl_mi355_may_defer", False) and layer.input_scale is None
                      and x.dim() == 2 and x.is_cuda and DEFER_MIN_ROWS < x.shape[0] <= 128)
-        if may_defer and hasattr(layer, "_sgl_mi355_partials_ok"):
+        if may_defer and layer._sgl_mi355_partials_ok is not None:
             may_defer = layer._sgl_mi355_partials_ok(x.shape[0], x.dtype)
+        if may_defer and not deferred.hint_decode and (layer._sgl_mi355_is_qkv or not torch.cuda.is_current_stream_capturing()):
+            # an extend pass: nobody there takes a qkv projection's partials, and an eager prefill of <= 128 rows is host-bound
+            # -- the lazy objects would cost more Python time than the finalize launch they save (deferred.hint_decode)
+            may_defer = False
         if may_defer and getattr(layer, "_sgl_mi355_defer_epilogue", False):
             if comp is None:
                 x2 = x if x.is_contiguous() else x.contiguous()

@@ -16,6 +16,15 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+@pytest.fixture(autouse=True)
+def _decode_hint():
+    """deferred.hint_decode is set per batch by MI355AttnBackend.init_forward_metadata (a speed hint: an eager extend pass of
+    <= 128 rows keeps its GEMMs plain); tests that drive layers without a backend start from the default."""
+    deferred.hint_decode = True
+    yield
+    deferred.hint_decode = True
+
+
 def _row_linear(k, n, g, dtype, bias=False):
     lin = RowParallelLinear(k, n, bias=bias, params_dtype=dtype, quant_config=W8A8Fp8Config(is_checkpoint_fp8_serialized=False)).to(DEV)
     w = (torch.rand(n, k, generator=g, device=DEV) * 2e-2 - 1e-2).to(dtype)
@@ -401,7 +410,7 @@ def test_prefill_gate_up_hands_silu_and_mul_its_result(T, H, I, monkeypatch):
 
 
 @pytest.mark.parametrize("quant", ["fp8", "none"])
-@pytest.mark.parametrize("mode,B,T", [("decode", 8, 8), ("extend", 3, 200)])
+@pytest.mark.parametrize("mode,B,T", [("decode", 8, 8), ("extend", 3, 300)])
 def test_finished_qkv_behind_a_lazy_handle_gets_rope_and_kv_write_in_one_launch(quant, mode, B, T, monkeypatch):
     """Outside the split-K window (a small decode batch, a prefill; FP8 or 16-bit weights) the qkv projection is finished by
     its own GEMM, but from the second pass on it travels behind a lazy handle: rotary_emb records, the backend runs
@@ -447,6 +456,11 @@ def test_finished_qkv_behind_a_lazy_handle_gets_rope_and_kv_write_in_one_launch(
     x = torch.randn(T, hidden, generator=g, device=DEV).to(dtype)
     q_size, kv_size = Hq * D, Hk * D
     k0, v0 = pool.k_buffer[0].clone(), pool.v_buffer[0].clone()
+    if mode == "decode":
+        # (8 rows, eager: the handle would cost more host time than the launch it saves, so the projection only hands it out under
+        #  graph capture -- which is how decode runs; stand in for the capture here)
+        from sglang_npu_amd import linear as L
+        monkeypatch.setattr(L.torch.cuda, "is_current_stream_capturing", lambda: True)
     fused, plain_rope = [], []
     real_f, real_r = ops.apply_rope_and_set_kv_buffer, ops.apply_rope_with_cos_sin_cache_inplace
     monkeypatch.setattr(ops, "apply_rope_and_set_kv_buffer", lambda *a, **k: (fused.append(1), real_f(*a, **k))[1])
