@@ -1,34 +1,36 @@
-"""A row-parallel FP8 GEMM whose epilogue has not run yet, handed through UNTOUCHED model code as a tensor.
+"""Lazy tensors: work that one drop-in class leaves for the next, handed through UNTOUCHED model code as a tensor.
 
-In the reference's call order (models/llama.py:  `hidden_states = self.mlp(hidden_states)` ... next layer:
-`hidden_states, residual = self.input_layernorm(hidden_states, residual)`, and the same between `o_proj` and
-`post_attention_layernorm`) the output of `o_proj` / `down_proj` goes straight into this backend's RMSNorm, which
-overwrites it (layernorm.py:82-85, fused_add_rmsnorm is in place).  At decode sizes the GEMM is a split-K weight streamer
-whose partial sums are finished by a separate `finalize` launch (~5 us) that the norm kernel can do on its way in
-(sgl_mi355_fused_add_rmsnorm_from_partials, bit-identical) -- this repo's own fused entry points have done so since round 2.
+SGLang's model files call the drop-in classes one after another (models/llama.py:94-98, 186-191, 245-268):
+`qkv_proj -> split -> rotary_emb -> attn -> o_proj -> post_attention_layernorm -> gate_up_proj -> act_fn -> down_proj -> next
+input_layernorm`.  This repo's own fused call order saves launches by letting a consumer finish its producer's work (the norm
+kernel runs the GEMM epilogue of `o_proj` / `down_proj` on its way in, the attention backend's RoPE + KV-write launch that of
+`qkv_proj`, ...).  The classes here let the REFERENCE call order do the same without touching the model: the producer returns a
+wrapper tensor subclass -- real shape / dtype / device, no storage -- and the consumer, one of this backend's own classes,
+recognises it and takes the unfinished work.  ANY other torch operation on such a tensor first runs the plain sequence (finalize,
+all-reduce, RoPE ...) and proceeds on the real tensor (`__torch_dispatch__`); this package's raw-pointer ops do the same when they
+take its pointer (ops._ptr; `data_ptr()` of the wrapper itself is 0, never a stale address).  So a lazy tensor is never observable
+as anything but the value the reference would hold at that point, bit for bit.  A producer only goes lazy after its consumer has
+ASKED (the consumer tags the producer on the first plain pass), i.e. from the second eager pass and in every graph captured after
+the usual warm-up.
 
-`DeferredEpilogue` lets the drop-in classes do the same without touching the model: `W8A8Fp8LinearMethod.apply` returns one
-(once the RMSNorm that consumed this layer's previous output has asked for it) and `RMSNorm.forward` consumes it.  It is a
-wrapper tensor subclass: shape / dtype / device are real, there is no storage, and ANY torch operation on it from anybody else
-first runs the plain finalize launch (and the all-reduce, see below) and proceeds on the real tensor (`__torch_dispatch__`) -- so it is never observable as
-anything but the GEMM's output; `data_ptr()` raises instead of returning garbage.  The partial sums live in the stream's
-split-K workspace: the workspace pool finishes a still-pending tensor BEFORE it hands the buffer to the next GEMM
-(ops._ScratchPool.get), under graph capture too (the finalize launch is captured where it happens).
-The qkv projection goes the same way to the attention backend (models/llama.py:186-189): `qkv.split(...)` on the lazy tensor
-gives lazy column ranges (DeferredCols), `RotaryEmbedding.forward` records the rotation instead of applying it,
-RadixAttention's `.view(-1, heads, head_dim)` stays lazy, and `MI355AttnBackend.forward_decode` finishes GEMM + RoPE + KV-pool
-write in one launch (rope_set_kv_from_partials).  Anybody else who reads q / k / v first gets finalize + the recorded RoPE, i.e.
-the reference's own sequence; reading the qkv handle AFTER the backend consumed it raises (there is no tensor any more).
-At prefill sizes the gate_up projection hands SiluAndMul its result the same way (models/llama.py:94-96): once SiluAndMul has
-asked, the GEMM runs with SiLU(gate) * up in its epilogue (the [T, 2I] product never goes to HBM), the lazy tensor carries that
-activation (`silu_act`) for SiluAndMul.forward, and anybody else who reads the gate_up matrix gets it computed then (a closure
-over the same FP8 operands launches the plain GEMM: rare, correct, one GEMM slower).
-Under tensor parallelism `RowParallelLinear.forward(x)` -- called without flags, as models/llama.py:97,190 does -- owns the
-all-reduce (linear.py:1302-1303).  Once the norm has asked, it returns this rank's finished GEMM output as a lazy tensor with
-`needs_allreduce`: the RMSNorm runs all-reduce + residual add + norm as ONE kernel on the P2P communicator
-(RMSNorm.forward_with_allreduce_fusion, the role upstream reserves for `can_fuse_mlp_allreduce`, which llama.py does not
-pass); anybody else gets the plain all-reduce first, exactly what the linear would have done.
-SGL_MI355_NO_DEFERRED_EPILOGUE=1 switches the mechanism off (the linear finishes its own output as before)."""
+* `DeferredEpilogue(part)`: a row-parallel FP8 GEMM (`o_proj`, `down_proj`; 33..128 rows) still in split-K partial sums;
+  consumer `RMSNorm.forward(x, residual)` -> sgl_mi355_fused_add_rmsnorm_from_partials (finalize + fused_add_rmsnorm [+ the FP8
+  companion], one launch).  The partial sums live in the stream's split-K workspace: the workspace pool finishes a pending tensor
+  BEFORE it hands the buffer to the next GEMM (ops._ScratchPool.get), under graph capture too.
+* the same with `needs_allreduce` under tensor parallelism: `RowParallelLinear.forward(x)` called without flags, as llama.py does,
+  owns the all-reduce (linear.py:1302-1303); the lazy tensor carries this rank's addend (finished sum or partials) and the norm
+  runs all-reduce + add + norm as ONE kernel on the P2P communicator (RMSNorm.forward_with_allreduce_fusion -- the role upstream
+  reserves for `can_fuse_mlp_allreduce`, which llama.py does not pass); anybody else gets the plain all-reduce first.
+* the qkv projection: `qkv.split(...)` on the lazy tensor gives lazy column ranges (`DeferredCols`), `RotaryEmbedding.forward`
+  RECORDS the rotation, RadixAttention's `.view(-1, heads, head_dim)` stays lazy, and `MI355AttnBackend.forward_decode` finishes
+  GEMM + RoPE + KV-pool write in one launch (rope_set_kv_from_partials).  Outside the split-K window the projection is finished
+  by its own GEMM but still travels behind a handle (`local=`), so that RoPE + KV write are one launch
+  (apply_rope_and_set_kv_buffer).  Anybody else who reads q / k / v first gets finalize + the recorded RoPE, the reference's own
+  sequence; reading the qkv handle AFTER the backend consumed the partials raises (there is no tensor any more).
+* the prefill gate_up projection (`compute=`): once SiluAndMul has asked, the GEMM runs with SiLU(gate) * up in its epilogue, the
+  lazy tensor carries that activation (`silu_act`), and anybody else who reads the [T, 2I] matrix gets it computed then (a
+  closure over the same FP8 operands launches the plain GEMM: rare, correct, one GEMM slower).
+SGL_MI355_NO_DEFERRED_EPILOGUE=1 switches all of it off (every class finishes its own output as before)."""
 from __future__ import annotations
 
 import os
