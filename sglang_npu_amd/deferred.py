@@ -8,7 +8,7 @@ kernel runs the GEMM epilogue of `o_proj` / `down_proj` on its way in, the atten
 wrapper tensor subclass -- real shape / dtype / device, no storage -- and the consumer, one of this backend's own classes,
 recognises it and takes the unfinished work.  ANY other torch operation on such a tensor first runs the plain sequence (finalize,
 all-reduce, RoPE ...) and proceeds on the real tensor (`__torch_dispatch__`); this package's raw-pointer ops do the same when they
-take its pointer (ops._ptr; `data_ptr()` of the wrapper itself is 0, never a stale address).  So a lazy tensor is never observable
+take its pointer (ops._ptr), and so does anybody's `data_ptr()` / `tolist()` / `numpy()` (answered by the finished tensor).  So a lazy tensor is never observable
 as anything but the value the reference would hold at that point, bit for bit.  A producer only goes lazy after its consumer has
 ASKED (the consumer tags the producer on the first plain pass), i.e. from the second eager pass and in every graph captured after
 the usual warm-up.
@@ -216,6 +216,19 @@ class DeferredCols(torch.Tensor):
 
     def __repr__(self):
         return f"DeferredCols([{self._c0}:{self._c1}] of {self._root!r}, shape {tuple(self.shape)})"
+
+
+def _passthrough(name):
+    def method(self, *args, **kwargs):
+        return getattr(self.materialize(), name)(*args, **kwargs)
+    method.__name__ = name
+    method.__doc__ = f"Tensor.{name} of the finished tensor (these do not go through the dispatcher: answered here, never garbage)."
+    return method
+
+
+for _name in ("data_ptr", "tolist", "numpy", "untyped_storage", "storage_offset", "__array__", "__dlpack__"):
+    setattr(DeferredEpilogue, _name, _passthrough(_name))
+    setattr(DeferredCols, _name, _passthrough(_name))
 
 
 def rope_target(query, key):

@@ -58,6 +58,11 @@ def test_ops_ptr_finishes_a_deferred_tensor_instead_of_passing_null():
     d = DeferredEpilogue(p)
     ptr = ops._ptr(d)
     assert p.finalized == 1 and ptr.value == d.materialize().data_ptr() and ptr.value != 0
+    # ... and so does anybody else who asks for the address or the values without going through the dispatcher
+    p2 = FakePartials()
+    d2 = DeferredEpilogue(p2)
+    assert d2.data_ptr() == d2.materialize().data_ptr() != 0 and p2.finalized == 1
+    assert d2.tolist() == d2.materialize().tolist() and (d2.float().numpy() == d2.materialize().float().numpy()).all()
 
 
 def test_workspace_pool_finishes_the_pending_tensor_before_the_buffer_is_reused(monkeypatch):
