@@ -34,7 +34,7 @@ extern "C" {
 #define SGL_MI355_ERR_RUNTIME 3          /* a HIP runtime call failed                */
 
 /* ABI version of this header; bumped on any signature change. */
-#define SGL_MI355_ABI_VERSION 12
+#define SGL_MI355_ABI_VERSION 13
 int sgl_mi355_abi_version(void);
 
 /* Copies the calling thread's last error message (NUL-terminated) into buf. Returns its length. */
@@ -664,6 +664,14 @@ int sgl_mi355_gemm16_nt_wshuffled(const void* x, const void* weight_shuffled, co
  * o_proj / down_proj / qkv of a bf16 model at decode sizes (layers/quantization/unquant.py: F.linear).  M > 128: the tiled
  * kernel cuts K into up to 640 / (tiles of 128 x 128) slices of at least 16 k-steps where its tiles would cover half the chip
  * or less for 64 k-steps or more (workspace: slices * M * N floats; too small a workspace runs the unsplit kernel). */
+/* The split-K form without its finalize launch (round 5): the fp32 partial sums [num_slices][M][N] stay in `workspace` for a
+ * consumer that runs the epilogue itself -- sgl_mi355_fp8_scaled_mm_finalize / *_from_partials with unit scales repeat
+ * gemm16_finalize_kernel's arithmetic (sum in slice order, + bias, one rounding).  1..128 rows; SGL_MI355_ERR_UNSUPPORTED
+ * (nothing launched) where the shape has no split-K form.  Replaces: the F.linear of an unquantised row-parallel / qkv layer
+ * (unquant.py:111-123) whose output goes straight into RMSNorm / RoPE + KV write (sglang_npu_amd/deferred.py). */
+int sgl_mi355_gemm16_nt_wshuffled_partials(const void* x, const void* weight_shuffled, float* workspace,
+                                           int64_t workspace_floats, int64_t M, int64_t N, int64_t K, int64_t x_stride_m,
+                                           int dtype, int32_t* num_slices, void* stream);
 int sgl_mi355_gemm16_nt_wshuffled_splitk(const void* x, const void* weight_shuffled, const void* bias, void* out,
                                          float* workspace, int64_t workspace_floats, int64_t M, int64_t N, int64_t K,
                                          int64_t x_stride_m, int dtype, void* stream);

@@ -310,6 +310,9 @@ int launch16_ph(const G16Args& p, int nc, int groups, hipStream_t s) {
 // Split-K form (pre-shuffled weights): (phase length, consumer waves, K slices) as gemm_fp8.hip launch_wstream picks them --
 // one workgroup per CU, fewest k-steps on the busiest CU -- then the finalize kernel.  `used` = false: the shape has no
 // split-K form (K / 64 not a multiple of a phase, or the workspace is too small); nothing was launched.
+// set by sgl_mi355_gemm16_nt_wshuffled_partials around its call: leave the slices unsummed and report their count
+thread_local int32_t* tl_g16_slices = nullptr;
+
 template <int DTYPE, int MB, int PH, bool NT>
 int launch16_slab_k(const G16Args& p, int nc, int groups, int SK, hipStream_t s) {
   auto kern = gemm16_wstream_kernel<DTYPE, MB, PH, NT, 1, 2, true, true>;
@@ -323,6 +326,10 @@ int launch16_slab_k(const G16Args& p, int nc, int groups, int SK, hipStream_t s)
   hipLaunchKernelGGL(kern, dim3((unsigned)groups, (unsigned)SK), dim3(64 * (nc + 1)), lds, s, p);
   int rc = check_hip(hipGetLastError(), "gemm16_wstream (split-K) launch");
   if (rc) return rc;
+  if (tl_g16_slices != nullptr) {  // the consumer runs the epilogue (sum in slice order, + bias, one rounding)
+    *tl_g16_slices = SK;
+    return 0;
+  }
   const int64_t total = (int64_t)p.M * p.N / 8;
   hipLaunchKernelGGL((gemm16_finalize_kernel<DTYPE>), dim3((unsigned)((total + 63) / 64)), dim3(64), 0, s, p, SK);
   return check_hip(hipGetLastError(), "gemm16_finalize launch");
@@ -714,6 +721,10 @@ static int gemm16_impl(const void* x, const void* weight, const void* bias, void
       if (rc || used) return rc;
     }
   }
+  if (tl_g16_slices != nullptr) {
+    set_error("gemm16_nt_wshuffled_partials: this shape has no split-K form (M=%ld N=%ld K=%ld)", (long)M, (long)N, (long)K);
+    return SGL_MI355_ERR_UNSUPPORTED;  // nothing launched: the caller runs the GEMM that finishes itself
+  }
 #define G16_D(D)                                   \
   do {                                             \
     if (M <= 16) return launch16<D, 1>(p, s);      \
@@ -741,6 +752,24 @@ extern "C" int sgl_mi355_gemm16_nt_wshuffled(const void* x, const void* weight_s
 // ... with an fp32 workspace for the split-K form: narrow N (fewer than ~200 workgroups of 8 column blocks) is cut along K into
 // slices of whole phases, partial sums go to `workspace` (num_slices * M * N floats, at most 16 * M * N) and a finalize kernel
 // sums them in slice order, adds the bias and rounds once.  Wide N runs the unsplit kernel as sgl_mi355_gemm16_nt_wshuffled.
+// The split-K form WITHOUT its finalize launch: fp32 partial sums [num_slices][M][N] stay in `workspace` for a consumer that
+// runs the epilogue itself -- the *_from_partials entry points of the FP8 path with unit scales (sum in slice order, + bias, one
+// rounding: gemm16_finalize_kernel's arithmetic).  Decode sizes only (M <= 128); SGL_MI355_ERR_UNSUPPORTED, nothing launched,
+// where the shape has no split-K form.
+extern "C" int sgl_mi355_gemm16_nt_wshuffled_partials(const void* x, const void* weight_shuffled, float* workspace,
+                                                      int64_t workspace_floats, int64_t M, int64_t N, int64_t K,
+                                                      int64_t x_stride_m, int dtype, int32_t* num_slices, void* stream) {
+  SGLM_CHECK_ARG(workspace != nullptr && workspace_floats > 0 && num_slices != nullptr,
+                 "gemm16_nt_wshuffled_partials: null workspace / num_slices");
+  SGLM_CHECK_ARG(M > 0 && M <= 128, "gemm16_nt_wshuffled_partials: decode sizes only (1..128 rows, got %ld)", (long)M);
+  *num_slices = 0;
+  tl_g16_slices = num_slices;
+  // (`out` is not written in this form; the workspace stands in for the non-null / alignment checks)
+  const int rc = gemm16_impl(x, weight_shuffled, nullptr, workspace, M, N, K, x_stride_m, K, 1, dtype, stream, workspace, workspace_floats);
+  tl_g16_slices = nullptr;
+  return rc;
+}
+
 extern "C" int sgl_mi355_gemm16_nt_wshuffled_splitk(const void* x, const void* weight_shuffled, const void* bias, void* out,
                                                     float* workspace, int64_t workspace_floats, int64_t M, int64_t N, int64_t K,
                                                     int64_t x_stride_m, int dtype, void* stream) {

@@ -1070,6 +1070,46 @@ def linear16(x: torch.Tensor, weight, bias: Optional[torch.Tensor] = None) -> to
     return out
 
 
+_UNIT_SCALES = {}
+
+
+def _unit_scales(device: torch.device, n: int) -> torch.Tensor:
+    """A cached float32 vector of ones (the scales of a GEMM that has none, for the *_from_partials consumers)."""
+    key = device.index
+    cur = _UNIT_SCALES.get(key)
+    if cur is None or cur.numel() < n:
+        if cur is not None and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the unit-scale vector would have to grow during graph capture: run one eager pass first")
+        cur = torch.ones(max(n, 32768), dtype=torch.float32, device=device)
+        _UNIT_SCALES[key] = cur  # (a replaced vector stays referenced by the GemmPartials / graphs that hold it)
+    return cur[:n]
+
+
+def linear16_partials(x: torch.Tensor, weight, bias: Optional[torch.Tensor] = None) -> Optional[GemmPartials]:
+    """Split-K half of linear16 on a fragment-major weight (ShuffledWeight16): raw fp32 partial sums as an ops.GemmPartials
+    whose scales are ones, so that part.finalize() and every *_from_partials consumer of the FP8 path finish it with
+    gemm16_finalize_kernel's arithmetic (sum in slice order, + bias, one rounding) -- bit-identical to linear16.  None (nothing
+    launched) where the shape has no split-K form: wide N, more than 128 rows."""
+    if not isinstance(weight, ShuffledWeight16):
+        return None
+    _need_gpu(x, weight.data, bias)
+    if x.dim() != 2 or x.stride(1) != 1 or x.dtype != weight.dtype or x.size(1) != weight.K:
+        raise RuntimeError("linear16_partials: x [M,K] must match the shuffled weight's dtype and K")
+    M = x.size(0)
+    if not (0 < M <= 128) or weight.N >= 16 * 8 * 200:
+        return None
+    ones = _unit_scales(x.device, max(M, weight.N))  # (before the workspace is taken: may allocate)
+    ws = _fp8_workspace.get(x.device, 16 * M * weight.N)
+    sk = ctypes.c_int32(0)
+    rc = _lib.lib().sgl_mi355_gemm16_nt_wshuffled_partials(
+        _ptr(x), _ptr(weight.data), _ptr(ws), _I64(ws.numel()), _I64(M), _I64(weight.N), _I64(weight.K),
+        _I64(x.stride(0) if M > 1 else weight.K), _I(_dtype_code(x)), ctypes.byref(sk), _stream(x))
+    if rc == 2:
+        return None
+    _lib.check(rc)
+    return GemmPartials(ws, sk.value, ones[:M], ones[:weight.N], bias, M, weight.N, x.dtype)
+
+
 _G16T_SK = int(os.environ.get("SGL_MI355_G16T_SK", "0") or 0)  # (read once, like the library reads it)
 _G16T_TILE = os.environ.get("SGL_MI355_G16T_TILE", "")
 

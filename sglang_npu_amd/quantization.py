@@ -151,7 +151,25 @@ class UnquantizedLinearMethod(LinearMethodBase):
             x2 = x.reshape(-1, x.shape[-1])
             rows = x2.shape[0]
             if (0 < rows <= LINEAR16_MAX_ROWS or (rows > 128 and LINEAR16_TILED)) and x2.stride(-1) == 1:
-                return ops.linear16(x2, fm, bias).reshape(x.shape[:-1] + (fm.N,))
+                # the hand-overs of deferred.py for an unquantised layer (same protocol as W8A8Fp8LinearMethod.apply): a
+                # row-parallel or qkv layer whose consumer has asked leaves its split-K partial sums unfinished at decode sizes
+                # (from one row on: narrow 16-bit layers run split-K + finalize at every decode size)
+                may_defer = (deferred.DEFERRED_EPILOGUES and getattr(layer, "_sgl_mi355_may_defer", False) and x.dim() == 2
+                             and rows <= 128)
+                if may_defer and layer._sgl_mi355_partials_ok is not None:
+                    may_defer = layer._sgl_mi355_partials_ok(rows, x.dtype)
+                if may_defer and not deferred.hint_decode and (layer._sgl_mi355_is_qkv or not torch.cuda.is_current_stream_capturing()):
+                    may_defer = False
+                if may_defer and getattr(layer, "_sgl_mi355_defer_epilogue", False):
+                    part = ops.linear16_partials(x2, fm, bias)
+                    if part is not None:
+                        return ops.defer_epilogue(part)
+                out = ops.linear16(x2, fm, bias).reshape(x.shape[:-1] + (fm.N,))
+                if may_defer:
+                    out._sgl_mi355_epilogue_producer = layer
+                    if out._base is not None:
+                        out._base._sgl_mi355_epilogue_producer = layer
+                return out
         return torch.nn.functional.linear(x, layer.weight, bias)
 
 

@@ -285,6 +285,35 @@ def _llama_attention_forward(qkv_proj, rot, attn, positions, hidden_states, fb, 
     return attn(q, k, v, fb), qkv
 
 
+@pytest.mark.parametrize("B,Hq,Hk,D,hidden,dtype", [(64, 32, 8, 128, 4096, torch.bfloat16)])
+def test_unquantised_qkv_chain_through_untouched_model_code(B, Hq, Hk, D, hidden, dtype, monkeypatch):
+    """The same chain with 16-bit weights (config 2): the streamer's split-K partials go to the backend's RoPE + KV-write launch;
+    bit-identical to linear16 -> split -> rotary_emb -> set_kv_buffer -> attention."""
+    from sglang_npu_amd.harness import RadixAttention
+    from sglang_npu_amd.layers import RotaryEmbedding
+    from sglang_npu_amd.linear import QKVParallelLinear
+    qkv_fp8, rot, attn, pool, fb, x, positions = _qkv_setup(B, Hq, Hk, D, hidden, dtype, seed=B + 1)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    qkv_proj = QKVParallelLinear(hidden, D, Hq, Hk, params_dtype=dtype).to(DEV)
+    qkv_proj.weight.data.copy_((torch.rand((Hq + 2 * Hk) * D, hidden, generator=g, device=DEV) * 4e-2 - 2e-2).to(dtype))
+    qkv_proj.quant_method.process_weights_after_loading(qkv_proj)
+    q_size, kv_size = Hq * D, Hk * D
+    k0, v0 = pool.k_buffer[0].clone(), pool.v_buffer[0].clone()
+    launches = []
+    real = ops.rope_set_kv_from_partials
+    monkeypatch.setattr(ops, "rope_set_kv_from_partials", lambda *a, **k: (launches.append(1), real(*a, **k))[1])
+    res = []
+    for it in range(3):
+        pool.k_buffer[0].copy_(k0)
+        pool.v_buffer[0].copy_(v0)
+        o, qkv = _llama_attention_forward(qkv_proj, rot, attn, positions, x, fb, q_size, kv_size)
+        torch.cuda.synchronize()
+        res.append((o.clone(), pool.k_buffer[0].clone(), pool.v_buffer[0].clone(), type(qkv)))
+    assert [r[3] for r in res] == [torch.Tensor, DeferredEpilogue, DeferredEpilogue] and len(launches) == 2
+    for r in res[1:]:
+        assert torch.equal(r[0], res[0][0]) and torch.equal(r[1], res[0][1]) and torch.equal(r[2], res[0][2])
+
+
 @pytest.mark.parametrize("B,Hq,Hk,D,hidden,dtype", [(64, 32, 8, 128, 4096, torch.bfloat16), (96, 8, 1, 128, 2048, torch.float16),
                                                     (40, 16, 16, 64, 1024, torch.bfloat16)])
 def test_qkv_chain_through_untouched_model_code(B, Hq, Hk, D, hidden, dtype, monkeypatch):
@@ -419,6 +448,8 @@ def test_finished_qkv_behind_a_lazy_handle_gets_rope_and_kv_write_in_one_launch(
                                         ReqToTokenPool, ServerArgs, install_attention_backend)
     from sglang_npu_amd.layers import RotaryEmbedding
     from sglang_npu_amd.linear import QKVParallelLinear
+    if quant == "none" and mode == "decode":
+        pytest.skip("16-bit weights at decode sizes leave split-K partials (test_unquantised_qkv_chain_...), not a finished tensor")
     Hq, Hk, D, hidden, dtype = 16, 4, 128, 2048, torch.bfloat16
     g = torch.Generator(device=DEV).manual_seed(B * 7 + T)
     cfg = ModelConfig(Hq, Hk, D, hidden, 2 * hidden, 1, 512, 512)
@@ -477,3 +508,31 @@ def test_finished_qkv_behind_a_lazy_handle_gets_rope_and_kv_write_in_one_launch(
     for r in res[1:]:
         assert torch.equal(r[0], res[0][0]) and torch.equal(r[1], res[0][1]) and torch.equal(r[2], res[0][2])
         assert torch.equal(r[4], res[0][4]), "the handle holds what the reference's in-place rotary_emb leaves in qkv"
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("T,K,H", [(64, 14336, 4096), (8, 4096, 4096), (100, 2048, 1024)])
+def test_unquantised_row_parallel_layer_hands_its_epilogue_to_the_norm(dtype, T, K, H):
+    """The 16-bit weight streamer's split-K form (config 2, the bf16 model): same protocol, same kernel on unit scales;
+    bit-identical to linear16 (split-K + its own finalize) followed by fused_add_rmsnorm."""
+    g = torch.Generator(device=DEV).manual_seed(T + K)
+    lin = RowParallelLinear(K, H, params_dtype=dtype).to(DEV)
+    lin.weight.data.copy_((torch.rand(H, K, generator=g, device=DEV) * 4e-2 - 2e-2).to(dtype))
+    lin.quant_method.process_weights_after_loading(lin)
+    norm = _norm(H, g, dtype)
+    x = torch.randn(T, K, generator=g, device=DEV).to(dtype)
+    r0 = torch.randn(T, H, generator=g, device=DEV).to(dtype)
+    kinds, outs = [], []
+    for it in range(3):
+        r = r0.clone()
+        y, _ = lin(x)
+        kinds.append(type(y))
+        h, r = norm(y, r)
+        outs.append((h.clone(), r.clone()))
+    assert kinds == [torch.Tensor, DeferredEpilogue, DeferredEpilogue]
+    for h, r in outs[1:]:
+        assert torch.equal(h, outs[0][0]) and torch.equal(r, outs[0][1]), "the 16-bit partials form must not move a bit"
+    # anybody else gets linear16's own result
+    y, _ = lin(x)
+    fm = lin.quant_method.weight_fm(lin)
+    assert isinstance(y, DeferredEpilogue) and torch.equal(y + 0, ops.linear16(x, fm))
