@@ -34,7 +34,7 @@ extern "C" {
 #define SGL_MI355_ERR_RUNTIME 3          /* a HIP runtime call failed                */
 
 /* ABI version of this header; bumped on any signature change. */
-#define SGL_MI355_ABI_VERSION 13
+#define SGL_MI355_ABI_VERSION 14
 int sgl_mi355_abi_version(void);
 
 /* Copies the calling thread's last error message (NUL-terminated) into buf. Returns its length. */
@@ -561,6 +561,14 @@ int sgl_mi355_awq_repack(const int32_t* qweight, const void* scales, const int32
 int sgl_mi355_awq_gemm_packed(const void* x, const uint32_t* wp, const uint32_t* sz, const void* bias, void* out,
                               float* workspace, int64_t workspace_floats, int64_t M, int64_t N, int64_t K,
                               int64_t group_size, int64_t x_stride_m, int dtype, void* stream);
+/* The same GEMM's split-K form without its finalize launch (round 5): fp32 partial sums [num_slices][M][N] stay in `workspace`
+ * for a consumer that runs the epilogue itself -- sgl_mi355_fp8_scaled_mm_finalize / *_from_partials on unit scales repeat
+ * awq_packed_finalize_kernel's arithmetic (sum in slice order, + bias, one rounding).  SGL_MI355_ERR_UNSUPPORTED (nothing
+ * launched) where the shape runs unsplit.  Replaces: AWQLinearMethod.apply (awq.py:401-418) of a row-parallel / qkv layer whose
+ * output goes straight into RMSNorm / RoPE + KV write (sglang_npu_amd/deferred.py). */
+int sgl_mi355_awq_gemm_packed_partials(const void* x, const uint32_t* wp, const uint32_t* sz, float* workspace,
+                                       int64_t workspace_floats, int64_t M, int64_t N, int64_t K, int64_t group_size,
+                                       int64_t x_stride_m, int dtype, int32_t* num_slices, void* stream);
 
 /* The same product for M > 64 (prefill): 128 x 128 x 64 tiles on the fp16 MFMA with the INT4 weights unpacked in
  * registers (csrc/awq_tiled.hip) -- the fused form of awq.py:413-417 / awq_gemm_triton (awq_triton.py:110-229).  No

@@ -12,7 +12,7 @@ import threading
 _PKG = os.path.dirname(os.path.abspath(__file__))
 # SGL_MI355_LIB: load another build of the same library (same-box A/B of kernel variants, tools/ab_variants.py)
 LIB_PATH = os.environ.get("SGL_MI355_LIB") or os.path.join(_PKG, "lib", "libsgl_mi355.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _lib = None
 _lock = threading.Lock()

@@ -573,8 +573,22 @@ __global__ __launch_bounds__(64) void awq_packed_finalize_kernel(AwqPArgs p, con
   }
 }
 
+// set by sgl_mi355_awq_gemm_packed_partials around its call: leave the K slices unsummed and report their count; decline
+// (nothing launched) where the dispatcher takes the unsplit form
+thread_local int32_t* tl_awq_slices = nullptr;
+
+template <bool SLAB>
+inline int awq_partials_precheck() {
+  if (tl_awq_slices != nullptr && !SLAB) {
+    set_error("awq_gemm_packed_partials: this shape runs unsplit (no partial sums to hand over)");
+    return SGL_MI355_ERR_UNSUPPORTED;
+  }
+  return 0;
+}
+
 template <int MB, int PH, bool SLAB>
 int launch_ph(const AwqPArgs& p, float* slabs, int SK, int pps, int nc, int groups, hipStream_t s) {
+  if (int pre = awq_partials_precheck<SLAB>()) return pre;
   auto kern = awq_wstream_kernel<MB, PH, SLAB>;
   constexpr int lds = 2 * PH * 16 * MB * 256;
   static int attr_rc = check_hip(
@@ -584,6 +598,7 @@ int launch_ph(const AwqPArgs& p, float* slabs, int SK, int pps, int nc, int grou
   hipLaunchKernelGGL(kern, dim3((unsigned)groups, (unsigned)SK), dim3(64 * (nc + 1)), lds, s, p, slabs, pps);
   int rc = check_hip(hipGetLastError(), "awq_wstream launch");
   if (rc || !SLAB) return rc;
+  if (tl_awq_slices != nullptr) { *tl_awq_slices = SK; return 0; }  // the consumer sums the slices (+ bias, one rounding)
   const int64_t total = (int64_t)p.M * p.N / 8;
   hipLaunchKernelGGL(awq_packed_finalize_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, s, p,
                      (const float*)slabs, SK);
@@ -592,6 +607,7 @@ int launch_ph(const AwqPArgs& p, float* slabs, int SK, int pps, int nc, int grou
 
 template <int MB, int PH, int PB, bool SLAB>
 int launch2_ph(const AwqPArgs& p, float* slabs, int SK, int pps, int nc, int groups, hipStream_t s) {
+  if (int pre = awq_partials_precheck<SLAB>()) return pre;
   auto kern = awq_wstream2_kernel<MB, PH, PB, SLAB>;
   constexpr int lds = 2 * PH * 16 * MB * 256;
   static int attr_rc = check_hip(
@@ -601,6 +617,7 @@ int launch2_ph(const AwqPArgs& p, float* slabs, int SK, int pps, int nc, int gro
   hipLaunchKernelGGL(kern, dim3((unsigned)groups, (unsigned)SK), dim3(64 * (nc + 1)), lds, s, p, slabs, pps);
   int rc = check_hip(hipGetLastError(), "awq_wstream2 launch");
   if (rc || !SLAB) return rc;
+  if (tl_awq_slices != nullptr) { *tl_awq_slices = SK; return 0; }
   const int64_t total = (int64_t)p.M * p.N / 8;
   hipLaunchKernelGGL(awq_packed_finalize_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, s, p,
                      (const float*)slabs, SK);
@@ -749,4 +766,22 @@ extern "C" int sgl_mi355_awq_gemm_packed(const void* x, const uint32_t* wp, cons
   if (M <= 16) return launch<1>(p, workspace, workspace_floats, s);
   if (M <= 32) return launch<2>(p, workspace, workspace_floats, s);
   return launch<4>(p, workspace, workspace_floats, s);
+}
+
+// sgl_mi355_awq_gemm_packed's split-K form WITHOUT its finalize launch: the fp32 partial sums [num_slices][M][N] stay in
+// `workspace` for a consumer that runs the epilogue itself (sum in slice order, + bias, one rounding: awq_packed_finalize_kernel's
+// arithmetic -- what the FP8 path's *_from_partials entry points do on unit scales).  SGL_MI355_ERR_UNSUPPORTED, nothing
+// launched, where the dispatcher would run the shape unsplit.
+extern "C" int sgl_mi355_awq_gemm_packed_partials(const void* x, const uint32_t* wp, const uint32_t* sz, float* workspace,
+                                                  int64_t workspace_floats, int64_t M, int64_t N, int64_t K, int64_t group_size,
+                                                  int64_t x_stride_m, int dtype, int32_t* num_slices, void* stream) {
+  SGLM_CHECK_ARG(workspace != nullptr && workspace_floats > 0 && num_slices != nullptr && M > 0,
+                 "awq_gemm_packed_partials: null workspace / num_slices, or no rows");
+  *num_slices = 0;
+  tl_awq_slices = num_slices;
+  // (`out` is not written in this form; the workspace stands in for the non-null / alignment checks)
+  const int rc = sgl_mi355_awq_gemm_packed(x, wp, sz, nullptr, workspace, workspace, workspace_floats, M, N, K, group_size, x_stride_m,
+                                           dtype, stream);
+  tl_awq_slices = nullptr;
+  return rc;
 }

@@ -952,11 +952,12 @@ def fused_add_rmsnorm_from_partials(part: GemmPartials, residual: torch.Tensor, 
     return (out, q, s) if with_fp8 else out
 
 
-def defer_epilogue(part: GemmPartials) -> DeferredEpilogue:
+def defer_epilogue(part: GemmPartials, pool=None) -> DeferredEpilogue:
     """`part` as a tensor for model code (deferred.py): finished by the RMSNorm that consumes it, by the first foreign operation
-    on it, or -- at the latest -- by the workspace pool before the next GEMM reuses the buffer the partial sums live in."""
+    on it, or -- at the latest -- by the workspace pool (`pool`: the one the partial sums live in) before the next GEMM reuses
+    the buffer."""
     d = DeferredEpilogue(part)
-    _fp8_workspace.set_pending(part.ws.device, d)
+    (pool or _fp8_workspace).set_pending(part.ws.device, d)
     return d
 
 
@@ -1349,6 +1350,32 @@ def awq_gemm_packed(x: torch.Tensor, wp: torch.Tensor, sz: torch.Tensor, group_s
         _ptr(x), _ptr(wp), _ptr(sz), _ptr(bias), _ptr(out), _ptr(ws), _I64(ws.numel()), _I64(M), _I64(N), _I64(K),
         _I64(group_size), _I64(x.stride(0) if M > 1 else K), _I(_dtype_code(x)), _stream(x)))
     return out
+
+
+def awq_gemm_packed_partials(x: torch.Tensor, wp: torch.Tensor, sz: torch.Tensor, group_size: int, bias=None) -> Optional[GemmPartials]:
+    """Split-K half of awq_gemm_packed: raw fp32 partial sums as an ops.GemmPartials with unit scales (finalize() and the
+    *_from_partials consumers of the FP8 path then repeat awq_packed_finalize_kernel's arithmetic: bit-identical to
+    awq_gemm_packed).  None (nothing launched) where the kernel runs the shape unsplit.  Hand it on with
+    defer_epilogue(part, pool=ops._awq_workspace)."""
+    _need_gpu(x, wp, sz, bias)
+    if x.dim() != 2 or x.stride(1) != 1 or x.dtype != torch.float16:
+        raise RuntimeError("awq_gemm_packed_partials: x must be a row-major fp16 [M,K] tensor")
+    M, K = x.shape
+    N = wp.size(0)
+    if wp.size(1) * 8 != _awq_kp(K) or sz.size(0) != N:
+        raise RuntimeError("awq_gemm_packed_partials: x and the packed weight shapes cannot be multiplied")
+    if not 0 < M <= 64:
+        return None
+    ones = _unit_scales(x.device, max(M, N))
+    ws = _awq_workspace.get(x.device, max(1, min(16, 256 // max(1, -(-N // 128)))) * M * N)
+    sk = ctypes.c_int32(0)
+    rc = _lib.lib().sgl_mi355_awq_gemm_packed_partials(
+        _ptr(x), _ptr(wp), _ptr(sz), _ptr(ws), _I64(ws.numel()), _I64(M), _I64(N), _I64(K), _I64(group_size),
+        _I64(x.stride(0) if M > 1 else K), _I(_dtype_code(x)), ctypes.byref(sk), _stream(x))
+    if rc == 2:
+        return None
+    _lib.check(rc)
+    return GemmPartials(ws, sk.value, ones[:M], ones[:N], bias, M, N, x.dtype)
 
 
 def awq_gemm_packed_tiled(x: torch.Tensor, wp: torch.Tensor, sz: torch.Tensor, group_size: int, bias=None) -> torch.Tensor:

@@ -488,7 +488,23 @@ class AWQLinearMethod(LinearMethodBase):
         if packed is not None and reshaped_x.dtype == torch.float16:
             rows = reshaped_x.shape[0]
             if rows <= 64:  # decode: weight-streaming kernel on the k-packed copy
+                # the hand-overs of deferred.py (same protocol as W8A8Fp8LinearMethod.apply): a row-parallel or qkv layer whose
+                # consumer has asked leaves its split-K partial sums unfinished
+                may_defer = (deferred.DEFERRED_EPILOGUES and getattr(layer, "_sgl_mi355_may_defer", False) and x.dim() == 2
+                             and reshaped_x.stride(-1) == 1)
+                if may_defer and layer._sgl_mi355_partials_ok is not None:
+                    may_defer = layer._sgl_mi355_partials_ok(rows, x.dtype)
+                if may_defer and not deferred.hint_decode and (layer._sgl_mi355_is_qkv or not torch.cuda.is_current_stream_capturing()):
+                    may_defer = False
+                if may_defer and getattr(layer, "_sgl_mi355_defer_epilogue", False):
+                    part = ops.awq_gemm_packed_partials(reshaped_x, packed[0], packed[1], packed[2], bias)
+                    if part is not None:
+                        return ops.defer_epilogue(part, pool=ops._awq_workspace)
                 out = ops.awq_gemm_packed(reshaped_x, packed[0], packed[1], packed[2], bias)
+                if may_defer:  # (tagged for the consumer that will ask: on the tensor AND on what its views call their base)
+                    res = out.reshape(out_shape)
+                    res._sgl_mi355_epilogue_producer = out._sgl_mi355_epilogue_producer = layer
+                    return res
             elif rows <= AWQ_TWO_PASS_MAX_ROWS:
                 # 65..128 rows: two passes of the 64-row streamer (rows are independent: the same bits as one call would give)
                 # -- the tiled kernel below puts a narrow layer on N / 128 CUs at this size (Llama-2-7B, bs = 128: 29.6 -> see

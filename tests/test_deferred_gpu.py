@@ -536,3 +536,35 @@ def test_unquantised_row_parallel_layer_hands_its_epilogue_to_the_norm(dtype, T,
     y, _ = lin(x)
     fm = lin.quant_method.weight_fm(lin)
     assert isinstance(y, DeferredEpilogue) and torch.equal(y + 0, ops.linear16(x, fm))
+
+
+@pytest.mark.parametrize("T,K,H", [(64, 11008, 4096), (8, 4096, 4096)])
+def test_awq_row_parallel_layer_hands_its_epilogue_to_the_norm(T, K, H):
+    """The AWQ decode streamer's split-K form (config 4): same protocol, the FP8 consumers on unit scales; bit-identical to
+    awq_gemm_packed (split-K + its own finalize) followed by fused_add_rmsnorm."""
+    from sglang_npu_amd.quantization import AWQConfig
+    dtype = torch.float16
+    g = torch.Generator(device=DEV).manual_seed(T + K)
+    lin = RowParallelLinear(K, H, params_dtype=dtype, quant_config=AWQConfig(4, 128, True)).to(DEV)
+    lin.qweight.data.copy_(torch.randint(-2 ** 31, 2 ** 31 - 1, lin.qweight.shape, generator=g, device=DEV, dtype=torch.int64).to(torch.int32))
+    lin.qzeros.data.copy_(torch.randint(-2 ** 31, 2 ** 31 - 1, lin.qzeros.shape, generator=g, device=DEV, dtype=torch.int64).to(torch.int32))
+    lin.scales.data.copy_((torch.rand(lin.scales.shape, generator=g, device=DEV) * 2e-3 + 1e-4).to(dtype))
+    lin.quant_method.process_weights_after_loading(lin)
+    norm = _norm(H, g, dtype)
+    x = torch.randn(T, K, generator=g, device=DEV).to(dtype)
+    r0 = torch.randn(T, H, generator=g, device=DEV).to(dtype)
+    kinds, outs = [], []
+    for it in range(3):
+        r = r0.clone()
+        y, _ = lin(x)
+        kinds.append(type(y))
+        h, r = norm(y, r)
+        outs.append((h.clone(), r.clone()))
+    if kinds[1] is torch.Tensor:
+        pytest.skip("the AWQ streamer runs this shape unsplit: nothing to hand over")
+    assert kinds == [torch.Tensor, DeferredEpilogue, DeferredEpilogue]
+    for h, r in outs[1:]:
+        assert torch.equal(h, outs[0][0]) and torch.equal(r, outs[0][1]), "the AWQ partials form must not move a bit"
+    y, _ = lin(x)
+    packed = lin.awq_packed
+    assert isinstance(y, DeferredEpilogue) and torch.equal(y + 0, ops.awq_gemm_packed(x, packed[0], packed[1], packed[2]))
