@@ -406,7 +406,8 @@ class MI355AttnBackend(AttentionBackend):
                            and q.shape[0] * layer.tp_k_head_num > NUM_CUS
                            and forward_batch.token_to_kv_pool.get_key_buffer(layer.layer_id).dtype == q.dtype)
         if self.measure_skip_decode_kernel:
-            # measurement aid (bench.py): the step WITHOUT the decode attention launch (KV write included), so that the
+            # measurement aid (bench.py): the step WITHOUT the decode attention launch (and without set_kv_buffer where that is
+            # still a launch of its own at this point; with the qkv hand-over above the KV write has already happened), so that the
             # kernel's in-step cost can be taken as the difference of two graph-replayed steps; the output is uninitialised
             # (in the form the skipped launch would have returned: the quantised pair when it quantises as well)
             if quant_in_launch:
