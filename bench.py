@@ -249,6 +249,12 @@ def time_attention_kernel(loop, steps):
     loop.graph = None
     try:
         for _ in range(steps):
+            # keep the GPU BEHIND the host for the whole eager step: the events bracket a launch on the device timeline, and where
+            # the device waits for the host (small kernels, Python between two launches) the start event would be stamped before
+            # the kernel has even been enqueued -- host time in a kernel's duration.  A spin of ~3 ms in front of the step lets
+            # the host queue the step ahead (a step is ~5 ms of host time, ~6 ms of device time).
+            if hasattr(torch.cuda, "_sleep"):
+                torch.cuda._sleep(6_000_000)
             loop.step()
         torch.cuda.synchronize()
     finally:
