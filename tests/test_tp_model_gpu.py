@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _run_stack(tp_rank, tp_world, device, fuse, async_ar, with_lm_head=False, reference_order=False, passes=1):
+def _run_stack(tp_rank, tp_world, device, fuse, async_ar, with_lm_head=False, reference_order=False, passes=1, quant="w8a8_fp8"):
     """One prefill-free decode step of a 2-layer stack (with_lm_head=False: the output is the final hidden state;
     True: the vocab-parallel LM head's logits after the all-gather over the ranks, logits_processor.py:430-505)."""
     from sglang_npu_amd import model as M
@@ -33,7 +33,7 @@ def _run_stack(tp_rank, tp_world, device, fuse, async_ar, with_lm_head=False, re
     M.FUSE_AR_NORM, M.ASYNC_AR = fuse, async_ar
     cfg = M.LLAMA3_8B
     B, ctx = 64, 96
-    net = M.LlamaForCausalLM(cfg, "w8a8_fp8", torch.bfloat16, str(device), num_layers=2,
+    net = M.LlamaForCausalLM(cfg, quant, torch.bfloat16, str(device), num_layers=2,
                              with_lm_head=with_lm_head).load_dummy_weights()
     max_len = ctx + 4
     n_tok = B * max_len + 1
@@ -102,6 +102,12 @@ def _worker(rank, world, port, q):
         # (down_proj, 28 Mi weights per rank, comes as split-K partials; o_proj, 8 Mi, as its finished local sum)
         assert D.DISPATCH_COUNTS["p2p+norm(partials)"] - partials_before == 4
         outs["reference_order"] = ref_order[0]
+        # the same through 16-bit weights (config 2 under TP): the streamer's split-K partials go to the fused all-reduce + norm on
+        # unit scales where the rule takes them (down_proj), the finished local sum elsewhere -- three passes, not one bit apart
+        dist.barrier()
+        ref16 = _run_stack(rank, world, dev, True, False, reference_order=True, passes=3, quant=None)
+        assert torch.isfinite(ref16[0]).all() and torch.equal(ref16[0], ref16[1]) and torch.equal(ref16[0], ref16[2]), \
+            "the lazy all-reduce changed the 16-bit model's reference-order result under TP"
         assert torch.equal(outs["sync"], outs["async"]), "side-stream all-reduce changed the result"
         assert torch.equal(outs["sync"], outs["fused"]), "fused all-reduce + norm kernel changed the result"
         gathered = [None] * world
