@@ -105,6 +105,10 @@ struct GemmArgs {
   const float* a_absmax = nullptr;
   float* a_scale_out = nullptr;
   int raster_gn = 1;  // tiled v3: column tiles per rasterisation group (see the kernel)
+  // tiled v3, RAWK form (prefill split-K over workgroups, round 5): blockIdx.y = K slice of `k_steps_per_slice` 128-byte
+  // k-steps; the raw fp32 accumulators go to slabs[slice][M][N] for a consumer that runs the epilogue (ops.GemmPartials)
+  float* slabs = nullptr;
+  int k_steps_per_slice = 0;
 };
 
 // Where a decode wave finds its weight fragments: scalar base of (column block, k-step 0), bytes between k-steps, and
@@ -1825,8 +1829,13 @@ __global__ __launch_bounds__(64 * WM * WN) void fp8_gemm_tiled2_kernel(GemmArgs 
 // For the shapes that give every CU exactly one 128-row tile (M = 1024 qkv: 256 tiles of 128 x 192), where the four-wave
 // workgroup leaves one wave per SIMD and every LDS / barrier / first-fragment latency is exposed; two co-resident waves per
 // SIMD are what the two-workgroups-per-CU form has from 512 tiles on.  Sums the k-steps in another order than KS = 1.
-template <int OUT_DTYPE, int NSTAGE, int RI, int WM, int WN, int CB = 4, bool SILU = false, int KS = 1>
+// RAWK (round 5): the K dimension is ALSO cut over workgroups (blockIdx.y = slice) and the accumulators leave as raw fp32 partial
+// sums -- the prefill counterpart of the decode streamers' split-K slabs, for narrow outputs with a long K (down_proj at 1024
+// rows: 128 tiles of 128 x 256 x two slices fill the chip with HALF the operand bytes per CU of the 256 tiles of 128 x 128).
+// The epilogue belongs to the consumer (RMSNorm from partials through deferred.py).
+template <int OUT_DTYPE, int NSTAGE, int RI, int WM, int WN, int CB = 4, bool SILU = false, int KS = 1, bool RAWK = false>
 __global__ __launch_bounds__(64 * WM * WN * KS, 2) void fp8_gemm_tiled3_kernel(GemmArgs p) {
+  static_assert(!RAWK || (KS == 1 && !SILU), "the raw split-K form is the plain one-group kernel");
   static_assert(NSTAGE >= 3, "the wait count below assumes A(kt) was issued before B(kt)");
   static_assert(CB == 3 || CB == 4, "column blocks per wave");
   static_assert(!SILU || CB == 4, "gate and up: two column blocks each");
@@ -1886,6 +1895,11 @@ __global__ __launch_bounds__(64 * WM * WN * KS, 2) void fp8_gemm_tiled3_kernel(G
     m = m < p.M ? m : p.M - 1;  // rows past the edge re-read a valid row; never stored
     a_src[u] = p.a + (int64_t)m * p.a_sm + 16 * j + (q / (TMB / 8)) * 128;
   }
+  const int kstep0 = RAWK ? (int)blockIdx.y * p.k_steps_per_slice : 0;  // first 128-byte k-step of this workgroup's K slice
+  if constexpr (RAWK) {
+#pragma unroll
+    for (int u = 0; u < UA; ++u) a_src[u] += (int64_t)kstep0 * 128;
+  }
   const uint32_t smem_base = lds_addr_of(smem);
   // (kt below counts loop iterations: KS k-steps each)
   auto dma_stage = [&](int stage, int kt) __attribute__((always_inline)) {
@@ -1906,9 +1920,9 @@ __global__ __launch_bounds__(64 * WM * WN * KS, 2) void fp8_gemm_tiled3_kernel(G
       nb = (n0 >> 4) + wn * CB + j;
       nb = nb < (p.N >> 4) ? nb : (p.N >> 4) - 1;
     }
-    b_blk[j] = p.b + (int64_t)nb * 16 * p.K;
+    b_blk[j] = p.b + (int64_t)nb * 16 * p.K + (int64_t)kstep0 * 2048;
   }
-  const int nk = (p.K >> 7) / KS;  // loop iterations
+  const int nk = RAWK ? p.k_steps_per_slice : (p.K >> 7) / KS;  // loop iterations
   auto load_b = [&](Frag32 (&q)[CB], int kt) __attribute__((always_inline)) {
     const uint32_t voff = (uint32_t)lane * 16 + (uint32_t)(KS * kt + kg) * 2048;
 #pragma unroll
@@ -2082,7 +2096,21 @@ __global__ __launch_bounds__(64 * WM * WN * KS, 2) void fp8_gemm_tiled3_kernel(G
     __syncthreads();  // every wave is done with the hand-over area: the epilogue patches below overlap it
     if (kg == 1) return;
   }
-  if constexpr (SILU) tiled_epilogue_silu<OUT_DTYPE, RI>(SGLM_T3_P, smem, acc, m0, n0, wm, wn, wave_t, lane);
+  if constexpr (RAWK) {
+    // raw partial sums: element (row 16 i + 4 g + r, column 16 j + r16) of the wave's tile; 16 lanes write 64 contiguous bytes
+    float* slab = p.slabs + (int64_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < RI; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * 16 * RI + 16 * i + 4 * g + r;
+#pragma unroll
+        for (int j = 0; j < CB; ++j) {
+          const int n = n0 + wn * 16 * CB + 16 * j + r16;
+          if (m < p.M && n < p.N) slab[(int64_t)m * p.N + n] = acc[i][j][r];
+        }
+      }
+  } else if constexpr (SILU) tiled_epilogue_silu<OUT_DTYPE, RI>(SGLM_T3_P, smem, acc, m0, n0, wm, wn, wave_t, lane);
   else tiled_epilogue<OUT_DTYPE, RI, CB>(SGLM_T3_P, smem, acc, m0, n0, wm, wn, wave_t, lane);
 #undef SGLM_T3_P
 #if SGLM_T3_TIMING
@@ -2525,8 +2553,37 @@ static int fp8_scaled_mm_partials_impl(int b_shuf, const void* mat_a, const void
                  "fp8_scaled_mm_partials: operands must be 16-byte aligned");
   *num_slices = 0;
   if (M > 128) {
-    set_error("fp8_scaled_mm_partials: only the decode kernels (M <= 128) have a split-K form");
-    return SGL_MI355_ERR_UNSUPPORTED;
+    // prefill sizes (round 5): the tiled kernel's raw split-K form where 128 x 256 tiles alone would leave the chip half empty
+    // and K is long enough to cut -- down_proj 14336 -> 4096 at 512 / 1024 rows (tools/exp/splitk_prefill_probe.py: the GEMM body
+    // 85 -> 57 us at 1024 rows).  Everything else has no such form: the caller runs the GEMM that finishes itself.
+    const int64_t tiles = ((M + 127) / 128) * ((N + 255) / 256);
+    const int64_t steps = K >> 7;
+    int S = tiles > 0 ? (int)(256 / tiles) : 0;
+    if (S > 4) S = 4;
+    while (S >= 2 && (steps % S != 0 || (steps / S) % 4 != 0 || steps / S < 24)) --S;
+    static const bool off = getenv("SGL_MI355_NO_PREFILL_SPLITK") != nullptr;  // A/B aid
+    if (off || !b_shuf || !shuffle_shape_ok(N, K) || K < 8192 || S < 2 || (N & 7) != 0 ||
+        workspace_floats < (int64_t)S * M * N) {
+      set_error("fp8_scaled_mm_partials: no split-K form for M=%ld N=%ld K=%ld (prefill sizes: pre-shuffled weight, K >= 8192, "
+                "at most 128 tiles of 128 x 256)", (long)M, (long)N, (long)K);
+      return SGL_MI355_ERR_UNSUPPORTED;
+    }
+    GemmArgs p3{(const uint8_t*)mat_a, a_stride_m, (const uint8_t*)mat_b, K, nullptr, nullptr, nullptr, nullptr, (int)M, (int)N, (int)K};
+    p3.b_shuf = 1;
+    p3.raster_gn = 4;
+    p3.slabs = workspace;
+    p3.k_steps_per_slice = (int)(steps / S);
+    auto k3 = fp8_gemm_tiled3_kernel<SGL_MI355_BF16, 3, 8, 1, 4, 4, false, 1, true>;
+    constexpr int lds3 = 3 * 128 * 128;
+    static int a3 = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(k3), hipFuncAttributeMaxDynamicSharedMemorySize, lds3),
+                              "hipFuncSetAttribute");
+    if (a3) return a3;
+    g_last_kernel = "tiled3_rawk";
+    hipLaunchKernelGGL(k3, dim3((unsigned)tiles, (unsigned)S), dim3(256), lds3, as_stream(stream), p3);
+    int rc3 = check_hip(hipGetLastError(), "fp8_gemm_tiled3 (raw split-K) launch");
+    if (rc3) return rc3;
+    *num_slices = S;
+    return 0;
   }
   SGLM_CHECK_ARG(!b_shuf || shuffle_shape_ok(N, K), "fp8_scaled_mm_partials_wshuffled: N %% 16 == 0 and K %% 512 == 0 required");
   GemmArgs p{(const uint8_t*)mat_a, a_stride_m, (const uint8_t*)mat_b, b_stride_n, nullptr, nullptr, nullptr, nullptr,

@@ -869,13 +869,21 @@ def fp8_scaled_mm_partials(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=Non
     """Split-K half of fp8_scaled_mm (same arguments); None when the shape has no split-K decode path."""
     _need_gpu(mat_a, mat_b, scales_a, scales_b, bias)
     M = mat_a.size(0)
-    if not (0 < M <= 128) or mat_a.dim() != 2 or mat_a.stride(1) != 1:
+    if M <= 0 or mat_a.dim() != 2 or mat_a.stride(1) != 1:
         return None
     shuf = mat_b.dtype == torch.uint8
-    if not shuf and (mat_b.dim() != 2 or mat_b.stride(0) != 1 or mat_b.size(0) != mat_a.size(1)):
+    if not shuf and (M > 128 or mat_b.dim() != 2 or mat_b.stride(0) != 1 or mat_b.size(0) != mat_a.size(1)):
         return None
     shuf, K, N, b_stride_n = _fp8_b_operand(mat_a, mat_b)
-    ws = _fp8_workspace.get(mat_a.device, max(32 * min(M, 64) * N, _fp8_slab_floats(M, N, K)))
+    if M > 128:
+        # prefill sizes: the tiled kernel's raw split-K form (narrow output, long K: down_proj) -- at most four slices of M x N
+        # floats; decided here so that shapes without the form do not grow the workspace
+        tiles = -(-M // 128) * -(-N // 256)
+        if K < 8192 or tiles > 128:
+            return None
+        ws = _fp8_workspace.get(mat_a.device, 4 * M * N)
+    else:
+        ws = _fp8_workspace.get(mat_a.device, max(32 * min(M, 64) * N, _fp8_slab_floats(M, N, K)))
     sk = ctypes.c_int32(0)
     if shuf:
         rc = _lib.lib().sgl_mi355_fp8_scaled_mm_partials_wshuffled(

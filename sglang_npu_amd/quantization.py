@@ -291,11 +291,15 @@ class W8A8Fp8LinearMethod(LinearMethodBase):
         # into this backend's RMSNorm: at decode sizes the GEMM is a split-K weight streamer, and once that norm has asked
         # (layers.RMSNorm.forward -> _sgl_mi355_defer_epilogue) the epilogue is left to it -- the output travels through the
         # model code as a DeferredEpilogue tensor (deferred.py; bit-identical, one launch less per GEMM).
+        rows = x.shape[0] if x.dim() == 2 else 0
+        # (33..128 rows: the decode streamers' split-K form; from 256 rows: the tiled kernel's raw split-K form for a narrow
+        #  output with a long K -- down_proj -- where ops.fp8_scaled_mm_partials has it; never the qkv projection there)
         may_defer = (deferred.DEFERRED_EPILOGUES and getattr(layer, "_sgl_mi355_may_defer", False) and layer.input_scale is None
-                     and x.dim() == 2 and x.is_cuda and DEFER_MIN_ROWS < x.shape[0] <= 128)
+                     and x.is_cuda and (DEFER_MIN_ROWS < rows <= 128 or (rows >= 256 and not layer._sgl_mi355_is_qkv)))
         if may_defer and layer._sgl_mi355_partials_ok is not None:
             may_defer = layer._sgl_mi355_partials_ok(x.shape[0], x.dtype)
-        if may_defer and not deferred.hint_decode and (layer._sgl_mi355_is_qkv or not torch.cuda.is_current_stream_capturing()):
+        if may_defer and rows <= 128 and not deferred.hint_decode and (layer._sgl_mi355_is_qkv
+                                                                       or not torch.cuda.is_current_stream_capturing()):
             # an extend pass: nobody there takes a qkv projection's partials, and an eager prefill of <= 128 rows is host-bound
             # -- the lazy objects would cost more Python time than the finalize launch they save (deferred.hint_decode)
             may_defer = False

@@ -568,3 +568,45 @@ def test_awq_row_parallel_layer_hands_its_epilogue_to_the_norm(T, K, H):
     y, _ = lin(x)
     packed = lin.awq_packed
     assert isinstance(y, DeferredEpilogue) and torch.equal(y + 0, ops.awq_gemm_packed(x, packed[0], packed[1], packed[2]))
+
+
+@pytest.mark.parametrize("T", [1024, 512, 1000, 300])
+def test_prefill_down_proj_leaves_raw_split_k_partials_to_the_norm(T):
+    """Prefill sizes, narrow output, long K (down_proj 14336 -> 4096): the tiled kernel's raw split-K form (K cut over
+    workgroups, fp32 partial sums) + the norm kernel as its epilogue.  Against an fp32 reference product within the GEMM
+    tolerance, bit-identical to its own explicit finalize + fused_add_rmsnorm, ragged row counts included."""
+    dtype, K, H = torch.bfloat16, 14336, 4096
+    g = torch.Generator(device=DEV).manual_seed(T)
+    lin, norm = _row_linear(K, H, g, dtype), _norm(H, g, dtype)
+    x = torch.randn(T, K, generator=g, device=DEV).to(dtype)
+    r0 = torch.randn(T, H, generator=g, device=DEV).to(dtype)
+    q = torch.empty_like(x, dtype=torch.float8_e4m3fn)
+    s = torch.empty(T, 1, device=DEV)
+    ops.sgl_per_token_quant_fp8(x, q, s)
+    part = ops.fp8_scaled_mm_partials(q, lin.weight, s, lin.weight_scale, dtype, None)
+    assert part is not None and 2 <= part.num_slices <= 4
+    full = ops.fp8_scaled_mm(q, lin.weight, s, lin.weight_scale, out_dtype=dtype)
+    fin = part.finalize()
+    # same products, another summation order: within a few ulp of the 16-bit output of each other
+    assert (fin.float() - full.float()).abs().max() <= 2.0 ** -6 * max(1.0, float(full.float().abs().max()))
+    kinds, outs = [], []
+    for it in range(3):
+        r = r0.clone()
+        y, _ = lin(x)
+        kinds.append(type(y))
+        h, r = norm(y, r)
+        outs.append((h.clone(), r.clone()))
+    assert kinds == [torch.Tensor, DeferredEpilogue, DeferredEpilogue]
+    y_ref = fin.clone()
+    r_ref = r0.clone()
+    ops.fused_add_rmsnorm(y_ref, r_ref, norm.weight.data, norm.variance_epsilon)
+    for h, r in outs[1:]:
+        assert torch.equal(h, y_ref) and torch.equal(r, r_ref)
+    assert (outs[0][0].float() - y_ref.float()).abs().max() < 0.06  # pass 0: the unsplit kernel's summation order
+    # shapes without the form stay plain: a short K, a wide output
+    o_proj = _row_linear(4096, 4096, g, dtype)
+    xo = torch.randn(T, 4096, generator=g, device=DEV).to(dtype)
+    for _ in range(2):
+        yo, _ = o_proj(xo)
+        assert type(yo) is torch.Tensor
+        norm(yo, r0.clone())
