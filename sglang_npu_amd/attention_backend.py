@@ -354,6 +354,8 @@ class MI355AttnBackend(AttentionBackend):
         """q / k / v are the column ranges of a FINISHED qkv projection behind a lazy handle with RoPE recorded (deferred.py): rotate
         q / k in place and write the KV rows in one launch; the handle then holds what the reference's in-place rotary_emb leaves."""
         qkv = root.pending_local()
+        if qkv is None:  # still split-K partials (a prefill-sized raw split-K form): finish the GEMM, then rotate + write as below
+            qkv = root.pending_partials().finalize()
         positions, rot = root._rope[0], root._rope[1]
         pool = forward_batch.token_to_kv_pool
         q, k, v = qkv[:, :q_size], qkv[:, q_size:q_size + kv_size], qkv[:, q_size + kv_size:]
@@ -556,7 +558,7 @@ class MI355AttnBackend(AttentionBackend):
                 # the column ranges of a finished qkv projection behind a lazy handle, RoPE recorded (deferred.py): RoPE + KV-pool
                 # write as one launch; the extend kernel then reads the rotated K / V as tensors
                 root = deferred.qkv_root(q, k, v, q_size, kv_size)
-                if root is not None and root.pending_local() is not None and not root.needs_allreduce:
+                if root is not None and not root.needs_allreduce:
                     q, k, v = self._rope_and_write(root, layer, forward_batch, q_size, kv_size)
                     save_kv_cache = False
             else:

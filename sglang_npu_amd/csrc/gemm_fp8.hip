@@ -2560,7 +2560,7 @@ static int fp8_scaled_mm_partials_impl(int b_shuf, const void* mat_a, const void
     const int64_t steps = K >> 7;
     int S = tiles > 0 ? (int)(256 / tiles) : 0;
     if (S > 4) S = 4;
-    while (S >= 2 && (steps % S != 0 || (steps / S) % 4 != 0 || steps / S < 24)) --S;
+    while (S >= 2 && (steps % S != 0 || (steps / S) % 4 != 0 || steps / S < 16)) --S;
     static const bool off = getenv("SGL_MI355_NO_PREFILL_SPLITK") != nullptr;  // A/B aid
     if (off || !b_shuf || !shuffle_shape_ok(N, K) || K < 8192 || S < 2 || (N & 7) != 0 ||
         workspace_floats < (int64_t)S * M * N) {

@@ -293,9 +293,9 @@ class W8A8Fp8LinearMethod(LinearMethodBase):
         # model code as a DeferredEpilogue tensor (deferred.py; bit-identical, one launch less per GEMM).
         rows = x.shape[0] if x.dim() == 2 else 0
         # (33..128 rows: the decode streamers' split-K form; from 256 rows: the tiled kernel's raw split-K form for a narrow
-        #  output with a long K -- down_proj -- where ops.fp8_scaled_mm_partials has it; never the qkv projection there)
+        #  output with a long K -- down_proj, a TP-sharded qkv behind a hidden size of 8192 -- where ops.fp8_scaled_mm_partials has it)
         may_defer = (deferred.DEFERRED_EPILOGUES and getattr(layer, "_sgl_mi355_may_defer", False) and layer.input_scale is None
-                     and x.is_cuda and (DEFER_MIN_ROWS < rows <= 128 or (rows >= 256 and not layer._sgl_mi355_is_qkv)))
+                     and x.is_cuda and (DEFER_MIN_ROWS < rows <= 128 or rows >= 256))
         if may_defer and layer._sgl_mi355_partials_ok is not None:
             may_defer = layer._sgl_mi355_partials_ok(x.shape[0], x.dtype)
         if may_defer and rows <= 128 and not deferred.hint_decode and (layer._sgl_mi355_is_qkv
